@@ -1,0 +1,88 @@
+"""Loader of the C-ABI HIP library (csrc/libgsr_hip.so, declared in include/gsr_hip.h).
+
+The product path has NO CPU fallback: if the library is missing, fails to load, or no HIP device
+is visible, every entry point raises ``RuntimeError``.  Build it with ``__graft_entry__.build()``
+(hipcc cross-compiles for gfx950 without a GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgsr_hip.so")
+
+GSR_OK = 0
+GSR_E_INVALID = -1
+GSR_E_HIP = -2
+GSR_E_NO_DEVICE = -3
+GSR_E_PRECONDITION = -4
+
+GSR_RNG_GLIBC = 0
+GSR_RNG_HASH = 1
+
+GSR_ICP_ACC_LEN = 32
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
+
+# name -> (restype, argtypes); mirrors include/gsr_hip.h one to one (tests/test_abi.py checks it)
+_vp, _i32, _i64, _u32, _u64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
+SIGNATURES = {
+    "gsr_last_error": (C.c_char_p, []),
+    "gsr_version": (C.c_char_p, []),
+    "gsr_device_count": (_i32, []),
+    "gsr_hem_create": (_i32, [C.POINTER(_vp), _i32, _vp]),
+    "gsr_hem_destroy": (_i32, [_vp]),
+    "gsr_hem_set_params": (_i32, [_vp, _f32, _f32, _f32, _f32]),
+    "gsr_hem_set_rng": (_i32, [_vp, _i32, _u32, _u64]),
+    "gsr_hem_get_rng_position": (_i32, [_vp, C.POINTER(_u64)]),
+    "gsr_hem_set_level0": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
+    "gsr_hem_set_state": (_i32, [_vp, _vp, _vp]),
+    "gsr_hem_run_level": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "gsr_hem_level_size": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32)]),
+    "gsr_hem_get_level": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
+    "gsr_hem_get_stats": (_i32, [_vp, C.POINTER(_i64)]),
+    "gsr_hem_get_phase_ms": (_i32, [_vp, C.POINTER(_f32)]),
+    "gsr_icp_create": (_i32, [C.POINTER(_vp), _i32, _vp]),
+    "gsr_icp_destroy": (_i32, [_vp]),
+    "gsr_icp_set_target": (_i32, [_vp, _vp, _vp, _i64, _f64, _i32]),
+    "gsr_icp_set_source": (_i32, [_vp, _vp, _i64, _i32]),
+    "gsr_icp_set_allreduce": (_i32, [_vp, ALLREDUCE_FN, _vp, _i64]),
+    "gsr_icp_accumulate": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp]),
+    "gsr_icp_register": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _i32, _vp, C.POINTER(_f64), C.POINTER(_f64),
+                                C.POINTER(_i32)]),
+    "gsr_icp_correspondences": (_i32, [_vp, _vp, _vp, _vp]),
+    "gsr_icp_get_timing": (_i32, [_vp, C.POINTER(_f32)]),
+    "gsr_normals_from_cov": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
+}
+
+_lib = None
+
+
+def load(require_device: bool = False):
+    """Return the ctypes handle of libgsr_hip.so; raise RuntimeError if it cannot serve the hot path."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"HIP extension missing: {LIB_PATH} not built.  Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(needs hipcc).  This backend has no CPU fallback.")
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # pragma: no cover - depends on the machine
+            raise RuntimeError(f"HIP extension failed to load ({LIB_PATH}): {e}.  This backend has no CPU fallback.") from e
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)          # AttributeError here = header/library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    if require_device and _lib.gsr_device_count() <= 0:
+        raise RuntimeError("no HIP device visible: the MI355X backend has no CPU fallback")
+    return _lib
+
+
+def check(code: int, what: str = ""):
+    if code != GSR_OK:
+        msg = load().gsr_last_error()
+        msg = msg.decode("utf-8", "replace") if msg else ""
+        raise RuntimeError(f"{what or 'gsr'} failed ({code}): {msg}")

@@ -1,0 +1,1050 @@
+// hem.hip -- Hierarchical-EM Gaussian-mixture level on MI355X (gfx950), behind include/gsr_hip.h.
+//
+// One call of gsr_hem_run_level is one Mixture::createClusterLevel of the reference
+// (src/cpp_ext/src/mixture.cpp:66-285).  The reference walks an AoS vector with a hash grid whose
+// cell is the LARGEST parent radius; here the level is laid out for the GPU instead:
+//
+//   level arrays (HBM, row-major, as the C ABI hands them over)
+//       xyz[n][3] color[n][3] cov6[n][6] opacity[n] weight[n] sh[n][F] is_parent[n]
+//   per-level working set, all in CELL-SORTED order (j = sorted position, order[j] = input index)
+//       A[j] = {x, y, z, det}            B[j] = {c00, c01, c02, c11}
+//       C[j] = {c12, c22, col_r, col_g}  D[j] = {col_b, opacity, weight, flags}     (float4 each:
+//       one 16-byte load per lane, 1 KiB per wave instruction, candidates of a cell row contiguous)
+//       Rs[j] query radius, shs[j][F] SH rest, cellStart[cells+1] prefix table of a dense uniform grid
+//   pair list (parent-major CSR): pair_child[M] (sorted position), pair_wl[M] (w_s * clamp(L_si))
+//
+// Kernels (HBM-bound streaming unless noted):
+//   k_prep            det, query radius (closed-form eigenvalue, f64 trig), bounding box
+//   k_keys / sort     cell key per component, radix sort (rocPRIM) -> order[]
+//   k_gather / k_gather_sh   build the sorted working set
+//   k_select<COUNT|FILL>   one wavefront per parent: row spans of the grid that meet the query
+//                     sphere, exact radius test, colour gate, KL gate (bit-exact float32 maths, see
+//                     gsr_math.h), parent rule; FILL also evaluates the likelihood.  VALU-bound.
+//   sort pairs by child (rocPRIM, stable) + k_sumlw: per-child sum of wL in parent order --
+//                     deterministic, no float atomics
+//   k_mstep           one wavefront per parent: responsibilities, wave-shuffle reductions of the
+//                     1+3+3+6+1 moment sums, lane-per-coefficient accumulation of the SH rows
+//   k_orphans*, k_valid, k_compact   orphans, validity erase, output in the reference's order
+//                     (parents by ascending input index, then orphans by ascending input index)
+//
+// Any conservative neighbour search is legal: the reference's candidate set is exactly
+// { i : |mu_i - mu_s|^2 < R_s^2 } (its 27-cell scan with cell >= R_s loses nothing), and that test
+// is re-evaluated here with the same float expression.
+#include "gsr_common.h"
+#include "gsr_math.h"
+
+#include <float.h>
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <vector>
+
+#include <rocprim/rocprim.hpp>
+
+namespace gsr {
+
+std::string& last_error() {
+    static thread_local std::string s;
+    return s;
+}
+int32_t fail(int32_t code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return code;
+}
+
+void GlibcRng::seed(uint32_t s) {
+    if (s == 0) s = 1;
+    int32_t word = (int32_t)s;
+    st[0] = (uint32_t)word;
+    for (int i = 1; i < 31; ++i) {
+        int32_t hi = word / 127773, lo = word % 127773;
+        word = 16807 * lo - 2836 * hi;
+        if (word < 0) word += 2147483647;
+        st[i] = (uint32_t)word;
+    }
+    f = 3; r = 0;
+    for (int i = 0; i < 310; ++i) next();
+}
+
+// ------------------------------------------------------------------------------------------------
+// device-side structures
+// ------------------------------------------------------------------------------------------------
+struct GridParams {
+    float ox, oy, oz;      // origin (bbox min of the finite points)
+    float c, inv_c;        // cell edge and its reciprocal
+    float slack;           // absolute slack used when culling rows (covers float rounding of cell_of)
+    int gx, gy, gz;        // grid dimensions
+    int ncells;
+};
+
+__device__ __forceinline__ unsigned enc_f(float f) {      // order-preserving float -> uint
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __host__ inline float dec_f(unsigned u) {
+    unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    float f;
+    memcpy(&f, &v, 4);
+    return f;
+}
+
+// Monotone non-decreasing map coordinate -> cell index in [0, g-1]; NaN -> 0.
+__device__ __forceinline__ int cell_of(float v, float o, float inv_c, int g) {
+    float t = (v - o) * inv_c;
+    t = fminf(fmaxf(t, 0.0f), (float)(g - 1));
+    return (int)t;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_prep: det, parent query radius, bounding box of the finite centres
+//   radius = delta * sqrtf(lambda_max)                       (mixture.cpp:88)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict__ xyz,
+                                              const float* __restrict__ cov6,
+                                              const uint8_t* __restrict__ is_parent, float delta,
+                                              float* __restrict__ det, float* __restrict__ radius,
+                                              unsigned* __restrict__ bbox) {
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        s6 c = {cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5]};
+        det[i] = det6(c);
+        float R = 0.0f;
+        if (is_parent[i]) R = delta * sqrtf(eig_max6(c));
+        radius[i] = R;
+        float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX) {   // finite only
+            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+            mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+            mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        }
+    }
+    for (int k = 0; k < 3; ++k) { mn[k] = wave_min(mn[k]); mx[k] = wave_max(mx[k]); }
+    if ((threadIdx.x & 63) == 0) {
+        for (int k = 0; k < 3; ++k) {
+            atomicMin(&bbox[k], enc_f(mn[k]));
+            atomicMax(&bbox[3 + k], enc_f(mx[k]));
+        }
+    }
+}
+
+// Grid geometry from the bounding box: about `target` components per cell, at most `max_cells` cells.
+__global__ void k_grid_params(const unsigned* __restrict__ bbox, int64_t n, float target, int max_cells,
+                              GridParams* __restrict__ gp) {
+    float mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) { mn[k] = dec_f(bbox[k]); mx[k] = dec_f(bbox[3 + k]); }
+    GridParams g;
+    if (!(mx[0] >= mn[0]) || !(mx[1] >= mn[1]) || !(mx[2] >= mn[2])) {   // no finite point at all
+        g.ox = g.oy = g.oz = 0.0f; g.c = 1.0f; g.inv_c = 1.0f; g.slack = 0.0f; g.gx = g.gy = g.gz = 1; g.ncells = 1;
+        *gp = g;
+        return;
+    }
+    float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+    float emax = fmaxf(ex, fmaxf(ey, ez));
+    float eps = emax * 1e-6f + 1e-30f;
+    double vol = (double)(ex + eps) * (double)(ey + eps) * (double)(ez + eps);
+    double c = cbrt(vol * (double)target / (double)(n > 0 ? n : 1));
+    if (!(c > 0.0)) c = 1.0;
+    int gx, gy, gz;
+    for (;;) {
+        double fx = floor(ex / c) + 1.0, fy = floor(ey / c) + 1.0, fz = floor(ez / c) + 1.0;
+        if (fx * fy * fz <= (double)max_cells && fx < 2e6 && fy < 2e6 && fz < 2e6) { gx = (int)fx; gy = (int)fy; gz = (int)fz; break; }
+        c *= 1.2599210498948732;
+    }
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+    g.c = (float)c; g.inv_c = 1.0f / g.c;
+    g.slack = 1e-5f * (emax + g.c);
+    g.gx = gx; g.gy = gy; g.gz = gz; g.ncells = gx * gy * gz;
+    *gp = g;
+}
+
+__global__ __launch_bounds__(256) void k_keys(int64_t n, const float* __restrict__ xyz,
+                                              const GridParams* __restrict__ gpp,
+                                              unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
+    const GridParams g = *gpp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int cx = cell_of(xyz[3 * i], g.ox, g.inv_c, g.gx);
+        int cy = cell_of(xyz[3 * i + 1], g.oy, g.inv_c, g.gy);
+        int cz = cell_of(xyz[3 * i + 2], g.oz, g.inv_c, g.gz);
+        keys[i] = (unsigned)((cz * g.gy + cy) * g.gx + cx);
+        idx[i] = (unsigned)i;
+    }
+}
+
+// start[k] = number of sorted keys < k, for k in [0, nkeys]; sorted ascending.  Each run head fills
+// the (possibly empty) range of key values that precede it.
+template <typename OffT>
+__global__ __launch_bounds__(256) void k_run_starts(int64_t m, const unsigned* __restrict__ skeys, int64_t nkeys,
+                                                    OffT* __restrict__ start) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+        unsigned k = skeys[j];
+        int64_t prev = j == 0 ? -1 : (int64_t)skeys[j - 1];
+        if ((int64_t)k != prev)
+            for (int64_t c = prev + 1; c <= (int64_t)k; ++c) start[c] = (OffT)j;
+        if (j == m - 1)
+            for (int64_t c = (int64_t)k + 1; c <= nkeys; ++c) start[c] = (OffT)m;
+    }
+}
+template <typename OffT>
+__global__ void k_fill_const(int64_t n, OffT* p, OffT v) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) p[j] = v;
+}
+
+// Sorted working set.
+__global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __restrict__ order,
+                                                const float* __restrict__ xyz, const float* __restrict__ color,
+                                                const float* __restrict__ cov6, const float* __restrict__ opacity,
+                                                const float* __restrict__ weight, const uint8_t* __restrict__ is_parent,
+                                                const float* __restrict__ det, const float* __restrict__ radius,
+                                                float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
+                                                float4* __restrict__ D, float* __restrict__ Rs, int* __restrict__ pflag) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = order[j];
+        const unsigned fl = is_parent[i] ? 1u : 0u;
+        A[j] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], det[i]);
+        B[j] = make_float4(cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3]);
+        C[j] = make_float4(cov6[6 * i + 4], cov6[6 * i + 5], color[3 * i], color[3 * i + 1]);
+        D[j] = make_float4(color[3 * i + 2], opacity[i], weight[i], __uint_as_float(fl));
+        Rs[j] = radius[i];
+        pflag[j] = (int)fl;
+    }
+}
+__global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, const unsigned* __restrict__ order,
+                                                   const float* __restrict__ sh, float* __restrict__ shs) {
+    const int64_t total = n * F;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t j = t / F;
+        int f = (int)(t - j * F);
+        shs[t] = sh[(int64_t)order[j] * F + f];
+    }
+}
+__global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __restrict__ flag, const int* __restrict__ pos,
+                                                      unsigned* __restrict__ list) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        if (flag[j]) list[pos[j]] = (unsigned)j;
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_select: child selection (mixture.cpp:102-137) and, in FILL mode, wL_si (mixture.cpp:140-164)
+// ------------------------------------------------------------------------------------------------
+struct SelectArgs {
+    const float4 *A, *B, *C, *D;
+    const float* Rs;
+    const unsigned* plist;
+    const int* cellStart;
+    const GridParams* gp;
+    int P;
+    float colorThr, kldThr, tau2;
+    // COUNT
+    unsigned* pcnt;
+    unsigned long long* cand_total;
+    // FILL
+    const int64_t* poff;
+    unsigned* pair_child;
+    float* pair_wl;
+};
+
+template <bool FILL>
+__global__ __launch_bounds__(256) void k_select(SelectArgs a) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= a.P) return;
+    const GridParams g = *a.gp;
+    const int js = (int)a.plist[p];
+    const float4 pa = a.A[js], pb = a.B[js], pc = a.C[js], pd = a.D[js];
+    const f3 pm = {pa.x, pa.y, pa.z};
+    const float det_p = pa.w;
+    const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
+    const f3 pcol = {pc.z, pc.w, pd.x};
+    const float pweight = pd.z;
+    const s6 pinv = inverse6(pcov, det_p);
+    const float R = a.Rs[js];
+    const float R2 = R * R;
+
+    unsigned count = 0;
+    unsigned long long scanned = 0;
+    int64_t base = FILL ? a.poff[p] : 0;
+
+    // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
+    const bool pm_finite = fabsf(pm.x) <= FLT_MAX && fabsf(pm.y) <= FLT_MAX && fabsf(pm.z) <= FLT_MAX;
+    if (R2 > 0.0f && pm_finite) {
+        const float Ra = fabsf(R) * 1.00001f + g.slack;             // conservative search extent
+        const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
+        const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
+        const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
+        const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+        const int nrows = ny * nz;
+        const float Ra2 = Ra * Ra;
+        for (int rb = 0; rb < nrows; rb += 64) {
+            const int r = rb + lane;
+            int s = 0, e = 0;
+            if (r < nrows) {
+                const int ry = y0 + r % ny, rz = z0 + r / ny;
+                // distance from the parent to the row's y/z slab (widened by the rounding slack)
+                const float ylo = g.oy + ry * g.c - g.slack, yhi = g.oy + (ry + 1) * g.c + g.slack;
+                const float zlo = g.oz + rz * g.c - g.slack, zhi = g.oz + (rz + 1) * g.c + g.slack;
+                const float dy = fmaxf(0.0f, fmaxf(ylo - pm.y, pm.y - yhi));
+                const float dz = fmaxf(0.0f, fmaxf(zlo - pm.z, pm.z - zhi));
+                const float rem = Ra2 - dy * dy - dz * dz;
+                if (rem >= 0.0f) {
+                    const float hx = sqrtf(rem) * 1.00001f + g.slack;
+                    int xa = cell_of(pm.x - hx, g.ox, g.inv_c, g.gx), xb = cell_of(pm.x + hx, g.ox, g.inv_c, g.gx);
+                    xa = xa < x0 ? x0 : xa;
+                    xb = xb > x1 ? x1 : xb;
+                    const int rowbase = (rz * g.gy + ry) * g.gx;
+                    s = a.cellStart[rowbase + xa];
+                    e = a.cellStart[rowbase + xb + 1];
+                }
+            }
+            unsigned long long nonempty = __ballot(e > s);
+            while (nonempty) {
+                const int rl = __ffsll((long long)nonempty) - 1;
+                nonempty &= nonempty - 1;
+                const int ss = __shfl(s, rl), ee = __shfl(e, rl);
+                scanned += (unsigned long long)(ee - ss);
+                for (int j0 = ss; j0 < ee; j0 += 64) {
+                    const int j = j0 + lane;
+                    bool acc = false;
+                    float wl = 0.0f;
+                    if (j < ee) {
+                        const float4 ca = a.A[j];
+                        const f3 cm = {ca.x, ca.y, ca.z};
+                        const f3 dq = sub3(pm, cm);                       // query - point (pointindex.cpp:137)
+                        const float d2 = dot3(dq, dq);
+                        if (d2 < R2) {
+                            const float4 cc = a.C[j], cd = a.D[j];
+                            const f3 ccol = {cc.z, cc.w, cd.x};
+                            const f3 dc = sub3(ccol, pcol);               // ColorDelta(child, parent)
+                            const float cdiff = sqrtf(dot3(dc, dc));
+                            if (!(cdiff > a.colorThr)) {                  // mixture.cpp:122-124
+                                const float4 cb = a.B[j];
+                                const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
+                                const float det_c = ca.w;
+                                const f3 d = sub3(cm, pm);
+                                const float k = kld6(d, ccov, det_c, pinv, det_p);
+                                if (!(k > a.kldThr)) {                    // mixture.cpp:126-129 (NaN passes)
+                                    const bool child_is_parent = (__float_as_uint(cd.w) & 1u) != 0u;
+                                    if (!(child_is_parent && j != js)) {  // mixture.cpp:131-133
+                                        acc = true;
+                                        if (FILL) {
+                                            // hemLikelihoodOpacity, mixture.cpp:54-64
+                                            const float distanceDiff = sqrtf(d2);
+                                            const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
+                                            const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
+                                            const float L = distWeight * cd.y * colorInfluence * sqrtf(det_c);
+                                            wl = pweight * ref_clamp(L, FLT_MIN, 1e8f);
+                                        }
+                                    }
+                                }
+                            }
+                        }
+                    }
+                    if (FILL) {
+                        const unsigned long long m = __ballot(acc);
+                        if (acc) {
+                            const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                            a.pair_child[pos] = (unsigned)j;
+                            a.pair_wl[pos] = wl;
+                        }
+                        base += __popcll(m);
+                    } else {
+                        count += acc ? 1u : 0u;
+                    }
+                }
+            }
+        }
+    }
+    if (!FILL) {
+        for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
+        if (lane == 0) {
+            a.pcnt[p] = count;
+            atomicAdd(a.cand_total, scanned);
+        }
+    }
+}
+
+// per-child sum of wL_si, sequential in the (stable) sorted pair order (mixture.cpp:162)
+__global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restrict__ cstart,
+                                               const float* __restrict__ wl_sorted, float* __restrict__ sumLw,
+                                               int* __restrict__ orphan_flag) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        float s = 0.0f;
+        for (int64_t k = cstart[j]; k < cstart[j + 1]; ++k) s += wl_sorted[k];
+        sumLw[j] = s;
+        orphan_flag[j] = s == 0.0f ? 1 : 0;
+    }
+}
+
+// flags back to INPUT order, where the output ranks are defined (mixture.cpp:169,250-253)
+__global__ __launch_bounds__(256) void k_flags_to_input_order(int64_t n, const unsigned* __restrict__ order,
+                                                              const int* __restrict__ pflag_sorted,
+                                                              const int* __restrict__ oflag_sorted,
+                                                              int* __restrict__ pflag_in, int* __restrict__ oflag_in) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = order[j];
+        pflag_in[i] = pflag_sorted[j];
+        oflag_in[i] = oflag_sorted[j];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// k_mstep: responsibilities and moment-matching update (mixture.cpp:167-247), one wavefront per parent
+// ------------------------------------------------------------------------------------------------
+struct MstepArgs {
+    const float4 *A, *B, *C, *D;
+    const float* shs;
+    const float* sumLw;
+    const unsigned* plist;
+    const unsigned* order;
+    const int* prank_in;       // exclusive scan of the parent flags in input order
+    const int64_t* poff;
+    const unsigned* pcnt;
+    const unsigned* pair_child;
+    const float* pair_wl;
+    int P, F;
+    float *o_xyz, *o_color, *o_cov6, *o_opacity, *o_weight, *o_sh;
+};
+
+#define MSTEP_CHUNK 256
+__global__ __launch_bounds__(256) void k_mstep(MstepArgs a) {
+    __shared__ float s_w[4][MSTEP_CHUNK];
+    __shared__ unsigned s_j[4][MSTEP_CHUNK];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wv;
+    if (p >= a.P) return;
+    const int js = (int)a.plist[p];
+    const float4 pa = a.A[js];
+    const f3 pm = {pa.x, pa.y, pa.z};
+    const int64_t off = a.poff[p];
+    const unsigned cnt = a.pcnt[p];
+
+    float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
+    float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
+    // SH accumulators: lane f owns coefficients f, f+64, ... (F <= 256 supported per pass)
+    float shacc[4] = {0, 0, 0, 0};
+    const int nF = (a.F + 63) / 64;
+
+    for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
+        const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
+        // part 1: lane <-> pair; moment partial sums
+        for (unsigned k = lane; k < cn; k += 64) {
+            const unsigned j = a.pair_child[off + c0 + k];
+            const float wl = a.pair_wl[off + c0 + k];
+            const float sl = a.sumLw[j];
+            float w = 0.0f;
+            unsigned jj = 0xffffffffu;                         // marks "skip" (sumLw == 0, mixture.cpp:190)
+            if (sl != 0.0f) {
+                const float4 ca = a.A[j], cb = a.B[j], cc = a.C[j], cd = a.D[j];
+                const float r_is = wl / sl;                    // mixture.cpp:196
+                w = r_is * cd.z;                               // * child.weight (:197)
+                jj = j;
+                const f3 cm = {ca.x, ca.y, ca.z};
+                const f3 d = sub3(cm, pm);
+                w_s += w;
+                smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
+                scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
+                v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
+                v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
+                so += w * cd.y;
+            }
+            s_w[wv][k] = w;
+            s_j[wv][k] = jj;
+        }
+        __builtin_amdgcn_wave_barrier();
+        // part 2: lane <-> SH coefficient; children in pair order
+        if (a.F > 0) {
+            for (unsigned k = 0; k < cn; ++k) {
+                const unsigned j = s_j[wv][k];
+                if (j == 0xffffffffu) continue;
+                const float w = s_w[wv][k];
+                const float* row = a.shs + (int64_t)j * a.F;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int f = lane + 64 * q;
+                    if (q < nF && f < a.F) shacc[q] += row[f] * w;
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    w_s = wave_sum(w_s);
+    smx = wave_sum(smx); smy = wave_sum(smy); smz = wave_sum(smz);
+    scx = wave_sum(scx); scy = wave_sum(scy); scz = wave_sum(scz);
+    v00 = wave_sum(v00); v01 = wave_sum(v01); v02 = wave_sum(v02);
+    v11 = wave_sum(v11); v12 = wave_sum(v12); v22 = wave_sum(v22);
+    so = wave_sum(so);
+
+    const float inv_w = 1.0f / w_s;                            // mixture.cpp:209
+    const int64_t slot = a.prank_in[a.order[js]];
+    if (lane == 0) {
+        const float mx = smx * inv_w, my = smy * inv_w, mz = smz * inv_w;
+        const float dx = mx - pm.x, dy = my - pm.y, dz = mz - pm.z;
+        a.o_xyz[3 * slot] = mx; a.o_xyz[3 * slot + 1] = my; a.o_xyz[3 * slot + 2] = mz;
+        a.o_color[3 * slot] = scx * inv_w; a.o_color[3 * slot + 1] = scy * inv_w; a.o_color[3 * slot + 2] = scz * inv_w;
+        a.o_cov6[6 * slot] = v00 * inv_w - dx * dx;
+        a.o_cov6[6 * slot + 1] = v01 * inv_w - dx * dy;
+        a.o_cov6[6 * slot + 2] = v02 * inv_w - dx * dz;
+        a.o_cov6[6 * slot + 3] = v11 * inv_w - dy * dy;
+        a.o_cov6[6 * slot + 4] = v12 * inv_w - dy * dz;
+        a.o_cov6[6 * slot + 5] = v22 * inv_w - dz * dz;
+        a.o_opacity[slot] = inv_w * so;
+        a.o_weight[slot] = w_s;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int f = lane + 64 * q;
+        if (q < nF && f < a.F) a.o_sh[slot * a.F + f] = shacc[q] * inv_w;
+    }
+}
+
+// orphans: components no parent addressed (sumLw == 0) are copied unchanged after all parents
+__global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigned* __restrict__ order,
+                                                 const int* __restrict__ oflag_sorted, const int* __restrict__ orank_in,
+                                                 const float4* __restrict__ A, const float4* __restrict__ B,
+                                                 const float4* __restrict__ C, const float4* __restrict__ D,
+                                                 float* o_xyz, float* o_color, float* o_cov6, float* o_opacity,
+                                                 float* o_weight, int64_t* __restrict__ oslot_sorted) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        int64_t slot = -1;
+        if (oflag_sorted[j]) {
+            slot = (int64_t)P + orank_in[order[j]];
+            const float4 a = A[j], b = B[j], c = C[j], d = D[j];
+            o_xyz[3 * slot] = a.x; o_xyz[3 * slot + 1] = a.y; o_xyz[3 * slot + 2] = a.z;
+            o_color[3 * slot] = c.z; o_color[3 * slot + 1] = c.w; o_color[3 * slot + 2] = d.x;
+            o_cov6[6 * slot] = b.x; o_cov6[6 * slot + 1] = b.y; o_cov6[6 * slot + 2] = b.z;
+            o_cov6[6 * slot + 3] = b.w; o_cov6[6 * slot + 4] = c.x; o_cov6[6 * slot + 5] = c.y;
+            o_opacity[slot] = d.y;
+            o_weight[slot] = d.z;
+        }
+        oslot_sorted[j] = slot;
+    }
+}
+__global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, const int64_t* __restrict__ oslot_sorted,
+                                                    const float* __restrict__ shs, float* __restrict__ o_sh) {
+    const int64_t total = n * F;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = t / F;
+        const int64_t slot = oslot_sorted[j];
+        if (slot >= 0) o_sh[slot * F + (t - j * F)] = shs[t];
+    }
+}
+
+// parent flags from 32-bit draws: rand01() < 1/rho with rand01 = float(r) / float(0xffffffff)
+// (base.hpp:53-56, mixture.cpp:257-259)
+__global__ __launch_bounds__(256) void k_flags_from_draws(int64_t n, const unsigned* __restrict__ draws, float prob,
+                                                          uint8_t* __restrict__ is_parent) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float r01 = (float)draws[i] / 4294967296.0f;
+        is_parent[i] = r01 < prob ? 1 : 0;
+    }
+}
+__device__ __forceinline__ unsigned hash32(unsigned long long x) {      // splitmix64 finaliser
+    x += 0x9e3779b97f4a7c15ull;
+    x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ull;
+    x = (x ^ (x >> 27)) * 0x94d049bb133111ebull;
+    x = x ^ (x >> 31);
+    return (unsigned)(x >> 32);
+}
+__global__ __launch_bounds__(256) void k_flags_hash(int64_t n, unsigned seed, unsigned long long first_draw, float prob,
+                                                    uint8_t* __restrict__ is_parent) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned r = hash32(((unsigned long long)seed << 40) ^ (first_draw + (unsigned long long)i));
+        const float r01 = (float)r / 4294967296.0f;
+        is_parent[i] = r01 < prob ? 1 : 0;
+    }
+}
+
+// validity (mixture.cpp:262-282): keep iff !(isnan(mean) || isnan(det) || det <= 0)
+__global__ __launch_bounds__(256) void k_valid(int64_t n, const float* __restrict__ xyz, const float* __restrict__ cov6,
+                                               int* __restrict__ keep) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        s6 c = {cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5]};
+        const float d = det6(c);
+        const bool bad = (x != x) || (y != y) || (z != z) || (d != d) || (d <= 0.0f);
+        keep[i] = bad ? 0 : 1;
+    }
+}
+__global__ __launch_bounds__(256) void k_compact_rows(int64_t n, int width, const int* __restrict__ keep,
+                                                      const int* __restrict__ pos, const float* __restrict__ src,
+                                                      float* __restrict__ dst) {
+    const int64_t total = n * width;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = t / width;
+        if (keep[i]) dst[(int64_t)pos[i] * width + (t - i * width)] = src[t];
+    }
+}
+__global__ __launch_bounds__(256) void k_compact_bytes(int64_t n, const int* __restrict__ keep, const int* __restrict__ pos,
+                                                       const uint8_t* __restrict__ src, uint8_t* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (keep[i]) dst[pos[i]] = src[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct Level {
+    int64_t n = 0;
+    int F = 0;
+    DevBuf xyz, color, cov6, opacity, weight, sh, is_parent;
+    int32_t reserve(int64_t m, int f) {
+        const size_t mm = (size_t)(m > 0 ? m : 1);
+        GSR_TRY(xyz.reserve(mm * 3 * 4)); GSR_TRY(color.reserve(mm * 3 * 4)); GSR_TRY(cov6.reserve(mm * 6 * 4));
+        GSR_TRY(opacity.reserve(mm * 4)); GSR_TRY(weight.reserve(mm * 4));
+        GSR_TRY(sh.reserve(mm * (size_t)(f > 0 ? f : 1) * 4)); GSR_TRY(is_parent.reserve(mm));
+        return GSR_OK;
+    }
+    void release() { xyz.release(); color.release(); cov6.release(); opacity.release(); weight.release(); sh.release(); is_parent.release(); }
+    void swap(Level& o) {
+        std::swap(n, o.n); std::swap(F, o.F);
+        xyz.swap(o.xyz); color.swap(o.color); cov6.swap(o.cov6); opacity.swap(o.opacity);
+        weight.swap(o.weight); sh.swap(o.sh); is_parent.swap(o.is_parent);
+    }
+};
+
+}  // namespace gsr
+
+using namespace gsr;
+
+struct gsr_hem_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    float rho = 3.0f, delta = 3.0f, kappa = 2.5f, tau = 1.0f;
+    int rng_mode = GSR_RNG_GLIBC;
+    uint32_t rng_seed = 1;
+    uint64_t rng_pos = 0;           // hem::rand() values consumed so far
+    GlibcRng rng;                   // positioned at rng_pos
+    bool rng_ready = false;
+    Level cur, nxt, tmp;
+    bool have_level = false;
+    // workspace
+    DevBuf det, radius, bbox, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
+    DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
+    DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
+    std::vector<unsigned> h_draws;
+    int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float phase_ms[6] = {0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float cell_target = 8.0f;
+    int max_cells = 1 << 24;
+};
+
+namespace {
+
+int32_t sync_rng(gsr_hem_ctx* c) {
+    if (c->rng_ready) return GSR_OK;
+    c->rng.seed(c->rng_seed);
+    for (uint64_t i = 0; i < c->rng_pos; ++i) c->rng.hem_rand();
+    c->rng_ready = true;
+    return GSR_OK;
+}
+
+// draw n parent flags for `lv` in order (consumes n hem::rand() values)
+int32_t draw_flags(gsr_hem_ctx* c, Level& lv) {
+    const int64_t n = lv.n;
+    const float prob = 1.0f / c->rho;
+    if (n == 0) return GSR_OK;
+    if (c->rng_mode == GSR_RNG_HASH) {
+        hipLaunchKernelGGL(k_flags_hash, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, c->rng_seed,
+                           (unsigned long long)c->rng_pos, prob, lv.is_parent.as<uint8_t>());
+        c->rng_pos += (uint64_t)n;
+        c->rng_ready = false;
+        return GSR_OK;
+    }
+    GSR_TRY(sync_rng(c));
+    c->h_draws.resize((size_t)n);
+    for (int64_t i = 0; i < n; ++i) c->h_draws[(size_t)i] = c->rng.hem_rand();
+    c->rng_pos += (uint64_t)n;
+    GSR_TRY(c->draws.reserve((size_t)n * 4));
+    GSR_HIP(hipMemcpyAsync(c->draws.p, c->h_draws.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_flags_from_draws, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, c->draws.as<unsigned>(), prob,
+                       lv.is_parent.as<uint8_t>());
+    GSR_HIP(hipStreamSynchronize(c->stream));   // h_draws is reused by the next call
+    return GSR_OK;
+}
+
+template <typename T>
+int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n) {
+    size_t bytes = 0;
+    GSR_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (T)0, (size_t)n, rocprim::plus<T>(), c->stream));
+    GSR_TRY(c->rocprim_tmp.reserve(bytes));
+    GSR_HIP(rocprim::exclusive_scan(c->rocprim_tmp.p, bytes, in, out, (T)0, (size_t)n, rocprim::plus<T>(), c->stream));
+    return GSR_OK;
+}
+
+template <typename V>
+int32_t sort_pairs(gsr_hem_ctx* c, const unsigned* kin, unsigned* kout, const V* vin, V* vout, int64_t n, int end_bit) {
+    size_t bytes = 0;
+    GSR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
+    GSR_TRY(c->rocprim_tmp.reserve(bytes));
+    GSR_HIP(rocprim::radix_sort_pairs(c->rocprim_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
+    return GSR_OK;
+}
+
+int bits_for(int64_t n) {
+    int b = 1;
+    while (b < 32 && ((int64_t)1 << b) < n) ++b;
+    return b;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* gsr_last_error(void) { return last_error().c_str(); }
+const char* gsr_version(void) { return "gsr_hip 0.1 gfx950"; }
+int32_t gsr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
+    if (!out) return fail(GSR_E_INVALID, "gsr_hem_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GSR_E_NO_DEVICE, "gsr_hem_create: no HIP device visible (this backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GSR_E_INVALID, "gsr_hem_create: device %d out of range (0..%d)", device, ndev - 1);
+    GSR_HIP(hipSetDevice(device));
+    gsr_hem_ctx* c = new gsr_hem_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    for (int i = 0; i < 7; ++i) {
+        hipError_t e = hipEventCreate(&c->ev[i]);
+        if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+    }
+    if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
+    *out = c;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
+    if (!c) return GSR_OK;
+    (void)hipSetDevice(c->device);
+    c->cur.release(); c->nxt.release(); c->tmp.release();
+    DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
+                     &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
+                     &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
+                     &c->orank_in, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+    for (DevBuf* b : all) b->release();
+    for (int i = 0; i < 7; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    delete c;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_set_params(gsr_hem_ctx* c, float rho, float delta, float kappa, float tau) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_params: NULL context");
+    c->rho = rho; c->delta = delta; c->kappa = kappa; c->tau = tau;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_set_rng(gsr_hem_ctx* c, int32_t mode, uint32_t seed, uint64_t skip) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_rng: NULL context");
+    if (mode != GSR_RNG_GLIBC && mode != GSR_RNG_HASH) return fail(GSR_E_INVALID, "gsr_hem_set_rng: unknown mode %d", mode);
+    c->rng_mode = mode; c->rng_seed = seed; c->rng_pos = skip; c->rng_ready = false;
+    return GSR_OK;
+}
+int32_t gsr_hem_get_rng_position(gsr_hem_ctx* c, uint64_t* draws) {
+    if (!c || !draws) return fail(GSR_E_INVALID, "gsr_hem_get_rng_position: NULL argument");
+    *draws = c->rng_pos;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_set_level0(gsr_hem_ctx* c, const float* xyz, const float* color, const float* cov6,
+                           const float* opacity, const float* sh, int64_t n, int32_t F, int32_t on_device) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_level0: NULL context");
+    if (n < 0 || F < 0) return fail(GSR_E_INVALID, "gsr_hem_set_level0: negative size (n=%lld, F=%d)", (long long)n, F);
+    if (F > 256) return fail(GSR_E_INVALID, "gsr_hem_set_level0: F=%d exceeds the supported 256 feature floats", F);
+    if (n >= ((int64_t)1 << 31) - 1) return fail(GSR_E_INVALID, "gsr_hem_set_level0: n=%lld exceeds 2^31-2", (long long)n);
+    if (n > 0 && (!xyz || !color || !cov6 || !opacity || (F > 0 && !sh)))
+        return fail(GSR_E_INVALID, "gsr_hem_set_level0: NULL array");
+    GSR_HIP(hipSetDevice(c->device));
+    Level& L = c->cur;
+    GSR_TRY(L.reserve(n, F));
+    L.n = n; L.F = F;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (n > 0) {
+        GSR_HIP(hipMemcpyAsync(L.xyz.p, xyz, (size_t)n * 12, kind, c->stream));
+        GSR_HIP(hipMemcpyAsync(L.color.p, color, (size_t)n * 12, kind, c->stream));
+        GSR_HIP(hipMemcpyAsync(L.cov6.p, cov6, (size_t)n * 24, kind, c->stream));
+        GSR_HIP(hipMemcpyAsync(L.opacity.p, opacity, (size_t)n * 4, kind, c->stream));
+        if (F > 0) GSR_HIP(hipMemcpyAsync(L.sh.p, sh, (size_t)n * F * 4, kind, c->stream));
+        hipLaunchKernelGGL(k_fill_const<float>, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, L.weight.as<float>(), 1.0f);   // mixture.cpp:315
+    }
+    GSR_TRY(draw_flags(c, L));                                  // mixture.cpp:330
+    GSR_HIP(hipStreamSynchronize(c->stream));
+    c->have_level = true;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_set_state(gsr_hem_ctx* c, const uint8_t* parent_mask, const float* weight) {
+    if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_set_state: no level set");
+    GSR_HIP(hipSetDevice(c->device));
+    if (c->cur.n > 0) {
+        if (parent_mask) GSR_HIP(hipMemcpyAsync(c->cur.is_parent.p, parent_mask, (size_t)c->cur.n, hipMemcpyHostToDevice, c->stream));
+        if (weight) GSR_HIP(hipMemcpyAsync(c->cur.weight.p, weight, (size_t)c->cur.n * 4, hipMemcpyHostToDevice, c->stream));
+        GSR_HIP(hipStreamSynchronize(c->stream));
+    }
+    return GSR_OK;
+}
+
+int32_t gsr_hem_level_size(gsr_hem_ctx* c, int64_t* n, int32_t* F) {
+    if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_level_size: no level set");
+    if (n) *n = c->cur.n;
+    if (F) *F = c->cur.F;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_get_level(gsr_hem_ctx* c, float* xyz, float* color, float* cov6, float* opacity, float* sh,
+                          float* weight, uint8_t* is_parent, int32_t on_device) {
+    if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_get_level: no level set");
+    GSR_HIP(hipSetDevice(c->device));
+    const Level& L = c->cur;
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    const size_t n = (size_t)L.n;
+    if (n > 0) {
+        if (xyz) GSR_HIP(hipMemcpyAsync(xyz, L.xyz.p, n * 12, kind, c->stream));
+        if (color) GSR_HIP(hipMemcpyAsync(color, L.color.p, n * 12, kind, c->stream));
+        if (cov6) GSR_HIP(hipMemcpyAsync(cov6, L.cov6.p, n * 24, kind, c->stream));
+        if (opacity) GSR_HIP(hipMemcpyAsync(opacity, L.opacity.p, n * 4, kind, c->stream));
+        if (sh && L.F > 0) GSR_HIP(hipMemcpyAsync(sh, L.sh.p, n * (size_t)L.F * 4, kind, c->stream));
+        if (weight) GSR_HIP(hipMemcpyAsync(weight, L.weight.p, n * 4, kind, c->stream));
+        if (is_parent) GSR_HIP(hipMemcpyAsync(is_parent, L.is_parent.p, n, kind, c->stream));
+        GSR_HIP(hipStreamSynchronize(c->stream));
+    }
+    return GSR_OK;
+}
+
+int32_t gsr_hem_get_stats(gsr_hem_ctx* c, int64_t* out8) {
+    if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_stats: NULL argument");
+    memcpy(out8, c->stats, sizeof(c->stats));
+    return GSR_OK;
+}
+int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out6) {
+    if (!c || !out6) return fail(GSR_E_INVALID, "gsr_hem_get_phase_ms: NULL argument");
+    memcpy(out6, c->phase_ms, sizeof(c->phase_ms));
+    return GSR_OK;
+}
+
+int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
+    if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_run_level: no level set");
+    GSR_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    Level& L = c->cur;
+    const int64_t n = L.n;
+    const int F = L.F;
+    memset(c->stats, 0, sizeof(c->stats));
+    c->stats[6] = n;
+    if (n == 0) {
+        if (n_out) *n_out = 0;
+        if (n_dropped) *n_dropped = 0;
+        return GSR_OK;
+    }
+    const dim3 blk(256);
+    const dim3 grd(stride_grid(n));
+    GSR_HIP(hipEventRecord(c->ev[0], st));
+
+    // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
+    GSR_TRY(c->det.reserve(n * 4)); GSR_TRY(c->radius.reserve(n * 4)); GSR_TRY(c->bbox.reserve(64));
+    GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(64));
+    {
+        unsigned init[6];
+        float big = FLT_MAX, sml = -FLT_MAX;
+        unsigned ub, us;
+        memcpy(&ub, &big, 4); memcpy(&us, &sml, 4);
+        // encoded +FLT_MAX for the mins, encoded -FLT_MAX for the maxes
+        unsigned eb = ub | 0x80000000u, es = ~us;
+        init[0] = init[1] = init[2] = eb; init[3] = init[4] = init[5] = es;
+        GSR_HIP(hipMemcpyAsync(c->bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+        GSR_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
+    }
+    hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.cov6.as<float>(), L.is_parent.as<uint8_t>(), c->delta,
+                       c->det.as<float>(), c->radius.as<float>(), c->bbox.as<unsigned>());
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1), 0, st, c->bbox.as<unsigned>(), n, c->cell_target, c->max_cells,
+                       c->gparams.as<GridParams>());
+    GridParams gp;
+    GSR_HIP(hipMemcpyAsync(&gp, c->gparams.p, sizeof(gp), hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipStreamSynchronize(st));
+    c->stats[5] = gp.ncells;
+
+    GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->order.reserve(n * 4));
+    hipLaunchKernelGGL(k_keys, grd, blk, 0, st, n, L.xyz.as<float>(), c->gparams.as<GridParams>(), c->keys.as<unsigned>(), c->idx.as<unsigned>());
+    GSR_TRY(sort_pairs<unsigned>(c, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(), c->order.as<unsigned>(), n,
+                                 bits_for(gp.ncells)));
+    GSR_TRY(c->cellStart.reserve(((size_t)gp.ncells + 1) * 4));
+    hipLaunchKernelGGL(k_run_starts<int>, grd, blk, 0, st, n, c->skeys.as<unsigned>(), (int64_t)gp.ncells, c->cellStart.as<int>());
+
+    GSR_TRY(c->A.reserve(n * 16)); GSR_TRY(c->B.reserve(n * 16)); GSR_TRY(c->C.reserve(n * 16)); GSR_TRY(c->D.reserve(n * 16));
+    GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
+    GSR_TRY(c->shs.reserve((size_t)n * (F > 0 ? F : 1) * 4));
+    hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(),
+                       L.opacity.as<float>(), L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->det.as<float>(), c->radius.as<float>(),
+                       c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>());
+    if (F > 0)
+        hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
+    GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
+    hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
+    int last_pos = 0, last_flag = 0;
+    GSR_HIP(hipMemcpyAsync(&last_pos, c->ppos.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipMemcpyAsync(&last_flag, c->pflag.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipStreamSynchronize(st));
+    const int P = last_pos + last_flag;
+    c->stats[0] = P;
+    GSR_HIP(hipEventRecord(c->ev[1], st));
+
+    // ---- 2. selection: count, scan, fill --------------------------------------------------------
+    const size_t Pm = (size_t)(P > 0 ? P : 1);
+    GSR_TRY(c->pcnt.reserve(Pm * 4)); GSR_TRY(c->poff.reserve((Pm + 1) * 8)); GSR_TRY(c->scratch.reserve((Pm + 1) * 8));
+    SelectArgs sa;
+    memset(&sa, 0, sizeof(sa));
+    sa.A = c->A.as<float4>(); sa.B = c->B.as<float4>(); sa.C = c->C.as<float4>(); sa.D = c->D.as<float4>();
+    sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
+    sa.gp = c->gparams.as<GridParams>(); sa.P = P;
+    sa.colorThr = c->kappa * c->kappa * 0.5f;     // mixture.cpp:123
+    sa.kldThr = c->delta * c->delta * 0.5f;       // mixture.cpp:128
+    sa.tau2 = c->tau * c->tau;                    // mixture.cpp:58,61
+    sa.pcnt = c->pcnt.as<unsigned>();
+    sa.cand_total = c->counters.as<unsigned long long>();
+    int64_t M = 0;
+    if (P > 0) {
+        hipLaunchKernelGGL(k_select<false>, dim3(ceil_div(P, 4)), blk, 0, st, sa);
+        // offsets: widen counts to int64 and scan
+        int64_t* cnt64 = c->scratch.as<int64_t>();
+        {
+            // small helper kernel inline: reuse k_run_starts-free path via rocprim transform
+            GSR_HIP(rocprim::transform(c->pcnt.as<unsigned>(), cnt64, (size_t)P, [] __device__(unsigned v) { return (int64_t)v; }, st));
+        }
+        GSR_TRY(exclusive_scan<int64_t>(c, cnt64, c->poff.as<int64_t>(), P));
+        int64_t last_off = 0;
+        unsigned last_cnt = 0;
+        unsigned long long cand = 0;
+        GSR_HIP(hipMemcpyAsync(&last_off, c->poff.as<int64_t>() + (P - 1), 8, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipMemcpyAsync(&last_cnt, c->pcnt.as<unsigned>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipMemcpyAsync(&cand, c->counters.p, 8, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        M = last_off + (int64_t)last_cnt;
+        c->stats[4] = (int64_t)cand;
+    }
+    c->stats[1] = M;
+    const size_t Mm = (size_t)(M > 0 ? M : 1);
+    GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
+    GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
+    if (M > 0) {
+        sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
+        hipLaunchKernelGGL(k_select<true>, dim3(ceil_div(P, 4)), blk, 0, st, sa);
+    }
+    GSR_HIP(hipEventRecord(c->ev[2], st));
+
+    // ---- 3. per-child sums of wL (deterministic: stable sort by child, sequential sum) ----------
+    GSR_TRY(c->cstart.reserve(((size_t)n + 1) * 8)); GSR_TRY(c->sumLw.reserve(n * 4)); GSR_TRY(c->oflag.reserve(n * 4));
+    if (M > 0) {
+        GSR_TRY(sort_pairs<float>(c, c->pair_child.as<unsigned>(), c->spair_child.as<unsigned>(), c->pair_wl.as<float>(),
+                                  c->spair_wl.as<float>(), M, bits_for(n)));
+        hipLaunchKernelGGL(k_run_starts<int64_t>, dim3(stride_grid(M)), blk, 0, st, M, c->spair_child.as<unsigned>(), n, c->cstart.as<int64_t>());
+    } else {
+        hipLaunchKernelGGL(k_fill_const<int64_t>, grd, blk, 0, st, n + 1, c->cstart.as<int64_t>(), (int64_t)0);
+    }
+    hipLaunchKernelGGL(k_sumlw, grd, blk, 0, st, n, c->cstart.as<int64_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
+    GSR_HIP(hipEventRecord(c->ev[3], st));
+
+    // ---- 4. output ranks in input order; M-step; orphans -----------------------------------------
+    GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
+    GSR_TRY(c->oslot.reserve(n * 8));
+    hipLaunchKernelGGL(k_flags_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), c->pflag.as<int>(), c->oflag.as<int>(),
+                       c->pflag_in.as<int>(), c->oflag_in.as<int>());
+    GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
+    GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
+    int o_last = 0, o_flag = 0;
+    GSR_HIP(hipMemcpyAsync(&o_last, c->orank_in.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipMemcpyAsync(&o_flag, c->oflag_in.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipStreamSynchronize(st));
+    const int64_t n_orph = (int64_t)o_last + o_flag;
+    c->stats[2] = n_orph;
+    const int64_t n_pre = (int64_t)P + n_orph;
+
+    Level& O = c->nxt;
+    GSR_TRY(O.reserve(n_pre, F));
+    O.n = n_pre; O.F = F;
+    if (P > 0) {
+        MstepArgs ma;
+        memset(&ma, 0, sizeof(ma));
+        ma.A = c->A.as<float4>(); ma.B = c->B.as<float4>(); ma.C = c->C.as<float4>(); ma.D = c->D.as<float4>();
+        ma.shs = c->shs.as<float>(); ma.sumLw = c->sumLw.as<float>(); ma.plist = c->plist.as<unsigned>(); ma.order = c->order.as<unsigned>();
+        ma.prank_in = c->prank_in.as<int>(); ma.poff = c->poff.as<int64_t>(); ma.pcnt = c->pcnt.as<unsigned>();
+        ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
+        ma.P = P; ma.F = F;
+        ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
+        ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
+        hipLaunchKernelGGL(k_mstep, dim3(ceil_div(P, 4)), blk, 0, st, ma);
+    }
+    hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
+                       c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
+                       O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>());
+    if (F > 0 && n_orph > 0)
+        hipLaunchKernelGGL(k_orphans_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
+    GSR_HIP(hipEventRecord(c->ev[4], st));
+
+    // ---- 5. new parent flags (one draw per component, before the erase), validity erase ---------
+    GSR_TRY(draw_flags(c, O));
+    int64_t dropped = 0;
+    if (n_pre > 0) {
+        GSR_TRY(c->keep.reserve(n_pre * 4)); GSR_TRY(c->kpos.reserve(n_pre * 4));
+        const dim3 g2(stride_grid(n_pre));
+        hipLaunchKernelGGL(k_valid, g2, blk, 0, st, n_pre, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>());
+        GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
+        int k_last = 0, k_flag = 0;
+        GSR_HIP(hipMemcpyAsync(&k_last, c->kpos.as<int>() + (n_pre - 1), 4, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipMemcpyAsync(&k_flag, c->keep.as<int>() + (n_pre - 1), 4, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        const int64_t n_keep = (int64_t)k_last + k_flag;
+        dropped = n_pre - n_keep;
+        if (dropped > 0) {
+            Level& T = c->tmp;
+            GSR_TRY(T.reserve(n_keep, F));
+            T.n = n_keep; T.F = F;
+            const int* keep = c->keep.as<int>();
+            const int* pos = c->kpos.as<int>();
+            hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 3)), blk, 0, st, n_pre, 3, keep, pos, O.xyz.as<float>(), T.xyz.as<float>());
+            hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 3)), blk, 0, st, n_pre, 3, keep, pos, O.color.as<float>(), T.color.as<float>());
+            hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 6)), blk, 0, st, n_pre, 6, keep, pos, O.cov6.as<float>(), T.cov6.as<float>());
+            hipLaunchKernelGGL(k_compact_rows, g2, blk, 0, st, n_pre, 1, keep, pos, O.opacity.as<float>(), T.opacity.as<float>());
+            hipLaunchKernelGGL(k_compact_rows, g2, blk, 0, st, n_pre, 1, keep, pos, O.weight.as<float>(), T.weight.as<float>());
+            if (F > 0)
+                hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * F)), blk, 0, st, n_pre, F, keep, pos, O.sh.as<float>(), T.sh.as<float>());
+            hipLaunchKernelGGL(k_compact_bytes, g2, blk, 0, st, n_pre, keep, pos, O.is_parent.as<uint8_t>(), T.is_parent.as<uint8_t>());
+            O.swap(T);
+        }
+    }
+    GSR_HIP(hipEventRecord(c->ev[5], st));
+    GSR_HIP(hipStreamSynchronize(st));
+    c->cur.swap(c->nxt);
+    c->stats[3] = dropped;
+    c->stats[7] = c->cur.n;
+    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
+    (void)hipEventElapsedTime(&c->phase_ms[5], c->ev[0], c->ev[5]);
+    if (n_out) *n_out = c->cur.n;
+    if (n_dropped) *n_dropped = dropped;
+    return GSR_OK;
+}
+
+}  // extern "C"

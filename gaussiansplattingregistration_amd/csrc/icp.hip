@@ -1,0 +1,729 @@
+// icp.hip -- the per-iteration ICP step on MI355X (gfx950), behind include/gsr_hip.h.
+//
+// Replaces what the reference reaches through Open3D 0.16.0's registration_icp
+// (src/utils/local_registration_util.py:76-100): for every source point, transform, nearest target
+// neighbour within max_corr, residual / Jacobian, and the reduction that the estimator solves.
+// The reference's Open3D walks a KD-tree per point under OpenMP; here:
+//
+//   target (once per call)  cell-sorted float4 {x, y, z, bits(input index)} + optional double3
+//                           normals, dense uniform grid with cell >= max_corr, prefix table
+//                           cellStart[cells+1] -- the 27 cells around a query bound the search
+//   k_icp_accumulate<KIND>  ONE fused pass per ICP iteration: p = T*p0 in float64, 9 contiguous
+//                           row spans (3 cells each) of the sorted target, exact 1-NN
+//                           (ties -> lowest input index), strict d^2 < max_corr^2, residual and
+//                           Jacobian, float64 accumulators reduced wave -> block -> per-block
+//                           partials; k_icp_finalize sums the partials in a fixed order.
+//                           No per-point writes; algorithmic bytes 24 (point-to-point) or
+//                           48 (point-to-plane, float64 normals) per source point.
+//   host (this file)        3x3 Jacobi SVD (Umeyama) or 6x6 LDL^T solve in float64 on 32 doubles,
+//                           convergence test, optional all-reduce callback for multi-GPU source splits.
+//
+// Accumulator layout (GSR_ICP_ACC_LEN = 32 doubles), see include/gsr_hip.h.
+#include "gsr_common.h"
+
+#include <float.h>
+#include <math.h>
+#include <string.h>
+
+#include <rocprim/rocprim.hpp>
+
+namespace gsr {
+
+struct IcpGrid {
+    double ox, oy, oz, inv_c, c;
+    double cx, cy, cz;     // centre used to condition the point-to-point sums
+    int gx, gy, gz, ncells;
+};
+
+__device__ __forceinline__ int icp_cell(double v, double o, double inv_c, int g) {
+    double t = (v - o) * inv_c;
+    t = fmin(fmax(t, 0.0), (double)(g - 1));      // NaN -> 0
+    return (int)t;
+}
+
+__global__ __launch_bounds__(256) void k_icp_bbox(int64_t n, const float* __restrict__ xyz, unsigned* __restrict__ bbox) {
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX) {
+            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+            mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+            mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+        }
+    }
+    for (int k = 0; k < 3; ++k)
+        for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) {
+            unsigned a = __float_as_uint(mn[k]), b = __float_as_uint(mx[k]);
+            a = (a & 0x80000000u) ? ~a : (a | 0x80000000u);
+            b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+            atomicMin(&bbox[k], a);
+            atomicMax(&bbox[3 + k], b);
+        }
+}
+
+__global__ __launch_bounds__(256) void k_icp_keys(int64_t n, const float* __restrict__ xyz, IcpGrid g,
+                                                  unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int cx = icp_cell((double)xyz[3 * i], g.ox, g.inv_c, g.gx);
+        int cy = icp_cell((double)xyz[3 * i + 1], g.oy, g.inv_c, g.gy);
+        int cz = icp_cell((double)xyz[3 * i + 2], g.oz, g.inv_c, g.gz);
+        keys[i] = (unsigned)((cz * g.gy + cy) * g.gx + cx);
+        idx[i] = (unsigned)i;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_icp_cell_starts(int64_t m, const unsigned* __restrict__ skeys, int64_t nkeys,
+                                                         int* __restrict__ start) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < m; j += (int64_t)gridDim.x * blockDim.x) {
+        unsigned k = skeys[j];
+        int64_t prev = j == 0 ? -1 : (int64_t)skeys[j - 1];
+        if ((int64_t)k != prev)
+            for (int64_t c = prev + 1; c <= (int64_t)k; ++c) start[c] = (int)j;
+        if (j == m - 1)
+            for (int64_t c = (int64_t)k + 1; c <= nkeys; ++c) start[c] = (int)m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_icp_gather_target(int64_t n, const unsigned* __restrict__ order,
+                                                           const float* __restrict__ xyz, const double* __restrict__ nrm,
+                                                           float4* __restrict__ Tq, double* __restrict__ Tn) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned i = order[j];
+        Tq[j] = make_float4(xyz[3 * (int64_t)i], xyz[3 * (int64_t)i + 1], xyz[3 * (int64_t)i + 2], __uint_as_float(i));
+        if (nrm) {
+            Tn[3 * j] = nrm[3 * (int64_t)i]; Tn[3 * j + 1] = nrm[3 * (int64_t)i + 1]; Tn[3 * j + 2] = nrm[3 * (int64_t)i + 2];
+        }
+    }
+}
+
+struct Xform { double m[12]; };   // rows 0..2 of the 4x4
+
+// Nearest target neighbour of p (float64) among the 27 cells around it.  Returns the SORTED position
+// (or -1) and d^2; ties go to the lowest input index, as the CPU oracle does.
+__device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restrict__ cellStart,
+                                           const float4* __restrict__ Tq, double px, double py, double pz, double& best_d2) {
+    int best = -1;
+    unsigned best_i = 0xffffffffu;
+    double bd = 1.0 / 0.0;
+    if (!(px == px) || !(py == py) || !(pz == pz)) { best_d2 = bd; return -1; }
+    const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
+    const int xa = cx > 0 ? cx - 1 : 0, xb = cx < g.gx - 1 ? cx + 1 : g.gx - 1;
+    for (int dz = -1; dz <= 1; ++dz) {
+        const int z = cz + dz;
+        if (z < 0 || z >= g.gz) continue;
+        for (int dy = -1; dy <= 1; ++dy) {
+            const int y = cy + dy;
+            if (y < 0 || y >= g.gy) continue;
+            const int rowbase = (z * g.gy + y) * g.gx;
+            const int s = cellStart[rowbase + xa], e = cellStart[rowbase + xb + 1];
+            for (int j = s; j < e; ++j) {
+                const float4 q = Tq[j];
+                const double dx = px - (double)q.x, dyy = py - (double)q.y, dzz = pz - (double)q.z;
+                const double d2 = dx * dx + dyy * dyy + dzz * dzz;
+                const unsigned qi = __float_as_uint(q.w);
+                if (d2 < bd || (d2 == bd && qi < best_i)) { bd = d2; best = j; best_i = qi; }
+            }
+        }
+    }
+    best_d2 = bd;
+    return best;
+}
+
+__device__ __forceinline__ double icp_weight(int loss, double k, double r) {   // Open3D RobustKernel.cpp
+    switch (loss) {
+        case GSR_LOSS_TUKEY: { double t = fmin(1.0, fabs(r) / k); double u = 1.0 - t * t; return u * u; }
+        case GSR_LOSS_CAUCHY: { double t = r / k; return 1.0 / (1.0 + t * t); }
+        case GSR_LOSS_GM: { double t = k + r * r; return k / (t * t); }
+        case GSR_LOSS_HUBER: { double e = fabs(r); return k / fmax(e, k); }
+        default: return 1.0;
+    }
+}
+
+template <int NACC>
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ partials) {
+    __shared__ double s_red[4][NACC];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) {
+        double v = acc[k];
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == 0) s_red[wv][k] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NACC) {
+        const int k = threadIdx.x;
+        partials[(int64_t)blockIdx.x * GSR_ICP_ACC_LEN + k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+    }
+}
+
+// KIND 0: point-to-point sums (17 values); KIND 1: point-to-plane normal equations (30 values)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float* __restrict__ src, Xform T, IcpGrid g,
+                                                        const int* __restrict__ cellStart, const float4* __restrict__ Tq,
+                                                        const double* __restrict__ Tn, double max_corr2, int loss, double kparam,
+                                                        double* __restrict__ partials) {
+    constexpr int NACC = KIND == 0 ? 17 : 30;
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
+        const double px = T.m[0] * x + T.m[1] * y + T.m[2] * z + T.m[3];
+        const double py = T.m[4] * x + T.m[5] * y + T.m[6] * z + T.m[7];
+        const double pz = T.m[8] * x + T.m[9] * y + T.m[10] * z + T.m[11];
+        double d2;
+        const int j = icp_nearest(g, cellStart, Tq, px, py, pz, d2);
+        if (j < 0 || !(d2 < max_corr2)) continue;
+        const float4 q = Tq[j];
+        const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+        acc[0] += 1.0;
+        acc[1] += d2;
+        if (KIND == 0) {
+            const double ax = px - g.cx, ay = py - g.cy, az = pz - g.cz;
+            const double bx = qx - g.cx, by = qy - g.cy, bz = qz - g.cz;
+            acc[2] += ax; acc[3] += ay; acc[4] += az;
+            acc[5] += bx; acc[6] += by; acc[7] += bz;
+            acc[8] += ax * bx; acc[9] += ax * by; acc[10] += ax * bz;
+            acc[11] += ay * bx; acc[12] += ay * by; acc[13] += ay * bz;
+            acc[14] += az * bx; acc[15] += az * by; acc[16] += az * bz;
+        } else {
+            const double nx = Tn[3 * (int64_t)j], ny = Tn[3 * (int64_t)j + 1], nz = Tn[3 * (int64_t)j + 2];
+            const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
+            const double w = icp_weight(loss, kparam, r);
+            const double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+            int t = 2;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[t++] += J[a] * w * J[b];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[23 + a] += J[a] * w * r;
+            acc[29] += r * r;
+        }
+    }
+    block_reduce_store<NACC>(acc, partials);
+}
+
+__global__ void k_icp_finalize(int nblocks, const double* __restrict__ partials, double* __restrict__ out) {
+    const int k = threadIdx.x;
+    if (k >= GSR_ICP_ACC_LEN) return;
+    double s = 0.0;
+    for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * GSR_ICP_ACC_LEN + k];
+    out[k] = s;
+}
+
+__global__ __launch_bounds__(256) void k_icp_correspond(int64_t ns, const float* __restrict__ src, Xform T, IcpGrid g,
+                                                        const int* __restrict__ cellStart, const float4* __restrict__ Tq,
+                                                        double max_corr2, int64_t* __restrict__ out_idx, double* __restrict__ out_d2) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
+        const double px = T.m[0] * x + T.m[1] * y + T.m[2] * z + T.m[3];
+        const double py = T.m[4] * x + T.m[5] * y + T.m[6] * z + T.m[7];
+        const double pz = T.m[8] * x + T.m[9] * y + T.m[10] * z + T.m[11];
+        double d2;
+        const int j = icp_nearest(g, cellStart, Tq, px, py, pz, d2);
+        if (j >= 0 && d2 < max_corr2) { out_idx[i] = (int64_t)__float_as_uint(Tq[j].w); out_d2[i] = d2; }
+        else { out_idx[i] = -1; out_d2[i] = 0.0; }
+    }
+}
+
+// ---- normals from splat covariances (Open3D FastEigen3x3, Eberly's robust 3x3 eigensolver) -------
+__device__ __forceinline__ void cross3d(const double a[3], const double b[3], double o[3]) {
+    o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0];
+}
+__device__ void eigvec0_d(const double A[3][3], double ev, double out[3]) {
+    double r0[3] = {A[0][0] - ev, A[0][1], A[0][2]};
+    double r1[3] = {A[0][1], A[1][1] - ev, A[1][2]};
+    double r2[3] = {A[0][2], A[1][2], A[2][2] - ev};
+    double c01[3], c02[3], c12[3];
+    cross3d(r0, r1, c01); cross3d(r0, r2, c02); cross3d(r1, r2, c12);
+    double d0 = c01[0] * c01[0] + c01[1] * c01[1] + c01[2] * c01[2];
+    double d1 = c02[0] * c02[0] + c02[1] * c02[1] + c02[2] * c02[2];
+    double d2 = c12[0] * c12[0] + c12[1] * c12[1] + c12[2] * c12[2];
+    double dmax = d0;
+    int imax = 0;
+    if (d1 > dmax) { dmax = d1; imax = 1; }
+    if (d2 > dmax) { dmax = d2; imax = 2; }
+    const double inv = 1.0 / sqrt(dmax);
+    for (int k = 0; k < 3; ++k) out[k] = (imax == 0 ? c01[k] : (imax == 1 ? c02[k] : c12[k])) * inv;
+}
+__device__ void eigvec1_d(const double A[3][3], const double e0[3], double ev1, double out[3]) {
+    double U[3], V[3];
+    if (fabs(e0[0]) > fabs(e0[1])) {
+        double inv = 1.0 / sqrt(e0[0] * e0[0] + e0[2] * e0[2]);
+        U[0] = -e0[2] * inv; U[1] = 0; U[2] = e0[0] * inv;
+    } else {
+        double inv = 1.0 / sqrt(e0[1] * e0[1] + e0[2] * e0[2]);
+        U[0] = 0; U[1] = e0[2] * inv; U[2] = -e0[1] * inv;
+    }
+    cross3d(e0, U, V);
+    double AU[3], AV[3];
+    for (int i = 0; i < 3; ++i) {
+        AU[i] = A[i][0] * U[0] + A[i][1] * U[1] + A[i][2] * U[2];
+        AV[i] = A[i][0] * V[0] + A[i][1] * V[1] + A[i][2] * V[2];
+    }
+    double m00 = U[0] * AU[0] + U[1] * AU[1] + U[2] * AU[2] - ev1;
+    double m01 = U[0] * AV[0] + U[1] * AV[1] + U[2] * AV[2];
+    double m11 = V[0] * AV[0] + V[1] * AV[1] + V[2] * AV[2] - ev1;
+    const double a00 = fabs(m00), a01 = fabs(m01), a11 = fabs(m11);
+    if (a00 >= a11) {
+        if (fmax(a00, a01) > 0) {
+            if (a00 >= a01) { m01 /= m00; m00 = 1 / sqrt(1 + m01 * m01); m01 *= m00; }
+            else { m00 /= m01; m01 = 1 / sqrt(1 + m00 * m00); m00 *= m01; }
+            for (int i = 0; i < 3; ++i) out[i] = m01 * U[i] - m00 * V[i];
+        } else for (int i = 0; i < 3; ++i) out[i] = U[i];
+    } else {
+        if (fmax(a11, a01) > 0) {
+            if (a11 >= a01) { m01 /= m11; m11 = 1 / sqrt(1 + m01 * m01); m01 *= m11; }
+            else { m11 /= m01; m01 = 1 / sqrt(1 + m11 * m11); m11 *= m01; }
+            for (int i = 0; i < 3; ++i) out[i] = m11 * U[i] - m01 * V[i];
+        } else for (int i = 0; i < 3; ++i) out[i] = U[i];
+    }
+}
+__global__ __launch_bounds__(256) void k_normals_from_cov(int64_t n, const float* __restrict__ cov6, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double c00 = cov6[6 * i], c01 = cov6[6 * i + 1], c02 = cov6[6 * i + 2], c11 = cov6[6 * i + 3], c12 = cov6[6 * i + 4], c22 = cov6[6 * i + 5];
+        double v[3] = {0, 0, 0};
+        double mx = fmax(fmax(fmax(c00, c01), fmax(c02, c11)), fmax(c12, c22));
+        if (mx != 0 && mx == mx) {
+            double A[3][3] = {{c00 / mx, c01 / mx, c02 / mx}, {c01 / mx, c11 / mx, c12 / mx}, {c02 / mx, c12 / mx, c22 / mx}};
+            const double norm = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+            if (norm > 0) {
+                const double q = (A[0][0] + A[1][1] + A[2][2]) / 3;
+                const double b00 = A[0][0] - q, b11 = A[1][1] - q, b22 = A[2][2] - q;
+                const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2) / 6);
+                const double k00 = b11 * b22 - A[1][2] * A[1][2];
+                const double k01 = A[0][1] * b22 - A[1][2] * A[0][2];
+                const double k02 = A[0][1] * A[1][2] - b11 * A[0][2];
+                const double det = (b00 * k00 - A[0][1] * k01 + A[0][2] * k02) / (p * p * p);
+                const double half_det = fmin(fmax(det * 0.5, -1.0), 1.0);
+                const double angle = acos(half_det) / 3.0;
+                const double two_thirds_pi = 2.09439510239319549;
+                const double beta2 = cos(angle) * 2, beta0 = cos(angle + two_thirds_pi) * 2, beta1 = -(beta0 + beta2);
+                const double ev[3] = {q + p * beta0, q + p * beta1, q + p * beta2};
+                double e0[3], e1[3], e2[3];
+                if (half_det >= 0) {
+                    eigvec0_d(A, ev[2], e2);
+                    if (ev[2] < ev[0] && ev[2] < ev[1]) { v[0] = e2[0]; v[1] = e2[1]; v[2] = e2[2]; }
+                    else {
+                        eigvec1_d(A, e2, ev[1], e1);
+                        if (ev[1] < ev[0] && ev[1] < ev[2]) { v[0] = e1[0]; v[1] = e1[1]; v[2] = e1[2]; }
+                        else cross3d(e1, e2, v);
+                    }
+                } else {
+                    eigvec0_d(A, ev[0], e0);
+                    if (ev[0] < ev[1] && ev[0] < ev[2]) { v[0] = e0[0]; v[1] = e0[1]; v[2] = e0[2]; }
+                    else {
+                        eigvec1_d(A, e0, ev[1], e1);
+                        if (ev[1] < ev[0] && ev[1] < ev[2]) { v[0] = e1[0]; v[1] = e1[1]; v[2] = e1[2]; }
+                        else cross3d(e0, e1, v);
+                    }
+                }
+            } else {
+                if (A[0][0] < A[1][1] && A[0][0] < A[2][2]) v[0] = 1;
+                else if (A[1][1] < A[0][0] && A[1][1] < A[2][2]) v[1] = 1;
+                else v[2] = 1;
+            }
+        }
+        const double nn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (nn == 0.0 || nn != nn) { v[0] = 0; v[1] = 0; v[2] = 1; }
+        out[3 * i] = v[0]; out[3 * i + 1] = v[1]; out[3 * i + 2] = v[2];
+    }
+}
+
+// ---- host-side float64 solves ----------------------------------------------------------------------
+static void svd3(const double Ain[3][3], double U[3][3], double s[3], double V[3][3]) {
+    double B[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { B[i][j] = Ain[i][j]; V[i][j] = i == j; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                double alpha = 0, beta = 0, gamma = 0;
+                for (int i = 0; i < 3; ++i) { alpha += B[i][p] * B[i][p]; beta += B[i][q] * B[i][q]; gamma += B[i][p] * B[i][q]; }
+                if (gamma == 0) continue;
+                off = fmax(off, fabs(gamma) / sqrt(alpha * beta + 1e-300));
+                const double zeta = (beta - alpha) / (2 * gamma);
+                const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1 + zeta * zeta));
+                const double c = 1 / sqrt(1 + t * t), sn = c * t;
+                for (int i = 0; i < 3; ++i) {
+                    const double bp = B[i][p], bq = B[i][q];
+                    B[i][p] = c * bp - sn * bq; B[i][q] = sn * bp + c * bq;
+                    const double vp = V[i][p], vq = V[i][q];
+                    V[i][p] = c * vp - sn * vq; V[i][q] = sn * vp + c * vq;
+                }
+            }
+        if (off < 1e-17) break;
+    }
+    int order[3] = {0, 1, 2};
+    double nrm[3];
+    for (int j = 0; j < 3; ++j) nrm[j] = sqrt(B[0][j] * B[0][j] + B[1][j] * B[1][j] + B[2][j] * B[2][j]);
+    for (int a = 0; a < 2; ++a) for (int b = a + 1; b < 3; ++b) if (nrm[order[b]] > nrm[order[a]]) { int t = order[a]; order[a] = order[b]; order[b] = t; }
+    double Vs[3][3], Bs[3][3];
+    for (int j = 0; j < 3; ++j) { s[j] = nrm[order[j]]; for (int i = 0; i < 3; ++i) { Vs[i][j] = V[i][order[j]]; Bs[i][j] = B[i][order[j]]; } }
+    memcpy(V, Vs, sizeof(Vs));
+    if (!(s[0] > 0)) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) U[i][j] = i == j; return; }
+    for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) U[i][j] = s[j] > 0 ? Bs[i][j] / s[j] : 0.0;
+    if (s[1] <= 1e-12 * s[0]) {
+        double u0[3] = {U[0][0], U[1][0], U[2][0]};
+        int k = fabs(u0[0]) < fabs(u0[1]) ? (fabs(u0[0]) < fabs(u0[2]) ? 0 : 2) : (fabs(u0[1]) < fabs(u0[2]) ? 1 : 2);
+        double e[3] = {0, 0, 0};
+        e[k] = 1;
+        const double d = u0[k];
+        double v[3] = {e[0] - d * u0[0], e[1] - d * u0[1], e[2] - d * u0[2]};
+        const double n = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        for (int i = 0; i < 3; ++i) U[i][1] = v[i] / n;
+    }
+    if (s[2] <= 1e-12 * s[0]) {
+        U[0][2] = U[1][0] * U[2][1] - U[2][0] * U[1][1];
+        U[1][2] = U[2][0] * U[0][1] - U[0][0] * U[2][1];
+        U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
+    }
+}
+static double det3(const double m[3][3]) {
+    return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+static void solve6(const double A_[6][6], const double b_[6], double x[6]) {
+    double A[6][6], b[6], L[6][6] = {{0}}, D[6];
+    int perm[6];
+    for (int i = 0; i < 6; ++i) { perm[i] = i; b[i] = b_[i]; for (int j = 0; j < 6; ++j) A[i][j] = A_[i][j]; }
+    for (int k = 0; k < 6; ++k) {
+        int piv = k;
+        for (int i = k + 1; i < 6; ++i) if (fabs(A[i][i]) > fabs(A[piv][piv])) piv = i;
+        if (piv != k) {
+            for (int j = 0; j < 6; ++j) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
+            for (int i = 0; i < 6; ++i) { double t = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = t; }
+            for (int j = 0; j < k; ++j) { double t = L[k][j]; L[k][j] = L[piv][j]; L[piv][j] = t; }
+            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        }
+        D[k] = A[k][k];
+        L[k][k] = 1;
+        for (int i = k + 1; i < 6; ++i) L[i][k] = A[i][k] / D[k];
+        for (int i = k + 1; i < 6; ++i) for (int j = k + 1; j < 6; ++j) A[i][j] -= L[i][k] * D[k] * L[j][k];
+    }
+    double y[6], z[6];
+    for (int i = 0; i < 6; ++i) { double s = b[perm[i]]; for (int j = 0; j < i; ++j) s -= L[i][j] * y[j]; y[i] = s; }
+    for (int i = 0; i < 6; ++i) y[i] /= D[i];
+    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < 6; ++j) s -= L[j][i] * z[j]; z[i] = s; }
+    for (int i = 0; i < 6; ++i) x[perm[i]] = z[i];
+}
+static void mat4_identity(double T[16]) { memset(T, 0, 16 * sizeof(double)); T[0] = T[5] = T[10] = T[15] = 1; }
+static void mat4_mul(const double A[16], const double B[16], double C[16]) {
+    double R[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j]; R[4 * i + j] = s; }
+    memcpy(C, R, sizeof(R));
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+struct gsr_icp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    IcpGrid grid;
+    bool have_target = false, have_normals = false, have_source = false;
+    int64_t nt = 0, ns = 0, ns_global = 0;
+    double max_corr = 0;
+    DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
+    gsr_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms_build = 0, ms_iter = 0;
+    int n_iter_kernels = 0;
+    int max_cells = 1 << 24;
+    int nblocks = 1024;
+};
+
+namespace {
+
+int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, double k, double* acc, bool timed) {
+    if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
+    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
+    if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
+        return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
+    hipStream_t st = c->stream;
+    Xform X;
+    for (int i = 0; i < 12; ++i) X.m[i] = T[i];
+    int nb = c->nblocks;
+    if ((int64_t)nb * 256 > c->ns) nb = (int)((c->ns + 255) / 256);
+    if (nb < 1) nb = 1;
+    GSR_TRY(c->partials.reserve((size_t)nb * GSR_ICP_ACC_LEN * 8));
+    GSR_TRY(c->acc_dev.reserve(GSR_ICP_ACC_LEN * 8));
+    GSR_HIP(hipMemsetAsync(c->partials.p, 0, (size_t)nb * GSR_ICP_ACC_LEN * 8, st));
+    if (timed) GSR_HIP(hipEventRecord(c->e0, st));
+    const double mc2 = c->max_corr * c->max_corr;
+    if (kind == GSR_ICP_POINT_TO_POINT)
+        hipLaunchKernelGGL(k_icp_accumulate<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(),
+                           c->Tq.as<float4>(), (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
+    else
+        hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(),
+                           c->Tq.as<float4>(), c->Tn.as<double>(), mc2, loss, k, c->partials.as<double>());
+    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(64), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>());
+    if (timed) GSR_HIP(hipEventRecord(c->e1, st));
+    GSR_HIP(hipMemcpyAsync(acc, c->acc_dev.p, GSR_ICP_ACC_LEN * 8, hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipStreamSynchronize(st));
+    if (timed) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->e0, c->e1);
+        c->ms_iter += ms;
+        c->n_iter_kernels += 1;
+    }
+    if (c->allreduce) {
+        int32_t r = c->allreduce(acc, GSR_ICP_ACC_LEN, c->allreduce_user);
+        if (r != 0) return fail(GSR_E_INVALID, "icp: all-reduce callback returned %d", r);
+    }
+    return GSR_OK;
+}
+
+// estimator update from the reduced accumulators (Open3D TransformationEstimation*.ComputeTransformation)
+void estimate_update(const gsr_icp_ctx* c, int kind, const double* acc, double update[16]) {
+    mat4_identity(update);
+    const double n = acc[0];
+    if (!(n > 0)) return;                                   // no correspondences -> identity
+    if (kind == GSR_ICP_POINT_TO_POINT) {                   // Eigen::umeyama(src, dst, false)
+        const double mp[3] = {acc[2] / n, acc[3] / n, acc[4] / n}, mq[3] = {acc[5] / n, acc[6] / n, acc[7] / n};
+        double sigma[3][3], U[3][3], V[3][3], s[3];
+        for (int r = 0; r < 3; ++r)
+            for (int col = 0; col < 3; ++col) sigma[r][col] = acc[8 + 3 * col + r] / n - mq[r] * mp[col];   // dst x src^T
+        svd3(sigma, U, s, V);
+        double S[3] = {1, 1, 1};
+        if (det3(U) * det3(V) < 0) S[2] = -1;
+        double R[3][3];
+        for (int r = 0; r < 3; ++r)
+            for (int col = 0; col < 3; ++col) { double v = 0; for (int k = 0; k < 3; ++k) v += U[r][k] * S[k] * V[col][k]; R[r][col] = v; }
+        const double ctr[3] = {c->grid.cx, c->grid.cy, c->grid.cz};
+        for (int r = 0; r < 3; ++r) {
+            for (int col = 0; col < 3; ++col) update[4 * r + col] = R[r][col];
+            double Rp = 0;
+            for (int col = 0; col < 3; ++col) Rp += R[r][col] * (mp[col] + ctr[col]);
+            update[4 * r + 3] = mq[r] + ctr[r] - Rp;
+        }
+    } else {                                                 // x = solve(JTJ, -JTr); Rz(x2) Ry(x1) Rx(x0), t = x3..5
+        double JTJ[6][6], nb[6], x[6];
+        int t = 2;
+        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { JTJ[a][b] = acc[t]; JTJ[b][a] = acc[t]; ++t; }
+        for (int a = 0; a < 6; ++a) nb[a] = -acc[23 + a];
+        solve6(JTJ, nb, x);
+        const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
+        update[0] = cg * cb; update[1] = cg * sb * sa - sg * ca; update[2] = cg * sb * ca + sg * sa; update[3] = x[3];
+        update[4] = sg * cb; update[5] = sg * sb * sa + cg * ca; update[6] = sg * sb * ca - cg * sa; update[7] = x[4];
+        update[8] = -sb;     update[9] = cb * sa;                update[10] = cb * ca;               update[11] = x[5];
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
+    if (!out) return fail(GSR_E_INVALID, "gsr_icp_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GSR_E_NO_DEVICE, "gsr_icp_create: no HIP device visible (this backend has no CPU fallback)");
+    if (device < 0 || device >= ndev) return fail(GSR_E_INVALID, "gsr_icp_create: device %d out of range", device);
+    GSR_HIP(hipSetDevice(device));
+    gsr_icp_ctx* c = new gsr_icp_ctx();
+    c->device = device;
+    c->stream = (hipStream_t)stream;
+    if (hipEventCreate(&c->e0) != hipSuccess || hipEventCreate(&c->e1) != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate failed"); }
+    *out = c;
+    return GSR_OK;
+}
+
+int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
+    if (!c) return GSR_OK;
+    (void)hipSetDevice(c->device);
+    DevBuf* all[] = {&c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
+                     &c->src, &c->partials, &c->acc_dev, &c->rocprim_tmp, &c->corr_idx, &c->corr_d2};
+    for (DevBuf* b : all) b->release();
+    if (c->e0) (void)hipEventDestroy(c->e0);
+    if (c->e1) (void)hipEventDestroy(c->e1);
+    delete c;
+    return GSR_OK;
+}
+
+int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* normals, int64_t n, double max_corr, int32_t on_device) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_target: NULL context");
+    if (!(max_corr > 0)) return fail(GSR_E_PRECONDITION, "max_correspondence_distance must be > 0 (got %g)", max_corr);
+    if (n <= 0 || !xyz) return fail(GSR_E_PRECONDITION, "gsr_icp_set_target: empty target cloud");
+    if (n >= ((int64_t)1 << 31) - 1) return fail(GSR_E_INVALID, "gsr_icp_set_target: n too large");
+    GSR_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    GSR_HIP(hipEventRecord(c->e0, st));
+    const float* dxyz = xyz;
+    const double* dnrm = normals;
+    if (!on_device) {
+        GSR_TRY(c->stage_xyz.reserve((size_t)n * 12));
+        GSR_HIP(hipMemcpyAsync(c->stage_xyz.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, st));
+        dxyz = c->stage_xyz.as<float>();
+        if (normals) {
+            GSR_TRY(c->stage_nrm.reserve((size_t)n * 24));
+            GSR_HIP(hipMemcpyAsync(c->stage_nrm.p, normals, (size_t)n * 24, hipMemcpyHostToDevice, st));
+            dnrm = c->stage_nrm.as<double>();
+        }
+    }
+    // bounding box of the finite points
+    GSR_TRY(c->bbox.reserve(64));
+    {
+        float big = FLT_MAX, sml = -FLT_MAX;
+        unsigned ub, us;
+        memcpy(&ub, &big, 4); memcpy(&us, &sml, 4);
+        unsigned init[6] = {ub | 0x80000000u, ub | 0x80000000u, ub | 0x80000000u, ~us, ~us, ~us};
+        GSR_HIP(hipMemcpyAsync(c->bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
+    }
+    hipLaunchKernelGGL(k_icp_bbox, dim3(stride_grid(n)), dim3(256), 0, st, n, dxyz, c->bbox.as<unsigned>());
+    unsigned hb[6];
+    GSR_HIP(hipMemcpyAsync(hb, c->bbox.p, sizeof(hb), hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipStreamSynchronize(st));
+    double mn[3], mx[3];
+    for (int k = 0; k < 3; ++k) {
+        unsigned a = hb[k], b = hb[3 + k];
+        a = (a & 0x80000000u) ? (a & 0x7fffffffu) : ~a;
+        b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
+        float fa, fb;
+        memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
+        mn[k] = fa; mx[k] = fb;
+    }
+    IcpGrid g;
+    if (!(mx[0] >= mn[0])) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }
+    double cell = max_corr;
+    for (;;) {
+        double fx = floor((mx[0] - mn[0]) / cell) + 1, fy = floor((mx[1] - mn[1]) / cell) + 1, fz = floor((mx[2] - mn[2]) / cell) + 1;
+        if (fx * fy * fz <= (double)c->max_cells) { g.gx = (int)fx; g.gy = (int)fy; g.gz = (int)fz; break; }
+        cell *= 1.2599210498948732;
+    }
+    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+    g.c = cell; g.inv_c = 1.0 / cell;
+    g.cx = 0.5 * (mn[0] + mx[0]); g.cy = 0.5 * (mn[1] + mx[1]); g.cz = 0.5 * (mn[2] + mx[2]);
+    g.ncells = g.gx * g.gy * g.gz;
+    c->grid = g;
+    GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->order.reserve(n * 4));
+    hipLaunchKernelGGL(k_icp_keys, dim3(stride_grid(n)), dim3(256), 0, st, n, dxyz, g, c->keys.as<unsigned>(), c->idx.as<unsigned>());
+    int bits = 1;
+    while (bits < 32 && ((int64_t)1 << bits) < g.ncells) ++bits;
+    size_t bytes = 0;
+    GSR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+                                      c->order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
+    GSR_TRY(c->rocprim_tmp.reserve(bytes));
+    GSR_HIP(rocprim::radix_sort_pairs(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+                                      c->order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
+    GSR_TRY(c->cellStart.reserve(((size_t)g.ncells + 1) * 4));
+    hipLaunchKernelGGL(k_icp_cell_starts, dim3(stride_grid(n)), dim3(256), 0, st, n, c->skeys.as<unsigned>(), (int64_t)g.ncells, c->cellStart.as<int>());
+    GSR_TRY(c->Tq.reserve((size_t)n * 16));
+    if (normals) GSR_TRY(c->Tn.reserve((size_t)n * 24));
+    hipLaunchKernelGGL(k_icp_gather_target, dim3(stride_grid(n)), dim3(256), 0, st, n, c->order.as<unsigned>(), dxyz, dnrm,
+                       c->Tq.as<float4>(), normals ? c->Tn.as<double>() : (double*)nullptr);
+    GSR_HIP(hipEventRecord(c->e1, st));
+    GSR_HIP(hipStreamSynchronize(st));
+    (void)hipEventElapsedTime(&c->ms_build, c->e0, c->e1);
+    c->nt = n; c->max_corr = max_corr; c->have_target = true; c->have_normals = normals != nullptr;
+    return GSR_OK;
+}
+
+int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t on_device) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_source: NULL context");
+    if (n <= 0 || !xyz) return fail(GSR_E_PRECONDITION, "gsr_icp_set_source: empty source cloud");
+    GSR_HIP(hipSetDevice(c->device));
+    GSR_TRY(c->src.reserve((size_t)n * 12));
+    GSR_HIP(hipMemcpyAsync(c->src.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
+    GSR_HIP(hipStreamSynchronize(c->stream));
+    c->ns = n; c->have_source = true;
+    if (!c->allreduce) c->ns_global = n;
+    return GSR_OK;
+}
+
+int32_t gsr_icp_set_allreduce(gsr_icp_ctx* c, gsr_allreduce_fn fn, void* user, int64_t n_source_global) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_allreduce: NULL context");
+    c->allreduce = fn; c->allreduce_user = user;
+    c->ns_global = fn ? n_source_global : c->ns;
+    return GSR_OK;
+}
+
+int32_t gsr_icp_accumulate(gsr_icp_ctx* c, const double* T, int32_t kind, int32_t loss, double k, double* acc) {
+    if (!c || !T || !acc) return fail(GSR_E_INVALID, "gsr_icp_accumulate: NULL argument");
+    GSR_HIP(hipSetDevice(c->device));
+    return run_accumulate(c, T, kind, loss, k, acc, false);
+}
+
+int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int32_t loss, double k, double rel_fitness,
+                         double rel_rmse, int32_t max_iter, double* out_T, double* fitness, double* inlier_rmse, int32_t* iterations) {
+    if (!c || !init_T || !out_T) return fail(GSR_E_INVALID, "gsr_icp_register: NULL argument");
+    GSR_HIP(hipSetDevice(c->device));
+    c->ms_iter = 0; c->n_iter_kernels = 0;
+    double T[16], acc[GSR_ICP_ACC_LEN], update[16];
+    memcpy(T, init_T, sizeof(T));
+    GSR_TRY(run_accumulate(c, T, kind, loss, k, acc, true));
+    const double nsg = (double)(c->ns_global > 0 ? c->ns_global : c->ns);
+    double fit = acc[0] > 0 ? acc[0] / nsg : 0.0, rmse = acc[0] > 0 ? sqrt(acc[1] / acc[0]) : 0.0;
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        estimate_update(c, kind, acc, update);
+        mat4_mul(update, T, T);
+        GSR_TRY(run_accumulate(c, T, kind, loss, k, acc, true));
+        const double fit2 = acc[0] > 0 ? acc[0] / nsg : 0.0, rmse2 = acc[0] > 0 ? sqrt(acc[1] / acc[0]) : 0.0;
+        const bool stop = fabs(fit - fit2) < rel_fitness && fabs(rmse - rmse2) < rel_rmse;
+        fit = fit2; rmse = rmse2;
+        if (stop) { ++it; break; }
+    }
+    memcpy(out_T, T, sizeof(T));
+    if (fitness) *fitness = fit;
+    if (inlier_rmse) *inlier_rmse = rmse;
+    if (iterations) *iterations = it;
+    return GSR_OK;
+}
+
+int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, double* d2) {
+    if (!c || !T || !idx || !d2) return fail(GSR_E_INVALID, "gsr_icp_correspondences: NULL argument");
+    if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
+    GSR_HIP(hipSetDevice(c->device));
+    GSR_TRY(c->corr_idx.reserve((size_t)c->ns * 8)); GSR_TRY(c->corr_d2.reserve((size_t)c->ns * 8));
+    Xform X;
+    for (int i = 0; i < 12; ++i) X.m[i] = T[i];
+    hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->grid,
+                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->corr_idx.as<int64_t>(), c->corr_d2.as<double>());
+    GSR_HIP(hipMemcpyAsync(idx, c->corr_idx.p, (size_t)c->ns * 8, hipMemcpyDeviceToHost, c->stream));
+    GSR_HIP(hipMemcpyAsync(d2, c->corr_d2.p, (size_t)c->ns * 8, hipMemcpyDeviceToHost, c->stream));
+    GSR_HIP(hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+int32_t gsr_icp_get_timing(gsr_icp_ctx* c, float* out3) {
+    if (!c || !out3) return fail(GSR_E_INVALID, "gsr_icp_get_timing: NULL argument");
+    out3[0] = c->ms_build; out3[1] = c->ms_iter; out3[2] = (float)c->n_iter_kernels;
+    return GSR_OK;
+}
+
+int32_t gsr_normals_from_cov(const float* cov6, int64_t n, double* normals, int32_t on_device, int32_t device, void* stream) {
+    if (n < 0 || (n > 0 && (!cov6 || !normals))) return fail(GSR_E_INVALID, "gsr_normals_from_cov: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GSR_E_NO_DEVICE, "gsr_normals_from_cov: no HIP device visible (this backend has no CPU fallback)");
+    if (n == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (on_device) {
+        hipLaunchKernelGGL(k_normals_from_cov, dim3(stride_grid(n)), dim3(256), 0, st, n, cov6, normals);
+        GSR_HIP(hipStreamSynchronize(st));
+        return GSR_OK;
+    }
+    DevBuf in, out;
+    int32_t r = in.reserve((size_t)n * 24);
+    if (r == GSR_OK) r = out.reserve((size_t)n * 24);
+    if (r != GSR_OK) { in.release(); out.release(); return r; }
+    hipError_t e = hipMemcpyAsync(in.p, cov6, (size_t)n * 24, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_normals_from_cov, dim3(stride_grid(n)), dim3(256), 0, st, n, in.as<float>(), out.as<double>());
+        e = hipMemcpyAsync(normals, out.p, (size_t)n * 24, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    in.release(); out.release();
+    if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_normals_from_cov: %s", hipGetErrorString(e));
+    return GSR_OK;
+}
+
+}  // extern "C"

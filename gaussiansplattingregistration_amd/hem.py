@@ -1,0 +1,176 @@
+"""Host side of the HEM half: one ``HemMixture`` is one ``hem::Mixture`` of the reference
+(``src/cpp_ext/include/mixture.hpp:47-76``), living on one MI355X behind the C ABI.
+
+Arrays may be numpy arrays (staged through host memory by the library) or PyTorch-ROCm tensors on
+the context's device (zero-copy: only ``data_ptr()`` crosses the ABI).  PyTorch is plumbing here --
+device memory and streams -- all arithmetic is in the HIP kernels of ``csrc/hem.hip``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+try:  # torch is optional for host-array use
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+__all__ = ["HemMixture", "create_mixture"]
+
+
+def _is_tensor(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+def _prep(a, shape, device_index):
+    """-> (pointer, keepalive, on_device) for a float32 array of the given shape."""
+    if _is_tensor(a):
+        if a.is_cuda:
+            if a.device.index != device_index:
+                raise RuntimeError(f"tensor lives on {a.device}, context on cuda:{device_index}")
+            t = a.detach().to(torch.float32).reshape(shape).contiguous()
+            return t.data_ptr(), t, True
+        a = a.detach().cpu().numpy()
+    arr = np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(shape))
+    return arr.ctypes.data, arr, False
+
+
+class HemMixture:
+    """Hierarchical-EM mixture on the GPU.
+
+    Parameters follow ``hem::Mixture`` / ``GaussianMixtureParams`` (``src/params/merge_parameters.py:5-10``):
+    ``hem_reduction`` (rho), ``distance_delta``, ``color_delta``, ``decay_rate``.
+    ``rng_mode``: ``"glibc"`` replays the reference's libc ``rand()`` stream (parity), ``"hash"`` is a
+    counter-based device generator with the same distribution.
+    """
+
+    def __init__(self, hem_reduction=3.0, distance_delta=3.0, color_delta=2.5, decay_rate=1.0, device=0,
+                 stream=None, rng_mode="glibc", rng_seed=1, rng_skip=0):
+        self._L = _lib.load(require_device=True)
+        self.device = int(device)
+        if stream is None and torch is not None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        _lib.check(self._L.gsr_hem_create(C.byref(h), self.device, C.c_void_p(stream or 0)), "gsr_hem_create")
+        self._h = h
+        _lib.check(self._L.gsr_hem_set_params(h, hem_reduction, distance_delta, color_delta, decay_rate), "gsr_hem_set_params")
+        mode = {"glibc": _lib.GSR_RNG_GLIBC, "hash": _lib.GSR_RNG_HASH}[rng_mode]
+        _lib.check(self._L.gsr_hem_set_rng(h, mode, rng_seed, rng_skip), "gsr_hem_set_rng")
+        self.F = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gsr_hem_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- level 0 -----------------------------------------------------------------------------------
+    def set_level0(self, xyz, colors, opacities, covariance, features):
+        """``MixtureLevel.CreateMixtureLevel`` argument order (``mixturelevel.hpp:17-22``)."""
+        n = int(xyz.shape[0]) if hasattr(xyz, "shape") else len(xyz)
+        if n == 0:
+            F = 0
+        else:
+            f = features
+            F = int(f.shape[1]) if hasattr(f, "shape") and len(f.shape) == 2 else (len(f[0]) if len(f) else 0)
+        self.F = F
+        px, kx, dx = _prep(xyz, (n, 3), self.device)
+        pc, kc, dc = _prep(colors, (n, 3), self.device)
+        pv, kv, dv = _prep(covariance, (n, 6), self.device)
+        po, ko, do = _prep(opacities, (n,), self.device)
+        if F > 0:
+            ps, ks, ds = _prep(features, (n, F), self.device)
+        else:
+            ps, ks, ds = 0, None, dx
+        if len({dx, dc, dv, do, ds}) != 1:
+            raise RuntimeError("all level-0 arrays must live in the same place (all host or all device)")
+        if dx and torch is not None:
+            torch.cuda.current_stream(self.device).synchronize()
+        _lib.check(self._L.gsr_hem_set_level0(self._h, px, pc, pv, po, ps, n, F, 1 if dx else 0), "gsr_hem_set_level0")
+        del kx, kc, kv, ko, ks
+
+    def set_state(self, parent_mask=None, weight=None):
+        pm = None if parent_mask is None else np.ascontiguousarray(parent_mask, dtype=np.uint8)
+        w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float32)
+        _lib.check(self._L.gsr_hem_set_state(self._h, None if pm is None else pm.ctypes.data,
+                                             None if w is None else w.ctypes.data), "gsr_hem_set_state")
+
+    # -- levels ------------------------------------------------------------------------------------
+    def run_level(self):
+        """One ``createClusterLevel``.  Returns ``(n_out, n_dropped)``."""
+        n_out, n_drop = C.c_int64(0), C.c_int64(0)
+        _lib.check(self._L.gsr_hem_run_level(self._h, C.byref(n_out), C.byref(n_drop)), "gsr_hem_run_level")
+        return int(n_out.value), int(n_drop.value)
+
+    @property
+    def size(self):
+        n, F = C.c_int64(0), C.c_int32(0)
+        _lib.check(self._L.gsr_hem_level_size(self._h, C.byref(n), C.byref(F)), "gsr_hem_level_size")
+        return int(n.value)
+
+    def get_level(self, as_torch=False, with_state=False):
+        """Current level as a dict of arrays: xyz, color, cov6, opacity, sh (+ weight, is_parent)."""
+        n, F = self.size, self.F
+        if as_torch:
+            dev = torch.device("cuda", self.device)
+            out = {"xyz": torch.empty((n, 3), dtype=torch.float32, device=dev),
+                   "color": torch.empty((n, 3), dtype=torch.float32, device=dev),
+                   "cov6": torch.empty((n, 6), dtype=torch.float32, device=dev),
+                   "opacity": torch.empty((n,), dtype=torch.float32, device=dev),
+                   "sh": torch.empty((n, F), dtype=torch.float32, device=dev)}
+            if with_state:
+                out["weight"] = torch.empty((n,), dtype=torch.float32, device=dev)
+                out["is_parent"] = torch.empty((n,), dtype=torch.uint8, device=dev)
+            ptr = lambda k: out[k].data_ptr() if k in out else None
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            out = {"xyz": np.empty((n, 3), np.float32), "color": np.empty((n, 3), np.float32),
+                   "cov6": np.empty((n, 6), np.float32), "opacity": np.empty((n,), np.float32),
+                   "sh": np.empty((n, F), np.float32)}
+            if with_state:
+                out["weight"] = np.empty((n,), np.float32)
+                out["is_parent"] = np.empty((n,), np.uint8)
+            ptr = lambda k: out[k].ctypes.data if k in out else None
+        _lib.check(self._L.gsr_hem_get_level(self._h, ptr("xyz"), ptr("color"), ptr("cov6"), ptr("opacity"),
+                                             ptr("sh") if F > 0 else None, ptr("weight"), ptr("is_parent"),
+                                             1 if as_torch else 0), "gsr_hem_get_level")
+        return out
+
+    def stats(self):
+        s = (C.c_int64 * 8)()
+        _lib.check(self._L.gsr_hem_get_stats(self._h, s), "gsr_hem_get_stats")
+        t = (C.c_float * 6)()
+        _lib.check(self._L.gsr_hem_get_phase_ms(self._h, t), "gsr_hem_get_phase_ms")
+        pos = C.c_uint64(0)
+        _lib.check(self._L.gsr_hem_get_rng_position(self._h, C.byref(pos)), "gsr_hem_get_rng_position")
+        return {"parents": s[0], "pairs": s[1], "orphans": s[2], "dropped": s[3], "candidates": s[4], "cells": s[5],
+                "n_in": s[6], "n_out": s[7], "ms_grid": t[0], "ms_select": t[1], "ms_sumlw": t[2], "ms_mstep": t[3],
+                "ms_flags": t[4], "ms_level": t[5], "rng_draws": int(pos.value)}
+
+
+def create_mixture(cloud: dict, cluster_level: int, hem_reduction=3.0, distance_delta=3.0, color_delta=2.5,
+                   decay_rate=1.0, device=0, as_torch=False, rng_mode="glibc", rng_seed=1, rng_skip=0):
+    """``MixtureCreator.CreateMixture`` on a dict cloud: returns (levels, stats), level 0 dropped."""
+    with HemMixture(hem_reduction, distance_delta, color_delta, decay_rate, device=device, rng_mode=rng_mode,
+                    rng_seed=rng_seed, rng_skip=rng_skip) as m:
+        m.set_level0(cloud["xyz"], cloud["color"], cloud["opacity"], cloud["cov6"], cloud["sh"])
+        levels, stats = [], []
+        for _ in range(int(cluster_level)):
+            m.run_level()
+            stats.append(m.stats())
+            levels.append(m.get_level(as_torch=as_torch))
+        return levels, stats

@@ -1,0 +1,183 @@
+"""Host side of the ICP half: ``registration_icp`` semantics of Open3D 0.16.0 (what the reference's
+``do_icp_registration`` reaches, ``src/utils/local_registration_util.py:76-100``) on one MI355X, with
+an optional ``torch.distributed`` all-reduce of the accumulator vector for multi-GPU source splits.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+try:
+    import torch
+except Exception:  # pragma: no cover
+    torch = None
+
+__all__ = ["IcpContext", "registration_icp_arrays", "normals_from_cov", "RegistrationResult"]
+
+KIND_POINT_TO_POINT = 0
+KIND_POINT_TO_PLANE = 1
+LOSS_L2, LOSS_TUKEY, LOSS_CAUCHY, LOSS_GM, LOSS_HUBER = 0, 1, 2, 3, 4
+
+
+class RegistrationResult:
+    """The three fields the reference's callers read (``registration_controller.py:145-148``)."""
+
+    def __init__(self, transformation, fitness, inlier_rmse, iterations=0, correspondence_set=None):
+        self.transformation = transformation
+        self.fitness = fitness
+        self.inlier_rmse = inlier_rmse
+        self.iterations = iterations
+        self.correspondence_set = correspondence_set
+
+    def __repr__(self):
+        return (f"RegistrationResult with fitness={self.fitness:e}, inlier_rmse={self.inlier_rmse:e}, "
+                f"and iterations={self.iterations}")
+
+
+def _is_tensor(a):
+    return torch is not None and isinstance(a, torch.Tensor)
+
+
+def _prep(a, shape, dtype, device_index):
+    tdt = {np.float32: "float32", np.float64: "float64"}[dtype]
+    if _is_tensor(a):
+        if a.is_cuda:
+            if a.device.index != device_index:
+                raise RuntimeError(f"tensor lives on {a.device}, context on cuda:{device_index}")
+            t = a.detach().to(getattr(torch, tdt)).reshape(shape).contiguous()
+            return t.data_ptr(), t, True
+        a = a.detach().cpu().numpy()
+    arr = np.ascontiguousarray(np.asarray(a, dtype=dtype).reshape(shape))
+    return arr.ctypes.data, arr, False
+
+
+class IcpContext:
+    """Target index + source buffer on one GPU."""
+
+    def __init__(self, device=0, stream=None):
+        self._L = _lib.load(require_device=True)
+        self.device = int(device)
+        if stream is None and torch is not None and torch.cuda.is_available():
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+        h = C.c_void_p()
+        _lib.check(self._L.gsr_icp_create(C.byref(h), self.device, C.c_void_p(stream or 0)), "gsr_icp_create")
+        self._h = h
+        self._cb = None
+        self.n_source = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.gsr_icp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def _sync_torch(self):
+        if torch is not None and torch.cuda.is_available():
+            torch.cuda.current_stream(self.device).synchronize()
+
+    def set_target(self, xyz, normals, max_corr):
+        n = int(xyz.shape[0])
+        px, kx, dx = _prep(xyz, (n, 3), np.float32, self.device)
+        pn, kn, dn = (None, None, dx) if normals is None else _prep(normals, (n, 3), np.float64, self.device)
+        if dn != dx:
+            raise RuntimeError("target points and normals must live in the same place (both host or both device)")
+        if dx:
+            self._sync_torch()
+        _lib.check(self._L.gsr_icp_set_target(self._h, px, pn, n, float(max_corr), 1 if dx else 0), "gsr_icp_set_target")
+
+    def set_source(self, xyz):
+        n = int(xyz.shape[0])
+        px, kx, dx = _prep(xyz, (n, 3), np.float32, self.device)
+        if dx:
+            self._sync_torch()
+        _lib.check(self._L.gsr_icp_set_source(self._h, px, n, 1 if dx else 0), "gsr_icp_set_source")
+        self.n_source = n
+
+    def set_allreduce(self, fn, n_source_global):
+        """``fn(numpy float64[32]) -> None`` must sum the vector over all ranks in place."""
+        if fn is None:
+            self._cb = None
+            _lib.check(self._L.gsr_icp_set_allreduce(self._h, _lib.ALLREDUCE_FN(), None, 0), "gsr_icp_set_allreduce")
+            return
+
+        def _tramp(buf, length, _user):
+            try:
+                arr = np.ctypeslib.as_array(buf, shape=(length,))
+                fn(arr)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb = _lib.ALLREDUCE_FN(_tramp)
+        _lib.check(self._L.gsr_icp_set_allreduce(self._h, self._cb, None, int(n_source_global)), "gsr_icp_set_allreduce")
+
+    def accumulate(self, T, kind=0, loss=0, k=0.0):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+        acc = np.zeros(_lib.GSR_ICP_ACC_LEN, np.float64)
+        _lib.check(self._L.gsr_icp_accumulate(self._h, T.ctypes.data, kind, loss, float(k), acc.ctypes.data), "gsr_icp_accumulate")
+        return acc
+
+    def register(self, init=None, kind=0, loss=0, k=0.0, rel_fitness=1e-6, rel_rmse=1e-6, max_iter=30):
+        init = np.eye(4) if init is None else np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
+        T = np.empty((4, 4), np.float64)
+        fit, rmse, it = C.c_double(0), C.c_double(0), C.c_int32(0)
+        _lib.check(self._L.gsr_icp_register(self._h, init.ctypes.data, kind, loss, float(k), float(rel_fitness), float(rel_rmse),
+                                            int(max_iter), T.ctypes.data, C.byref(fit), C.byref(rmse), C.byref(it)),
+                   "gsr_icp_register")
+        return {"transformation": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iterations": int(it.value)}
+
+    def correspondences(self, T):
+        T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
+        idx = np.empty(self.n_source, np.int64)
+        d2 = np.empty(self.n_source, np.float64)
+        _lib.check(self._L.gsr_icp_correspondences(self._h, T.ctypes.data, idx.ctypes.data, d2.ctypes.data), "gsr_icp_correspondences")
+        return idx, d2
+
+    def timing(self):
+        t = (C.c_float * 3)()
+        _lib.check(self._L.gsr_icp_get_timing(self._h, t), "gsr_icp_get_timing")
+        return {"ms_build": t[0], "ms_iters": t[1], "iter_kernels": int(t[2])}
+
+
+def registration_icp_arrays(src_xyz, tgt_xyz, tgt_normals, init, kind=0, loss=0, k=0.0, max_corr=1.0, rel_fitness=1e-6,
+                            rel_rmse=1e-6, max_iter=30, device=0):
+    """One ``registration_icp`` on raw arrays; returns dict(transformation, fitness, inlier_rmse, iterations)."""
+    with IcpContext(device=device) as c:
+        c.set_target(tgt_xyz, tgt_normals, max_corr)
+        c.set_source(src_xyz)
+        out = c.register(init, kind, loss, k, rel_fitness, rel_rmse, max_iter)
+        out.update(c.timing())
+        return out
+
+
+def normals_from_cov(cov6, device=0):
+    """float64 unit normals (n,3) = smallest-eigenvalue eigenvector of each splat covariance."""
+    L = _lib.load(require_device=True)
+    n = int(cov6.shape[0])
+    if _is_tensor(cov6) and cov6.is_cuda:
+        t = cov6.detach().to(torch.float32).reshape(n, 6).contiguous()
+        out = torch.empty((n, 3), dtype=torch.float64, device=t.device)
+        torch.cuda.current_stream(t.device.index).synchronize()
+        _lib.check(L.gsr_normals_from_cov(t.data_ptr(), n, out.data_ptr(), 1, t.device.index,
+                                          C.c_void_p(torch.cuda.current_stream(t.device.index).cuda_stream)), "gsr_normals_from_cov")
+        return out
+    a = np.ascontiguousarray(cov6.detach().cpu().numpy() if _is_tensor(cov6) else cov6, dtype=np.float32).reshape(n, 6)
+    out = np.empty((n, 3), np.float64)
+    _lib.check(L.gsr_normals_from_cov(a.ctypes.data, n, out.ctypes.data, 0, int(device), None), "gsr_normals_from_cov")
+    return out

@@ -1,0 +1,165 @@
+/* include/gsr_hip.h -- C ABI of the MI355X (gfx950) registration backend, libgsr_hip.so.
+ *
+ * Drop-in boundary for the ONE data-parallel hot path of erikszasz/GaussianSplattingRegistration:
+ * the Hierarchical-EM Gaussian-mixture downsampler and the per-iteration ICP step.  Plain pointers
+ * and sizes only -- no torch, no C++ types.  Every entry point returns 0 on success or a negative
+ * GSR_E_* code; gsr_last_error() returns the thread-local message of the last failure.
+ *
+ * Which reference interface each group replaces (paths relative to the reference repository):
+ *
+ *   gsr_hem_*   replaces the pybind11 module `mixture_bind` (src/cpp_ext/mixture_bind.cpp:11-61):
+ *                 MixtureLevel.CreateMixtureLevel(xyz, colors, opacities, covariance, features)
+ *                     src/cpp_ext/include/mixturelevel.hpp:17-22, src/mixturelevel.cpp:14-28  -> gsr_hem_set_level0
+ *                 MixtureCreator.CreateMixture(clusterLevel, hemReduction, distanceDelta, colorDelta, decayRate, level)
+ *                     src/cpp_ext/mixture_wrapper.hpp:10, mixture_wrapper.cpp:10-18              -> gsr_hem_create + gsr_hem_run_level x clusterLevel
+ *                 MixtureLevel.CreatePythonLists(level)  src/mixturelevel.cpp:30-70             -> gsr_hem_get_level
+ *               (arithmetic: src/cpp_ext/src/mixture.cpp:54-64,66-285,287-333; include/gaussian.hpp:82-114;
+ *                include/vec.hpp:736-768,863-872; src/pointindex.cpp:55-143; include/base.hpp:24-27,44-56)
+ *
+ *   gsr_icp_*   replaces what src/utils/local_registration_util.py:76-100 (do_icp_registration) reaches
+ *               through open3d==0.16.0 (requirements.txt:3): registration_icp with
+ *               TransformationEstimationPointToPoint / PointToPlane(loss) (:39-51, :58-73) and
+ *               ICPConvergenceCriteria (:54-55).
+ *
+ *   gsr_normals_from_cov  replaces the estimate_normals() call on a cloud whose covariances were set
+ *               from the splat covariances (src/utils/point_cloud_converter.py:40-43).
+ *
+ * Memory: every array argument is row-major and contiguous.  `on_device != 0` means the pointer is a
+ * HIP device pointer on the context's device (e.g. a PyTorch-ROCm tensor's data_ptr()); otherwise it
+ * is host memory and the library stages it.  The caller owns everything it passes and receives; the
+ * library owns only its context and workspace, released by the matching *_destroy.
+ * Contexts are single-owner and not re-entrant; different contexts may run concurrently on
+ * different streams / GPUs.  `stream` is a hipStream_t (NULL = the default stream).
+ */
+#ifndef GSR_HIP_H
+#define GSR_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_OK              0
+#define GSR_E_INVALID      -1   /* bad argument (NULL handle, negative size, wrong state) */
+#define GSR_E_HIP          -2   /* a HIP runtime call failed (message carries hipGetErrorString) */
+#define GSR_E_NO_DEVICE    -3   /* no gfx950 device visible: the product path has no CPU fallback */
+#define GSR_E_PRECONDITION -4   /* ICP preconditions: max_corr <= 0, point-to-plane without normals, empty cloud */
+
+const char* gsr_last_error(void);
+/* "gsr_hip <version> gfx950" */
+const char* gsr_version(void);
+/* Number of visible HIP devices (0 when none; never fails). */
+int32_t gsr_device_count(void);
+
+/* ------------------------------------------------------------------------------------------- HEM */
+
+typedef struct gsr_hem_ctx gsr_hem_ctx;
+
+/* RNG that draws the parent flags (mixture.cpp:256-259,330):
+ *   GSR_RNG_GLIBC  glibc TYPE_3 rand() model, eight rand()%16 nibbles per flag (base.hpp:44-56);
+ *                  seed 1 + skip 0 replays a fresh reference process.  Parity mode (default).
+ *   GSR_RNG_HASH   counter-based hash of (seed, draw index): same distribution, not the same stream. */
+#define GSR_RNG_GLIBC 0
+#define GSR_RNG_HASH  1
+
+int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream);
+int32_t gsr_hem_destroy(gsr_hem_ctx* ctx);
+
+/* hemReduction, distanceDelta, colorDelta, decayRate -- src/params/merge_parameters.py:5-10 */
+int32_t gsr_hem_set_params(gsr_hem_ctx* ctx, float hem_reduction, float distance_delta,
+                           float color_delta, float decay_rate);
+/* rng_skip = number of hem::rand() values already consumed from the stream (lets a second cloud
+ * continue the first cloud's stream as qt_gaussian_mixture.py:55,79 does). */
+int32_t gsr_hem_set_rng(gsr_hem_ctx* ctx, int32_t mode, uint32_t seed, uint64_t rng_skip);
+int32_t gsr_hem_get_rng_position(gsr_hem_ctx* ctx, uint64_t* draws);
+
+/* Level 0: xyz[n*3], color[n*3] (SH DC), cov6[n*6] (xx,xy,xz,yy,yz,zz), opacity[n] (RAW logit),
+ * sh[n*F] (SH rest, coefficient-major); float32.  Sets weight = 1 and draws the n initial parent
+ * flags (Mixture::initMixture, mixture.cpp:287-333).  F may be 0 (sh may then be NULL). */
+int32_t gsr_hem_set_level0(gsr_hem_ctx* ctx, const float* xyz, const float* color, const float* cov6,
+                           const float* opacity, const float* sh, int64_t n, int32_t F, int32_t on_device);
+/* Override internal per-component state of the CURRENT level (either may be NULL):
+ * parent_mask[n] (0/1 bytes, consumes no RNG draws) and weight[n].  Host pointers. */
+int32_t gsr_hem_set_state(gsr_hem_ctx* ctx, const uint8_t* parent_mask, const float* weight);
+
+/* One clustering level on the current level (Mixture::createClusterLevel, mixture.cpp:66-285).
+ * n_out = components of the new level (after the validity erase); n_dropped = components erased by
+ * it (the reference prints these to cerr, mixture.cpp:270-274).  The new level becomes current. */
+int32_t gsr_hem_run_level(gsr_hem_ctx* ctx, int64_t* n_out, int64_t* n_dropped);
+
+int32_t gsr_hem_level_size(gsr_hem_ctx* ctx, int64_t* n, int32_t* F);
+/* Copy the current level into caller buffers (any may be NULL).  weight / is_parent are internal
+ * state the reference never exports (mixture.hpp:33-44); offered for single-level checks. */
+int32_t gsr_hem_get_level(gsr_hem_ctx* ctx, float* xyz, float* color, float* cov6, float* opacity,
+                          float* sh, float* weight, uint8_t* is_parent, int32_t on_device);
+
+/* Counters of the most recent gsr_hem_run_level:
+ *  [0] parents  [1] accepted (parent,child) pairs  [2] orphans  [3] dropped  [4] candidates scanned
+ *  [5] grid cells  [6] components in  [7] components out */
+int32_t gsr_hem_get_stats(gsr_hem_ctx* ctx, int64_t* out8);
+/* Device time of the phases of the most recent level, in milliseconds (hipEvent pairs on the
+ * context's stream):  [0] prep+grid  [1] selection (count+fill)  [2] per-child sums
+ * [3] M-step + orphans  [4] flags+validity  [5] whole level */
+int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* ctx, float* out6);
+
+/* ------------------------------------------------------------------------------------------- ICP */
+
+typedef struct gsr_icp_ctx gsr_icp_ctx;
+
+#define GSR_ICP_POINT_TO_POINT 0   /* LocalRegistrationType.ICP_Point_To_Point, local_registration_util.py:33 */
+#define GSR_ICP_POINT_TO_PLANE 1   /* LocalRegistrationType.ICP_Point_To_Plane, :34 */
+
+#define GSR_LOSS_L2     0          /* KernelLossFunctionType.Loss_None or k == 0, :63-64 */
+#define GSR_LOSS_TUKEY  1
+#define GSR_LOSS_CAUCHY 2
+#define GSR_LOSS_GM     3
+#define GSR_LOSS_HUBER  4
+
+int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream);
+int32_t gsr_icp_destroy(gsr_icp_ctx* ctx);
+
+/* Target cloud: xyz[n*3] float32 (the reference widens the float32 splat positions to float64,
+ * point_cloud_converter.py:33), normals[n*3] float64 or NULL (Open3D normals are float64).  Builds
+ * the uniform-grid index used for the nearest-neighbour search; cell edge >= max_corr, so the 27
+ * cells around a query bound the search. */
+int32_t gsr_icp_set_target(gsr_icp_ctx* ctx, const float* xyz, const double* normals, int64_t n,
+                           double max_corr, int32_t on_device);
+int32_t gsr_icp_set_source(gsr_icp_ctx* ctx, const float* xyz, int64_t n, int32_t on_device);
+/* Multi-GPU source split: this rank owns source points, the target is replicated.  `allreduce` is
+ * called once per correspondence evaluation with the rank-local accumulator vector (float64[len],
+ * host memory) and must replace it by the element-wise sum over ranks (RCCL/gloo all-reduce in the
+ * host language).  NULL = single rank.  n_source_global = source points over all ranks. */
+typedef int32_t (*gsr_allreduce_fn)(double* buf, int32_t len, void* user);
+int32_t gsr_icp_set_allreduce(gsr_icp_ctx* ctx, gsr_allreduce_fn fn, void* user, int64_t n_source_global);
+
+/* One correspondence evaluation + accumulator reduction at transform T (row-major 4x4 float64):
+ * acc[0]=count, acc[1]=sum d^2, then for point-to-point acc[2..4]=sum p, [5..7]=sum q, [8..16]=sum p q^T
+ * (p = transformed source, q = matched target, both relative to the target-bbox centre);
+ * for point-to-plane acc[2..22]=upper triangle of J^T w J (row-major), [23..28]=J^T w r, [29]=sum r^2.
+ * len(acc) = GSR_ICP_ACC_LEN.  This is the "hot loop" exposed for tests and for RCCL all-reduce. */
+#define GSR_ICP_ACC_LEN 32
+int32_t gsr_icp_accumulate(gsr_icp_ctx* ctx, const double* T, int32_t kind, int32_t loss, double k,
+                           double* acc);
+
+/* registration_icp: iterate until |dfitness| < rel_fitness && |drmse| < rel_rmse or max_iter.
+ * out_T row-major 4x4 float64.  iterations = estimator updates applied. */
+int32_t gsr_icp_register(gsr_icp_ctx* ctx, const double* init_T, int32_t kind, int32_t loss, double k,
+                         double rel_fitness, double rel_rmse, int32_t max_iter,
+                         double* out_T, double* fitness, double* inlier_rmse, int32_t* iterations);
+/* Nearest target index (or -1) and squared distance for every source point at transform T. */
+int32_t gsr_icp_correspondences(gsr_icp_ctx* ctx, const double* T, int64_t* idx, double* d2);
+/* Device milliseconds: [0] target index build, [1] all correspondence/accumulate kernels of the last
+ * gsr_icp_register, [2] their count. */
+int32_t gsr_icp_get_timing(gsr_icp_ctx* ctx, float* out3);
+
+/* Normals = unit eigenvector of the smallest eigenvalue of each 3x3 splat covariance, computed in
+ * float64 from the float32 covariance widened to float64 (as Open3D does on the converted cloud);
+ * a zero vector becomes (0,0,1).  cov6[n*6] float32 in, normals[n*3] float64 out. */
+int32_t gsr_normals_from_cov(const float* cov6, int64_t n, double* normals, int32_t on_device,
+                             int32_t device, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSR_HIP_H */
