@@ -54,6 +54,10 @@ SIGNATURES = {
     "gsr_icp_correspondences": (_i32, [_vp, _vp, _vp, _vp]),
     "gsr_icp_get_timing": (_i32, [_vp, C.POINTER(_f32)]),
     "gsr_normals_from_cov": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
+    "gsr_icp_solve": (_i32, [_vp, _i32, _vp, _vp]),
+    "gsr_icp_get_centre": (_i32, [_vp, _vp]),
+    "gsr_debug_logf": (_i32, [_vp, _i64, _vp, _i32]),
+    "gsr_debug_kld": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32]),
 }
 
 _lib = None

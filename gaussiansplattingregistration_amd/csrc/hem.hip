@@ -599,6 +599,21 @@ __global__ __launch_bounds__(256) void k_compact_bytes(int64_t n, const int* __r
         if (keep[i]) dst[pos[i]] = src[i];
 }
 
+// test hooks: the exact device functions the selection kernel uses
+__global__ void k_debug_logf(int64_t n, const float* __restrict__ x, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = glibc_logf(x[i]);
+}
+__global__ void k_debug_kld(int64_t n, const float* __restrict__ cm, const float* __restrict__ cc, const float* __restrict__ pm,
+                            const float* __restrict__ pc, float* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const f3 a = {cm[3 * i], cm[3 * i + 1], cm[3 * i + 2]}, b = {pm[3 * i], pm[3 * i + 1], pm[3 * i + 2]};
+        const s6 ca = {cc[6 * i], cc[6 * i + 1], cc[6 * i + 2], cc[6 * i + 3], cc[6 * i + 4], cc[6 * i + 5]};
+        const s6 cb = {pc[6 * i], pc[6 * i + 1], pc[6 * i + 2], pc[6 * i + 3], pc[6 * i + 4], pc[6 * i + 5]};
+        const float dp = det6(cb);
+        out[i] = kld6(sub3(a, b), ca, det6(ca), inverse6(cb, dp), dp);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -642,8 +657,9 @@ struct gsr_hem_ctx {
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
     std::vector<unsigned> h_draws;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    float phase_ms[6] = {0, 0, 0, 0, 0, 0};
-    hipEvent_t ev[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of k_select<COUNT> and k_select<FILL>
     float cell_target = 8.0f;
     int max_cells = 1 << 24;
 };
@@ -729,8 +745,12 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     gsr_hem_ctx* c = new gsr_hem_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < 8; ++i) {
         hipError_t e = hipEventCreate(&c->ev[i]);
+        if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+    }
+    for (int i = 0; i < 4; ++i) {
+        hipError_t e = hipEventCreate(&c->evk[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
@@ -747,7 +767,8 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
-    for (int i = 0; i < 7; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+    for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
     delete c;
     return GSR_OK;
 }
@@ -840,9 +861,9 @@ int32_t gsr_hem_get_stats(gsr_hem_ctx* c, int64_t* out8) {
     memcpy(out8, c->stats, sizeof(c->stats));
     return GSR_OK;
 }
-int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out6) {
-    if (!c || !out6) return fail(GSR_E_INVALID, "gsr_hem_get_phase_ms: NULL argument");
-    memcpy(out6, c->phase_ms, sizeof(c->phase_ms));
+int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out8) {
+    if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_phase_ms: NULL argument");
+    memcpy(out8, c->phase_ms, sizeof(c->phase_ms));
     return GSR_OK;
 }
 
@@ -927,7 +948,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.cand_total = c->counters.as<unsigned long long>();
     int64_t M = 0;
     if (P > 0) {
+        GSR_HIP(hipEventRecord(c->evk[0], st));
         hipLaunchKernelGGL(k_select<false>, dim3(ceil_div(P, 4)), blk, 0, st, sa);
+        GSR_HIP(hipEventRecord(c->evk[1], st));
         // offsets: widen counts to int64 and scan
         int64_t* cnt64 = c->scratch.as<int64_t>();
         {
@@ -951,7 +974,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
     if (M > 0) {
         sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
+        GSR_HIP(hipEventRecord(c->evk[2], st));
         hipLaunchKernelGGL(k_select<true>, dim3(ceil_div(P, 4)), blk, 0, st, sa);
+        GSR_HIP(hipEventRecord(c->evk[3], st));
     }
     GSR_HIP(hipEventRecord(c->ev[2], st));
 
@@ -1042,8 +1067,58 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     c->stats[7] = c->cur.n;
     for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&c->phase_ms[5], c->ev[0], c->ev[5]);
+    c->phase_ms[6] = c->phase_ms[7] = 0.0f;
+    if (P > 0) (void)hipEventElapsedTime(&c->phase_ms[6], c->evk[0], c->evk[1]);
+    if (M > 0) (void)hipEventElapsedTime(&c->phase_ms[7], c->evk[2], c->evk[3]);
     if (n_out) *n_out = c->cur.n;
     if (n_dropped) *n_dropped = dropped;
+    return GSR_OK;
+}
+
+int32_t gsr_debug_logf(const float* x, int64_t n, float* out, int32_t device) {
+    if (n < 0 || (n > 0 && (!x || !out))) return fail(GSR_E_INVALID, "gsr_debug_logf: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GSR_E_NO_DEVICE, "gsr_debug_logf: no HIP device visible");
+    if (n == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    DevBuf a, b;
+    int32_t r = a.reserve((size_t)n * 4);
+    if (r == GSR_OK) r = b.reserve((size_t)n * 4);
+    hipError_t e = hipSuccess;
+    if (r == GSR_OK) {
+        e = hipMemcpy(a.p, x, (size_t)n * 4, hipMemcpyHostToDevice);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_debug_logf, dim3(stride_grid(n)), dim3(256), 0, nullptr, n, a.as<float>(), b.as<float>());
+            e = hipMemcpy(out, b.p, (size_t)n * 4, hipMemcpyDeviceToHost);
+        }
+    }
+    a.release(); b.release();
+    if (r != GSR_OK) return r;
+    if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_debug_logf: %s", hipGetErrorString(e));
+    return GSR_OK;
+}
+
+int32_t gsr_debug_kld(const float* cm, const float* cc, const float* pm, const float* pc, int64_t n, float* out, int32_t device) {
+    if (n < 0 || (n > 0 && (!cm || !cc || !pm || !pc || !out))) return fail(GSR_E_INVALID, "gsr_debug_kld: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GSR_E_NO_DEVICE, "gsr_debug_kld: no HIP device visible");
+    if (n == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    DevBuf b[5];
+    const size_t sz[5] = {(size_t)n * 12, (size_t)n * 24, (size_t)n * 12, (size_t)n * 24, (size_t)n * 4};
+    const float* src[4] = {cm, cc, pm, pc};
+    int32_t r = GSR_OK;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 5 && r == GSR_OK; ++i) r = b[i].reserve(sz[i]);
+    for (int i = 0; i < 4 && r == GSR_OK && e == hipSuccess; ++i) e = hipMemcpy(b[i].p, src[i], sz[i], hipMemcpyHostToDevice);
+    if (r == GSR_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_kld, dim3(stride_grid(n)), dim3(256), 0, nullptr, n, b[0].as<float>(), b[1].as<float>(), b[2].as<float>(),
+                           b[3].as<float>(), b[4].as<float>());
+        e = hipMemcpy(out, b[4].p, sz[4], hipMemcpyDeviceToHost);
+    }
+    for (int i = 0; i < 5; ++i) b[i].release();
+    if (r != GSR_OK) return r;
+    if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_debug_kld: %s", hipGetErrorString(e));
     return GSR_OK;
 }
 

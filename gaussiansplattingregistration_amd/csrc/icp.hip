@@ -480,7 +480,7 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
 }
 
 // estimator update from the reduced accumulators (Open3D TransformationEstimation*.ComputeTransformation)
-void estimate_update(const gsr_icp_ctx* c, int kind, const double* acc, double update[16]) {
+void estimate_update(const double ctr[3], int kind, const double* acc, double update[16]) {
     mat4_identity(update);
     const double n = acc[0];
     if (!(n > 0)) return;                                   // no correspondences -> identity
@@ -495,7 +495,6 @@ void estimate_update(const gsr_icp_ctx* c, int kind, const double* acc, double u
         double R[3][3];
         for (int r = 0; r < 3; ++r)
             for (int col = 0; col < 3; ++col) { double v = 0; for (int k = 0; k < 3; ++k) v += U[r][k] * S[k] * V[col][k]; R[r][col] = v; }
-        const double ctr[3] = {c->grid.cx, c->grid.cy, c->grid.cz};
         for (int r = 0; r < 3; ++r) {
             for (int col = 0; col < 3; ++col) update[4 * r + col] = R[r][col];
             double Rp = 0;
@@ -662,7 +661,8 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
     double fit = acc[0] > 0 ? acc[0] / nsg : 0.0, rmse = acc[0] > 0 ? sqrt(acc[1] / acc[0]) : 0.0;
     int it = 0;
     for (; it < max_iter; ++it) {
-        estimate_update(c, kind, acc, update);
+        const double ctr[3] = {c->grid.cx, c->grid.cy, c->grid.cz};
+        estimate_update(ctr, kind, acc, update);
         mat4_mul(update, T, T);
         GSR_TRY(run_accumulate(c, T, kind, loss, k, acc, true));
         const double fit2 = acc[0] > 0 ? acc[0] / nsg : 0.0, rmse2 = acc[0] > 0 ? sqrt(acc[1] / acc[0]) : 0.0;
@@ -689,6 +689,20 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     GSR_HIP(hipMemcpyAsync(idx, c->corr_idx.p, (size_t)c->ns * 8, hipMemcpyDeviceToHost, c->stream));
     GSR_HIP(hipMemcpyAsync(d2, c->corr_d2.p, (size_t)c->ns * 8, hipMemcpyDeviceToHost, c->stream));
     GSR_HIP(hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+
+int32_t gsr_icp_solve(const double* acc, int32_t kind, const double* centre, double* update) {
+    if (!acc || !update) return fail(GSR_E_INVALID, "gsr_icp_solve: NULL argument");
+    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE) return fail(GSR_E_INVALID, "gsr_icp_solve: unknown kind %d", kind);
+    const double zero[3] = {0, 0, 0};
+    estimate_update(centre ? centre : zero, kind, acc, update);
+    return GSR_OK;
+}
+
+int32_t gsr_icp_get_centre(gsr_icp_ctx* c, double* centre3) {
+    if (!c || !centre3 || !c->have_target) return fail(GSR_E_INVALID, "gsr_icp_get_centre: no target set");
+    centre3[0] = c->grid.cx; centre3[1] = c->grid.cy; centre3[2] = c->grid.cz;
     return GSR_OK;
 }
 

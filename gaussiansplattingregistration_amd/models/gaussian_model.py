@@ -1,0 +1,122 @@
+"""Splat tensor container with the accessor names of the reference's ``GaussianModel``
+(``src/models/gaussian_model.py:21``) -- the part of it the hot path touches.
+
+Kept (same names / shapes): ``get_xyz (N,3)`` ``:56-57``, ``get_colors (N,3)`` ``:66-67``,
+``get_spherical_harmonics (N, 3*((deg+1)^2-1))`` ``:70-71``, ``get_raw_opacity (N,1)`` ``:78-79``,
+``get_covariance(1) (N,6)`` ``:89-91``, ``get_full_covariance()`` ``:81-87``, ``from_mixture(model, sh_degree)``
+``:141-153``, ``move_to_device`` ``:223-234``, ``clone_gaussian``.  ``from_arrays`` builds level 0 from
+raw arrays (the ``.ply`` reader of ``:98-139`` needs ``plyfile`` -- SURVEY.md 8f N3, not this round).
+
+``from_mixture`` does not run the reference's ``torch.linalg.eigh`` scaling/rotation rebuild
+(``:151-153,242-265``; the reference's own comment calls it unused) unless asked: registration only
+consumes xyz / covariance.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .gaussian_mixture_level import GaussianMixtureModel
+
+
+def _t(a, device, shape=None):
+    if isinstance(a, torch.Tensor):
+        t = a.detach().to(device=device, dtype=torch.float32)
+    else:
+        t = torch.as_tensor(np.asarray(a, dtype=np.float32), device=device)
+    return t.reshape(shape) if shape is not None else t
+
+
+class GaussianModel:
+    def __init__(self, device_name="cpu"):
+        self.sh_degree = -1
+        self.device_name = device_name
+        self._xyz = torch.empty(0)
+        self._features_dc = torch.empty(0)
+        self._features_rest = torch.empty(0)
+        self._scaling = torch.empty(0)
+        self._rotation = torch.empty(0)
+        self._opacity = torch.empty(0)
+        self._covariance = torch.empty(0)
+
+    # -- accessors (reference names) -------------------------------------------------------------
+    @property
+    def get_xyz(self):
+        return self._xyz
+
+    @property
+    def get_colors(self):
+        return self._features_dc.flatten(start_dim=1)
+
+    @property
+    def get_spherical_harmonics(self):
+        return self._features_rest.flatten(start_dim=1)
+
+    @property
+    def get_features(self):
+        return torch.cat((self._features_dc, self._features_rest), dim=1)
+
+    @property
+    def get_raw_opacity(self):
+        return self._opacity
+
+    @property
+    def get_opacity_with_activation(self):
+        return torch.sigmoid(self._opacity)
+
+    def get_full_covariance(self, scaling_modifier=1.0):
+        c = self._covariance
+        full = torch.stack([c[:, [0, 1, 2]], c[:, [1, 3, 4]], c[:, [2, 4, 5]]], dim=1)
+        if scaling_modifier == 1:
+            return full
+        return full * float(scaling_modifier) ** 2
+
+    def get_covariance(self, scaling_modifier=1):
+        if scaling_modifier == 1:
+            return self._covariance
+        # the reference applies the diagonal scaling twice (gaussian_model.py:93-96): S (S C S^T) S^T
+        return self._covariance * float(scaling_modifier) ** 4
+
+    def __len__(self):
+        return int(self._xyz.shape[0])
+
+    # -- construction ------------------------------------------------------------------------------
+    def from_arrays(self, xyz, colors, opacities, covariance, features, sh_degree):
+        """Level 0 from the five arrays the HEM boundary takes (opacity RAW)."""
+        n = int(xyz.shape[0])
+        self.sh_degree = sh_degree
+        k = (sh_degree + 1) ** 2 - 1
+        self._xyz = _t(xyz, self.device_name, (n, 3))
+        self._features_dc = _t(colors, self.device_name, (n, 1, 3))
+        self._features_rest = _t(features, self.device_name, (n, k, 3))
+        self._opacity = _t(opacities, self.device_name, (n, 1))
+        self._covariance = _t(covariance, self.device_name, (n, 6))
+        return self
+
+    def from_mixture(self, gaussian_mixture: GaussianMixtureModel, sh_degree: int, decompose: bool = False):
+        self.sh_degree = sh_degree
+        k = (sh_degree + 1) ** 2 - 1
+        self._xyz = _t(gaussian_mixture.xyz, self.device_name)
+        n = int(self._xyz.shape[0])
+        self._features_dc = _t(gaussian_mixture.colors, self.device_name).view(-1, 1, 3)
+        self._features_rest = _t(gaussian_mixture.features, self.device_name).view(-1, k, 3)
+        self._opacity = _t(gaussian_mixture.opacities, self.device_name)
+        self._covariance = _t(gaussian_mixture.covariance, self.device_name).view(n, 6)
+        if decompose:
+            ev, evec = torch.linalg.eigh(self.get_full_covariance())
+            self._scaling, self._rotation = ev, evec
+        return self
+
+    def clone_gaussian(self):
+        m = GaussianModel(self.device_name)
+        m.sh_degree = self.sh_degree
+        for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_covariance"):
+            setattr(m, name, getattr(self, name).clone().detach())
+        return m
+
+    def move_to_device(self, device_name):
+        if self.device_name == device_name:
+            return
+        self.device_name = device_name
+        for name in ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity", "_covariance"):
+            setattr(self, name, getattr(self, name).to(device_name))

@@ -113,3 +113,42 @@ def make_pair(n: int, seed: int = 0, sh_degree: int = 3, jitter: float = 0.002,
         rng = np.random.default_rng(seed + 7919)
         source["xyz"] = (source["xyz"] + rng.normal(0, jitter, source["xyz"].shape)).astype(np.float32)
     return source, target, T_gt
+
+
+def make_cloud_torch(n: int, seed: int = 0, device="cuda:0", sh_degree: int = 3, h: float | None = None):
+    """Same distributions as ``make_cloud`` drawn directly on the GPU with torch's generator (for the
+    5M-splat benchmark / full-size tests: no host staging).  Not the same stream as the NumPy recipe."""
+    import torch
+    if h is None:
+        h = half_extent(n)
+    F = 3 * ((sh_degree + 1) ** 2 - 1)
+    g = torch.Generator(device=device).manual_seed(seed)
+    xyz = (torch.rand((n, 3), device=device, generator=g) * 2 - 1) * h
+    s = torch.exp(torch.randn((n, 3), device=device, generator=g) * 0.5 - 2.5)
+    q = torch.nn.functional.normalize(torch.randn((n, 4), device=device, generator=g), dim=1)
+    w, x, y, z = q.unbind(1)
+    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).view(n, 3, 3)
+    L = R * s[:, None, :]
+    C = L @ L.transpose(1, 2)
+    cov6 = torch.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1).contiguous()
+    del R, L, C
+    col = torch.randn((n, 3), device=device, generator=g) * 0.5
+    op = torch.randn((n,), device=device, generator=g) * 2.0
+    sh = torch.randn((n, F), device=device, generator=g) * 0.1
+    return {"xyz": xyz, "color": col, "opacity": op, "cov6": cov6, "sh": sh, "sh_degree": sh_degree, "h": float(h)}
+
+
+def apply_rigid_torch(cloud: dict, T):
+    """Rigid motion of a device cloud (float64 maths, float32 storage)."""
+    import torch
+    Tt = torch.as_tensor(np.asarray(T), dtype=torch.float64, device=cloud["xyz"].device)
+    R, t = Tt[:3, :3], Tt[:3, 3]
+    out = dict(cloud)
+    out["xyz"] = (cloud["xyz"].double() @ R.T + t).float()
+    c = cloud["cov6"].double()
+    C = torch.stack([c[:, [0, 1, 2]], c[:, [1, 3, 4]], c[:, [2, 4, 5]]], 1)
+    C = R @ C @ R.T
+    out["cov6"] = torch.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1).float().contiguous()
+    return out

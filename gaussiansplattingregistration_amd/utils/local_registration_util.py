@@ -1,0 +1,170 @@
+"""Drop-in for the reference's ``src/utils/local_registration_util.py`` with the Open3D calls replaced
+by the MI355X ICP kernels.
+
+Same public names, argument meaning and error behaviour:
+
+* ``KernelLossFunctionType`` / ``LocalRegistrationType`` -- integer ``.value`` = declaration order and
+  ``.instance_name`` = the GUI label (reference ``:6-36``);
+* ``get_rejection_loss`` (``:58-73``), ``get_estimation`` (``:39-51``), ``get_convergence_criteria`` (``:54-55``)
+  return light descriptors instead of Open3D objects;
+* ``do_icp_registration(point_cloud_first, point_cloud_second, init_transform, registration_params)``
+  (``:76-100``) returns an object with ``.transformation`` (4x4 float64), ``.fitness``, ``.inlier_rmse``.
+  The ten-positional-argument form the multiscale worker *intends*
+  (``src/gui/workers/registration/qt_multiscale_registrator.py:84-87,136-138,218-220`` -- a ``TypeError``
+  at the reference's HEAD) is accepted too.
+
+Open3D raises ``RuntimeError`` for ``max_correspondence_distance <= 0`` and for point-to-plane ICP on
+a target without normals; so does this module.  Colored / Generalized ICP are outside this round's
+scope and raise ``NotImplementedError``.
+"""
+from __future__ import annotations
+
+from enum import Enum
+
+import numpy as np
+
+from .. import icp as _icp
+
+
+class KernelLossFunctionType(Enum):
+    def __new__(cls, *args, **kwds):
+        value = len(cls.__members__)
+        obj = object.__new__(cls)
+        obj._value_ = value
+        return obj
+
+    def __init__(self, name):
+        self.instance_name = name
+
+    Loss_None = "None"
+    Tukey_Loss = "Tukey loss"
+    Cauchy_Loss = "Cauchy loss"
+    GMLoss = "GM loss"
+    Huber_Loss = "Huber loss"
+
+
+class LocalRegistrationType(Enum):
+    def __new__(cls, *args, **kwds):
+        value = len(cls.__members__)
+        obj = object.__new__(cls)
+        obj._value_ = value
+        return obj
+
+    def __init__(self, name):
+        self.instance_name = name
+
+    ICP_Point_To_Point = "Point-to-Point ICP"
+    ICP_Point_To_Plane = "Point-to-Plane ICP"
+    ICP_Color = "Colored ICP"
+    ICP_General = "Generalized ICP"
+
+
+class RobustLoss:
+    """Stand-in for ``o3d.pipelines.registration.{L2,Tukey,Cauchy,GM,Huber}Loss``: (code, k)."""
+
+    def __init__(self, code, k=0.0, name="L2Loss"):
+        self.code, self.k, self.name = code, float(k), name
+
+    def __repr__(self):
+        return f"{self.name}(k={self.k})" if self.code else "L2Loss()"
+
+
+class Estimation:
+    """Stand-in for ``TransformationEstimationPointToPoint`` / ``PointToPlane(loss)``."""
+
+    def __init__(self, kind, loss=None, name=""):
+        self.kind, self.loss, self.name = kind, loss, name
+
+    def __repr__(self):
+        return f"{self.name}({self.loss!r})" if self.loss is not None else f"{self.name}()"
+
+
+class ConvergenceCriteria:
+    def __init__(self, relative_fitness=1e-6, relative_rmse=1e-6, max_iteration=30):
+        self.relative_fitness, self.relative_rmse, self.max_iteration = relative_fitness, relative_rmse, max_iteration
+
+
+def get_estimation(registration_type, loss_function):
+    if loss_function is None:
+        return Estimation(_icp.KIND_POINT_TO_POINT, None, "TransformationEstimationPointToPoint")
+    if registration_type is LocalRegistrationType.ICP_Point_To_Point:
+        return Estimation(_icp.KIND_POINT_TO_POINT, None, "TransformationEstimationPointToPoint")
+    if registration_type is LocalRegistrationType.ICP_Point_To_Plane:
+        return Estimation(_icp.KIND_POINT_TO_PLANE, loss_function, "TransformationEstimationPointToPlane")
+    if registration_type is LocalRegistrationType.ICP_Color:
+        return Estimation(-1, loss_function, "TransformationEstimationForColoredICP")
+    if registration_type is LocalRegistrationType.ICP_General:
+        return Estimation(-2, loss_function, "TransformationEstimationForGeneralizedICP")
+    return None
+
+
+def get_convergence_criteria(relative_fitness, relative_rmse, max_iteration):
+    return ConvergenceCriteria(relative_fitness, relative_rmse, max_iteration)
+
+
+def get_rejection_loss(rejection_type, k_value, registration_type):
+    if registration_type is LocalRegistrationType.ICP_Point_To_Point:
+        return None
+    if rejection_type is KernelLossFunctionType.Loss_None or k_value == 0.0:
+        return RobustLoss(_icp.LOSS_L2, 0.0, "L2Loss")
+    if rejection_type is KernelLossFunctionType.Tukey_Loss:
+        return RobustLoss(_icp.LOSS_TUKEY, k_value, "TukeyLoss")
+    if rejection_type is KernelLossFunctionType.Cauchy_Loss:
+        return RobustLoss(_icp.LOSS_CAUCHY, k_value, "CauchyLoss")
+    if rejection_type is KernelLossFunctionType.GMLoss:
+        return RobustLoss(_icp.LOSS_GM, k_value, "GMLoss")
+    if rejection_type is KernelLossFunctionType.Huber_Loss:
+        return RobustLoss(_icp.LOSS_HUBER, k_value, "HuberLoss")
+    return None
+
+
+def registration_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, device=None,
+                     allreduce=None, n_source_global=None):
+    """``o3d.pipelines.registration.registration_icp`` on ``PointCloud`` records (see ``point_cloud.py``)."""
+    if not (max_correspondence_distance > 0.0):
+        raise RuntimeError("[Open3D Error] Invalid max_correspondence_distance.")
+    if estimation_method.kind == _icp.KIND_POINT_TO_PLANE and not target.has_normals():
+        raise RuntimeError("[Open3D Error] TransformationEstimationPointToPlane and "
+                           "TransformationEstimationColoredICP require pre-computed normal vectors for target PointCloud.")
+    if estimation_method.kind < 0:
+        raise NotImplementedError(f"{estimation_method.name} is not part of this backend yet (SURVEY.md 8f, N2)")
+    dev = device if device is not None else getattr(target, "device_index", 0)
+    loss = estimation_method.loss or RobustLoss(_icp.LOSS_L2)
+    with _icp.IcpContext(device=dev) as ctx:
+        ctx.set_target(target.xyz32, target.normals if estimation_method.kind == _icp.KIND_POINT_TO_PLANE else None,
+                       max_correspondence_distance)
+        ctx.set_source(source.xyz32)
+        if allreduce is not None:
+            ctx.set_allreduce(allreduce, n_source_global)
+        r = ctx.register(np.asarray(init, dtype=np.float64), estimation_method.kind, loss.code, loss.k,
+                         criteria.relative_fitness, criteria.relative_rmse, criteria.max_iteration)
+        res = _icp.RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], r["iterations"])
+        res.timing = ctx.timing()
+        return res
+
+
+def do_icp_registration(point_cloud_first, point_cloud_second, init_transform, registration_params, *extra, **kw):
+    """Reference signature (4 arguments) or the multiscale worker's intended 10-positional form:
+    ``(pc1, pc2, T, registration_type, max_correspondence, relative_fitness, relative_rmse, max_iteration,
+    rejection_type, k_value)``."""
+    if extra:
+        if len(extra) != 6:
+            raise TypeError(f"do_icp_registration() takes 4 or 10 positional arguments but {4 + len(extra)} were given")
+        from ..params.registration_parameters import LocalRegistrationParams
+        registration_params = LocalRegistrationParams(registration_type=registration_params, max_correspondence=extra[0],
+                                                      relative_fitness=extra[1], relative_rmse=extra[2], max_iteration=extra[3],
+                                                      rejection_type=extra[4], k_value=extra[5])
+    loss_function = get_rejection_loss(registration_params.rejection_type, registration_params.k_value,
+                                       registration_params.registration_type)
+    estimation_method = get_estimation(registration_params.registration_type, loss_function)
+    convergence_criteria = get_convergence_criteria(registration_params.relative_fitness,
+                                                    registration_params.relative_rmse,
+                                                    registration_params.max_iteration)
+    max_correspondence = registration_params.max_correspondence
+    rt = registration_params.registration_type
+    if rt in (LocalRegistrationType.ICP_Point_To_Point, LocalRegistrationType.ICP_Point_To_Plane):
+        return registration_icp(point_cloud_first, point_cloud_second, max_correspondence, init_transform,
+                                estimation_method, convergence_criteria, **kw)
+    if rt in (LocalRegistrationType.ICP_Color, LocalRegistrationType.ICP_General):
+        raise NotImplementedError(f"{rt.instance_name} is not part of this backend yet (SURVEY.md 8f, N2)")
+    return None

@@ -1,0 +1,15 @@
+"""``convert_gs_to_open3d_pc`` of the reference (``src/utils/point_cloud_converter.py:31-49``) without
+Open3D and without the host round trip the reference's README calls too slow (``README.md:115``):
+positions, SH-DC colours (``sh2rgb``), packed covariances and covariance-derived normals stay on the
+device the model lives on."""
+from __future__ import annotations
+
+from ..models.point_cloud import PointCloud
+from .graphics_utils import sh2rgb
+
+
+def convert_gs_to_open3d_pc(gaussian):
+    pc = PointCloud(xyz32=gaussian.get_xyz.detach(), colors=sh2rgb(gaussian.get_colors.detach().double()),
+                    cov6=gaussian.get_covariance(1).detach())
+    pc.estimate_normals()
+    return pc

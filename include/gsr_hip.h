@@ -99,9 +99,10 @@ int32_t gsr_hem_get_level(gsr_hem_ctx* ctx, float* xyz, float* color, float* cov
  *  [5] grid cells  [6] components in  [7] components out */
 int32_t gsr_hem_get_stats(gsr_hem_ctx* ctx, int64_t* out8);
 /* Device time of the phases of the most recent level, in milliseconds (hipEvent pairs on the
- * context's stream):  [0] prep+grid  [1] selection (count+fill)  [2] per-child sums
- * [3] M-step + orphans  [4] flags+validity  [5] whole level */
-int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* ctx, float* out6);
+ * context's stream):  [0] prep+grid  [1] selection (count+scan+fill)  [2] per-child sums
+ * [3] M-step + orphans  [4] flags+validity  [5] whole level
+ * [6] the k_select<COUNT> launch alone  [7] the k_select<FILL> launch alone */
+int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* ctx, float* out8);
 
 /* ------------------------------------------------------------------------------------------- ICP */
 
@@ -158,6 +159,23 @@ int32_t gsr_icp_get_timing(gsr_icp_ctx* ctx, float* out3);
  * a zero vector becomes (0,0,1).  cov6[n*6] float32 in, normals[n*3] float64 out. */
 int32_t gsr_normals_from_cov(const float* cov6, int64_t n, double* normals, int32_t on_device,
                              int32_t device, void* stream);
+
+/* Estimator solve on the HOST from a reduced accumulator vector (no GPU involved): the 3x3 Jacobi
+ * SVD of Eigen::umeyama (point-to-point) or the 6x6 LDL^T solve + Rz*Ry*Rx of Open3D's point-to-plane
+ * estimator.  centre[3] = the point the point-to-point sums are relative to (ignored for
+ * point-to-plane).  update = row-major 4x4.  Every rank of a multi-GPU run calls this on the same
+ * all-reduced vector and so gets the identical update. */
+int32_t gsr_icp_solve(const double* acc, int32_t kind, const double* centre, double* update);
+/* The centre used by the context's point-to-point sums (target bounding-box centre). */
+int32_t gsr_icp_get_centre(gsr_icp_ctx* ctx, double* centre3);
+
+/* ------------------------------------------------------------------------------- test hooks (device) */
+/* out[i] = the kernels' logf (glibc-compatible, gsr_math.h) of x[i]; host pointers. */
+int32_t gsr_debug_logf(const float* x, int64_t n, float* out, int32_t device);
+/* out[i] = KL gate value of child i against parent i as the selection kernel computes it; host pointers,
+ * child_mean/parent_mean [n*3], child_cov6/parent_cov6 [n*6]. */
+int32_t gsr_debug_kld(const float* child_mean, const float* child_cov6, const float* parent_mean,
+                      const float* parent_cov6, int64_t n, float* out, int32_t device);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,73 @@
+"""N>1 path on CPU: two gloo ranks split the source, all-reduce the accumulator vector through the
+product's parallel.make_allreduce, solve on every rank with the product's host solve, and land on the
+single-process answer.  (Rank-local accumulators come from a NumPy stand-in of the kernel here; the
+kernel itself is checked against the oracle in the -m gpu tests.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+
+def _acc_numpy(src, tgt, T, max_corr, centre):
+    from scipy.spatial import cKDTree
+    p = src @ T[:3, :3].T + T[:3, 3]
+    d, j = cKDTree(tgt).query(p, k=1)
+    m = d * d < max_corr * max_corr
+    a, b = p[m] - centre, tgt[j[m]] - centre
+    acc = np.zeros(32)
+    acc[0], acc[1] = m.sum(), (d[m] ** 2).sum()
+    acc[2:5], acc[5:8] = a.sum(0), b.sum(0)
+    acc[8:17] = (a[:, :, None] * b[:, None, :]).sum(0).reshape(-1)
+    return acc
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from gaussiansplattingregistration_amd import _lib, parallel, synth
+    r, w, _ = parallel.init_distributed("gloo")
+    assert (r, w) == (rank, world)
+    src, tgt, T_gt = synth.make_pair(3000, seed=3, sh_degree=0)
+    s, t = src["xyz"].astype(np.float64), tgt["xyz"].astype(np.float64)
+    lo, hi = parallel.shard_range(len(s), rank, world)
+    centre = 0.5 * (t.min(0) + t.max(0))
+    allreduce = parallel.make_allreduce()
+    L = _lib.load()
+    T = np.eye(4)
+    for _ in range(6):
+        acc = _acc_numpy(s[lo:hi], t, T, 0.25, centre)
+        allreduce(acc)                                      # the ONLY exchange per iteration
+        upd = np.zeros((4, 4))
+        assert L.gsr_icp_solve(acc.ctypes.data, 0, centre.ctypes.data, upd.ctypes.data) == 0
+        T = upd @ T
+    q.put((rank, T, acc[0]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_source_split_equals_single_process(hip_lib, oracle):
+    from gaussiansplattingregistration_amd import parallel, synth
+    assert parallel.shard_range(10, 0, 3) == (0, 4) and parallel.shard_range(10, 2, 3) == (7, 10)
+    assert parallel.assign_clouds(2, 1, 2) == [1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    res.sort(key=lambda x: x[0])
+    assert np.array_equal(res[0][1], res[1][1])             # every rank holds the identical transform
+    assert res[0][2] == res[1][2] == 3000                   # reduced correspondence count is global
+    src, tgt, T_gt = synth.make_pair(3000, seed=3, sh_degree=0)
+    want = oracle.icp(src["xyz"], tgt["xyz"], None, np.eye(4), kind=0, max_corr=0.25, max_iter=6, rel_fitness=0, rel_rmse=0)
+    assert np.linalg.norm(res[0][1] - want["transformation"]) < 1e-9

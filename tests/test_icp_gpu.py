@@ -1,0 +1,120 @@
+"""ICP parity proper (HIP path through the C ABI) against the oracle and the committed fixture.
+Tolerance (BASELINE.json north_star): final transform within 1e-5 Frobenius."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+TOL_T = 1e-5
+
+
+def _cov3(c6):
+    c = c6.astype(np.float64)
+    return np.stack([c[:, [0, 1, 2]], c[:, [1, 3, 4]], c[:, [2, 4, 5]]], 1)
+
+
+@pytest.mark.parametrize("name,kind,loss,k", [("p2p", 0, 0, 0.0), ("p2plane", 1, 0, 0.0), ("p2plane_tukey", 1, 1, 0.05),
+                                              ("p2plane_huber", 1, 4, 0.01)])
+def test_gpu_vs_icp_fixture(name, kind, loss, k):
+    from gaussiansplattingregistration_amd import icp
+    g = load_golden("icp_pair")
+    r = icp.registration_icp_arrays(g["src_xyz"], g["tgt_xyz"], g["tgt_normals"], np.eye(4), kind=kind, loss=loss, k=k,
+                                    max_corr=float(g["max_corr"]), max_iter=int(g["max_iter"]))
+    assert r["iterations"] == int(g[f"{name}_iters"])
+    assert np.linalg.norm(r["transformation"] - g[f"{name}_T"]) < TOL_T
+    assert abs(r["fitness"] - float(g[f"{name}_fitness"])) < 1e-9 and abs(r["inlier_rmse"] - float(g[f"{name}_rmse"])) < 1e-8
+    assert np.linalg.norm(r["transformation"] - g["T_gt"]) < 5e-3
+
+
+@pytest.mark.parametrize("kind,loss,k", [(0, 0, 0.0), (1, 0, 0.0), (1, 2, 0.05), (1, 3, 0.05)])
+def test_gpu_vs_oracle_100k(oracle, kind, loss, k):
+    from gaussiansplattingregistration_amd import icp, synth
+    src, tgt, T_gt = synth.make_pair(100000, seed=5, sh_degree=0, angle_deg=2.0)
+    nrm = icp.normals_from_cov(tgt["cov6"])
+    assert np.abs(np.abs((nrm * oracle.normals_from_cov(_cov3(tgt["cov6"]))).sum(1)) - 1).max() < 1e-9
+    init = np.eye(4)
+    init[:3, 3] = [0.01, -0.02, 0.005]
+    w = oracle.icp(src["xyz"], tgt["xyz"], nrm, init, kind=kind, loss=loss, k=k, max_corr=0.2, max_iter=15)
+    r = icp.registration_icp_arrays(src["xyz"], tgt["xyz"], nrm, init, kind=kind, loss=loss, k=k, max_corr=0.2, max_iter=15)
+    assert r["iterations"] == w["iterations"]
+    assert np.linalg.norm(r["transformation"] - w["transformation"]) < TOL_T
+    assert abs(r["fitness"] - w["fitness"]) < 1e-9 and abs(r["inlier_rmse"] - w["inlier_rmse"]) < 1e-8
+
+
+def test_correspondences_exact(oracle):
+    from gaussiansplattingregistration_amd import icp, synth
+    src, tgt, T_gt = synth.make_pair(50000, seed=7, sh_degree=0)
+    T = np.eye(4)
+    T[:3, 3] = 0.03
+    with icp.IcpContext() as c:
+        c.set_target(tgt["xyz"], None, 0.15)
+        c.set_source(src["xyz"])
+        idx, d2 = c.correspondences(T)
+    widx, wd2 = oracle.icp_correspond(src["xyz"], tgt["xyz"], T, 0.15)
+    assert np.array_equal(idx, widx)                           # index work: bit-exact
+    assert np.allclose(d2, wd2, rtol=1e-12, atol=0)
+    assert (idx < 0).any() and (idx >= 0).any()                # both outcomes exercised
+
+
+def test_accumulators_match_numpy():
+    from gaussiansplattingregistration_amd import icp, synth
+    src, tgt, _ = synth.make_pair(20000, seed=8, sh_degree=0)
+    with icp.IcpContext() as c:
+        c.set_target(tgt["xyz"], None, 0.2)
+        c.set_source(src["xyz"])
+        acc = c.accumulate(np.eye(4), kind=0)
+        idx, d2 = c.correspondences(np.eye(4))
+    m = idx >= 0
+    assert acc[0] == m.sum() and abs(acc[1] - d2[m].sum()) < 1e-9 * d2[m].sum()
+
+
+def test_do_icp_registration_and_multiscale_driver(oracle):
+    """Reference-shaped call path: GaussianModel -> HEM worker -> converter -> multiscale ICP (intended 10-arg form),
+    against the oracle chained the same way."""
+    import torch
+    from gaussiansplattingregistration_amd import mixture_bind, synth
+    from gaussiansplattingregistration_amd.controllers.downsampler_controller import DownsamplerController
+    from gaussiansplattingregistration_amd.controllers.registration_controller import RegistrationController
+    from gaussiansplattingregistration_amd.models.data_repository import DataRepository, UIStateRepository
+    from gaussiansplattingregistration_amd.models.gaussian_model import GaussianModel
+    from gaussiansplattingregistration_amd.params import GaussianMixtureParams
+    from gaussiansplattingregistration_amd.utils.local_registration_util import KernelLossFunctionType, LocalRegistrationType
+    from gaussiansplattingregistration_amd.utils.point_cloud_converter import convert_gs_to_open3d_pc
+
+    src, tgt, T_gt = synth.make_pair(20000, seed=11, sh_degree=1, angle_deg=3.0)
+    repo, ui = DataRepository(), UIStateRepository()
+    for c, gl, ol in ((src, repo.pc_gaussian_list_first, repo.pc_open3d_list_first), (tgt, repo.pc_gaussian_list_second, repo.pc_open3d_list_second)):
+        gm = GaussianModel("cuda:0").from_arrays(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"], 1)
+        gl.append(gm)
+        ol.append(convert_gs_to_open3d_pc(gm))
+    mixture_bind.reset_rng()
+    DownsamplerController(repo).create_mixture(GaussianMixtureParams(cluster_level=2))
+    assert len(repo.pc_open3d_list_first) == 3 and len(repo.pc_gaussian_list_second) == 3      # [orig, L1, L2]
+    rc = RegistrationController(repo, ui)
+    voxel, iters = [0.6, 0.4, 0.2], [20, 15, 10]
+    res = rc.execute_multiscale_registration(False, "", "", LocalRegistrationType.ICP_Point_To_Plane, 1e-6, 1e-6, voxel, iters,
+                                             KernelLossFunctionType.Loss_None, 0.0, True)
+    assert res is not None, rc.errors
+    T = res.result.transformation
+    assert np.array_equal(ui.transformation_matrix, T)
+    # oracle chain on the very same level clouds (coarse -> fine)
+    Tw = np.eye(4)
+    for k in range(3):
+        s, t = repo.pc_open3d_list_first[-(k + 1)], repo.pc_open3d_list_second[-(k + 1)]
+        nrm = t.normals.cpu().numpy() if isinstance(t.normals, torch.Tensor) else t.normals
+        w = oracle.icp(s.points, t.points, nrm, Tw, kind=1, max_corr=voxel[k], max_iter=iters[k])
+        Tw = w["transformation"]
+    assert np.linalg.norm(T - Tw) < TOL_T
+    assert np.linalg.norm(T - T_gt) < 0.05
+
+
+def test_icp_error_behaviour():
+    from gaussiansplattingregistration_amd import icp
+    with icp.IcpContext() as c:
+        with pytest.raises(RuntimeError, match="max_correspondence_distance"):
+            c.set_target(np.zeros((4, 3), np.float32), None, 0.0)
+        c.set_target(np.random.rand(10, 3).astype(np.float32), None, 0.5)
+        c.set_source(np.random.rand(10, 3).astype(np.float32))
+        with pytest.raises(RuntimeError, match="normals"):
+            c.register(kind=1)
