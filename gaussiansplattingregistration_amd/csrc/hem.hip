@@ -244,7 +244,22 @@ __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __re
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_select: child selection (mixture.cpp:102-137) and, in FILL mode, wL_si (mixture.cpp:140-164)
+// k_select: child selection (mixture.cpp:102-137) and wL_si (mixture.cpp:140-164), one wavefront per parent
+//
+//   rows      the grid rows (fixed y,z cell) that meet the query sphere; lane r of a 64-row batch
+//             computes the contiguous span [s,e) of sorted components of its row, x-clipped to the sphere
+//   flatten   a wave inclusive scan of the span lengths turns the batch into ONE virtual candidate
+//             array; each lane finds its candidate by a 6-step shuffle binary search, so the radius
+//             test runs with all 64 lanes busy whatever the span lengths are
+//   stage 1   exact radius test  d2 < R^2  (pointindex.cpp:137); survivors are compacted (ballot +
+//             popcount) into a per-wave LDS queue
+//   stage 2   whenever the queue holds >= 64 survivors: colour gate, KL gate, parent rule on 64
+//             survivors at once (the expensive part runs on full waves), likelihood for the accepted
+//   modes     COUNT  only counts accepted pairs (first pass of the two-pass fallback)
+//             FILL   writes pairs at poff[p]  (second pass of the fallback)
+//             SPARSE single pass: writes pairs at coff[p] (capacity = candidates scanned, from
+//                    k_select<SPANS>), count to pcnt[p]; k_compact_pairs then packs them
+//             SPANS  only sums the span lengths (capacity for SPARSE)
 // ------------------------------------------------------------------------------------------------
 struct SelectArgs {
     const float4 *A, *B, *C, *D;
@@ -254,39 +269,104 @@ struct SelectArgs {
     const GridParams* gp;
     int P;
     float colorThr, kldThr, tau2;
-    // COUNT
-    unsigned* pcnt;
-    unsigned long long* cand_total;
-    // FILL
-    const int64_t* poff;
+    unsigned* pcnt;                 // COUNT / SPARSE out: accepted pairs per parent
+    unsigned* pcap;                 // SPANS out: candidates scanned per parent
+    unsigned long long* cand_total; // SPANS / COUNT: total candidates scanned
+    const int64_t* poff;            // FILL: compact offsets;  SPARSE: capacity offsets
     unsigned* pair_child;
     float* pair_wl;
 };
 
-template <bool FILL>
+enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2, SEL_SPANS = 3 };
+#define SEL_QCAP 128
+
+struct ParentRec {
+    f3 pm, pcol;
+    s6 pinv;
+    float det_p, pweight, R2;
+    int js;
+};
+
+// stage 2 on up to 64 queued survivors (lane < cnt holds one)
+template <int MODE>
+__device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, const unsigned* q,
+                                              unsigned& count, int64_t& base) {
+    bool acc = false;
+    float wl = 0.0f;
+    int j = 0;
+    if (lane < cnt) {
+        j = (int)q[lane];
+        const float4 ca = a.A[j], cc = a.C[j], cd = a.D[j];
+        const f3 cm = {ca.x, ca.y, ca.z};
+        const f3 ccol = {cc.z, cc.w, cd.x};
+        const f3 dc = sub3(ccol, pr.pcol);                    // ColorDelta(child, parent), gaussian.hpp:111-114
+        const float cdiff = sqrtf(dot3(dc, dc));
+        if (!(cdiff > a.colorThr)) {                          // mixture.cpp:122-124
+            const float4 cb = a.B[j];
+            const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
+            const float det_c = ca.w;
+            const f3 d = sub3(cm, pr.pm);
+            const float k = kld6(d, ccov, det_c, pr.pinv, pr.det_p);
+            if (!(k > a.kldThr)) {                            // mixture.cpp:126-129 (NaN passes)
+                const bool child_is_parent = (__float_as_uint(cd.w) & 1u) != 0u;
+                if (!(child_is_parent && j != pr.js)) {       // mixture.cpp:131-133
+                    acc = true;
+                    if (MODE != SEL_COUNT) {
+                        // hemLikelihoodOpacity, mixture.cpp:54-64 (parent - child)
+                        const f3 dq = sub3(pr.pm, cm);
+                        const float distanceDiff = sqrtf(dot3(dq, dq));
+                        const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
+                        const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
+                        const float L = distWeight * cd.y * colorInfluence * sqrtf(det_c);
+                        wl = pr.pweight * ref_clamp(L, FLT_MIN, 1e8f);
+                    }
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(acc);
+    if (MODE != SEL_COUNT) {
+        if (acc) {
+            const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            a.pair_child[pos] = (unsigned)j;
+            a.pair_wl[pos] = wl;
+        }
+        base += __popcll(m);
+    }
+    count += (unsigned)__popcll(m);
+}
+
+template <int MODE>
 __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
-    const int lane = threadIdx.x & 63;
-    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    __shared__ unsigned s_q[4][SEL_QCAP];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int p = blockIdx.x * 4 + wv;
     if (p >= a.P) return;
     const GridParams g = *a.gp;
-    const int js = (int)a.plist[p];
-    const float4 pa = a.A[js], pb = a.B[js], pc = a.C[js], pd = a.D[js];
-    const f3 pm = {pa.x, pa.y, pa.z};
-    const float det_p = pa.w;
-    const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
-    const f3 pcol = {pc.z, pc.w, pd.x};
-    const float pweight = pd.z;
-    const s6 pinv = inverse6(pcov, det_p);
-    const float R = a.Rs[js];
-    const float R2 = R * R;
+    ParentRec pr;
+    pr.js = (int)a.plist[p];
+    {
+        const float4 pa = a.A[pr.js], pb = a.B[pr.js], pc = a.C[pr.js], pd = a.D[pr.js];
+        pr.pm = {pa.x, pa.y, pa.z};
+        pr.det_p = pa.w;
+        const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
+        pr.pcol = {pc.z, pc.w, pd.x};
+        pr.pweight = pd.z;
+        pr.pinv = inverse6(pcov, pr.det_p);
+    }
+    const float R = a.Rs[pr.js];
+    pr.R2 = R * R;
+    const f3 pm = pr.pm;
 
-    unsigned count = 0;
-    unsigned long long scanned = 0;
-    int64_t base = FILL ? a.poff[p] : 0;
+    unsigned count = 0;                 // accepted pairs (uniform across the wave)
+    unsigned long long scanned = 0;     // candidates scanned (uniform)
+    int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
+    int qn = 0;                         // survivors waiting in the LDS queue (uniform)
+    unsigned* q = s_q[wv];
 
     // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
     const bool pm_finite = fabsf(pm.x) <= FLT_MAX && fabsf(pm.y) <= FLT_MAX && fabsf(pm.z) <= FLT_MAX;
-    if (R2 > 0.0f && pm_finite) {
+    if (pr.R2 > 0.0f && pm_finite) {
         const float Ra = fabsf(R) * 1.00001f + g.slack;             // conservative search extent
         const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
         const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
@@ -296,7 +376,7 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
         const float Ra2 = Ra * Ra;
         for (int rb = 0; rb < nrows; rb += 64) {
             const int r = rb + lane;
-            int s = 0, e = 0;
+            int s = 0, len = 0;
             if (r < nrows) {
                 const int ry = y0 + r % ny, rz = z0 + r / ny;
                 // distance from the parent to the row's y/z slab (widened by the rounding slack)
@@ -312,74 +392,77 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
                     xb = xb > x1 ? x1 : xb;
                     const int rowbase = (rz * g.gy + ry) * g.gx;
                     s = a.cellStart[rowbase + xa];
-                    e = a.cellStart[rowbase + xb + 1];
+                    len = a.cellStart[rowbase + xb + 1] - s;
                 }
             }
-            unsigned long long nonempty = __ballot(e > s);
-            while (nonempty) {
-                const int rl = __ffsll((long long)nonempty) - 1;
-                nonempty &= nonempty - 1;
-                const int ss = __shfl(s, rl), ee = __shfl(e, rl);
-                scanned += (unsigned long long)(ee - ss);
-                for (int j0 = ss; j0 < ee; j0 += 64) {
-                    const int j = j0 + lane;
-                    bool acc = false;
-                    float wl = 0.0f;
-                    if (j < ee) {
-                        const float4 ca = a.A[j];
-                        const f3 cm = {ca.x, ca.y, ca.z};
-                        const f3 dq = sub3(pm, cm);                       // query - point (pointindex.cpp:137)
-                        const float d2 = dot3(dq, dq);
-                        if (d2 < R2) {
-                            const float4 cc = a.C[j], cd = a.D[j];
-                            const f3 ccol = {cc.z, cc.w, cd.x};
-                            const f3 dc = sub3(ccol, pcol);               // ColorDelta(child, parent)
-                            const float cdiff = sqrtf(dot3(dc, dc));
-                            if (!(cdiff > a.colorThr)) {                  // mixture.cpp:122-124
-                                const float4 cb = a.B[j];
-                                const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
-                                const float det_c = ca.w;
-                                const f3 d = sub3(cm, pm);
-                                const float k = kld6(d, ccov, det_c, pinv, det_p);
-                                if (!(k > a.kldThr)) {                    // mixture.cpp:126-129 (NaN passes)
-                                    const bool child_is_parent = (__float_as_uint(cd.w) & 1u) != 0u;
-                                    if (!(child_is_parent && j != js)) {  // mixture.cpp:131-133
-                                        acc = true;
-                                        if (FILL) {
-                                            // hemLikelihoodOpacity, mixture.cpp:54-64
-                                            const float distanceDiff = sqrtf(d2);
-                                            const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
-                                            const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
-                                            const float L = distWeight * cd.y * colorInfluence * sqrtf(det_c);
-                                            wl = pweight * ref_clamp(L, FLT_MIN, 1e8f);
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (FILL) {
-                        const unsigned long long m = __ballot(acc);
-                        if (acc) {
-                            const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                            a.pair_child[pos] = (unsigned)j;
-                            a.pair_wl[pos] = wl;
-                        }
-                        base += __popcll(m);
-                    } else {
-                        count += acc ? 1u : 0u;
-                    }
+            // inclusive scan of the span lengths over the wave
+            int incl = len;
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            const int total = __shfl(incl, 63);
+            scanned += (unsigned long long)total;
+            if (MODE == SEL_SPANS) continue;
+            const int excl = incl - len;
+            for (int v0 = 0; v0 < total; v0 += 64) {
+                const int v = v0 + lane;
+                const bool valid = v < total;
+                const int vv = valid ? v : total - 1;
+                // smallest row rr with incl[rr] > vv; every lane takes part in every shuffle (uniform control flow)
+                int lo = 0, hi = 63;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const int iv = __shfl(incl, mid);
+                    if (iv > vv) hi = mid; else lo = mid + 1;
+                }
+                const int j = __shfl(s, lo) + (vv - __shfl(excl, lo));
+                bool in = false;
+                if (valid) {
+                    const float4 ca = a.A[j];
+                    const f3 cm = {ca.x, ca.y, ca.z};
+                    const f3 dq = sub3(pm, cm);                           // query - point (pointindex.cpp:137)
+                    in = dot3(dq, dq) < pr.R2;
+                }
+                const unsigned long long m = __ballot(in);
+                if (in) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)j;
+                qn += __popcll(m);
+                __builtin_amdgcn_wave_barrier();
+                if (qn >= 64) {
+                    select_stage2<MODE>(a, pr, lane, 64, q, count, base);
+                    __builtin_amdgcn_wave_barrier();
+                    const unsigned carry = (lane < qn - 64) ? q[64 + lane] : 0u;
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < qn - 64) q[lane] = carry;
+                    qn -= 64;
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
         }
+        if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, count, base);
     }
-    if (!FILL) {
-        for (int o = 32; o > 0; o >>= 1) count += __shfl_xor(count, o);
-        if (lane == 0) {
-            a.pcnt[p] = count;
+    if (lane == 0) {
+        if (MODE == SEL_SPANS) {
+            a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
             atomicAdd(a.cand_total, scanned);
+        } else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) {
+            a.pcnt[p] = count;
+            if (MODE == SEL_COUNT) atomicAdd(a.cand_total, scanned);
         }
     }
+}
+
+// pack the sparse per-parent segments [coff[p], coff[p]+pcnt[p]) into the compact CSR [poff[p], ...)
+__global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __restrict__ coff, const int64_t* __restrict__ poff,
+                                                       const unsigned* __restrict__ pcnt, const unsigned* __restrict__ sc,
+                                                       const float* __restrict__ sw, unsigned* __restrict__ dc, float* __restrict__ dw) {
+    const int lane = threadIdx.x & 63;
+    const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (p >= P) return;
+    const int64_t so = coff[p], dof = poff[p];
+    const unsigned n = pcnt[p];
+    for (unsigned k = lane; k < n; k += 64) { dc[dof + k] = sc[so + k]; dw[dof + k] = sw[so + k]; }
 }
 
 // per-child sum of wL_si, sequential in the (stable) sorted pair order (mixture.cpp:162)
@@ -548,12 +631,88 @@ __global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, const int6
     }
 }
 
-// parent flags from 32-bit draws: rand01() < 1/rho with rand01 = float(r) / float(0xffffffff)
-// (base.hpp:53-56, mixture.cpp:257-259)
-__global__ __launch_bounds__(256) void k_flags_from_draws(int64_t n, const unsigned* __restrict__ draws, float prob,
-                                                          uint8_t* __restrict__ is_parent) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float r01 = (float)draws[i] / 4294967296.0f;
+// ------------------------------------------------------------------------------------------------
+// Parent flags from the glibc TYPE_3 rand() stream, generated ON THE DEVICE.
+//
+// libc rand() (what hem::rand() consumes, base.hpp:44-56) is the additive lagged-Fibonacci sequence
+//     y_n = y_{n-3} + y_{n-31}  (mod 2^32),   rand() number k = y_{310+k} >> 1,
+// seeded with 31 words by srand().  The recurrence is linear, so y_{m+k} = sum_j a_k[j] * y_{m+j} with
+// a_k = x^k mod (x^31 - x^28 - 1) over Z/2^32: every thread jumps to the start of its own chunk of the
+// stream by square-and-multiply on precomputed x^(2^b), then runs the recurrence sequentially for
+// its chunk.  Flag i = rand01() < 1/rho with rand01 = float(r)/float(0xffffffff), r = eight
+// successive rand()%16 nibbles, low nibble first (base.hpp:44-56, mixture.cpp:257-259,330).
+// LDS layout is [word][thread] so that the uniform loop indices are bank-conflict free.
+// ------------------------------------------------------------------------------------------------
+#define RNG_THREADS 64
+#define RNG_CHUNK 512
+struct RngBase { unsigned y[31]; };   // y_{-31} .. y_{-1}
+
+__global__ __launch_bounds__(RNG_THREADS) void k_flags_glibc(int64_t n, unsigned long long first_draw, float prob, RngBase base,
+                                                             const unsigned* __restrict__ xpow /* [48][31] */,
+                                                             uint8_t* __restrict__ is_parent) {
+    __shared__ unsigned s_a[31][RNG_THREADS];      // polynomial a_k
+    __shared__ unsigned s_t[31][RNG_THREADS];      // scratch polynomial / later: the 31-word state ring
+    const int t = threadIdx.x;
+    const int64_t chunk = (int64_t)blockIdx.x * RNG_THREADS + t;
+    const int64_t i0 = chunk * RNG_CHUNK;
+    if (i0 >= n) return;
+    // index (in y) of the first rand() value of this chunk
+    unsigned long long k = 310ull + 8ull * (first_draw + (unsigned long long)i0);
+    // a = x^k mod P by square-and-multiply over the bits of k
+    for (int j = 0; j < 31; ++j) s_a[j][t] = j == 0 ? 1u : 0u;
+    for (int b = 0; b < 48; ++b) {
+        if (!((k >> b) & 1ull)) continue;
+        const unsigned* xb = xpow + b * 31;
+        // product of degree <= 60, reduced on the fly: coefficient d of a*xb
+        unsigned hi[30];                              // degrees 31..60
+#pragma unroll
+        for (int d = 60; d >= 31; --d) {
+            unsigned acc = 0;
+            for (int i = d - 30; i <= 30; ++i) acc += s_a[i][t] * xb[d - i];
+            hi[d - 31] = acc;
+        }
+        for (int d = 0; d <= 30; ++d) {
+            unsigned acc = 0;
+            for (int i = 0; i <= d; ++i) acc += s_a[i][t] * xb[d - i];
+            s_t[d][t] = acc;
+        }
+        // x^d = x^(d-3) + x^(d-31), from the top down
+#pragma unroll
+        for (int d = 60; d >= 31; --d) {
+            const unsigned c = hi[d - 31];
+            if (d - 3 >= 31) hi[d - 3 - 31] += c; else s_t[d - 3][t] += c;
+            s_t[d - 31][t] += c;
+        }
+        for (int j = 0; j < 31; ++j) s_a[j][t] = s_t[j][t];
+    }
+    // state ring: y_{k-31+i} = dot(a_{k+i}, base), a_{k+i+1} = x * a_{k+i} mod P
+    unsigned ring[31];
+#pragma unroll
+    for (int i = 0; i < 31; ++i) {
+        unsigned acc = 0;
+        for (int j = 0; j < 31; ++j) acc += s_a[j][t] * base.y[j];
+        ring[i] = acc;
+        const unsigned top = s_a[30][t];
+        for (int j = 30; j >= 1; --j) s_a[j][t] = s_a[j - 1][t];
+        s_a[0][t] = top;
+        s_a[28][t] += top;
+    }
+#pragma unroll
+    for (int i = 0; i < 31; ++i) s_t[i][t] = ring[i];      // slot i holds y_{k-31+i}; y_n lives in slot (n-k) mod 31
+    int f = 0;                                              // slot of y_{n-31} (overwritten by y_n)
+    int r = 28;                                             // slot of y_{n-3}
+    const int64_t iend = (i0 + RNG_CHUNK < n) ? i0 + RNG_CHUNK : n;
+    for (int64_t i = i0; i < iend; ++i) {
+        unsigned x = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const unsigned v = s_t[f][t] + s_t[r][t];
+            s_t[f][t] = v;
+            x |= ((v >> 1) & 15u) << (4 * q);
+            f = f == 30 ? 0 : f + 1;
+            r = r == 30 ? 0 : r + 1;
+        }
+        const float r01 = (float)x / 4294967296.0f;
         is_parent[i] = r01 < prob ? 1 : 0;
     }
 }
@@ -647,15 +806,16 @@ struct gsr_hem_ctx {
     int rng_mode = GSR_RNG_GLIBC;
     uint32_t rng_seed = 1;
     uint64_t rng_pos = 0;           // hem::rand() values consumed so far
-    GlibcRng rng;                   // positioned at rng_pos
+    unsigned rng_base[31];          // y_{-31..-1} of the seeded glibc stream
     bool rng_ready = false;
     Level cur, nxt, tmp;
     bool have_level = false;
     // workspace
     DevBuf det, radius, bbox, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
+    DevBuf pcap, coff, sp_child, sp_wl;
+    bool sparse_path = false;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
-    std::vector<unsigned> h_draws;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -666,12 +826,23 @@ struct gsr_hem_ctx {
 
 namespace {
 
-int32_t sync_rng(gsr_hem_ctx* c) {
-    if (c->rng_ready) return GSR_OK;
-    c->rng.seed(c->rng_seed);
-    for (uint64_t i = 0; i < c->rng_pos; ++i) c->rng.hem_rand();
-    c->rng_ready = true;
-    return GSR_OK;
+// x^(2^b) mod (x^31 - x^28 - 1) over Z/2^32, b = 0..47 (host, once)
+void rng_polymul(const unsigned* a, const unsigned* b, unsigned* out) {
+    unsigned prod[61];
+    for (int d = 0; d < 61; ++d) prod[d] = 0;
+    for (int i = 0; i < 31; ++i) for (int j = 0; j < 31; ++j) prod[i + j] += a[i] * b[j];
+    for (int d = 60; d >= 31; --d) { const unsigned c = prod[d]; prod[d - 3] += c; prod[d - 31] += c; }
+    for (int d = 0; d < 31; ++d) out[d] = prod[d];
+}
+const unsigned* rng_xpow_table() {
+    static unsigned tab[48 * 31];
+    static bool ready = false;
+    if (!ready) {
+        for (int j = 0; j < 31; ++j) tab[j] = j == 1 ? 1u : 0u;                 // x^1
+        for (int b = 1; b < 48; ++b) rng_polymul(tab + (b - 1) * 31, tab + (b - 1) * 31, tab + b * 31);
+        ready = true;
+    }
+    return tab;
 }
 
 // draw n parent flags for `lv` in order (consumes n hem::rand() values)
@@ -683,18 +854,32 @@ int32_t draw_flags(gsr_hem_ctx* c, Level& lv) {
         hipLaunchKernelGGL(k_flags_hash, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, c->rng_seed,
                            (unsigned long long)c->rng_pos, prob, lv.is_parent.as<uint8_t>());
         c->rng_pos += (uint64_t)n;
-        c->rng_ready = false;
         return GSR_OK;
     }
-    GSR_TRY(sync_rng(c));
-    c->h_draws.resize((size_t)n);
-    for (int64_t i = 0; i < n; ++i) c->h_draws[(size_t)i] = c->rng.hem_rand();
+    if (!c->rng_ready) {                      // seed words and the jump table, once per context / reseed
+        unsigned st[31];
+        {   // srand(seed) fills 31 words (Schrage LCG); keep them BEFORE the 310 discarded outputs
+            uint32_t s = c->rng_seed ? c->rng_seed : 1u;
+            int32_t word = (int32_t)s;
+            st[0] = (unsigned)word;
+            for (int i = 1; i < 31; ++i) {
+                int32_t hi = word / 127773, lo = word % 127773;
+                word = 16807 * lo - 2836 * hi;
+                if (word < 0) word += 2147483647;
+                st[i] = (unsigned)word;
+            }
+        }
+        for (int j = 0; j < 31; ++j) c->rng_base[j] = st[(j + 3) % 31];        // y_{-31+j} = x_{(j+3) mod 31}
+        GSR_TRY(c->draws.reserve(48 * 31 * 4));
+        GSR_HIP(hipMemcpyAsync(c->draws.p, rng_xpow_table(), 48 * 31 * 4, hipMemcpyHostToDevice, c->stream));
+        c->rng_ready = true;
+    }
+    RngBase base;
+    for (int j = 0; j < 31; ++j) base.y[j] = c->rng_base[j];
+    const int64_t chunks = (n + RNG_CHUNK - 1) / RNG_CHUNK;
+    hipLaunchKernelGGL(k_flags_glibc, dim3((unsigned)((chunks + RNG_THREADS - 1) / RNG_THREADS)), dim3(RNG_THREADS), 0, c->stream, n,
+                       (unsigned long long)c->rng_pos, prob, base, c->draws.as<unsigned>(), lv.is_parent.as<uint8_t>());
     c->rng_pos += (uint64_t)n;
-    GSR_TRY(c->draws.reserve((size_t)n * 4));
-    GSR_HIP(hipMemcpyAsync(c->draws.p, c->h_draws.data(), (size_t)n * 4, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_flags_from_draws, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, c->draws.as<unsigned>(), prob,
-                       lv.is_parent.as<uint8_t>());
-    GSR_HIP(hipStreamSynchronize(c->stream));   // h_draws is reused by the next call
     return GSR_OK;
 }
 
@@ -765,7 +950,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
@@ -933,9 +1118,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     c->stats[0] = P;
     GSR_HIP(hipEventRecord(c->ev[1], st));
 
-    // ---- 2. selection: count, scan, fill --------------------------------------------------------
+    // ---- 2. selection ------------------------------------------------------------------------------
+    // Fast path (SPARSE): one evaluation pass.  k_select<SPANS> sums the span lengths per parent (an
+    // upper bound of its child count), the pass writes each parent's pairs at the head of a segment of
+    // that capacity, k_compact_pairs packs them.  The sparse buffers cost 8 bytes per candidate
+    // scanned; when that exceeds the budget (GSR_HEM_SPARSE_GB, default 1/3 of free HBM) the two-pass
+    // COUNT + FILL fallback runs instead (same device code, evaluates every candidate twice).
     const size_t Pm = (size_t)(P > 0 ? P : 1);
-    GSR_TRY(c->pcnt.reserve(Pm * 4)); GSR_TRY(c->poff.reserve((Pm + 1) * 8)); GSR_TRY(c->scratch.reserve((Pm + 1) * 8));
+    GSR_TRY(c->pcnt.reserve(Pm * 4)); GSR_TRY(c->pcap.reserve(Pm * 4)); GSR_TRY(c->poff.reserve((Pm + 1) * 8));
+    GSR_TRY(c->coff.reserve((Pm + 1) * 8)); GSR_TRY(c->scratch.reserve((Pm + 1) * 8));
     SelectArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.A = c->A.as<float4>(); sa.B = c->B.as<float4>(); sa.C = c->C.as<float4>(); sa.D = c->D.as<float4>();
@@ -945,39 +1136,66 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.kldThr = c->delta * c->delta * 0.5f;       // mixture.cpp:128
     sa.tau2 = c->tau * c->tau;                    // mixture.cpp:58,61
     sa.pcnt = c->pcnt.as<unsigned>();
+    sa.pcap = c->pcap.as<unsigned>();
     sa.cand_total = c->counters.as<unsigned long long>();
     int64_t M = 0;
-    if (P > 0) {
-        GSR_HIP(hipEventRecord(c->evk[0], st));
-        hipLaunchKernelGGL(k_select<false>, dim3(ceil_div(P, 4)), blk, 0, st, sa);
-        GSR_HIP(hipEventRecord(c->evk[1], st));
-        // offsets: widen counts to int64 and scan
+    const dim3 sgrid(ceil_div(P > 0 ? P : 1, 4));
+    auto widen_scan = [&](const unsigned* cnt, int64_t* off) -> int32_t {      // off = exclusive scan of cnt (int64)
         int64_t* cnt64 = c->scratch.as<int64_t>();
-        {
-            // small helper kernel inline: reuse k_run_starts-free path via rocprim transform
-            GSR_HIP(rocprim::transform(c->pcnt.as<unsigned>(), cnt64, (size_t)P, [] __device__(unsigned v) { return (int64_t)v; }, st));
-        }
-        GSR_TRY(exclusive_scan<int64_t>(c, cnt64, c->poff.as<int64_t>(), P));
-        int64_t last_off = 0;
-        unsigned last_cnt = 0;
+        GSR_HIP(rocprim::transform(cnt, cnt64, (size_t)P, [] __device__(unsigned v) { return (int64_t)v; }, st));
+        return exclusive_scan<int64_t>(c, cnt64, off, P);
+    };
+    if (P > 0) {
+        hipLaunchKernelGGL(k_select<SEL_SPANS>, sgrid, blk, 0, st, sa);
         unsigned long long cand = 0;
-        GSR_HIP(hipMemcpyAsync(&last_off, c->poff.as<int64_t>() + (P - 1), 8, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipMemcpyAsync(&last_cnt, c->pcnt.as<unsigned>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
         GSR_HIP(hipMemcpyAsync(&cand, c->counters.p, 8, hipMemcpyDeviceToHost, st));
         GSR_HIP(hipStreamSynchronize(st));
-        M = last_off + (int64_t)last_cnt;
         c->stats[4] = (int64_t)cand;
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
+        size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 3;
+        if (const char* e = getenv("GSR_HEM_SPARSE_GB")) budget = (size_t)(atof(e) * 1073741824.0);
+        const bool sparse = (double)cand * 8.0 <= (double)budget && cand < (1ull << 40);
+        if (sparse) {
+            GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>()));
+            const size_t Cm = (size_t)(cand > 0 ? cand : 1);
+            GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
+            sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
+            GSR_HIP(hipEventRecord(c->evk[2], st));
+            hipLaunchKernelGGL(k_select<SEL_SPARSE>, sgrid, blk, 0, st, sa);
+            GSR_HIP(hipEventRecord(c->evk[3], st));
+        } else {
+            GSR_HIP(hipMemsetAsync(c->counters.p, 0, 8, st));
+            GSR_HIP(hipEventRecord(c->evk[0], st));
+            hipLaunchKernelGGL(k_select<SEL_COUNT>, sgrid, blk, 0, st, sa);
+            GSR_HIP(hipEventRecord(c->evk[1], st));
+        }
+        GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>()));
+        int64_t last_off = 0;
+        unsigned last_cnt = 0;
+        GSR_HIP(hipMemcpyAsync(&last_off, c->poff.as<int64_t>() + (P - 1), 8, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipMemcpyAsync(&last_cnt, c->pcnt.as<unsigned>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        M = last_off + (int64_t)last_cnt;
+        const size_t Mm = (size_t)(M > 0 ? M : 1);
+        GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
+        GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
+        if (M > 0) {
+            if (sparse) {
+                hipLaunchKernelGGL(k_compact_pairs, sgrid, blk, 0, st, P, c->coff.as<int64_t>(), c->poff.as<int64_t>(), c->pcnt.as<unsigned>(),
+                                   c->sp_child.as<unsigned>(), c->sp_wl.as<float>(), c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
+            } else {
+                sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
+                GSR_HIP(hipEventRecord(c->evk[2], st));
+                hipLaunchKernelGGL(k_select<SEL_FILL>, sgrid, blk, 0, st, sa);
+                GSR_HIP(hipEventRecord(c->evk[3], st));
+            }
+        }
+        c->sparse_path = sparse;
+    } else {
+        GSR_TRY(c->pair_child.reserve(4)); GSR_TRY(c->pair_wl.reserve(4)); GSR_TRY(c->spair_child.reserve(4)); GSR_TRY(c->spair_wl.reserve(4));
     }
     c->stats[1] = M;
-    const size_t Mm = (size_t)(M > 0 ? M : 1);
-    GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
-    GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
-    if (M > 0) {
-        sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
-        GSR_HIP(hipEventRecord(c->evk[2], st));
-        hipLaunchKernelGGL(k_select<true>, dim3(ceil_div(P, 4)), blk, 0, st, sa);
-        GSR_HIP(hipEventRecord(c->evk[3], st));
-    }
     GSR_HIP(hipEventRecord(c->ev[2], st));
 
     // ---- 3. per-child sums of wL (deterministic: stable sort by child, sequential sum) ----------
@@ -1068,8 +1286,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&c->phase_ms[5], c->ev[0], c->ev[5]);
     c->phase_ms[6] = c->phase_ms[7] = 0.0f;
-    if (P > 0) (void)hipEventElapsedTime(&c->phase_ms[6], c->evk[0], c->evk[1]);
-    if (M > 0) (void)hipEventElapsedTime(&c->phase_ms[7], c->evk[2], c->evk[3]);
+    if (P > 0 && !c->sparse_path) (void)hipEventElapsedTime(&c->phase_ms[6], c->evk[0], c->evk[1]);
+    if (P > 0 && (M > 0 || c->sparse_path)) (void)hipEventElapsedTime(&c->phase_ms[7], c->evk[2], c->evk[3]);
     if (n_out) *n_out = c->cur.n;
     if (n_dropped) *n_dropped = dropped;
     return GSR_OK;

@@ -78,6 +78,11 @@ class HemMixture:
     def __exit__(self, *exc):
         self.close()
 
+    def set_rng(self, mode="glibc", seed=1, skip=0):
+        """Reposition the parent-flag stream (e.g. to replay a fresh reference process on a reused context)."""
+        m = {"glibc": _lib.GSR_RNG_GLIBC, "hash": _lib.GSR_RNG_HASH}[mode]
+        _lib.check(self._L.gsr_hem_set_rng(self._h, m, seed, skip), "gsr_hem_set_rng")
+
     # -- level 0 -----------------------------------------------------------------------------------
     def set_level0(self, xyz, colors, opacities, covariance, features):
         """``MixtureLevel.CreateMixtureLevel`` argument order (``mixturelevel.hpp:17-22``)."""

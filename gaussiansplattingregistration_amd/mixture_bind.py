@@ -129,8 +129,9 @@ def _as_array(a, width, what):
             raise RuntimeError(f"Python list must have exactly {width} elements." if width > 1 else f"ragged {what}")
     if width == 1:
         return np.ascontiguousarray(arr, dtype=np.float32).reshape(-1)
-    if arr.size == 0:
-        return np.zeros((0, max(width, 0)), np.float32)
+    if arr.size == 0:                     # empty level, or F = 0 feature rows: keep the row count
+        rows = arr.shape[0] if arr.ndim >= 1 else 0
+        return np.zeros((rows, arr.shape[1] if (arr.ndim == 2 and width == 0) else max(width, 0)), np.float32)
     if arr.ndim != 2 or (width > 0 and arr.shape[1] != width):
         raise RuntimeError(f"Python list must have exactly {width} elements.")
     return np.ascontiguousarray(arr, dtype=np.float32)

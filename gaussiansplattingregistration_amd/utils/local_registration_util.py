@@ -119,7 +119,7 @@ def get_rejection_loss(rejection_type, k_value, registration_type):
 
 
 def registration_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, device=None,
-                     allreduce=None, n_source_global=None):
+                     allreduce=None, n_source_global=None, ctx=None):
     """``o3d.pipelines.registration.registration_icp`` on ``PointCloud`` records (see ``point_cloud.py``)."""
     if not (max_correspondence_distance > 0.0):
         raise RuntimeError("[Open3D Error] Invalid max_correspondence_distance.")
@@ -130,7 +130,10 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
         raise NotImplementedError(f"{estimation_method.name} is not part of this backend yet (SURVEY.md 8f, N2)")
     dev = device if device is not None else getattr(target, "device_index", 0)
     loss = estimation_method.loss or RobustLoss(_icp.LOSS_L2)
-    with _icp.IcpContext(device=dev) as ctx:
+    own = ctx is None            # a caller-provided context keeps its workspace across calls (no allocation in steady state)
+    if own:
+        ctx = _icp.IcpContext(device=dev)
+    try:
         ctx.set_target(target.xyz32, target.normals if estimation_method.kind == _icp.KIND_POINT_TO_PLANE else None,
                        max_correspondence_distance)
         ctx.set_source(source.xyz32)
@@ -141,6 +144,9 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
         res = _icp.RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], r["iterations"])
         res.timing = ctx.timing()
         return res
+    finally:
+        if own:
+            ctx.close()
 
 
 def do_icp_registration(point_cloud_first, point_cloud_second, init_transform, registration_params, *extra, **kw):
