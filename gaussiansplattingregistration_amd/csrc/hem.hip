@@ -7,8 +7,8 @@
 //   level arrays (HBM, row-major, as the C ABI hands them over)
 //       xyz[n][3] color[n][3] cov6[n][6] opacity[n] weight[n] sh[n][F] is_parent[n]
 //   per-level working set, all in CELL-SORTED order (j = sorted position, order[j] = input index)
-//       A[j] = {x, y, z, det}            B[j] = {c00, c01, c02, c11}
-//       C[j] = {c12, c22, col_r, col_g}  D[j] = {col_b, opacity, weight, flags}     (float4 each:
+//       A[j] = {x, y, z, flags}          B[j] = {c00, c01, c02, c11}
+//       C[j] = {c12, c22, col_r, col_g}  D[j] = {col_b, opacity, weight, det}       (float4 each:
 //       one 16-byte load per lane, 1 KiB per wave instruction, candidates of a cell row contiguous)
 //       Rs[j] query radius, shs[j][F] SH rest, cellStart[cells+1] prefix table of a dense uniform grid
 //   pair list (parent-major CSR): pair_child[M] (sorted position), pair_wl[M] (w_s * clamp(L_si))
@@ -119,19 +119,46 @@ __device__ __forceinline__ float wave_sum(float v) {
 // k_prep: det, parent query radius, bounding box of the finite centres
 //   radius = delta * sqrtf(lambda_max)                       (mixture.cpp:88)
 // ------------------------------------------------------------------------------------------------
+// Is this component "regular" for the stage-1 Mahalanobis pre-reject of k_select?  Finite, positive
+// definite (Sylvester), sane magnitudes and condition number <= ~80, judged on float32 closed-form
+// eigenvalues (accuracy ~1e-4 lambda_max is ample for a threshold at lambda_min > 0.0125 lambda_max).
+__device__ __forceinline__ bool is_regular(const s6& c, float det, float x, float y, float z) {
+    const float big = 1e12f;
+    if (!(fabsf(x) < big && fabsf(y) < big && fabsf(z) < big)) return false;
+    if (!(fabsf(c.e00) < big && fabsf(c.e01) < big && fabsf(c.e02) < big && fabsf(c.e11) < big && fabsf(c.e12) < big && fabsf(c.e22) < big)) return false;
+    const float m2 = c.e00 * c.e11 - c.e01 * c.e01;
+    if (!(c.e00 > 1e-12f && m2 > 0.0f && det > 1e-36f)) return false;
+    // eigenvalues of the symmetric 3x3 (trigonometric form, float32)
+    const float q = (c.e00 + c.e11 + c.e22) * (1.0f / 3.0f);
+    const float b00 = c.e00 - q, b11 = c.e11 - q, b22 = c.e22 - q;
+    const float p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0f * (c.e01 * c.e01 + c.e02 * c.e02 + c.e12 * c.e12);
+    const float pp = sqrtf(p2 * (1.0f / 6.0f));
+    if (!(pp > 0.0f)) return true;                      // isotropic: kappa = 1
+    const float ip = 1.0f / pp;
+    const float a00 = b00 * ip, a11 = b11 * ip, a22 = b22 * ip, a01 = c.e01 * ip, a02 = c.e02 * ip, a12 = c.e12 * ip;
+    float hd = 0.5f * (a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02));
+    hd = fminf(fmaxf(hd, -1.0f), 1.0f);
+    const float phi = acosf(hd) * (1.0f / 3.0f);
+    const float lmax = q + 2.0f * pp * cosf(phi);
+    const float lmin = q + 2.0f * pp * cosf(phi + 2.0943951023931953f);
+    return lmin > 0.0125f * lmax && lmax > 0.0f;
+}
+
 __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict__ xyz,
                                               const float* __restrict__ cov6,
                                               const uint8_t* __restrict__ is_parent, float delta,
                                               float* __restrict__ det, float* __restrict__ radius,
-                                              unsigned* __restrict__ bbox) {
+                                              uint8_t* __restrict__ regular, unsigned* __restrict__ bbox) {
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         s6 c = {cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5]};
-        det[i] = det6(c);
+        const float dt = det6(c);
+        det[i] = dt;
         float R = 0.0f;
         if (is_parent[i]) R = delta * sqrtf(eig_max6(c));
         radius[i] = R;
         float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        regular[i] = is_regular(c, dt, x, y, z) ? 1 : 0;
         if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX) {   // finite only
             mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
             mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
@@ -215,17 +242,18 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
                                                 const float* __restrict__ cov6, const float* __restrict__ opacity,
                                                 const float* __restrict__ weight, const uint8_t* __restrict__ is_parent,
                                                 const float* __restrict__ det, const float* __restrict__ radius,
-                                                float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
+                                                const uint8_t* __restrict__ regular, float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
                                                 float4* __restrict__ D, float* __restrict__ Rs, int* __restrict__ pflag) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = order[j];
-        const unsigned fl = is_parent[i] ? 1u : 0u;
-        A[j] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], det[i]);
+        const unsigned par = is_parent[i] ? 1u : 0u;
+        const unsigned fl = par | (regular[i] ? 2u : 0u);           // bit 0 parent, bit 1 regular
+        A[j] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __uint_as_float(fl));
         B[j] = make_float4(cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3]);
         C[j] = make_float4(cov6[6 * i + 4], cov6[6 * i + 5], color[3 * i], color[3 * i + 1]);
-        D[j] = make_float4(color[3 * i + 2], opacity[i], weight[i], __uint_as_float(fl));
+        D[j] = make_float4(color[3 * i + 2], opacity[i], weight[i], det[i]);
         Rs[j] = radius[i];
-        pflag[j] = (int)fl;
+        pflag[j] = (int)par;
     }
 }
 __global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, const unsigned* __restrict__ order,
@@ -271,7 +299,6 @@ struct SelectArgs {
     float colorThr, kldThr, tau2;
     unsigned* pcnt;                 // COUNT / SPARSE out: accepted pairs per parent
     unsigned* pcap;                 // SPANS out: candidates scanned per parent
-    unsigned long long* cand_total; // SPANS / COUNT: total candidates scanned
     const int64_t* poff;            // FILL: compact offsets;  SPARSE: capacity offsets
     unsigned* pair_child;
     float* pair_wl;
@@ -284,6 +311,7 @@ struct ParentRec {
     f3 pm, pcol;
     s6 pinv;
     float det_p, pweight, R2;
+    float smdMax;      // stage-1 pre-reject bound on the squared Mahalanobis distance (+inf = disabled)
     int js;
 };
 
@@ -304,11 +332,11 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
         if (!(cdiff > a.colorThr)) {                          // mixture.cpp:122-124
             const float4 cb = a.B[j];
             const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
-            const float det_c = ca.w;
+            const float det_c = cd.w;
             const f3 d = sub3(cm, pr.pm);
             const float k = kld6(d, ccov, det_c, pr.pinv, pr.det_p);
             if (!(k > a.kldThr)) {                            // mixture.cpp:126-129 (NaN passes)
-                const bool child_is_parent = (__float_as_uint(cd.w) & 1u) != 0u;
+                const bool child_is_parent = (__float_as_uint(ca.w) & 1u) != 0u;
                 if (!(child_is_parent && j != pr.js)) {       // mixture.cpp:131-133
                     acc = true;
                     if (MODE != SEL_COUNT) {
@@ -348,7 +376,13 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
     {
         const float4 pa = a.A[pr.js], pb = a.B[pr.js], pc = a.C[pr.js], pd = a.D[pr.js];
         pr.pm = {pa.x, pa.y, pa.z};
-        pr.det_p = pa.w;
+        pr.det_p = pd.w;
+        // Stage-1 pre-reject (exactness argument in DESIGN.md "KL gate pre-reject"): for a regular parent
+        // and a regular child, tr(P^-1 C) - 3 - ln(|C|/|P|) >= 0 in exact arithmetic and the reference's
+        // float32 evaluation of it is >= -0.15, so  smd > 2*thr + 0.2 (+0.1%)  implies  KLD_float32 > thr:
+        // the pair is rejected by the reference too, and no NaN can arise.  smd itself is the SAME
+        // float32 expression the KL gate evaluates.
+        pr.smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * a.kldThr + 0.2f) * 1.001f : __builtin_inff();
         const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
         pr.pcol = {pc.z, pc.w, pd.x};
         pr.pweight = pd.z;
@@ -424,6 +458,11 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
                     const f3 cm = {ca.x, ca.y, ca.z};
                     const f3 dq = sub3(pm, cm);                           // query - point (pointindex.cpp:137)
                     in = dot3(dq, dq) < pr.R2;
+                    if (in && (__float_as_uint(ca.w) & 2u)) {             // regular child: Mahalanobis pre-reject
+                        const f3 d = sub3(cm, pm);
+                        const float smd = dot3(d, mul6(pr.pinv, d));      // gaussian.hpp:82-85, as kld6 computes it
+                        in = !(smd > pr.smdMax);
+                    }
                 }
                 const unsigned long long m = __ballot(in);
                 if (in) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)j;
@@ -442,14 +481,9 @@ __global__ __launch_bounds__(256) void k_select(SelectArgs a) {
         }
         if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, count, base);
     }
-    if (lane == 0) {
-        if (MODE == SEL_SPANS) {
-            a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
-            atomicAdd(a.cand_total, scanned);
-        } else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) {
-            a.pcnt[p] = count;
-            if (MODE == SEL_COUNT) atomicAdd(a.cand_total, scanned);
-        }
+    if (lane == 0) {       // no global atomics here: one hot address serialises 10^6 waves (totals come from the scans)
+        if (MODE == SEL_SPANS) a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
+        else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[p] = count;
     }
 }
 
@@ -811,6 +845,7 @@ struct gsr_hem_ctx {
     Level cur, nxt, tmp;
     bool have_level = false;
     // workspace
+    DevBuf regular;
     DevBuf det, radius, bbox, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl;
     bool sparse_path = false;
@@ -950,7 +985,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->regular, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
@@ -1071,7 +1106,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_HIP(hipEventRecord(c->ev[0], st));
 
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
-    GSR_TRY(c->det.reserve(n * 4)); GSR_TRY(c->radius.reserve(n * 4)); GSR_TRY(c->bbox.reserve(64));
+    GSR_TRY(c->det.reserve(n * 4)); GSR_TRY(c->radius.reserve(n * 4)); GSR_TRY(c->bbox.reserve(64)); GSR_TRY(c->regular.reserve(n));
     GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(64));
     {
         unsigned init[6];
@@ -1085,7 +1120,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
     }
     hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.cov6.as<float>(), L.is_parent.as<uint8_t>(), c->delta,
-                       c->det.as<float>(), c->radius.as<float>(), c->bbox.as<unsigned>());
+                       c->det.as<float>(), c->radius.as<float>(), c->regular.as<uint8_t>(), c->bbox.as<unsigned>());
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1), 0, st, c->bbox.as<unsigned>(), n, c->cell_target, c->max_cells,
                        c->gparams.as<GridParams>());
     GridParams gp;
@@ -1105,7 +1140,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->shs.reserve((size_t)n * (F > 0 ? F : 1) * 4));
     hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(),
                        L.opacity.as<float>(), L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->det.as<float>(), c->radius.as<float>(),
-                       c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>());
+                       c->regular.as<uint8_t>(), c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>());
     if (F > 0)
         hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
@@ -1137,7 +1172,6 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.tau2 = c->tau * c->tau;                    // mixture.cpp:58,61
     sa.pcnt = c->pcnt.as<unsigned>();
     sa.pcap = c->pcap.as<unsigned>();
-    sa.cand_total = c->counters.as<unsigned long long>();
     int64_t M = 0;
     const dim3 sgrid(ceil_div(P > 0 ? P : 1, 4));
     auto widen_scan = [&](const unsigned* cnt, int64_t* off) -> int32_t {      // off = exclusive scan of cnt (int64)
@@ -1147,9 +1181,16 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     };
     if (P > 0) {
         hipLaunchKernelGGL(k_select<SEL_SPANS>, sgrid, blk, 0, st, sa);
+        GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>()));
         unsigned long long cand = 0;
-        GSR_HIP(hipMemcpyAsync(&cand, c->counters.p, 8, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipStreamSynchronize(st));
+        {
+            int64_t last_off = 0;
+            unsigned last_cap = 0;
+            GSR_HIP(hipMemcpyAsync(&last_off, c->coff.as<int64_t>() + (P - 1), 8, hipMemcpyDeviceToHost, st));
+            GSR_HIP(hipMemcpyAsync(&last_cap, c->pcap.as<unsigned>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
+            GSR_HIP(hipStreamSynchronize(st));
+            cand = (unsigned long long)last_off + last_cap;
+        }
         c->stats[4] = (int64_t)cand;
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -1157,7 +1198,6 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         if (const char* e = getenv("GSR_HEM_SPARSE_GB")) budget = (size_t)(atof(e) * 1073741824.0);
         const bool sparse = (double)cand * 8.0 <= (double)budget && cand < (1ull << 40);
         if (sparse) {
-            GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>()));
             const size_t Cm = (size_t)(cand > 0 ? cand : 1);
             GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
             sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
@@ -1165,7 +1205,6 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             hipLaunchKernelGGL(k_select<SEL_SPARSE>, sgrid, blk, 0, st, sa);
             GSR_HIP(hipEventRecord(c->evk[3], st));
         } else {
-            GSR_HIP(hipMemsetAsync(c->counters.p, 0, 8, st));
             GSR_HIP(hipEventRecord(c->evk[0], st));
             hipLaunchKernelGGL(k_select<SEL_COUNT>, sgrid, blk, 0, st, sa);
             GSR_HIP(hipEventRecord(c->evk[1], st));

@@ -206,12 +206,14 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float*
     block_reduce_store<NACC>(acc, partials);
 }
 
-__global__ void k_icp_finalize(int nblocks, const double* __restrict__ partials, double* __restrict__ out) {
-    const int k = threadIdx.x;
-    if (k >= GSR_ICP_ACC_LEN) return;
+// One wavefront per accumulator: lane l sums the partials of blocks l, l+64, ... in order, then a fixed
+// shuffle tree combines the 64 lane sums -- a deterministic order whatever the launch.
+__global__ __launch_bounds__(64) void k_icp_finalize(int nblocks, const double* __restrict__ partials, double* __restrict__ out) {
+    const int k = blockIdx.x, lane = threadIdx.x;
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += partials[(int64_t)b * GSR_ICP_ACC_LEN + k];
-    out[k] = s;
+    for (int b = lane; b < nblocks; b += 64) s += partials[(int64_t)b * GSR_ICP_ACC_LEN + k];
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) out[k] = s;
 }
 
 __global__ __launch_bounds__(256) void k_icp_correspond(int64_t ns, const float* __restrict__ src, Xform T, IcpGrid g,
@@ -462,7 +464,7 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     else
         hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(),
                            c->Tq.as<float4>(), c->Tn.as<double>(), mc2, loss, k, c->partials.as<double>());
-    hipLaunchKernelGGL(k_icp_finalize, dim3(1), dim3(64), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>());
+    hipLaunchKernelGGL(k_icp_finalize, dim3(GSR_ICP_ACC_LEN), dim3(64), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>());
     if (timed) GSR_HIP(hipEventRecord(c->e1, st));
     GSR_HIP(hipMemcpyAsync(acc, c->acc_dev.p, GSR_ICP_ACC_LEN * 8, hipMemcpyDeviceToHost, st));
     GSR_HIP(hipStreamSynchronize(st));
