@@ -102,6 +102,16 @@ __device__ __forceinline__ int cell_of(float v, float o, float inv_c, int g) {
     return (int)t;
 }
 
+// XCD-aware block remap (MI355X: 8 XCDs, each with its own 4 MiB L2; blocks are dealt round-robin over
+// the XCDs).  Blocks b, b+8, b+16, ... share an XCD, so give them CONSECUTIVE logical tiles: every XCD
+// then sweeps its own contiguous run of cell-sorted parents and the children they share stay in that
+// XCD's L2.  Launch with a grid of 8*ceil(nblk/8) blocks; returns -1 for the padding blocks.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int chunk = (nblk + 7) >> 3;
+    const int t = (bid & 7) * chunk + (bid >> 3);
+    return t < nblk ? t : -1;
+}
+
 __device__ __forceinline__ float wave_min(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
     return v;
@@ -364,11 +374,12 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     count += (unsigned)__popcll(m);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void k_select(SelectArgs a) {
-    __shared__ unsigned s_q[4][SEL_QCAP];
+// WPB = wavefronts (= parents) per workgroup (runtime choice, GSR_HEM_WPB).
+template <int MODE, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
+    __shared__ unsigned s_q[WPB][SEL_QCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int p = blockIdx.x * 4 + wv;
+    const int p = blockIdx.x * WPB + wv;
     if (p >= a.P) return;
     const GridParams g = *a.gp;
     ParentRec pr;
@@ -542,11 +553,12 @@ struct MstepArgs {
 };
 
 #define MSTEP_CHUNK 256
-__global__ __launch_bounds__(256) void k_mstep(MstepArgs a) {
-    __shared__ float s_w[4][MSTEP_CHUNK];
-    __shared__ unsigned s_j[4][MSTEP_CHUNK];
+template <int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
+    __shared__ float s_w[WPB][MSTEP_CHUNK];
+    __shared__ unsigned s_j[WPB][MSTEP_CHUNK];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int p = blockIdx.x * 4 + wv;
+    const int p = blockIdx.x * WPB + wv;
     if (p >= a.P) return;
     const int js = (int)a.plist[p];
     const float4 pa = a.A[js];
@@ -856,6 +868,8 @@ struct gsr_hem_ctx {
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of k_select<COUNT> and k_select<FILL>
     float cell_target = 8.0f;
+    int wpb = 2, wpb_m = 1;      // parents per workgroup in k_select / k_mstep (measured on MI355X: work per parent is
+                                 // heavy-tailed, small workgroups free their CU slot sooner; 4/8/16 were 10-120% slower)
     int max_cells = 1 << 24;
 };
 
@@ -973,6 +987,8 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         hipError_t e = hipEventCreate(&c->evk[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
+    if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb = v; }
+    if (const char* s = getenv("GSR_HEM_WPB_M")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb_m = v; }
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     *out = c;
     return GSR_OK;
@@ -1174,13 +1190,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.pcap = c->pcap.as<unsigned>();
     int64_t M = 0;
     const dim3 sgrid(ceil_div(P > 0 ? P : 1, 4));
+    const int wpb = c->wpb;
     auto widen_scan = [&](const unsigned* cnt, int64_t* off) -> int32_t {      // off = exclusive scan of cnt (int64)
         int64_t* cnt64 = c->scratch.as<int64_t>();
         GSR_HIP(rocprim::transform(cnt, cnt64, (size_t)P, [] __device__(unsigned v) { return (int64_t)v; }, st));
         return exclusive_scan<int64_t>(c, cnt64, off, P);
     };
     if (P > 0) {
-        hipLaunchKernelGGL(k_select<SEL_SPANS>, sgrid, blk, 0, st, sa);
+        switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_SPANS, 1>), dim3(P), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_SPANS, 2>), dim3(ceil_div(P, 2)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_SPANS, 4>), dim3(ceil_div(P, 4)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_SPANS, 8>), dim3(ceil_div(P, 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_SPANS, 16>), dim3(ceil_div(P, 16)), dim3(1024), 0, st, sa); break; }
         GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>()));
         unsigned long long cand = 0;
         {
@@ -1202,11 +1219,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
             sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
             GSR_HIP(hipEventRecord(c->evk[2], st));
-            hipLaunchKernelGGL(k_select<SEL_SPARSE>, sgrid, blk, 0, st, sa);
+            switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_SPARSE, 1>), dim3(P), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_SPARSE, 2>), dim3(ceil_div(P, 2)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_SPARSE, 4>), dim3(ceil_div(P, 4)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_SPARSE, 8>), dim3(ceil_div(P, 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_SPARSE, 16>), dim3(ceil_div(P, 16)), dim3(1024), 0, st, sa); break; }
             GSR_HIP(hipEventRecord(c->evk[3], st));
         } else {
             GSR_HIP(hipEventRecord(c->evk[0], st));
-            hipLaunchKernelGGL(k_select<SEL_COUNT>, sgrid, blk, 0, st, sa);
+            switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_COUNT, 1>), dim3(P), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_COUNT, 2>), dim3(ceil_div(P, 2)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_COUNT, 4>), dim3(ceil_div(P, 4)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_COUNT, 8>), dim3(ceil_div(P, 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_COUNT, 16>), dim3(ceil_div(P, 16)), dim3(1024), 0, st, sa); break; }
             GSR_HIP(hipEventRecord(c->evk[1], st));
         }
         GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>()));
@@ -1226,7 +1243,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             } else {
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
                 GSR_HIP(hipEventRecord(c->evk[2], st));
-                hipLaunchKernelGGL(k_select<SEL_FILL>, sgrid, blk, 0, st, sa);
+                switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_FILL, 1>), dim3(P), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_FILL, 2>), dim3(ceil_div(P, 2)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_FILL, 4>), dim3(ceil_div(P, 4)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_FILL, 8>), dim3(ceil_div(P, 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_FILL, 16>), dim3(ceil_div(P, 16)), dim3(1024), 0, st, sa); break; }
                 GSR_HIP(hipEventRecord(c->evk[3], st));
             }
         }
@@ -1277,7 +1294,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.P = P; ma.F = F;
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
-        hipLaunchKernelGGL(k_mstep, dim3(ceil_div(P, 4)), blk, 0, st, ma);
+        switch (c->wpb_m) {
+            case 1: hipLaunchKernelGGL(k_mstep<1>, dim3(P), dim3(64), 0, st, ma); break;
+            case 2: hipLaunchKernelGGL(k_mstep<2>, dim3(ceil_div(P, 2)), dim3(128), 0, st, ma); break;
+            case 4: hipLaunchKernelGGL(k_mstep<4>, dim3(ceil_div(P, 4)), dim3(256), 0, st, ma); break;
+            case 8: hipLaunchKernelGGL(k_mstep<8>, dim3(ceil_div(P, 8)), dim3(512), 0, st, ma); break;
+            default: hipLaunchKernelGGL(k_mstep<16>, dim3(ceil_div(P, 16)), dim3(1024), 0, st, ma); break;
+        }
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),

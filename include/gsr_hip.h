@@ -101,7 +101,8 @@ int32_t gsr_hem_get_stats(gsr_hem_ctx* ctx, int64_t* out8);
 /* Device time of the phases of the most recent level, in milliseconds (hipEvent pairs on the
  * context's stream):  [0] prep+grid  [1] selection (count+scan+fill)  [2] per-child sums
  * [3] M-step + orphans  [4] flags+validity  [5] whole level
- * [6] the k_select<COUNT> launch alone  [7] the k_select<FILL> launch alone */
+ * [6] the k_select<COUNT> launch alone (two-pass fallback only, else 0)
+ * [7] the k_select<SPARSE> launch alone (or k_select<FILL> on the fallback) */
 int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* ctx, float* out8);
 
 /* ------------------------------------------------------------------------------------------- ICP */

@@ -1,0 +1,20 @@
+"""One cloud, N splats, L HEM levels on the GPU -- a short target for rocprofv3 / PMC passes and sweeps."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from gaussiansplattingregistration_amd import hem, synth
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
+L = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+c = synth.make_cloud_torch(n, seed=100)
+m = hem.HemMixture()
+for rep in range(reps):
+    m.set_rng("glibc", 1, 0)
+    m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+    for l in range(L):
+        torch.cuda.synchronize(); t = time.perf_counter()
+        m.run_level()
+        torch.cuda.synchronize(); dt = time.perf_counter() - t
+        st = m.stats()
+        print(f"rep{rep} L{l+1}: wall {dt*1e3:.2f} ms", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}, flush=True)
