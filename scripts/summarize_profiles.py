@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 output of scripts/gpu_round.sh into the small tracked files under profiles/.
+
+usage: python scripts/summarize_profiles.py gpurun_out/r01 profiles/r01
+Writes <dst>_kernel_stats.csv (the --stats summary, kernel names shortened), <dst>_pmc.json (per-kernel
+counter sums / launch, with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applied where
+stated) and copies the bench JSON lines."""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+
+
+def short(name):
+    name = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", name)
+    m = re.search(r"(radix_sort_\w+|scan_\w+|lookback_scan\w*|transform_\w+|init_\w+)", name)
+    if "rocprim" in name and m:
+        return "rocprim::" + m.group(1)
+    name = re.sub(r"\(.*", "", name).replace("void ", "")
+    return name[:90]
+
+
+f = glob.glob(os.path.join(src, "prof_stats", "*", "*kernel_stats.csv"))
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    agg = collections.OrderedDict()
+    for r in rows:
+        k = short(r["Name"])
+        a = agg.setdefault(k, [0, 0.0, 1e30, 0.0])
+        a[0] += int(r["Calls"]); a[1] += float(r["TotalDurationNs"]); a[2] = min(a[2], float(r["MinNs"])); a[3] = max(a[3], float(r["MaxNs"]))
+    tot = sum(a[1] for a in agg.values())
+    with open(dst + "_kernel_stats.csv", "w") as o:
+        o.write("kernel,calls,total_ms,avg_ms,pct,min_ms,max_ms\n")
+        for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+            o.write(f"{k},{a[0]},{a[1]/1e6:.3f},{a[1]/a[0]/1e6:.4f},{100*a[1]/tot:.2f},{a[2]/1e6:.4f},{a[3]/1e6:.4f}\n")
+
+pmc = collections.defaultdict(lambda: collections.defaultdict(float))
+launches = collections.defaultdict(int)
+for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+        seen = set()
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if not k.startswith("gsr::"):
+                continue
+            pmc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+            key = (d, k, r["Dispatch_Id"])
+            if d == "pmc_fetch" and key not in seen:
+                seen.add(key); launches[k] += 1
+out = {}
+for k, v in pmc.items():
+    n = max(1, launches.get(k, 1))
+    e = {"launches_in_pass": n}
+    for c, val in v.items():
+        e[c + "_per_launch"] = val / n
+    if "FETCH_SIZE" in v:
+        # FETCH_SIZE/WRITE_SIZE are in KiB; gfx950 reports half the bytes of wide coalesced reads (MI355X_MICROARCH.md, HBM)
+        e["hbm_read_bytes_per_launch_x2_corrected"] = v["FETCH_SIZE"] * 1024 * 2 / n
+        e["hbm_read_bytes_per_launch_raw"] = v["FETCH_SIZE"] * 1024 / n
+    if "WRITE_SIZE" in v:
+        e["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024 / n
+    if "TCC_HIT_sum" in v:
+        e["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    out[k] = e
+json.dump(out, open(dst + "_pmc.json", "w"), indent=1, sort_keys=True)
+for name in ("bench.json", "bench_prof.json", "pytest_gpu.log", "smoke.log"):
+    p = os.path.join(src, name)
+    if os.path.exists(p):
+        shutil.copy(p, dst + "_" + name)
+print("wrote", dst + "_kernel_stats.csv", dst + "_pmc.json")
