@@ -10,7 +10,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgsr_hip.so")
+LIB_PATH = os.environ.get("GSR_HIP_LIB") or os.path.join(_HERE, "csrc", "libgsr_hip.so")   # GSR_HIP_LIB: A/B builds
 
 GSR_OK = 0
 GSR_E_INVALID = -1

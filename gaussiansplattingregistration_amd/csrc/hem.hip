@@ -286,9 +286,9 @@ __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __re
 //
 //   rows      the grid rows (fixed y,z cell) that meet the query sphere; lane r of a 64-row batch
 //             computes the contiguous span [s,e) of sorted components of its row, x-clipped to the sphere
-//   flatten   a wave inclusive scan of the span lengths turns the batch into ONE virtual candidate
-//             array; each lane finds its candidate by a 6-step shuffle binary search, so the radius
-//             test runs with all 64 lanes busy whatever the span lengths are
+//   stream    a row's span is contiguous in the sorted arrays: groups of 16/32/64 lanes (chosen per
+//             batch from the mean row length) each walk one row with strided indices, 4/2/1 rows in
+//             flight -- no per-candidate search, coalesced 16-byte loads
 //   stage 1   exact radius test  d2 < R^2  (pointindex.cpp:137); survivors are compacted (ballot +
 //             popcount) into a per-wave LDS queue
 //   stage 2   whenever the queue holds >= 64 survivors: colour gate, KL gate, parent rule on 64
@@ -315,7 +315,8 @@ struct SelectArgs {
 };
 
 enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2, SEL_SPANS = 3 };
-#define SEL_QCAP 128
+#define SEL_QCAP 512          // survivor ring (power of two >= 64 + SEL_U*64)
+#define SEL_U 4            // row steps whose candidate loads are in flight together
 
 struct ParentRec {
     f3 pm, pcol;
@@ -325,53 +326,72 @@ struct ParentRec {
     int js;
 };
 
-// stage 2 on up to 64 queued survivors (lane < cnt holds one)
+// wL_si = w_s * clamp(hemLikelihoodOpacity, FLT_MIN, 1e8)   (mixture.cpp:54-64,155-158)
+__device__ __forceinline__ float wl_of(const SelectArgs& a, const ParentRec& pr, int j) {
+    const float4 ca = a.A[j], cc = a.C[j], cd = a.D[j];
+    const f3 cm = {ca.x, ca.y, ca.z};
+    const f3 ccol = {cc.z, cc.w, cd.x};
+    const f3 dc = sub3(ccol, pr.pcol);
+    const float cdiff = sqrtf(dot3(dc, dc));                      // = dist(parent.color, child.color)
+    const f3 dq = sub3(pr.pm, cm);
+    const float distanceDiff = sqrtf(dot3(dq, dq));
+    const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
+    const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
+    const float L = distWeight * cd.y * colorInfluence * sqrtf(cd.w);
+    return pr.pweight * ref_clamp(L, FLT_MIN, 1e8f);
+}
+
+// stage 2 on up to 64 queued survivors (lane < cnt holds one): colour gate, KL gate, parent rule.
+// The KL gate's log is the expensive part (float64 table algorithm).  For a regular pair the gate is
+// first decided with a fast log: kld_fast differs from the reference value by far less than the
+// margin m, so  kld_fast > thr + m  =>  KLD > thr  and  kld_fast < thr - m  =>  !(KLD > thr);  only the
+// lanes in between (a few per 10^4), and every irregular pair, evaluate the exact expression.
 template <int MODE>
-__device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, const unsigned* q,
+__device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, const unsigned* q, int qh,
                                               unsigned& count, int64_t& base) {
     bool acc = false;
-    float wl = 0.0f;
     int j = 0;
     if (lane < cnt) {
-        j = (int)q[lane];
-        const float4 ca = a.A[j], cc = a.C[j], cd = a.D[j];
+        j = (int)q[(qh + lane) & (SEL_QCAP - 1)];
+        const float4 ca = a.A[j], cb = a.B[j], cc = a.C[j], cd = a.D[j];   // all four up front: one round trip
         const f3 cm = {ca.x, ca.y, ca.z};
         const f3 ccol = {cc.z, cc.w, cd.x};
         const f3 dc = sub3(ccol, pr.pcol);                    // ColorDelta(child, parent), gaussian.hpp:111-114
         const float cdiff = sqrtf(dot3(dc, dc));
         if (!(cdiff > a.colorThr)) {                          // mixture.cpp:122-124
-            const float4 cb = a.B[j];
             const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
             const float det_c = cd.w;
             const f3 d = sub3(cm, pr.pm);
-            const float k = kld6(d, ccov, det_c, pr.pinv, pr.det_p);
-            if (!(k > a.kldThr)) {                            // mixture.cpp:126-129 (NaN passes)
+            const float smd = dot3(d, mul6(pr.pinv, d));      // gaussian.hpp:82-85
+            const float tr = trace_prod6(pr.pinv, ccov);
+            bool pass, decided = false;
+            if (pr.smdMax < 3.0e38f && (__float_as_uint(ca.w) & 2u)) {      // regular parent and child
+                const float lg = __logf(__fdividef(det_c, pr.det_p));
+                const float kf = 0.5f * (smd + tr - 3.0f - lg);
+                const float m = 1e-4f * (fabsf(smd) + fabsf(tr) + fabsf(lg) + 3.0f);
+                if (kf > a.kldThr + m) { pass = false; decided = true; }
+                else if (kf < a.kldThr - m) { pass = true; decided = true; }
+            }
+            if (!decided) {
+                const float k = 0.5f * (smd + tr - 3.0f - glibc_logf(det_c / pr.det_p));   // gaussian.hpp:106-109
+                pass = !(k > a.kldThr);                       // mixture.cpp:126-129 (NaN passes)
+            }
+            if (pass) {
                 const bool child_is_parent = (__float_as_uint(ca.w) & 1u) != 0u;
-                if (!(child_is_parent && j != pr.js)) {       // mixture.cpp:131-133
-                    acc = true;
-                    if (MODE != SEL_COUNT) {
-                        // hemLikelihoodOpacity, mixture.cpp:54-64 (parent - child)
-                        const f3 dq = sub3(pr.pm, cm);
-                        const float distanceDiff = sqrtf(dot3(dq, dq));
-                        const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
-                        const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
-                        const float L = distWeight * cd.y * colorInfluence * sqrtf(det_c);
-                        wl = pr.pweight * ref_clamp(L, FLT_MIN, 1e8f);
-                    }
-                }
+                acc = !(child_is_parent && j != pr.js);       // mixture.cpp:131-133
             }
         }
     }
     const unsigned long long m = __ballot(acc);
-    if (MODE != SEL_COUNT) {
-        if (acc) {
-            const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-            a.pair_child[pos] = (unsigned)j;
-            a.pair_wl[pos] = wl;
-        }
-        base += __popcll(m);
+    const int na = __popcll(m);
+    count += (unsigned)na;
+    if (MODE == SEL_COUNT || na == 0) return;
+    if (acc) {                                                // likelihood + pair record (mixture.cpp:54-64,155-158)
+        const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+        a.pair_child[pos] = (unsigned)j;
+        a.pair_wl[pos] = wl_of(a, pr, j);
     }
-    count += (unsigned)__popcll(m);
+    base += na;
 }
 
 // WPB = wavefronts (= parents) per workgroup (runtime choice, GSR_HEM_WPB).
@@ -406,7 +426,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     unsigned count = 0;                 // accepted pairs (uniform across the wave)
     unsigned long long scanned = 0;     // candidates scanned (uniform)
     int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
-    int qn = 0;                         // survivors waiting in the LDS queue (uniform)
+    int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
     unsigned* q = s_q[wv];
 
     // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
@@ -440,57 +460,66 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
                     len = a.cellStart[rowbase + xb + 1] - s;
                 }
             }
-            // inclusive scan of the span lengths over the wave
-            int incl = len;
-            for (int o = 1; o < 64; o <<= 1) {
-                const int t = __shfl_up(incl, o);
-                if (lane >= o) incl += t;
-            }
-            const int total = __shfl(incl, 63);
+            int total = len;                                   // candidates of this batch of rows
+            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
             scanned += (unsigned long long)total;
-            if (MODE == SEL_SPANS) continue;
-            const int excl = incl - len;
-            for (int v0 = 0; v0 < total; v0 += 64) {
-                const int v = v0 + lane;
-                const bool valid = v < total;
-                const int vv = valid ? v : total - 1;
-                // smallest row rr with incl[rr] > vv; every lane takes part in every shuffle (uniform control flow)
-                int lo = 0, hi = 63;
+            if (MODE == SEL_SPANS || total == 0) continue;
+            // Row streaming with lane groups: a row's span is contiguous, so a group of GS lanes walks it
+            // with plain strided indices (no per-candidate search); 64/GS rows are in flight at once.
+            // GS adapts to the mean row length of the batch: short rows (small parents) -> 16 lanes.
+            // The kernel is latency bound (one 1-KiB load per wave in flight = ~20 KB per CU), so the
+            // loads of SEL_U consecutive row steps are issued back to back before any is consumed.
+            const int nrb = nrows - rb < 64 ? nrows - rb : 64;
+            const int gshift = total >= 40 * nrb ? 6 : (total >= 20 * nrb ? 5 : 4);
+            const int gsz = 1 << gshift, gl = lane & (gsz - 1), gi = lane >> gshift, ng = 64 >> gshift;
+            int maxlen = len;
+            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(maxlen, o); maxlen = t > maxlen ? t : maxlen; }
+            for (int k0 = 0; k0 < maxlen; k0 += gsz) {
+                const int k = k0 + gl;
+                for (int r0 = 0; r0 < nrb; r0 += SEL_U * ng) {
+                    float4 ca[SEL_U];
+                    int jj[SEL_U];
+                    unsigned long long actm[SEL_U];
 #pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const int mid = (lo + hi) >> 1;
-                    const int iv = __shfl(incl, mid);
-                    if (iv > vv) hi = mid; else lo = mid + 1;
-                }
-                const int j = __shfl(s, lo) + (vv - __shfl(excl, lo));
-                bool in = false;
-                if (valid) {
-                    const float4 ca = a.A[j];
-                    const f3 cm = {ca.x, ca.y, ca.z};
-                    const f3 dq = sub3(pm, cm);                           // query - point (pointindex.cpp:137)
-                    in = dot3(dq, dq) < pr.R2;
-                    if (in && (__float_as_uint(ca.w) & 2u)) {             // regular child: Mahalanobis pre-reject
-                        const f3 d = sub3(cm, pm);
-                        const float smd = dot3(d, mul6(pr.pinv, d));      // gaussian.hpp:82-85, as kld6 computes it
-                        in = !(smd > pr.smdMax);
+                    for (int u = 0; u < SEL_U; ++u) {
+                        const int rr = (r0 + u * ng + gi) & 63;
+                        const int rs = __shfl(s, rr), rl = __shfl(len, rr);
+                        const bool act = (r0 + u * ng + gi) < nrb && k < rl;
+                        actm[u] = __ballot(act);
+                        jj[u] = act ? rs + k : pr.js;     // inactive lanes load a valid dummy record: an UNCONDITIONAL
+                        ca[u] = a.A[jj[u]];               // load lets the SEL_U loads overlap (a branch per load would
+                    }                                     // make hipcc wait vmcnt(0) after each one)
+#pragma unroll
+                    for (int u = 0; u < SEL_U; ++u) {
+                        if (actm[u] == 0ull) continue;
+                        bool in = false;
+                        if ((actm[u] >> lane) & 1ull) {
+                            const f3 cm = {ca[u].x, ca[u].y, ca[u].z};
+                            const f3 dq = sub3(pm, cm);                   // query - point (pointindex.cpp:137)
+                            in = dot3(dq, dq) < pr.R2;
+                            if (in && (__float_as_uint(ca[u].w) & 2u)) {  // regular child: Mahalanobis pre-reject
+                                const f3 d = sub3(cm, pm);
+                                const float smd = dot3(d, mul6(pr.pinv, d));   // gaussian.hpp:82-85, as kld6 computes it
+                                in = !(smd > pr.smdMax);
+                            }
+                        }
+                        const unsigned long long m = __ballot(in);
+                        if (m == 0ull) continue;
+                        if (in) q[(qh + qn + __popcll(m & ((1ull << lane) - 1ull))) & (SEL_QCAP - 1)] = (unsigned)jj[u];
+                        qn += __popcll(m);
                     }
-                }
-                const unsigned long long m = __ballot(in);
-                if (in) q[qn + __popcll(m & ((1ull << lane) - 1ull))] = (unsigned)j;
-                qn += __popcll(m);
-                __builtin_amdgcn_wave_barrier();
-                if (qn >= 64) {
-                    select_stage2<MODE>(a, pr, lane, 64, q, count, base);
+                    // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
                     __builtin_amdgcn_wave_barrier();
-                    const unsigned carry = (lane < qn - 64) ? q[64 + lane] : 0u;
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < qn - 64) q[lane] = carry;
-                    qn -= 64;
+                    while (qn >= 64) {
+                        select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base);
+                        qh = (qh + 64) & (SEL_QCAP - 1);
+                        qn -= 64;
+                    }
                     __builtin_amdgcn_wave_barrier();
                 }
             }
         }
-        if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, count, base);
+        if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base);
     }
     if (lane == 0) {       // no global atomics here: one hot address serialises 10^6 waves (totals come from the scans)
         if (MODE == SEL_SPANS) a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
@@ -553,6 +582,7 @@ struct MstepArgs {
 };
 
 #define MSTEP_CHUNK 256
+#define MSTEP_U 8             // SH rows whose loads are in flight together
 template <int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ float s_w[WPB][MSTEP_CHUNK];
@@ -574,15 +604,16 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
 
     for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
         const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
-        // part 1: lane <-> pair; moment partial sums
+        // part 1: lane <-> pair; moment partial sums.  All gathers of a pair are issued together and
+        // unconditionally (a load under `if (sumLw != 0)` would cost an extra dependent round trip).
         for (unsigned k = lane; k < cn; k += 64) {
             const unsigned j = a.pair_child[off + c0 + k];
             const float wl = a.pair_wl[off + c0 + k];
             const float sl = a.sumLw[j];
+            const float4 ca = a.A[j], cb = a.B[j], cc = a.C[j], cd = a.D[j];
             float w = 0.0f;
             unsigned jj = 0xffffffffu;                         // marks "skip" (sumLw == 0, mixture.cpp:190)
             if (sl != 0.0f) {
-                const float4 ca = a.A[j], cb = a.B[j], cc = a.C[j], cd = a.D[j];
                 const float r_is = wl / sl;                    // mixture.cpp:196
                 w = r_is * cd.z;                               // * child.weight (:197)
                 jj = j;
@@ -599,17 +630,31 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
             s_j[wv][k] = jj;
         }
         __builtin_amdgcn_wave_barrier();
-        // part 2: lane <-> SH coefficient; children in pair order
+        // part 2: lane <-> SH coefficient; children in pair order, MSTEP_U rows in flight at a time.
+        // Skipped children load the parent's own row (a valid address) and are masked out of the sum.
         if (a.F > 0) {
-            for (unsigned k = 0; k < cn; ++k) {
-                const unsigned j = s_j[wv][k];
-                if (j == 0xffffffffu) continue;
-                const float w = s_w[wv][k];
-                const float* row = a.shs + (int64_t)j * a.F;
+            for (unsigned k0 = 0; k0 < cn; k0 += MSTEP_U) {
+                float rowv[MSTEP_U][4];
+                float wv_[MSTEP_U];
+                bool ok[MSTEP_U];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int f = lane + 64 * q;
-                    if (q < nF && f < a.F) shacc[q] += row[f] * w;
+                for (int u = 0; u < MSTEP_U; ++u) {
+                    const unsigned k = k0 + u;
+                    const unsigned j = k < cn ? s_j[wv][k] : 0xffffffffu;
+                    ok[u] = j != 0xffffffffu;
+                    wv_[u] = k < cn ? s_w[wv][k] : 0.0f;
+                    const float* row = a.shs + (int64_t)(ok[u] ? j : (unsigned)js) * a.F;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int f = lane + 64 * q;
+                        rowv[u][q] = (q < nF && f < a.F) ? row[f] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < MSTEP_U; ++u) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (q < nF && ok[u]) shacc[q] += rowv[u][q] * wv_[u];
                 }
             }
         }

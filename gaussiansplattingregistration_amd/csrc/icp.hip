@@ -6,10 +6,11 @@
 // The reference's Open3D walks a KD-tree per point under OpenMP; here:
 //
 //   target (once per call)  cell-sorted float4 {x, y, z, bits(input index)} + optional double3
-//                           normals, dense uniform grid with cell >= max_corr, prefix table
-//                           cellStart[cells+1] -- the 27 cells around a query bound the search
-//   k_icp_accumulate<KIND>  ONE fused pass per ICP iteration: p = T*p0 in float64, 9 contiguous
-//                           row spans (3 cells each) of the sorted target, exact 1-NN
+//                           normals, dense uniform grid (about 2 points per cell, never finer than
+//                           max_corr/8), prefix table cellStart[cells+1]
+//   source (once per call)  sorted by the same grid's cell so that neighbouring lanes walk the same cells
+//   k_icp_accumulate<KIND>  ONE fused pass per ICP iteration: p = T*p0 in float64, expanding ring
+//                           search over contiguous row spans of the sorted target, exact 1-NN
 //                           (ties -> lowest input index), strict d^2 < max_corr^2, residual and
 //                           Jacobian, float64 accumulators reduced wave -> block -> per-block
 //                           partials; k_icp_finalize sums the partials in a fixed order.
@@ -33,6 +34,7 @@ struct IcpGrid {
     double ox, oy, oz, inv_c, c;
     double cx, cy, cz;     // centre used to condition the point-to-point sums
     int gx, gy, gz, ncells;
+    int rings;             // ceil(max_corr / c): cells beyond this Chebyshev ring cannot hold an accepted neighbour
 };
 
 __device__ __forceinline__ int icp_cell(double v, double o, double inv_c, int g) {
@@ -98,10 +100,34 @@ __global__ __launch_bounds__(256) void k_icp_gather_target(int64_t n, const unsi
     }
 }
 
+__global__ __launch_bounds__(256) void k_icp_gather_source(int64_t n, const unsigned* __restrict__ order, const float* __restrict__ xyz,
+                                                           float* __restrict__ out) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = order[j];
+        out[3 * j] = xyz[3 * i]; out[3 * j + 1] = xyz[3 * i + 1]; out[3 * j + 2] = xyz[3 * i + 2];
+    }
+}
+
 struct Xform { double m[12]; };   // rows 0..2 of the 4x4
 
-// Nearest target neighbour of p (float64) among the 27 cells around it.  Returns the SORTED position
-// (or -1) and d^2; ties go to the lowest input index, as the CPU oracle does.
+// Exact nearest target neighbour of p (float64) by an expanding ring search over the uniform grid.
+// Ring r = the cells at Chebyshev distance r from p's (clamped) cell.  Every point in a cell beyond
+// ring r is at Euclidean distance >= r*c from p, so the search stops as soon as the best squared
+// distance is below (r*c)^2, and never needs to go past ring `rings` = ceil(max_corr / c) because
+// farther points cannot be accepted (d^2 < max_corr^2) anyway.  Returns the SORTED position (or -1)
+// and d^2; ties go to the lowest input index, as the CPU oracle does.
+__device__ __forceinline__ void icp_scan_span(const int* __restrict__ cellStart, const float4* __restrict__ Tq, int first, int last,
+                                              double px, double py, double pz, double& bd, int& best, unsigned& best_i) {
+    const int s = cellStart[first], e = cellStart[last + 1];
+    for (int j = s; j < e; ++j) {
+        const float4 q = Tq[j];
+        const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
+        const double d2 = dx * dx + dy * dy + dz * dz;
+        const unsigned qi = __float_as_uint(q.w);
+        if (d2 < bd || (d2 == bd && qi < best_i)) { bd = d2; best = j; best_i = qi; }
+    }
+}
+
 __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restrict__ cellStart,
                                            const float4* __restrict__ Tq, double px, double py, double pz, double& best_d2) {
     int best = -1;
@@ -109,23 +135,27 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
     double bd = 1.0 / 0.0;
     if (!(px == px) || !(py == py) || !(pz == pz)) { best_d2 = bd; return -1; }
     const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
-    const int xa = cx > 0 ? cx - 1 : 0, xb = cx < g.gx - 1 ? cx + 1 : g.gx - 1;
-    for (int dz = -1; dz <= 1; ++dz) {
-        const int z = cz + dz;
-        if (z < 0 || z >= g.gz) continue;
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int y = cy + dy;
-            if (y < 0 || y >= g.gy) continue;
-            const int rowbase = (z * g.gy + y) * g.gx;
-            const int s = cellStart[rowbase + xa], e = cellStart[rowbase + xb + 1];
-            for (int j = s; j < e; ++j) {
-                const float4 q = Tq[j];
-                const double dx = px - (double)q.x, dyy = py - (double)q.y, dzz = pz - (double)q.z;
-                const double d2 = dx * dx + dyy * dyy + dzz * dzz;
-                const unsigned qi = __float_as_uint(q.w);
-                if (d2 < bd || (d2 == bd && qi < best_i)) { bd = d2; best = j; best_i = qi; }
+    for (int r = 0; r <= g.rings; ++r) {
+        for (int dz = -r; dz <= r; ++dz) {
+            const int z = cz + dz;
+            if (z < 0 || z >= g.gz) continue;
+            const int adz = dz < 0 ? -dz : dz;
+            for (int dy = -r; dy <= r; ++dy) {
+                const int y = cy + dy;
+                if (y < 0 || y >= g.gy) continue;
+                const int ady = dy < 0 ? -dy : dy;
+                const int rowbase = (z * g.gy + y) * g.gx;
+                if (adz == r || ady == r) {                       // a face row of the ring: the whole x span
+                    const int xa = cx - r > 0 ? cx - r : 0, xb = cx + r < g.gx - 1 ? cx + r : g.gx - 1;
+                    icp_scan_span(cellStart, Tq, rowbase + xa, rowbase + xb, px, py, pz, bd, best, best_i);
+                } else {                                          // interior row: only the two end cells
+                    if (cx - r >= 0) icp_scan_span(cellStart, Tq, rowbase + cx - r, rowbase + cx - r, px, py, pz, bd, best, best_i);
+                    if (cx + r < g.gx) icp_scan_span(cellStart, Tq, rowbase + cx + r, rowbase + cx + r, px, py, pz, bd, best, best_i);
+                }
             }
         }
+        const double reach = (double)r * g.c * 0.999999999;
+        if (bd < reach * reach) break;
     }
     best_d2 = bd;
     return best;
@@ -218,9 +248,11 @@ __global__ __launch_bounds__(64) void k_icp_finalize(int nblocks, const double* 
 
 __global__ __launch_bounds__(256) void k_icp_correspond(int64_t ns, const float* __restrict__ src, Xform T, IcpGrid g,
                                                         const int* __restrict__ cellStart, const float4* __restrict__ Tq,
-                                                        double max_corr2, int64_t* __restrict__ out_idx, double* __restrict__ out_d2) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
-        const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
+                                                        double max_corr2, const unsigned* __restrict__ src_order,
+                                                        int64_t* __restrict__ out_idx, double* __restrict__ out_d2) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = src_order ? (int64_t)src_order[k] : k;          // results go back to the caller's order
+        const double x = (double)src[3 * k], y = (double)src[3 * k + 1], z = (double)src[3 * k + 2];
         const double px = T.m[0] * x + T.m[1] * y + T.m[2] * z + T.m[3];
         const double py = T.m[4] * x + T.m[5] * y + T.m[6] * z + T.m[7];
         const double pz = T.m[8] * x + T.m[9] * y + T.m[10] * z + T.m[11];
@@ -430,6 +462,8 @@ struct gsr_icp_ctx {
     bool have_target = false, have_normals = false, have_source = false;
     int64_t nt = 0, ns = 0, ns_global = 0;
     double max_corr = 0;
+    DevBuf src_raw, src_order;
+    bool src_sorted = false;
     DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
     gsr_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
@@ -539,7 +573,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
 int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
-    DevBuf* all[] = {&c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
+    DevBuf* all[] = {&c->src_raw, &c->src_order, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
                      &c->src, &c->partials, &c->acc_dev, &c->rocprim_tmp, &c->corr_idx, &c->corr_d2};
     for (DevBuf* b : all) b->release();
     if (c->e0) (void)hipEventDestroy(c->e0);
@@ -592,7 +626,15 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     }
     IcpGrid g;
     if (!(mx[0] >= mn[0])) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }
-    double cell = max_corr;
+    // cell: about two target points per cell, but no finer than max_corr/8 (bounds the ring count)
+    double cell;
+    {
+        const double ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+        const double emax = fmax(ex, fmax(ey, ez)), eps = emax * 1e-6 + 1e-30;
+        cell = cbrt((ex + eps) * (ey + eps) * (ez + eps) * 2.0 / (double)n);
+        if (!(cell > 0)) cell = max_corr;
+        if (cell < max_corr / 8.0) cell = max_corr / 8.0;
+    }
     for (;;) {
         double fx = floor((mx[0] - mn[0]) / cell) + 1, fy = floor((mx[1] - mn[1]) / cell) + 1, fz = floor((mx[2] - mn[2]) / cell) + 1;
         if (fx * fy * fz <= (double)c->max_cells) { g.gx = (int)fx; g.gy = (int)fy; g.gz = (int)fz; break; }
@@ -602,6 +644,8 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     g.c = cell; g.inv_c = 1.0 / cell;
     g.cx = 0.5 * (mn[0] + mx[0]); g.cy = 0.5 * (mn[1] + mx[1]); g.cz = 0.5 * (mn[2] + mx[2]);
     g.ncells = g.gx * g.gy * g.gz;
+    g.rings = (int)ceil(max_corr / cell);
+    if (g.rings < 1) g.rings = 1;
     c->grid = g;
     GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->order.reserve(n * 4));
     hipLaunchKernelGGL(k_icp_keys, dim3(stride_grid(n)), dim3(256), 0, st, n, dxyz, g, c->keys.as<unsigned>(), c->idx.as<unsigned>());
@@ -623,16 +667,39 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     GSR_HIP(hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&c->ms_build, c->e0, c->e1);
     c->nt = n; c->max_corr = max_corr; c->have_target = true; c->have_normals = normals != nullptr;
+    c->have_source = false;              // the source is sorted by the target grid: set it again after a new target
     return GSR_OK;
 }
 
 int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t on_device) {
     if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_source: NULL context");
     if (n <= 0 || !xyz) return fail(GSR_E_PRECONDITION, "gsr_icp_set_source: empty source cloud");
+    if (n >= ((int64_t)1 << 31) - 1) return fail(GSR_E_INVALID, "gsr_icp_set_source: n too large");
     GSR_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
     GSR_TRY(c->src.reserve((size_t)n * 12));
-    GSR_HIP(hipMemcpyAsync(c->src.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, c->stream));
-    GSR_HIP(hipStreamSynchronize(c->stream));
+    c->src_sorted = false;
+    if (c->have_target) {
+        // sort the source by the TARGET grid's cell (rigid motions keep neighbours neighbours): lanes of a
+        // wave then walk the same target cells, and the per-point ring searches share cache lines
+        GSR_TRY(c->src_raw.reserve((size_t)n * 12));
+        GSR_HIP(hipMemcpyAsync(c->src_raw.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->src_order.reserve(n * 4));
+        hipLaunchKernelGGL(k_icp_keys, dim3(stride_grid(n)), dim3(256), 0, st, n, c->src_raw.as<float>(), c->grid, c->keys.as<unsigned>(), c->idx.as<unsigned>());
+        int bits = 1;
+        while (bits < 32 && ((int64_t)1 << bits) < c->grid.ncells) ++bits;
+        size_t bytes = 0;
+        GSR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+                                          c->src_order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
+        GSR_TRY(c->rocprim_tmp.reserve(bytes));
+        GSR_HIP(rocprim::radix_sort_pairs(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+                                          c->src_order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
+        hipLaunchKernelGGL(k_icp_gather_source, dim3(stride_grid(n)), dim3(256), 0, st, n, c->src_order.as<unsigned>(), c->src_raw.as<float>(), c->src.as<float>());
+        c->src_sorted = true;
+    } else {
+        GSR_HIP(hipMemcpyAsync(c->src.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    }
+    GSR_HIP(hipStreamSynchronize(st));
     c->ns = n; c->have_source = true;
     if (!c->allreduce) c->ns_global = n;
     return GSR_OK;
@@ -687,7 +754,8 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
     hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->grid,
-                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->corr_idx.as<int64_t>(), c->corr_d2.as<double>());
+                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr,
+                       c->corr_idx.as<int64_t>(), c->corr_d2.as<double>());
     GSR_HIP(hipMemcpyAsync(idx, c->corr_idx.p, (size_t)c->ns * 8, hipMemcpyDeviceToHost, c->stream));
     GSR_HIP(hipMemcpyAsync(d2, c->corr_d2.p, (size_t)c->ns * 8, hipMemcpyDeviceToHost, c->stream));
     GSR_HIP(hipStreamSynchronize(c->stream));

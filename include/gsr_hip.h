@@ -123,8 +123,9 @@ int32_t gsr_icp_destroy(gsr_icp_ctx* ctx);
 
 /* Target cloud: xyz[n*3] float32 (the reference widens the float32 splat positions to float64,
  * point_cloud_converter.py:33), normals[n*3] float64 or NULL (Open3D normals are float64).  Builds
- * the uniform-grid index used for the nearest-neighbour search; cell edge >= max_corr, so the 27
- * cells around a query bound the search. */
+ * the uniform-grid index used for the exact nearest-neighbour search (expanding rings of cells, at
+ * most ceil(max_corr / cell) of them).  Call it BEFORE gsr_icp_set_source: the source is kept sorted by
+ * this grid, and a new target invalidates the source. */
 int32_t gsr_icp_set_target(gsr_icp_ctx* ctx, const float* xyz, const double* normals, int64_t n,
                            double max_corr, int32_t on_device);
 int32_t gsr_icp_set_source(gsr_icp_ctx* ctx, const float* xyz, int64_t n, int32_t on_device);
