@@ -303,6 +303,7 @@ struct SelectArgs {
     const float4 *A, *B, *C, *D;
     const float* Rs;
     const unsigned* plist;
+    const unsigned* porder;         // processing order of the parents (heavy ones first), or NULL = natural order
     const int* cellStart;
     const GridParams* gp;
     int P;
@@ -341,11 +342,9 @@ __device__ __forceinline__ float wl_of(const SelectArgs& a, const ParentRec& pr,
     return pr.pweight * ref_clamp(L, FLT_MIN, 1e8f);
 }
 
-// stage 2 on up to 64 queued survivors (lane < cnt holds one): colour gate, KL gate, parent rule.
-// The KL gate's log is the expensive part (float64 table algorithm).  For a regular pair the gate is
-// first decided with a fast log: kld_fast differs from the reference value by far less than the
-// margin m, so  kld_fast > thr + m  =>  KLD > thr  and  kld_fast < thr - m  =>  !(KLD > thr);  only the
-// lanes in between (a few per 10^4), and every irregular pair, evaluate the exact expression.
+// stage 2 on up to 64 queued survivors (lane < cnt holds one): colour gate, KL gate, parent rule, likelihood.
+// (A fast-log pre-decision of the KL gate and a separate third stage for the likelihood were built and
+// measured on MI355X: both cut VALU instructions and neither cut time -- the kernel is latency bound.)
 template <int MODE>
 __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, const unsigned* q, int qh,
                                               unsigned& count, int64_t& base) {
@@ -364,18 +363,8 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
             const f3 d = sub3(cm, pr.pm);
             const float smd = dot3(d, mul6(pr.pinv, d));      // gaussian.hpp:82-85
             const float tr = trace_prod6(pr.pinv, ccov);
-            bool pass, decided = false;
-            if (pr.smdMax < 3.0e38f && (__float_as_uint(ca.w) & 2u)) {      // regular parent and child
-                const float lg = __logf(__fdividef(det_c, pr.det_p));
-                const float kf = 0.5f * (smd + tr - 3.0f - lg);
-                const float m = 1e-4f * (fabsf(smd) + fabsf(tr) + fabsf(lg) + 3.0f);
-                if (kf > a.kldThr + m) { pass = false; decided = true; }
-                else if (kf < a.kldThr - m) { pass = true; decided = true; }
-            }
-            if (!decided) {
-                const float k = 0.5f * (smd + tr - 3.0f - glibc_logf(det_c / pr.det_p));   // gaussian.hpp:106-109
-                pass = !(k > a.kldThr);                       // mixture.cpp:126-129 (NaN passes)
-            }
+            const float k = 0.5f * (smd + tr - 3.0f - glibc_logf(det_c / pr.det_p));   // gaussian.hpp:106-109
+            const bool pass = !(k > a.kldThr);                // mixture.cpp:126-129 (NaN passes)
             if (pass) {
                 const bool child_is_parent = (__float_as_uint(ca.w) & 1u) != 0u;
                 acc = !(child_is_parent && j != pr.js);       // mixture.cpp:131-133
@@ -399,8 +388,9 @@ template <int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     __shared__ unsigned s_q[WPB][SEL_QCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int p = blockIdx.x * WPB + wv;
-    if (p >= a.P) return;
+    const int slot = blockIdx.x * WPB + wv;
+    if (slot >= a.P) return;
+    const int p = a.porder ? (int)a.porder[slot] : slot;
     const GridParams g = *a.gp;
     ParentRec pr;
     pr.js = (int)a.plist[p];
@@ -421,6 +411,13 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     }
     const float R = a.Rs[pr.js];
     pr.R2 = R * R;
+    // the parent record is wave-uniform: pin it in SGPRs (frees ~17 VGPRs -> one more wave per SIMD)
+#define GSR_UNI(x) x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)))
+    GSR_UNI(pr.pm.x); GSR_UNI(pr.pm.y); GSR_UNI(pr.pm.z); GSR_UNI(pr.pcol.x); GSR_UNI(pr.pcol.y); GSR_UNI(pr.pcol.z);
+    GSR_UNI(pr.pinv.e00); GSR_UNI(pr.pinv.e01); GSR_UNI(pr.pinv.e02); GSR_UNI(pr.pinv.e11); GSR_UNI(pr.pinv.e12); GSR_UNI(pr.pinv.e22);
+    GSR_UNI(pr.det_p); GSR_UNI(pr.pweight); GSR_UNI(pr.R2); GSR_UNI(pr.smdMax);
+#undef GSR_UNI
+    pr.js = __builtin_amdgcn_readfirstlane(pr.js);
     const f3 pm = pr.pm;
 
     unsigned count = 0;                 // accepted pairs (uniform across the wave)
@@ -527,6 +524,19 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     }
 }
 
+// Longest-processing-time-first: work per parent is heavy-tailed (a few parents scan 10^5 candidates), so the
+// heavy ones are launched first and the many light ones fill in behind them; otherwise a heavy parent that
+// happens to sit late in the spatial order is the kernel's tail.  key = 0 heavy / 1 light, stable sort.
+__global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __restrict__ work, unsigned thr,
+                                                    unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const unsigned w = work[p];
+        // classes: 0 = >= 64 thr, 1 = >= 8 thr, 2 = >= thr, 3 = light
+        keys[p] = w >= 64u * thr ? 0u : (w >= 8u * thr ? 1u : (w >= thr ? 2u : 3u));
+        idx[p] = (unsigned)p;
+    }
+}
+
 // pack the sparse per-parent segments [coff[p], coff[p]+pcnt[p]) into the compact CSR [poff[p], ...)
 __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __restrict__ coff, const int64_t* __restrict__ poff,
                                                        const unsigned* __restrict__ pcnt, const unsigned* __restrict__ sc,
@@ -571,6 +581,7 @@ struct MstepArgs {
     const float* shs;
     const float* sumLw;
     const unsigned* plist;
+    const unsigned* porder;    // processing order (heavy parents first) or NULL
     const unsigned* order;
     const int* prank_in;       // exclusive scan of the parent flags in input order
     const int64_t* poff;
@@ -588,8 +599,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ float s_w[WPB][MSTEP_CHUNK];
     __shared__ unsigned s_j[WPB][MSTEP_CHUNK];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int p = blockIdx.x * WPB + wv;
-    if (p >= a.P) return;
+    const int slot_ = blockIdx.x * WPB + wv;
+    if (slot_ >= a.P) return;
+    const int p = a.porder ? (int)a.porder[slot_] : slot_;
     const int js = (int)a.plist[p];
     const float4 pa = a.A[js];
     const f3 pm = {pa.x, pa.y, pa.z};
@@ -904,7 +916,8 @@ struct gsr_hem_ctx {
     // workspace
     DevBuf regular;
     DevBuf det, radius, bbox, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
-    DevBuf pcap, coff, sp_child, sp_wl;
+    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx;
+    bool use_lpt = true;
     bool sparse_path = false;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
@@ -1032,6 +1045,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         hipError_t e = hipEventCreate(&c->evk[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
+    if (const char* s = getenv("GSR_HEM_LPT")) c->use_lpt = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb = v; }
     if (const char* s = getenv("GSR_HEM_WPB_M")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb_m = v; }
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
@@ -1046,7 +1060,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->regular, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->regular, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
@@ -1254,6 +1268,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             cand = (unsigned long long)last_off + last_cap;
         }
         c->stats[4] = (int64_t)cand;
+        // processing order: heavy parents first (by candidates scanned), spatial order within a class
+        GSR_TRY(c->porder.reserve(Pm * 4)); GSR_TRY(c->pkeys.reserve(Pm * 4)); GSR_TRY(c->pkeys2.reserve(Pm * 4)); GSR_TRY(c->pidx.reserve(Pm * 4));
+        {
+            const unsigned thr = (unsigned)(8.0 * (double)cand / (double)P) + 1u;      // "heavy" = 8x the mean
+            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), thr, c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
+            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 2));
+            sa.porder = c->use_lpt ? c->porder.as<unsigned>() : nullptr;
+        }
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
         size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 3;
@@ -1337,6 +1359,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.prank_in = c->prank_in.as<int>(); ma.poff = c->poff.as<int64_t>(); ma.pcnt = c->pcnt.as<unsigned>();
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
+        ma.porder = (c->use_lpt && c->sparse_path) ? c->porder.as<unsigned>() : nullptr;
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
         switch (c->wpb_m) {
