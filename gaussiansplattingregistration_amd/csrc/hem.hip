@@ -112,6 +112,17 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
     return t < nblk ? t : -1;
 }
 
+// Processing slot of a block.  The first `hb` blocks (heavy parents, launched first) keep the natural
+// order; the remaining blocks (light parents in Z-order) are dealt to the XCDs in contiguous chunks so
+// that every XCD's L2 serves one compact 3-D region.  hb is a multiple of 8, so (bid - hb) & 7 is still
+// the XCD group of the block.  Returns -1 for padding blocks.
+__device__ __forceinline__ int block_slot(int bid, int nblk, int hb, int xcd) {
+    if (!xcd) return bid < nblk ? bid : -1;
+    if (bid < hb) return bid < nblk ? bid : -1;
+    const int t = xcd_remap(bid - hb, nblk - hb);
+    return t < 0 ? -1 : hb + t;
+}
+
 __device__ __forceinline__ float wave_min(float v) {
     for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
     return v;
@@ -304,6 +315,8 @@ struct SelectArgs {
     const float* Rs;
     const unsigned* plist;
     const unsigned* porder;         // processing order of the parents (heavy ones first), or NULL = natural order
+    int xcd;                        // 1 = light parents are dealt to the XCDs in contiguous chunks (block_slot)
+    const int* nheavy;              // device: number of heavy parents at the head of porder
     const int* cellStart;
     const GridParams* gp;
     int P;
@@ -388,7 +401,11 @@ template <int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     __shared__ unsigned s_q[WPB][SEL_QCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int slot = blockIdx.x * WPB + wv;
+    const int nblk = (a.P + WPB - 1) / WPB;
+    const int hb = a.nheavy ? (((*a.nheavy + WPB - 1) / WPB + 7) & ~7) : 0;
+    const int bid = block_slot((int)blockIdx.x, nblk, hb < nblk ? hb : nblk, a.xcd);
+    if (bid < 0) return;
+    const int slot = bid * WPB + wv;
     if (slot >= a.P) return;
     const int p = a.porder ? (int)a.porder[slot] : slot;
     const GridParams g = *a.gp;
@@ -527,14 +544,48 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
 // Longest-processing-time-first: work per parent is heavy-tailed (a few parents scan 10^5 candidates), so the
 // heavy ones are launched first and the many light ones fill in behind them; otherwise a heavy parent that
 // happens to sit late in the spatial order is the kernel's tail.  key = 0 heavy / 1 light, stable sort.
+__device__ __forceinline__ unsigned spread10(unsigned v) {      // 10 bits -> every third bit
+    v &= 0x3ffu;
+    v = (v | (v << 16)) & 0x030000ffu;
+    v = (v | (v << 8)) & 0x0300f00fu;
+    v = (v | (v << 4)) & 0x030c30c3u;
+    v = (v | (v << 2)) & 0x09249249u;
+    return v;
+}
+// key = [work class : 2 bits][Morton code of the parent's cell : 30 bits].  Within a class the parents are
+// processed along a Z-order curve: the parents in flight at any time then cover a compact 3-D block, so
+// the children / candidates they share stay in L2 (the x-fastest linear order of the arrays makes the
+// in-flight set a full-width slab of the scene, which does not fit).
 __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __restrict__ work, unsigned thr,
+                                                    const unsigned* __restrict__ plist, const float4* __restrict__ A,
+                                                    const GridParams* __restrict__ gpp, int use_morton,
                                                     unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
+    const GridParams g = *gpp;
+    int gm = g.gx > g.gy ? g.gx : g.gy;
+    gm = gm > g.gz ? gm : g.gz;
+    int sh = 0;
+    while ((gm >> sh) > 1024) ++sh;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const unsigned w = work[p];
         // classes: 0 = >= 64 thr, 1 = >= 8 thr, 2 = >= thr, 3 = light
-        keys[p] = w >= 64u * thr ? 0u : (w >= 8u * thr ? 1u : (w >= thr ? 2u : 3u));
+        const unsigned cls = w >= 64u * thr ? 0u : (w >= 8u * thr ? 1u : (w >= thr ? 2u : 3u));
+        unsigned m = 0;
+        if (use_morton) {
+            const float4 a = A[plist[p]];
+            const unsigned cx = (unsigned)cell_of(a.x, g.ox, g.inv_c, g.gx) >> sh;
+            const unsigned cy = (unsigned)cell_of(a.y, g.oy, g.inv_c, g.gy) >> sh;
+            const unsigned cz = (unsigned)cell_of(a.z, g.oz, g.inv_c, g.gz) >> sh;
+            m = spread10(cx) | (spread10(cy) << 1) | (spread10(cz) << 2);
+        }
+        keys[p] = (cls << 30) | m;
         idx[p] = (unsigned)p;
     }
+}
+
+__global__ void k_count_heavy(int P, const unsigned* __restrict__ sorted_keys, int* __restrict__ out) {
+    int lo = 0, hi = P;                       // first key >= (3 << 30)
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << 30)) hi = mid; else lo = mid + 1; }
+    *out = lo;
 }
 
 // pack the sparse per-parent segments [coff[p], coff[p]+pcnt[p]) into the compact CSR [poff[p], ...)
@@ -582,6 +633,8 @@ struct MstepArgs {
     const float* sumLw;
     const unsigned* plist;
     const unsigned* porder;    // processing order (heavy parents first) or NULL
+    int xcd;
+    const int* nheavy;
     const unsigned* order;
     const int* prank_in;       // exclusive scan of the parent flags in input order
     const int64_t* poff;
@@ -594,12 +647,17 @@ struct MstepArgs {
 
 #define MSTEP_CHUNK 256
 #define MSTEP_U 8             // SH rows whose loads are in flight together
-template <int WPB>
+// NQ = SH coefficients per lane (1 when F <= 64 -- the usual case, SH degree <= 3 has F = 45 -- else 4)
+template <int WPB, int NQ>
 __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ float s_w[WPB][MSTEP_CHUNK];
     __shared__ unsigned s_j[WPB][MSTEP_CHUNK];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int slot_ = blockIdx.x * WPB + wv;
+    const int nblk_ = (a.P + WPB - 1) / WPB;
+    const int hb_ = a.nheavy ? (((*a.nheavy + WPB - 1) / WPB + 7) & ~7) : 0;
+    const int bid_ = block_slot((int)blockIdx.x, nblk_, hb_ < nblk_ ? hb_ : nblk_, a.xcd);
+    if (bid_ < 0) return;
+    const int slot_ = bid_ * WPB + wv;
     if (slot_ >= a.P) return;
     const int p = a.porder ? (int)a.porder[slot_] : slot_;
     const int js = (int)a.plist[p];
@@ -611,8 +669,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
     float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
     // SH accumulators: lane f owns coefficients f, f+64, ... (F <= 256 supported per pass)
-    float shacc[4] = {0, 0, 0, 0};
-    const int nF = (a.F + 63) / 64;
+    float shacc[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) shacc[q] = 0.0f;
 
     for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
         const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
@@ -646,7 +705,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         // Skipped children load the parent's own row (a valid address) and are masked out of the sum.
         if (a.F > 0) {
             for (unsigned k0 = 0; k0 < cn; k0 += MSTEP_U) {
-                float rowv[MSTEP_U][4];
+                float rowv[MSTEP_U][NQ];
                 float wv_[MSTEP_U];
                 bool ok[MSTEP_U];
 #pragma unroll
@@ -657,16 +716,16 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                     wv_[u] = k < cn ? s_w[wv][k] : 0.0f;
                     const float* row = a.shs + (int64_t)(ok[u] ? j : (unsigned)js) * a.F;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < NQ; ++q) {
                         const int f = lane + 64 * q;
-                        rowv[u][q] = (q < nF && f < a.F) ? row[f] : 0.0f;
+                        rowv[u][q] = f < a.F ? row[f] : 0.0f;
                     }
                 }
 #pragma unroll
                 for (int u = 0; u < MSTEP_U; ++u) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (q < nF && ok[u]) shacc[q] += rowv[u][q] * wv_[u];
+                    for (int q = 0; q < NQ; ++q)
+                        if (ok[u]) shacc[q] += rowv[u][q] * wv_[u];
                 }
             }
         }
@@ -696,9 +755,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         a.o_weight[slot] = w_s;
     }
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < NQ; ++q) {
         const int f = lane + 64 * q;
-        if (q < nF && f < a.F) a.o_sh[slot * a.F + f] = shacc[q] * inv_w;
+        if (f < a.F) a.o_sh[slot * a.F + f] = shacc[q] * inv_w;
     }
 }
 
@@ -917,7 +976,8 @@ struct gsr_hem_ctx {
     DevBuf regular;
     DevBuf det, radius, bbox, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx;
-    bool use_lpt = true;
+    bool use_lpt = true, use_morton = true, use_xcd = true;
+    int mstep_lds = 0;              // extra dynamic LDS per k_mstep workgroup: caps waves per CU (experiment knob)
     bool sparse_path = false;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
@@ -1045,7 +1105,10 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         hipError_t e = hipEventCreate(&c->evk[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
+    if (const char* s = getenv("GSR_HEM_MSTEP_LDS")) c->mstep_lds = atoi(s);
     if (const char* s = getenv("GSR_HEM_LPT")) c->use_lpt = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_MORTON")) c->use_morton = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_XCD")) c->use_xcd = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb = v; }
     if (const char* s = getenv("GSR_HEM_WPB_M")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb_m = v; }
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
@@ -1256,7 +1319,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         return exclusive_scan<int64_t>(c, cnt64, off, P);
     };
     if (P > 0) {
-        switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_SPANS, 1>), dim3(P), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_SPANS, 2>), dim3(ceil_div(P, 2)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_SPANS, 4>), dim3(ceil_div(P, 4)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_SPANS, 8>), dim3(ceil_div(P, 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_SPANS, 16>), dim3(ceil_div(P, 16)), dim3(1024), 0, st, sa); break; }
+        switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_SPANS, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_SPANS, 2>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_SPANS, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_SPANS, 8>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_SPANS, 16>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), 0, st, sa); break; }
         GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>()));
         unsigned long long cand = 0;
         {
@@ -1272,9 +1335,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(c->porder.reserve(Pm * 4)); GSR_TRY(c->pkeys.reserve(Pm * 4)); GSR_TRY(c->pkeys2.reserve(Pm * 4)); GSR_TRY(c->pidx.reserve(Pm * 4));
         {
             const unsigned thr = (unsigned)(8.0 * (double)cand / (double)P) + 1u;      // "heavy" = 8x the mean
-            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), thr, c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
-            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 2));
+            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), thr, c->plist.as<unsigned>(), c->A.as<float4>(),
+                               c->gparams.as<GridParams>(), c->use_morton ? 1 : 0, c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
+            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 32));
+            hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
             sa.porder = c->use_lpt ? c->porder.as<unsigned>() : nullptr;
+            sa.xcd = (c->use_xcd && c->use_lpt) ? 1 : 0;
+            sa.nheavy = c->counters.as<int>() + 8;
         }
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -1286,11 +1353,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
             sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
             GSR_HIP(hipEventRecord(c->evk[2], st));
-            switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_SPARSE, 1>), dim3(P), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_SPARSE, 2>), dim3(ceil_div(P, 2)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_SPARSE, 4>), dim3(ceil_div(P, 4)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_SPARSE, 8>), dim3(ceil_div(P, 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_SPARSE, 16>), dim3(ceil_div(P, 16)), dim3(1024), 0, st, sa); break; }
+            switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_SPARSE, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_SPARSE, 2>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_SPARSE, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_SPARSE, 8>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_SPARSE, 16>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), 0, st, sa); break; }
             GSR_HIP(hipEventRecord(c->evk[3], st));
         } else {
             GSR_HIP(hipEventRecord(c->evk[0], st));
-            switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_COUNT, 1>), dim3(P), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_COUNT, 2>), dim3(ceil_div(P, 2)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_COUNT, 4>), dim3(ceil_div(P, 4)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_COUNT, 8>), dim3(ceil_div(P, 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_COUNT, 16>), dim3(ceil_div(P, 16)), dim3(1024), 0, st, sa); break; }
+            switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_COUNT, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_COUNT, 2>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_COUNT, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_COUNT, 8>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_COUNT, 16>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), 0, st, sa); break; }
             GSR_HIP(hipEventRecord(c->evk[1], st));
         }
         GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>()));
@@ -1310,7 +1377,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             } else {
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
                 GSR_HIP(hipEventRecord(c->evk[2], st));
-                switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_FILL, 1>), dim3(P), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_FILL, 2>), dim3(ceil_div(P, 2)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_FILL, 4>), dim3(ceil_div(P, 4)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_FILL, 8>), dim3(ceil_div(P, 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_FILL, 16>), dim3(ceil_div(P, 16)), dim3(1024), 0, st, sa); break; }
+                switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_FILL, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_FILL, 2>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_FILL, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_FILL, 8>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_FILL, 16>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), 0, st, sa); break; }
                 GSR_HIP(hipEventRecord(c->evk[3], st));
             }
         }
@@ -1360,14 +1427,16 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
         ma.porder = (c->use_lpt && c->sparse_path) ? c->porder.as<unsigned>() : nullptr;
+        ma.xcd = (c->use_xcd && ma.porder) ? 1 : 0;
+        ma.nheavy = c->counters.as<int>() + 8;
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
         switch (c->wpb_m) {
-            case 1: hipLaunchKernelGGL(k_mstep<1>, dim3(P), dim3(64), 0, st, ma); break;
-            case 2: hipLaunchKernelGGL(k_mstep<2>, dim3(ceil_div(P, 2)), dim3(128), 0, st, ma); break;
-            case 4: hipLaunchKernelGGL(k_mstep<4>, dim3(ceil_div(P, 4)), dim3(256), 0, st, ma); break;
-            case 8: hipLaunchKernelGGL(k_mstep<8>, dim3(ceil_div(P, 8)), dim3(512), 0, st, ma); break;
-            default: hipLaunchKernelGGL(k_mstep<16>, dim3(ceil_div(P, 16)), dim3(1024), 0, st, ma); break;
+            case 1: if (F <= 64) hipLaunchKernelGGL((k_mstep<1, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<1, 4>), dim3(8 * ceil_div(P, 8)), dim3(64), c->mstep_lds, st, ma); break;
+            case 2: if (F <= 64) hipLaunchKernelGGL((k_mstep<2, 1>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<2, 4>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), c->mstep_lds, st, ma); break;
+            case 4: if (F <= 64) hipLaunchKernelGGL((k_mstep<4, 1>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<4, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), c->mstep_lds, st, ma); break;
+            case 8: if (F <= 64) hipLaunchKernelGGL((k_mstep<8, 1>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<8, 4>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), c->mstep_lds, st, ma); break;
+            default: if (F <= 64) hipLaunchKernelGGL((k_mstep<16, 1>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<16, 4>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), c->mstep_lds, st, ma); break;
         }
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
