@@ -91,6 +91,23 @@ def hot_path_step(ctxs, lru, PointCloud, src, tgt, device, sync):
     return out
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/*_pmc.json,
+    written by scripts/summarize_profiles.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
+    passes of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.getmtime)
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and "hbm_read_bytes_per_launch_x2_corrected" in v:
+                return v["hbm_read_bytes_per_launch_x2_corrected"] + v.get("hbm_write_bytes_per_launch", 0.0), os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline():
     """The reference's own extension (or the oracle port) on this box's host cores, bounded sample."""
     from gaussiansplattingregistration_amd import synth
@@ -213,6 +230,7 @@ def main():
         lvl1 = [k for k in kern if k["n_in"] == n]
         lvl_bytes = np.mean([bytes_level(k["n_in"], k["n_out"], F) for k in lvl1])
         lvl_ms = np.mean([k["ms_level"] for k in lvl1])
+        traffic, traffic_src = pmc_traffic("gsr::k_select<2")
         line = {
             "metric": "Gaussians/sec through HEM level + ICP iters/sec, 2x5M-splat pair",
             "value": hem_gauss / hem_s,
@@ -233,10 +251,10 @@ def main():
             "hem_phase_ms_per_step": {k: v / a.steps for k, v in phases.items()},
             "roofline": {"bound": "hbm", "kernel": "k_select<SPARSE> (child selection + likelihood, one wavefront per parent)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": None,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches": int(len(fill_ms)), "avg_units_per_launch": float(n_in.mean()),
                          "bytes_per_unit": B_GEOM,
-                         "note": "VALU-bound pair evaluation, not HBM-bound: see DESIGN.md (pairs/s vs VALU peak)",
+                         "note": "latency-bound neighbour evaluation (about 470 candidate tests per splat), not HBM-bound: see DESIGN.md section 4",
                          "level1": {"algorithmic_bytes": float(lvl_bytes), "ms": float(lvl_ms),
                                     "achieved_GBps": float(lvl_bytes / (lvl_ms * 1e-3) / 1e9),
                                     "frac": float(lvl_bytes / (lvl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},

@@ -317,6 +317,12 @@ struct SelectArgs {
     const unsigned* porder;         // processing order of the parents (heavy ones first), or NULL = natural order
     int xcd;                        // 1 = light parents are dealt to the XCDs in contiguous chunks (block_slot)
     const int* nheavy;              // device: number of heavy parents at the head of porder
+    // Work items.  A heavy parent is split into several items, each taking every nparts-th batch of 64 grid
+    // rows; NI items in all (NI == P and vparent == NULL when nothing is split).  pcap / pcnt / poff are
+    // indexed by ITEM in the SPANS / SPARSE / COUNT / FILL modes.
+    int NI;
+    const unsigned* vparent;        // item -> parent index (into plist)
+    const unsigned* vpart;          // item -> part | (nparts << 16)
     const int* cellStart;
     const GridParams* gp;
     int P;
@@ -401,13 +407,16 @@ template <int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     __shared__ unsigned s_q[WPB][SEL_QCAP];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nblk = (a.P + WPB - 1) / WPB;
+    const int nblk = (a.NI + WPB - 1) / WPB;
     const int hb = a.nheavy ? (((*a.nheavy + WPB - 1) / WPB + 7) & ~7) : 0;
     const int bid = block_slot((int)blockIdx.x, nblk, hb < nblk ? hb : nblk, a.xcd);
     if (bid < 0) return;
     const int slot = bid * WPB + wv;
-    if (slot >= a.P) return;
-    const int p = a.porder ? (int)a.porder[slot] : slot;
+    if (slot >= a.NI) return;
+    const int item = a.porder ? (int)a.porder[slot] : slot;
+    const int p = a.vparent ? (int)a.vparent[item] : item;
+    const unsigned vpi = a.vpart ? a.vpart[item] : (1u << 16);
+    const int part = (int)(vpi & 0xffffu), nparts = (int)(vpi >> 16);
     const GridParams g = *a.gp;
     ParentRec pr;
     pr.js = (int)a.plist[p];
@@ -439,7 +448,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
 
     unsigned count = 0;                 // accepted pairs (uniform across the wave)
     unsigned long long scanned = 0;     // candidates scanned (uniform)
-    int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
+    int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[item] : 0;
     int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
     unsigned* q = s_q[wv];
 
@@ -454,6 +463,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
         const int nrows = ny * nz;
         const float Ra2 = Ra * Ra;
         for (int rb = 0; rb < nrows; rb += 64) {
+            if (nparts > 1 && ((rb >> 6) % nparts) != part) continue;      // this batch of rows belongs to another item
             const int r = rb + lane;
             int s = 0, len = 0;
             if (r < nrows) {
@@ -536,8 +546,8 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
         if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base);
     }
     if (lane == 0) {       // no global atomics here: one hot address serialises 10^6 waves (totals come from the scans)
-        if (MODE == SEL_SPANS) a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
-        else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[p] = count;
+        if (MODE == SEL_SPANS) a.pcap[item] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
+        else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[item] = count;
     }
 }
 
@@ -557,8 +567,8 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {      // 10 bits -> ev
 // the children / candidates they share stay in L2 (the x-fastest linear order of the arrays makes the
 // in-flight set a full-width slab of the scene, which does not fit).
 __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __restrict__ work, unsigned thr,
-                                                    const unsigned* __restrict__ plist, const float4* __restrict__ A,
-                                                    const GridParams* __restrict__ gpp, int use_morton,
+                                                    const unsigned* __restrict__ plist, const unsigned* __restrict__ vparent,
+                                                    const float4* __restrict__ A, const GridParams* __restrict__ gpp, int use_morton,
                                                     unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
     const GridParams g = *gpp;
     int gm = g.gx > g.gy ? g.gx : g.gy;
@@ -571,7 +581,7 @@ __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __res
         const unsigned cls = w >= 64u * thr ? 0u : (w >= 8u * thr ? 1u : (w >= thr ? 2u : 3u));
         unsigned m = 0;
         if (use_morton) {
-            const float4 a = A[plist[p]];
+            const float4 a = A[plist[vparent ? vparent[p] : (unsigned)p]];
             const unsigned cx = (unsigned)cell_of(a.x, g.ox, g.inv_c, g.gx) >> sh;
             const unsigned cy = (unsigned)cell_of(a.y, g.oy, g.inv_c, g.gy) >> sh;
             const unsigned cz = (unsigned)cell_of(a.z, g.oz, g.inv_c, g.gz) >> sh;
@@ -582,22 +592,53 @@ __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __res
     }
 }
 
+// split heavy parents: parts = ceil(candidates / part_cap), at most 64
+__global__ __launch_bounds__(256) void k_nparts(int P, const unsigned* __restrict__ pcap, unsigned part_cap, int* __restrict__ nparts) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        unsigned n = (pcap[p] + part_cap - 1) / part_cap;
+        nparts[p] = (int)(n < 1u ? 1u : (n > 64u ? 64u : n));
+    }
+}
+__global__ __launch_bounds__(256) void k_fill_items(int P, const int* __restrict__ nparts, const int* __restrict__ vstart,
+                                                    unsigned* __restrict__ vparent, unsigned* __restrict__ vpart) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int n = nparts[p], v0 = vstart[p];
+        for (int k = 0; k < n; ++k) { vparent[v0 + k] = (unsigned)p; vpart[v0 + k] = (unsigned)k | ((unsigned)n << 16); }
+    }
+}
+// accepted pairs of a parent = sum over its items
+__global__ __launch_bounds__(256) void k_sum_parts(int P, const int* __restrict__ nparts, const int* __restrict__ vstart,
+                                                   const unsigned* __restrict__ vcnt, unsigned* __restrict__ pcnt) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        unsigned s = 0;
+        for (int k = 0, v0 = vstart[p]; k < nparts[p]; ++k) s += vcnt[v0 + k];
+        pcnt[p] = s;
+    }
+}
+
 __global__ void k_count_heavy(int P, const unsigned* __restrict__ sorted_keys, int* __restrict__ out) {
     int lo = 0, hi = P;                       // first key >= (3 << 30)
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << 30)) hi = mid; else lo = mid + 1; }
     *out = lo;
 }
 
-// pack the sparse per-parent segments [coff[p], coff[p]+pcnt[p]) into the compact CSR [poff[p], ...)
-__global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __restrict__ coff, const int64_t* __restrict__ poff,
-                                                       const unsigned* __restrict__ pcnt, const unsigned* __restrict__ sc,
+// pack the sparse per-item segments [coff[v], coff[v]+vcnt[v]) into the compact per-parent CSR [poff[p], ...):
+// the items of a parent are concatenated in part order (deterministic)
+__global__ __launch_bounds__(256) void k_compact_pairs(int P, const int* __restrict__ nparts, const int* __restrict__ vstart,
+                                                       const int64_t* __restrict__ coff, const unsigned* __restrict__ vcnt,
+                                                       const int64_t* __restrict__ poff, const unsigned* __restrict__ sc,
                                                        const float* __restrict__ sw, unsigned* __restrict__ dc, float* __restrict__ dw) {
     const int lane = threadIdx.x & 63;
     const int p = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (p >= P) return;
-    const int64_t so = coff[p], dof = poff[p];
-    const unsigned n = pcnt[p];
-    for (unsigned k = lane; k < n; k += 64) { dc[dof + k] = sc[so + k]; dw[dof + k] = sw[so + k]; }
+    int64_t dof = poff[p];
+    const int v0 = nparts ? vstart[p] : p, n = nparts ? nparts[p] : 1;
+    for (int k = 0; k < n; ++k) {
+        const int64_t so = coff[v0 + k];
+        const unsigned cnt = vcnt[v0 + k];
+        for (unsigned i = lane; i < cnt; i += 64) { dc[dof + i] = sc[so + i]; dw[dof + i] = sw[so + i]; }
+        dof += cnt;
+    }
 }
 
 // per-child sum of wL_si, sequential in the (stable) sorted pair order (mixture.cpp:162)
@@ -975,7 +1016,9 @@ struct gsr_hem_ctx {
     // workspace
     DevBuf regular;
     DevBuf det, radius, bbox, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
-    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx;
+    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, morder, nparts, vstart, vparent, vpart, vcap, vcnt;
+    int part_cap = 0;               // candidates per work item when a heavy parent is split; 0 = never (measured: 8192 cuts
+                                    // the select kernel by 4% and costs as much in the extra SPANS pass and scans)
     bool use_lpt = true, use_morton = true, use_xcd = true;
     int mstep_lds = 0;              // extra dynamic LDS per k_mstep workgroup: caps waves per CU (experiment knob)
     bool sparse_path = false;
@@ -1106,6 +1149,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
     if (const char* s = getenv("GSR_HEM_MSTEP_LDS")) c->mstep_lds = atoi(s);
+    if (const char* s = getenv("GSR_HEM_PART_CAP")) c->part_cap = atoi(s);
     if (const char* s = getenv("GSR_HEM_LPT")) c->use_lpt = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MORTON")) c->use_morton = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_XCD")) c->use_xcd = atoi(s) != 0;
@@ -1123,7 +1167,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->regular, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->regular, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
@@ -1293,52 +1337,92 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 
     // ---- 2. selection ------------------------------------------------------------------------------
     // Fast path (SPARSE): one evaluation pass.  k_select<SPANS> sums the span lengths per parent (an
-    // upper bound of its child count), the pass writes each parent's pairs at the head of a segment of
-    // that capacity, k_compact_pairs packs them.  The sparse buffers cost 8 bytes per candidate
-    // scanned; when that exceeds the budget (GSR_HEM_SPARSE_GB, default 1/3 of free HBM) the two-pass
-    // COUNT + FILL fallback runs instead (same device code, evaluates every candidate twice).
+    // upper bound of its child count); heavy parents are split into work items of <= ~8k candidates
+    // (work per parent is heavy-tailed: R^3 is log-normal); every item writes its pairs at the head of a
+    // segment of its capacity; k_compact_pairs packs them per parent.  The sparse buffers cost 8 bytes
+    // per candidate scanned; when that exceeds the budget (GSR_HEM_SPARSE_GB, default 1/3 of free HBM)
+    // the two-pass COUNT + FILL fallback runs instead (same device code, evaluates every candidate twice).
     const size_t Pm = (size_t)(P > 0 ? P : 1);
     GSR_TRY(c->pcnt.reserve(Pm * 4)); GSR_TRY(c->pcap.reserve(Pm * 4)); GSR_TRY(c->poff.reserve((Pm + 1) * 8));
-    GSR_TRY(c->coff.reserve((Pm + 1) * 8)); GSR_TRY(c->scratch.reserve((Pm + 1) * 8));
+    GSR_TRY(c->scratch.reserve((Pm * 2 + 128) * 8));
     SelectArgs sa;
     memset(&sa, 0, sizeof(sa));
     sa.A = c->A.as<float4>(); sa.B = c->B.as<float4>(); sa.C = c->C.as<float4>(); sa.D = c->D.as<float4>();
     sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
-    sa.gp = c->gparams.as<GridParams>(); sa.P = P;
+    sa.gp = c->gparams.as<GridParams>(); sa.P = P; sa.NI = P;
     sa.colorThr = c->kappa * c->kappa * 0.5f;     // mixture.cpp:123
     sa.kldThr = c->delta * c->delta * 0.5f;       // mixture.cpp:128
     sa.tau2 = c->tau * c->tau;                    // mixture.cpp:58,61
     sa.pcnt = c->pcnt.as<unsigned>();
     sa.pcap = c->pcap.as<unsigned>();
     int64_t M = 0;
-    const dim3 sgrid(ceil_div(P > 0 ? P : 1, 4));
     const int wpb = c->wpb;
-    auto widen_scan = [&](const unsigned* cnt, int64_t* off) -> int32_t {      // off = exclusive scan of cnt (int64)
+#define GSR_LAUNCH_SELECT(MODE, NITEMS)                                                                                              \
+    switch (wpb) {                                                                                                                   \
+        case 1: hipLaunchKernelGGL((k_select<MODE, 1>), dim3(8 * ceil_div((NITEMS), 8)), dim3(64), 0, st, sa); break;                 \
+        case 2: hipLaunchKernelGGL((k_select<MODE, 2>), dim3(8 * ceil_div(ceil_div((NITEMS), 2), 8)), dim3(128), 0, st, sa); break;   \
+        case 4: hipLaunchKernelGGL((k_select<MODE, 4>), dim3(8 * ceil_div(ceil_div((NITEMS), 4), 8)), dim3(256), 0, st, sa); break;   \
+        case 8: hipLaunchKernelGGL((k_select<MODE, 8>), dim3(8 * ceil_div(ceil_div((NITEMS), 8), 8)), dim3(512), 0, st, sa); break;   \
+        default: hipLaunchKernelGGL((k_select<MODE, 16>), dim3(8 * ceil_div(ceil_div((NITEMS), 16), 8)), dim3(1024), 0, st, sa); break; \
+    }
+    auto widen_scan = [&](const unsigned* cnt, int64_t* off, int64_t count) -> int32_t {      // off = exclusive scan of cnt (int64)
+        GSR_TRY(c->scratch.reserve(((size_t)count + 128) * 8));
         int64_t* cnt64 = c->scratch.as<int64_t>();
-        GSR_HIP(rocprim::transform(cnt, cnt64, (size_t)P, [] __device__(unsigned v) { return (int64_t)v; }, st));
-        return exclusive_scan<int64_t>(c, cnt64, off, P);
+        GSR_HIP(rocprim::transform(cnt, cnt64, (size_t)count, [] __device__(unsigned v) { return (int64_t)v; }, st));
+        return exclusive_scan<int64_t>(c, cnt64, off, count);
     };
+    auto total_of = [&](const int64_t* off, const unsigned* cnt, int64_t count, int64_t* out) -> int32_t {
+        int64_t last_off = 0;
+        unsigned last = 0;
+        GSR_HIP(hipMemcpyAsync(&last_off, off + (count - 1), 8, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipMemcpyAsync(&last, cnt + (count - 1), 4, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        *out = last_off + (int64_t)last;
+        return GSR_OK;
+    };
+    c->sparse_path = false;
     if (P > 0) {
-        switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_SPANS, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_SPANS, 2>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_SPANS, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_SPANS, 8>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_SPANS, 16>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), 0, st, sa); break; }
-        GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>()));
-        unsigned long long cand = 0;
-        {
-            int64_t last_off = 0;
-            unsigned last_cap = 0;
-            GSR_HIP(hipMemcpyAsync(&last_off, c->coff.as<int64_t>() + (P - 1), 8, hipMemcpyDeviceToHost, st));
-            GSR_HIP(hipMemcpyAsync(&last_cap, c->pcap.as<unsigned>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
+        GSR_LAUNCH_SELECT(SEL_SPANS, P);                                  // candidates scanned per parent
+        // work items: split the heavy parents
+        int V = P;
+        bool split = false;
+        GSR_TRY(c->nparts.reserve(Pm * 4)); GSR_TRY(c->vstart.reserve((Pm + 1) * 4));
+        if (c->part_cap > 0) {
+            hipLaunchKernelGGL(k_nparts, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), (unsigned)c->part_cap, c->nparts.as<int>());
+            GSR_TRY(exclusive_scan<int>(c, c->nparts.as<int>(), c->vstart.as<int>(), P));
+            int lo = 0, ln = 0;
+            GSR_HIP(hipMemcpyAsync(&lo, c->vstart.as<int>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
+            GSR_HIP(hipMemcpyAsync(&ln, c->nparts.as<int>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
             GSR_HIP(hipStreamSynchronize(st));
-            cand = (unsigned long long)last_off + last_cap;
+            V = lo + ln;
+            split = V > P;
         }
+        const size_t Vm = (size_t)V;
+        GSR_TRY(c->coff.reserve((Vm + 1) * 8));
+        const unsigned* icap = c->pcap.as<unsigned>();            // capacity per item
+        if (split) {
+            GSR_TRY(c->vparent.reserve(Vm * 4)); GSR_TRY(c->vpart.reserve(Vm * 4)); GSR_TRY(c->vcap.reserve(Vm * 4)); GSR_TRY(c->vcnt.reserve(Vm * 4));
+            hipLaunchKernelGGL(k_fill_items, dim3(stride_grid(P)), blk, 0, st, P, c->nparts.as<int>(), c->vstart.as<int>(), c->vparent.as<unsigned>(),
+                               c->vpart.as<unsigned>());
+            sa.NI = V; sa.vparent = c->vparent.as<unsigned>(); sa.vpart = c->vpart.as<unsigned>();
+            sa.pcap = c->vcap.as<unsigned>();
+            GSR_LAUNCH_SELECT(SEL_SPANS, V);                              // exact capacity of every item
+            icap = c->vcap.as<unsigned>();
+        }
+        GSR_TRY(widen_scan(icap, c->coff.as<int64_t>(), V));
+        int64_t cand_i = 0;
+        GSR_TRY(total_of(c->coff.as<int64_t>(), icap, V, &cand_i));
+        const unsigned long long cand = (unsigned long long)cand_i;
         c->stats[4] = (int64_t)cand;
-        // processing order: heavy parents first (by candidates scanned), spatial order within a class
-        GSR_TRY(c->porder.reserve(Pm * 4)); GSR_TRY(c->pkeys.reserve(Pm * 4)); GSR_TRY(c->pkeys2.reserve(Pm * 4)); GSR_TRY(c->pidx.reserve(Pm * 4));
+        // processing order: heavy items first, the light ones along a Z-order curve
+        GSR_TRY(c->porder.reserve(Vm * 4)); GSR_TRY(c->pkeys.reserve(Vm * 4)); GSR_TRY(c->pkeys2.reserve(Vm * 4)); GSR_TRY(c->pidx.reserve(Vm * 4));
         {
-            const unsigned thr = (unsigned)(8.0 * (double)cand / (double)P) + 1u;      // "heavy" = 8x the mean
-            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), thr, c->plist.as<unsigned>(), c->A.as<float4>(),
+            const unsigned thr = (unsigned)(8.0 * (double)cand / (double)V) + 1u;      // "heavy" = 8x the mean
+            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(V)), blk, 0, st, V, icap, thr, c->plist.as<unsigned>(),
+                               split ? c->vparent.as<unsigned>() : (const unsigned*)nullptr, c->A.as<float4>(),
                                c->gparams.as<GridParams>(), c->use_morton ? 1 : 0, c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
-            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 32));
-            hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
+            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), V, 32));
+            hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, V, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
             sa.porder = c->use_lpt ? c->porder.as<unsigned>() : nullptr;
             sa.xcd = (c->use_xcd && c->use_lpt) ? 1 : 0;
             sa.nheavy = c->counters.as<int>() + 8;
@@ -1352,39 +1436,54 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             const size_t Cm = (size_t)(cand > 0 ? cand : 1);
             GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
             sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
+            sa.pcnt = split ? c->vcnt.as<unsigned>() : c->pcnt.as<unsigned>();
             GSR_HIP(hipEventRecord(c->evk[2], st));
-            switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_SPARSE, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_SPARSE, 2>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_SPARSE, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_SPARSE, 8>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_SPARSE, 16>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), 0, st, sa); break; }
+            GSR_LAUNCH_SELECT(SEL_SPARSE, V);
             GSR_HIP(hipEventRecord(c->evk[3], st));
+            if (split)
+                hipLaunchKernelGGL(k_sum_parts, dim3(stride_grid(P)), blk, 0, st, P, c->nparts.as<int>(), c->vstart.as<int>(), c->vcnt.as<unsigned>(),
+                                   c->pcnt.as<unsigned>());
         } else {
+            // fallback: whole parents, two passes
+            sa.NI = P; sa.vparent = nullptr; sa.vpart = nullptr; sa.porder = nullptr; sa.xcd = 0; sa.nheavy = nullptr;
+            sa.pcnt = c->pcnt.as<unsigned>();
             GSR_HIP(hipEventRecord(c->evk[0], st));
-            switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_COUNT, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_COUNT, 2>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_COUNT, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_COUNT, 8>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_COUNT, 16>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), 0, st, sa); break; }
+            GSR_LAUNCH_SELECT(SEL_COUNT, P);
             GSR_HIP(hipEventRecord(c->evk[1], st));
         }
-        GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>()));
-        int64_t last_off = 0;
-        unsigned last_cnt = 0;
-        GSR_HIP(hipMemcpyAsync(&last_off, c->poff.as<int64_t>() + (P - 1), 8, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipMemcpyAsync(&last_cnt, c->pcnt.as<unsigned>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipStreamSynchronize(st));
-        M = last_off + (int64_t)last_cnt;
+        GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), P));
+        GSR_TRY(total_of(c->poff.as<int64_t>(), c->pcnt.as<unsigned>(), P, &M));
         const size_t Mm = (size_t)(M > 0 ? M : 1);
         GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
         GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
         if (M > 0) {
             if (sparse) {
-                hipLaunchKernelGGL(k_compact_pairs, sgrid, blk, 0, st, P, c->coff.as<int64_t>(), c->poff.as<int64_t>(), c->pcnt.as<unsigned>(),
-                                   c->sp_child.as<unsigned>(), c->sp_wl.as<float>(), c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
+                hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 4)), blk, 0, st, P, split ? c->nparts.as<int>() : (const int*)nullptr,
+                                   split ? c->vstart.as<int>() : (const int*)nullptr, c->coff.as<int64_t>(),
+                                   split ? c->vcnt.as<unsigned>() : c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), c->sp_child.as<unsigned>(),
+                                   c->sp_wl.as<float>(), c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
             } else {
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
                 GSR_HIP(hipEventRecord(c->evk[2], st));
-                switch (wpb) { case 1: hipLaunchKernelGGL((k_select<SEL_FILL, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, sa); break; case 2: hipLaunchKernelGGL((k_select<SEL_FILL, 2>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), 0, st, sa); break; case 4: hipLaunchKernelGGL((k_select<SEL_FILL, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), 0, st, sa); break; case 8: hipLaunchKernelGGL((k_select<SEL_FILL, 8>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), 0, st, sa); break; default: hipLaunchKernelGGL((k_select<SEL_FILL, 16>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), 0, st, sa); break; }
+                GSR_LAUNCH_SELECT(SEL_FILL, P);
                 GSR_HIP(hipEventRecord(c->evk[3], st));
             }
         }
         c->sparse_path = sparse;
+        // M-step processing order: heavy parents (by accepted pairs) first, the rest in Z-order
+        if (c->use_lpt && M > 0) {
+            const unsigned thr = (unsigned)(8.0 * (double)M / (double)P) + 1u;
+            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcnt.as<unsigned>(), thr, c->plist.as<unsigned>(),
+                               (const unsigned*)nullptr, c->A.as<float4>(), c->gparams.as<GridParams>(), c->use_morton ? 1 : 0,
+                               c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
+            GSR_TRY(c->morder.reserve(Pm * 4));
+            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->morder.as<unsigned>(), P, 32));
+            hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 9);
+        }
     } else {
         GSR_TRY(c->pair_child.reserve(4)); GSR_TRY(c->pair_wl.reserve(4)); GSR_TRY(c->spair_child.reserve(4)); GSR_TRY(c->spair_wl.reserve(4));
     }
+#undef GSR_LAUNCH_SELECT
     c->stats[1] = M;
     GSR_HIP(hipEventRecord(c->ev[2], st));
 
@@ -1426,9 +1525,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.prank_in = c->prank_in.as<int>(); ma.poff = c->poff.as<int64_t>(); ma.pcnt = c->pcnt.as<unsigned>();
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
-        ma.porder = (c->use_lpt && c->sparse_path) ? c->porder.as<unsigned>() : nullptr;
+        ma.porder = (c->use_lpt && M > 0) ? c->morder.as<unsigned>() : nullptr;
         ma.xcd = (c->use_xcd && ma.porder) ? 1 : 0;
-        ma.nheavy = c->counters.as<int>() + 8;
+        ma.nheavy = c->counters.as<int>() + 9;
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
         switch (c->wpb_m) {
