@@ -195,9 +195,43 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
     }
 }
 
-// Grid geometry from the bounding box: about `target` components per cell, at most `max_cells` cells.
-__global__ void k_grid_params(const unsigned* __restrict__ bbox, int64_t n, float target, int max_cells,
-                              GridParams* __restrict__ gp) {
+// Per-axis histograms (HIST_BINS bins over the bounding box of the finite centres): the grid is laid over
+// the box that holds all but the outermost 0.1 % of the centres per side, so that a few far-away
+// background splats cannot blow the cells up.  Centres outside that box are clamped into the boundary
+// cells (cell_of is a monotone, non-expanding map, so the neighbour search stays conservative; the
+// boundary rows are treated as half-infinite slabs when rows are culled).
+#define HIST_BINS 1024
+__global__ __launch_bounds__(256) void k_hist(int64_t n, const float* __restrict__ xyz, const unsigned* __restrict__ bbox,
+                                              unsigned* __restrict__ hist /* [3][HIST_BINS] */) {
+    __shared__ unsigned s_h[3 * HIST_BINS];
+    for (int k = threadIdx.x; k < 3 * HIST_BINS; k += blockDim.x) s_h[k] = 0u;
+    __syncthreads();
+    float mn[3], sc[3];
+    for (int k = 0; k < 3; ++k) {
+        mn[k] = dec_f(bbox[k]);
+        const float ext = dec_f(bbox[3 + k]) - mn[k];
+        sc[k] = ext > 0.0f ? (float)HIST_BINS / ext : 0.0f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+        if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX) {
+            const float v[3] = {x, y, z};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int b = (int)((v[k] - mn[k]) * sc[k]);
+                b = b < 0 ? 0 : (b > HIST_BINS - 1 ? HIST_BINS - 1 : b);
+                atomicAdd(&s_h[k * HIST_BINS + b], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 3 * HIST_BINS; k += blockDim.x)
+        if (s_h[k]) atomicAdd(&hist[k], s_h[k]);
+}
+
+// Grid geometry: about `target` components per cell over the robust box, at most `max_cells` cells.
+__global__ void k_grid_params(const unsigned* __restrict__ bbox, const unsigned* __restrict__ hist, int64_t n, float target,
+                              int max_cells, GridParams* __restrict__ gp) {
     float mn[3], mx[3];
     for (int k = 0; k < 3; ++k) { mn[k] = dec_f(bbox[k]); mx[k] = dec_f(bbox[3 + k]); }
     GridParams g;
@@ -206,11 +240,31 @@ __global__ void k_grid_params(const unsigned* __restrict__ bbox, int64_t n, floa
         *gp = g;
         return;
     }
+    // robust box: drop the outermost 0.1 % per side (whole bins), then one bin of margin
+    double inside = (double)n;
+    for (int k = 0; k < 3; ++k) {
+        const float ext = mx[k] - mn[k];
+        if (!(ext > 0.0f)) continue;
+        unsigned long long tot = 0;
+        for (int b = 0; b < HIST_BINS; ++b) tot += hist[k * HIST_BINS + b];
+        const unsigned long long cut = tot / 1000ull;
+        int lo = 0, hi = HIST_BINS - 1;
+        unsigned long long acc = 0;
+        while (lo < HIST_BINS - 1 && acc + hist[k * HIST_BINS + lo] <= cut) { acc += hist[k * HIST_BINS + lo]; ++lo; }
+        acc = 0;
+        while (hi > lo && acc + hist[k * HIST_BINS + hi] <= cut) { acc += hist[k * HIST_BINS + hi]; --hi; }
+        lo = lo > 0 ? lo - 1 : 0;
+        hi = hi < HIST_BINS - 1 ? hi + 1 : HIST_BINS - 1;
+        const float w = ext / (float)HIST_BINS;
+        const float nmn = mn[k] + w * (float)lo, nmx = mn[k] + w * (float)(hi + 1);
+        mn[k] = nmn; mx[k] = nmx < mx[k] ? nmx : mx[k];
+        inside *= 0.998;
+    }
     float ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
     float emax = fmaxf(ex, fmaxf(ey, ez));
     float eps = emax * 1e-6f + 1e-30f;
     double vol = (double)(ex + eps) * (double)(ey + eps) * (double)(ez + eps);
-    double c = cbrt(vol * (double)target / (double)(n > 0 ? n : 1));
+    double c = cbrt(vol * (double)target / (inside > 1.0 ? inside : 1.0));
     if (!(c > 0.0)) c = 1.0;
     int gx, gy, gz;
     for (;;) {
@@ -469,8 +523,9 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
             if (r < nrows) {
                 const int ry = y0 + r % ny, rz = z0 + r / ny;
                 // distance from the parent to the row's y/z slab (widened by the rounding slack)
-                const float ylo = g.oy + ry * g.c - g.slack, yhi = g.oy + (ry + 1) * g.c + g.slack;
-                const float zlo = g.oz + rz * g.c - g.slack, zhi = g.oz + (rz + 1) * g.c + g.slack;
+                // (the first / last row of the grid also holds every centre clamped in from outside: half-infinite)
+                const float ylo = ry == 0 ? -FLT_MAX : g.oy + ry * g.c - g.slack, yhi = ry == g.gy - 1 ? FLT_MAX : g.oy + (ry + 1) * g.c + g.slack;
+                const float zlo = rz == 0 ? -FLT_MAX : g.oz + rz * g.c - g.slack, zhi = rz == g.gz - 1 ? FLT_MAX : g.oz + (rz + 1) * g.c + g.slack;
                 const float dy = fmaxf(0.0f, fmaxf(ylo - pm.y, pm.y - yhi));
                 const float dz = fmaxf(0.0f, fmaxf(zlo - pm.z, pm.z - zhi));
                 const float rem = Ra2 - dy * dy - dz * dz;
@@ -1014,7 +1069,7 @@ struct gsr_hem_ctx {
     Level cur, nxt, tmp;
     bool have_level = false;
     // workspace
-    DevBuf regular;
+    DevBuf regular, hist;
     DevBuf det, radius, bbox, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, morder, nparts, vstart, vparent, vpart, vcap, vcnt;
     int part_cap = 0;               // candidates per work item when a heavy parent is split; 0 = never (measured: 8192 cuts
@@ -1167,7 +1222,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->regular, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->regular, &c->hist, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
@@ -1303,7 +1358,10 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     }
     hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.cov6.as<float>(), L.is_parent.as<uint8_t>(), c->delta,
                        c->det.as<float>(), c->radius.as<float>(), c->regular.as<uint8_t>(), c->bbox.as<unsigned>());
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1), 0, st, c->bbox.as<unsigned>(), n, c->cell_target, c->max_cells,
+    GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
+    GSR_HIP(hipMemsetAsync(c->hist.p, 0, 3 * HIST_BINS * 4, st));
+    hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>());
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), n, c->cell_target, c->max_cells,
                        c->gparams.as<GridParams>());
     GridParams gp;
     GSR_HIP(hipMemcpyAsync(&gp, c->gparams.p, sizeof(gp), hipMemcpyDeviceToHost, st));
