@@ -4,8 +4,8 @@
 Kept (same names / shapes): ``get_xyz (N,3)`` ``:56-57``, ``get_colors (N,3)`` ``:66-67``,
 ``get_spherical_harmonics (N, 3*((deg+1)^2-1))`` ``:70-71``, ``get_raw_opacity (N,1)`` ``:78-79``,
 ``get_covariance(1) (N,6)`` ``:89-91``, ``get_full_covariance()`` ``:81-87``, ``from_mixture(model, sh_degree)``
-``:141-153``, ``move_to_device`` ``:223-234``, ``clone_gaussian``.  ``from_arrays`` builds level 0 from
-raw arrays (the ``.ply`` reader of ``:98-139`` needs ``plyfile`` -- SURVEY.md 8f N3, not this round).
+``:141-153``, ``move_to_device`` ``:223-234``, ``clone_gaussian``, ``from_ply`` / ``save_ply`` (``:98-139,169-185``; own
+reader/writer in ``utils/ply_io.py``, ``plyfile`` is not needed).  ``from_arrays`` builds level 0 from raw arrays.
 
 ``from_mixture`` does not run the reference's ``torch.linalg.eigh`` scaling/rotation rebuild
 (``:151-153,242-265``; the reference's own comment calls it unused) unless asked: registration only
@@ -92,6 +92,25 @@ class GaussianModel:
         self._opacity = _t(opacities, self.device_name, (n, 1))
         self._covariance = _t(covariance, self.device_name, (n, 6))
         return self
+
+    def from_ply(self, path_or_arrays):
+        """``GaussianModel.from_ply`` (reference ``gaussian_model.py:98-139``) from a file path (own reader,
+        ``utils/ply_io.py``) or from the dict ``ply_io.load_gaussian_arrays`` returns."""
+        from ..utils import ply_io
+        d = ply_io.load_gaussian_arrays(path_or_arrays) if isinstance(path_or_arrays, (str, bytes)) or hasattr(path_or_arrays, "__fspath__") else path_or_arrays
+        self.from_arrays(d["xyz"], d["color"], d["opacity"], d["cov6"], d["sh"], d["sh_degree"])
+        self._scaling = _t(d["scale"], self.device_name)
+        self._rotation = _t(d["rot"], self.device_name)
+        return self
+
+    def save_ply(self, path):
+        """``GaussianModel.save_ply`` (``gaussian_model.py:169-185``)."""
+        from ..utils import ply_io
+        if self._scaling.numel() == 0:
+            raise RuntimeError("save_ply needs scaling/rotation: build the model with from_ply or from_mixture(..., decompose=True)")
+        c = lambda t: t.detach().cpu().numpy()
+        ply_io.save_gaussian_ply(path, c(self._xyz), c(self.get_colors), c(self.get_spherical_harmonics), c(self._opacity),
+                                 c(self._scaling), c(self._rotation))
 
     def from_mixture(self, gaussian_mixture: GaussianMixtureModel, sh_degree: int, decompose: bool = False):
         self.sh_degree = sh_degree

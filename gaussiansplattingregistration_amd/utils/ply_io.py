@@ -1,0 +1,116 @@
+"""3DGS ``.ply`` reader / writer without ``plyfile`` (absent in this image): the on-disk format either
+side of the hot path.
+
+Layout as the reference reads and writes it (``src/models/gaussian_model.py:98-139,155-185``): one ``vertex``
+element, float32 properties ``x y z nx ny nz f_dc_0..2 f_rest_0..(3K-1) opacity scale_0..2 rot_0..3`` in
+binary little endian.  ``f_rest`` is stored channel-major on disk (``(P, 3, K)``) and transposed to the
+coefficient-major ``(P, K, 3)`` tensors the model keeps (``gaussian_model.py:115-116,131-134``);
+``opacity`` is the raw logit, ``scale`` the log standard deviations, ``rot`` the (w, x, y, z) quaternion.
+ASCII ply files are read too.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+_PLY_TYPES = {"char": "i1", "uchar": "u1", "short": "i2", "ushort": "u2", "int": "i4", "uint": "u4", "float": "f4",
+              "double": "f8", "int8": "i1", "uint8": "u1", "int16": "i2", "uint16": "u2", "int32": "i4", "uint32": "u4",
+              "float32": "f4", "float64": "f8"}
+
+
+def read_ply_vertices(path) -> np.ndarray:
+    """Return the ``vertex`` element as a structured numpy array."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError(f"{path}: not a ply file")
+        fmt, n, props, in_vertex = None, 0, [], False
+        while True:
+            line = f.readline()
+            if not line:
+                raise ValueError(f"{path}: truncated ply header")
+            tok = line.decode("ascii", "replace").split()
+            if not tok:
+                continue
+            if tok[0] == "format":
+                fmt = tok[1]
+            elif tok[0] == "element":
+                in_vertex = tok[1] == "vertex"
+                if in_vertex:
+                    n = int(tok[2])
+            elif tok[0] == "property" and in_vertex:
+                if tok[1] == "list":
+                    raise ValueError(f"{path}: list properties in the vertex element are not supported")
+                props.append((tok[2], _PLY_TYPES[tok[1]]))
+            elif tok[0] == "end_header":
+                break
+        if fmt == "ascii":
+            data = np.loadtxt(f, max_rows=n, ndmin=2)
+            out = np.empty(n, dtype=[(name, "<" + t) for name, t in props])
+            for k, (name, _) in enumerate(props):
+                out[name] = data[:, k]
+            return out
+        endian = "<" if fmt == "binary_little_endian" else ">"
+        dt = np.dtype([(name, endian + t) for name, t in props])
+        out = np.fromfile(f, dtype=dt, count=n)
+        if out.shape[0] != n:
+            raise ValueError(f"{path}: expected {n} vertices, found {out.shape[0]}")
+        return out
+
+
+def is_gaussian_ply(vertices: np.ndarray) -> bool:
+    names = vertices.dtype.names or ()
+    return all(k in names for k in ("x", "y", "z", "opacity", "f_dc_0", "scale_0", "rot_0"))
+
+
+def load_gaussian_arrays(path) -> dict:
+    """``GaussianModel.from_ply`` arithmetic on the host: the five level-0 arrays + scaling/rotation.
+
+    xyz (P,3), colors (P,3) = SH DC, sh (P, 3K) coefficient-major flattened, opacity (P,) raw, cov6 (P,6) from
+    ``R diag(exp(scale))^2 R^T`` (``gaussian_model.py:34-38,139``, ``general_utils.py:43-80``), scale (P,3) log, rot (P,4)."""
+    v = read_ply_vertices(path)
+    if not is_gaussian_ply(v):
+        raise ValueError(f"{path}: not a Gaussian-splat ply (missing opacity / f_dc / scale / rot properties)")
+    names = v.dtype.names
+    P = v.shape[0]
+    xyz = np.stack([v["x"], v["y"], v["z"]], 1).astype(np.float32)
+    dc = np.stack([v["f_dc_0"], v["f_dc_1"], v["f_dc_2"]], 1).astype(np.float32)
+    rest_names = sorted([k for k in names if k.startswith("f_rest_")], key=lambda s: int(s.split("_")[-1]))
+    K3 = len(rest_names)
+    sh_degree = int(round(((K3 + 3) / 3) ** 0.5 - 1))
+    K = (sh_degree + 1) ** 2 - 1
+    rest = np.stack([v[k] for k in rest_names], 1).astype(np.float32) if K3 else np.zeros((P, 0), np.float32)
+    rest = rest.reshape(P, 3, K).transpose(0, 2, 1).reshape(P, 3 * K)          # (P,3,K) on disk -> (P,K,3) flattened
+    scale = np.stack([v[k] for k in sorted([k for k in names if k.startswith("scale_")], key=lambda s: int(s.split("_")[-1]))], 1).astype(np.float32)
+    rot = np.stack([v[k] for k in sorted([k for k in names if k.startswith("rot")], key=lambda s: int(s.split("_")[-1]))], 1).astype(np.float32)
+    q = rot / np.linalg.norm(rot, axis=1, keepdims=True)
+    r, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    R = np.empty((P, 3, 3), np.float32)
+    R[:, 0, 0] = 1 - 2 * (y * y + z * z); R[:, 0, 1] = 2 * (x * y - r * z); R[:, 0, 2] = 2 * (x * z + r * y)
+    R[:, 1, 0] = 2 * (x * y + r * z); R[:, 1, 1] = 1 - 2 * (x * x + z * z); R[:, 1, 2] = 2 * (y * z - r * x)
+    R[:, 2, 0] = 2 * (x * z - r * y); R[:, 2, 1] = 2 * (y * z + r * x); R[:, 2, 2] = 1 - 2 * (x * x + y * y)
+    L = R * np.exp(scale)[:, None, :]
+    C = L @ L.transpose(0, 2, 1)
+    cov6 = np.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1).astype(np.float32)
+    return {"xyz": xyz, "color": dc, "sh": np.ascontiguousarray(rest), "opacity": np.asarray(v["opacity"], np.float32),
+            "cov6": cov6, "scale": scale, "rot": rot, "sh_degree": sh_degree}
+
+
+def save_gaussian_ply(path, xyz, colors, sh, opacity, scale, rot):
+    """``GaussianModel.save_ply`` (``gaussian_model.py:169-185``): binary little endian, normals zero."""
+    xyz = np.asarray(xyz, np.float32)
+    P = xyz.shape[0]
+    sh = np.asarray(sh, np.float32).reshape(P, -1)
+    K = sh.shape[1] // 3
+    rest = sh.reshape(P, K, 3).transpose(0, 2, 1).reshape(P, 3 * K)            # back to channel-major on disk
+    cols = [xyz, np.zeros((P, 3), np.float32), np.asarray(colors, np.float32).reshape(P, 3), rest,
+            np.asarray(opacity, np.float32).reshape(P, 1), np.asarray(scale, np.float32).reshape(P, -1),
+            np.asarray(rot, np.float32).reshape(P, -1)]
+    names = ["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(3 * K)] + ["opacity"]
+    names += [f"scale_{i}" for i in range(cols[5].shape[1])] + [f"rot_{i}" for i in range(cols[6].shape[1])]
+    data = np.ascontiguousarray(np.concatenate(cols, 1).astype("<f4"))
+    with open(path, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\n")
+        f.write(f"element vertex {P}\n".encode())
+        for nme in names:
+            f.write(f"property float {nme}\n".encode())
+        f.write(b"end_header\n")
+        data.tofile(f)

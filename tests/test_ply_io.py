@@ -1,0 +1,52 @@
+"""3DGS .ply round trip (own reader/writer; the reference uses plyfile: gaussian_model.py:98-139,169-185)."""
+import numpy as np
+import torch
+
+from gaussiansplattingregistration_amd import synth
+from gaussiansplattingregistration_amd.models.gaussian_model import GaussianModel
+from gaussiansplattingregistration_amd.utils import ply_io
+
+
+def test_ply_round_trip_and_covariance(tmp_path):
+    rng = np.random.default_rng(0)
+    P, deg = 300, 3
+    K = (deg + 1) ** 2 - 1
+    xyz = rng.normal(size=(P, 3)).astype(np.float32)
+    dc = rng.normal(size=(P, 3)).astype(np.float32)
+    sh = rng.normal(size=(P, 3 * K)).astype(np.float32)            # coefficient-major (P, K, 3) flattened
+    op = rng.normal(size=(P,)).astype(np.float32)
+    scale = rng.normal(-2.5, 0.5, (P, 3)).astype(np.float32)
+    rot = rng.normal(size=(P, 4)).astype(np.float32)
+    path = tmp_path / "cloud.ply"
+    ply_io.save_gaussian_ply(path, xyz, dc, sh, op, scale, rot)
+    v = ply_io.read_ply_vertices(path)
+    assert v.shape[0] == P and ply_io.is_gaussian_ply(v)
+    # on disk f_rest is channel-major: f_rest_0..K-1 = channel 0 of every coefficient (gaussian_model.py:115-116)
+    assert np.array_equal(v["f_rest_0"], sh.reshape(P, K, 3)[:, 0, 0]) and np.array_equal(v["f_rest_1"], sh.reshape(P, K, 3)[:, 1, 0])
+    d = ply_io.load_gaussian_arrays(path)
+    assert d["sh_degree"] == deg
+    for a, b in ((d["xyz"], xyz), (d["color"], dc), (d["sh"], sh), (d["opacity"], op), (d["scale"], scale), (d["rot"], rot)):
+        assert np.array_equal(a, b)
+    # covariance = R diag(exp(scale))^2 R^T, packed xx xy xz yy yz zz
+    q = rot.astype(np.float64) / np.linalg.norm(rot.astype(np.float64), axis=1, keepdims=True)
+    R = synth._quat_to_rot(q)
+    L = R * np.exp(scale.astype(np.float64))[:, None, :]
+    C = L @ L.transpose(0, 2, 1)
+    want = C[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
+    assert np.allclose(d["cov6"], want, rtol=2e-5, atol=2e-7 * np.abs(want).max())      # float32 products, as the reference computes them
+    g = GaussianModel("cpu").from_ply(str(path))
+    assert g.sh_degree == deg and g.get_spherical_harmonics.shape == (P, 3 * K) and g.get_covariance(1).shape == (P, 6)
+    assert torch.equal(g.get_colors, torch.from_numpy(dc))
+    out = tmp_path / "again.ply"
+    g.save_ply(str(out))
+    assert open(out, "rb").read() == open(path, "rb").read()      # byte-identical round trip
+
+
+def test_ascii_ply_and_rejects(tmp_path):
+    p = tmp_path / "a.ply"
+    p.write_text("ply\nformat ascii 1.0\nelement vertex 2\nproperty float x\nproperty float y\nproperty float z\nend_header\n1 2 3\n4 5 6\n")
+    v = ply_io.read_ply_vertices(p)
+    assert v["y"].tolist() == [2.0, 5.0] and not ply_io.is_gaussian_ply(v)
+    import pytest
+    with pytest.raises(ValueError):
+        ply_io.load_gaussian_arrays(p)
