@@ -375,6 +375,7 @@ struct SelectArgs {
     // rows; NI items in all (NI == P and vparent == NULL when nothing is split).  pcap / pcnt / poff are
     // indexed by ITEM in the SPANS / SPARSE / COUNT / FILL modes.
     int NI;
+    int own_lo, own_hi;             // sharded level: this rank evaluates parents [own_lo, own_hi) of plist only
     const unsigned* vparent;        // item -> parent index (into plist)
     const unsigned* vpart;          // item -> part | (nparts << 16)
     const int* cellStart;
@@ -471,6 +472,13 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     const int p = a.vparent ? (int)a.vparent[item] : item;
     const unsigned vpi = a.vpart ? a.vpart[item] : (1u << 16);
     const int part = (int)(vpi & 0xffffu), nparts = (int)(vpi >> 16);
+    if (p < a.own_lo || p >= a.own_hi) {          // another rank's parent: no work, no pairs
+        if (lane == 0) {
+            if (MODE == SEL_SPANS) a.pcap[item] = 0u;
+            else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[item] = 0u;
+        }
+        return;
+    }
     const GridParams g = *a.gp;
     ParentRec pr;
     pr.js = (int)a.plist[p];
@@ -708,6 +716,11 @@ __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restr
     }
 }
 
+__global__ __launch_bounds__(256) void k_orphan_flags(int64_t n, const float* __restrict__ sumLw, int* __restrict__ orphan_flag) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        orphan_flag[j] = sumLw[j] == 0.0f ? 1 : 0;
+}
+
 // flags back to INPUT order, where the output ranks are defined (mixture.cpp:169,250-253)
 __global__ __launch_bounds__(256) void k_flags_to_input_order(int64_t n, const unsigned* __restrict__ order,
                                                               const int* __restrict__ pflag_sorted,
@@ -731,6 +744,7 @@ struct MstepArgs {
     const unsigned* porder;    // processing order (heavy parents first) or NULL
     int xcd;
     const int* nheavy;
+    int own_lo, own_hi;        // sharded level: parents of other ranks are skipped (their output rows stay zero)
     const unsigned* order;
     const int* prank_in;       // exclusive scan of the parent flags in input order
     const int64_t* poff;
@@ -756,6 +770,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     const int slot_ = bid_ * WPB + wv;
     if (slot_ >= a.P) return;
     const int p = a.porder ? (int)a.porder[slot_] : slot_;
+    if (p < a.own_lo || p >= a.own_hi) return;
     const int js = (int)a.plist[p];
     const float4 pa = a.A[js];
     const f3 pm = {pa.x, pa.y, pa.z};
@@ -1075,6 +1090,9 @@ struct gsr_hem_ctx {
     int part_cap = 0;               // candidates per work item when a heavy parent is split; 0 = never (measured: 8192 cuts
                                     // the select kernel by 4% and costs as much in the extra SPANS pass and scans)
     bool use_lpt = true, use_morton = true, use_xcd = true;
+    int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
+    gsr_allreduce_dev_fn shard_allreduce = nullptr;
+    void* shard_user = nullptr;
     int mstep_lds = 0;              // extra dynamic LDS per k_mstep workgroup: caps waves per CU (experiment knob)
     bool sparse_path = false;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
@@ -1248,6 +1266,14 @@ int32_t gsr_hem_get_rng_position(gsr_hem_ctx* c, uint64_t* draws) {
     return GSR_OK;
 }
 
+int32_t gsr_hem_set_shard(gsr_hem_ctx* c, int32_t rank, int32_t world, gsr_allreduce_dev_fn fn, void* user) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_shard: NULL context");
+    if (world < 1 || rank < 0 || rank >= world) return fail(GSR_E_INVALID, "gsr_hem_set_shard: rank %d of %d", rank, world);
+    if (world > 1 && !fn) return fail(GSR_E_INVALID, "gsr_hem_set_shard: world > 1 needs an all-reduce callback");
+    c->shard_rank = rank; c->shard_world = world; c->shard_allreduce = fn; c->shard_user = user;
+    return GSR_OK;
+}
+
 int32_t gsr_hem_set_level0(gsr_hem_ctx* c, const float* xyz, const float* color, const float* cov6,
                            const float* opacity, const float* sh, int64_t n, int32_t F, int32_t on_device) {
     if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_level0: NULL context");
@@ -1408,6 +1434,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.A = c->A.as<float4>(); sa.B = c->B.as<float4>(); sa.C = c->C.as<float4>(); sa.D = c->D.as<float4>();
     sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
     sa.gp = c->gparams.as<GridParams>(); sa.P = P; sa.NI = P;
+    // work sharding: rank r of W evaluates the contiguous run [P r / W, P (r+1) / W) of the cell-sorted parents
+    const bool sharded = c->shard_world > 1 && c->shard_allreduce != nullptr;
+    const int own_lo = sharded ? (int)((int64_t)P * c->shard_rank / c->shard_world) : 0;
+    const int own_hi = sharded ? (int)((int64_t)P * (c->shard_rank + 1) / c->shard_world) : P;
+    sa.own_lo = own_lo; sa.own_hi = own_hi;
     sa.colorThr = c->kappa * c->kappa * 0.5f;     // mixture.cpp:123
     sa.kldThr = c->delta * c->delta * 0.5f;       // mixture.cpp:128
     sa.tau2 = c->tau * c->tau;                    // mixture.cpp:58,61
@@ -1555,6 +1586,12 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL(k_fill_const<int64_t>, grd, blk, 0, st, n + 1, c->cstart.as<int64_t>(), (int64_t)0);
     }
     hipLaunchKernelGGL(k_sumlw, grd, blk, 0, st, n, c->cstart.as<int64_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
+    if (sharded) {
+        // exchange 1: every rank holds the sums over ITS parents; the total decides responsibilities and orphans
+        GSR_HIP(hipStreamSynchronize(st));
+        if (c->shard_allreduce(c->sumLw.p, n, c->shard_user) != 0) return fail(GSR_E_INVALID, "gsr_hem_run_level: all-reduce callback failed (sumLw)");
+        hipLaunchKernelGGL(k_orphan_flags, grd, blk, 0, st, n, c->sumLw.as<float>(), c->oflag.as<int>());
+    }
     GSR_HIP(hipEventRecord(c->ev[3], st));
 
     // ---- 4. output ranks in input order; M-step; orphans -----------------------------------------
@@ -1575,6 +1612,12 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     Level& O = c->nxt;
     GSR_TRY(O.reserve(n_pre, F));
     O.n = n_pre; O.F = F;
+    if (sharded && P > 0) {          // rows of the other ranks' parents stay zero and are filled in by the all-reduce
+        GSR_HIP(hipMemsetAsync(O.xyz.p, 0, (size_t)P * 12, st)); GSR_HIP(hipMemsetAsync(O.color.p, 0, (size_t)P * 12, st));
+        GSR_HIP(hipMemsetAsync(O.cov6.p, 0, (size_t)P * 24, st)); GSR_HIP(hipMemsetAsync(O.opacity.p, 0, (size_t)P * 4, st));
+        GSR_HIP(hipMemsetAsync(O.weight.p, 0, (size_t)P * 4, st));
+        if (F > 0) GSR_HIP(hipMemsetAsync(O.sh.p, 0, (size_t)P * F * 4, st));
+    }
     if (P > 0) {
         MstepArgs ma;
         memset(&ma, 0, sizeof(ma));
@@ -1583,6 +1626,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.prank_in = c->prank_in.as<int>(); ma.poff = c->poff.as<int64_t>(); ma.pcnt = c->pcnt.as<unsigned>();
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
+        ma.own_lo = own_lo; ma.own_hi = own_hi;
         ma.porder = (c->use_lpt && M > 0) ? c->morder.as<unsigned>() : nullptr;
         ma.xcd = (c->use_xcd && ma.porder) ? 1 : 0;
         ma.nheavy = c->counters.as<int>() + 9;
@@ -1601,6 +1645,18 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                        O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>());
     if (F > 0 && n_orph > 0)
         hipLaunchKernelGGL(k_orphans_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
+    if (sharded && P > 0) {
+        // exchange 2: the P merged components (every row written by exactly one rank, zero elsewhere, so the
+        // sum is exact); the orphan rows behind them are computed identically on every rank
+        GSR_HIP(hipStreamSynchronize(st));
+        int rc = c->shard_allreduce(O.xyz.p, (int64_t)P * 3, c->shard_user);
+        if (rc == 0) rc = c->shard_allreduce(O.color.p, (int64_t)P * 3, c->shard_user);
+        if (rc == 0) rc = c->shard_allreduce(O.cov6.p, (int64_t)P * 6, c->shard_user);
+        if (rc == 0) rc = c->shard_allreduce(O.opacity.p, (int64_t)P, c->shard_user);
+        if (rc == 0) rc = c->shard_allreduce(O.weight.p, (int64_t)P, c->shard_user);
+        if (rc == 0 && F > 0) rc = c->shard_allreduce(O.sh.p, (int64_t)P * F, c->shard_user);
+        if (rc != 0) return fail(GSR_E_INVALID, "gsr_hem_run_level: all-reduce callback failed (outputs)");
+    }
     GSR_HIP(hipEventRecord(c->ev[4], st));
 
     // ---- 5. new parent flags (one draw per component, before the erase), validity erase ---------

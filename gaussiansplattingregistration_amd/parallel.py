@@ -9,6 +9,11 @@ ROCm, ``gloo`` on CPU test boxes).  The reference has no distributed code at all
   (32 float64) and ONE all-reduce(sum) of that vector per iteration is the only exchange
   (``make_allreduce``).  It is latency-bound (256 bytes), so xGMI link bandwidth is irrelevant;
   every rank then solves the same 3x3 SVD / 6x6 system and stops on the same reduced fitness/RMSE.
+* **One large cloud, HEM** -- work-sharded levels (``hem_sharded``): the level data is replicated, the
+  cell-sorted parents are split into ``world`` contiguous runs (spatial slabs), and a level makes two
+  all-reduces: the per-child sums of wL (float32[n]) and the merged components (each row written by one
+  rank, zeros elsewhere, so the sum is exact).  Flags, orphans and the validity erase are computed
+  identically on every rank.
 """
 from __future__ import annotations
 
@@ -23,7 +28,7 @@ except Exception:  # pragma: no cover
     torch = None
     dist = None
 
-__all__ = ["init_distributed", "shard_range", "make_allreduce", "assign_clouds", "registration_icp_sharded"]
+__all__ = ["init_distributed", "shard_range", "make_allreduce", "assign_clouds", "registration_icp_sharded", "hem_sharded"]
 
 
 def init_distributed(backend: str | None = None):
@@ -85,3 +90,26 @@ def registration_icp_sharded(source, target, max_correspondence_distance, init, 
     ar = make_allreduce(group, None if device is None else torch.device("cuda", device))
     return registration_icp(local, target, max_correspondence_distance, init, estimation_method, criteria,
                             device=device, allreduce=ar, n_source_global=n)
+
+
+def hem_sharded(cloud: dict, cluster_level: int, rank: int, world: int, device=None, group=None, allreduce=None,
+                as_torch=False, **hem_params):
+    """``MixtureCreator.CreateMixture`` of ONE large cloud with the work of every level split over ``world``
+    GPUs (BASELINE config 5).  Every rank passes the same full ``cloud`` (replicated data); rank r evaluates
+    the r-th spatial slab of parents; two RCCL all-reduces per level (per-child sums, merged components).
+    Every rank returns the identical list of levels.  ``allreduce(tensor)`` defaults to
+    ``torch.distributed.all_reduce`` on ``group``."""
+    from . import hem as _hem
+    if allreduce is None and world > 1:
+        def allreduce(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    dev = device if device is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    with _hem.HemMixture(device=dev, **hem_params) as m:
+        m.set_shard(rank, world, allreduce)
+        m.set_level0(cloud["xyz"], cloud["color"], cloud["opacity"], cloud["cov6"], cloud["sh"])
+        levels, stats = [], []
+        for _ in range(int(cluster_level)):
+            m.run_level()
+            stats.append(m.stats())
+            levels.append(m.get_level(as_torch=as_torch))
+        return levels, stats

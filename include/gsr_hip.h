@@ -83,6 +83,16 @@ int32_t gsr_hem_set_level0(gsr_hem_ctx* ctx, const float* xyz, const float* colo
  * parent_mask[n] (0/1 bytes, consumes no RNG draws) and weight[n].  Host pointers. */
 int32_t gsr_hem_set_state(gsr_hem_ctx* ctx, const uint8_t* parent_mask, const float* weight);
 
+/* Work-sharded levels for ONE large cloud on several GPUs (the reference has no such
+ * thing).  Every rank holds the full level (replicated data, deterministic replicated grid); rank r of
+ * `world` evaluates the contiguous run [P r/world, P (r+1)/world) of the cell-sorted parents -- a spatial
+ * slab -- and the level makes two exchanges through `fn`: the per-child sums of wL (float32[n]) and the
+ * P merged components (every row written by exactly one rank, zero elsewhere).  `fn(dev_ptr, count,
+ * user)` must replace the float32 DEVICE buffer by its element-wise sum over the ranks (RCCL all-reduce in
+ * the host language) and return 0.  world == 1 / fn == NULL restores the single-GPU level. */
+typedef int32_t (*gsr_allreduce_dev_fn)(void* dev_f32, int64_t count, void* user);
+int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_allreduce_dev_fn fn, void* user);
+
 /* One clustering level on the current level (Mixture::createClusterLevel, mixture.cpp:66-285).
  * n_out = components of the new level (after the validity erase); n_dropped = components erased by
  * it (the reference prints these to cerr, mixture.cpp:270-274).  The new level becomes current. */
