@@ -24,6 +24,7 @@
 
 #include <float.h>
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <rocprim/rocprim.hpp>
@@ -161,6 +162,94 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
     return best;
 }
 
+// ---- cooperative search: ICP_LPP lanes per source point -------------------------------------------------
+// A per-thread ring search is a chain of ~10 dependent (cellStart -> candidates) round trips; with 8 lanes
+// per point each lane walks 1-2 row spans and the group's best is combined with 3 xor-shuffles, so the
+// chain is ~5x shorter and the (latency-bound) search kernel needs few registers.  Same result as
+// icp_nearest: exact nearest neighbour, ties to the lowest input index.
+#define ICP_LPP 8
+__device__ __forceinline__ void icp_group_min(double& bd, int& best, unsigned& best_i) {
+#pragma unroll
+    for (int o = 1; o < ICP_LPP; o <<= 1) {
+        const double od = __shfl_xor(bd, o);
+        const int ob = __shfl_xor(best, o);
+        const unsigned oi = __shfl_xor(best_i, o);
+        if (od < bd || (od == bd && oi < best_i)) { bd = od; best = ob; best_i = oi; }
+    }
+}
+
+__device__ __forceinline__ int icp_nearest_group(const IcpGrid& g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
+                                                 double px, double py, double pz, int sub, double& best_d2) {
+    int best = -1;
+    unsigned best_i = 0xffffffffu;
+    double bd = 1.0 / 0.0;
+    if (!(px == px) || !(py == py) || !(pz == pz)) { best_d2 = bd; return -1; }
+    const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
+    // rings 0 and 1 together: the 3x3x3 block as 9 row spans of 3 cells; lane `sub` takes rows sub and sub+8
+    {
+        const int xa = cx > 0 ? cx - 1 : 0, xb = cx < g.gx - 1 ? cx + 1 : g.gx - 1;
+        for (int t = sub; t < 9; t += ICP_LPP) {
+            const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+            if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) continue;
+            const int rowbase = (z * g.gy + y) * g.gx;
+            icp_scan_span(cellStart, Tq, rowbase + xa, rowbase + xb, px, py, pz, bd, best, best_i);
+        }
+        icp_group_min(bd, best, best_i);
+    }
+    for (int r = 2; r <= g.rings; ++r) {
+        const double reach = (double)(r - 1) * g.c * 0.999999999;      // everything inside ring r-1 has been seen
+        if (bd < reach * reach) break;
+        const int w = 2 * r + 1;
+        for (int t = sub; t < w * w; t += ICP_LPP) {
+            const int dz = t / w - r, dy = t % w - r;
+            const int z = cz + dz, y = cy + dy;
+            if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) continue;
+            const int rowbase = (z * g.gy + y) * g.gx;
+            const int adz = dz < 0 ? -dz : dz, ady = dy < 0 ? -dy : dy;
+            if (adz == r || ady == r) {
+                const int xa = cx - r > 0 ? cx - r : 0, xb = cx + r < g.gx - 1 ? cx + r : g.gx - 1;
+                icp_scan_span(cellStart, Tq, rowbase + xa, rowbase + xb, px, py, pz, bd, best, best_i);
+            } else {
+                if (cx - r >= 0) icp_scan_span(cellStart, Tq, rowbase + cx - r, rowbase + cx - r, px, py, pz, bd, best, best_i);
+                if (cx + r < g.gx) icp_scan_span(cellStart, Tq, rowbase + cx + r, rowbase + cx + r, px, py, pz, bd, best, best_i);
+            }
+        }
+        icp_group_min(bd, best, best_i);
+    }
+    best_d2 = bd;
+    return best;
+}
+
+struct IcpState;
+__device__ __forceinline__ bool icp_state_done(const IcpState* st);
+__device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]);
+
+// nn_j[i] = sorted target position of the accepted nearest neighbour of source point i, or -1
+template <bool FROM_STATE>
+__global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restrict__ src, Xform X, const IcpState* __restrict__ st,
+                                                IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
+                                                double max_corr2, int* __restrict__ nn_j) {
+    double T[12];
+    if (FROM_STATE) {
+        if (icp_state_done(st)) return;
+        icp_state_T(st, T);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = X.m[i];
+    }
+    const int sub = threadIdx.x & (ICP_LPP - 1);
+    const int64_t stride = (int64_t)gridDim.x * (blockDim.x / ICP_LPP);
+    for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / ICP_LPP) + (threadIdx.x / ICP_LPP); i < ns; i += stride) {
+        const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
+        const double px = T[0] * x + T[1] * y + T[2] * z + T[3];
+        const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
+        const double pz = T[8] * x + T[9] * y + T[10] * z + T[11];
+        double d2;
+        const int j = icp_nearest_group(g, cellStart, Tq, px, py, pz, sub, d2);
+        if (sub == 0) nn_j[i] = (j >= 0 && d2 < max_corr2) ? j : -1;
+    }
+}
+
 __device__ __forceinline__ double icp_weight(int loss, double k, double r) {   // Open3D RobustKernel.cpp
     switch (loss) {
         case GSR_LOSS_TUKEY: { double t = fmin(1.0, fabs(r) / k); double u = 1.0 - t * t; return u * u; }
@@ -191,9 +280,9 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 // KIND 0: point-to-point sums (17 values); KIND 1: point-to-plane normal equations (30 values)
 template <int KIND>
 __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float* __restrict__ src, Xform T, IcpGrid g,
-                                                        const int* __restrict__ cellStart, const float4* __restrict__ Tq,
-                                                        const double* __restrict__ Tn, double max_corr2, int loss, double kparam,
-                                                        double* __restrict__ partials) {
+                                                        const int* __restrict__ cellStart, const int* __restrict__ nn_j,
+                                                        const float4* __restrict__ Tq, const double* __restrict__ Tn, double max_corr2,
+                                                        int loss, double kparam, double* __restrict__ partials) {
     constexpr int NACC = KIND == 0 ? 17 : 30;
     double acc[NACC];
 #pragma unroll
@@ -203,11 +292,19 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float*
         const double px = T.m[0] * x + T.m[1] * y + T.m[2] * z + T.m[3];
         const double py = T.m[4] * x + T.m[5] * y + T.m[6] * z + T.m[7];
         const double pz = T.m[8] * x + T.m[9] * y + T.m[10] * z + T.m[11];
-        double d2;
-        const int j = icp_nearest(g, cellStart, Tq, px, py, pz, d2);
-        if (j < 0 || !(d2 < max_corr2)) continue;
+        int j;
+        if (nn_j) {                                 // optional two-kernel form: neighbours from k_icp_nn (accepted or -1)
+            j = nn_j[i];
+            if (j < 0) continue;
+        } else {
+            double dd;
+            j = icp_nearest(g, cellStart, Tq, px, py, pz, dd);
+            if (j < 0 || !(dd < max_corr2)) continue;
+        }
         const float4 q = Tq[j];
         const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+        const double ddx = px - qx, ddy = py - qy, ddz = pz - qz;
+        const double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
         acc[0] += 1.0;
         acc[1] += d2;
         if (KIND == 0) {
@@ -246,20 +343,21 @@ __global__ __launch_bounds__(64) void k_icp_finalize(int nblocks, const double* 
     if (lane == 0) out[k] = s;
 }
 
-__global__ __launch_bounds__(256) void k_icp_correspond(int64_t ns, const float* __restrict__ src, Xform T, IcpGrid g,
-                                                        const int* __restrict__ cellStart, const float4* __restrict__ Tq,
-                                                        double max_corr2, const unsigned* __restrict__ src_order,
+__global__ __launch_bounds__(256) void k_icp_correspond(int64_t ns, const float* __restrict__ src, Xform T, const int* __restrict__ nn_j,
+                                                        const float4* __restrict__ Tq, const unsigned* __restrict__ src_order,
                                                         int64_t* __restrict__ out_idx, double* __restrict__ out_d2) {
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < ns; k += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = src_order ? (int64_t)src_order[k] : k;          // results go back to the caller's order
+        const int j = nn_j[k];
+        if (j < 0) { out_idx[i] = -1; out_d2[i] = 0.0; continue; }
         const double x = (double)src[3 * k], y = (double)src[3 * k + 1], z = (double)src[3 * k + 2];
         const double px = T.m[0] * x + T.m[1] * y + T.m[2] * z + T.m[3];
         const double py = T.m[4] * x + T.m[5] * y + T.m[6] * z + T.m[7];
         const double pz = T.m[8] * x + T.m[9] * y + T.m[10] * z + T.m[11];
-        double d2;
-        const int j = icp_nearest(g, cellStart, Tq, px, py, pz, d2);
-        if (j >= 0 && d2 < max_corr2) { out_idx[i] = (int64_t)__float_as_uint(Tq[j].w); out_d2[i] = d2; }
-        else { out_idx[i] = -1; out_d2[i] = 0.0; }
+        const float4 q = Tq[j];
+        const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
+        out_idx[i] = (int64_t)__float_as_uint(q.w);
+        out_d2[i] = dx * dx + dy * dy + dz * dz;
     }
 }
 
@@ -367,8 +465,8 @@ __global__ __launch_bounds__(256) void k_normals_from_cov(int64_t n, const float
     }
 }
 
-// ---- host-side float64 solves ----------------------------------------------------------------------
-static void svd3(const double Ain[3][3], double U[3][3], double s[3], double V[3][3]) {
+// ---- float64 solves (host and device: the device-resident ICP loop runs them in one thread) ----------
+__host__ __device__ static void svd3(const double Ain[3][3], double U[3][3], double s[3], double V[3][3]) {
     double B[3][3];
     for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { B[i][j] = Ain[i][j]; V[i][j] = i == j; }
     for (int sweep = 0; sweep < 60; ++sweep) {
@@ -397,7 +495,7 @@ static void svd3(const double Ain[3][3], double U[3][3], double s[3], double V[3
     for (int a = 0; a < 2; ++a) for (int b = a + 1; b < 3; ++b) if (nrm[order[b]] > nrm[order[a]]) { int t = order[a]; order[a] = order[b]; order[b] = t; }
     double Vs[3][3], Bs[3][3];
     for (int j = 0; j < 3; ++j) { s[j] = nrm[order[j]]; for (int i = 0; i < 3; ++i) { Vs[i][j] = V[i][order[j]]; Bs[i][j] = B[i][order[j]]; } }
-    memcpy(V, Vs, sizeof(Vs));
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = Vs[i][j];
     if (!(s[0] > 0)) { for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) U[i][j] = i == j; return; }
     for (int j = 0; j < 3; ++j) for (int i = 0; i < 3; ++i) U[i][j] = s[j] > 0 ? Bs[i][j] / s[j] : 0.0;
     if (s[1] <= 1e-12 * s[0]) {
@@ -416,11 +514,11 @@ static void svd3(const double Ain[3][3], double U[3][3], double s[3], double V[3
         U[2][2] = U[0][0] * U[1][1] - U[1][0] * U[0][1];
     }
 }
-static double det3(const double m[3][3]) {
+__host__ __device__ static double det3(const double m[3][3]) {
     return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
            m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
 }
-static void solve6(const double A_[6][6], const double b_[6], double x[6]) {
+__host__ __device__ static void solve6(const double A_[6][6], const double b_[6], double x[6]) {
     double A[6][6], b[6], L[6][6] = {{0}}, D[6];
     int perm[6];
     for (int i = 0; i < 6; ++i) { perm[i] = i; b[i] = b_[i]; for (int j = 0; j < 6; ++j) A[i][j] = A_[i][j]; }
@@ -444,79 +542,15 @@ static void solve6(const double A_[6][6], const double b_[6], double x[6]) {
     for (int i = 5; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < 6; ++j) s -= L[j][i] * z[j]; z[i] = s; }
     for (int i = 0; i < 6; ++i) x[perm[i]] = z[i];
 }
-static void mat4_identity(double T[16]) { memset(T, 0, 16 * sizeof(double)); T[0] = T[5] = T[10] = T[15] = 1; }
-static void mat4_mul(const double A[16], const double B[16], double C[16]) {
+__host__ __device__ static void mat4_identity(double T[16]) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0; }
+__host__ __device__ static void mat4_mul(const double A[16], const double B[16], double C[16]) {
     double R[16];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double s = 0; for (int k = 0; k < 4; ++k) s += A[4 * i + k] * B[4 * k + j]; R[4 * i + j] = s; }
-    memcpy(C, R, sizeof(R));
-}
-
-}  // namespace gsr
-
-using namespace gsr;
-
-struct gsr_icp_ctx {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    IcpGrid grid;
-    bool have_target = false, have_normals = false, have_source = false;
-    int64_t nt = 0, ns = 0, ns_global = 0;
-    double max_corr = 0;
-    DevBuf src_raw, src_order;
-    bool src_sorted = false;
-    DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
-    gsr_allreduce_fn allreduce = nullptr;
-    void* allreduce_user = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    float ms_build = 0, ms_iter = 0;
-    int n_iter_kernels = 0;
-    int max_cells = 1 << 24;
-    int nblocks = 1024;
-};
-
-namespace {
-
-int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, double k, double* acc, bool timed) {
-    if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
-    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
-    if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
-        return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
-    hipStream_t st = c->stream;
-    Xform X;
-    for (int i = 0; i < 12; ++i) X.m[i] = T[i];
-    int nb = c->nblocks;
-    if ((int64_t)nb * 256 > c->ns) nb = (int)((c->ns + 255) / 256);
-    if (nb < 1) nb = 1;
-    GSR_TRY(c->partials.reserve((size_t)nb * GSR_ICP_ACC_LEN * 8));
-    GSR_TRY(c->acc_dev.reserve(GSR_ICP_ACC_LEN * 8));
-    GSR_HIP(hipMemsetAsync(c->partials.p, 0, (size_t)nb * GSR_ICP_ACC_LEN * 8, st));
-    if (timed) GSR_HIP(hipEventRecord(c->e0, st));
-    const double mc2 = c->max_corr * c->max_corr;
-    if (kind == GSR_ICP_POINT_TO_POINT)
-        hipLaunchKernelGGL(k_icp_accumulate<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(),
-                           c->Tq.as<float4>(), (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
-    else
-        hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(),
-                           c->Tq.as<float4>(), c->Tn.as<double>(), mc2, loss, k, c->partials.as<double>());
-    hipLaunchKernelGGL(k_icp_finalize, dim3(GSR_ICP_ACC_LEN), dim3(64), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>());
-    if (timed) GSR_HIP(hipEventRecord(c->e1, st));
-    GSR_HIP(hipMemcpyAsync(acc, c->acc_dev.p, GSR_ICP_ACC_LEN * 8, hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipStreamSynchronize(st));
-    if (timed) {
-        float ms = 0;
-        (void)hipEventElapsedTime(&ms, c->e0, c->e1);
-        c->ms_iter += ms;
-        c->n_iter_kernels += 1;
-    }
-    if (c->allreduce) {
-        int32_t r = c->allreduce(acc, GSR_ICP_ACC_LEN, c->allreduce_user);
-        if (r != 0) return fail(GSR_E_INVALID, "icp: all-reduce callback returned %d", r);
-    }
-    return GSR_OK;
+    for (int i = 0; i < 16; ++i) C[i] = R[i];
 }
 
 // estimator update from the reduced accumulators (Open3D TransformationEstimation*.ComputeTransformation)
-void estimate_update(const double ctr[3], int kind, const double* acc, double update[16]) {
+__host__ __device__ static void estimate_update(const double ctr[3], int kind, const double* acc, double update[16]) {
     mat4_identity(update);
     const double n = acc[0];
     if (!(n > 0)) return;                                   // no correspondences -> identity
@@ -550,6 +584,199 @@ void estimate_update(const double ctr[3], int kind, const double* acc, double up
     }
 }
 
+
+// ---- device-resident ICP loop -------------------------------------------------------------------------
+// registration_icp's loop needs, per iteration, one correspondence pass and a 3x3 / 6x6 solve on 32
+// doubles.  Driving it from the host costs a device->host copy and a stream synchronisation per
+// iteration (~60 us, comparable to the kernel itself on small levels); here the transform, the
+// convergence test and the solve stay on the device: k_icp_accumulate_dev reads T from IcpState,
+// k_icp_step reduces the block partials (same fixed order as k_icp_finalize), tests convergence,
+// solves and updates T in ONE thread.  The host enqueues iterations in chunks and looks at `done` once
+// per chunk; iterations enqueued after convergence return immediately.
+struct IcpState {
+    double T[16];
+    double fit, rmse;          // of the latest evaluation
+    double ctr[3], nsg, rel_fit, rel_rmse;
+    int iters, done, max_iter, kind, evals;
+};
+
+__device__ __forceinline__ bool icp_state_done(const IcpState* st) { return st->done != 0; }
+__device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]) {
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = st->T[i];
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, const IcpState* __restrict__ st,
+                                                            IcpGrid g, const int* __restrict__ cellStart, const int* __restrict__ nn_j,
+                                                            const float4* __restrict__ Tq, const double* __restrict__ Tn, double max_corr2,
+                                                            int loss, double kparam, double* __restrict__ partials) {
+    if (st->done) return;
+    constexpr int NACC = KIND == 0 ? 17 : 30;
+    double T[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T[i] = st->T[i];
+    double acc[NACC];
+#pragma unroll
+    for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
+        const double px = T[0] * x + T[1] * y + T[2] * z + T[3];
+        const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
+        const double pz = T[8] * x + T[9] * y + T[10] * z + T[11];
+        int j;
+        if (nn_j) {                                 // optional two-kernel form: neighbours from k_icp_nn (accepted or -1)
+            j = nn_j[i];
+            if (j < 0) continue;
+        } else {
+            double dd;
+            j = icp_nearest(g, cellStart, Tq, px, py, pz, dd);
+            if (j < 0 || !(dd < max_corr2)) continue;
+        }
+        const float4 q = Tq[j];
+        const double qx = (double)q.x, qy = (double)q.y, qz = (double)q.z;
+        const double ddx = px - qx, ddy = py - qy, ddz = pz - qz;
+        const double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
+        acc[0] += 1.0;
+        acc[1] += d2;
+        if (KIND == 0) {
+            const double ax = px - g.cx, ay = py - g.cy, az = pz - g.cz;
+            const double bx = qx - g.cx, by = qy - g.cy, bz = qz - g.cz;
+            acc[2] += ax; acc[3] += ay; acc[4] += az;
+            acc[5] += bx; acc[6] += by; acc[7] += bz;
+            acc[8] += ax * bx; acc[9] += ax * by; acc[10] += ax * bz;
+            acc[11] += ay * bx; acc[12] += ay * by; acc[13] += ay * bz;
+            acc[14] += az * bx; acc[15] += az * by; acc[16] += az * bz;
+        } else {
+            const double nx = Tn[3 * (int64_t)j], ny = Tn[3 * (int64_t)j + 1], nz = Tn[3 * (int64_t)j + 2];
+            const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
+            const double w = icp_weight(loss, kparam, r);
+            const double J[6] = {py * nz - pz * ny, pz * nx - px * nz, px * ny - py * nx, nx, ny, nz};
+            int t = 2;
+#pragma unroll
+            for (int a = 0; a < 6; ++a)
+#pragma unroll
+                for (int b = a; b < 6; ++b) acc[t++] += J[a] * w * J[b];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) acc[23 + a] += J[a] * w * r;
+            acc[29] += r * r;
+        }
+    }
+    block_reduce_store<NACC>(acc, partials);
+}
+
+__global__ __launch_bounds__(1024) void k_icp_step(int nblocks, const double* __restrict__ partials, IcpState* __restrict__ st) {
+    __shared__ double s_acc[GSR_ICP_ACC_LEN];
+    if (st->done) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;         // 16 wavefronts, 2 accumulators each
+    for (int k = wv; k < GSR_ICP_ACC_LEN; k += 16) {
+        double s = 0.0;
+        for (int b = lane; b < nblocks; b += 64) s += partials[(int64_t)b * GSR_ICP_ACC_LEN + k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) s_acc[k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    double acc[GSR_ICP_ACC_LEN];
+    for (int k = 0; k < GSR_ICP_ACC_LEN; ++k) acc[k] = s_acc[k];
+    const double fit = acc[0] > 0 ? acc[0] / st->nsg : 0.0, rmse = acc[0] > 0 ? sqrt(acc[1] / acc[0]) : 0.0;
+    const bool first = st->evals == 0;
+    const bool stop = !first && fabs(st->fit - fit) < st->rel_fit && fabs(st->rmse - rmse) < st->rel_rmse;
+    st->fit = fit; st->rmse = rmse;
+    st->evals += 1;
+    if (stop || st->iters >= st->max_iter) { st->done = 1; return; }
+    double update[16], T[16];
+    estimate_update(st->ctr, st->kind, acc, update);
+    for (int i = 0; i < 16; ++i) T[i] = st->T[i];
+    mat4_mul(update, T, T);
+    for (int i = 0; i < 16; ++i) st->T[i] = T[i];
+    st->iters += 1;
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+struct gsr_icp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    IcpGrid grid;
+    bool have_target = false, have_normals = false, have_source = false;
+    int64_t nt = 0, ns = 0, ns_global = 0;
+    double max_corr = 0;
+    DevBuf src_raw, src_order, state, nn_j;
+    bool src_sorted = false;
+    bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
+    bool nn_kernel = false;         // GSR_ICP_NN_KERNEL=1: separate 8-lanes-per-point search kernel (measured 1.5x SLOWER
+                                    // than the fused thread-per-point search at 5M points: kept for the correspondence API)
+    double cell_target = 2.0;       // target points per grid cell (GSR_ICP_CELL_TARGET).  Measured at 5M x 5M: 0.5 makes a
+                                    // converged iteration 1.7x faster but a cold start (offsets ~ max_corr) 1.6x slower: keep 2
+    DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
+    gsr_allreduce_fn allreduce = nullptr;
+    void* allreduce_user = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    float ms_build = 0, ms_iter = 0;
+    int n_iter_kernels = 0;
+    int max_cells = 1 << 25;
+    int nblocks = 1024;
+};
+
+namespace {
+
+// grid of the cooperative search kernel: 256 / ICP_LPP points per block, capped (grid-stride loop)
+inline int nn_grid(int64_t ns) {
+    int64_t g = (ns * ICP_LPP + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 16384) g = 16384;
+    return (int)g;
+}
+
+int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, double k, double* acc, bool timed) {
+    if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
+    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
+    if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
+        return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
+    hipStream_t st = c->stream;
+    Xform X;
+    for (int i = 0; i < 12; ++i) X.m[i] = T[i];
+    int nb = c->nblocks;
+    if ((int64_t)nb * 256 > c->ns) nb = (int)((c->ns + 255) / 256);
+    if (nb < 1) nb = 1;
+    GSR_TRY(c->partials.reserve((size_t)nb * GSR_ICP_ACC_LEN * 8));
+    GSR_TRY(c->acc_dev.reserve(GSR_ICP_ACC_LEN * 8));
+    GSR_HIP(hipMemsetAsync(c->partials.p, 0, (size_t)nb * GSR_ICP_ACC_LEN * 8, st));
+    if (timed) GSR_HIP(hipEventRecord(c->e0, st));
+    const double mc2 = c->max_corr * c->max_corr;
+    const int* nnj = nullptr;
+    if (c->nn_kernel) {
+        GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
+        hipLaunchKernelGGL(k_icp_nn<false>, dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                           c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+        nnj = c->nn_j.as<int>();
+    }
+    if (kind == GSR_ICP_POINT_TO_POINT)
+        hipLaunchKernelGGL(k_icp_accumulate<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
+                           c->Tq.as<float4>(), (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
+    else
+        hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
+                           c->Tq.as<float4>(), c->Tn.as<double>(), mc2, loss, k, c->partials.as<double>());
+    hipLaunchKernelGGL(k_icp_finalize, dim3(GSR_ICP_ACC_LEN), dim3(64), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>());
+    if (timed) GSR_HIP(hipEventRecord(c->e1, st));
+    GSR_HIP(hipMemcpyAsync(acc, c->acc_dev.p, GSR_ICP_ACC_LEN * 8, hipMemcpyDeviceToHost, st));
+    GSR_HIP(hipStreamSynchronize(st));
+    if (timed) {
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, c->e0, c->e1);
+        c->ms_iter += ms;
+        c->n_iter_kernels += 1;
+    }
+    if (c->allreduce) {
+        int32_t r = c->allreduce(acc, GSR_ICP_ACC_LEN, c->allreduce_user);
+        if (r != 0) return fail(GSR_E_INVALID, "icp: all-reduce callback returned %d", r);
+    }
+    return GSR_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -566,6 +793,10 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     c->device = device;
     c->stream = (hipStream_t)stream;
     if (hipEventCreate(&c->e0) != hipSuccess || hipEventCreate(&c->e1) != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate failed"); }
+    if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_NN_KERNEL")) c->nn_kernel = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_CELL_TARGET")) { double v = atof(e); if (v > 0.01 && v < 1000) c->cell_target = v; }
+    if (const char* e = getenv("GSR_ICP_MAX_CELLS")) { int v = atoi(e); if (v >= 1024) c->max_cells = v; }
     *out = c;
     return GSR_OK;
 }
@@ -573,7 +804,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
 int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
-    DevBuf* all[] = {&c->src_raw, &c->src_order, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
+    DevBuf* all[] = {&c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
                      &c->src, &c->partials, &c->acc_dev, &c->rocprim_tmp, &c->corr_idx, &c->corr_d2};
     for (DevBuf* b : all) b->release();
     if (c->e0) (void)hipEventDestroy(c->e0);
@@ -631,7 +862,7 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     {
         const double ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
         const double emax = fmax(ex, fmax(ey, ez)), eps = emax * 1e-6 + 1e-30;
-        cell = cbrt((ex + eps) * (ey + eps) * (ez + eps) * 2.0 / (double)n);
+        cell = cbrt((ex + eps) * (ey + eps) * (ez + eps) * c->cell_target / (double)n);
         if (!(cell > 0)) cell = max_corr;
         if (cell < max_corr / 8.0) cell = max_corr / 8.0;
     }
@@ -723,6 +954,61 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
     if (!c || !init_T || !out_T) return fail(GSR_E_INVALID, "gsr_icp_register: NULL argument");
     GSR_HIP(hipSetDevice(c->device));
     c->ms_iter = 0; c->n_iter_kernels = 0;
+    if (!c->allreduce && c->device_loop) {
+        // device-resident loop (single rank): no per-iteration host round trip
+        if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
+        if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
+        if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
+            return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
+        hipStream_t st = c->stream;
+        IcpState hs;
+        memset(&hs, 0, sizeof(hs));
+        memcpy(hs.T, init_T, sizeof(hs.T));
+        hs.ctr[0] = c->grid.cx; hs.ctr[1] = c->grid.cy; hs.ctr[2] = c->grid.cz;
+        hs.nsg = (double)c->ns; hs.rel_fit = rel_fitness; hs.rel_rmse = rel_rmse;
+        hs.max_iter = max_iter < 0 ? 0 : max_iter; hs.kind = kind;
+        GSR_TRY(c->state.reserve(sizeof(IcpState)));
+        GSR_HIP(hipMemcpyAsync(c->state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
+        int nb = c->nblocks;
+        if ((int64_t)nb * 256 > c->ns) nb = (int)((c->ns + 255) / 256);
+        if (nb < 1) nb = 1;
+        GSR_TRY(c->partials.reserve((size_t)nb * GSR_ICP_ACC_LEN * 8));
+        GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
+        GSR_HIP(hipMemsetAsync(c->partials.p, 0, (size_t)nb * GSR_ICP_ACC_LEN * 8, st));
+        const double mc2 = c->max_corr * c->max_corr;
+        const int total_evals = hs.max_iter + 1;
+        int issued = 0;
+        GSR_HIP(hipEventRecord(c->e0, st));
+        while (issued < total_evals) {
+            const int chunk = total_evals - issued < 8 ? total_evals - issued : 8;
+            const int* nnj = c->nn_kernel ? c->nn_j.as<int>() : (const int*)nullptr;
+            for (int i = 0; i < chunk; ++i) {
+                if (c->nn_kernel)
+                    hipLaunchKernelGGL(k_icp_nn<true>, dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
+                                       c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+                if (kind == GSR_ICP_POINT_TO_POINT)
+                    hipLaunchKernelGGL(k_icp_accumulate_dev<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
+                else
+                    hipLaunchKernelGGL(k_icp_accumulate_dev<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tn.as<double>(), mc2, loss, k, c->partials.as<double>());
+                hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>());
+            }
+            issued += chunk;
+            GSR_HIP(hipMemcpyAsync(&hs, c->state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
+            GSR_HIP(hipStreamSynchronize(st));
+            if (hs.done) break;
+        }
+        GSR_HIP(hipEventRecord(c->e1, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        (void)hipEventElapsedTime(&c->ms_iter, c->e0, c->e1);
+        c->n_iter_kernels = hs.evals;
+        memcpy(out_T, hs.T, sizeof(hs.T));
+        if (fitness) *fitness = hs.fit;
+        if (inlier_rmse) *inlier_rmse = hs.rmse;
+        if (iterations) *iterations = hs.iters;
+        return GSR_OK;
+    }
     double T[16], acc[GSR_ICP_ACC_LEN], update[16];
     memcpy(T, init_T, sizeof(T));
     GSR_TRY(run_accumulate(c, T, kind, loss, k, acc, true));
@@ -753,9 +1039,12 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     GSR_TRY(c->corr_idx.reserve((size_t)c->ns * 8)); GSR_TRY(c->corr_d2.reserve((size_t)c->ns * 8));
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
-    hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->grid,
-                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr,
-                       c->corr_idx.as<int64_t>(), c->corr_d2.as<double>());
+    GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
+    hipLaunchKernelGGL(k_icp_nn<false>, dim3(nn_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
+    hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->nn_j.as<int>(),
+                       c->Tq.as<float4>(), c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->corr_idx.as<int64_t>(),
+                       c->corr_d2.as<double>());
     GSR_HIP(hipMemcpyAsync(idx, c->corr_idx.p, (size_t)c->ns * 8, hipMemcpyDeviceToHost, c->stream));
     GSR_HIP(hipMemcpyAsync(d2, c->corr_d2.p, (size_t)c->ns * 8, hipMemcpyDeviceToHost, c->stream));
     GSR_HIP(hipStreamSynchronize(c->stream));
