@@ -169,7 +169,7 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
                                               const float* __restrict__ cov6,
                                               const uint8_t* __restrict__ is_parent, float delta,
                                               float* __restrict__ det, float* __restrict__ radius,
-                                              uint8_t* __restrict__ regular, unsigned* __restrict__ bbox) {
+                                              uint8_t* __restrict__ regular, unsigned* __restrict__ bbox_part) {
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         s6 c = {cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5]};
@@ -186,12 +186,46 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
             mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
         }
     }
+    // per-block partial box, no atomics: 10^4 same-address atomics cost ~0.5 ms on this part (they serialise
+    // across the XCDs); k_bbox_reduce folds the partials
+    __shared__ float s_mn[4][3], s_mx[4][3];
     for (int k = 0; k < 3; ++k) { mn[k] = wave_min(mn[k]); mx[k] = wave_max(mx[k]); }
-    if ((threadIdx.x & 63) == 0) {
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 3; ++k) { s_mn[threadIdx.x >> 6][k] = mn[k]; s_mx[threadIdx.x >> 6][k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = s_mn[0][k], b = s_mx[0][k];
+        for (int w = 1; w < 4; ++w) { a = fminf(a, s_mn[w][k]); b = fmaxf(b, s_mx[w][k]); }
+        bbox_part[6 * blockIdx.x + k] = enc_f(a);
+        bbox_part[6 * blockIdx.x + 3 + k] = enc_f(b);
+    }
+}
+// bbox[0..2] = min, bbox[3..5] = max over the per-block partial boxes (order-preserving uint encoding)
+__global__ __launch_bounds__(256) void k_bbox_reduce(int nblocks, const unsigned* __restrict__ part, unsigned* __restrict__ bbox) {
+    __shared__ unsigned s_v[4][6];
+    unsigned v[6];
+    for (int k = 0; k < 3; ++k) { v[k] = 0xffffffffu; v[3 + k] = 0u; }
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
         for (int k = 0; k < 3; ++k) {
-            atomicMin(&bbox[k], enc_f(mn[k]));
-            atomicMax(&bbox[3 + k], enc_f(mx[k]));
+            const unsigned lo = part[6 * b + k], hi = part[6 * b + 3 + k];
+            v[k] = lo < v[k] ? lo : v[k];
+            v[3 + k] = hi > v[3 + k] ? hi : v[3 + k];
         }
+    for (int k = 0; k < 3; ++k)
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned lo = (unsigned)__shfl_xor((int)v[k], o), hi = (unsigned)__shfl_xor((int)v[3 + k], o);
+            v[k] = lo < v[k] ? lo : v[k];
+            v[3 + k] = hi > v[3 + k] ? hi : v[3 + k];
+        }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 6; ++k) s_v[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        unsigned r = s_v[0][k];
+        for (int w = 1; w < 4; ++w) r = k < 3 ? (s_v[w][k] < r ? s_v[w][k] : r) : (s_v[w][k] > r ? s_v[w][k] : r);
+        bbox[k] = r;
     }
 }
 
@@ -318,7 +352,8 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
                                                 const float* __restrict__ weight, const uint8_t* __restrict__ is_parent,
                                                 const float* __restrict__ det, const float* __restrict__ radius,
                                                 const uint8_t* __restrict__ regular, float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
-                                                float4* __restrict__ D, float* __restrict__ Rs, int* __restrict__ pflag) {
+                                                float4* __restrict__ D, float* __restrict__ Rs, int* __restrict__ pflag, int* __restrict__ iflag) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) iflag[n] = 0;       // the scan runs over n + 1 entries: irank[n] = total
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = order[j];
         const unsigned par = is_parent[i] ? 1u : 0u;
@@ -329,6 +364,7 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
         D[j] = make_float4(color[3 * i + 2], opacity[i], weight[i], det[i]);
         Rs[j] = radius[i];
         pflag[j] = (int)par;
+        iflag[j] = regular[i] ? 0 : 1;
     }
 }
 __global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, const unsigned* __restrict__ order,
@@ -379,6 +415,10 @@ struct SelectArgs {
     const unsigned* vparent;        // item -> parent index (into plist)
     const unsigned* vpart;          // item -> part | (nparts << 16)
     const int* cellStart;
+    const int* irank;               // irank[j] = number of irregular components among sorted positions [0, j)   (n + 1 entries)
+    const unsigned* ipos;           // sorted positions of the irregular components, ascending
+    int n_irr;
+    int ell;                        // 1 = clip the grid rows of a regular parent to its Mahalanobis ellipsoid
     const GridParams* gp;
     int P;
     float colorThr, kldThr, tau2;
@@ -457,6 +497,154 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     base += na;
 }
 
+// Row clipping by the parent's pre-reject ellipsoid E = { x : (x-mu)^T P^-1 (x-mu) <= T }.  A regular child outside E
+// fails the stage-1 pre-reject anyway, so for a regular parent only the grid cells E touches need scanning (E is
+// inscribed in the query sphere and typically holds 1/3 of its volume).  For a row (= the slab dy in [cy-hy, cy+hy],
+// dz in [cz-hz, cz+hz] relative to the parent) write  smd = M00 (dx - xc(dy,dz))^2 + S(dy,dz)  with xc linear and
+// S the Schur-complement form K; sqrt(S) is a norm, so over the slab  sqrt(S) >= sqrt(S(c)) - sqrt(lmax(K)) |h|,
+// lmax(K) <= tr K, and |xc - xc(c)| <= (|M01| hy + |M02| hz) / M00: a conservative x interval in ~40 flops.
+// T carries 1% over smdMax: the float32 rounding of smd and of K is < 1e-3 relative for kappa(P) < 80.
+struct EllClip {
+    float on;                 // 1.0f = clip (regular parent with a sane Schur complement)
+    float k11, k12, k22, kr, im00, m01, m02, T;
+};
+
+// One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
+// REGULAR ones (stage 1: radius test + Mahalanobis pre-reject); IRR = true scans the list of irregular components
+// (ipos, addressed through irank at the cell boundaries) with the radius test only.  Survivors go to the LDS ring.
+template <int MODE, bool IRR>
+__device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const EllClip& ec, float R,
+                                            int lane, int part, int nparts, unsigned* q, int& qh, int& qn, unsigned& count,
+                                            unsigned long long& scanned, int64_t& base) {
+    const f3 pm = pr.pm;
+    const float Ra = fabsf(R) * 1.00001f + g.slack;             // conservative search extent
+    const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
+    const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
+    const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
+    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+    const int nrows = ny * nz;
+    const float Ra2 = Ra * Ra;
+    const bool clip = !IRR && ec.on != 0.0f;
+    for (int rb = 0; rb < nrows; rb += 64) {
+        if (nparts > 1 && ((rb >> 6) % nparts) != part) continue;      // this batch of rows belongs to another item
+        const int r = rb + lane;
+        int s = 0, len = 0;
+        if (r < nrows) {
+            const int ry = y0 + r % ny, rz = z0 + r / ny;
+            // distance from the parent to the row's y/z slab (widened by the rounding slack)
+            // (the first / last row of the grid also holds every centre clamped in from outside: half-infinite)
+            const bool edge = ry == 0 || ry == g.gy - 1 || rz == 0 || rz == g.gz - 1;
+            const float ylo = ry == 0 ? -FLT_MAX : g.oy + ry * g.c - g.slack, yhi = ry == g.gy - 1 ? FLT_MAX : g.oy + (ry + 1) * g.c + g.slack;
+            const float zlo = rz == 0 ? -FLT_MAX : g.oz + rz * g.c - g.slack, zhi = rz == g.gz - 1 ? FLT_MAX : g.oz + (rz + 1) * g.c + g.slack;
+            const float dy = fmaxf(0.0f, fmaxf(ylo - pm.y, pm.y - yhi));
+            const float dz = fmaxf(0.0f, fmaxf(zlo - pm.z, pm.z - zhi));
+            const float rem = Ra2 - dy * dy - dz * dz;
+            if (rem >= 0.0f) {
+                const float hx = sqrtf(rem) * 1.00001f + g.slack;
+                float lo = -hx, hi = hx;                                   // x interval relative to the parent
+                if (clip && !edge) {
+                    const float cy = 0.5f * (ylo + yhi) - pm.y, cz = 0.5f * (zlo + zhi) - pm.z;
+                    const float hy = 0.5f * (yhi - ylo), hz = 0.5f * (zhi - zlo);
+                    const float sc = sqrtf(fmaxf(0.0f, ec.k11 * cy * cy + 2.0f * ec.k12 * cy * cz + ec.k22 * cz * cz));
+                    const float smin = fmaxf(0.0f, sc * 0.999f - ec.kr * sqrtf(hy * hy + hz * hz));
+                    const float rem2 = ec.T - smin * smin;
+                    if (rem2 < 0.0f) {
+                        lo = 1.0f; hi = -1.0f;                             // the row misses the ellipsoid
+                    } else {
+                        const float w = sqrtf(rem2 * ec.im00) * 1.001f;
+                        const float xc = -(ec.m01 * cy + ec.m02 * cz) * ec.im00;
+                        const float dl = (fabsf(ec.m01) * hy + fabsf(ec.m02) * hz) * ec.im00 * 1.001f;
+                        const float pad = g.slack + 1e-5f * fabsf(xc);
+                        lo = fmaxf(lo, xc - dl - w - pad);
+                        hi = fminf(hi, xc + dl + w + pad);
+                    }
+                }
+                if (lo <= hi) {
+                    int xa = cell_of(pm.x + lo, g.ox, g.inv_c, g.gx), xb = cell_of(pm.x + hi, g.ox, g.inv_c, g.gx);
+                    xa = xa < x0 ? x0 : xa;
+                    xb = xb > x1 ? x1 : xb;
+                    const int rowbase = (rz * g.gy + ry) * g.gx;
+                    s = a.cellStart[rowbase + xa];
+                    int e = a.cellStart[rowbase + xb + 1];
+                    if (IRR) { s = a.irank[s]; e = a.irank[e]; }
+                    len = e - s;
+                }
+            }
+        }
+        // pack the non-empty rows to the front of the wave (the ellipsoid misses many rows of the bounding square)
+        const unsigned long long nz_m = __ballot(len > 0);
+        const int nrb = __popcll(nz_m);
+        if (nrb == 0) continue;
+        {
+            const unsigned long long lt = (1ull << lane) - 1ull;
+            const int dst = len > 0 ? __popcll(nz_m & lt) : nrb + __popcll(~nz_m & lt);
+            s = __builtin_amdgcn_ds_permute(dst << 2, s);
+            len = __builtin_amdgcn_ds_permute(dst << 2, len);
+        }
+        int total = len;                                   // candidates of this batch of rows
+        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
+        scanned += (unsigned long long)total;
+        if (MODE == SEL_SPANS) continue;
+        // Row streaming with lane groups: a row's span is contiguous, so a group of GS lanes walks it
+        // with plain strided indices (no per-candidate search); 64/GS rows are in flight at once.
+        // GS adapts to the mean row length of the batch: short rows (small parents) -> 16 lanes.
+        // The kernel is latency bound (one 1-KiB load per wave in flight = ~20 KB per CU), so the
+        // loads of SEL_U consecutive row steps are issued back to back before any is consumed.
+        const int gshift = total >= 40 * nrb ? 6 : (total >= 20 * nrb ? 5 : 4);
+        const int gsz = 1 << gshift, gl = lane & (gsz - 1), gi = lane >> gshift, ng = 64 >> gshift;
+        int maxlen = len;
+        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(maxlen, o); maxlen = t > maxlen ? t : maxlen; }
+        for (int k0 = 0; k0 < maxlen; k0 += gsz) {
+            const int k = k0 + gl;
+            for (int r0 = 0; r0 < nrb; r0 += SEL_U * ng) {
+                float4 ca[SEL_U];
+                int jj[SEL_U];
+                unsigned long long actm[SEL_U];
+#pragma unroll
+                for (int u = 0; u < SEL_U; ++u) {
+                    const int rr = (r0 + u * ng + gi) & 63;
+                    const int rs = __shfl(s, rr), rl = __shfl(len, rr);
+                    const bool act = (r0 + u * ng + gi) < nrb && k < rl;
+                    actm[u] = __ballot(act);
+                    if (IRR) jj[u] = act ? (int)a.ipos[rs + k] : pr.js;
+                    else jj[u] = act ? rs + k : pr.js;   // inactive lanes load a valid dummy record: an UNCONDITIONAL
+                    ca[u] = a.A[jj[u]];               // load lets the SEL_U loads overlap (a branch per load would
+                }                                     // make hipcc wait vmcnt(0) after each one)
+#pragma unroll
+                for (int u = 0; u < SEL_U; ++u) {
+                    if (actm[u] == 0ull) continue;
+                    bool in = false;
+                    if ((actm[u] >> lane) & 1ull) {
+                        const f3 cm = {ca[u].x, ca[u].y, ca[u].z};
+                        const f3 dq = sub3(pm, cm);                   // query - point (pointindex.cpp:137)
+                        in = dot3(dq, dq) < pr.R2;
+                        if (!IRR) {
+                            in = in && (__float_as_uint(ca[u].w) & 2u);   // irregular children belong to pass B
+                            if (in) {                                     // regular child: Mahalanobis pre-reject
+                                const f3 d = sub3(cm, pm);
+                                const float smd = dot3(d, mul6(pr.pinv, d));   // gaussian.hpp:82-85, as kld6 computes it
+                                in = !(smd > pr.smdMax);
+                            }
+                        }
+                    }
+                    const unsigned long long m = __ballot(in);
+                    if (m == 0ull) continue;
+                    if (in) q[(qh + qn + __popcll(m & ((1ull << lane) - 1ull))) & (SEL_QCAP - 1)] = (unsigned)jj[u];
+                    qn += __popcll(m);
+                }
+                // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
+                __builtin_amdgcn_wave_barrier();
+                while (qn >= 64) {
+                    select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base);
+                    qh = (qh + 64) & (SEL_QCAP - 1);
+                    qn -= 64;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
 // WPB = wavefronts (= parents) per workgroup (runtime choice, GSR_HEM_WPB).
 template <int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
@@ -499,14 +687,28 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     }
     const float R = a.Rs[pr.js];
     pr.R2 = R * R;
+    EllClip ec;
+    {
+        const s6& M = pr.pinv;
+        ec.im00 = 1.0f / M.e00;
+        ec.m01 = M.e01; ec.m02 = M.e02;
+        ec.k11 = M.e11 - M.e01 * M.e01 * ec.im00;
+        ec.k12 = M.e12 - M.e01 * M.e02 * ec.im00;
+        ec.k22 = M.e22 - M.e02 * M.e02 * ec.im00;
+        ec.kr = sqrtf(ec.k11 + ec.k22) * 1.001f;
+        ec.T = pr.smdMax * 1.01f;
+        const bool ok = a.ell && pr.smdMax < FLT_MAX && M.e00 > 0.0f && ec.im00 < FLT_MAX && ec.k11 > 0.0f && ec.k22 > 0.0f &&
+                        ec.k11 * ec.k22 > ec.k12 * ec.k12 && ec.kr < FLT_MAX;
+        ec.on = ok ? 1.0f : 0.0f;
+    }
     // the parent record is wave-uniform: pin it in SGPRs (frees ~17 VGPRs -> one more wave per SIMD)
 #define GSR_UNI(x) x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)))
     GSR_UNI(pr.pm.x); GSR_UNI(pr.pm.y); GSR_UNI(pr.pm.z); GSR_UNI(pr.pcol.x); GSR_UNI(pr.pcol.y); GSR_UNI(pr.pcol.z);
     GSR_UNI(pr.pinv.e00); GSR_UNI(pr.pinv.e01); GSR_UNI(pr.pinv.e02); GSR_UNI(pr.pinv.e11); GSR_UNI(pr.pinv.e12); GSR_UNI(pr.pinv.e22);
     GSR_UNI(pr.det_p); GSR_UNI(pr.pweight); GSR_UNI(pr.R2); GSR_UNI(pr.smdMax);
+    GSR_UNI(ec.on); GSR_UNI(ec.k11); GSR_UNI(ec.k12); GSR_UNI(ec.k22); GSR_UNI(ec.kr); GSR_UNI(ec.im00); GSR_UNI(ec.m01); GSR_UNI(ec.m02); GSR_UNI(ec.T);
 #undef GSR_UNI
     pr.js = __builtin_amdgcn_readfirstlane(pr.js);
-    const f3 pm = pr.pm;
 
     unsigned count = 0;                 // accepted pairs (uniform across the wave)
     unsigned long long scanned = 0;     // candidates scanned (uniform)
@@ -515,97 +717,12 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     unsigned* q = s_q[wv];
 
     // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
-    const bool pm_finite = fabsf(pm.x) <= FLT_MAX && fabsf(pm.y) <= FLT_MAX && fabsf(pm.z) <= FLT_MAX;
+    const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
     if (pr.R2 > 0.0f && pm_finite) {
-        const float Ra = fabsf(R) * 1.00001f + g.slack;             // conservative search extent
-        const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
-        const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
-        const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
-        const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-        const int nrows = ny * nz;
-        const float Ra2 = Ra * Ra;
-        for (int rb = 0; rb < nrows; rb += 64) {
-            if (nparts > 1 && ((rb >> 6) % nparts) != part) continue;      // this batch of rows belongs to another item
-            const int r = rb + lane;
-            int s = 0, len = 0;
-            if (r < nrows) {
-                const int ry = y0 + r % ny, rz = z0 + r / ny;
-                // distance from the parent to the row's y/z slab (widened by the rounding slack)
-                // (the first / last row of the grid also holds every centre clamped in from outside: half-infinite)
-                const float ylo = ry == 0 ? -FLT_MAX : g.oy + ry * g.c - g.slack, yhi = ry == g.gy - 1 ? FLT_MAX : g.oy + (ry + 1) * g.c + g.slack;
-                const float zlo = rz == 0 ? -FLT_MAX : g.oz + rz * g.c - g.slack, zhi = rz == g.gz - 1 ? FLT_MAX : g.oz + (rz + 1) * g.c + g.slack;
-                const float dy = fmaxf(0.0f, fmaxf(ylo - pm.y, pm.y - yhi));
-                const float dz = fmaxf(0.0f, fmaxf(zlo - pm.z, pm.z - zhi));
-                const float rem = Ra2 - dy * dy - dz * dz;
-                if (rem >= 0.0f) {
-                    const float hx = sqrtf(rem) * 1.00001f + g.slack;
-                    int xa = cell_of(pm.x - hx, g.ox, g.inv_c, g.gx), xb = cell_of(pm.x + hx, g.ox, g.inv_c, g.gx);
-                    xa = xa < x0 ? x0 : xa;
-                    xb = xb > x1 ? x1 : xb;
-                    const int rowbase = (rz * g.gy + ry) * g.gx;
-                    s = a.cellStart[rowbase + xa];
-                    len = a.cellStart[rowbase + xb + 1] - s;
-                }
-            }
-            int total = len;                                   // candidates of this batch of rows
-            for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-            scanned += (unsigned long long)total;
-            if (MODE == SEL_SPANS || total == 0) continue;
-            // Row streaming with lane groups: a row's span is contiguous, so a group of GS lanes walks it
-            // with plain strided indices (no per-candidate search); 64/GS rows are in flight at once.
-            // GS adapts to the mean row length of the batch: short rows (small parents) -> 16 lanes.
-            // The kernel is latency bound (one 1-KiB load per wave in flight = ~20 KB per CU), so the
-            // loads of SEL_U consecutive row steps are issued back to back before any is consumed.
-            const int nrb = nrows - rb < 64 ? nrows - rb : 64;
-            const int gshift = total >= 40 * nrb ? 6 : (total >= 20 * nrb ? 5 : 4);
-            const int gsz = 1 << gshift, gl = lane & (gsz - 1), gi = lane >> gshift, ng = 64 >> gshift;
-            int maxlen = len;
-            for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(maxlen, o); maxlen = t > maxlen ? t : maxlen; }
-            for (int k0 = 0; k0 < maxlen; k0 += gsz) {
-                const int k = k0 + gl;
-                for (int r0 = 0; r0 < nrb; r0 += SEL_U * ng) {
-                    float4 ca[SEL_U];
-                    int jj[SEL_U];
-                    unsigned long long actm[SEL_U];
-#pragma unroll
-                    for (int u = 0; u < SEL_U; ++u) {
-                        const int rr = (r0 + u * ng + gi) & 63;
-                        const int rs = __shfl(s, rr), rl = __shfl(len, rr);
-                        const bool act = (r0 + u * ng + gi) < nrb && k < rl;
-                        actm[u] = __ballot(act);
-                        jj[u] = act ? rs + k : pr.js;     // inactive lanes load a valid dummy record: an UNCONDITIONAL
-                        ca[u] = a.A[jj[u]];               // load lets the SEL_U loads overlap (a branch per load would
-                    }                                     // make hipcc wait vmcnt(0) after each one)
-#pragma unroll
-                    for (int u = 0; u < SEL_U; ++u) {
-                        if (actm[u] == 0ull) continue;
-                        bool in = false;
-                        if ((actm[u] >> lane) & 1ull) {
-                            const f3 cm = {ca[u].x, ca[u].y, ca[u].z};
-                            const f3 dq = sub3(pm, cm);                   // query - point (pointindex.cpp:137)
-                            in = dot3(dq, dq) < pr.R2;
-                            if (in && (__float_as_uint(ca[u].w) & 2u)) {  // regular child: Mahalanobis pre-reject
-                                const f3 d = sub3(cm, pm);
-                                const float smd = dot3(d, mul6(pr.pinv, d));   // gaussian.hpp:82-85, as kld6 computes it
-                                in = !(smd > pr.smdMax);
-                            }
-                        }
-                        const unsigned long long m = __ballot(in);
-                        if (m == 0ull) continue;
-                        if (in) q[(qh + qn + __popcll(m & ((1ull << lane) - 1ull))) & (SEL_QCAP - 1)] = (unsigned)jj[u];
-                        qn += __popcll(m);
-                    }
-                    // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
-                    __builtin_amdgcn_wave_barrier();
-                    while (qn >= 64) {
-                        select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base);
-                        qh = (qh + 64) & (SEL_QCAP - 1);
-                        qn -= 64;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-        }
+        // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
+        // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
+        select_scan<MODE, false>(a, g, pr, ec, R, lane, part, nparts, q, qh, qn, count, scanned, base);
+        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, ec, R, lane, part, nparts, q, qh, qn, count, scanned, base);
         if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base);
     }
     if (lane == 0) {       // no global atomics here: one hot address serialises 10^6 waves (totals come from the scans)
@@ -909,84 +1026,87 @@ __global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, const int6
 //
 // libc rand() (what hem::rand() consumes, base.hpp:44-56) is the additive lagged-Fibonacci sequence
 //     y_n = y_{n-3} + y_{n-31}  (mod 2^32),   rand() number k = y_{310+k} >> 1,
-// seeded with 31 words by srand().  The recurrence is linear, so y_{m+k} = sum_j a_k[j] * y_{m+j} with
-// a_k = x^k mod (x^31 - x^28 - 1) over Z/2^32: every thread jumps to the start of its own chunk of the
-// stream by square-and-multiply on precomputed x^(2^b), then runs the recurrence sequentially for
-// its chunk.  Flag i = rand01() < 1/rho with rand01 = float(r)/float(0xffffffff), r = eight
-// successive rand()%16 nibbles, low nibble first (base.hpp:44-56, mixture.cpp:257-259,330).
-// LDS layout is [word][thread] so that the uniform loop indices are bank-conflict free.
+// seeded with 31 words by srand().  The recurrence is linear: with a_k = x^k mod (x^31 - x^28 - 1) over
+// Z/2^32 and Y the sequence continued from any 31-word state,  y_{k-31+m} = sum_j a_k[j] * Y[m+j].
+// Flag i = rand01() < 1/rho with rand01 = float(r)/float(0xffffffff), r = eight successive rand()%16
+// nibbles, low nibble first (base.hpp:44-56, mixture.cpp:257-259,330).
+//
+// Two kernels.  k_rng_block_state: one wavefront per block of RNG_THREADS*RNG_ELEMS flags jumps to the
+// block's position k_b by square-and-multiply on precomputed x^(2^b) (lane j holds coefficient j, a
+// polynomial product is 31 lane-broadcast multiply-adds) and writes the 61 sequence values around k_b.
+// k_flags_glibc: thread t needs the state 992 t draws further on, a_{992 t} is a per-context table, so its
+// 31-word state is a 31x31 correlation of that table row with the block's 61 values; it then runs the
+// recurrence for its 124 flags with the state ring in registers (the unrolled body covers 31 flags =
+// 248 draws = 8 full turns of the ring, so every ring index is a compile-time constant).
+// (First version: one thread jumped 48 bits by itself and kept the ring in LDS -- 0.33 ms per call at any
+// size, 8 calls per bench step.)
 // ------------------------------------------------------------------------------------------------
 #define RNG_THREADS 64
-#define RNG_CHUNK 512
-struct RngBase { unsigned y[31]; };   // y_{-31} .. y_{-1}
+#define RNG_ELEMS 124                          // flags per thread = 4 * 31
+#define RNG_BLOCK_ELEMS (RNG_THREADS * RNG_ELEMS)
+#define RNG_TAB_XPOW 0                         // [48][31]  x^(2^b)
+#define RNG_TAB_T (48 * 31)                    // [31][64]  coefficient j of x^(8 * RNG_ELEMS * t)
+#define RNG_TAB_YBASE (RNG_TAB_T + 31 * 64)    // [91]      the sequence continued from the seed state: y_{-31} .. y_{59}
+#define RNG_TAB_WORDS (RNG_TAB_YBASE + 96)
 
-__global__ __launch_bounds__(RNG_THREADS) void k_flags_glibc(int64_t n, unsigned long long first_draw, float prob, RngBase base,
-                                                             const unsigned* __restrict__ xpow /* [48][31] */,
-                                                             uint8_t* __restrict__ is_parent) {
-    __shared__ unsigned s_a[31][RNG_THREADS];      // polynomial a_k
-    __shared__ unsigned s_t[31][RNG_THREADS];      // scratch polynomial / later: the 31-word state ring
-    const int t = threadIdx.x;
-    const int64_t chunk = (int64_t)blockIdx.x * RNG_THREADS + t;
-    const int64_t i0 = chunk * RNG_CHUNK;
-    if (i0 >= n) return;
-    // index (in y) of the first rand() value of this chunk
-    unsigned long long k = 310ull + 8ull * (first_draw + (unsigned long long)i0);
-    // a = x^k mod P by square-and-multiply over the bits of k
-    for (int j = 0; j < 31; ++j) s_a[j][t] = j == 0 ? 1u : 0u;
+__global__ __launch_bounds__(64) void k_rng_block_state(unsigned long long first_draw, const unsigned* __restrict__ tab,
+                                                        unsigned* __restrict__ blockY /* [nblocks][64] */) {
+    const int lane = threadIdx.x;
+    const unsigned long long k = 310ull + 8ull * (first_draw + (unsigned long long)blockIdx.x * RNG_BLOCK_ELEMS);
+    unsigned a = lane == 0 ? 1u : 0u;                       // x^0
     for (int b = 0; b < 48; ++b) {
         if (!((k >> b) & 1ull)) continue;
-        const unsigned* xb = xpow + b * 31;
-        // product of degree <= 60, reduced on the fly: coefficient d of a*xb
-        unsigned hi[30];                              // degrees 31..60
-#pragma unroll
-        for (int d = 60; d >= 31; --d) {
-            unsigned acc = 0;
-            for (int i = d - 30; i <= 30; ++i) acc += s_a[i][t] * xb[d - i];
-            hi[d - 31] = acc;
+        unsigned v = lane < 31 ? tab[RNG_TAB_XPOW + b * 31 + lane] : 0u;   // v = x^i * xb mod P, i = 0
+        unsigned c = 0;
+        for (int i = 0; i < 31; ++i) {
+            c += (unsigned)__shfl((int)a, i) * v;
+            const unsigned top = (unsigned)__shfl((int)v, 30), up = (unsigned)__shfl_up((int)v, 1);
+            v = lane == 0 ? top : up;                       // x * v:  x^31 = x^28 + 1
+            if (lane == 28) v += top;
+            if (lane > 30) v = 0u;
         }
-        for (int d = 0; d <= 30; ++d) {
-            unsigned acc = 0;
-            for (int i = 0; i <= d; ++i) acc += s_a[i][t] * xb[d - i];
-            s_t[d][t] = acc;
-        }
-        // x^d = x^(d-3) + x^(d-31), from the top down
-#pragma unroll
-        for (int d = 60; d >= 31; --d) {
-            const unsigned c = hi[d - 31];
-            if (d - 3 >= 31) hi[d - 3 - 31] += c; else s_t[d - 3][t] += c;
-            s_t[d - 31][t] += c;
-        }
-        for (int j = 0; j < 31; ++j) s_a[j][t] = s_t[j][t];
+        a = c;
     }
-    // state ring: y_{k-31+i} = dot(a_{k+i}, base), a_{k+i+1} = x * a_{k+i} mod P
-    unsigned ring[31];
+    unsigned y = 0;                                         // lane m: y_{k-31+m} = sum_j a[j] * Ybase[m+j]
+    for (int j = 0; j < 31; ++j) {
+        const unsigned aj = (unsigned)__shfl((int)a, j);
+        if (lane < 61) y += aj * tab[RNG_TAB_YBASE + lane + j];
+    }
+    blockY[(size_t)blockIdx.x * 64 + lane] = y;
+}
+
+__global__ __launch_bounds__(RNG_THREADS) void k_flags_glibc(int64_t n, float prob, const unsigned* __restrict__ tab,
+                                                             const unsigned* __restrict__ blockY, uint8_t* __restrict__ is_parent) {
+    const int t = threadIdx.x;
+    const int64_t i0 = ((int64_t)blockIdx.x * RNG_THREADS + t) * RNG_ELEMS;
+    if (i0 >= n) return;
+    unsigned T[31];
+#pragma unroll
+    for (int j = 0; j < 31; ++j) T[j] = tab[RNG_TAB_T + j * 64 + t];
+    const unsigned* Yb = blockY + (size_t)blockIdx.x * 64;  // uniform: scalar loads
+    unsigned ring[31];                                      // slot i holds y_{k-31+i}; y_n lives in slot (n-k) mod 31
 #pragma unroll
     for (int i = 0; i < 31; ++i) {
         unsigned acc = 0;
-        for (int j = 0; j < 31; ++j) acc += s_a[j][t] * base.y[j];
+#pragma unroll
+        for (int j = 0; j < 31; ++j) acc += T[j] * Yb[i + j];
         ring[i] = acc;
-        const unsigned top = s_a[30][t];
-        for (int j = 30; j >= 1; --j) s_a[j][t] = s_a[j - 1][t];
-        s_a[0][t] = top;
-        s_a[28][t] += top;
     }
+    for (int it = 0; it < RNG_ELEMS / 31; ++it) {
 #pragma unroll
-    for (int i = 0; i < 31; ++i) s_t[i][t] = ring[i];      // slot i holds y_{k-31+i}; y_n lives in slot (n-k) mod 31
-    int f = 0;                                              // slot of y_{n-31} (overwritten by y_n)
-    int r = 28;                                             // slot of y_{n-3}
-    const int64_t iend = (i0 + RNG_CHUNK < n) ? i0 + RNG_CHUNK : n;
-    for (int64_t i = i0; i < iend; ++i) {
-        unsigned x = 0;
+        for (int e = 0; e < 31; ++e) {
+            unsigned x = 0;
 #pragma unroll
-        for (int q = 0; q < 8; ++q) {
-            const unsigned v = s_t[f][t] + s_t[r][t];
-            s_t[f][t] = v;
-            x |= ((v >> 1) & 15u) << (4 * q);
-            f = f == 30 ? 0 : f + 1;
-            r = r == 30 ? 0 : r + 1;
+            for (int q = 0; q < 8; ++q) {
+                const int f = (e * 8 + q) % 31, r = (e * 8 + q + 28) % 31;   // slots of y_{n-31} (overwritten by y_n) and y_{n-3}
+                const unsigned v = ring[f] + ring[r];
+                ring[f] = v;
+                x |= ((v >> 1) & 15u) << (4 * q);
+            }
+            const int64_t i = i0 + it * 31 + e;
+            const float r01 = (float)x / 4294967296.0f;
+            if (i < n) is_parent[i] = r01 < prob ? 1 : 0;
         }
-        const float r01 = (float)x / 4294967296.0f;
-        is_parent[i] = r01 < prob ? 1 : 0;
     }
 }
 __device__ __forceinline__ unsigned hash32(unsigned long long x) {      // splitmix64 finaliser
@@ -1084,12 +1204,12 @@ struct gsr_hem_ctx {
     Level cur, nxt, tmp;
     bool have_level = false;
     // workspace
-    DevBuf regular, hist;
-    DevBuf det, radius, bbox, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
+    DevBuf regular, hist, iflag, irank, ipos, rng_blocks;
+    DevBuf det, radius, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, morder, nparts, vstart, vparent, vpart, vcap, vcnt;
     int part_cap = 0;               // candidates per work item when a heavy parent is split; 0 = never (measured: 8192 cuts
                                     // the select kernel by 4% and costs as much in the extra SPANS pass and scans)
-    bool use_lpt = true, use_morton = true, use_xcd = true;
+    bool use_lpt = true, use_morton = true, use_xcd = true, use_ell = true;
     int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
     gsr_allreduce_dev_fn shard_allreduce = nullptr;
     void* shard_user = nullptr;
@@ -1153,15 +1273,32 @@ int32_t draw_flags(gsr_hem_ctx* c, Level& lv) {
             }
         }
         for (int j = 0; j < 31; ++j) c->rng_base[j] = st[(j + 3) % 31];        // y_{-31+j} = x_{(j+3) mod 31}
-        GSR_TRY(c->draws.reserve(48 * 31 * 4));
-        GSR_HIP(hipMemcpyAsync(c->draws.p, rng_xpow_table(), 48 * 31 * 4, hipMemcpyHostToDevice, c->stream));
+        // device tables: x^(2^b), the per-thread jumps x^(8 * RNG_ELEMS * t), and the sequence continued from the seed state
+        std::vector<unsigned> tab(RNG_TAB_WORDS, 0u);
+        memcpy(tab.data() + RNG_TAB_XPOW, rng_xpow_table(), 48 * 31 * 4);
+        {
+            unsigned step[31], cur[31], nxt[31];
+            for (int j = 0; j < 31; ++j) { step[j] = j == 0 ? 1u : 0u; cur[j] = step[j]; }
+            for (int b = 0; b < 48; ++b)
+                if (((unsigned long long)(8 * RNG_ELEMS) >> b) & 1ull) { rng_polymul(step, rng_xpow_table() + b * 31, nxt); memcpy(step, nxt, sizeof(step)); }
+            for (int t = 0; t < RNG_THREADS; ++t) {
+                for (int j = 0; j < 31; ++j) tab[RNG_TAB_T + j * 64 + t] = cur[j];
+                rng_polymul(cur, step, nxt);
+                memcpy(cur, nxt, sizeof(cur));
+            }
+        }
+        for (int m = 0; m < 91; ++m)
+            tab[RNG_TAB_YBASE + m] = m < 31 ? c->rng_base[m] : tab[RNG_TAB_YBASE + m - 3] + tab[RNG_TAB_YBASE + m - 31];
+        GSR_TRY(c->draws.reserve(RNG_TAB_WORDS * 4));
+        GSR_HIP(hipMemcpy(c->draws.p, tab.data(), RNG_TAB_WORDS * 4, hipMemcpyHostToDevice));
         c->rng_ready = true;
     }
-    RngBase base;
-    for (int j = 0; j < 31; ++j) base.y[j] = c->rng_base[j];
-    const int64_t chunks = (n + RNG_CHUNK - 1) / RNG_CHUNK;
-    hipLaunchKernelGGL(k_flags_glibc, dim3((unsigned)((chunks + RNG_THREADS - 1) / RNG_THREADS)), dim3(RNG_THREADS), 0, c->stream, n,
-                       (unsigned long long)c->rng_pos, prob, base, c->draws.as<unsigned>(), lv.is_parent.as<uint8_t>());
+    const int64_t nblocks = (n + RNG_BLOCK_ELEMS - 1) / RNG_BLOCK_ELEMS;
+    GSR_TRY(c->rng_blocks.reserve((size_t)nblocks * 64 * 4));
+    hipLaunchKernelGGL(k_rng_block_state, dim3((unsigned)nblocks), dim3(64), 0, c->stream, (unsigned long long)c->rng_pos,
+                       c->draws.as<unsigned>(), c->rng_blocks.as<unsigned>());
+    hipLaunchKernelGGL(k_flags_glibc, dim3((unsigned)nblocks), dim3(RNG_THREADS), 0, c->stream, n, prob, c->draws.as<unsigned>(),
+                       c->rng_blocks.as<unsigned>(), lv.is_parent.as<uint8_t>());
     c->rng_pos += (uint64_t)n;
     return GSR_OK;
 }
@@ -1226,6 +1363,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_LPT")) c->use_lpt = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MORTON")) c->use_morton = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_XCD")) c->use_xcd = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb = v; }
     if (const char* s = getenv("GSR_HEM_WPB_M")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb_m = v; }
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
@@ -1237,10 +1375,10 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
     c->cur.release(); c->nxt.release(); c->tmp.release();
-    DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
+    DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->regular, &c->hist, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->regular, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
@@ -1371,19 +1509,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
     GSR_TRY(c->det.reserve(n * 4)); GSR_TRY(c->radius.reserve(n * 4)); GSR_TRY(c->bbox.reserve(64)); GSR_TRY(c->regular.reserve(n));
     GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(64));
-    {
-        unsigned init[6];
-        float big = FLT_MAX, sml = -FLT_MAX;
-        unsigned ub, us;
-        memcpy(&ub, &big, 4); memcpy(&us, &sml, 4);
-        // encoded +FLT_MAX for the mins, encoded -FLT_MAX for the maxes
-        unsigned eb = ub | 0x80000000u, es = ~us;
-        init[0] = init[1] = init[2] = eb; init[3] = init[4] = init[5] = es;
-        GSR_HIP(hipMemcpyAsync(c->bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
-        GSR_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
-    }
+    GSR_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
+    GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 6 * 4));
     hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.cov6.as<float>(), L.is_parent.as<uint8_t>(), c->delta,
-                       c->det.as<float>(), c->radius.as<float>(), c->regular.as<uint8_t>(), c->bbox.as<unsigned>());
+                       c->det.as<float>(), c->radius.as<float>(), c->regular.as<uint8_t>(), c->bbox_part.as<unsigned>());
+    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>());
     GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
     GSR_HIP(hipMemsetAsync(c->hist.p, 0, 3 * HIST_BINS * 4, st));
     hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>());
@@ -1402,16 +1532,21 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     hipLaunchKernelGGL(k_run_starts<int>, grd, blk, 0, st, n, c->skeys.as<unsigned>(), (int64_t)gp.ncells, c->cellStart.as<int>());
 
     GSR_TRY(c->A.reserve(n * 16)); GSR_TRY(c->B.reserve(n * 16)); GSR_TRY(c->C.reserve(n * 16)); GSR_TRY(c->D.reserve(n * 16));
-    GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
+    GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4));
+    GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
     GSR_TRY(c->shs.reserve((size_t)n * (F > 0 ? F : 1) * 4));
     hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(),
                        L.opacity.as<float>(), L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->det.as<float>(), c->radius.as<float>(),
-                       c->regular.as<uint8_t>(), c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>());
+                       c->regular.as<uint8_t>(), c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
     if (F > 0)
         hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
-    int last_pos = 0, last_flag = 0;
+    // the irregular components (never pre-rejected): their sorted positions, and their rank at every position
+    GSR_TRY(exclusive_scan<int>(c, c->iflag.as<int>(), c->irank.as<int>(), n + 1));
+    hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->iflag.as<int>(), c->irank.as<int>(), c->ipos.as<unsigned>());
+    int last_pos = 0, last_flag = 0, n_irr = 0;
+    GSR_HIP(hipMemcpyAsync(&n_irr, c->irank.as<int>() + n, 4, hipMemcpyDeviceToHost, st));
     GSR_HIP(hipMemcpyAsync(&last_pos, c->ppos.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
     GSR_HIP(hipMemcpyAsync(&last_flag, c->pflag.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
     GSR_HIP(hipStreamSynchronize(st));
@@ -1434,6 +1569,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.A = c->A.as<float4>(); sa.B = c->B.as<float4>(); sa.C = c->C.as<float4>(); sa.D = c->D.as<float4>();
     sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
     sa.gp = c->gparams.as<GridParams>(); sa.P = P; sa.NI = P;
+    sa.irank = c->irank.as<int>(); sa.ipos = c->ipos.as<unsigned>(); sa.n_irr = n_irr; sa.ell = c->use_ell ? 1 : 0;
     // work sharding: rank r of W evaluates the contiguous run [P r / W, P (r+1) / W) of the cell-sorted parents
     const bool sharded = c->shard_world > 1 && c->shard_allreduce != nullptr;
     const int own_lo = sharded ? (int)((int64_t)P * c->shard_rank / c->shard_world) : 0;

@@ -44,7 +44,7 @@ __device__ __forceinline__ int icp_cell(double v, double o, double inv_c, int g)
     return (int)t;
 }
 
-__global__ __launch_bounds__(256) void k_icp_bbox(int64_t n, const float* __restrict__ xyz, unsigned* __restrict__ bbox) {
+__global__ __launch_bounds__(256) void k_icp_bbox(int64_t n, const float* __restrict__ xyz, float* __restrict__ bbox_part) {
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -54,16 +54,38 @@ __global__ __launch_bounds__(256) void k_icp_bbox(int64_t n, const float* __rest
             mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
         }
     }
+    // per-block partial box, no atomics (10^4 same-address atomics cost ~0.5 ms: they serialise across the XCDs)
+    __shared__ float s_mn[4][3], s_mx[4][3];
     for (int k = 0; k < 3; ++k)
         for (int o = 32; o > 0; o >>= 1) { mn[k] = fminf(mn[k], __shfl_xor(mn[k], o)); mx[k] = fmaxf(mx[k], __shfl_xor(mx[k], o)); }
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 3; ++k) {
-            unsigned a = __float_as_uint(mn[k]), b = __float_as_uint(mx[k]);
-            a = (a & 0x80000000u) ? ~a : (a | 0x80000000u);
-            b = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
-            atomicMin(&bbox[k], a);
-            atomicMax(&bbox[3 + k], b);
-        }
+        for (int k = 0; k < 3; ++k) { s_mn[threadIdx.x >> 6][k] = mn[k]; s_mx[threadIdx.x >> 6][k] = mx[k]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        float a = s_mn[0][k], b = s_mx[0][k];
+        for (int w = 1; w < 4; ++w) { a = fminf(a, s_mn[w][k]); b = fmaxf(b, s_mx[w][k]); }
+        bbox_part[6 * blockIdx.x + k] = a;
+        bbox_part[6 * blockIdx.x + 3 + k] = b;
+    }
+}
+// bbox[0..2] = min, bbox[3..5] = max over the per-block partial boxes
+__global__ __launch_bounds__(256) void k_icp_bbox_reduce(int nblocks, const float* __restrict__ part, float* __restrict__ bbox) {
+    __shared__ float s_v[4][6];
+    float v[6] = {FLT_MAX, FLT_MAX, FLT_MAX, -FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+        for (int k = 0; k < 3; ++k) { v[k] = fminf(v[k], part[6 * b + k]); v[3 + k] = fmaxf(v[3 + k], part[6 * b + 3 + k]); }
+    for (int k = 0; k < 3; ++k)
+        for (int o = 32; o > 0; o >>= 1) { v[k] = fminf(v[k], __shfl_xor(v[k], o)); v[3 + k] = fmaxf(v[3 + k], __shfl_xor(v[3 + k], o)); }
+    if ((threadIdx.x & 63) == 0)
+        for (int k = 0; k < 6; ++k) s_v[threadIdx.x >> 6][k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        const int k = threadIdx.x;
+        float r = s_v[0][k];
+        for (int w = 1; w < 4; ++w) r = k < 3 ? fminf(r, s_v[w][k]) : fmaxf(r, s_v[w][k]);
+        bbox[k] = r;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_icp_keys(int64_t n, const float* __restrict__ xyz, IcpGrid g,
@@ -834,27 +856,15 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
         }
     }
     // bounding box of the finite points
-    GSR_TRY(c->bbox.reserve(64));
-    {
-        float big = FLT_MAX, sml = -FLT_MAX;
-        unsigned ub, us;
-        memcpy(&ub, &big, 4); memcpy(&us, &sml, 4);
-        unsigned init[6] = {ub | 0x80000000u, ub | 0x80000000u, ub | 0x80000000u, ~us, ~us, ~us};
-        GSR_HIP(hipMemcpyAsync(c->bbox.p, init, sizeof(init), hipMemcpyHostToDevice, st));
-    }
-    hipLaunchKernelGGL(k_icp_bbox, dim3(stride_grid(n)), dim3(256), 0, st, n, dxyz, c->bbox.as<unsigned>());
-    unsigned hb[6];
+    const int nbb = stride_grid(n);
+    GSR_TRY(c->bbox.reserve(64 + (size_t)nbb * 24));
+    hipLaunchKernelGGL(k_icp_bbox, dim3(nbb), dim3(256), 0, st, n, dxyz, c->bbox.as<float>() + 16);
+    hipLaunchKernelGGL(k_icp_bbox_reduce, dim3(1), dim3(256), 0, st, nbb, c->bbox.as<float>() + 16, c->bbox.as<float>());
+    float hb[6];
     GSR_HIP(hipMemcpyAsync(hb, c->bbox.p, sizeof(hb), hipMemcpyDeviceToHost, st));
     GSR_HIP(hipStreamSynchronize(st));
     double mn[3], mx[3];
-    for (int k = 0; k < 3; ++k) {
-        unsigned a = hb[k], b = hb[3 + k];
-        a = (a & 0x80000000u) ? (a & 0x7fffffffu) : ~a;
-        b = (b & 0x80000000u) ? (b & 0x7fffffffu) : ~b;
-        float fa, fb;
-        memcpy(&fa, &a, 4); memcpy(&fb, &b, 4);
-        mn[k] = fa; mx[k] = fb;
-    }
+    for (int k = 0; k < 3; ++k) { mn[k] = hb[k]; mx[k] = hb[3 + k]; }
     IcpGrid g;
     if (!(mx[0] >= mn[0])) { mn[0] = mn[1] = mn[2] = 0; mx[0] = mx[1] = mx[2] = 0; }
     // cell: about two target points per cell, but no finer than max_corr/8 (bounds the ring count)

@@ -315,3 +315,62 @@ def test_work_sharded_level_equals_single_gpu():
                 assert _rel(levels[k][f], want[k][f]) < 1e-5, (r, k, f)
                 assert np.array_equal(levels[k][f], out[0][0][k][f])
     assert sum(out[r][1][0]["pairs"] for r in range(W)) == wst[0]["pairs"]
+
+
+def _needle_cloud(n, seed, frac=0.35, sh_degree=1):
+    """A cloud where `frac` of the splats are irregular for the pre-reject (condition number >> 80: needles and
+    discs, the shape real 3DGS splats often have), some with enormous anisotropy."""
+    from gaussiansplattingregistration_amd import synth
+    rng = np.random.default_rng(seed)
+    c = synth.make_cloud(n, seed=seed, h=1.0, sh_degree=sh_degree)
+    k = int(n * frac)
+    idx = rng.choice(n, k, replace=False)
+    s = np.exp(rng.normal(-2.5, 0.5, (k, 3)))
+    s[:, 0] *= rng.choice([1e-2, 3e-2, 1e-3], k)              # squash one axis: kappa = 1e3 .. 1e6
+    s[: k // 2, 1] *= 0.05                                      # half of them needles (two thin axes)
+    q = rng.normal(size=(k, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    R = synth._quat_to_rot(q)
+    L = R * s[:, None, :]
+    C = (L @ L.transpose(0, 2, 1)).astype(np.float32)
+    c["cov6"][idx] = C[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
+    return c
+
+
+@pytest.mark.gpu
+def test_many_irregular_components(oracle):
+    """35 % of the components bypass the Mahalanobis pre-reject (second pass of k_select over the irregular list);
+    regular parents clip their rows to the ellipsoid.  Discrete results equal the oracle's."""
+    from gaussiansplattingregistration_amd import hem
+    c = _needle_cloud(40000, seed=31)
+    want, wst = oracle.hem(c, 2)
+    with hem.HemMixture() as m:
+        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+        for k in range(2):
+            m.run_level()
+            st = m.stats()
+            got = m.get_level()
+            if k == 0:
+                assert (st["parents"], st["pairs"], st["orphans"], st["dropped"]) == (wst[0]["parents"], wst[0]["pairs"], wst[0]["orphans"], wst[0]["dropped"])
+                _check_level(got, want[k], ("needles", k))
+            else:
+                _check_level_mostly(got, want[k], ("needles", k))
+
+
+@pytest.mark.gpu
+def test_ellipsoid_row_clipping_changes_nothing(monkeypatch):
+    """Clipping a regular parent's grid rows to its pre-reject ellipsoid only skips candidates the pre-reject
+    would discard: the pair count of a level is identical with the clipping switched off (GSR_HEM_ELL=0)."""
+    from gaussiansplattingregistration_amd import hem, synth
+    res = {}
+    for ell in ("1", "0"):
+        monkeypatch.setenv("GSR_HEM_ELL", ell)
+        out = []
+        for c in (synth.make_cloud(300000, seed=8), _needle_cloud(100000, seed=9, frac=0.2)):
+            with hem.HemMixture() as m:
+                m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+                m.run_level()      # one level: later levels inherit summation-order noise (the pair order differs)
+                st = m.stats()
+                out.append((st["parents"], st["pairs"], st["orphans"], st["dropped"], m.get_level()["xyz"].shape[0]))
+        res[ell] = out
+    assert res["1"] == res["0"], (res["1"], res["0"])
