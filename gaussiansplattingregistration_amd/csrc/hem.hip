@@ -165,21 +165,23 @@ __device__ __forceinline__ bool is_regular(const s6& c, float det, float x, floa
     return lmin > 0.0125f * lmax && lmax > 0.0f;
 }
 
-__global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict__ xyz,
-                                              const float* __restrict__ cov6,
-                                              const uint8_t* __restrict__ is_parent, float delta,
-                                              float* __restrict__ det, float* __restrict__ radius,
-                                              uint8_t* __restrict__ regular, unsigned* __restrict__ bbox_part) {
+__global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict__ xyz, const float* __restrict__ color,
+                                              const float* __restrict__ cov6, const float* __restrict__ opacity,
+                                              const float* __restrict__ weight, const uint8_t* __restrict__ is_parent,
+                                              float4* __restrict__ rec /* [n][4], input order */, unsigned* __restrict__ bbox_part) {
+    // The four float4 of a component (the A/B/C/D layout of the working set) are packed here, in INPUT order and
+    // with coalesced reads, so that the gather into cell order fetches one 64-byte record per component instead
+    // of touching nine arrays at a random index (9 x 128-byte lines -> 0.9 ms at 5 M; one line -> 0.3 ms).
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         s6 c = {cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5]};
         const float dt = det6(c);
-        det[i] = dt;
-        float R = 0.0f;
-        if (is_parent[i]) R = delta * sqrtf(eig_max6(c));
-        radius[i] = R;
         float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        regular[i] = is_regular(c, dt, x, y, z) ? 1 : 0;
+        const unsigned fl = (is_parent[i] ? 1u : 0u) | (is_regular(c, dt, x, y, z) ? 2u : 0u);   // bit 0 parent, bit 1 regular
+        rec[4 * i] = make_float4(x, y, z, __uint_as_float(fl));
+        rec[4 * i + 1] = make_float4(c.e00, c.e01, c.e02, c.e11);
+        rec[4 * i + 2] = make_float4(c.e12, c.e22, color[3 * i], color[3 * i + 1]);
+        rec[4 * i + 3] = make_float4(color[3 * i + 2], opacity[i], weight[i], dt);
         if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX) {   // finite only
             mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
             mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
@@ -266,12 +268,13 @@ __global__ __launch_bounds__(256) void k_hist(int64_t n, const float* __restrict
 // Grid geometry: about `target` components per cell over the robust box, at most `max_cells` cells.
 __global__ void k_grid_params(const unsigned* __restrict__ bbox, const unsigned* __restrict__ hist, int64_t n, float target,
                               int max_cells, GridParams* __restrict__ gp) {
+    const int lane = threadIdx.x;                    // launched with ONE wavefront
     float mn[3], mx[3];
     for (int k = 0; k < 3; ++k) { mn[k] = dec_f(bbox[k]); mx[k] = dec_f(bbox[3 + k]); }
     GridParams g;
     if (!(mx[0] >= mn[0]) || !(mx[1] >= mn[1]) || !(mx[2] >= mn[2])) {   // no finite point at all
         g.ox = g.oy = g.oz = 0.0f; g.c = 1.0f; g.inv_c = 1.0f; g.slack = 0.0f; g.gx = g.gy = g.gz = 1; g.ncells = 1;
-        *gp = g;
+        if (lane == 0) *gp = g;
         return;
     }
     // robust box: drop the outermost 0.1 % per side (whole bins), then one bin of margin
@@ -279,14 +282,29 @@ __global__ void k_grid_params(const unsigned* __restrict__ bbox, const unsigned*
     for (int k = 0; k < 3; ++k) {
         const float ext = mx[k] - mn[k];
         if (!(ext > 0.0f)) continue;
-        unsigned long long tot = 0;
-        for (int b = 0; b < HIST_BINS; ++b) tot += hist[k * HIST_BINS + b];
+        // one wavefront: lane l owns bins [16 l, 16 l + 16); the cumulative counts are monotone, so the number of
+        // bins whose running total stays <= cut IS the index the sequential scan would stop at
+        unsigned hv[HIST_BINS / 64];
+        unsigned long long mine = 0;
+        for (int b = 0; b < HIST_BINS / 64; ++b) { hv[b] = hist[k * HIST_BINS + lane * (HIST_BINS / 64) + b]; mine += hv[b]; }
+        unsigned long long incl = mine;                                   // inclusive scan over the lanes
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long t = __shfl_up(incl, o);
+            if (lane >= o) incl += t;
+        }
+        const unsigned long long tot = __shfl(incl, 63);
         const unsigned long long cut = tot / 1000ull;
-        int lo = 0, hi = HIST_BINS - 1;
-        unsigned long long acc = 0;
-        while (lo < HIST_BINS - 1 && acc + hist[k * HIST_BINS + lo] <= cut) { acc += hist[k * HIST_BINS + lo]; ++lo; }
-        acc = 0;
-        while (hi > lo && acc + hist[k * HIST_BINS + hi] <= cut) { acc += hist[k * HIST_BINS + hi]; --hi; }
+        int cl = 0, ch = 0;
+        {
+            unsigned long long run = incl - mine;                         // total of the lanes below
+            for (int b = 0; b < HIST_BINS / 64; ++b) { run += hv[b]; cl += run <= cut ? 1 : 0; }
+            run = tot - incl;                                             // total of the lanes above
+            for (int b = HIST_BINS / 64 - 1; b >= 0; --b) { run += hv[b]; ch += run <= cut ? 1 : 0; }
+        }
+        for (int o = 32; o > 0; o >>= 1) { cl += __shfl_xor(cl, o); ch += __shfl_xor(ch, o); }
+        int lo = cl < HIST_BINS - 1 ? cl : HIST_BINS - 1;
+        int hi = HIST_BINS - 1 - ch;
+        hi = hi > lo ? hi : lo;
         lo = lo > 0 ? lo - 1 : 0;
         hi = hi < HIST_BINS - 1 ? hi + 1 : HIST_BINS - 1;
         const float w = ext / (float)HIST_BINS;
@@ -310,7 +328,7 @@ __global__ void k_grid_params(const unsigned* __restrict__ bbox, const unsigned*
     g.c = (float)c; g.inv_c = 1.0f / g.c;
     g.slack = 1e-5f * (emax + g.c);
     g.gx = gx; g.gy = gy; g.gz = gz; g.ncells = gx * gy * gz;
-    *gp = g;
+    if (lane == 0) *gp = g;
 }
 
 __global__ __launch_bounds__(256) void k_keys(int64_t n, const float* __restrict__ xyz,
@@ -346,25 +364,24 @@ __global__ void k_fill_const(int64_t n, OffT* p, OffT v) {
 }
 
 // Sorted working set.
-__global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __restrict__ order,
-                                                const float* __restrict__ xyz, const float* __restrict__ color,
-                                                const float* __restrict__ cov6, const float* __restrict__ opacity,
-                                                const float* __restrict__ weight, const uint8_t* __restrict__ is_parent,
-                                                const float* __restrict__ det, const float* __restrict__ radius,
-                                                const uint8_t* __restrict__ regular, float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
+//   radius = delta * sqrtf(lambda_max) for the parents                       (mixture.cpp:88)
+__global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __restrict__ order, const float4* __restrict__ rec, float delta,
+                                                float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
                                                 float4* __restrict__ D, float* __restrict__ Rs, int* __restrict__ pflag, int* __restrict__ iflag) {
     if (blockIdx.x == 0 && threadIdx.x == 0) iflag[n] = 0;       // the scan runs over n + 1 entries: irank[n] = total
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = order[j];
-        const unsigned par = is_parent[i] ? 1u : 0u;
-        const unsigned fl = par | (regular[i] ? 2u : 0u);           // bit 0 parent, bit 1 regular
-        A[j] = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], __uint_as_float(fl));
-        B[j] = make_float4(cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3]);
-        C[j] = make_float4(cov6[6 * i + 4], cov6[6 * i + 5], color[3 * i], color[3 * i + 1]);
-        D[j] = make_float4(color[3 * i + 2], opacity[i], weight[i], det[i]);
-        Rs[j] = radius[i];
-        pflag[j] = (int)par;
-        iflag[j] = regular[i] ? 0 : 1;
+        const float4 a = rec[4 * i], b = rec[4 * i + 1], cc = rec[4 * i + 2], d = rec[4 * i + 3];
+        const unsigned fl = __float_as_uint(a.w);
+        A[j] = a; B[j] = b; C[j] = cc; D[j] = d;
+        float R = 0.0f;
+        if (fl & 1u) {
+            const s6 cov = {b.x, b.y, b.z, b.w, cc.x, cc.y};
+            R = delta * sqrtf(eig_max6(cov));
+        }
+        Rs[j] = R;
+        pflag[j] = (int)(fl & 1u);
+        iflag[j] = (fl & 2u) ? 0 : 1;
     }
 }
 __global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, const unsigned* __restrict__ order,
@@ -1204,8 +1221,9 @@ struct gsr_hem_ctx {
     Level cur, nxt, tmp;
     bool have_level = false;
     // workspace
-    DevBuf regular, hist, iflag, irank, ipos, rng_blocks;
-    DevBuf det, radius, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
+    DevBuf hist, iflag, irank, ipos, rng_blocks;
+    unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
+    DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, morder, nparts, vstart, vparent, vpart, vcap, vcnt;
     int part_cap = 0;               // candidates per work item when a heavy parent is split; 0 = never (measured: 8192 cuts
                                     // the select kernel by 4% and costs as much in the extra SPANS pass and scans)
@@ -1303,6 +1321,25 @@ int32_t draw_flags(gsr_hem_ctx* c, Level& lv) {
     return GSR_OK;
 }
 
+// Small device values the host needs (counts, totals, the grid geometry) are written by one tiny kernel straight
+// into pinned, device-visible host memory: one launch + one stream synchronisation per round trip.  (Separate
+// hipMemcpyAsync calls into pageable memory cost ~20 us each on top of the synchronisation.)
+struct Collect {
+    const void* src[8];
+    int bytes[8];          // 4 or 8
+    int n;
+};
+__global__ void k_collect(Collect q, unsigned long long* __restrict__ dst) {
+    const int t = threadIdx.x;
+    if (t < q.n) dst[t] = q.bytes[t] == 8 ? *(const unsigned long long*)q.src[t] : (unsigned long long)*(const unsigned*)q.src[t];
+}
+int32_t read_back(gsr_hem_ctx* c, const Collect& q, unsigned long long* out) {
+    hipLaunchKernelGGL(k_collect, dim3(1), dim3(8), 0, c->stream, q, c->host_rb);
+    GSR_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < q.n; ++i) out[i] = c->host_rb[i];
+    return GSR_OK;
+}
+
 template <typename T>
 int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n) {
     size_t bytes = 0;
@@ -1358,6 +1395,10 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         hipError_t e = hipEventCreate(&c->evk[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
+    {
+        hipError_t e = hipHostMalloc((void**)&c->host_rb, 64, hipHostMallocDefault);
+        if (e != hipSuccess) { c->host_rb = nullptr; delete c; return fail(GSR_E_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
+    }
     if (const char* s = getenv("GSR_HEM_MSTEP_LDS")) c->mstep_lds = atoi(s);
     if (const char* s = getenv("GSR_HEM_PART_CAP")) c->part_cap = atoi(s);
     if (const char* s = getenv("GSR_HEM_LPT")) c->use_lpt = atoi(s) != 0;
@@ -1375,11 +1416,12 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
     c->cur.release(); c->nxt.release(); c->tmp.release();
-    DevBuf* all[] = {&c->det, &c->radius, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
+    DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->regular, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
+    if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
     delete c;
@@ -1507,21 +1549,28 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_HIP(hipEventRecord(c->ev[0], st));
 
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
-    GSR_TRY(c->det.reserve(n * 4)); GSR_TRY(c->radius.reserve(n * 4)); GSR_TRY(c->bbox.reserve(64)); GSR_TRY(c->regular.reserve(n));
+    GSR_TRY(c->rec.reserve(n * 64)); GSR_TRY(c->bbox.reserve(64));
     GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(64));
     GSR_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
     GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 6 * 4));
-    hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.cov6.as<float>(), L.is_parent.as<uint8_t>(), c->delta,
-                       c->det.as<float>(), c->radius.as<float>(), c->regular.as<uint8_t>(), c->bbox_part.as<unsigned>());
+    hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
+                       L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>());
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>());
     GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
     GSR_HIP(hipMemsetAsync(c->hist.p, 0, 3 * HIST_BINS * 4, st));
     hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>());
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(1), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), n, c->cell_target, c->max_cells,
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), n, c->cell_target, c->max_cells,
                        c->gparams.as<GridParams>());
     GridParams gp;
-    GSR_HIP(hipMemcpyAsync(&gp, c->gparams.p, sizeof(gp), hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipStreamSynchronize(st));
+    {
+        static_assert(sizeof(GridParams) == 40, "GridParams is read back as five 8-byte words");
+        Collect q;
+        q.n = 5;
+        for (int i = 0; i < 5; ++i) { q.src[i] = (const char*)c->gparams.p + 8 * i; q.bytes[i] = 8; }
+        unsigned long long w[8];
+        GSR_TRY(read_back(c, q, w));
+        memcpy(&gp, w, sizeof(gp));
+    }
     c->stats[5] = gp.ncells;
 
     GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->order.reserve(n * 4));
@@ -1535,9 +1584,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4));
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
     GSR_TRY(c->shs.reserve((size_t)n * (F > 0 ? F : 1) * 4));
-    hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(),
-                       L.opacity.as<float>(), L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->det.as<float>(), c->radius.as<float>(),
-                       c->regular.as<uint8_t>(), c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
+    hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), c->rec.as<float4>(), c->delta, c->A.as<float4>(), c->B.as<float4>(),
+                       c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
     if (F > 0)
         hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
@@ -1546,10 +1594,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(exclusive_scan<int>(c, c->iflag.as<int>(), c->irank.as<int>(), n + 1));
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->iflag.as<int>(), c->irank.as<int>(), c->ipos.as<unsigned>());
     int last_pos = 0, last_flag = 0, n_irr = 0;
-    GSR_HIP(hipMemcpyAsync(&n_irr, c->irank.as<int>() + n, 4, hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipMemcpyAsync(&last_pos, c->ppos.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipMemcpyAsync(&last_flag, c->pflag.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipStreamSynchronize(st));
+    {
+        Collect q;
+        q.n = 3;
+        q.src[0] = c->irank.as<int>() + n; q.src[1] = c->ppos.as<int>() + (n - 1); q.src[2] = c->pflag.as<int>() + (n - 1);
+        q.bytes[0] = q.bytes[1] = q.bytes[2] = 4;
+        unsigned long long w[8];
+        GSR_TRY(read_back(c, q, w));
+        n_irr = (int)w[0]; last_pos = (int)w[1]; last_flag = (int)w[2];
+    }
     const int P = last_pos + last_flag;
     c->stats[0] = P;
     GSR_HIP(hipEventRecord(c->ev[1], st));
@@ -1597,12 +1650,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         return exclusive_scan<int64_t>(c, cnt64, off, count);
     };
     auto total_of = [&](const int64_t* off, const unsigned* cnt, int64_t count, int64_t* out) -> int32_t {
-        int64_t last_off = 0;
-        unsigned last = 0;
-        GSR_HIP(hipMemcpyAsync(&last_off, off + (count - 1), 8, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipMemcpyAsync(&last, cnt + (count - 1), 4, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipStreamSynchronize(st));
-        *out = last_off + (int64_t)last;
+        Collect q;
+        q.n = 2;
+        q.src[0] = off + (count - 1); q.bytes[0] = 8;
+        q.src[1] = cnt + (count - 1); q.bytes[1] = 4;
+        unsigned long long w[8];
+        GSR_TRY(read_back(c, q, w));
+        *out = (int64_t)w[0] + (int64_t)(unsigned)w[1];
         return GSR_OK;
     };
     c->sparse_path = false;
@@ -1615,11 +1669,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         if (c->part_cap > 0) {
             hipLaunchKernelGGL(k_nparts, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), (unsigned)c->part_cap, c->nparts.as<int>());
             GSR_TRY(exclusive_scan<int>(c, c->nparts.as<int>(), c->vstart.as<int>(), P));
-            int lo = 0, ln = 0;
-            GSR_HIP(hipMemcpyAsync(&lo, c->vstart.as<int>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
-            GSR_HIP(hipMemcpyAsync(&ln, c->nparts.as<int>() + (P - 1), 4, hipMemcpyDeviceToHost, st));
-            GSR_HIP(hipStreamSynchronize(st));
-            V = lo + ln;
+            Collect q;
+            q.n = 2;
+            q.src[0] = c->vstart.as<int>() + (P - 1); q.src[1] = c->nparts.as<int>() + (P - 1);
+            q.bytes[0] = q.bytes[1] = 4;
+            unsigned long long w[8];
+            GSR_TRY(read_back(c, q, w));
+            V = (int)w[0] + (int)w[1];
             split = V > P;
         }
         const size_t Vm = (size_t)V;
@@ -1738,9 +1794,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
     GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
     int o_last = 0, o_flag = 0;
-    GSR_HIP(hipMemcpyAsync(&o_last, c->orank_in.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipMemcpyAsync(&o_flag, c->oflag_in.as<int>() + (n - 1), 4, hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipStreamSynchronize(st));
+    {
+        Collect q;
+        q.n = 2;
+        q.src[0] = c->orank_in.as<int>() + (n - 1); q.src[1] = c->oflag_in.as<int>() + (n - 1);
+        q.bytes[0] = q.bytes[1] = 4;
+        unsigned long long w[8];
+        GSR_TRY(read_back(c, q, w));
+        o_last = (int)w[0]; o_flag = (int)w[1];
+    }
     const int64_t n_orph = (int64_t)o_last + o_flag;
     c->stats[2] = n_orph;
     const int64_t n_pre = (int64_t)P + n_orph;
@@ -1804,9 +1866,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL(k_valid, g2, blk, 0, st, n_pre, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>());
         GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
         int k_last = 0, k_flag = 0;
-        GSR_HIP(hipMemcpyAsync(&k_last, c->kpos.as<int>() + (n_pre - 1), 4, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipMemcpyAsync(&k_flag, c->keep.as<int>() + (n_pre - 1), 4, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipStreamSynchronize(st));
+        {
+            Collect q;
+            q.n = 2;
+            q.src[0] = c->kpos.as<int>() + (n_pre - 1); q.src[1] = c->keep.as<int>() + (n_pre - 1);
+            q.bytes[0] = q.bytes[1] = 4;
+            unsigned long long w[8];
+            GSR_TRY(read_back(c, q, w));
+            k_last = (int)w[0]; k_flag = (int)w[1];
+        }
         const int64_t n_keep = (int64_t)k_last + k_flag;
         dropped = n_pre - n_keep;
         if (dropped > 0) {
