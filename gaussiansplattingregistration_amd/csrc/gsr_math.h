@@ -65,7 +65,9 @@ __device__ __constant__ static const double k_logf_tab[32] = {
     0x1.b2036576afce6p-1, 0x1.526e57720db08p-3,  0x1.9c2d163a1aa2dp-1, 0x1.bc2860d224770p-3,
     0x1.886e6037841edp-1, 0x1.1058bc8a07ee1p-2,  0x1.767dcf5534862p-1, 0x1.4043057b6ee09p-2};
 
-__device__ __forceinline__ float glibc_logf(float x) {
+// `tab` = the 32 doubles of k_logf_tab (k_select keeps a copy in LDS: a per-lane lookup in __constant__ memory is a
+// vector-memory gather with its full round-trip latency in the middle of the KL gate)
+__device__ __forceinline__ float glibc_logf_tab(float x, const double* tab) {
     uint32_t ix = __float_as_uint(x);
     if (ix == 0x3f800000u) return 0.0f;
     if (ix - 0x00800000u >= 0x7f800000u - 0x00800000u) {
@@ -79,7 +81,7 @@ __device__ __forceinline__ float glibc_logf(float x) {
     int i = (tmp >> 19) & 15;
     int k = (int32_t)tmp >> 23;
     uint32_t iz = ix - (tmp & 0xff800000u);
-    double invc = k_logf_tab[2 * i], logc = k_logf_tab[2 * i + 1];
+    double invc = tab[2 * i], logc = tab[2 * i + 1];
     double z = (double)__uint_as_float(iz);
     double r = z * invc - 1.0;
     double y0 = logc + (double)k * 0x1.62e42fefa39efp-1;
@@ -89,6 +91,7 @@ __device__ __forceinline__ float glibc_logf(float x) {
     y = y * r2 + (y0 + r);
     return (float)y;
 }
+__device__ __forceinline__ float glibc_logf(float x) { return glibc_logf_tab(x, k_logf_tab); }
 
 // Kullback-Leibler gate value, include/gaussian.hpp:106-109 (child c against parent p).
 //   d = mu_c - mu_p;  pinv = inverse(cov_p)

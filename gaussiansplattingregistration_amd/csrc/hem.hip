@@ -384,13 +384,14 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
         iflag[j] = (fl & 2u) ? 0 : 1;
     }
 }
-__global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, const unsigned* __restrict__ order,
+// shs rows have a stride of Fp >= F floats (pad = zeros; Fp == F today, see gsr_hem_run_level).
+__global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, int Fp, const unsigned* __restrict__ order,
                                                    const float* __restrict__ sh, float* __restrict__ shs) {
-    const int64_t total = n * F;
+    const int64_t total = n * Fp;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t j = t / F;
-        int f = (int)(t - j * F);
-        shs[t] = sh[(int64_t)order[j] * F + f];
+        int64_t j = t / Fp;
+        int f = (int)(t - j * Fp);
+        shs[t] = f < F ? sh[(int64_t)order[j] * F + f] : 0.0f;
     }
 }
 __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __restrict__ flag, const int* __restrict__ pos,
@@ -432,6 +433,13 @@ struct SelectArgs {
     const unsigned* vparent;        // item -> parent index (into plist)
     const unsigned* vpart;          // item -> part | (nparts << 16)
     const int* cellStart;
+    // Row cache: the first SPANS launch (rows_write = 1) stores the non-empty grid rows (start, length) of every
+    // parent's regular pass; every later launch of the level reads them back instead of recomputing the clipping.
+    const double* logtab;           // glibc logf table (LDS copy)
+    int2* rows;                     // NULL = no cache (rows are recomputed by every launch)
+    const int64_t* rowoff;          // parent -> first slot in rows
+    unsigned* rown;                 // parent -> number of cached rows
+    int rows_write;
     const int* irank;               // irank[j] = number of irregular components among sorted positions [0, j)   (n + 1 entries)
     const unsigned* ipos;           // sorted positions of the irregular components, ascending
     int n_irr;
@@ -458,43 +466,57 @@ struct ParentRec {
     int js;
 };
 
-// wL_si = w_s * clamp(hemLikelihoodOpacity, FLT_MIN, 1e8)   (mixture.cpp:54-64,155-158)
-__device__ __forceinline__ float wl_of(const SelectArgs& a, const ParentRec& pr, int j) {
-    const float4 ca = a.A[j], cc = a.C[j], cd = a.D[j];
-    const f3 cm = {ca.x, ca.y, ca.z};
-    const f3 ccol = {cc.z, cc.w, cd.x};
-    const f3 dc = sub3(ccol, pr.pcol);
-    const float cdiff = sqrtf(dot3(dc, dc));                      // = dist(parent.color, child.color)
-    const f3 dq = sub3(pr.pm, cm);
-    const float distanceDiff = sqrtf(dot3(dq, dq));
-    const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
-    const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
-    const float L = distWeight * cd.y * colorInfluence * sqrtf(cd.w);
-    return pr.pweight * ref_clamp(L, FLT_MIN, 1e8f);
+// Third-stage queue (per wave, in LDS): the accepted pairs wait here until 64 of them fill a wavefront, so that
+// the likelihood (two expf, two sqrtf, two IEEE divisions) runs on full waves instead of the ~26 % of the lanes
+// that pass the KL gate.  (The kernel is VALU bound: 94 % VALUBusy in the PMC pass of round r01b.)
+#define SEL_Q3CAP 128
+struct Q3 {
+    unsigned* j;
+    float *d2, *cd, *op, *det;
+    int h, n;                      // head, fill (wave-uniform)
+};
+
+// wL_si = w_s * clamp(hemLikelihoodOpacity, FLT_MIN, 1e8)   (mixture.cpp:54-64,155-158) for `cnt` queued pairs
+__device__ __forceinline__ void select_stage3(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, Q3& q3, int64_t& base) {
+    if (lane < cnt) {
+        const int k = (q3.h + lane) & (SEL_Q3CAP - 1);
+        const float distanceDiff = sqrtf(q3.d2[k]);
+        const float cdiff = q3.cd[k];
+        const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
+        const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
+        const float L = distWeight * q3.op[k] * colorInfluence * sqrtf(q3.det[k]);
+        a.pair_child[base + lane] = q3.j[k];
+        a.pair_wl[base + lane] = pr.pweight * ref_clamp(L, FLT_MIN, 1e8f);
+    }
+    base += cnt;
+    q3.h = (q3.h + cnt) & (SEL_Q3CAP - 1);
+    q3.n -= cnt;
 }
 
-// stage 2 on up to 64 queued survivors (lane < cnt holds one): colour gate, KL gate, parent rule, likelihood.
-// (A fast-log pre-decision of the KL gate and a separate third stage for the likelihood were built and
-// measured on MI355X: both cut VALU instructions and neither cut time -- the kernel is latency bound.)
+// stage 2 on up to 64 queued survivors (lane < cnt holds one): colour gate, KL gate, parent rule; accepted pairs
+// go to the third-stage queue.
 template <int MODE>
 __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, const unsigned* q, int qh,
-                                              unsigned& count, int64_t& base) {
+                                              unsigned& count, int64_t& base, Q3& q3) {
     bool acc = false;
     int j = 0;
+    float d2 = 0.0f, cdiff = 0.0f, op = 0.0f, det_c = 0.0f;
     if (lane < cnt) {
         j = (int)q[(qh + lane) & (SEL_QCAP - 1)];
         const float4 ca = a.A[j], cb = a.B[j], cc = a.C[j], cd = a.D[j];   // all four up front: one round trip
         const f3 cm = {ca.x, ca.y, ca.z};
         const f3 ccol = {cc.z, cc.w, cd.x};
         const f3 dc = sub3(ccol, pr.pcol);                    // ColorDelta(child, parent), gaussian.hpp:111-114
-        const float cdiff = sqrtf(dot3(dc, dc));
+        cdiff = sqrtf(dot3(dc, dc));
         if (!(cdiff > a.colorThr)) {                          // mixture.cpp:122-124
             const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
-            const float det_c = cd.w;
+            det_c = cd.w;
+            op = cd.y;
             const f3 d = sub3(cm, pr.pm);
+            d2 = dot3(d, d);                                  // == dot(pm - cm, pm - cm) bit for bit
             const float smd = dot3(d, mul6(pr.pinv, d));      // gaussian.hpp:82-85
             const float tr = trace_prod6(pr.pinv, ccov);
-            const float k = 0.5f * (smd + tr - 3.0f - glibc_logf(det_c / pr.det_p));   // gaussian.hpp:106-109
+            const float k = 0.5f * (smd + tr - 3.0f - glibc_logf_tab(det_c / pr.det_p, a.logtab));   // gaussian.hpp:106-109
             const bool pass = !(k > a.kldThr);                // mixture.cpp:126-129 (NaN passes)
             if (pass) {
                 const bool child_is_parent = (__float_as_uint(ca.w) & 1u) != 0u;
@@ -506,12 +528,14 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     const int na = __popcll(m);
     count += (unsigned)na;
     if (MODE == SEL_COUNT || na == 0) return;
-    if (acc) {                                                // likelihood + pair record (mixture.cpp:54-64,155-158)
-        const int64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
-        a.pair_child[pos] = (unsigned)j;
-        a.pair_wl[pos] = wl_of(a, pr, j);
+    if (acc) {
+        const int k = (q3.h + q3.n + __popcll(m & ((1ull << lane) - 1ull))) & (SEL_Q3CAP - 1);
+        q3.j[k] = (unsigned)j; q3.d2[k] = d2; q3.cd[k] = cdiff; q3.op[k] = op; q3.det[k] = det_c;
     }
-    base += na;
+    q3.n += na;
+    __builtin_amdgcn_wave_barrier();
+    if (q3.n >= 64) select_stage3(a, pr, lane, 64, q3, base);
+    __builtin_amdgcn_wave_barrier();
 }
 
 // Row clipping by the parent's pre-reject ellipsoid E = { x : (x-mu)^T P^-1 (x-mu) <= T }.  A regular child outside E
@@ -529,24 +553,34 @@ struct EllClip {
 // One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
 // REGULAR ones (stage 1: radius test + Mahalanobis pre-reject); IRR = true scans the list of irregular components
 // (ipos, addressed through irank at the cell boundaries) with the radius test only.  Survivors go to the LDS ring.
-template <int MODE, bool IRR>
+template <int MODE, bool IRR, bool CACHED>
 __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const EllClip& ec, float R,
-                                            int lane, int part, int nparts, unsigned* q, int& qh, int& qn, unsigned& count,
-                                            unsigned long long& scanned, int64_t& base) {
+                                            int lane, int p, int part, int nparts, unsigned* q, int& qh, int& qn, unsigned& count,
+                                            unsigned long long& scanned, int64_t& base, Q3& q3) {
     const f3 pm = pr.pm;
+    const bool writing = !IRR && !CACHED && MODE == SEL_SPANS && a.rows != nullptr && a.rows_write != 0;
+    constexpr bool cached = !IRR && CACHED;           // compile-time: the cached kernels carry no clipping code
+    int64_t rbase = 0;                                          // wave-uniform: keep it in SGPRs
+    if (!IRR && (CACHED || writing)) {
+        const int64_t v = a.rowoff[p];
+        rbase = ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+    }
+    int written = 0;
     const float Ra = fabsf(R) * 1.00001f + g.slack;             // conservative search extent
     const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
     const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
     const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-    const int nrows = ny * nz;
+    const int nrows = __builtin_amdgcn_readfirstlane(cached ? (int)a.rown[p] : ny * nz);
     const float Ra2 = Ra * Ra;
     const bool clip = !IRR && ec.on != 0.0f;
     for (int rb = 0; rb < nrows; rb += 64) {
         if (nparts > 1 && ((rb >> 6) % nparts) != part) continue;      // this batch of rows belongs to another item
         const int r = rb + lane;
         int s = 0, len = 0;
-        if (r < nrows) {
+        if (cached) {
+            if (r < nrows) { const int2 v = a.rows[rbase + r]; s = v.x; len = v.y; }
+        } else if (r < nrows) {
             const int ry = y0 + r % ny, rz = z0 + r / ny;
             // distance from the parent to the row's y/z slab (widened by the rounding slack)
             // (the first / last row of the grid also holds every centre clamped in from outside: half-infinite)
@@ -592,11 +626,15 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
         const unsigned long long nz_m = __ballot(len > 0);
         const int nrb = __popcll(nz_m);
         if (nrb == 0) continue;
-        {
+        if (!cached) {
             const unsigned long long lt = (1ull << lane) - 1ull;
             const int dst = len > 0 ? __popcll(nz_m & lt) : nrb + __popcll(~nz_m & lt);
             s = __builtin_amdgcn_ds_permute(dst << 2, s);
             len = __builtin_amdgcn_ds_permute(dst << 2, len);
+        }
+        if (writing) {
+            if (lane < nrb) a.rows[rbase + written + lane] = make_int2(s, len);
+            written += nrb;
         }
         int total = len;                                   // candidates of this batch of rows
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
@@ -652,7 +690,7 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
                 // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
                 __builtin_amdgcn_wave_barrier();
                 while (qn >= 64) {
-                    select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base);
+                    select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base, q3);
                     qh = (qh + 64) & (SEL_QCAP - 1);
                     qn -= 64;
                 }
@@ -660,13 +698,41 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
             }
         }
     }
+    if (writing && lane == 0) a.rown[p] = (unsigned)written;
+}
+
+// Upper bound of the grid rows a parent's search touches (the bounding square of its sphere): sizes the row cache.
+__device__ __forceinline__ int parent_row_bound(const GridParams& g, const f3& pm, float R) {
+    const bool pm_finite = fabsf(pm.x) <= FLT_MAX && fabsf(pm.y) <= FLT_MAX && fabsf(pm.z) <= FLT_MAX;
+    if (!(R * R > 0.0f) || !pm_finite) return 0;
+    const float Ra = fabsf(R) * 1.00001f + g.slack;
+    const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
+    const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
+    return (y1 - y0 + 1) * (z1 - z0 + 1);
+}
+__global__ __launch_bounds__(256) void k_rowcap(int P, const unsigned* __restrict__ plist, const float4* __restrict__ A,
+                                                const float* __restrict__ Rs, const GridParams* __restrict__ gpp, unsigned* __restrict__ rowcap) {
+    const GridParams g = *gpp;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const int js = (int)plist[p];
+        const float4 a = A[js];
+        const f3 pm = {a.x, a.y, a.z};
+        rowcap[p] = (unsigned)parent_row_bound(g, pm, Rs[js]);
+    }
 }
 
 // WPB = wavefronts (= parents) per workgroup (runtime choice, GSR_HEM_WPB).
-template <int MODE, int WPB>
+template <int MODE, int WPB, bool CACHED>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     __shared__ unsigned s_q[WPB][SEL_QCAP];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    __shared__ double s_logtab[32];
+    __shared__ unsigned s_q3j[WPB][SEL_Q3CAP];
+    __shared__ float s_q3f[WPB][4][SEL_Q3CAP];
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    if (MODE != SEL_SPANS) {                       // every wave writes the same 32 values: no barrier needed
+        if (lane < 32) s_logtab[lane] = k_logf_tab[lane];
+        a.logtab = s_logtab;
+    }
     const int nblk = (a.NI + WPB - 1) / WPB;
     const int hb = a.nheavy ? (((*a.nheavy + WPB - 1) / WPB + 7) & ~7) : 0;
     const int bid = block_slot((int)blockIdx.x, nblk, hb < nblk ? hb : nblk, a.xcd);
@@ -674,12 +740,12 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     const int slot = bid * WPB + wv;
     if (slot >= a.NI) return;
     const int item = a.porder ? (int)a.porder[slot] : slot;
-    const int p = a.vparent ? (int)a.vparent[item] : item;
+    const int p = __builtin_amdgcn_readfirstlane(a.vparent ? (int)a.vparent[item] : item);
     const unsigned vpi = a.vpart ? a.vpart[item] : (1u << 16);
     const int part = (int)(vpi & 0xffffu), nparts = (int)(vpi >> 16);
     if (p < a.own_lo || p >= a.own_hi) {          // another rank's parent: no work, no pairs
         if (lane == 0) {
-            if (MODE == SEL_SPANS) a.pcap[item] = 0u;
+            if (MODE == SEL_SPANS) { a.pcap[item] = 0u; if (a.rows && a.rows_write) a.rown[p] = 0u; }
             else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[item] = 0u;
         }
         return;
@@ -732,15 +798,19 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[item] : 0;
     int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
     unsigned* q = s_q[wv];
+    Q3 q3 = {s_q3j[wv], s_q3f[wv][0], s_q3f[wv][1], s_q3f[wv][2], s_q3f[wv][3], 0, 0};
 
     // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
     const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
     if (pr.R2 > 0.0f && pm_finite) {
         // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
         // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
-        select_scan<MODE, false>(a, g, pr, ec, R, lane, part, nparts, q, qh, qn, count, scanned, base);
-        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, ec, R, lane, part, nparts, q, qh, qn, count, scanned, base);
-        if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base);
+        select_scan<MODE, false, CACHED>(a, g, pr, ec, R, lane, p, part, nparts, q, qh, qn, count, scanned, base, q3);
+        if (a.n_irr > 0) select_scan<MODE, true, CACHED>(a, g, pr, ec, R, lane, p, part, nparts, q, qh, qn, count, scanned, base, q3);
+        if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base, q3);
+        if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, pr, lane, q3.n, q3, base);
+    } else if (MODE == SEL_SPANS && a.rows && a.rows_write && lane == 0) {
+        a.rown[p] = 0u;
     }
     if (lane == 0) {       // no global atomics here: one hot address serialises 10^6 waves (totals come from the scans)
         if (MODE == SEL_SPANS) a.pcap[item] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
@@ -873,6 +943,7 @@ __global__ __launch_bounds__(256) void k_flags_to_input_order(int64_t n, const u
 struct MstepArgs {
     const float4 *A, *B, *C, *D;
     const float* shs;
+    int Fp;                         // row stride of shs (F rounded up to 16)
     const float* sumLw;
     const unsigned* plist;
     const unsigned* porder;    // processing order (heavy parents first) or NULL
@@ -891,6 +962,9 @@ struct MstepArgs {
 
 #define MSTEP_CHUNK 256
 #define MSTEP_U 8             // SH rows whose loads are in flight together
+#define MSTEP_U4 4            // F <= 64: load instructions in flight, each fetching the rows of four children
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };      // 4-byte aligned float4 (SH rows are 4 F bytes apart)
+
 // NQ = SH coefficients per lane (1 when F <= 64 -- the usual case, SH degree <= 3 has F = 45 -- else 4)
 template <int WPB, int NQ>
 __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
@@ -914,9 +988,17 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
     float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
     // SH accumulators: lane f owns coefficients f, f+64, ... (F <= 256 supported per pass)
-    float shacc[NQ];
+    // NQ == 0 (F <= 64): 16 lanes x float4 cover one SH row, so ONE load instruction fetches the rows of FOUR
+    // children (lane group g = lane / 16 <-> child k0 + 4 u + g); the four group sums are folded at the end.
+    // The per-child bookkeeping (LDS reads, address arithmetic) was the cost of this part: the kernel is VALU bound.
+    constexpr int NQA = NQ > 0 ? NQ : 1;
+    float shacc[NQA];
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) shacc[q] = 0.0f;
+    for (int q = 0; q < NQA; ++q) shacc[q] = 0.0f;
+    float4 acc4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const int gl = lane & 15, g4 = lane >> 4;
+    const int nl = (a.F + 3) >> 2;                              // lanes of a group that hold coefficients
+    const int glc = gl < nl ? gl : 0;                           // idle lanes re-read the first float4 (discarded)
 
     for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
         const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
@@ -948,9 +1030,32 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         __builtin_amdgcn_wave_barrier();
         // part 2: lane <-> SH coefficient; children in pair order, MSTEP_U rows in flight at a time.
         // Skipped children load the parent's own row (a valid address) and are masked out of the sum.
-        if (a.F > 0) {
+        if (NQ == 0) {
+            if (a.F > 0) {
+                for (unsigned k0 = 0; k0 < cn; k0 += 4 * MSTEP_U4) {
+                    f4u rowv[MSTEP_U4];
+                    float wv_[MSTEP_U4];
+#pragma unroll
+                    for (int u = 0; u < MSTEP_U4; ++u) {
+                        const unsigned k = k0 + 4 * u + g4;
+                        const unsigned kc = k < cn ? k : cn - 1;   // unconditional LDS reads (a branch per read serialises them)
+                        const unsigned j = s_j[wv][kc];
+                        const float wk = s_w[wv][kc];
+                        const bool ok = k < cn && j != 0xffffffffu;
+                        wv_[u] = ok ? wk : 0.0f;
+                        rowv[u] = *(const f4u*)(a.shs + (int64_t)(ok ? j : (unsigned)js) * a.Fp + 4 * glc);
+                        if (!ok) rowv[u] = f4u{0.0f, 0.0f, 0.0f, 0.0f};
+                    }
+#pragma unroll
+                    for (int u = 0; u < MSTEP_U4; ++u) {
+                        acc4.x += rowv[u].x * wv_[u]; acc4.y += rowv[u].y * wv_[u];
+                        acc4.z += rowv[u].z * wv_[u]; acc4.w += rowv[u].w * wv_[u];
+                    }
+                }
+            }
+        } else if (a.F > 0) {
             for (unsigned k0 = 0; k0 < cn; k0 += MSTEP_U) {
-                float rowv[MSTEP_U][NQ];
+                float rowv[MSTEP_U][NQA];
                 float wv_[MSTEP_U];
                 bool ok[MSTEP_U];
 #pragma unroll
@@ -959,9 +1064,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                     const unsigned j = k < cn ? s_j[wv][k] : 0xffffffffu;
                     ok[u] = j != 0xffffffffu;
                     wv_[u] = k < cn ? s_w[wv][k] : 0.0f;
-                    const float* row = a.shs + (int64_t)(ok[u] ? j : (unsigned)js) * a.F;
+                    const float* row = a.shs + (int64_t)(ok[u] ? j : (unsigned)js) * a.Fp;
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q) {
+                    for (int q = 0; q < NQA; ++q) {
                         const int f = lane + 64 * q;
                         rowv[u][q] = f < a.F ? row[f] : 0.0f;
                     }
@@ -969,7 +1074,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
 #pragma unroll
                 for (int u = 0; u < MSTEP_U; ++u) {
 #pragma unroll
-                    for (int q = 0; q < NQ; ++q)
+                    for (int q = 0; q < NQA; ++q)
                         if (ok[u]) shacc[q] += rowv[u][q] * wv_[u];
                 }
             }
@@ -999,10 +1104,24 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         a.o_opacity[slot] = inv_w * so;
         a.o_weight[slot] = w_s;
     }
+    if (NQ == 0) {
+        float v[4] = {acc4.x, acc4.y, acc4.z, acc4.w};
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-        const int f = lane + 64 * q;
-        if (f < a.F) a.o_sh[slot * a.F + f] = shacc[q] * inv_w;
+        for (int c = 0; c < 4; ++c) {
+            v[c] += __shfl_xor(v[c], 16);
+            v[c] += __shfl_xor(v[c], 32);
+        }
+        if (g4 == 0 && gl < nl) {
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+                if (4 * gl + c < a.F) a.o_sh[slot * a.F + 4 * gl + c] = v[c] * inv_w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NQA; ++q) {
+            const int f = lane + 64 * q;
+            if (f < a.F) a.o_sh[slot * a.F + f] = shacc[q] * inv_w;
+        }
     }
 }
 
@@ -1028,13 +1147,13 @@ __global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigne
         oslot_sorted[j] = slot;
     }
 }
-__global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, const int64_t* __restrict__ oslot_sorted,
+__global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int Fp, const int64_t* __restrict__ oslot_sorted,
                                                     const float* __restrict__ shs, float* __restrict__ o_sh) {
     const int64_t total = n * F;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t j = t / F;
         const int64_t slot = oslot_sorted[j];
-        if (slot >= 0) o_sh[slot * F + (t - j * F)] = shs[t];
+        if (slot >= 0) o_sh[slot * F + (t - j * F)] = shs[j * Fp + (t - j * F)];
     }
 }
 
@@ -1221,13 +1340,13 @@ struct gsr_hem_ctx {
     Level cur, nxt, tmp;
     bool have_level = false;
     // workspace
-    DevBuf hist, iflag, irank, ipos, rng_blocks;
+    DevBuf hist, iflag, irank, ipos, rng_blocks, rowcap, rowoff, rown, rows;
     unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, morder, nparts, vstart, vparent, vpart, vcap, vcnt;
     int part_cap = 0;               // candidates per work item when a heavy parent is split; 0 = never (measured: 8192 cuts
                                     // the select kernel by 4% and costs as much in the extra SPANS pass and scans)
-    bool use_lpt = true, use_morton = true, use_xcd = true, use_ell = true;
+    bool use_lpt = true, use_morton = true, use_xcd = true, use_ell = true, use_rowcache = false;   // row cache: measured neutral on MI355X (kernel -1.5 %, phase +1 %)
     int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
     gsr_allreduce_dev_fn shard_allreduce = nullptr;
     void* shard_user = nullptr;
@@ -1405,7 +1524,8 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_MORTON")) c->use_morton = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_XCD")) c->use_xcd = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
-    if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb = v; }
+    if (const char* s = getenv("GSR_HEM_ROWCACHE")) c->use_rowcache = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->wpb = v; }
     if (const char* s = getenv("GSR_HEM_WPB_M")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb_m = v; }
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     *out = c;
@@ -1419,7 +1539,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->rowcap, &c->rowoff, &c->rown, &c->rows, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1583,11 +1703,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->A.reserve(n * 16)); GSR_TRY(c->B.reserve(n * 16)); GSR_TRY(c->C.reserve(n * 16)); GSR_TRY(c->D.reserve(n * 16));
     GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4));
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
-    GSR_TRY(c->shs.reserve((size_t)n * (F > 0 ? F : 1) * 4));
+    // row stride of the sorted SH rows.  Padding rows to 64 bytes (Fp = 48 for F = 45) was measured: k_mstep -1.5 %,
+    // k_gather_sh +50 % -> not worth it; rows stay packed and k_mstep reads them as 4-byte aligned float4.
+    const int Fp = F;
+    GSR_TRY(c->shs.reserve((size_t)n * (Fp > 0 ? Fp : 1) * 4 + 16));      // +16: the float4 reads of k_mstep may run past the last row
     hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), c->rec.as<float4>(), c->delta, c->A.as<float4>(), c->B.as<float4>(),
                        c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
     if (F > 0)
-        hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
+        hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * Fp)), blk, 0, st, n, F, Fp, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
     // the irregular components (never pre-rejected): their sorted positions, and their rank at every position
@@ -1635,14 +1758,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.pcap = c->pcap.as<unsigned>();
     int64_t M = 0;
     const int wpb = c->wpb;
-#define GSR_LAUNCH_SELECT(MODE, NITEMS)                                                                                              \
+#define GSR_LAUNCH_SELECT_C(MODE, NITEMS, CACHED)                                                                                    \
     switch (wpb) {                                                                                                                   \
-        case 1: hipLaunchKernelGGL((k_select<MODE, 1>), dim3(8 * ceil_div((NITEMS), 8)), dim3(64), 0, st, sa); break;                 \
-        case 2: hipLaunchKernelGGL((k_select<MODE, 2>), dim3(8 * ceil_div(ceil_div((NITEMS), 2), 8)), dim3(128), 0, st, sa); break;   \
-        case 4: hipLaunchKernelGGL((k_select<MODE, 4>), dim3(8 * ceil_div(ceil_div((NITEMS), 4), 8)), dim3(256), 0, st, sa); break;   \
-        case 8: hipLaunchKernelGGL((k_select<MODE, 8>), dim3(8 * ceil_div(ceil_div((NITEMS), 8), 8)), dim3(512), 0, st, sa); break;   \
-        default: hipLaunchKernelGGL((k_select<MODE, 16>), dim3(8 * ceil_div(ceil_div((NITEMS), 16), 8)), dim3(1024), 0, st, sa); break; \
+        case 1: hipLaunchKernelGGL((k_select<MODE, 1, CACHED>), dim3(8 * ceil_div((NITEMS), 8)), dim3(64), 0, st, sa); break;         \
+        case 2: hipLaunchKernelGGL((k_select<MODE, 2, CACHED>), dim3(8 * ceil_div(ceil_div((NITEMS), 2), 8)), dim3(128), 0, st, sa); break; \
+        default: hipLaunchKernelGGL((k_select<MODE, 4, CACHED>), dim3(8 * ceil_div(ceil_div((NITEMS), 4), 8)), dim3(256), 0, st, sa); break; \
     }
+    // the first SPANS launch of a level fills the row cache; every later launch reads it (kernels without clipping code)
+#define GSR_LAUNCH_SELECT(MODE, NITEMS)                                                                                              \
+    if (sa.rows != nullptr && !sa.rows_write) { GSR_LAUNCH_SELECT_C(MODE, NITEMS, true) } else { GSR_LAUNCH_SELECT_C(MODE, NITEMS, false) }
     auto widen_scan = [&](const unsigned* cnt, int64_t* off, int64_t count) -> int32_t {      // off = exclusive scan of cnt (int64)
         GSR_TRY(c->scratch.reserve(((size_t)count + 128) * 8));
         int64_t* cnt64 = c->scratch.as<int64_t>();
@@ -1661,7 +1785,24 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     };
     c->sparse_path = false;
     if (P > 0) {
+        // row cache (8 bytes per grid row of every parent's bounding square), when it fits the budget
+        if (c->use_rowcache) {
+            GSR_TRY(c->rowcap.reserve(Pm * 4)); GSR_TRY(c->rowoff.reserve((Pm + 1) * 8)); GSR_TRY(c->rown.reserve(Pm * 4));
+            hipLaunchKernelGGL(k_rowcap, dim3(stride_grid(P)), blk, 0, st, P, c->plist.as<unsigned>(), c->A.as<float4>(), c->Rs.as<float>(),
+                               c->gparams.as<GridParams>(), c->rowcap.as<unsigned>());
+            GSR_TRY(widen_scan(c->rowcap.as<unsigned>(), c->rowoff.as<int64_t>(), P));
+            int64_t nrows_total = 0;
+            GSR_TRY(total_of(c->rowoff.as<int64_t>(), c->rowcap.as<unsigned>(), P, &nrows_total));
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            if ((size_t)nrows_total * 8 <= (free_b + c->rows.cap) / 8) {
+                GSR_TRY(c->rows.reserve((size_t)(nrows_total > 0 ? nrows_total : 1) * 8));
+                sa.rows = c->rows.as<int2>(); sa.rowoff = c->rowoff.as<int64_t>(); sa.rown = c->rown.as<unsigned>();
+            }
+        }
+        sa.rows_write = 1;
         GSR_LAUNCH_SELECT(SEL_SPANS, P);                                  // candidates scanned per parent
+        sa.rows_write = 0;
         // work items: split the heavy parents
         int V = P;
         bool split = false;
@@ -1765,6 +1906,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(c->pair_child.reserve(4)); GSR_TRY(c->pair_wl.reserve(4)); GSR_TRY(c->spair_child.reserve(4)); GSR_TRY(c->spair_wl.reserve(4));
     }
 #undef GSR_LAUNCH_SELECT
+#undef GSR_LAUNCH_SELECT_C
     c->stats[1] = M;
     GSR_HIP(hipEventRecord(c->ev[2], st));
 
@@ -1820,7 +1962,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         MstepArgs ma;
         memset(&ma, 0, sizeof(ma));
         ma.A = c->A.as<float4>(); ma.B = c->B.as<float4>(); ma.C = c->C.as<float4>(); ma.D = c->D.as<float4>();
-        ma.shs = c->shs.as<float>(); ma.sumLw = c->sumLw.as<float>(); ma.plist = c->plist.as<unsigned>(); ma.order = c->order.as<unsigned>();
+        ma.shs = c->shs.as<float>(); ma.Fp = Fp; ma.sumLw = c->sumLw.as<float>(); ma.plist = c->plist.as<unsigned>(); ma.order = c->order.as<unsigned>();
         ma.prank_in = c->prank_in.as<int>(); ma.poff = c->poff.as<int64_t>(); ma.pcnt = c->pcnt.as<unsigned>();
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
@@ -1831,18 +1973,18 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
         switch (c->wpb_m) {
-            case 1: if (F <= 64) hipLaunchKernelGGL((k_mstep<1, 1>), dim3(8 * ceil_div(P, 8)), dim3(64), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<1, 4>), dim3(8 * ceil_div(P, 8)), dim3(64), c->mstep_lds, st, ma); break;
-            case 2: if (F <= 64) hipLaunchKernelGGL((k_mstep<2, 1>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<2, 4>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), c->mstep_lds, st, ma); break;
-            case 4: if (F <= 64) hipLaunchKernelGGL((k_mstep<4, 1>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<4, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), c->mstep_lds, st, ma); break;
-            case 8: if (F <= 64) hipLaunchKernelGGL((k_mstep<8, 1>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<8, 4>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), c->mstep_lds, st, ma); break;
-            default: if (F <= 64) hipLaunchKernelGGL((k_mstep<16, 1>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<16, 4>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), c->mstep_lds, st, ma); break;
+            case 1: if (F <= 64) hipLaunchKernelGGL((k_mstep<1, 0>), dim3(8 * ceil_div(P, 8)), dim3(64), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<1, 4>), dim3(8 * ceil_div(P, 8)), dim3(64), c->mstep_lds, st, ma); break;
+            case 2: if (F <= 64) hipLaunchKernelGGL((k_mstep<2, 0>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<2, 4>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), c->mstep_lds, st, ma); break;
+            case 4: if (F <= 64) hipLaunchKernelGGL((k_mstep<4, 0>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<4, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), c->mstep_lds, st, ma); break;
+            case 8: if (F <= 64) hipLaunchKernelGGL((k_mstep<8, 0>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<8, 4>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), c->mstep_lds, st, ma); break;
+            default: if (F <= 64) hipLaunchKernelGGL((k_mstep<16, 0>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<16, 4>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), c->mstep_lds, st, ma); break;
         }
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
                        O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>());
     if (F > 0 && n_orph > 0)
-        hipLaunchKernelGGL(k_orphans_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
+        hipLaunchKernelGGL(k_orphans_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, Fp, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
     if (sharded && P > 0) {
         // exchange 2: the P merged components (every row written by exactly one rank, zero elsewhere, so the
         // sum is exact); the orphan rows behind them are computed identically on every rank
