@@ -151,6 +151,14 @@ __device__ __forceinline__ void icp_scan_span(const int* __restrict__ cellStart,
     }
 }
 
+// Distance from coordinate v to the slab of cell k along one axis (0 inside), shrunk by a relative 1e-9 so that the
+// float64 rounding of the cell classification can never make a bound too large.
+__device__ __forceinline__ double icp_slab_dist(double v, double o, double c, int k, double eps) {
+    const double lo = o + (double)k * c, hi = o + (double)(k + 1) * c;
+    const double d = (v < lo ? lo - v : (v > hi ? v - hi : 0.0)) * 0.999999999 - eps;
+    return d > 0.0 ? d : 0.0;
+}
+
 __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restrict__ cellStart,
                                            const float4* __restrict__ Tq, double px, double py, double pz, double& best_d2) {
     int best = -1;
@@ -158,26 +166,53 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
     double bd = 1.0 / 0.0;
     if (!(px == px) || !(py == py) || !(pz == pz)) { best_d2 = bd; return -1; }
     const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
+    // absolute slack of every geometric bound: ~500 ulp of the largest coordinate involved
+    const double eps = 1e-13 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.ox) + fabs(g.oy) + fabs(g.oz) + g.c * (double)(g.gx + g.gy + g.gz));
     for (int r = 0; r <= g.rings; ++r) {
         for (int dz = -r; dz <= r; ++dz) {
             const int z = cz + dz;
             if (z < 0 || z >= g.gz) continue;
             const int adz = dz < 0 ? -dz : dz;
+            const double dzb = icp_slab_dist(pz, g.oz, g.c, z, eps);
             for (int dy = -r; dy <= r; ++dy) {
                 const int y = cy + dy;
                 if (y < 0 || y >= g.gy) continue;
                 const int ady = dy < 0 ? -dy : dy;
+                // prune by the best so far: every point of this row is at least (dyb, dzb) away in y / z, and a cell
+                // at x-distance dxb adds that.  STRICT comparisons: a candidate at exactly the best distance can still
+                // win the tie on its index, so only cells that are strictly farther are skipped.
+                const double dyb = icp_slab_dist(py, g.oy, g.c, y, eps);
+                const double rem = bd - dyb * dyb - dzb * dzb;
+                if (rem < 0.0) continue;
+                int xlo = 0, xhi = g.gx - 1;
+                if (rem < 1e300) {                                // a finite best: clip the x span to |dx| <= sqrt(rem)
+                    const double hx = (double)(sqrtf((float)rem) * 1.0001f) + eps + 1e-30;
+                    xlo = icp_cell(px - hx, g.ox, g.inv_c, g.gx);
+                    xhi = icp_cell(px + hx, g.ox, g.inv_c, g.gx);
+                }
                 const int rowbase = (z * g.gy + y) * g.gx;
                 if (adz == r || ady == r) {                       // a face row of the ring: the whole x span
-                    const int xa = cx - r > 0 ? cx - r : 0, xb = cx + r < g.gx - 1 ? cx + r : g.gx - 1;
-                    icp_scan_span(cellStart, Tq, rowbase + xa, rowbase + xb, px, py, pz, bd, best, best_i);
+                    int xa = cx - r > 0 ? cx - r : 0, xb = cx + r < g.gx - 1 ? cx + r : g.gx - 1;
+                    xa = xa > xlo ? xa : xlo;
+                    xb = xb < xhi ? xb : xhi;
+                    if (xa <= xb) icp_scan_span(cellStart, Tq, rowbase + xa, rowbase + xb, px, py, pz, bd, best, best_i);
                 } else {                                          // interior row: only the two end cells
-                    if (cx - r >= 0) icp_scan_span(cellStart, Tq, rowbase + cx - r, rowbase + cx - r, px, py, pz, bd, best, best_i);
-                    if (cx + r < g.gx) icp_scan_span(cellStart, Tq, rowbase + cx + r, rowbase + cx + r, px, py, pz, bd, best, best_i);
+                    if (cx - r >= 0 && cx - r >= xlo) icp_scan_span(cellStart, Tq, rowbase + cx - r, rowbase + cx - r, px, py, pz, bd, best, best_i);
+                    if (cx + r < g.gx && cx + r <= xhi) icp_scan_span(cellStart, Tq, rowbase + cx + r, rowbase + cx + r, px, py, pz, bd, best, best_i);
                 }
             }
         }
-        const double reach = (double)r * g.c * 0.999999999;
+        // every cell within Chebyshev distance r has been seen: an unseen point lies beyond one of the faces of that
+        // block (faces on the grid boundary have nothing behind them), i.e. at least `reach` away
+        double reach = 1.0 / 0.0;
+        if (cx - r > 0) reach = fmin(reach, px - (g.ox + (double)(cx - r) * g.c));
+        if (cx + r < g.gx - 1) reach = fmin(reach, (g.ox + (double)(cx + r + 1) * g.c) - px);
+        if (cy - r > 0) reach = fmin(reach, py - (g.oy + (double)(cy - r) * g.c));
+        if (cy + r < g.gy - 1) reach = fmin(reach, (g.oy + (double)(cy + r + 1) * g.c) - py);
+        if (cz - r > 0) reach = fmin(reach, pz - (g.oz + (double)(cz - r) * g.c));
+        if (cz + r < g.gz - 1) reach = fmin(reach, (g.oz + (double)(cz + r + 1) * g.c) - pz);
+        reach = reach * 0.999999999 - eps;
+        reach = reach > 0.0 ? reach : 0.0;
         if (bd < reach * reach) break;
     }
     best_d2 = bd;
@@ -247,7 +282,7 @@ __device__ __forceinline__ bool icp_state_done(const IcpState* st);
 __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]);
 
 // nn_j[i] = sorted target position of the accepted nearest neighbour of source point i, or -1
-template <bool FROM_STATE>
+template <bool FROM_STATE, bool COOP>
 __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restrict__ src, Xform X, const IcpState* __restrict__ st,
                                                 IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
                                                 double max_corr2, int* __restrict__ nn_j) {
@@ -258,6 +293,18 @@ __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restr
     } else {
 #pragma unroll
         for (int i = 0; i < 12; ++i) T[i] = X.m[i];
+    }
+    if (!COOP) {                                    // one thread per source point: a search kernel with few registers
+        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
+            const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
+            const double px = T[0] * x + T[1] * y + T[2] * z + T[3];
+            const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
+            const double pz = T[8] * x + T[9] * y + T[10] * z + T[11];
+            double d2;
+            const int j = icp_nearest(g, cellStart, Tq, px, py, pz, d2);
+            nn_j[i] = (j >= 0 && d2 < max_corr2) ? j : -1;
+        }
+        return;
     }
     const int sub = threadIdx.x & (ICP_LPP - 1);
     const int64_t stride = (int64_t)gridDim.x * (blockDim.x / ICP_LPP);
@@ -729,8 +776,12 @@ struct gsr_icp_ctx {
     DevBuf src_raw, src_order, state, nn_j;
     bool src_sorted = false;
     bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
-    bool nn_kernel = false;         // GSR_ICP_NN_KERNEL=1: separate 8-lanes-per-point search kernel (measured 1.5x SLOWER
-                                    // than the fused thread-per-point search at 5M points: kept for the correspondence API)
+    // Search / accumulate split (GSR_ICP_NN_KERNEL): 0 = one fused kernel (120 VGPRs with the 30 float64 accumulators:
+    // 4 waves per SIMD); 2 = a thread-per-point search kernel (56 VGPRs, 8 waves per SIMD) writes nn_j and a streaming
+    // kernel accumulates -- the search is latency bound, so occupancy wins: 21 % faster at 5 M points, equal at 0.5 M,
+    // 8 % slower at 0.2 M (one more launch).  -1 = choose by size.  1 = eight lanes per point (1.5x slower, kept as a switch).
+    int nn_kernel = -1;
+    int nn_mode() const { return nn_kernel >= 0 ? nn_kernel : (ns >= 1000000 ? 2 : 0); }
     double cell_target = 2.0;       // target points per grid cell (GSR_ICP_CELL_TARGET).  Measured at 5M x 5M: 0.5 makes a
                                     // converged iteration 1.7x faster but a cold start (offsets ~ max_corr) 1.6x slower: keep 2
     DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
@@ -746,6 +797,12 @@ struct gsr_icp_ctx {
 namespace {
 
 // grid of the cooperative search kernel: 256 / ICP_LPP points per block, capped (grid-stride loop)
+inline int nn_grid1(int64_t ns) {      // one thread per point
+    int64_t g = (ns + 255) / 256;
+    if (g < 1) g = 1;
+    if (g > 16384) g = 16384;
+    return (int)g;
+}
 inline int nn_grid(int64_t ns) {
     int64_t g = (ns * ICP_LPP + 255) / 256;
     if (g < 1) g = 1;
@@ -770,10 +827,14 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     if (timed) GSR_HIP(hipEventRecord(c->e0, st));
     const double mc2 = c->max_corr * c->max_corr;
     const int* nnj = nullptr;
-    if (c->nn_kernel) {
+    if (c->nn_mode()) {
         GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-        hipLaunchKernelGGL(k_icp_nn<false>, dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                           c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+        if (c->nn_mode() == 2)
+            hipLaunchKernelGGL((k_icp_nn<false, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                               c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+        else
+            hipLaunchKernelGGL((k_icp_nn<false, true>), dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                               c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
         nnj = c->nn_j.as<int>();
     }
     if (kind == GSR_ICP_POINT_TO_POINT)
@@ -816,7 +877,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     c->stream = (hipStream_t)stream;
     if (hipEventCreate(&c->e0) != hipSuccess || hipEventCreate(&c->e1) != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate failed"); }
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
-    if (const char* e = getenv("GSR_ICP_NN_KERNEL")) c->nn_kernel = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_NN_KERNEL")) c->nn_kernel = atoi(e);
     if (const char* e = getenv("GSR_ICP_CELL_TARGET")) { double v = atof(e); if (v > 0.01 && v < 1000) c->cell_target = v; }
     if (const char* e = getenv("GSR_ICP_MAX_CELLS")) { int v = atoi(e); if (v >= 1024) c->max_cells = v; }
     *out = c;
@@ -991,10 +1052,13 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         GSR_HIP(hipEventRecord(c->e0, st));
         while (issued < total_evals) {
             const int chunk = total_evals - issued < 8 ? total_evals - issued : 8;
-            const int* nnj = c->nn_kernel ? c->nn_j.as<int>() : (const int*)nullptr;
+            const int* nnj = c->nn_mode() ? c->nn_j.as<int>() : (const int*)nullptr;
             for (int i = 0; i < chunk; ++i) {
-                if (c->nn_kernel)
-                    hipLaunchKernelGGL(k_icp_nn<true>, dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
+                if (c->nn_mode() == 2)
+                    hipLaunchKernelGGL((k_icp_nn<true, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
+                                       c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+                else if (c->nn_mode())
+                    hipLaunchKernelGGL((k_icp_nn<true, true>), dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
                                        c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
                 if (kind == GSR_ICP_POINT_TO_POINT)
                     hipLaunchKernelGGL(k_icp_accumulate_dev<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
@@ -1050,8 +1114,12 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
     GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-    hipLaunchKernelGGL(k_icp_nn<false>, dim3(nn_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
+    if (c->nn_mode() == 1)      // same search as the registration loop uses
+        hipLaunchKernelGGL((k_icp_nn<false, true>), dim3(nn_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                           c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
+    else
+        hipLaunchKernelGGL((k_icp_nn<false, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                           c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
     hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->nn_j.as<int>(),
                        c->Tq.as<float4>(), c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->corr_idx.as<int64_t>(),
                        c->corr_d2.as<double>());
