@@ -254,7 +254,7 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches": int(len(fill_ms)), "avg_units_per_launch": float(n_in.mean()),
                          "bytes_per_unit": B_GEOM,
-                         "note": "latency-bound neighbour evaluation (about 470 candidate tests per splat), not HBM-bound: see DESIGN.md section 4",
+                         "note": "VALU-bound neighbour evaluation (about 240 candidate tests and 80 KL divergences per splat; PMC: VALUBusy 94 %), not HBM-bound: see DESIGN.md section 4",
                          "level1": {"algorithmic_bytes": float(lvl_bytes), "ms": float(lvl_ms),
                                     "achieved_GBps": float(lvl_bytes / (lvl_ms * 1e-3) / 1e9),
                                     "frac": float(lvl_bytes / (lvl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},
