@@ -131,6 +131,15 @@ __global__ __launch_bounds__(256) void k_icp_gather_source(int64_t n, const unsi
     }
 }
 
+__global__ __launch_bounds__(256) void k_icp_gather_cov(int64_t n, const unsigned* __restrict__ order, const double* __restrict__ in,
+                                                        double* __restrict__ out) {
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < 6 * n; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = t / 6;
+        const int k = (int)(t - 6 * j);
+        out[t] = in[6 * (order ? (int64_t)order[j] : j) + k];
+    }
+}
+
 struct Xform { double m[12]; };   // rows 0..2 of the 4x4
 
 // Exact nearest target neighbour of p (float64) by an expanding ring search over the uniform grid.
@@ -329,6 +338,79 @@ __device__ __forceinline__ double icp_weight(int loss, double k, double r) {   /
     }
 }
 
+// Symmetric 3x3 eigen-decomposition (cyclic Jacobi, float64): A = V diag(lam) V^T.
+__host__ __device__ static void sym_eig3(double a00, double a01, double a02, double a11, double a12, double a22, double V[3][3], double lam[3]) {
+    double A[3][3] = {{a00, a01, a02}, {a01, a11, a12}, {a02, a12, a22}};
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) V[i][j] = i == j ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (!(off > 1e-40 * dg)) break;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double x = A[k][p], y = A[k][q]; A[k][p] = c * x - sn * y; A[k][q] = sn * x + c * y; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double x = A[p][k], y = A[q][k]; A[p][k] = c * x - sn * y; A[q][k] = sn * x + c * y; }
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { const double x = V[k][p], y = V[k][q]; V[k][p] = c * x - sn * y; V[k][q] = sn * x + c * y; }
+            }
+    }
+    lam[0] = A[0][0]; lam[1] = A[1][1]; lam[2] = A[2][2];
+}
+
+// Generalized ICP (Open3D GeneralizedICP.cpp, ComputeTransformation): three residual rows of one matched pair into
+// acc[2..29].  cs6 = the source covariance in the ORIGINAL frame (rotated here by R = T[0:3,0:3]), ct6 = target's.
+template <int NACC>
+__device__ __forceinline__ void icp_gicp_rows(double (&acc)[NACC], const double* T, double px, double py, double pz, double qx, double qy,
+                                              double qz, const double* __restrict__ cs6, const double* __restrict__ ct6, int loss, double kparam) {
+    const double c0[3][3] = {{cs6[0], cs6[1], cs6[2]}, {cs6[1], cs6[3], cs6[4]}, {cs6[2], cs6[4], cs6[5]}};
+    const double R[3][3] = {{T[0], T[1], T[2]}, {T[4], T[5], T[6]}, {T[8], T[9], T[10]}};
+    double RC[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) RC[a][b] = R[a][0] * c0[0][b] + R[a][1] * c0[1][b] + R[a][2] * c0[2][b];
+    double M[6];                                   // Ct + R Cs R^T, upper triangle
+    {
+        int t = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = a; b < 3; ++b) { M[t] = ct6[t] + (RC[a][0] * R[b][0] + RC[a][1] * R[b][1] + RC[a][2] * R[b][2]); ++t; }
+    }
+    double V[3][3], lam[3], W[3][3];
+    sym_eig3(M[0], M[1], M[2], M[3], M[4], M[5], V, lam);
+    const double is[3] = {1.0 / sqrt(lam[0]), 1.0 / sqrt(lam[1]), 1.0 / sqrt(lam[2])};
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) W[a][b] = V[a][0] * is[0] * V[b][0] + V[a][1] * is[1] * V[b][1] + V[a][2] * is[2] * V[b][2];
+    const double d[3] = {px - qx, py - qy, pz - qz};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        // J_i = [ (W * -skew(p)).row(i), W.row(i) ],  -skew(p) = [[0, pz, -py], [-pz, 0, px], [py, -px, 0]]
+        const double J[6] = {W[i][1] * -pz + W[i][2] * py, W[i][0] * pz + W[i][2] * -px, W[i][0] * -py + W[i][1] * px,
+                             W[i][0], W[i][1], W[i][2]};
+        const double r = W[i][0] * d[0] + W[i][1] * d[1] + W[i][2] * d[2];
+        const double w = icp_weight(loss, kparam, r);
+        int t = 2;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[t++] += J[a] * w * J[b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[23 + a] += J[a] * w * r;
+        acc[29] += r * r;
+    }
+}
+
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ partials) {
     __shared__ double s_red[4][NACC];
@@ -350,7 +432,8 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
 template <int KIND>
 __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float* __restrict__ src, Xform T, IcpGrid g,
                                                         const int* __restrict__ cellStart, const int* __restrict__ nn_j,
-                                                        const float4* __restrict__ Tq, const double* __restrict__ Tn, double max_corr2,
+                                                        const float4* __restrict__ Tq, const double* __restrict__ Tn,
+                                                        const double* __restrict__ Sc, double max_corr2,
                                                         int loss, double kparam, double* __restrict__ partials) {
     constexpr int NACC = KIND == 0 ? 17 : 30;
     double acc[NACC];
@@ -384,6 +467,8 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float*
             acc[8] += ax * bx; acc[9] += ax * by; acc[10] += ax * bz;
             acc[11] += ay * bx; acc[12] += ay * by; acc[13] += ay * bz;
             acc[14] += az * bx; acc[15] += az * by; acc[16] += az * bz;
+        } else if (KIND == 2) {
+            icp_gicp_rows<NACC>(acc, T.m, px, py, pz, qx, qy, qz, Sc + 6 * i, Tn + 6 * (int64_t)j, loss, kparam);
         } else {
             const double nx = Tn[3 * (int64_t)j], ny = Tn[3 * (int64_t)j + 1], nz = Tn[3 * (int64_t)j + 2];
             const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
@@ -678,7 +763,8 @@ __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]) {
 template <int KIND>
 __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, const IcpState* __restrict__ st,
                                                             IcpGrid g, const int* __restrict__ cellStart, const int* __restrict__ nn_j,
-                                                            const float4* __restrict__ Tq, const double* __restrict__ Tn, double max_corr2,
+                                                            const float4* __restrict__ Tq, const double* __restrict__ Tn,
+                                                            const double* __restrict__ Sc, double max_corr2,
                                                             int loss, double kparam, double* __restrict__ partials) {
     if (st->done) return;
     constexpr int NACC = KIND == 0 ? 17 : 30;
@@ -716,6 +802,8 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
             acc[8] += ax * bx; acc[9] += ax * by; acc[10] += ax * bz;
             acc[11] += ay * bx; acc[12] += ay * by; acc[13] += ay * bz;
             acc[14] += az * bx; acc[15] += az * by; acc[16] += az * bz;
+        } else if (KIND == 2) {
+            icp_gicp_rows<NACC>(acc, T, px, py, pz, qx, qy, qz, Sc + 6 * i, Tn + 6 * (int64_t)j, loss, kparam);
         } else {
             const double nx = Tn[3 * (int64_t)j], ny = Tn[3 * (int64_t)j + 1], nz = Tn[3 * (int64_t)j + 2];
             const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
@@ -773,7 +861,8 @@ struct gsr_icp_ctx {
     bool have_target = false, have_normals = false, have_source = false;
     int64_t nt = 0, ns = 0, ns_global = 0;
     double max_corr = 0;
-    DevBuf src_raw, src_order, state, nn_j;
+    DevBuf src_raw, src_order, state, nn_j, Tc, Sc, stage_cov;
+    bool have_tcov = false, have_scov = false;
     bool src_sorted = false;
     bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
     // Search / accumulate split (GSR_ICP_NN_KERNEL): 0 = one fused kernel (120 VGPRs with the 30 float64 accumulators:
@@ -812,9 +901,12 @@ inline int nn_grid(int64_t ns) {
 
 int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, double k, double* acc, bool timed) {
     if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
-    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
+    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE && kind != GSR_ICP_GENERALIZED)
+        return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
     if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
         return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
+    if (kind == GSR_ICP_GENERALIZED && (!c->have_tcov || !c->have_scov))
+        return fail(GSR_E_PRECONDITION, "TransformationEstimationForGeneralizedICP requires source and target covariances");
     hipStream_t st = c->stream;
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
@@ -839,10 +931,13 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     }
     if (kind == GSR_ICP_POINT_TO_POINT)
         hipLaunchKernelGGL(k_icp_accumulate<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
-                           c->Tq.as<float4>(), (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
-    else
+                           c->Tq.as<float4>(), (const double*)nullptr, (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
+    else if (kind == GSR_ICP_POINT_TO_PLANE)
         hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
-                           c->Tq.as<float4>(), c->Tn.as<double>(), mc2, loss, k, c->partials.as<double>());
+                           c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
+    else
+        hipLaunchKernelGGL(k_icp_accumulate<2>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
+                           c->Tq.as<float4>(), c->Tc.as<double>(), c->Sc.as<double>(), mc2, loss, k, c->partials.as<double>());
     hipLaunchKernelGGL(k_icp_finalize, dim3(GSR_ICP_ACC_LEN), dim3(64), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>());
     if (timed) GSR_HIP(hipEventRecord(c->e1, st));
     GSR_HIP(hipMemcpyAsync(acc, c->acc_dev.p, GSR_ICP_ACC_LEN * 8, hipMemcpyDeviceToHost, st));
@@ -887,7 +982,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
 int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
-    DevBuf* all[] = {&c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
+    DevBuf* all[] = {&c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->Tc, &c->Sc, &c->stage_cov, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
                      &c->src, &c->partials, &c->acc_dev, &c->rocprim_tmp, &c->corr_idx, &c->corr_d2};
     for (DevBuf* b : all) b->release();
     if (c->e0) (void)hipEventDestroy(c->e0);
@@ -969,6 +1064,7 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     GSR_HIP(hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&c->ms_build, c->e0, c->e1);
     c->nt = n; c->max_corr = max_corr; c->have_target = true; c->have_normals = normals != nullptr;
+    c->have_tcov = false; c->have_scov = false;
     c->have_source = false;              // the source is sorted by the target grid: set it again after a new target
     return GSR_OK;
 }
@@ -1002,8 +1098,37 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t 
         GSR_HIP(hipMemcpyAsync(c->src.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
     GSR_HIP(hipStreamSynchronize(st));
-    c->ns = n; c->have_source = true;
+    c->ns = n; c->have_source = true; c->have_scov = false;
     if (!c->allreduce) c->ns_global = n;
+    return GSR_OK;
+}
+
+static int32_t set_cov(gsr_icp_ctx* c, const double* cov6, int64_t n, const unsigned* order, DevBuf& dst, int32_t on_device) {
+    GSR_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const double* in = cov6;
+    if (!on_device) {
+        GSR_TRY(c->stage_cov.reserve((size_t)n * 48));
+        GSR_HIP(hipMemcpyAsync(c->stage_cov.p, cov6, (size_t)n * 48, hipMemcpyHostToDevice, st));
+        in = c->stage_cov.as<double>();
+    }
+    GSR_TRY(dst.reserve((size_t)n * 48));
+    hipLaunchKernelGGL(k_icp_gather_cov, dim3(stride_grid(6 * n)), dim3(256), 0, st, n, order, in, dst.as<double>());
+    GSR_HIP(hipStreamSynchronize(st));
+    return GSR_OK;
+}
+int32_t gsr_icp_set_target_cov(gsr_icp_ctx* c, const double* cov6, int32_t on_device) {
+    if (!c || !cov6) return fail(GSR_E_INVALID, "gsr_icp_set_target_cov: NULL argument");
+    if (!c->have_target) return fail(GSR_E_PRECONDITION, "gsr_icp_set_target_cov: set the target first");
+    GSR_TRY(set_cov(c, cov6, c->nt, c->order.as<unsigned>(), c->Tc, on_device));
+    c->have_tcov = true;
+    return GSR_OK;
+}
+int32_t gsr_icp_set_source_cov(gsr_icp_ctx* c, const double* cov6, int32_t on_device) {
+    if (!c || !cov6) return fail(GSR_E_INVALID, "gsr_icp_set_source_cov: NULL argument");
+    if (!c->have_source) return fail(GSR_E_PRECONDITION, "gsr_icp_set_source_cov: set the source first");
+    GSR_TRY(set_cov(c, cov6, c->ns, c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->Sc, on_device));
+    c->have_scov = true;
     return GSR_OK;
 }
 
@@ -1028,9 +1153,12 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
     if (!c->allreduce && c->device_loop) {
         // device-resident loop (single rank): no per-iteration host round trip
         if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
-        if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
+        if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE && kind != GSR_ICP_GENERALIZED)
+            return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
         if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
             return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
+        if (kind == GSR_ICP_GENERALIZED && (!c->have_tcov || !c->have_scov))
+            return fail(GSR_E_PRECONDITION, "TransformationEstimationForGeneralizedICP requires source and target covariances");
         hipStream_t st = c->stream;
         IcpState hs;
         memset(&hs, 0, sizeof(hs));
@@ -1062,10 +1190,16 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
                                        c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
                 if (kind == GSR_ICP_POINT_TO_POINT)
                     hipLaunchKernelGGL(k_icp_accumulate_dev<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
-                else
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), (const double*)nullptr, (const double*)nullptr, mc2, loss, k,
+                                       c->partials.as<double>());
+                else if (kind == GSR_ICP_POINT_TO_PLANE)
                     hipLaunchKernelGGL(k_icp_accumulate_dev<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tn.as<double>(), mc2, loss, k, c->partials.as<double>());
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, mc2, loss, k,
+                                       c->partials.as<double>());
+                else
+                    hipLaunchKernelGGL(k_icp_accumulate_dev<2>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tc.as<double>(), c->Sc.as<double>(), mc2, loss, k,
+                                       c->partials.as<double>());
                 hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>());
             }
             issued += chunk;
@@ -1131,7 +1265,8 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
 
 int32_t gsr_icp_solve(const double* acc, int32_t kind, const double* centre, double* update) {
     if (!acc || !update) return fail(GSR_E_INVALID, "gsr_icp_solve: NULL argument");
-    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE) return fail(GSR_E_INVALID, "gsr_icp_solve: unknown kind %d", kind);
+    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE && kind != GSR_ICP_GENERALIZED)
+        return fail(GSR_E_INVALID, "gsr_icp_solve: unknown kind %d", kind);
     const double zero[3] = {0, 0, 0};
     estimate_update(centre ? centre : zero, kind, acc, update);
     return GSR_OK;

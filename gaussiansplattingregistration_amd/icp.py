@@ -19,6 +19,7 @@ __all__ = ["IcpContext", "registration_icp_arrays", "normals_from_cov", "Registr
 
 KIND_POINT_TO_POINT = 0
 KIND_POINT_TO_PLANE = 1
+KIND_GENERALIZED = 2
 LOSS_L2, LOSS_TUKEY, LOSS_CAUCHY, LOSS_GM, LOSS_HUBER = 0, 1, 2, 3, 4
 
 
@@ -98,6 +99,7 @@ class IcpContext:
         if dx:
             self._sync_torch()
         _lib.check(self._L.gsr_icp_set_target(self._h, px, pn, n, float(max_corr), 1 if dx else 0), "gsr_icp_set_target")
+        self.n_target = n
 
     def set_source(self, xyz):
         n = int(xyz.shape[0])
@@ -106,6 +108,35 @@ class IcpContext:
             self._sync_torch()
         _lib.check(self._L.gsr_icp_set_source(self._h, px, n, 1 if dx else 0), "gsr_icp_set_source")
         self.n_source = n
+
+    @staticmethod
+    def _cov6(cov):
+        """(N,6) [xx,xy,xz,yy,yz,zz] or (N,3,3) covariances -> contiguous (N,6) float64 (numpy or tensor kept as is)."""
+        if _is_tensor(cov):
+            import torch
+            if cov.dim() == 3:
+                cov = torch.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+            return cov.to(torch.float64).contiguous()
+        cov = np.asarray(cov)
+        if cov.ndim == 3:
+            cov = np.stack([cov[:, 0, 0], cov[:, 0, 1], cov[:, 0, 2], cov[:, 1, 1], cov[:, 1, 2], cov[:, 2, 2]], 1)
+        return np.ascontiguousarray(cov, dtype=np.float64)
+
+    def set_target_cov(self, cov):
+        """Target covariances for generalized ICP, in the order of the points given to ``set_target``."""
+        c6 = self._cov6(cov)
+        p, keep, on_dev = _prep(c6, (self.n_target, 6), np.float64, self.device)
+        if on_dev:
+            self._sync_torch()
+        _lib.check(self._L.gsr_icp_set_target_cov(self._h, p, 1 if on_dev else 0), "gsr_icp_set_target_cov")
+
+    def set_source_cov(self, cov):
+        """Source covariances (original frame; the library rotates them with the current transform)."""
+        c6 = self._cov6(cov)
+        p, keep, on_dev = _prep(c6, (self.n_source, 6), np.float64, self.device)
+        if on_dev:
+            self._sync_torch()
+        _lib.check(self._L.gsr_icp_set_source_cov(self._h, p, 1 if on_dev else 0), "gsr_icp_set_source_cov")
 
     def set_allreduce(self, fn, n_source_global):
         """``fn(numpy float64[32]) -> None`` must sum the vector over all ranks in place."""
@@ -156,11 +187,17 @@ class IcpContext:
 
 
 def registration_icp_arrays(src_xyz, tgt_xyz, tgt_normals, init, kind=0, loss=0, k=0.0, max_corr=1.0, rel_fitness=1e-6,
-                            rel_rmse=1e-6, max_iter=30, device=0):
-    """One ``registration_icp`` on raw arrays; returns dict(transformation, fitness, inlier_rmse, iterations)."""
+                            rel_rmse=1e-6, max_iter=30, device=0, src_cov=None, tgt_cov=None):
+    """One ``registration_icp`` on raw arrays; returns dict(transformation, fitness, inlier_rmse, iterations).
+    kind 2 (generalized ICP) needs ``src_cov`` / ``tgt_cov`` ((N,6) or (N,3,3))."""
     with IcpContext(device=device) as c:
         c.set_target(tgt_xyz, tgt_normals, max_corr)
         c.set_source(src_xyz)
+        if kind == 2:
+            if src_cov is None or tgt_cov is None:
+                raise RuntimeError("TransformationEstimationForGeneralizedICP requires source and target covariances")
+            c.set_target_cov(tgt_cov)
+            c.set_source_cov(src_cov)
         out = c.register(init, kind, loss, k, rel_fitness, rel_rmse, max_iter)
         out.update(c.timing())
         return out

@@ -14,8 +14,11 @@ Same public names, argument meaning and error behaviour:
   at the reference's HEAD) is accepted too.
 
 Open3D raises ``RuntimeError`` for ``max_correspondence_distance <= 0`` and for point-to-plane ICP on
-a target without normals; so does this module.  Colored / Generalized ICP are outside this round's
-scope and raise ``NotImplementedError``.
+a target without normals; so does this module.  Generalized ICP (``registration_generalized_icp``, reference
+``:96-98``) runs on the clouds' own covariances -- the reference's clouds always carry the splat covariances
+(``point_cloud_converter.py:38``), which Open3D then uses as given; a cloud without covariances raises (Open3D
+would estimate them from 20-nearest-neighbour normals, which this backend does not build).  Colored ICP is outside
+this round's scope and raises ``NotImplementedError``.
 """
 from __future__ import annotations
 
@@ -94,7 +97,7 @@ def get_estimation(registration_type, loss_function):
     if registration_type is LocalRegistrationType.ICP_Color:
         return Estimation(-1, loss_function, "TransformationEstimationForColoredICP")
     if registration_type is LocalRegistrationType.ICP_General:
-        return Estimation(-2, loss_function, "TransformationEstimationForGeneralizedICP")
+        return Estimation(_icp.KIND_GENERALIZED, loss_function, "TransformationEstimationForGeneralizedICP")
     return None
 
 
@@ -128,6 +131,9 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
                            "TransformationEstimationColoredICP require pre-computed normal vectors for target PointCloud.")
     if estimation_method.kind < 0:
         raise NotImplementedError(f"{estimation_method.name} is not part of this backend yet (SURVEY.md 8f, N2)")
+    if estimation_method.kind == _icp.KIND_GENERALIZED and not (source.has_covariances() and target.has_covariances()):
+        raise RuntimeError("registration_generalized_icp: this backend uses the clouds' own covariances "
+                           "(point_cloud_converter.py:38 always sets them); a cloud without covariances is not supported")
     dev = device if device is not None else getattr(target, "device_index", 0)
     loss = estimation_method.loss or RobustLoss(_icp.LOSS_L2)
     own = ctx is None            # a caller-provided context keeps its workspace across calls (no allocation in steady state)
@@ -137,6 +143,9 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
         ctx.set_target(target.xyz32, target.normals if estimation_method.kind == _icp.KIND_POINT_TO_PLANE else None,
                        max_correspondence_distance)
         ctx.set_source(source.xyz32)
+        if estimation_method.kind == _icp.KIND_GENERALIZED:
+            ctx.set_target_cov(target.cov6)
+            ctx.set_source_cov(source.cov6)
         if allreduce is not None:
             ctx.set_allreduce(allreduce, n_source_global)
         r = ctx.register(np.asarray(init, dtype=np.float64), estimation_method.kind, loss.code, loss.k,
@@ -147,6 +156,14 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
     finally:
         if own:
             ctx.close()
+
+
+def registration_generalized_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, **kw):
+    """``o3d.pipelines.registration.registration_generalized_icp`` (Open3D GeneralizedICP.cpp: the ICP loop with
+    ``TransformationEstimationForGeneralizedICP``) on clouds that carry covariances."""
+    if estimation_method.kind != _icp.KIND_GENERALIZED:
+        raise RuntimeError("registration_generalized_icp needs TransformationEstimationForGeneralizedICP")
+    return registration_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, **kw)
 
 
 def do_icp_registration(point_cloud_first, point_cloud_second, init_transform, registration_params, *extra, **kw):
@@ -171,6 +188,9 @@ def do_icp_registration(point_cloud_first, point_cloud_second, init_transform, r
     if rt in (LocalRegistrationType.ICP_Point_To_Point, LocalRegistrationType.ICP_Point_To_Plane):
         return registration_icp(point_cloud_first, point_cloud_second, max_correspondence, init_transform,
                                 estimation_method, convergence_criteria, **kw)
-    if rt in (LocalRegistrationType.ICP_Color, LocalRegistrationType.ICP_General):
+    if rt is LocalRegistrationType.ICP_General:
+        return registration_generalized_icp(point_cloud_first, point_cloud_second, max_correspondence, init_transform,
+                                            estimation_method, convergence_criteria, **kw)
+    if rt is LocalRegistrationType.ICP_Color:
         raise NotImplementedError(f"{rt.instance_name} is not part of this backend yet (SURVEY.md 8f, N2)")
     return None

@@ -121,6 +121,7 @@ typedef struct gsr_icp_ctx gsr_icp_ctx;
 
 #define GSR_ICP_POINT_TO_POINT 0   /* LocalRegistrationType.ICP_Point_To_Point, local_registration_util.py:33 */
 #define GSR_ICP_POINT_TO_PLANE 1   /* LocalRegistrationType.ICP_Point_To_Plane, :34 */
+#define GSR_ICP_GENERALIZED    2   /* LocalRegistrationType.ICP_General, :36 (registration_generalized_icp, :96-98) */
 
 #define GSR_LOSS_L2     0          /* KernelLossFunctionType.Loss_None or k == 0, :63-64 */
 #define GSR_LOSS_TUKEY  1
@@ -139,6 +140,12 @@ int32_t gsr_icp_destroy(gsr_icp_ctx* ctx);
 int32_t gsr_icp_set_target(gsr_icp_ctx* ctx, const float* xyz, const double* normals, int64_t n,
                            double max_corr, int32_t on_device);
 int32_t gsr_icp_set_source(gsr_icp_ctx* ctx, const float* xyz, int64_t n, int32_t on_device);
+/* Per-point covariances for GSR_ICP_GENERALIZED: cov6[n*6] float64 (xx, xy, xz, yy, yz, zz), in the order of the
+ * points last given to gsr_icp_set_target / gsr_icp_set_source (call these after them).  The reference's clouds
+ * carry the splats' own covariances (point_cloud_converter.py:38), which Open3D's generalized ICP then uses as
+ * they are; the source covariances follow the source under the current transform (C <- R C R^T). */
+int32_t gsr_icp_set_target_cov(gsr_icp_ctx* ctx, const double* cov6, int32_t on_device);
+int32_t gsr_icp_set_source_cov(gsr_icp_ctx* ctx, const double* cov6, int32_t on_device);
 /* Multi-GPU source split: this rank owns source points, the target is replicated.  `allreduce` is
  * called once per correspondence evaluation with the rank-local accumulator vector (float64[len],
  * host memory) and must replace it by the element-wise sum over ranks (RCCL/gloo all-reduce in the
@@ -149,7 +156,8 @@ int32_t gsr_icp_set_allreduce(gsr_icp_ctx* ctx, gsr_allreduce_fn fn, void* user,
 /* One correspondence evaluation + accumulator reduction at transform T (row-major 4x4 float64):
  * acc[0]=count, acc[1]=sum d^2, then for point-to-point acc[2..4]=sum p, [5..7]=sum q, [8..16]=sum p q^T
  * (p = transformed source, q = matched target, both relative to the target-bbox centre);
- * for point-to-plane acc[2..22]=upper triangle of J^T w J (row-major), [23..28]=J^T w r, [29]=sum r^2.
+ * for point-to-plane and generalized ICP acc[2..22]=upper triangle of J^T w J (row-major), [23..28]=J^T w r,
+ * [29]=sum r^2 (generalized: three residual rows per pair, J = W [-skew(p) | I], W = (Ct + R Cs R^T)^-1/2).
  * len(acc) = GSR_ICP_ACC_LEN.  This is the "hot loop" exposed for tests and for RCCL all-reduce. */
 #define GSR_ICP_ACC_LEN 32
 int32_t gsr_icp_accumulate(gsr_icp_ctx* ctx, const double* T, int32_t kind, int32_t loss, double k,

@@ -380,6 +380,127 @@ int32_t gsr_oracle_icp(const double* src_, int64_t ns, const double* tgt_, const
     return it;
 }
 
+// Generalized ICP (Open3D 0.16.0 cpp/open3d/pipelines/registration/GeneralizedICP.cpp), as the reference reaches it
+// at src/utils/local_registration_util.py:96-98 with clouds that carry per-point covariances
+// (point_cloud_converter.py:38), so InitializePointCloudForGeneralizedICP keeps them ("pre-computed covariances").
+//   loop      : RegistrationICP (above); PointCloud::Transform also rotates the source covariances, C <- R C R^T
+//   estimate  : d = vs - vt, M = Ct + Cs, W = M^-1/2 (principal root), J = W [-skew(vs) | I]  (3 rows),
+//               r_i = W.row(i).d, w_i = kernel(r_i); JTJ += w_i J_i J_i^T, JTr += w_i r_i J_i; x = solve(JTJ, -JTr)
+// cov arguments: n x 9 float64 (row-major 3x3).
+static void sym_eig3(const double A_[3][3], double V[3][3], double lam[3]) {      // cyclic Jacobi, float64
+    double A[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A[i][j] = A_[i][j]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 60; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double dg = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (!(off > 1e-40 * dg)) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
+                const double c = 1.0 / std::sqrt(t * t + 1.0), sn = t * c;
+                for (int k = 0; k < 3; ++k) {           // A <- A G
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {           // A <- G^T A
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq;
+                }
+            }
+    }
+    for (int i = 0; i < 3; ++i) lam[i] = A[i][i];
+}
+static void inv_sqrt3(const double M[3][3], double W[3][3]) {
+    double V[3][3], lam[3];
+    sym_eig3(M, V, lam);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double s = 0;
+            for (int k = 0; k < 3; ++k) s += V[i][k] * (1.0 / std::sqrt(lam[k])) * V[j][k];
+            W[i][j] = s;
+        }
+}
+
+int32_t gsr_oracle_gicp(const double* src_, const double* src_cov, int64_t ns, const double* tgt_, const double* tgt_cov,
+                        int64_t nt, const double* init4x4, int32_t loss, double k, double max_corr, double rel_fitness,
+                        double rel_rmse, int32_t max_iter, int32_t threads, double* out_T, double* out_fitness,
+                        double* out_rmse) {
+    if (!(max_corr > 0)) return -1;
+    if (!src_cov || !tgt_cov) return -2;
+    if (ns <= 0 || nt <= 0) return -3;
+    std::vector<P3> src(ns), tgt(nt);
+    std::memcpy(src.data(), src_, sizeof(P3) * ns);
+    std::memcpy(tgt.data(), tgt_, sizeof(P3) * nt);
+    std::vector<double> cs(src_cov, src_cov + 9 * ns);
+    KdTree tree;
+    tree.create(tgt.data(), nt);
+    auto rotate_covs = [&](const M4& U) {
+        for (int64_t i = 0; i < ns; ++i) {
+            double* C = cs.data() + 9 * i;
+            double RC[3][3], out[3][3];
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s = 0; for (int m = 0; m < 3; ++m) s += U.a[a][m] * C[3 * m + b]; RC[a][b] = s; }
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s = 0; for (int m = 0; m < 3; ++m) s += RC[a][m] * U.a[b][m]; out[a][b] = s; }
+            for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) C[3 * a + b] = out[a][b];
+        }
+    };
+    M4 T;
+    std::memcpy(&T, init4x4, sizeof(M4));
+    bool is_identity = true;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (T.a[i][j] != (i == j ? 1.0 : 0.0)) is_identity = false;
+    if (!is_identity) { transform_points(src, T); rotate_covs(T); }
+    Eval res = evaluate(src, tree, nt, max_corr, threads);
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        M4 update = identity4();
+        const size_t nc = res.si.size();
+        if (nc > 0) {
+            double JTJ[6][6] = {{0}}, JTr[6] = {0};
+            for (size_t c = 0; c < nc; ++c) {
+                const P3& vs = src[res.si[c]];
+                const P3& vt = tgt[res.ti[c]];
+                const double* Cs = cs.data() + 9 * res.si[c];
+                const double* Ct = tgt_cov + 9 * res.ti[c];
+                double M[3][3], W[3][3];
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) M[a][b] = Ct[3 * a + b] + Cs[3 * a + b];
+                inv_sqrt3(M, W);
+                const double d[3] = {vs.x - vt.x, vs.y - vt.y, vs.z - vt.z};
+                const double nsk[3][3] = {{0, vs.z, -vs.y}, {-vs.z, 0, vs.x}, {vs.y, -vs.x, 0}};      // -skew(vs)
+                for (int i = 0; i < 3; ++i) {
+                    double J[6];
+                    for (int b = 0; b < 3; ++b) { double s = 0; for (int m = 0; m < 3; ++m) s += W[i][m] * nsk[m][b]; J[b] = s; }
+                    for (int b = 0; b < 3; ++b) J[3 + b] = W[i][b];
+                    const double r = W[i][0] * d[0] + W[i][1] * d[1] + W[i][2] * d[2];
+                    const double w = kernel_weight(loss, k, r);
+                    for (int p = 0; p < 6; ++p) {
+                        for (int q = 0; q < 6; ++q) JTJ[p][q] += J[p] * w * J[q];
+                        JTr[p] += J[p] * w * r;
+                    }
+                }
+            }
+            double nb[6], x[6];
+            for (int p = 0; p < 6; ++p) nb[p] = -JTr[p];
+            solve6(JTJ, nb, x);
+            update = vec6_to_mat4(x);
+        }
+        T = mul4(update, T);
+        transform_points(src, update);
+        rotate_covs(update);
+        Eval backup = std::move(res);
+        res = evaluate(src, tree, nt, max_corr, threads);
+        if (std::fabs(backup.fitness - res.fitness) < rel_fitness && std::fabs(backup.rmse - res.rmse) < rel_rmse) { ++it; break; }
+    }
+    std::memcpy(out_T, &T, sizeof(M4));
+    *out_fitness = res.fitness;
+    *out_rmse = res.rmse;
+    return it;
+}
+
 int gsr_oracle_icp_correspond(const double* src_, int64_t ns, const double* tgt_, int64_t nt,
                               const double* T4x4, double max_corr, int32_t threads,
                               int64_t* out_idx, double* out_d2) {

@@ -214,6 +214,29 @@ def icp(src, tgt, tgt_normals=None, init=None, kind=0, loss=0, k=0.0, max_corr=1
     return out
 
 
+def gicp(src, src_cov, tgt, tgt_cov, init=None, loss=0, k=0.0, max_corr=1.0, rel_fitness=1e-6, rel_rmse=1e-6, max_iter=30,
+         threads=0):
+    """registration_generalized_icp on the oracle (covariances (N,3,3) float64, used as given)."""
+    src = _c(src, np.float64).reshape(-1, 3)
+    tgt = _c(tgt, np.float64).reshape(-1, 3)
+    sc = _c(src_cov, np.float64).reshape(-1, 9)
+    tc = _c(tgt_cov, np.float64).reshape(-1, 9)
+    init = np.eye(4) if init is None else _c(init, np.float64).reshape(4, 4)
+    T = np.empty((4, 4), np.float64)
+    fit, rmse = C.c_double(0), C.c_double(0)
+    fn = lib().gsr_oracle_gicp
+    fn.restype = C.c_int32
+    P = C.c_void_p
+    fn.argtypes = [P, P, C.c_int64, P, P, C.c_int64, P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int32,
+                   C.c_int32, P, P, P]
+    it = fn(src.ctypes.data, sc.ctypes.data, src.shape[0], tgt.ctypes.data, tc.ctypes.data, tgt.shape[0], init.ctypes.data, loss, k,
+            max_corr, rel_fitness, rel_rmse, max_iter, threads, T.ctypes.data, C.addressof(fit), C.addressof(rmse))
+    if it < 0:
+        raise RuntimeError({-1: "max_correspondence_distance must be > 0", -2: "generalized ICP requires covariances",
+                            -3: "empty point cloud"}.get(it, f"gicp oracle error {it}"))
+    return {"transformation": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iterations": int(it)}
+
+
 def icp_correspond(src, tgt, T, max_corr, threads=0):
     src = _c(src, np.float64).reshape(-1, 3)
     tgt = _c(tgt, np.float64).reshape(-1, 3)

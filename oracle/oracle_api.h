@@ -72,6 +72,12 @@ int32_t gsr_oracle_icp(const double* src, int64_t ns, const double* tgt, const d
                        double max_corr, double rel_fitness, double rel_rmse, int32_t max_iter,
                        int32_t threads, double* out_T4x4, double* out_fitness, double* out_rmse,
                        double* trace /* optional, (max_iter+1) x 18: fitness, rmse, T(16) per evaluation */);
+// Generalized ICP (Open3D GeneralizedICP.cpp) with the clouds' own covariances (n x 9 float64, row-major 3x3).
+// Same loop, losses and return convention as gsr_oracle_icp; -2 = a covariance array is missing.
+int32_t gsr_oracle_gicp(const double* src, const double* src_cov3x3, int64_t ns, const double* tgt, const double* tgt_cov3x3,
+                        int64_t nt, const double* init4x4, int32_t loss, double k, double max_corr, double rel_fitness,
+                        double rel_rmse, int32_t max_iter, int32_t threads, double* out_T4x4, double* out_fitness,
+                        double* out_rmse);
 // One correspondence evaluation: nearest target index (or -1) and squared distance for every source point.
 int gsr_oracle_icp_correspond(const double* src, int64_t ns, const double* tgt, int64_t nt,
                               const double* T4x4, double max_corr, int32_t threads,

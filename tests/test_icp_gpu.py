@@ -146,6 +146,54 @@ def test_do_icp_registration_and_multiscale_driver(oracle):
     assert np.linalg.norm(T - T_gt) < 0.05
 
 
+def _cov33(c6):
+    c6 = np.asarray(c6, np.float64)
+    return np.stack([c6[:, [0, 1, 2]], c6[:, [1, 3, 4]], c6[:, [2, 4, 5]]], 1)
+
+
+@pytest.mark.parametrize("loss,k,n", [(0, 0.0, 5000), (1, 0.5, 5000), (4, 0.3, 5000), (0, 0.0, 150000)])
+def test_generalized_icp_vs_oracle(oracle, loss, k, n):
+    """registration_generalized_icp with the splats' own covariances (reference local_registration_util.py:96-98):
+    GPU against the oracle (itself cross-checked against NumPy/SciPy), L2 / Tukey / Huber, small and large."""
+    from gaussiansplattingregistration_amd import icp, synth
+    src, tgt, T_gt = synth.make_pair(n, seed=13, sh_degree=0)
+    r = icp.registration_icp_arrays(src["xyz"], tgt["xyz"], None, np.eye(4), kind=2, loss=loss, k=k, max_corr=0.3, max_iter=25,
+                                    src_cov=src["cov6"], tgt_cov=tgt["cov6"])
+    w = oracle.gicp(src["xyz"], _cov33(src["cov6"]), tgt["xyz"], _cov33(tgt["cov6"]), np.eye(4), loss=loss, k=k, max_corr=0.3,
+                    max_iter=25)
+    assert r["iterations"] == w["iterations"]
+    assert np.linalg.norm(r["transformation"] - w["transformation"]) < TOL_T
+    assert abs(r["fitness"] - w["fitness"]) < 1e-9 and abs(r["inlier_rmse"] - w["inlier_rmse"]) < 1e-8
+    if n <= 5000:                                                     # (the big scene's offset needs more than 25 iterations)
+        assert np.linalg.norm(r["transformation"] - T_gt) < 0.05
+
+
+def test_generalized_icp_through_do_icp_registration(oracle):
+    """The reference-shaped call: LocalRegistrationType.ICP_General on converted clouds (device tensors, non-identity init)."""
+    from gaussiansplattingregistration_amd import synth
+    from gaussiansplattingregistration_amd.models.gaussian_model import GaussianModel
+    from gaussiansplattingregistration_amd.params.registration_parameters import LocalRegistrationParams
+    from gaussiansplattingregistration_amd.utils.local_registration_util import (KernelLossFunctionType, LocalRegistrationType,
+                                                                                 do_icp_registration)
+    from gaussiansplattingregistration_amd.utils.point_cloud_converter import convert_gs_to_open3d_pc
+    src, tgt, T_gt = synth.make_pair(8000, seed=14, sh_degree=0)
+    pcs = []
+    for c in (src, tgt):
+        gm = GaussianModel("cuda:0").from_arrays(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"], 0)
+        pcs.append(convert_gs_to_open3d_pc(gm))
+    init = synth.rigid_transform(1.0, (0, 0, 1), (0.01, 0.0, -0.01))
+    p = LocalRegistrationParams(registration_type=LocalRegistrationType.ICP_General, max_correspondence=0.3, relative_fitness=1e-6,
+                                relative_rmse=1e-6, max_iteration=20, rejection_type=KernelLossFunctionType.Cauchy_Loss, k_value=0.4)
+    res = do_icp_registration(pcs[0], pcs[1], init, p)
+    w = oracle.gicp(src["xyz"], _cov33(src["cov6"]), tgt["xyz"], _cov33(tgt["cov6"]), init, loss=2, k=0.4, max_corr=0.3, max_iter=20)
+    assert np.linalg.norm(res.transformation - w["transformation"]) < TOL_T
+    assert abs(res.fitness - w["fitness"]) < 1e-9
+    # covariances are mandatory for this estimator here
+    pcs[0].cov6 = None
+    with pytest.raises(RuntimeError, match="covariances"):
+        do_icp_registration(pcs[0], pcs[1], init, p)
+
+
 def test_icp_error_behaviour():
     from gaussiansplattingregistration_amd import icp
     with icp.IcpContext() as c:

@@ -71,6 +71,75 @@ def test_icp_oracle_vs_scipy(oracle, kind):
     assert np.linalg.norm(r["transformation"] - T_gt) < 5e-3       # recovers the ground-truth motion
 
 
+def _cov33(c6):
+    c6 = np.asarray(c6, np.float64)
+    return np.stack([c6[:, [0, 1, 2]], c6[:, [1, 3, 4]], c6[:, [2, 4, 5]]], 1)
+
+
+def _gicp_numpy(src, sc, tgt, tc, init, max_corr, max_iter, rel=1e-6):
+    """Independent restatement of Open3D's registration_generalized_icp with given covariances (L2 loss):
+    cKDTree correspondences, W = (Ct + Cs)^-1/2 by numpy eigh, J = W [-skew(p) | I], numpy solve."""
+    tree = cKDTree(tgt)
+    T = init.copy()
+    p = src @ T[:3, :3].T + T[:3, 3]
+    C = np.einsum("ab,nbc,dc->nad", T[:3, :3], sc, T[:3, :3])
+
+    def evaluate(p):
+        d, j = tree.query(p)
+        m = d < max_corr
+        if not m.any():
+            return m, j, 0.0, 0.0
+        return m, j, m.mean(), float(np.sqrt((d[m] ** 2).mean()))
+
+    m, j, fit, rmse = evaluate(p)
+    it = 0
+    for it in range(1, max_iter + 1):
+        ps, qs = p[m], tgt[j[m]]
+        M = tc[j[m]] + C[m]
+        lam, V = np.linalg.eigh(M)
+        W = np.einsum("nik,nk,njk->nij", V, lam ** -0.5, V)
+        d = ps - qs
+        r = np.einsum("nij,nj->ni", W, d)
+        nsk = np.zeros((len(ps), 3, 3))
+        nsk[:, 0, 1], nsk[:, 0, 2] = ps[:, 2], -ps[:, 1]
+        nsk[:, 1, 0], nsk[:, 1, 2] = -ps[:, 2], ps[:, 0]
+        nsk[:, 2, 0], nsk[:, 2, 1] = ps[:, 1], -ps[:, 0]
+        J = np.concatenate([W @ nsk, W], axis=2).reshape(-1, 6)
+        x = np.linalg.solve(J.T @ J, -(J.T @ r.reshape(-1)))
+        a, b, g = x[:3]
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        Rz = np.array([[np.cos(g), -np.sin(g), 0], [np.sin(g), np.cos(g), 0], [0, 0, 1]])
+        U = np.eye(4)
+        U[:3, :3] = Rz @ Ry @ Rx
+        U[:3, 3] = x[3:]
+        T = U @ T
+        p = p @ U[:3, :3].T + U[:3, 3]
+        C = np.einsum("ab,nbc,dc->nad", U[:3, :3], C, U[:3, :3])
+        m, j, fit2, rmse2 = evaluate(p)
+        done = abs(fit2 - fit) < rel and abs(rmse2 - rmse) < rel
+        fit, rmse = fit2, rmse2
+        if done:
+            break
+    return T, fit, rmse, it
+
+
+def test_gicp_oracle_vs_numpy(oracle):
+    """Generalized ICP with the splats' own covariances (what the reference's clouds carry): the C++ restatement against
+    an independent NumPy/SciPy one, and against the ground-truth motion."""
+    src, tgt, T_gt = synth.make_pair(3000, seed=11, sh_degree=0)
+    sc, tc = _cov33(src["cov6"]), _cov33(tgt["cov6"])
+    s64, t64 = src["xyz"].astype(np.float64), tgt["xyz"].astype(np.float64)
+    got = oracle.gicp(s64, sc, t64, tc, np.eye(4), max_corr=0.4, max_iter=30)
+    T, fit, rmse, it = _gicp_numpy(s64, sc, t64, tc, np.eye(4), 0.4, 30)
+    assert got["iterations"] == it
+    assert np.linalg.norm(got["transformation"] - T) < 1e-9
+    assert abs(got["fitness"] - fit) < 1e-12 and abs(got["inlier_rmse"] - rmse) < 1e-10
+    assert np.linalg.norm(got["transformation"] - T_gt) < 0.05
+    with pytest.raises(RuntimeError, match="max_correspondence_distance"):
+        oracle.gicp(s64, sc, t64, tc, np.eye(4), max_corr=0.0)
+
+
 def test_icp_golden_fixture_is_reproduced(oracle):
     g = load_golden("icp_pair")
     for name, kind, loss, k in (("p2p", 0, 0, 0.0), ("p2plane", 1, 0, 0.0), ("p2plane_tukey", 1, 1, 0.05), ("p2plane_huber", 1, 4, 0.01)):
