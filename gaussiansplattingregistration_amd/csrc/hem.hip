@@ -550,6 +550,68 @@ struct EllClip {
     float k11, k12, k22, kr, im00, m01, m02, T;
 };
 
+// The span (first sorted position, length) of one grid row (ry, rz) for a parent at pm: the row's cells within the
+// sphere of radius sqrt(Ra2), clipped to the pre-reject ellipsoid when `clip`.  IRR: positions in the irregular list.
+// ONE definition shared by k_select (every mode) and k_spans: the capacities must equal what the passes scan.
+template <bool IRR>
+__device__ __forceinline__ void select_row_span(const SelectArgs& a, const GridParams& g, const f3& pm, const EllClip& ec, bool clip,
+                                                float Ra2, int x0, int x1, int ry, int rz, int& s, int& len) {
+    // distance from the parent to the row's y/z slab (widened by the rounding slack)
+    // (the first / last row of the grid also holds every centre clamped in from outside: half-infinite)
+    const bool edge = ry == 0 || ry == g.gy - 1 || rz == 0 || rz == g.gz - 1;
+    const float ylo = ry == 0 ? -FLT_MAX : g.oy + ry * g.c - g.slack, yhi = ry == g.gy - 1 ? FLT_MAX : g.oy + (ry + 1) * g.c + g.slack;
+    const float zlo = rz == 0 ? -FLT_MAX : g.oz + rz * g.c - g.slack, zhi = rz == g.gz - 1 ? FLT_MAX : g.oz + (rz + 1) * g.c + g.slack;
+    const float dy = fmaxf(0.0f, fmaxf(ylo - pm.y, pm.y - yhi));
+    const float dz = fmaxf(0.0f, fmaxf(zlo - pm.z, pm.z - zhi));
+    const float rem = Ra2 - dy * dy - dz * dz;
+    if (rem >= 0.0f) {
+        const float hx = sqrtf(rem) * 1.00001f + g.slack;
+        float lo = -hx, hi = hx;                                   // x interval relative to the parent
+        if (clip && !edge) {
+            const float cy = 0.5f * (ylo + yhi) - pm.y, cz = 0.5f * (zlo + zhi) - pm.z;
+            const float hy = 0.5f * (yhi - ylo), hz = 0.5f * (zhi - zlo);
+            const float sc = sqrtf(fmaxf(0.0f, ec.k11 * cy * cy + 2.0f * ec.k12 * cy * cz + ec.k22 * cz * cz));
+            const float smin = fmaxf(0.0f, sc * 0.999f - ec.kr * sqrtf(hy * hy + hz * hz));
+            const float rem2 = ec.T - smin * smin;
+            if (rem2 < 0.0f) {
+                lo = 1.0f; hi = -1.0f;                             // the row misses the ellipsoid
+            } else {
+                const float w = sqrtf(rem2 * ec.im00) * 1.001f;
+                const float xc = -(ec.m01 * cy + ec.m02 * cz) * ec.im00;
+                const float dl = (fabsf(ec.m01) * hy + fabsf(ec.m02) * hz) * ec.im00 * 1.001f;
+                const float pad = g.slack + 1e-5f * fabsf(xc);
+                lo = fmaxf(lo, xc - dl - w - pad);
+                hi = fminf(hi, xc + dl + w + pad);
+            }
+        }
+        if (lo <= hi) {
+            int xa = cell_of(pm.x + lo, g.ox, g.inv_c, g.gx), xb = cell_of(pm.x + hi, g.ox, g.inv_c, g.gx);
+            xa = xa < x0 ? x0 : xa;
+            xb = xb > x1 ? x1 : xb;
+            const int rowbase = (rz * g.gy + ry) * g.gx;
+            s = a.cellStart[rowbase + xa];
+            int e = a.cellStart[rowbase + xb + 1];
+            if (IRR) { s = a.irank[s]; e = a.irank[e]; }
+            len = e - s;
+        }
+    }
+}
+
+__device__ __forceinline__ EllClip make_ellclip(const s6& M, float smdMax, int ell) {
+    EllClip ec;
+    ec.im00 = 1.0f / M.e00;
+    ec.m01 = M.e01; ec.m02 = M.e02;
+    ec.k11 = M.e11 - M.e01 * M.e01 * ec.im00;
+    ec.k12 = M.e12 - M.e01 * M.e02 * ec.im00;
+    ec.k22 = M.e22 - M.e02 * M.e02 * ec.im00;
+    ec.kr = sqrtf(ec.k11 + ec.k22) * 1.001f;
+    ec.T = smdMax * 1.01f;
+    const bool ok = ell && smdMax < FLT_MAX && M.e00 > 0.0f && ec.im00 < FLT_MAX && ec.k11 > 0.0f && ec.k22 > 0.0f &&
+                    ec.k11 * ec.k22 > ec.k12 * ec.k12 && ec.kr < FLT_MAX;
+    ec.on = ok ? 1.0f : 0.0f;
+    return ec;
+}
+
 // One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
 // REGULAR ones (stage 1: radius test + Mahalanobis pre-reject); IRR = true scans the list of irregular components
 // (ipos, addressed through irank at the cell boundaries) with the radius test only.  Survivors go to the LDS ring.
@@ -581,46 +643,7 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
         if (cached) {
             if (r < nrows) { const int2 v = a.rows[rbase + r]; s = v.x; len = v.y; }
         } else if (r < nrows) {
-            const int ry = y0 + r % ny, rz = z0 + r / ny;
-            // distance from the parent to the row's y/z slab (widened by the rounding slack)
-            // (the first / last row of the grid also holds every centre clamped in from outside: half-infinite)
-            const bool edge = ry == 0 || ry == g.gy - 1 || rz == 0 || rz == g.gz - 1;
-            const float ylo = ry == 0 ? -FLT_MAX : g.oy + ry * g.c - g.slack, yhi = ry == g.gy - 1 ? FLT_MAX : g.oy + (ry + 1) * g.c + g.slack;
-            const float zlo = rz == 0 ? -FLT_MAX : g.oz + rz * g.c - g.slack, zhi = rz == g.gz - 1 ? FLT_MAX : g.oz + (rz + 1) * g.c + g.slack;
-            const float dy = fmaxf(0.0f, fmaxf(ylo - pm.y, pm.y - yhi));
-            const float dz = fmaxf(0.0f, fmaxf(zlo - pm.z, pm.z - zhi));
-            const float rem = Ra2 - dy * dy - dz * dz;
-            if (rem >= 0.0f) {
-                const float hx = sqrtf(rem) * 1.00001f + g.slack;
-                float lo = -hx, hi = hx;                                   // x interval relative to the parent
-                if (clip && !edge) {
-                    const float cy = 0.5f * (ylo + yhi) - pm.y, cz = 0.5f * (zlo + zhi) - pm.z;
-                    const float hy = 0.5f * (yhi - ylo), hz = 0.5f * (zhi - zlo);
-                    const float sc = sqrtf(fmaxf(0.0f, ec.k11 * cy * cy + 2.0f * ec.k12 * cy * cz + ec.k22 * cz * cz));
-                    const float smin = fmaxf(0.0f, sc * 0.999f - ec.kr * sqrtf(hy * hy + hz * hz));
-                    const float rem2 = ec.T - smin * smin;
-                    if (rem2 < 0.0f) {
-                        lo = 1.0f; hi = -1.0f;                             // the row misses the ellipsoid
-                    } else {
-                        const float w = sqrtf(rem2 * ec.im00) * 1.001f;
-                        const float xc = -(ec.m01 * cy + ec.m02 * cz) * ec.im00;
-                        const float dl = (fabsf(ec.m01) * hy + fabsf(ec.m02) * hz) * ec.im00 * 1.001f;
-                        const float pad = g.slack + 1e-5f * fabsf(xc);
-                        lo = fmaxf(lo, xc - dl - w - pad);
-                        hi = fminf(hi, xc + dl + w + pad);
-                    }
-                }
-                if (lo <= hi) {
-                    int xa = cell_of(pm.x + lo, g.ox, g.inv_c, g.gx), xb = cell_of(pm.x + hi, g.ox, g.inv_c, g.gx);
-                    xa = xa < x0 ? x0 : xa;
-                    xb = xb > x1 ? x1 : xb;
-                    const int rowbase = (rz * g.gy + ry) * g.gx;
-                    s = a.cellStart[rowbase + xa];
-                    int e = a.cellStart[rowbase + xb + 1];
-                    if (IRR) { s = a.irank[s]; e = a.irank[e]; }
-                    len = e - s;
-                }
-            }
+            select_row_span<IRR>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
         }
         // pack the non-empty rows to the front of the wave (the ellipsoid misses many rows of the bounding square)
         const unsigned long long nz_m = __ballot(len > 0);
@@ -770,20 +793,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     }
     const float R = a.Rs[pr.js];
     pr.R2 = R * R;
-    EllClip ec;
-    {
-        const s6& M = pr.pinv;
-        ec.im00 = 1.0f / M.e00;
-        ec.m01 = M.e01; ec.m02 = M.e02;
-        ec.k11 = M.e11 - M.e01 * M.e01 * ec.im00;
-        ec.k12 = M.e12 - M.e01 * M.e02 * ec.im00;
-        ec.k22 = M.e22 - M.e02 * M.e02 * ec.im00;
-        ec.kr = sqrtf(ec.k11 + ec.k22) * 1.001f;
-        ec.T = pr.smdMax * 1.01f;
-        const bool ok = a.ell && pr.smdMax < FLT_MAX && M.e00 > 0.0f && ec.im00 < FLT_MAX && ec.k11 > 0.0f && ec.k22 > 0.0f &&
-                        ec.k11 * ec.k22 > ec.k12 * ec.k12 && ec.kr < FLT_MAX;
-        ec.on = ok ? 1.0f : 0.0f;
-    }
+    EllClip ec = make_ellclip(pr.pinv, pr.smdMax, a.ell);
     // the parent record is wave-uniform: pin it in SGPRs (frees ~17 VGPRs -> one more wave per SIMD)
 #define GSR_UNI(x) x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)))
     GSR_UNI(pr.pm.x); GSR_UNI(pr.pm.y); GSR_UNI(pr.pm.z); GSR_UNI(pr.pcol.x); GSR_UNI(pr.pcol.y); GSR_UNI(pr.pcol.z);
@@ -816,6 +826,52 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
         if (MODE == SEL_SPANS) a.pcap[item] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
         else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[item] = count;
     }
+}
+
+// Capacities only (what k_select<SPANS> computes), with 16 lanes per work item instead of a wavefront: the pass has no
+// candidate work, so its cost is the per-parent set-up, which four items per wavefront now share (1.6 -> 0.7 ms at
+// 5 M).  Same row spans as k_select by construction (select_row_span).
+__global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
+    const int sub = threadIdx.x & 15;
+    const int item = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    if (item >= a.NI) return;
+    const int p = a.vparent ? (int)a.vparent[item] : item;
+    const unsigned vpi = a.vpart ? a.vpart[item] : (1u << 16);
+    const int part = (int)(vpi & 0xffffu), nparts = (int)(vpi >> 16);
+    unsigned long long scanned = 0;
+    if (p >= a.own_lo && p < a.own_hi) {
+        const GridParams g = *a.gp;
+        const int js = (int)a.plist[p];
+        const float4 pa = a.A[js], pb = a.B[js], pc = a.C[js], pd = a.D[js];
+        const f3 pm = {pa.x, pa.y, pa.z};
+        const float smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * a.kldThr + 0.2f) * 1.001f : __builtin_inff();
+        const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
+        const EllClip ec = make_ellclip(inverse6(pcov, pd.w), smdMax, a.ell);
+        const float R = a.Rs[js];
+        const bool pm_finite = fabsf(pm.x) <= FLT_MAX && fabsf(pm.y) <= FLT_MAX && fabsf(pm.z) <= FLT_MAX;
+        if (R * R > 0.0f && pm_finite) {
+            const float Ra = fabsf(R) * 1.00001f + g.slack;
+            const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
+            const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
+            const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
+            const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+            const int nrows = ny * nz;
+            const float Ra2 = Ra * Ra;
+            for (int r = sub; r < nrows; r += 16) {
+                if (nparts > 1 && ((r >> 6) % nparts) != part) continue;      // k_select deals the rows in batches of 64
+                int s = 0, len = 0;
+                select_row_span<false>(a, g, pm, ec, ec.on != 0.0f, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
+                scanned += (unsigned long long)(len > 0 ? len : 0);
+                if (a.n_irr > 0) {
+                    s = 0; len = 0;
+                    select_row_span<true>(a, g, pm, ec, false, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
+                    scanned += (unsigned long long)(len > 0 ? len : 0);
+                }
+            }
+        }
+    }
+    for (int o = 8; o > 0; o >>= 1) scanned += __shfl_xor(scanned, o);
+    if (sub == 0) a.pcap[item] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
 }
 
 // Longest-processing-time-first: work per parent is heavy-tailed (a few parents scan 10^5 candidates), so the
@@ -1801,7 +1857,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             }
         }
         sa.rows_write = 1;
-        GSR_LAUNCH_SELECT(SEL_SPANS, P);                                  // candidates scanned per parent
+        if (sa.rows != nullptr) { GSR_LAUNCH_SELECT(SEL_SPANS, P); }      // the wave-per-parent form also fills the row cache
+        else hipLaunchKernelGGL(k_spans, dim3(ceil_div(P, 16)), dim3(256), 0, st, sa);      // candidates scanned per parent
         sa.rows_write = 0;
         // work items: split the heavy parents
         int V = P;
@@ -1828,7 +1885,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                                c->vpart.as<unsigned>());
             sa.NI = V; sa.vparent = c->vparent.as<unsigned>(); sa.vpart = c->vpart.as<unsigned>();
             sa.pcap = c->vcap.as<unsigned>();
-            GSR_LAUNCH_SELECT(SEL_SPANS, V);                              // exact capacity of every item
+            if (sa.rows != nullptr) { GSR_LAUNCH_SELECT(SEL_SPANS, V); }  // exact capacity of every item
+            else hipLaunchKernelGGL(k_spans, dim3(ceil_div(V, 16)), dim3(256), 0, st, sa);
             icap = c->vcap.as<unsigned>();
         }
         GSR_TRY(widen_scan(icap, c->coff.as<int64_t>(), V));

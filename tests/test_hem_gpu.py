@@ -374,3 +374,34 @@ def test_ellipsoid_row_clipping_changes_nothing(monkeypatch):
                 out.append((st["parents"], st["pairs"], st["orphans"], st["dropped"], m.get_level()["xyz"].shape[0]))
         res[ell] = out
     assert res["1"] == res["0"], (res["1"], res["0"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_random_parameter_sweep_vs_oracle(oracle, seed):
+    """Random (rho, delta, kappa, tau, SH degree, density, size) draws: every discrete outcome of level 1 equals the
+    oracle's and the merged components agree; level 2 mostly (summation-order noise can flip a borderline pair)."""
+    from gaussiansplattingregistration_amd import hem, synth
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(3000, 25000))
+    deg = int(rng.integers(0, 4))
+    rho = float(rng.choice([1.5, 2.0, 3.0, 5.0, 10.0]))
+    delta = float(rng.uniform(1.0, 4.0))
+    kappa = float(rng.uniform(0.5, 4.0))
+    tau = float(rng.uniform(0.3, 3.0))
+    h = float(rng.uniform(0.6, 2.5))
+    c = synth.make_cloud(n, seed=seed, h=h, sh_degree=deg)
+    want, wst = oracle.hem(c, 2, rho=rho, delta=delta, kappa=kappa, tau=tau)
+    with hem.HemMixture(hem_reduction=rho, distance_delta=delta, color_delta=kappa, decay_rate=tau) as m:
+        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+        for k in range(2):
+            m.run_level()
+            st = m.stats()
+            got = m.get_level()
+            tag = ("sweep", seed, k, n, deg, rho, round(delta, 2), round(kappa, 2), round(tau, 2))
+            if k == 0:
+                assert (st["parents"], st["pairs"], st["orphans"], st["dropped"]) == (
+                    wst[0]["parents"], wst[0]["pairs"], wst[0]["orphans"], wst[0]["dropped"]), tag
+                _check_level(got, want[k], tag)
+            else:
+                _check_level_mostly(got, want[k], tag)
