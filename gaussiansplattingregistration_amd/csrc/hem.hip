@@ -388,6 +388,14 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
 __global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, int Fp, const unsigned* __restrict__ order,
                                                    const float* __restrict__ sh, float* __restrict__ shs) {
     const int64_t total = n * Fp;
+    if (total < ((int64_t)1 << 31)) {              // 32-bit index arithmetic: a 64-bit division per element costs ~80 instructions
+        const unsigned tot = (unsigned)total, step = gridDim.x * blockDim.x, uF = (unsigned)Fp;
+        for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += step) {
+            const unsigned j = t / uF, f = t - j * uF;
+            shs[t] = f < (unsigned)F ? sh[(int64_t)order[j] * F + f] : 0.0f;
+        }
+        return;
+    }
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         int64_t j = t / Fp;
         int f = (int)(t - j * Fp);
@@ -1218,6 +1226,15 @@ __global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigne
 __global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int Fp, const int64_t* __restrict__ oslot_sorted,
                                                     const float* __restrict__ shs, float* __restrict__ o_sh) {
     const int64_t total = n * F;
+    if (total < ((int64_t)1 << 31)) {
+        const unsigned tot = (unsigned)total, step = gridDim.x * blockDim.x, uF = (unsigned)F;
+        for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += step) {
+            const unsigned j = t / uF, f = t - j * uF;
+            const int64_t slot = oslot_sorted[j];
+            if (slot >= 0) o_sh[slot * F + f] = shs[(int64_t)j * Fp + f];
+        }
+        return;
+    }
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t j = t / F;
         const int64_t slot = oslot_sorted[j];
