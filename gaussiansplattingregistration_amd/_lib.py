@@ -50,6 +50,9 @@ SIGNATURES = {
     "gsr_icp_set_target": (_i32, [_vp, _vp, _vp, _i64, _f64, _i32]),
     "gsr_icp_set_source": (_i32, [_vp, _vp, _i64, _i32]),
     "gsr_icp_set_target_cov": (_i32, [_vp, _vp, _i32]),
+    "gsr_voxel_down_sample": (_i32, [_i32, _vp, _vp, _vp, _vp, _i64, _f64, _i32, C.POINTER(_vp), C.POINTER(_i64)]),
+    "gsr_voxel_fetch": (_i32, [_vp, _vp, _vp, _vp, _i32]),
+    "gsr_voxel_free": (_i32, [_vp]),
     "gsr_icp_set_source_cov": (_i32, [_vp, _vp, _i32]),
     "gsr_icp_set_allreduce": (_i32, [_vp, ALLREDUCE_FN, _vp, _i64]),
     "gsr_icp_accumulate": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp]),

@@ -1,7 +1,7 @@
 """Headless ``RegistrationController`` (reference ``src/controllers/registration_controller.py:24-28,93-120,145-163``)."""
 from __future__ import annotations
 
-from ..workers.registrators import LocalRegistrator, MultiScaleRegistratorMixture
+from ..workers.registrators import LocalRegistrator, MultiScaleRegistratorMixture, MultiScaleRegistratorVoxel
 
 
 class RegistrationController:
@@ -22,13 +22,19 @@ class RegistrationController:
     def execute_multiscale_registration(self, use_corresponding, sparse_first, sparse_second, registration_type,
                                         relative_fitness, relative_rmse, voxel_values, iter_values, rejection_type, k_value,
                                         use_mixture=True):
-        if not use_mixture:
-            raise NotImplementedError("voxel-downsample multiscale path is SURVEY.md 8f N2; use_mixture=True only")
         repo = self.data_repository
-        worker = MultiScaleRegistratorMixture(repo.pc_open3d_list_first, repo.pc_open3d_list_second,
-                                              self.ui_repository.transformation_matrix, use_corresponding, sparse_first,
-                                              sparse_second, registration_type, relative_fitness, relative_rmse,
-                                              voxel_values, iter_values, rejection_type, k_value)
+        if use_mixture:
+            worker = MultiScaleRegistratorMixture(repo.pc_open3d_list_first, repo.pc_open3d_list_second,
+                                                  self.ui_repository.transformation_matrix, use_corresponding, sparse_first,
+                                                  sparse_second, registration_type, relative_fitness, relative_rmse,
+                                                  voxel_values, iter_values, rejection_type, k_value)
+        else:
+            # the original clouds (the reference indexes the second list with [1], registration_controller.py:108 --
+            # an IndexError without mixtures and the wrong cloud with them; the original cloud [0] is what is meant)
+            worker = MultiScaleRegistratorVoxel(repo.pc_open3d_list_first[0], repo.pc_open3d_list_second[0],
+                                                self.ui_repository.transformation_matrix, use_corresponding, sparse_first,
+                                                sparse_second, registration_type, relative_fitness, relative_rmse,
+                                                voxel_values, iter_values, rejection_type, k_value)
         result = worker.run()
         self.errors = worker.errors
         if result is not None:

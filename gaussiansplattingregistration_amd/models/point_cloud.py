@@ -67,6 +67,16 @@ class PointCloud:
         self.normals = icp.normals_from_cov(self.cov6, device=self.device_index)
         return self
 
+    def voxel_down_sample(self, voxel_size):
+        """``o3d.geometry.PointCloud.voxel_down_sample``: one point per occupied voxel = the mean of the voxel's points,
+        covariances and colours (float64 means, kept here in the record's float32 storage; voxels in ascending index
+        order).  Runs on the GPU (``csrc/voxel.hip``)."""
+        from .. import voxel
+        xyz, cov6, col = voxel.voxel_down_sample(self.xyz32, voxel_size, cov6=self.cov6, color=self.colors, device=self.device_index,
+                                                 as_torch=_is_tensor(self.xyz32) and self.xyz32.is_cuda)
+        f32 = (lambda a: None if a is None else (a.float() if _is_tensor(a) else a.astype(np.float32)))
+        return PointCloud(xyz32=f32(xyz), colors=f32(col), cov6=f32(cov6))
+
     def transform(self, T):
         T = np.asarray(T, dtype=np.float64)
         p = self.points @ T[:3, :3].T + T[:3, 3]

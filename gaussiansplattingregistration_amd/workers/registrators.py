@@ -112,3 +112,53 @@ class MultiScaleRegistratorMixture:
 
     def cancel(self):
         self.signal_cancel = True
+
+
+class MultiScaleRegistratorVoxel(MultiScaleRegistratorMixture):
+    """Voxel multiscale registration (reference ``qt_multiscale_registrator.py:102-160``): per scale both clouds are
+    voxel-down-sampled at ``voxel_values[scale]``, normals come from the averaged covariances (Open3D's
+    ``estimate_normals`` uses a cloud's covariances when it has them, so the hybrid search parameter of the reference
+    call is inert), and ICP runs with ``max_correspondence = voxel_values[scale]``."""
+
+    def __init__(self, pc1, pc2, init_trans, use_corresponding, sparse_first, sparse_second, registration_type,
+                 relative_fitness, relative_rmse, voxel_values, iter_values, rejection_type, k_value, progress=None):
+        super().__init__([pc1], [pc2], init_trans, use_corresponding, sparse_first, sparse_second, registration_type,
+                         relative_fitness, relative_rmse, voxel_values, iter_values, rejection_type, k_value, progress)
+        self.pc1, self.pc2 = pc1, pc2
+
+    def _check_valid_data(self):            # :116-122
+        if len(self.iter_values) != len(self.voxel_values):
+            self.errors.append("The number of iteration and voxel values provided do not match.")
+            return False
+        return True
+
+    def _register_main_point_clouds(self, initial_transformation):   # :124-150
+        current_trans = initial_transformation
+        results = None
+        for scale in range(len(self.iter_values)):
+            if self.signal_cancel:
+                return None
+            max_iter, radius = self.iter_values[scale], self.voxel_values[scale]
+            source_down = target_down = None
+            try:
+                source_down = self.pc1.voxel_down_sample(radius)
+                target_down = self.pc2.voxel_down_sample(radius)
+                source_down.estimate_normals()
+                target_down.estimate_normals()
+                results = do_icp_registration(source_down, target_down, current_trans, self.registration_type, radius,
+                                              self.relative_fitness, self.relative_rmse, max_iter, self.rejection_type,
+                                              self.k_value)
+            except RuntimeError as e:
+                self.errors.append(f"{e}\nSource: \"{source_down}\"\nTarget: \"{target_down}\"")
+                return None
+            self.level_results.append(results)
+            if self._progress:
+                self._progress(int((scale + 1) / len(self.iter_values) * 100))
+            current_trans = results.transformation
+        return results
+
+    def run(self):
+        out = super().run()
+        if out is not None:
+            out.registration_data.used_gaussian_mixtures = False
+        return out

@@ -197,6 +197,22 @@ int32_t gsr_debug_logf(const float* x, int64_t n, float* out, int32_t device);
 int32_t gsr_debug_kld(const float* child_mean, const float* child_cov6, const float* parent_mean,
                       const float* parent_cov6, int64_t n, float* out, int32_t device);
 
+/* ------------------------------------------------------------------------------ voxel down-sampling */
+
+/* PointCloud::VoxelDownSample (Open3D 0.16.0 PointCloud.cpp), the first step of the reference's voxel multiscale
+ * registration (src/gui/workers/registration/qt_multiscale_registrator.py:127-128): voxel_min_bound = min_bound -
+ * voxel_size / 2, index = floor((p - voxel_min_bound) / voxel_size) in float64, every voxel averages its points,
+ * covariances and colours (float64 sums in input order / count).  Voxels come out in ascending (ix, iy, iz) order
+ * (Open3D: unordered_map order).  xyz[n*3], cov6[n*6] or NULL, color[n*3] or NULL, float32.  The result object
+ * holds the float64 means on the device until gsr_voxel_free. */
+typedef struct gsr_voxel_result gsr_voxel_result;
+int32_t gsr_voxel_down_sample(int32_t device, void* stream, const float* xyz, const float* cov6, const float* color,
+                              int64_t n, double voxel_size, int32_t on_device, gsr_voxel_result** out,
+                              int64_t* n_voxels);
+/* xyz[V*3], cov6[V*6] or NULL, color[V*3] or NULL, float64, host or device memory. */
+int32_t gsr_voxel_fetch(gsr_voxel_result* r, double* xyz, double* cov6, double* color, int32_t on_device);
+int32_t gsr_voxel_free(gsr_voxel_result* r);
+
 #ifdef __cplusplus
 }
 #endif

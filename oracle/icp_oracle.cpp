@@ -28,6 +28,7 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <map>
 #include <vector>
 #ifdef _OPENMP
 #include <omp.h>
@@ -499,6 +500,46 @@ int32_t gsr_oracle_gicp(const double* src_, const double* src_cov, int64_t ns, c
     *out_fitness = res.fitness;
     *out_rmse = res.rmse;
     return it;
+}
+
+// PointCloud::VoxelDownSample (Open3D 0.16.0 cpp/open3d/geometry/PointCloud.cpp), the voxel multiscale path of the
+// reference (qt_multiscale_registrator.py:127-128): voxel_min_bound = min_bound - voxel_size / 2,
+// index = floor((p - voxel_min_bound) / voxel_size) per axis (float64), every voxel averages its points, colours and
+// covariances (sum in insertion order / count).  Open3D emits the voxels in unordered_map order; here they are
+// emitted in ascending (ix, iy, iz) order -- the defined order of the build's own output.
+// xyz n x 3, color n x 3 or NULL, cov n x 9 or NULL (all float64).  Returns the number of voxels; call with
+// out_* = NULL to size the outputs (out_xyz V x 3, out_color V x 3, out_cov V x 9).
+int64_t gsr_oracle_voxel_down_sample(const double* xyz, const double* color, const double* cov, int64_t n, double voxel_size,
+                                     double* out_xyz, double* out_color, double* out_cov) {
+    if (!(voxel_size > 0.0)) return -1;
+    if (n <= 0) return 0;
+    double mn[3] = {1e300, 1e300, 1e300};
+    for (int64_t i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) mn[a] = std::min(mn[a], xyz[3 * i + a]);
+    for (int a = 0; a < 3; ++a) mn[a] -= voxel_size * 0.5;
+    struct Key { int v[3]; bool operator<(const Key& o) const { return std::lexicographical_compare(v, v + 3, o.v, o.v + 3); } };
+    struct Acc { double p[3] = {0, 0, 0}, c[3] = {0, 0, 0}, C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}; int64_t num = 0; };
+    std::map<Key, Acc> vox;
+    for (int64_t i = 0; i < n; ++i) {
+        Key k;
+        for (int a = 0; a < 3; ++a) k.v[a] = (int)std::floor((xyz[3 * i + a] - mn[a]) / voxel_size);
+        Acc& acc = vox[k];
+        for (int a = 0; a < 3; ++a) acc.p[a] += xyz[3 * i + a];
+        if (color) for (int a = 0; a < 3; ++a) acc.c[a] += color[3 * i + a];
+        if (cov) for (int a = 0; a < 9; ++a) acc.C[a] += cov[9 * i + a];
+        acc.num++;
+    }
+    if (out_xyz) {
+        int64_t v = 0;
+        for (const auto& kv : vox) {
+            const Acc& acc = kv.second;
+            const double d = (double)acc.num;
+            for (int a = 0; a < 3; ++a) out_xyz[3 * v + a] = acc.p[a] / d;
+            if (color && out_color) for (int a = 0; a < 3; ++a) out_color[3 * v + a] = acc.c[a] / d;
+            if (cov && out_cov) for (int a = 0; a < 9; ++a) out_cov[9 * v + a] = acc.C[a] / d;
+            ++v;
+        }
+    }
+    return (int64_t)vox.size();
 }
 
 int gsr_oracle_icp_correspond(const double* src_, int64_t ns, const double* tgt_, int64_t nt,

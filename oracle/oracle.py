@@ -237,6 +237,28 @@ def gicp(src, src_cov, tgt, tgt_cov, init=None, loss=0, k=0.0, max_corr=1.0, rel
     return {"transformation": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iterations": int(it)}
 
 
+def voxel_down_sample(xyz, voxel_size, color=None, cov=None):
+    """Open3D ``voxel_down_sample`` on float64 arrays; voxels in ascending (ix, iy, iz) order.  -> (xyz, color, cov)."""
+    x = _c(xyz, np.float64).reshape(-1, 3)
+    col = None if color is None else _c(color, np.float64).reshape(-1, 3)
+    cv = None if cov is None else _c(cov, np.float64).reshape(-1, 9)
+    fn = lib().gsr_oracle_voxel_down_sample
+    fn.restype = C.c_int64
+    P = C.c_void_p
+    fn.argtypes = [P, P, P, C.c_int64, C.c_double, P, P, P]
+    pc = None if col is None else col.ctypes.data
+    pv = None if cv is None else cv.ctypes.data
+    v = fn(x.ctypes.data, pc, pv, x.shape[0], float(voxel_size), None, None, None)
+    if v < 0:
+        raise RuntimeError("[VoxelDownSample] voxel_size <= 0.")
+    ox = np.empty((v, 3), np.float64)
+    oc = None if col is None else np.empty((v, 3), np.float64)
+    ov = None if cv is None else np.empty((v, 9), np.float64)
+    fn(x.ctypes.data, pc, pv, x.shape[0], float(voxel_size), ox.ctypes.data, None if oc is None else oc.ctypes.data,
+       None if ov is None else ov.ctypes.data)
+    return ox, oc, None if ov is None else ov.reshape(-1, 3, 3)
+
+
 def icp_correspond(src, tgt, T, max_corr, threads=0):
     src = _c(src, np.float64).reshape(-1, 3)
     tgt = _c(tgt, np.float64).reshape(-1, 3)

@@ -176,3 +176,23 @@ def test_icp_oracle_errors(oracle):
         oracle.icp(s, s, None, np.eye(4), kind=0, max_corr=0.0)
     with pytest.raises(RuntimeError):
         oracle.icp(s, s, None, np.eye(4), kind=1, max_corr=1.0)
+
+
+def test_voxel_down_sample_oracle_vs_numpy(oracle):
+    """Open3D VoxelDownSample restatement against an independent NumPy grouping (means per occupied voxel)."""
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-2, 3, (30000, 3)).astype(np.float32).astype(np.float64)
+    col = rng.uniform(0, 1, (30000, 3))
+    cov = rng.normal(size=(30000, 3, 3))
+    vs = 0.23
+    ox, oc, ov = oracle.voxel_down_sample(x, vs, col, cov)
+    idx = np.floor((x - (x.min(0) - vs * 0.5)) / vs).astype(np.int64)
+    key = (idx[:, 0] << 42) | (idx[:, 1] << 21) | idx[:, 2]
+    u, inv = np.unique(key, return_inverse=True)                 # ascending key = ascending (ix, iy, iz)
+    cnt = np.bincount(inv).astype(np.float64)
+    for got, src in ((ox, x), (oc, col), (ov.reshape(-1, 9), cov.reshape(-1, 9))):
+        acc = np.zeros((len(u), src.shape[1]))
+        np.add.at(acc, inv, src)
+        assert got.shape == acc.shape and np.allclose(got, acc / cnt[:, None], rtol=1e-13, atol=1e-15)
+    with pytest.raises(RuntimeError, match="voxel_size"):
+        oracle.voxel_down_sample(x, 0.0)
