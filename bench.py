@@ -165,12 +165,15 @@ def main():
 
     import torch
     import __graft_entry__ as g
-    g.build_hip()
-    from gaussiansplattingregistration_amd import hem, icp as icp_mod, parallel, synth
+    from gaussiansplattingregistration_amd import parallel
+    rank, world, local_rank = parallel.init_distributed()
+    if rank == 0:
+        g.build_hip()                       # one rank (re)builds a stale library, the others wait for it
+    if world > 1:
+        torch.distributed.barrier()
+    from gaussiansplattingregistration_amd import hem, icp as icp_mod, synth
     from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
     from gaussiansplattingregistration_amd.utils import local_registration_util as lru
-
-    rank, world, local_rank = parallel.init_distributed()
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
