@@ -54,6 +54,10 @@ SIGNATURES = {
     "gsr_voxel_fetch": (_i32, [_vp, _vp, _vp, _vp, _i32]),
     "gsr_voxel_free": (_i32, [_vp]),
     "gsr_icp_set_source_cov": (_i32, [_vp, _vp, _i32]),
+    "gsr_icp_set_target_color": (_i32, [_vp, _vp, _i32]),
+    "gsr_icp_set_source_color": (_i32, [_vp, _vp, _i32]),
+    "gsr_icp_set_lambda_geometric": (_i32, [_vp, _f64]),
+    "gsr_icp_get_color_gradient": (_i32, [_vp, _vp]),
     "gsr_icp_set_allreduce": (_i32, [_vp, ALLREDUCE_FN, _vp, _i64]),
     "gsr_icp_accumulate": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp]),
     "gsr_icp_register": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _i32, _vp, C.POINTER(_f64), C.POINTER(_f64),

@@ -26,6 +26,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <vector>
 
 #include <rocprim/rocprim.hpp>
 
@@ -141,6 +142,14 @@ __global__ __launch_bounds__(256) void k_icp_gather_cov(int64_t n, const unsigne
 }
 
 struct Xform { double m[12]; };   // rows 0..2 of the 4x4
+
+// Colored ICP operands (KIND 3): target intensity / colour gradient (cell-sorted), source intensity (source order)
+struct ColorArgs {
+    const double* t_int;
+    const double* t_grad;
+    const double* s_int;
+    double sqrt_lg, sqrt_lp;       // sqrt(lambda_geometric), sqrt(1 - lambda_geometric)
+};
 
 // Exact nearest target neighbour of p (float64) by an expanding ring search over the uniform grid.
 // Ring r = the cells at Chebyshev distance r from p's (clamped) cell.  Every point in a cell beyond
@@ -411,6 +420,153 @@ __device__ __forceinline__ void icp_gicp_rows(double (&acc)[NACC], const double*
     }
 }
 
+// Colored ICP (Open3D ColoredICP.cpp, ComputeTransformation): the geometric and the photometric row of one pair.
+template <int NACC>
+__device__ __forceinline__ void icp_colored_rows(double (&acc)[NACC], const ColorArgs& ca, double px, double py, double pz, double qx, double qy,
+                                                 double qz, double nx, double ny, double nz, int64_t i, int64_t j, int loss, double kparam) {
+    const double dn = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
+    double J[2][6], r[2];
+    J[0][0] = ca.sqrt_lg * (py * nz - pz * ny); J[0][1] = ca.sqrt_lg * (pz * nx - px * nz); J[0][2] = ca.sqrt_lg * (px * ny - py * nx);
+    J[0][3] = ca.sqrt_lg * nx; J[0][4] = ca.sqrt_lg * ny; J[0][5] = ca.sqrt_lg * nz;
+    r[0] = ca.sqrt_lg * dn;
+    const double pjx = px - dn * nx - qx, pjy = py - dn * ny - qy, pjz = pz - dn * nz - qz;      // vs_proj - vt
+    const double d0 = ca.t_grad[3 * j], d1 = ca.t_grad[3 * j + 1], d2 = ca.t_grad[3 * j + 2];
+    const double is0 = d0 * pjx + d1 * pjy + d2 * pjz + ca.t_int[j];
+    const double dd = d0 * nx + d1 * ny + d2 * nz;
+    const double m0 = -(d0 - dd * nx), m1 = -(d1 - dd * ny), m2 = -(d2 - dd * nz);               // -dit^T (I - n n^T)
+    J[1][0] = ca.sqrt_lp * (py * m2 - pz * m1); J[1][1] = ca.sqrt_lp * (pz * m0 - px * m2); J[1][2] = ca.sqrt_lp * (px * m1 - py * m0);
+    J[1][3] = ca.sqrt_lp * m0; J[1][4] = ca.sqrt_lp * m1; J[1][5] = ca.sqrt_lp * m2;
+    r[1] = ca.sqrt_lp * (ca.s_int[i] - is0);
+#pragma unroll
+    for (int row = 0; row < 2; ++row) {
+        const double w = icp_weight(loss, kparam, r[row]);
+        int t = 2;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) acc[t++] += J[row][a] * w * J[row][b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[23 + a] += J[row][a] * w * r[row];
+        acc[29] += r[row] * r[row];
+    }
+}
+
+// Colour gradient of every target point (Open3D InitializePointCloudForColoredICP): its ICP_KNN nearest neighbours
+// (itself first) within `radius`, ordered by (distance, input index); with >= 4 of them a 3x3 least-squares fit of the
+// intensity differences over the tangent-plane projections, plus the orthogonality row (nn-1) n.  One thread per
+// point; the k-best list lives in per-thread scratch.  Same expanding-ring search geometry as icp_nearest.
+#define ICP_KNN 30
+__global__ __launch_bounds__(256) void k_icp_color_gradient(int64_t nt, IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
+                                                            const double* __restrict__ Tn, const double* __restrict__ t_int, double radius,
+                                                            double* __restrict__ t_grad) {
+    for (int64_t jq = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; jq < nt; jq += (int64_t)gridDim.x * blockDim.x) {
+        const float4 qv = Tq[jq];
+        const double px = (double)qv.x, py = (double)qv.y, pz = (double)qv.z;
+        t_grad[3 * jq] = 0.0; t_grad[3 * jq + 1] = 0.0; t_grad[3 * jq + 2] = 0.0;
+        if (!(px == px) || !(py == py) || !(pz == pz)) continue;
+        double kd[ICP_KNN];
+        int kj[ICP_KNN];
+        unsigned ki[ICP_KNN];
+        int cnt = 0;
+        const double r2 = radius * radius;
+        const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
+        const double eps = 1e-13 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.ox) + fabs(g.oy) + fabs(g.oz) + g.c * (double)(g.gx + g.gy + g.gz));
+        const int rmax = (int)ceil(radius / g.c) + 1;
+        for (int r = 0; r <= rmax; ++r) {
+            for (int dz = -r; dz <= r; ++dz) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.gz) continue;
+                const int adz = dz < 0 ? -dz : dz;
+                for (int dy = -r; dy <= r; ++dy) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.gy) continue;
+                    const int ady = dy < 0 ? -dy : dy;
+                    const int rowbase = (z * g.gy + y) * g.gx;
+                    int spans[2][2];
+                    int nsp = 0;
+                    if (adz == r || ady == r) {
+                        const int xa = cx - r > 0 ? cx - r : 0, xb = cx + r < g.gx - 1 ? cx + r : g.gx - 1;
+                        if (xa <= xb) { spans[0][0] = rowbase + xa; spans[0][1] = rowbase + xb; nsp = 1; }
+                    } else {
+                        if (cx - r >= 0) { spans[nsp][0] = spans[nsp][1] = rowbase + cx - r; ++nsp; }
+                        if (cx + r < g.gx) { spans[nsp][0] = spans[nsp][1] = rowbase + cx + r; ++nsp; }
+                    }
+                    for (int sidx = 0; sidx < nsp; ++sidx) {
+                        const int s0 = cellStart[spans[sidx][0]], e0 = cellStart[spans[sidx][1] + 1];
+                        for (int j = s0; j < e0; ++j) {
+                            const float4 q = Tq[j];
+                            const double dx = px - (double)q.x, dy2 = py - (double)q.y, dz2 = pz - (double)q.z;
+                            const double d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
+                            const unsigned qi = __float_as_uint(q.w);
+                            if (!(d2 < r2)) continue;                        // the hybrid search keeps d^2 < radius^2
+                            if (cnt == ICP_KNN && !(d2 < kd[cnt - 1] || (d2 == kd[cnt - 1] && qi < ki[cnt - 1]))) continue;
+                            int pos = cnt < ICP_KNN ? cnt : ICP_KNN - 1;     // insertion into the list sorted by (d2, index)
+                            while (pos > 0 && (d2 < kd[pos - 1] || (d2 == kd[pos - 1] && qi < ki[pos - 1]))) {
+                                kd[pos] = kd[pos - 1]; kj[pos] = kj[pos - 1]; ki[pos] = ki[pos - 1];
+                                --pos;
+                            }
+                            kd[pos] = d2; kj[pos] = j; ki[pos] = qi;
+                            if (cnt < ICP_KNN) ++cnt;
+                        }
+                    }
+                }
+            }
+            // an unseen point lies at least `reach` away (see icp_nearest_from); done when the list is full and its
+            // worst entry is strictly closer, or when the radius is covered
+            double reach = 1.0 / 0.0;
+            if (cx - r > 0) reach = fmin(reach, px - (g.ox + (double)(cx - r) * g.c));
+            if (cx + r < g.gx - 1) reach = fmin(reach, (g.ox + (double)(cx + r + 1) * g.c) - px);
+            if (cy - r > 0) reach = fmin(reach, py - (g.oy + (double)(cy - r) * g.c));
+            if (cy + r < g.gy - 1) reach = fmin(reach, (g.oy + (double)(cy + r + 1) * g.c) - py);
+            if (cz - r > 0) reach = fmin(reach, pz - (g.oz + (double)(cz - r) * g.c));
+            if (cz + r < g.gz - 1) reach = fmin(reach, (g.oz + (double)(cz + r + 1) * g.c) - pz);
+            reach = reach * 0.999999999 - eps;
+            if (reach > 0.0 && ((cnt == ICP_KNN && kd[cnt - 1] < reach * reach) || r2 < reach * reach)) break;
+        }
+        if (cnt < 4) continue;
+        const double nx = Tn[3 * jq], ny = Tn[3 * jq + 1], nz = Tn[3 * jq + 2];
+        const double it = t_int[jq];
+        double A[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}}, b[3] = {0, 0, 0};
+        for (int i = 1; i < cnt; ++i) {
+            const float4 q = Tq[kj[i]];
+            const double vx = (double)q.x - px, vy = (double)q.y - py, vz = (double)q.z - pz;
+            const double dn = vx * nx + vy * ny + vz * nz;
+            const double row[3] = {(double)q.x - dn * nx - px, (double)q.y - dn * ny - py, (double)q.z - dn * nz - pz};
+            const double rhs = t_int[kj[i]] - it;
+            for (int p = 0; p < 3; ++p) { for (int c2 = 0; c2 < 3; ++c2) A[p][c2] += row[p] * row[c2]; b[p] += row[p] * rhs; }
+        }
+        const double f = (double)(cnt - 1);
+        const double row[3] = {f * nx, f * ny, f * nz};
+        for (int p = 0; p < 3; ++p) for (int c2 = 0; c2 < 3; ++c2) A[p][c2] += row[p] * row[c2];
+        // 3x3 solve: Gaussian elimination with partial pivoting
+        double M[3][4] = {{A[0][0], A[0][1], A[0][2], b[0]}, {A[1][0], A[1][1], A[1][2], b[1]}, {A[2][0], A[2][1], A[2][2], b[2]}};
+        for (int c2 = 0; c2 < 3; ++c2) {
+            int piv = c2;
+            for (int rr = c2 + 1; rr < 3; ++rr) if (fabs(M[rr][c2]) > fabs(M[piv][c2])) piv = rr;
+            for (int k2 = 0; k2 < 4; ++k2) { const double tmp = M[c2][k2]; M[c2][k2] = M[piv][k2]; M[piv][k2] = tmp; }
+            for (int rr = c2 + 1; rr < 3; ++rr) {
+                const double fct = M[rr][c2] / M[c2][c2];
+                for (int k2 = c2; k2 < 4; ++k2) M[rr][k2] -= fct * M[c2][k2];
+            }
+        }
+        double x[3];
+        for (int i = 2; i >= 0; --i) {
+            double v = M[i][3];
+            for (int k2 = i + 1; k2 < 3; ++k2) v -= M[i][k2] * x[k2];
+            x[i] = v / M[i][i];
+        }
+        t_grad[3 * jq] = x[0]; t_grad[3 * jq + 1] = x[1]; t_grad[3 * jq + 2] = x[2];
+    }
+}
+// intensity = mean of the three colour channels (float64), gathered into `order` (NULL = identity)
+__global__ __launch_bounds__(256) void k_icp_intensity(int64_t n, const unsigned* __restrict__ order, const double* __restrict__ rgb,
+                                                       double* __restrict__ out) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = order ? (int64_t)order[j] : j;
+        out[j] = (rgb[3 * i] + rgb[3 * i + 1] + rgb[3 * i + 2]) / 3.0;
+    }
+}
+
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ partials) {
     __shared__ double s_red[4][NACC];
@@ -433,7 +589,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float* __restrict__ src, Xform T, IcpGrid g,
                                                         const int* __restrict__ cellStart, const int* __restrict__ nn_j,
                                                         const float4* __restrict__ Tq, const double* __restrict__ Tn,
-                                                        const double* __restrict__ Sc, double max_corr2,
+                                                        const double* __restrict__ Sc, ColorArgs ca, double max_corr2,
                                                         int loss, double kparam, double* __restrict__ partials) {
     constexpr int NACC = KIND == 0 ? 17 : 30;
     double acc[NACC];
@@ -469,6 +625,8 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float*
             acc[14] += az * bx; acc[15] += az * by; acc[16] += az * bz;
         } else if (KIND == 2) {
             icp_gicp_rows<NACC>(acc, T.m, px, py, pz, qx, qy, qz, Sc + 6 * i, Tn + 6 * (int64_t)j, loss, kparam);
+        } else if (KIND == 3) {
+            icp_colored_rows<NACC>(acc, ca, px, py, pz, qx, qy, qz, Tn[3 * (int64_t)j], Tn[3 * (int64_t)j + 1], Tn[3 * (int64_t)j + 2], i, j, loss, kparam);
         } else {
             const double nx = Tn[3 * (int64_t)j], ny = Tn[3 * (int64_t)j + 1], nz = Tn[3 * (int64_t)j + 2];
             const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
@@ -764,7 +922,7 @@ template <int KIND>
 __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, const IcpState* __restrict__ st,
                                                             IcpGrid g, const int* __restrict__ cellStart, const int* __restrict__ nn_j,
                                                             const float4* __restrict__ Tq, const double* __restrict__ Tn,
-                                                            const double* __restrict__ Sc, double max_corr2,
+                                                            const double* __restrict__ Sc, ColorArgs ca, double max_corr2,
                                                             int loss, double kparam, double* __restrict__ partials) {
     if (st->done) return;
     constexpr int NACC = KIND == 0 ? 17 : 30;
@@ -804,6 +962,8 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
             acc[14] += az * bx; acc[15] += az * by; acc[16] += az * bz;
         } else if (KIND == 2) {
             icp_gicp_rows<NACC>(acc, T, px, py, pz, qx, qy, qz, Sc + 6 * i, Tn + 6 * (int64_t)j, loss, kparam);
+        } else if (KIND == 3) {
+            icp_colored_rows<NACC>(acc, ca, px, py, pz, qx, qy, qz, Tn[3 * (int64_t)j], Tn[3 * (int64_t)j + 1], Tn[3 * (int64_t)j + 2], i, j, loss, kparam);
         } else {
             const double nx = Tn[3 * (int64_t)j], ny = Tn[3 * (int64_t)j + 1], nz = Tn[3 * (int64_t)j + 2];
             const double r = (px - qx) * nx + (py - qy) * ny + (pz - qz) * nz;
@@ -861,8 +1021,9 @@ struct gsr_icp_ctx {
     bool have_target = false, have_normals = false, have_source = false;
     int64_t nt = 0, ns = 0, ns_global = 0;
     double max_corr = 0;
-    DevBuf src_raw, src_order, state, nn_j, Tc, Sc, stage_cov;
-    bool have_tcov = false, have_scov = false;
+    DevBuf src_raw, src_order, state, nn_j, Tc, Sc, stage_cov, Ti, Tg, Si;
+    bool have_tcov = false, have_scov = false, have_tcol = false, have_scol = false;
+    double lambda_geometric = 0.968;            // Open3D TransformationEstimationForColoredICP default
     bool src_sorted = false;
     bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
     // Search / accumulate split (GSR_ICP_NN_KERNEL): 0 = one fused kernel (120 VGPRs with the 30 float64 accumulators:
@@ -901,10 +1062,11 @@ inline int nn_grid(int64_t ns) {
 
 int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, double k, double* acc, bool timed) {
     if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
-    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE && kind != GSR_ICP_GENERALIZED)
-        return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
+    if (kind < GSR_ICP_POINT_TO_POINT || kind > GSR_ICP_COLORED) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
     if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
         return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
+    if (kind == GSR_ICP_COLORED && (!c->have_normals || !c->have_tcol || !c->have_scol))
+        return fail(GSR_E_PRECONDITION, "ColoredICP requires target normals and the colours of both clouds");
     if (kind == GSR_ICP_GENERALIZED && (!c->have_tcov || !c->have_scov))
         return fail(GSR_E_PRECONDITION, "TransformationEstimationForGeneralizedICP requires source and target covariances");
     hipStream_t st = c->stream;
@@ -929,15 +1091,19 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
                                c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
         nnj = c->nn_j.as<int>();
     }
-    if (kind == GSR_ICP_POINT_TO_POINT)
+    const ColorArgs cargs = {c->Ti.as<double>(), c->Tg.as<double>(), c->Si.as<double>(), sqrt(c->lambda_geometric), sqrt(1.0 - c->lambda_geometric)};
+    if (kind == GSR_ICP_COLORED)
+        hipLaunchKernelGGL(k_icp_accumulate<3>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
+                           c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, cargs, mc2, loss, k, c->partials.as<double>());
+    else if (kind == GSR_ICP_POINT_TO_POINT)
         hipLaunchKernelGGL(k_icp_accumulate<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
-                           c->Tq.as<float4>(), (const double*)nullptr, (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
+                           c->Tq.as<float4>(), (const double*)nullptr, (const double*)nullptr, cargs, mc2, loss, k, c->partials.as<double>());
     else if (kind == GSR_ICP_POINT_TO_PLANE)
         hipLaunchKernelGGL(k_icp_accumulate<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
-                           c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, mc2, loss, k, c->partials.as<double>());
+                           c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, cargs, mc2, loss, k, c->partials.as<double>());
     else
         hipLaunchKernelGGL(k_icp_accumulate<2>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), X, c->grid, c->cellStart.as<int>(), nnj,
-                           c->Tq.as<float4>(), c->Tc.as<double>(), c->Sc.as<double>(), mc2, loss, k, c->partials.as<double>());
+                           c->Tq.as<float4>(), c->Tc.as<double>(), c->Sc.as<double>(), cargs, mc2, loss, k, c->partials.as<double>());
     hipLaunchKernelGGL(k_icp_finalize, dim3(GSR_ICP_ACC_LEN), dim3(64), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>());
     if (timed) GSR_HIP(hipEventRecord(c->e1, st));
     GSR_HIP(hipMemcpyAsync(acc, c->acc_dev.p, GSR_ICP_ACC_LEN * 8, hipMemcpyDeviceToHost, st));
@@ -982,7 +1148,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
 int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
-    DevBuf* all[] = {&c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->Tc, &c->Sc, &c->stage_cov, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
+    DevBuf* all[] = {&c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->Tc, &c->Sc, &c->stage_cov, &c->Ti, &c->Tg, &c->Si, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
                      &c->src, &c->partials, &c->acc_dev, &c->rocprim_tmp, &c->corr_idx, &c->corr_d2};
     for (DevBuf* b : all) b->release();
     if (c->e0) (void)hipEventDestroy(c->e0);
@@ -1064,7 +1230,7 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     GSR_HIP(hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&c->ms_build, c->e0, c->e1);
     c->nt = n; c->max_corr = max_corr; c->have_target = true; c->have_normals = normals != nullptr;
-    c->have_tcov = false; c->have_scov = false;
+    c->have_tcov = false; c->have_scov = false; c->have_tcol = false; c->have_scol = false;
     c->have_source = false;              // the source is sorted by the target grid: set it again after a new target
     return GSR_OK;
 }
@@ -1098,7 +1264,7 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t 
         GSR_HIP(hipMemcpyAsync(c->src.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
     GSR_HIP(hipStreamSynchronize(st));
-    c->ns = n; c->have_source = true; c->have_scov = false;
+    c->ns = n; c->have_source = true; c->have_scov = false; c->have_scol = false;
     if (!c->allreduce) c->ns_global = n;
     return GSR_OK;
 }
@@ -1132,6 +1298,67 @@ int32_t gsr_icp_set_source_cov(gsr_icp_ctx* c, const double* cov6, int32_t on_de
     return GSR_OK;
 }
 
+int32_t gsr_icp_set_target_color(gsr_icp_ctx* c, const double* rgb, int32_t on_device) {
+    if (!c || !rgb) return fail(GSR_E_INVALID, "gsr_icp_set_target_color: NULL argument");
+    if (!c->have_target) return fail(GSR_E_PRECONDITION, "gsr_icp_set_target_color: set the target first");
+    if (!c->have_normals) return fail(GSR_E_PRECONDITION, "ColoredICP requires pre-computed normal vectors for target PointCloud.");
+    GSR_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int64_t n = c->nt;
+    const double* in = rgb;
+    if (!on_device) {
+        GSR_TRY(c->stage_cov.reserve((size_t)n * 24));
+        GSR_HIP(hipMemcpyAsync(c->stage_cov.p, rgb, (size_t)n * 24, hipMemcpyHostToDevice, st));
+        in = c->stage_cov.as<double>();
+    }
+    GSR_TRY(c->Ti.reserve((size_t)n * 8)); GSR_TRY(c->Tg.reserve((size_t)n * 24));
+    hipLaunchKernelGGL(k_icp_intensity, dim3(stride_grid(n)), dim3(256), 0, st, n, c->order.as<unsigned>(), in, c->Ti.as<double>());
+    // InitializePointCloudForColoredICP: KDTreeSearchParamHybrid(max_distance * 2, 30)
+    hipLaunchKernelGGL(k_icp_color_gradient, dim3(stride_grid(n)), dim3(256), 0, st, n, c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(),
+                       c->Tn.as<double>(), c->Ti.as<double>(), c->max_corr * 2.0, c->Tg.as<double>());
+    GSR_HIP(hipStreamSynchronize(st));
+    c->have_tcol = true;
+    return GSR_OK;
+}
+int32_t gsr_icp_set_source_color(gsr_icp_ctx* c, const double* rgb, int32_t on_device) {
+    if (!c || !rgb) return fail(GSR_E_INVALID, "gsr_icp_set_source_color: NULL argument");
+    if (!c->have_source) return fail(GSR_E_PRECONDITION, "gsr_icp_set_source_color: set the source first");
+    GSR_HIP(hipSetDevice(c->device));
+    hipStream_t st = c->stream;
+    const int64_t n = c->ns;
+    const double* in = rgb;
+    if (!on_device) {
+        GSR_TRY(c->stage_cov.reserve((size_t)n * 24));
+        GSR_HIP(hipMemcpyAsync(c->stage_cov.p, rgb, (size_t)n * 24, hipMemcpyHostToDevice, st));
+        in = c->stage_cov.as<double>();
+    }
+    GSR_TRY(c->Si.reserve((size_t)n * 8));
+    hipLaunchKernelGGL(k_icp_intensity, dim3(stride_grid(n)), dim3(256), 0, st, n, c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr,
+                       in, c->Si.as<double>());
+    GSR_HIP(hipStreamSynchronize(st));
+    c->have_scol = true;
+    return GSR_OK;
+}
+int32_t gsr_icp_set_lambda_geometric(gsr_icp_ctx* c, double lambda_geometric) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_lambda_geometric: NULL context");
+    if (!(lambda_geometric >= 0.0 && lambda_geometric <= 1.0)) return fail(GSR_E_INVALID, "lambda_geometric must lie in [0, 1]");
+    c->lambda_geometric = lambda_geometric;
+    return GSR_OK;
+}
+int32_t gsr_icp_get_color_gradient(gsr_icp_ctx* c, double* out) {
+    if (!c || !out) return fail(GSR_E_INVALID, "gsr_icp_get_color_gradient: NULL argument");
+    if (!c->have_tcol) return fail(GSR_E_PRECONDITION, "gsr_icp_get_color_gradient: set the target colours first");
+    GSR_HIP(hipSetDevice(c->device));
+    // back to the caller's point order (host memory)
+    std::vector<double> sorted((size_t)c->nt * 3);
+    std::vector<unsigned> order((size_t)c->nt);
+    GSR_HIP(hipMemcpy(sorted.data(), c->Tg.p, (size_t)c->nt * 24, hipMemcpyDeviceToHost));
+    GSR_HIP(hipMemcpy(order.data(), c->order.p, (size_t)c->nt * 4, hipMemcpyDeviceToHost));
+    for (int64_t j = 0; j < c->nt; ++j)
+        for (int a = 0; a < 3; ++a) out[3 * (size_t)order[j] + a] = sorted[3 * j + a];
+    return GSR_OK;
+}
+
 int32_t gsr_icp_set_allreduce(gsr_icp_ctx* c, gsr_allreduce_fn fn, void* user, int64_t n_source_global) {
     if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_allreduce: NULL context");
     c->allreduce = fn; c->allreduce_user = user;
@@ -1153,10 +1380,11 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
     if (!c->allreduce && c->device_loop) {
         // device-resident loop (single rank): no per-iteration host round trip
         if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
-        if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE && kind != GSR_ICP_GENERALIZED)
-            return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
+        if (kind < GSR_ICP_POINT_TO_POINT || kind > GSR_ICP_COLORED) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
         if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
             return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
+        if (kind == GSR_ICP_COLORED && (!c->have_normals || !c->have_tcol || !c->have_scol))
+            return fail(GSR_E_PRECONDITION, "ColoredICP requires target normals and the colours of both clouds");
         if (kind == GSR_ICP_GENERALIZED && (!c->have_tcov || !c->have_scov))
             return fail(GSR_E_PRECONDITION, "TransformationEstimationForGeneralizedICP requires source and target covariances");
         hipStream_t st = c->stream;
@@ -1175,6 +1403,7 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
         GSR_HIP(hipMemsetAsync(c->partials.p, 0, (size_t)nb * GSR_ICP_ACC_LEN * 8, st));
         const double mc2 = c->max_corr * c->max_corr;
+        const ColorArgs cargs = {c->Ti.as<double>(), c->Tg.as<double>(), c->Si.as<double>(), sqrt(c->lambda_geometric), sqrt(1.0 - c->lambda_geometric)};
         const int total_evals = hs.max_iter + 1;
         int issued = 0;
         GSR_HIP(hipEventRecord(c->e0, st));
@@ -1188,17 +1417,21 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
                 else if (c->nn_mode())
                     hipLaunchKernelGGL((k_icp_nn<true, true>), dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
                                        c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
-                if (kind == GSR_ICP_POINT_TO_POINT)
+                if (kind == GSR_ICP_COLORED)
+                    hipLaunchKernelGGL(k_icp_accumulate_dev<3>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, cargs, mc2, loss, k,
+                                       c->partials.as<double>());
+                else if (kind == GSR_ICP_POINT_TO_POINT)
                     hipLaunchKernelGGL(k_icp_accumulate_dev<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), (const double*)nullptr, (const double*)nullptr, mc2, loss, k,
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), (const double*)nullptr, (const double*)nullptr, cargs, mc2, loss, k,
                                        c->partials.as<double>());
                 else if (kind == GSR_ICP_POINT_TO_PLANE)
                     hipLaunchKernelGGL(k_icp_accumulate_dev<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, mc2, loss, k,
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, cargs, mc2, loss, k,
                                        c->partials.as<double>());
                 else
                     hipLaunchKernelGGL(k_icp_accumulate_dev<2>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tc.as<double>(), c->Sc.as<double>(), mc2, loss, k,
+                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tc.as<double>(), c->Sc.as<double>(), cargs, mc2, loss, k,
                                        c->partials.as<double>());
                 hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>());
             }
@@ -1265,8 +1498,7 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
 
 int32_t gsr_icp_solve(const double* acc, int32_t kind, const double* centre, double* update) {
     if (!acc || !update) return fail(GSR_E_INVALID, "gsr_icp_solve: NULL argument");
-    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE && kind != GSR_ICP_GENERALIZED)
-        return fail(GSR_E_INVALID, "gsr_icp_solve: unknown kind %d", kind);
+    if (kind < GSR_ICP_POINT_TO_POINT || kind > GSR_ICP_COLORED) return fail(GSR_E_INVALID, "gsr_icp_solve: unknown kind %d", kind);
     const double zero[3] = {0, 0, 0};
     estimate_update(centre ? centre : zero, kind, acc, update);
     return GSR_OK;

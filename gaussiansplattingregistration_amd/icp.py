@@ -20,6 +20,7 @@ __all__ = ["IcpContext", "registration_icp_arrays", "normals_from_cov", "Registr
 KIND_POINT_TO_POINT = 0
 KIND_POINT_TO_PLANE = 1
 KIND_GENERALIZED = 2
+KIND_COLORED = 3
 LOSS_L2, LOSS_TUKEY, LOSS_CAUCHY, LOSS_GM, LOSS_HUBER = 0, 1, 2, 3, 4
 
 
@@ -138,6 +139,28 @@ class IcpContext:
             self._sync_torch()
         _lib.check(self._L.gsr_icp_set_source_cov(self._h, p, 1 if on_dev else 0), "gsr_icp_set_source_cov")
 
+    def set_target_color(self, rgb):
+        """Target colours (N,3) for colored ICP; also prepares the colour gradients (needs target normals)."""
+        p, keep, on_dev = _prep(rgb, (self.n_target, 3), np.float64, self.device)
+        if on_dev:
+            self._sync_torch()
+        _lib.check(self._L.gsr_icp_set_target_color(self._h, p, 1 if on_dev else 0), "gsr_icp_set_target_color")
+
+    def set_source_color(self, rgb):
+        p, keep, on_dev = _prep(rgb, (self.n_source, 3), np.float64, self.device)
+        if on_dev:
+            self._sync_torch()
+        _lib.check(self._L.gsr_icp_set_source_color(self._h, p, 1 if on_dev else 0), "gsr_icp_set_source_color")
+
+    def set_lambda_geometric(self, lambda_geometric):
+        _lib.check(self._L.gsr_icp_set_lambda_geometric(self._h, float(lambda_geometric)), "gsr_icp_set_lambda_geometric")
+
+    def color_gradient(self):
+        """The target's colour gradients (N,3) float64 in the caller's point order (test / inspection hook)."""
+        out = np.empty((self.n_target, 3), np.float64)
+        _lib.check(self._L.gsr_icp_get_color_gradient(self._h, out.ctypes.data), "gsr_icp_get_color_gradient")
+        return out
+
     def set_allreduce(self, fn, n_source_global):
         """``fn(numpy float64[32]) -> None`` must sum the vector over all ranks in place."""
         if fn is None:
@@ -187,9 +210,11 @@ class IcpContext:
 
 
 def registration_icp_arrays(src_xyz, tgt_xyz, tgt_normals, init, kind=0, loss=0, k=0.0, max_corr=1.0, rel_fitness=1e-6,
-                            rel_rmse=1e-6, max_iter=30, device=0, src_cov=None, tgt_cov=None):
+                            rel_rmse=1e-6, max_iter=30, device=0, src_cov=None, tgt_cov=None, src_color=None, tgt_color=None,
+                            lambda_geometric=None):
     """One ``registration_icp`` on raw arrays; returns dict(transformation, fitness, inlier_rmse, iterations).
-    kind 2 (generalized ICP) needs ``src_cov`` / ``tgt_cov`` ((N,6) or (N,3,3))."""
+    kind 2 (generalized ICP) needs ``src_cov`` / ``tgt_cov`` ((N,6) or (N,3,3)); kind 3 (colored ICP) needs target normals
+    and ``src_color`` / ``tgt_color`` (N,3)."""
     with IcpContext(device=device) as c:
         c.set_target(tgt_xyz, tgt_normals, max_corr)
         c.set_source(src_xyz)
@@ -198,6 +223,13 @@ def registration_icp_arrays(src_xyz, tgt_xyz, tgt_normals, init, kind=0, loss=0,
                 raise RuntimeError("TransformationEstimationForGeneralizedICP requires source and target covariances")
             c.set_target_cov(tgt_cov)
             c.set_source_cov(src_cov)
+        if kind == 3:
+            if src_color is None or tgt_color is None:
+                raise RuntimeError("ColoredICP requires the colours of both clouds")
+            if lambda_geometric is not None:
+                c.set_lambda_geometric(lambda_geometric)
+            c.set_target_color(tgt_color)
+            c.set_source_color(src_color)
         out = c.register(init, kind, loss, k, rel_fitness, rel_rmse, max_iter)
         out.update(c.timing())
         return out

@@ -17,8 +17,8 @@ Open3D raises ``RuntimeError`` for ``max_correspondence_distance <= 0`` and for 
 a target without normals; so does this module.  Generalized ICP (``registration_generalized_icp``, reference
 ``:96-98``) runs on the clouds' own covariances -- the reference's clouds always carry the splat covariances
 (``point_cloud_converter.py:38``), which Open3D then uses as given; a cloud without covariances raises (Open3D
-would estimate them from 20-nearest-neighbour normals, which this backend does not build).  Colored ICP is outside
-this round's scope and raises ``NotImplementedError``.
+would estimate them from 20-nearest-neighbour normals, which this backend does not build).  Colored ICP
+(``registration_colored_icp``, ``:92-94``) needs target normals and the colours of both clouds, as Open3D does.
 """
 from __future__ import annotations
 
@@ -95,7 +95,7 @@ def get_estimation(registration_type, loss_function):
     if registration_type is LocalRegistrationType.ICP_Point_To_Plane:
         return Estimation(_icp.KIND_POINT_TO_PLANE, loss_function, "TransformationEstimationPointToPlane")
     if registration_type is LocalRegistrationType.ICP_Color:
-        return Estimation(-1, loss_function, "TransformationEstimationForColoredICP")
+        return Estimation(_icp.KIND_COLORED, loss_function, "TransformationEstimationForColoredICP")
     if registration_type is LocalRegistrationType.ICP_General:
         return Estimation(_icp.KIND_GENERALIZED, loss_function, "TransformationEstimationForGeneralizedICP")
     return None
@@ -126,11 +126,13 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
     """``o3d.pipelines.registration.registration_icp`` on ``PointCloud`` records (see ``point_cloud.py``)."""
     if not (max_correspondence_distance > 0.0):
         raise RuntimeError("[Open3D Error] Invalid max_correspondence_distance.")
-    if estimation_method.kind == _icp.KIND_POINT_TO_PLANE and not target.has_normals():
+    if estimation_method.kind in (_icp.KIND_POINT_TO_PLANE, _icp.KIND_COLORED) and not target.has_normals():
         raise RuntimeError("[Open3D Error] TransformationEstimationPointToPlane and "
                            "TransformationEstimationColoredICP require pre-computed normal vectors for target PointCloud.")
     if estimation_method.kind < 0:
         raise NotImplementedError(f"{estimation_method.name} is not part of this backend yet (SURVEY.md 8f, N2)")
+    if estimation_method.kind == _icp.KIND_COLORED and (source.colors is None or target.colors is None):
+        raise RuntimeError("[Open3D Error] ColoredICP requires color for both source and target PointCloud.")
     if estimation_method.kind == _icp.KIND_GENERALIZED and not (source.has_covariances() and target.has_covariances()):
         raise RuntimeError("registration_generalized_icp: this backend uses the clouds' own covariances "
                            "(point_cloud_converter.py:38 always sets them); a cloud without covariances is not supported")
@@ -140,12 +142,15 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
     if own:
         ctx = _icp.IcpContext(device=dev)
     try:
-        ctx.set_target(target.xyz32, target.normals if estimation_method.kind == _icp.KIND_POINT_TO_PLANE else None,
+        ctx.set_target(target.xyz32, target.normals if estimation_method.kind in (_icp.KIND_POINT_TO_PLANE, _icp.KIND_COLORED) else None,
                        max_correspondence_distance)
         ctx.set_source(source.xyz32)
         if estimation_method.kind == _icp.KIND_GENERALIZED:
             ctx.set_target_cov(target.cov6)
             ctx.set_source_cov(source.cov6)
+        if estimation_method.kind == _icp.KIND_COLORED:
+            ctx.set_target_color(target.colors)
+            ctx.set_source_color(source.colors)
         if allreduce is not None:
             ctx.set_allreduce(allreduce, n_source_global)
         r = ctx.register(np.asarray(init, dtype=np.float64), estimation_method.kind, loss.code, loss.k,
@@ -156,6 +161,15 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
     finally:
         if own:
             ctx.close()
+
+
+def registration_colored_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, **kw):
+    """``o3d.pipelines.registration.registration_colored_icp`` (Open3D ColoredICP.cpp: colour gradients of the target over
+    Hybrid(2 * max_correspondence_distance, 30) neighbourhoods, then the ICP loop with a geometric and a photometric
+    residual per pair, lambda_geometric = 0.968)."""
+    if estimation_method.kind != _icp.KIND_COLORED:
+        raise RuntimeError("registration_colored_icp needs TransformationEstimationForColoredICP")
+    return registration_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, **kw)
 
 
 def registration_generalized_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, **kw):
@@ -192,5 +206,6 @@ def do_icp_registration(point_cloud_first, point_cloud_second, init_transform, r
         return registration_generalized_icp(point_cloud_first, point_cloud_second, max_correspondence, init_transform,
                                             estimation_method, convergence_criteria, **kw)
     if rt is LocalRegistrationType.ICP_Color:
-        raise NotImplementedError(f"{rt.instance_name} is not part of this backend yet (SURVEY.md 8f, N2)")
+        return registration_colored_icp(point_cloud_first, point_cloud_second, max_correspondence, init_transform,
+                                        estimation_method, convergence_criteria, **kw)
     return None

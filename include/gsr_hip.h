@@ -122,6 +122,7 @@ typedef struct gsr_icp_ctx gsr_icp_ctx;
 #define GSR_ICP_POINT_TO_POINT 0   /* LocalRegistrationType.ICP_Point_To_Point, local_registration_util.py:33 */
 #define GSR_ICP_POINT_TO_PLANE 1   /* LocalRegistrationType.ICP_Point_To_Plane, :34 */
 #define GSR_ICP_GENERALIZED    2   /* LocalRegistrationType.ICP_General, :36 (registration_generalized_icp, :96-98) */
+#define GSR_ICP_COLORED        3   /* LocalRegistrationType.ICP_Color, :35 (registration_colored_icp, :92-94) */
 
 #define GSR_LOSS_L2     0          /* KernelLossFunctionType.Loss_None or k == 0, :63-64 */
 #define GSR_LOSS_TUKEY  1
@@ -146,6 +147,15 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* ctx, const float* xyz, int64_t n, int32_
  * they are; the source covariances follow the source under the current transform (C <- R C R^T). */
 int32_t gsr_icp_set_target_cov(gsr_icp_ctx* ctx, const double* cov6, int32_t on_device);
 int32_t gsr_icp_set_source_cov(gsr_icp_ctx* ctx, const double* cov6, int32_t on_device);
+/* Colours for GSR_ICP_COLORED: rgb[n*3] float64 in the order of the points last given to gsr_icp_set_target /
+ * gsr_icp_set_source (call after them; the target needs normals).  The target call also prepares the cloud as Open3D's
+ * InitializePointCloudForColoredICP does: per point, the 30 nearest neighbours within 2 * max_corr (ordered by
+ * distance, then index), a least-squares colour gradient in the tangent plane.  lambda_geometric defaults to 0.968
+ * (TransformationEstimationForColoredICP).  gsr_icp_get_color_gradient: the gradients [n*3], host memory, caller order. */
+int32_t gsr_icp_set_target_color(gsr_icp_ctx* ctx, const double* rgb, int32_t on_device);
+int32_t gsr_icp_set_source_color(gsr_icp_ctx* ctx, const double* rgb, int32_t on_device);
+int32_t gsr_icp_set_lambda_geometric(gsr_icp_ctx* ctx, double lambda_geometric);
+int32_t gsr_icp_get_color_gradient(gsr_icp_ctx* ctx, double* out);
 /* Multi-GPU source split: this rank owns source points, the target is replicated.  `allreduce` is
  * called once per correspondence evaluation with the rank-local accumulator vector (float64[len],
  * host memory) and must replace it by the element-wise sum over ranks (RCCL/gloo all-reduce in the
@@ -157,7 +167,8 @@ int32_t gsr_icp_set_allreduce(gsr_icp_ctx* ctx, gsr_allreduce_fn fn, void* user,
  * acc[0]=count, acc[1]=sum d^2, then for point-to-point acc[2..4]=sum p, [5..7]=sum q, [8..16]=sum p q^T
  * (p = transformed source, q = matched target, both relative to the target-bbox centre);
  * for point-to-plane and generalized ICP acc[2..22]=upper triangle of J^T w J (row-major), [23..28]=J^T w r,
- * [29]=sum r^2 (generalized: three residual rows per pair, J = W [-skew(p) | I], W = (Ct + R Cs R^T)^-1/2).
+ * [29]=sum r^2 (generalized: three residual rows per pair, J = W [-skew(p) | I], W = (Ct + R Cs R^T)^-1/2;
+ * colored: a geometric and a photometric row per pair).
  * len(acc) = GSR_ICP_ACC_LEN.  This is the "hot loop" exposed for tests and for RCCL all-reduce. */
 #define GSR_ICP_ACC_LEN 32
 int32_t gsr_icp_accumulate(gsr_icp_ctx* ctx, const double* T, int32_t kind, int32_t loss, double k,

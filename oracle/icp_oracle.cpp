@@ -100,6 +100,27 @@ struct KdTree {
         nearest(q, first, best, bestd);
         if (diff * diff <= bestd) nearest(q, second, best, bestd);
     }
+
+    // k nearest neighbours: `heap` is a max-heap on (distance, index) holding the k best so far
+    typedef std::pair<double, int64_t> DI;
+    void knn(const P3& q, int node, size_t k, std::vector<DI>& heap) const {
+        const Node& nd = nodes[node];
+        if (nd.axis < 0) {
+            for (int t = nd.lo; t < nd.hi; ++t) {
+                int64_t j = idx[t];
+                double dx = q.x - pts[j].x, dy = q.y - pts[j].y, dz = q.z - pts[j].z;
+                DI c(dx * dx + dy * dy + dz * dz, j);
+                if (heap.size() < k) { heap.push_back(c); std::push_heap(heap.begin(), heap.end()); }
+                else if (c < heap.front()) { std::pop_heap(heap.begin(), heap.end()); heap.back() = c; std::push_heap(heap.begin(), heap.end()); }
+            }
+            return;
+        }
+        double diff = coord(q, nd.axis) - nd.split;
+        int first = diff < 0 ? nd.left : nd.right;
+        int second = diff < 0 ? nd.right : nd.left;
+        knn(q, first, k, heap);
+        if (heap.size() < k || diff * diff <= heap.front().first) knn(q, second, k, heap);
+    }
 };
 
 // ---- small dense linear algebra in float64 --------------------------------------------------------
@@ -540,6 +561,148 @@ int64_t gsr_oracle_voxel_down_sample(const double* xyz, const double* color, con
         }
     }
     return (int64_t)vox.size();
+}
+
+// Colored ICP (Open3D 0.16.0 cpp/open3d/pipelines/registration/ColoredICP.cpp), reference call site
+// src/utils/local_registration_util.py:92-94.
+//   target preparation (InitializePointCloudForColoredICP, search = Hybrid(radius 2 max_corr, max_nn 30)):
+//       KDTreeFlann::SearchHybrid = the 30 nearest neighbours (the point itself first), cut at d^2 < radius^2;
+//       with nn >= 4 found: intensity it = mean(rgb); for neighbours 1..nn-1: row = (proj(v_adj) - vt), rhs = it_adj - it,
+//       proj = v_adj - ((v_adj - vt).nt) nt; last row = (nn-1) nt, rhs 0; gradient = solve(A^T A, A^T b) (LDLT)
+//   per pair, two rows (lambda_geometric = 0.968):
+//       r0 = sqrt(lg) (vs - vt).nt,                       J0 = sqrt(lg) [vs x nt, nt]
+//       r1 = sqrt(1-lg) (is - (dit.(vs_proj - vt) + it)), J1 = sqrt(1-lg) [vs x ditM, ditM],  ditM = -dit^T (I - nt nt^T)
+//   weights kernel(r), 6x6 solve, loop = RegistrationICP.
+static void solve3(const double A_[3][3], const double b_[3], double x[3]) {       // Gaussian elimination, partial pivoting
+    double A[3][4];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) A[i][j] = A_[i][j]; A[i][3] = b_[i]; }
+    for (int c = 0; c < 3; ++c) {
+        int piv = c;
+        for (int r = c + 1; r < 3; ++r) if (std::fabs(A[r][c]) > std::fabs(A[piv][c])) piv = r;
+        for (int j = 0; j < 4; ++j) std::swap(A[c][j], A[piv][j]);
+        for (int r = c + 1; r < 3; ++r) {
+            const double f = A[r][c] / A[c][c];
+            for (int j = c; j < 4; ++j) A[r][j] -= f * A[c][j];
+        }
+    }
+    for (int i = 2; i >= 0; --i) {
+        double v = A[i][3];
+        for (int j = i + 1; j < 3; ++j) v -= A[i][j] * x[j];
+        x[i] = v / A[i][i];
+    }
+}
+
+// color gradient of every target point; out n x 3
+void gsr_oracle_color_gradient(const double* tgt_, const double* tgt_normals, const double* tgt_colors, int64_t nt, double radius,
+                               int32_t max_nn, int32_t threads, double* out) {
+    std::vector<P3> tgt(nt);
+    std::memcpy(tgt.data(), tgt_, sizeof(P3) * nt);
+    const P3* nrm = reinterpret_cast<const P3*>(tgt_normals);
+    KdTree tree;
+    tree.create(tgt.data(), nt);
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t k = 0; k < nt; ++k) {
+        out[3 * k] = out[3 * k + 1] = out[3 * k + 2] = 0.0;
+        const P3& vt = tgt[k];
+        const P3& n = nrm[k];
+        const double it = (tgt_colors[3 * k] + tgt_colors[3 * k + 1] + tgt_colors[3 * k + 2]) / 3.0;
+        std::vector<KdTree::DI> heap;
+        tree.knn(vt, 0, (size_t)max_nn, heap);
+        std::sort(heap.begin(), heap.end());
+        size_t nn = 0;
+        while (nn < heap.size() && heap[nn].first < radius * radius) ++nn;
+        if (nn < 4) continue;
+        double AtA[3][3] = {{0}}, Atb[3] = {0};
+        for (size_t i = 1; i < nn; ++i) {
+            const int64_t a = heap[i].second;
+            const P3& va = tgt[a];
+            const double dn = (va.x - vt.x) * n.x + (va.y - vt.y) * n.y + (va.z - vt.z) * n.z;
+            const double row[3] = {va.x - dn * n.x - vt.x, va.y - dn * n.y - vt.y, va.z - dn * n.z - vt.z};
+            const double rhs = (tgt_colors[3 * a] + tgt_colors[3 * a + 1] + tgt_colors[3 * a + 2]) / 3.0 - it;
+            for (int p = 0; p < 3; ++p) { for (int q = 0; q < 3; ++q) AtA[p][q] += row[p] * row[q]; Atb[p] += row[p] * rhs; }
+        }
+        const double f = (double)(nn - 1);
+        const double row[3] = {f * n.x, f * n.y, f * n.z};
+        for (int p = 0; p < 3; ++p) for (int q = 0; q < 3; ++q) AtA[p][q] += row[p] * row[q];
+        solve3(AtA, Atb, out + 3 * k);
+    }
+}
+
+int32_t gsr_oracle_colored_icp(const double* src_, const double* src_colors, int64_t ns, const double* tgt_, const double* tgt_normals,
+                               const double* tgt_colors, int64_t nt, const double* init4x4, int32_t loss, double k, double lambda_geometric,
+                               double max_corr, double rel_fitness, double rel_rmse, int32_t max_iter, int32_t threads, double* out_T,
+                               double* out_fitness, double* out_rmse) {
+    if (!(max_corr > 0)) return -1;
+    if (!tgt_normals) return -2;
+    if (ns <= 0 || nt <= 0) return -3;
+    if (!src_colors || !tgt_colors) return -4;
+    std::vector<P3> src(ns), tgt(nt);
+    std::memcpy(src.data(), src_, sizeof(P3) * ns);
+    std::memcpy(tgt.data(), tgt_, sizeof(P3) * nt);
+    const P3* nrm = reinterpret_cast<const P3*>(tgt_normals);
+    std::vector<double> grad((size_t)nt * 3);
+    gsr_oracle_color_gradient(tgt_, tgt_normals, tgt_colors, nt, max_corr * 2.0, 30, threads, grad.data());
+    KdTree tree;
+    tree.create(tgt.data(), nt);
+    const double sg = std::sqrt(lambda_geometric), sp = std::sqrt(1.0 - lambda_geometric);
+    M4 T;
+    std::memcpy(&T, init4x4, sizeof(M4));
+    bool is_identity = true;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) if (T.a[i][j] != (i == j ? 1.0 : 0.0)) is_identity = false;
+    if (!is_identity) transform_points(src, T);
+    Eval res = evaluate(src, tree, nt, max_corr, threads);
+    int it = 0;
+    for (; it < max_iter; ++it) {
+        M4 update = identity4();
+        const size_t nc = res.si.size();
+        if (nc > 0) {
+            double JTJ[6][6] = {{0}}, JTr[6] = {0};
+            for (size_t c = 0; c < nc; ++c) {
+                const int64_t cs = res.si[c], ct = res.ti[c];
+                const P3& vs = src[cs];
+                const P3& vt = tgt[ct];
+                const P3& n = nrm[ct];
+                const double dn = (vs.x - vt.x) * n.x + (vs.y - vt.y) * n.y + (vs.z - vt.z) * n.z;
+                double J[2][6], r[2];
+                J[0][0] = sg * (vs.y * n.z - vs.z * n.y); J[0][1] = sg * (vs.z * n.x - vs.x * n.z); J[0][2] = sg * (vs.x * n.y - vs.y * n.x);
+                J[0][3] = sg * n.x; J[0][4] = sg * n.y; J[0][5] = sg * n.z;
+                r[0] = sg * dn;
+                const double pj[3] = {vs.x - dn * n.x - vt.x, vs.y - dn * n.y - vt.y, vs.z - dn * n.z - vt.z};     // vs_proj - vt
+                const double is = (src_colors[3 * cs] + src_colors[3 * cs + 1] + src_colors[3 * cs + 2]) / 3.0;
+                const double itn = (tgt_colors[3 * ct] + tgt_colors[3 * ct + 1] + tgt_colors[3 * ct + 2]) / 3.0;
+                const double* d = grad.data() + 3 * ct;
+                const double is0 = d[0] * pj[0] + d[1] * pj[1] + d[2] * pj[2] + itn;
+                const double dd = d[0] * n.x + d[1] * n.y + d[2] * n.z;
+                const double m[3] = {-(d[0] - dd * n.x), -(d[1] - dd * n.y), -(d[2] - dd * n.z)};                 // -dit^T (I - n n^T)
+                J[1][0] = sp * (vs.y * m[2] - vs.z * m[1]); J[1][1] = sp * (vs.z * m[0] - vs.x * m[2]); J[1][2] = sp * (vs.x * m[1] - vs.y * m[0]);
+                J[1][3] = sp * m[0]; J[1][4] = sp * m[1]; J[1][5] = sp * m[2];
+                r[1] = sp * (is - is0);
+                for (int row = 0; row < 2; ++row) {
+                    const double w = kernel_weight(loss, k, r[row]);
+                    for (int p = 0; p < 6; ++p) {
+                        for (int q = 0; q < 6; ++q) JTJ[p][q] += J[row][p] * w * J[row][q];
+                        JTr[p] += J[row][p] * w * r[row];
+                    }
+                }
+            }
+            double nb[6], x[6];
+            for (int p = 0; p < 6; ++p) nb[p] = -JTr[p];
+            solve6(JTJ, nb, x);
+            update = vec6_to_mat4(x);
+        }
+        T = mul4(update, T);
+        transform_points(src, update);
+        Eval backup = std::move(res);
+        res = evaluate(src, tree, nt, max_corr, threads);
+        if (std::fabs(backup.fitness - res.fitness) < rel_fitness && std::fabs(backup.rmse - res.rmse) < rel_rmse) { ++it; break; }
+    }
+    std::memcpy(out_T, &T, sizeof(M4));
+    *out_fitness = res.fitness;
+    *out_rmse = res.rmse;
+    return it;
 }
 
 int gsr_oracle_icp_correspond(const double* src_, int64_t ns, const double* tgt_, int64_t nt,

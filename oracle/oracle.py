@@ -259,6 +259,44 @@ def voxel_down_sample(xyz, voxel_size, color=None, cov=None):
     return ox, oc, None if ov is None else ov.reshape(-1, 3, 3)
 
 
+def color_gradient(tgt, tgt_normals, tgt_colors, radius, max_nn=30, threads=0):
+    t = _c(tgt, np.float64).reshape(-1, 3)
+    n = _c(tgt_normals, np.float64).reshape(-1, 3)
+    c = _c(tgt_colors, np.float64).reshape(-1, 3)
+    out = np.empty_like(t)
+    fn = lib().gsr_oracle_color_gradient
+    fn.restype = None
+    P = C.c_void_p
+    fn.argtypes = [P, P, P, C.c_int64, C.c_double, C.c_int32, C.c_int32, P]
+    fn(t.ctypes.data, n.ctypes.data, c.ctypes.data, t.shape[0], float(radius), int(max_nn), int(threads), out.ctypes.data)
+    return out
+
+
+def colored_icp(src, src_colors, tgt, tgt_normals, tgt_colors, init=None, loss=0, k=0.0, lambda_geometric=0.968, max_corr=1.0,
+                rel_fitness=1e-6, rel_rmse=1e-6, max_iter=30, threads=0):
+    """registration_colored_icp on the oracle."""
+    s = _c(src, np.float64).reshape(-1, 3)
+    sc = _c(src_colors, np.float64).reshape(-1, 3)
+    t = _c(tgt, np.float64).reshape(-1, 3)
+    tn = _c(tgt_normals, np.float64).reshape(-1, 3)
+    tc = _c(tgt_colors, np.float64).reshape(-1, 3)
+    init = np.eye(4) if init is None else _c(init, np.float64).reshape(4, 4)
+    T = np.empty((4, 4), np.float64)
+    fit, rmse = C.c_double(0), C.c_double(0)
+    fn = lib().gsr_oracle_colored_icp
+    fn.restype = C.c_int32
+    P = C.c_void_p
+    fn.argtypes = [P, P, C.c_int64, P, P, P, C.c_int64, P, C.c_int32, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double,
+                   C.c_int32, C.c_int32, P, P, P]
+    it = fn(s.ctypes.data, sc.ctypes.data, s.shape[0], t.ctypes.data, tn.ctypes.data, tc.ctypes.data, t.shape[0], init.ctypes.data,
+            loss, k, lambda_geometric, max_corr, rel_fitness, rel_rmse, max_iter, threads, T.ctypes.data, C.addressof(fit),
+            C.addressof(rmse))
+    if it < 0:
+        raise RuntimeError({-1: "max_correspondence_distance must be > 0", -2: "colored ICP requires target normals",
+                            -3: "empty point cloud", -4: "colored ICP requires colours"}.get(it, f"colored icp oracle error {it}"))
+    return {"transformation": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iterations": int(it)}
+
+
 def icp_correspond(src, tgt, T, max_corr, threads=0):
     src = _c(src, np.float64).reshape(-1, 3)
     tgt = _c(tgt, np.float64).reshape(-1, 3)

@@ -82,6 +82,14 @@ int32_t gsr_oracle_gicp(const double* src, const double* src_cov3x3, int64_t ns,
 // arrays, color / cov (n x 9) optional.  Returns the voxel count (out_* NULL = count only), -1 for voxel_size <= 0.
 int64_t gsr_oracle_voxel_down_sample(const double* xyz, const double* color, const double* cov3x3, int64_t n, double voxel_size,
                                      double* out_xyz, double* out_color, double* out_cov3x3);
+// Colored ICP (Open3D ColoredICP.cpp): colour gradient of every target point over its 30 nearest neighbours within
+// `radius` (n x 3 out), and the registration itself (lambda_geometric = 0.968 in Open3D; -4 = colours missing).
+void gsr_oracle_color_gradient(const double* tgt, const double* tgt_normals, const double* tgt_colors, int64_t nt, double radius,
+                               int32_t max_nn, int32_t threads, double* out_gradient);
+int32_t gsr_oracle_colored_icp(const double* src, const double* src_colors, int64_t ns, const double* tgt, const double* tgt_normals,
+                               const double* tgt_colors, int64_t nt, const double* init4x4, int32_t loss, double k,
+                               double lambda_geometric, double max_corr, double rel_fitness, double rel_rmse, int32_t max_iter,
+                               int32_t threads, double* out_T4x4, double* out_fitness, double* out_rmse);
 // One correspondence evaluation: nearest target index (or -1) and squared distance for every source point.
 int gsr_oracle_icp_correspond(const double* src, int64_t ns, const double* tgt, int64_t nt,
                               const double* T4x4, double max_corr, int32_t threads,

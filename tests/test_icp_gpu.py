@@ -194,6 +194,62 @@ def test_generalized_icp_through_do_icp_registration(oracle):
         do_icp_registration(pcs[0], pcs[1], init, p)
 
 
+def _colored_pair(n, seed, oracle):
+    from test_icp_oracle import _colored_pair as cp
+    return cp(n, seed, oracle)
+
+
+@pytest.mark.parametrize("n,radius", [(4000, 0.6), (4000, 0.09), (120000, 0.3)])
+def test_color_gradient_vs_oracle(oracle, n, radius):
+    """InitializePointCloudForColoredICP on the GPU: the 30 nearest neighbours within the radius, ordered by (distance,
+    index), and the tangent-plane least-squares gradient -- same neighbours, same summation order as the oracle."""
+    from gaussiansplattingregistration_amd import icp
+    s, scol, t, nrm, tcol, _ = _colored_pair(n, 15, oracle)
+    with icp.IcpContext() as c:
+        c.set_target(t.astype(np.float32), nrm, radius / 2.0)          # gradients use Hybrid(2 * max_corr, 30)
+        c.set_target_color(tcol)
+        got = c.color_gradient()
+    want = oracle.color_gradient(t.astype(np.float32).astype(np.float64), nrm, tcol, radius)
+    scale = max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() < 1e-9 * scale
+    if radius < 0.1:
+        assert (np.abs(want).sum(1) == 0).any()                      # points with fewer than 4 neighbours keep a zero gradient
+
+
+@pytest.mark.parametrize("loss,k", [(0, 0.0), (1, 0.4), (2, 0.3)])
+def test_colored_icp_vs_oracle(oracle, loss, k):
+    from gaussiansplattingregistration_amd import icp
+    s, scol, t, nrm, tcol, T_gt = _colored_pair(6000, 16, oracle)
+    s32, t32 = s.astype(np.float32), t.astype(np.float32)
+    r = icp.registration_icp_arrays(s32, t32, nrm, np.eye(4), kind=3, loss=loss, k=k, max_corr=0.3, max_iter=25, src_color=scol,
+                                    tgt_color=tcol)
+    w = oracle.colored_icp(s32.astype(np.float64), scol, t32.astype(np.float64), nrm, tcol, np.eye(4), loss=loss, k=k, max_corr=0.3,
+                           max_iter=25)
+    assert r["iterations"] == w["iterations"]
+    assert np.linalg.norm(r["transformation"] - w["transformation"]) < TOL_T
+    assert abs(r["fitness"] - w["fitness"]) < 1e-9 and abs(r["inlier_rmse"] - w["inlier_rmse"]) < 1e-8
+    assert np.linalg.norm(r["transformation"] - T_gt) < 0.05
+
+
+def test_colored_icp_through_do_icp_registration(oracle):
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+    from gaussiansplattingregistration_amd.params.registration_parameters import LocalRegistrationParams
+    from gaussiansplattingregistration_amd.utils.local_registration_util import (KernelLossFunctionType, LocalRegistrationType,
+                                                                                 do_icp_registration)
+    s, scol, t, nrm, tcol, T_gt = _colored_pair(5000, 17, oracle)
+    src = PointCloud(xyz32=s.astype(np.float32), colors=scol)
+    tgt = PointCloud(xyz32=t.astype(np.float32), colors=tcol, normals=nrm)
+    p = LocalRegistrationParams(registration_type=LocalRegistrationType.ICP_Color, max_correspondence=0.25, relative_fitness=1e-6,
+                                relative_rmse=1e-6, max_iteration=20, rejection_type=KernelLossFunctionType.Loss_None, k_value=0.0)
+    res = do_icp_registration(src, tgt, np.eye(4), p)
+    w = oracle.colored_icp(s.astype(np.float32).astype(np.float64), scol, t.astype(np.float32).astype(np.float64), nrm, tcol, np.eye(4),
+                           max_corr=0.25, max_iter=20)
+    assert np.linalg.norm(res.transformation - w["transformation"]) < TOL_T
+    tgt.colors = None
+    with pytest.raises(RuntimeError, match="color"):
+        do_icp_registration(src, tgt, np.eye(4), p)
+
+
 def test_icp_error_behaviour():
     from gaussiansplattingregistration_amd import icp
     with icp.IcpContext() as c:

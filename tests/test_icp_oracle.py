@@ -196,3 +196,105 @@ def test_voxel_down_sample_oracle_vs_numpy(oracle):
         assert got.shape == acc.shape and np.allclose(got, acc / cnt[:, None], rtol=1e-13, atol=1e-15)
     with pytest.raises(RuntimeError, match="voxel_size"):
         oracle.voxel_down_sample(x, 0.0)
+
+
+def _color_field(p):
+    """A smooth colour field over space (so that colour gradients exist and the photometric term carries signal)."""
+    p = np.asarray(p, np.float64)
+    r = 0.5 + 0.3 * np.sin(2.1 * p[:, 0] + 0.3) * np.cos(1.3 * p[:, 1])
+    g = 0.5 + 0.3 * np.sin(1.7 * p[:, 1] - 0.8 * p[:, 2])
+    b = 0.5 + 0.25 * np.cos(1.1 * p[:, 2] + 0.5 * p[:, 0])
+    return np.stack([r, g, b], 1)
+
+
+def _colored_pair(n, seed, oracle):
+    src, tgt, T_gt = synth.make_pair(n, seed=seed, sh_degree=0)
+    t64 = tgt["xyz"].astype(np.float64)
+    s64 = src["xyz"].astype(np.float64)
+    C = tgt["cov6"].astype(np.float64)
+    nrm = oracle.normals_from_cov(np.stack([C[:, [0, 1, 2]], C[:, [1, 3, 4]], C[:, [2, 4, 5]]], 1))
+    tcol = _color_field(t64)
+    scol = _color_field(s64 @ T_gt[:3, :3].T + T_gt[:3, 3])          # the colour the source point has where it belongs
+    return s64, scol, t64, nrm, tcol, T_gt
+
+
+def _color_gradient_numpy(t, nrm, col, radius, max_nn=30):
+    tree = cKDTree(t)
+    d, j = tree.query(t, k=max_nn)
+    inten = col.mean(1)
+    out = np.zeros_like(t)
+    for k in range(len(t)):
+        m = d[k] ** 2 < radius * radius
+        nn = int(m.sum())
+        if nn < 4:
+            continue
+        adj = j[k][:nn][1:]
+        v = t[adj] - t[k]
+        proj = v - (v @ nrm[k])[:, None] * nrm[k]
+        A = np.vstack([proj, (nn - 1) * nrm[k][None, :]])
+        b = np.concatenate([inten[adj] - inten[k], [0.0]])
+        out[k] = np.linalg.solve(A.T @ A, A.T @ b)
+    return out
+
+
+def test_color_gradient_oracle_vs_numpy(oracle):
+    s, scol, t, nrm, tcol, _ = _colored_pair(2500, 12, oracle)
+    got = oracle.color_gradient(t, nrm, tcol, 0.6)
+    want = _color_gradient_numpy(t, nrm, tcol, 0.6)
+    assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+    # a radius that leaves some points with fewer than 4 neighbours: their gradient stays zero
+    got2 = oracle.color_gradient(t, nrm, tcol, 0.08)
+    want2 = _color_gradient_numpy(t, nrm, tcol, 0.08)
+    assert (np.abs(want2).sum(1) == 0).any() and np.abs(got2 - want2).max() < 1e-8 * max(1.0, np.abs(want2).max())
+
+
+def test_colored_icp_oracle_vs_numpy(oracle):
+    """registration_colored_icp: C++ restatement against an independent NumPy/SciPy one (L2 loss, lambda 0.968)."""
+    s, scol, t, nrm, tcol, T_gt = _colored_pair(2500, 12, oracle)
+    max_corr, max_iter, lg = 0.3, 25, 0.968
+    got = oracle.colored_icp(s, scol, t, nrm, tcol, np.eye(4), max_corr=max_corr, max_iter=max_iter)
+    grad = _color_gradient_numpy(t, nrm, tcol, 2 * max_corr)
+    tree = cKDTree(t)
+    si, ti = scol.mean(1), tcol.mean(1)
+    T = np.eye(4)
+    p = s.copy()
+
+    def evaluate(p):
+        d, j = tree.query(p)
+        m = d < max_corr
+        return m, j, m.mean(), (float(np.sqrt((d[m] ** 2).mean())) if m.any() else 0.0)
+
+    m, j, fit, rmse = evaluate(p)
+    it = 0
+    for it in range(1, max_iter + 1):
+        vs, vt, n = p[m], t[j[m]], nrm[j[m]]
+        dn = ((vs - vt) * n).sum(1)
+        r0 = np.sqrt(lg) * dn
+        J0 = np.sqrt(lg) * np.hstack([np.cross(vs, n), n])
+        pj = vs - dn[:, None] * n - vt
+        dit = grad[j[m]]
+        is0 = (dit * pj).sum(1) + ti[j[m]]
+        ditM = -(dit - (dit * n).sum(1)[:, None] * n)
+        r1 = np.sqrt(1 - lg) * (si[m] - is0)
+        J1 = np.sqrt(1 - lg) * np.hstack([np.cross(vs, ditM), ditM])
+        J = np.vstack([J0, J1])
+        r = np.concatenate([r0, r1])
+        x = np.linalg.solve(J.T @ J, -(J.T @ r))
+        a, b, g = x[:3]
+        Rx = np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = np.array([[np.cos(b), 0, np.sin(b)], [0, 1, 0], [-np.sin(b), 0, np.cos(b)]])
+        Rz = np.array([[np.cos(g), -np.sin(g), 0], [np.sin(g), np.cos(g), 0], [0, 0, 1]])
+        U = np.eye(4)
+        U[:3, :3] = Rz @ Ry @ Rx
+        U[:3, 3] = x[3:]
+        T = U @ T
+        p = p @ U[:3, :3].T + U[:3, 3]
+        m, j, fit2, rmse2 = evaluate(p)
+        done = abs(fit2 - fit) < 1e-6 and abs(rmse2 - rmse) < 1e-6
+        fit, rmse = fit2, rmse2
+        if done:
+            break
+    assert got["iterations"] == it
+    assert np.linalg.norm(got["transformation"] - T) < 1e-8
+    assert abs(got["fitness"] - fit) < 1e-12 and abs(got["inlier_rmse"] - rmse) < 1e-9
+    assert np.linalg.norm(got["transformation"] - T_gt) < 0.05
