@@ -1735,7 +1735,19 @@ int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out8) {
     return GSR_OK;
 }
 
+// GSR_HEM_DEBUG_SYNC=1: synchronise and report after every stage of a level (localises a device fault)
+#define GSR_CHECKPOINT(label)                                                                       \
+    do {                                                                                            \
+        if (dbg_sync) {                                                                             \
+            hipError_t _e = hipStreamSynchronize(st);                                               \
+            fprintf(stderr, "[gsr_hem] %s: %s\n", label, hipGetErrorString(_e));                    \
+            fflush(stderr);                                                                         \
+            if (_e != hipSuccess) return fail(GSR_E_HIP, "%s: %s", label, hipGetErrorString(_e));   \
+        }                                                                                           \
+    } while (0)
+
 int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
+    const bool dbg_sync = getenv("GSR_HEM_DEBUG_SYNC") != nullptr;
     if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_run_level: no level set");
     GSR_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
@@ -1813,6 +1825,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     }
     const int P = last_pos + last_flag;
     c->stats[0] = P;
+    GSR_CHECKPOINT("grid + gather");
     GSR_HIP(hipEventRecord(c->ev[1], st));
 
     // ---- 2. selection ------------------------------------------------------------------------------
@@ -1820,7 +1833,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // upper bound of its child count); heavy parents are split into work items of <= ~8k candidates
     // (work per parent is heavy-tailed: R^3 is log-normal); every item writes its pairs at the head of a
     // segment of its capacity; k_compact_pairs packs them per parent.  The sparse buffers cost 8 bytes
-    // per candidate scanned; when that exceeds the budget (GSR_HEM_SPARSE_GB, default 1/3 of free HBM)
+    // per candidate scanned; when that exceeds the budget (GSR_HEM_SPARSE_GB, default 45 % of free HBM)
     // the two-pass COUNT + FILL fallback runs instead (same device code, evaluates every candidate twice).
     const size_t Pm = (size_t)(P > 0 ? P : 1);
     GSR_TRY(c->pcnt.reserve(Pm * 4)); GSR_TRY(c->pcap.reserve(Pm * 4)); GSR_TRY(c->poff.reserve((Pm + 1) * 8));
@@ -1938,7 +1951,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         }
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
-        size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 3;
+        size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 20 * 9;      // 45 % of what is free (a 40 M-splat level needs 79 GB)
         if (const char* e = getenv("GSR_HEM_SPARSE_GB")) budget = (size_t)(atof(e) * 1073741824.0);
         const bool sparse = (double)cand * 8.0 <= (double)budget && cand < (1ull << 40);
         if (sparse) {
@@ -1947,7 +1960,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
             sa.pcnt = split ? c->vcnt.as<unsigned>() : c->pcnt.as<unsigned>();
             GSR_HIP(hipEventRecord(c->evk[2], st));
+            GSR_CHECKPOINT("spans + ordering");
             GSR_LAUNCH_SELECT(SEL_SPARSE, V);
+            GSR_CHECKPOINT("k_select<SPARSE>");
             GSR_HIP(hipEventRecord(c->evk[3], st));
             if (split)
                 hipLaunchKernelGGL(k_sum_parts, dim3(stride_grid(P)), blk, 0, st, P, c->nparts.as<int>(), c->vstart.as<int>(), c->vcnt.as<unsigned>(),
@@ -1995,6 +2010,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 #undef GSR_LAUNCH_SELECT
 #undef GSR_LAUNCH_SELECT_C
     c->stats[1] = M;
+    GSR_CHECKPOINT("selection");
     GSR_HIP(hipEventRecord(c->ev[2], st));
 
     // ---- 3. per-child sums of wL (deterministic: stable sort by child, sequential sum) ----------
@@ -2002,6 +2018,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (M > 0) {
         GSR_TRY(sort_pairs<float>(c, c->pair_child.as<unsigned>(), c->spair_child.as<unsigned>(), c->pair_wl.as<float>(),
                                   c->spair_wl.as<float>(), M, bits_for(n)));
+        GSR_CHECKPOINT("pair sort");
         hipLaunchKernelGGL(k_run_starts<int64_t>, dim3(stride_grid(M)), blk, 0, st, M, c->spair_child.as<unsigned>(), n, c->cstart.as<int64_t>());
     } else {
         hipLaunchKernelGGL(k_fill_const<int64_t>, grd, blk, 0, st, n + 1, c->cstart.as<int64_t>(), (int64_t)0);
@@ -2013,6 +2030,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         if (c->shard_allreduce(c->sumLw.p, n, c->shard_user) != 0) return fail(GSR_E_INVALID, "gsr_hem_run_level: all-reduce callback failed (sumLw)");
         hipLaunchKernelGGL(k_orphan_flags, grd, blk, 0, st, n, c->sumLw.as<float>(), c->oflag.as<int>());
     }
+    GSR_CHECKPOINT("per-child sums");
     GSR_HIP(hipEventRecord(c->ev[3], st));
 
     // ---- 4. output ranks in input order; M-step; orphans -----------------------------------------
@@ -2084,6 +2102,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         if (rc == 0 && F > 0) rc = c->shard_allreduce(O.sh.p, (int64_t)P * F, c->shard_user);
         if (rc != 0) return fail(GSR_E_INVALID, "gsr_hem_run_level: all-reduce callback failed (outputs)");
     }
+    GSR_CHECKPOINT("M-step + orphans");
     GSR_HIP(hipEventRecord(c->ev[4], st));
 
     // ---- 5. new parent flags (one draw per component, before the erase), validity erase ---------
@@ -2123,6 +2142,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             O.swap(T);
         }
     }
+    GSR_CHECKPOINT("flags + validity");
     GSR_HIP(hipEventRecord(c->ev[5], st));
     GSR_HIP(hipStreamSynchronize(st));
     c->cur.swap(c->nxt);

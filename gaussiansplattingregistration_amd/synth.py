@@ -130,10 +130,12 @@ def make_cloud_torch(n: int, seed: int = 0, device="cuda:0", sh_degree: int = 3,
     R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                      2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
                      2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).view(n, 3, 3)
-    L = R * s[:, None, :]
-    C = L @ L.transpose(1, 2)
-    cov6 = torch.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1).contiguous()
-    del R, L, C
+    # Sigma = R diag(s^2) R^T written out element-wise: a batched matmul (torch.bmm) with more than 2^24 batches faults
+    # on this ROCm build, and the large-cloud runs (20 M, 40 M splats) go past that
+    s2 = s * s
+    cc = lambda a, b: (R[:, a, :] * R[:, b, :] * s2).sum(1)
+    cov6 = torch.stack([cc(0, 0), cc(0, 1), cc(0, 2), cc(1, 1), cc(1, 2), cc(2, 2)], 1).contiguous()
+    del R, s2
     col = torch.randn((n, 3), device=device, generator=g) * 0.5
     op = torch.randn((n,), device=device, generator=g) * 2.0
     sh = torch.randn((n, F), device=device, generator=g) * 0.1
@@ -149,6 +151,9 @@ def apply_rigid_torch(cloud: dict, T):
     out["xyz"] = (cloud["xyz"].double() @ R.T + t).float()
     c = cloud["cov6"].double()
     C = torch.stack([c[:, [0, 1, 2]], c[:, [1, 3, 4]], c[:, [2, 4, 5]]], 1)
-    C = R @ C @ R.T
+    n = C.shape[0]
+    D = (C.reshape(n * 3, 3) @ R.T).reshape(n, 3, 3)                       # C R^T as ONE (3n x 3) GEMM (no batched matmul:
+    C = (D.transpose(1, 2).reshape(n * 3, 3) @ R.T).reshape(n, 3, 3)       # torch.bmm faults past 2^24 batches here), then R (.)
+    C = C.transpose(1, 2)
     out["cov6"] = torch.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], 1).float().contiguous()
     return out
