@@ -7,9 +7,9 @@ Kept (same names / shapes): ``get_xyz (N,3)`` ``:56-57``, ``get_colors (N,3)`` `
 ``:141-153``, ``move_to_device`` ``:223-234``, ``clone_gaussian``, ``from_ply`` / ``save_ply`` (``:98-139,169-185``; own
 reader/writer in ``utils/ply_io.py``, ``plyfile`` is not needed).  ``from_arrays`` builds level 0 from raw arrays.
 
-``from_mixture`` does not run the reference's ``torch.linalg.eigh`` scaling/rotation rebuild
-(``:151-153,242-265``; the reference's own comment calls it unused) unless asked: registration only
-consumes xyz / covariance.
+``from_mixture`` runs the reference's scaling/rotation rebuild (``:151-153,242-265``: batched ``eigh``, axis matching,
+quaternions; the reference's own comment calls it unused) only when asked (``decompose=True``): registration only
+consumes xyz / covariance, and the rebuild is what ``save_ply`` of a down-sampled model needs.
 """
 from __future__ import annotations
 
@@ -25,6 +25,14 @@ def _t(a, device, shape=None):
     else:
         t = torch.as_tensor(np.asarray(a, dtype=np.float32), device=device)
     return t.reshape(shape) if shape is not None else t
+
+
+def _matrices_to_quaternions(R):
+    """(N,3,3) -> (N,4) (w, x, y, z), the trace formula the reference uses (``general_utils.py:94-100``; no branch for
+    w -> 0, as there)."""
+    w = torch.sqrt(1.0 + R[:, 0, 0] + R[:, 1, 1] + R[:, 2, 2]) * 0.5
+    d = 4.0 * w
+    return torch.stack((w, (R[:, 2, 1] - R[:, 1, 2]) / d, (R[:, 0, 2] - R[:, 2, 0]) / d, (R[:, 1, 0] - R[:, 0, 1]) / d), dim=-1)
 
 
 class GaussianModel:
@@ -122,9 +130,27 @@ class GaussianModel:
         self._opacity = _t(gaussian_mixture.opacities, self.device_name)
         self._covariance = _t(gaussian_mixture.covariance, self.device_name).view(n, 6)
         if decompose:
-            ev, evec = torch.linalg.eigh(self.get_full_covariance())
-            self._scaling, self._rotation = ev, evec
+            self._scaling, evec = self.decompose_covariance_matrix()
+            self._rotation = _matrices_to_quaternions(evec)
         return self
+
+    def decompose_covariance_matrix(self):
+        """Scaling / rotation of every component from its covariance (reference ``gaussian_model.py:242-265``): a batched
+        symmetric eigendecomposition, then eigenpair k goes to the slot of the coordinate axis its eigenvector is most
+        aligned with (row k of |V^T|, arg-max).  Two eigenvectors claiming the same axis overwrite each other in
+        eigenvalue order (the reference's ``scatter_`` leaves that case to the device; here it is deterministic), and an
+        unclaimed slot stays zero, as there.  Returns (values (N,3), vectors (N,3,3)); like the reference's, the
+        "scaling" is the eigenvalue itself, not its square root or logarithm."""
+        full = self.get_full_covariance()
+        ev, evec = torch.linalg.eigh(full)
+        slot = evec.transpose(1, 2).abs().argmax(dim=2)            # (N,3): axis claimed by eigenpair k
+        vals = torch.zeros_like(ev)
+        vecs = torch.zeros_like(evec)
+        rows = torch.arange(ev.shape[0], device=ev.device)
+        for k in range(3):                                         # ascending eigenvalue: the later claim wins
+            vals[rows, slot[:, k]] = ev[:, k]
+            vecs[rows, slot[:, k], :] = evec[:, k, :]
+        return vals, vecs
 
     def clone_gaussian(self):
         m = GaussianModel(self.device_name)

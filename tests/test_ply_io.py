@@ -50,3 +50,32 @@ def test_ascii_ply_and_rejects(tmp_path):
     import pytest
     with pytest.raises(ValueError):
         ply_io.load_gaussian_arrays(p)
+
+
+def test_from_mixture_decompose_and_save(tmp_path):
+    """from_mixture(decompose=True): eigenpairs matched to the coordinate axes and quaternions (reference
+    gaussian_model.py:151-153,242-265), enough to save a down-sampled model."""
+    c = synth.make_cloud(400, seed=4, sh_degree=1)
+
+    class Mix:
+        xyz, colors, features = c["xyz"], c["color"], c["sh"]
+        opacities, covariance = c["opacity"].reshape(-1, 1), c["cov6"]
+
+    g = GaussianModel("cpu").from_mixture(Mix, 1, decompose=True)
+    vals, vecs = g.decompose_covariance_matrix()
+    full = g.get_full_covariance()
+    ev, evec = torch.linalg.eigh(full)
+    claimed = evec.transpose(1, 2).abs().argmax(dim=2)
+    distinct = (claimed.sort(dim=1).values == torch.arange(3)).all(dim=1)          # every axis claimed exactly once
+    assert distinct.float().mean() > 0.5
+    # where the matching is a permutation: the same eigenvalues, and eigenvalue k / ROW k of eigh's matrix sit in the
+    # slot of the claimed axis (the reference scatters rows, gaussian_model.py:260-261)
+    assert torch.allclose(vals[distinct].sort(dim=1).values, ev[distinct], atol=1e-7)
+    rows = torch.arange(400)
+    for k in range(3):
+        assert torch.equal(vals[rows, claimed[:, k]][distinct], ev[:, k][distinct])
+        assert torch.equal(vecs[rows, claimed[:, k], :][distinct], evec[:, k, :][distinct])
+    assert g._scaling.shape == (400, 3) and g._rotation.shape == (400, 4)
+    out = tmp_path / "mix.ply"
+    g.save_ply(str(out))
+    assert ply_io.read_ply_vertices(out).shape[0] == 400
