@@ -152,6 +152,44 @@ class GaussianModel:
             vecs[rows, slot[:, k], :] = evec[:, k, :]
         return vals, vecs
 
+    # -- rigid motion and merge (reference ``gaussian_model.py:198-222,267-290``) ---------------------------------
+    def transform_gaussian_model(self, transformation_matrix):
+        """Apply a rigid 4x4 to positions, covariances and rotation quaternions, in place.  (SH coefficients are left
+        as they are, as in the reference.)"""
+        T = torch.as_tensor(transformation_matrix, dtype=torch.float32, device=self._xyz.device)
+        R, t = T[:3, :3], T[:3, 3]
+        self._xyz = self._xyz @ R.T + t
+        n = len(self)
+        C = self.get_full_covariance()
+        # R C R^T as two (3n x 3) GEMMs (a batched matmul with > 2^24 batches faults on this ROCm build)
+        D = (C.reshape(n * 3, 3) @ R.T).reshape(n, 3, 3)
+        C = (D.transpose(1, 2).reshape(n * 3, 3) @ R.T).reshape(n, 3, 3).transpose(1, 2)
+        self._covariance = torch.stack([C[:, 0, 0], C[:, 0, 1], C[:, 0, 2], C[:, 1, 1], C[:, 1, 2], C[:, 2, 2]], dim=1)
+        if self._rotation.numel():
+            qr = _matrices_to_quaternions(R[None])[0]                       # (w, x, y, z) of the motion
+            w0, x0, y0, z0 = self._rotation.unbind(-1)
+            w1, x1, y1, z1 = qr
+            q = torch.stack((w1 * w0 - x1 * x0 - y1 * y0 - z1 * z0,          # Hamilton product, reference operand order (:198-208)
+                             w1 * x0 + x1 * w0 + y1 * z0 - z1 * y0,
+                             w1 * y0 - x1 * z0 + y1 * w0 + z1 * x0,
+                             w1 * z0 + x1 * y0 - y1 * x0 + z1 * w0), dim=-1)
+            self._rotation = q / torch.linalg.vector_norm(q, dim=-1, keepdim=True)
+        return self
+
+    @staticmethod
+    def get_merged_gaussian_point_clouds(gaussian1, gaussian2, transformation_matrix):
+        """``gaussian1`` moved by the registration result, concatenated with ``gaussian2`` (the merged-cloud save)."""
+        g1 = gaussian1
+        if transformation_matrix is not None and not np.array_equal(np.asarray(transformation_matrix), np.eye(4)):
+            g1 = gaussian1.clone_gaussian()
+            g1.transform_gaussian_model(np.asarray(transformation_matrix, dtype=np.float32))
+        assert gaussian1.sh_degree == gaussian2.sh_degree
+        m = GaussianModel(gaussian2.device_name)
+        m.sh_degree = gaussian1.sh_degree
+        for name in ("_xyz", "_rotation", "_scaling", "_features_dc", "_features_rest", "_opacity", "_covariance"):
+            setattr(m, name, torch.cat((getattr(g1, name).to(gaussian2.device_name), getattr(gaussian2, name))))
+        return m
+
     def clone_gaussian(self):
         m = GaussianModel(self.device_name)
         m.sh_degree = self.sh_degree

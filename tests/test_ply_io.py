@@ -79,3 +79,29 @@ def test_from_mixture_decompose_and_save(tmp_path):
     out = tmp_path / "mix.ply"
     g.save_ply(str(out))
     assert ply_io.read_ply_vertices(out).shape[0] == 400
+
+
+def test_transform_and_merge_models():
+    """transform_gaussian_model / get_merged_gaussian_point_clouds (reference gaussian_model.py:198-222,267-290)."""
+    a = synth.make_cloud(300, seed=5, sh_degree=1)
+    b = synth.make_cloud(200, seed=6, sh_degree=1)
+    mk = lambda c: GaussianModel("cpu").from_arrays(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"], 1)
+    ga, gb = mk(a), mk(b)
+    q = np.random.default_rng(1).normal(size=(300, 4)).astype(np.float32)
+    ga._rotation = torch.from_numpy(q / np.linalg.norm(q, axis=1, keepdims=True))
+    ga._scaling = torch.zeros(300, 3)
+    gb._rotation, gb._scaling = torch.zeros(200, 4), torch.zeros(200, 3)
+    T = synth.rigid_transform(20.0, (1, -2, 0.5), (0.3, -0.1, 0.2))
+    m = GaussianModel.get_merged_gaussian_point_clouds(ga, gb, T)
+    assert len(m) == 500 and torch.equal(m.get_xyz[300:], gb.get_xyz) and torch.equal(ga.get_xyz, torch.from_numpy(a["xyz"]))
+    want_xyz = a["xyz"].astype(np.float64) @ T[:3, :3].T + T[:3, 3]
+    assert np.allclose(m.get_xyz[:300].numpy(), want_xyz, atol=1e-5)
+    want = synth.apply_rigid(a, T)["cov6"]
+    assert np.allclose(m.get_covariance(1)[:300].numpy(), want, rtol=1e-4, atol=1e-7)
+    # the quaternion of the moved splat = motion o original orientation
+    R0 = synth._quat_to_rot(ga._rotation.double().numpy())
+    R1 = synth._quat_to_rot(m._rotation[:300].double().numpy())
+    assert np.allclose(R1, T[:3, :3] @ R0, atol=1e-5)
+    # identity: no copy, plain concatenation
+    m2 = GaussianModel.get_merged_gaussian_point_clouds(ga, gb, np.eye(4))
+    assert torch.equal(m2.get_xyz[:300], ga.get_xyz)
