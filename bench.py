@@ -159,7 +159,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=5_000_000, help="splats per cloud")
+    ap.add_argument("--splats", "--n", dest="n", type=int, default=5_000_000, help="splats per cloud (use --splats under torchrun: its parser claims --n)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -179,6 +179,8 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: this backend has no CPU fallback")
     device = local_rank if world > 1 else 0
+    if os.environ.get("GSR_BENCH_SAME_DEVICE"):          # test hook: several ranks on one GPU (with GSR_DIST_BACKEND=gloo)
+        device = 0
     torch.cuda.set_device(device)
     dev = torch.device("cuda", device)
 
@@ -208,10 +210,11 @@ def main():
     sync(); barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        rdev = dev if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
-        agg = torch.tensor([sum(r["hem_s"] for r in runs), sum(r["icp_s"] for r in runs)], dtype=torch.float64, device=dev)
+        agg = torch.tensor([sum(r["hem_s"] for r in runs), sum(r["icp_s"] for r in runs)], dtype=torch.float64, device=rdev)
         torch.distributed.all_reduce(agg, op=torch.distributed.ReduceOp.MAX)
         hem_s, icp_s = float(agg[0]), float(agg[1])
     else:
