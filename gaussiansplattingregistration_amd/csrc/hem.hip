@@ -1460,14 +1460,15 @@ void rng_polymul(const unsigned* a, const unsigned* b, unsigned* out) {
     for (int d = 0; d < 31; ++d) out[d] = prod[d];
 }
 const unsigned* rng_xpow_table() {
-    static unsigned tab[48 * 31];
-    static bool ready = false;
-    if (!ready) {
-        for (int j = 0; j < 31; ++j) tab[j] = j == 1 ? 1u : 0u;                 // x^1
-        for (int b = 1; b < 48; ++b) rng_polymul(tab + (b - 1) * 31, tab + (b - 1) * 31, tab + b * 31);
-        ready = true;
-    }
-    return tab;
+    struct Table {                       // function-local static: initialised once, thread-safely (C++11)
+        unsigned tab[48 * 31];
+        Table() {
+            for (int j = 0; j < 31; ++j) tab[j] = j == 1 ? 1u : 0u;             // x^1
+            for (int b = 1; b < 48; ++b) rng_polymul(tab + (b - 1) * 31, tab + (b - 1) * 31, tab + b * 31);
+        }
+    };
+    static const Table t;
+    return t.tab;
 }
 
 // draw n parent flags for `lv` in order (consumes n hem::rand() values)
