@@ -671,62 +671,70 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
         for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
         scanned += (unsigned long long)total;
         if (MODE == SEL_SPANS) continue;
-        // Row streaming with lane groups: a row's span is contiguous, so a group of GS lanes walks it
-        // with plain strided indices (no per-candidate search); 64/GS rows are in flight at once.
-        // GS adapts to the mean row length of the batch: short rows (small parents) -> 16 lanes.
-        // The kernel is latency bound (one 1-KiB load per wave in flight = ~20 KB per CU), so the
-        // loads of SEL_U consecutive row steps are issued back to back before any is consumed.
-        const int gshift = total >= 40 * nrb ? 6 : (total >= 20 * nrb ? 5 : 4);
-        const int gsz = 1 << gshift, gl = lane & (gsz - 1), gi = lane >> gshift, ng = 64 >> gshift;
-        int maxlen = len;
-        for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(maxlen, o); maxlen = t > maxlen ? t : maxlen; }
-        for (int k0 = 0; k0 < maxlen; k0 += gsz) {
-            const int k = k0 + gl;
-            for (int r0 = 0; r0 < nrb; r0 += SEL_U * ng) {
-                float4 ca[SEL_U];
-                int jj[SEL_U];
-                unsigned long long actm[SEL_U];
+        // Flattened streaming: the candidates of the batch's rows form one index space [0, total); lane l of chunk t
+        // handles candidate c = t + l and finds its row by a binary search over the rows' exclusive prefix sums (six
+        // lane shuffles).  Every lane of every chunk but the last is busy.  (Measured: with one lane group per row and
+        // the loop bounded by the LONGEST row of the batch, rows + stage 1 took 4.85 of the kernel's 7.05 ms at 5 M -- the
+        // ellipsoid's edge rows are short and 9 of 10 lane slots were idle.)  The loads of SEL_U consecutive chunks are
+        // issued back to back before any is consumed.
+        int pre = len;                                      // inclusive prefix over the lanes (rows are packed to the front)
+        for (int o = 1; o < 64; o <<= 1) {
+            const int t = __shfl_up(pre, o);
+            if (lane >= o) pre += t;
+        }
+        pre -= len;                                         // exclusive; rows >= nrb hold `total`
+        for (int t0 = 0; t0 < total; t0 += 64 * SEL_U) {
+            float4 ca[SEL_U];
+            int jj[SEL_U];
+            unsigned long long actm[SEL_U];
 #pragma unroll
-                for (int u = 0; u < SEL_U; ++u) {
-                    const int rr = (r0 + u * ng + gi) & 63;
-                    const int rs = __shfl(s, rr), rl = __shfl(len, rr);
-                    const bool act = (r0 + u * ng + gi) < nrb && k < rl;
-                    actm[u] = __ballot(act);
-                    if (IRR) jj[u] = act ? (int)a.ipos[rs + k] : pr.js;
-                    else jj[u] = act ? rs + k : pr.js;   // inactive lanes load a valid dummy record: an UNCONDITIONAL
-                    ca[u] = a.A[jj[u]];               // load lets the SEL_U loads overlap (a branch per load would
-                }                                     // make hipcc wait vmcnt(0) after each one)
+            for (int u = 0; u < SEL_U; ++u) {
+                const int c = t0 + 64 * u + lane;
+                const bool act = c < total;
+                actm[u] = __ballot(act);
+                const int cc = act ? c : 0;
+                int row = 0;                                // largest row with pre[row] <= cc
 #pragma unroll
-                for (int u = 0; u < SEL_U; ++u) {
-                    if (actm[u] == 0ull) continue;
-                    bool in = false;
-                    if ((actm[u] >> lane) & 1ull) {
-                        const f3 cm = {ca[u].x, ca[u].y, ca[u].z};
-                        const f3 dq = sub3(pm, cm);                   // query - point (pointindex.cpp:137)
-                        in = dot3(dq, dq) < pr.R2;
-                        if (!IRR) {
-                            in = in && (__float_as_uint(ca[u].w) & 2u);   // irregular children belong to pass B
-                            if (in) {                                     // regular child: Mahalanobis pre-reject
-                                const f3 d = sub3(cm, pm);
-                                const float smd = dot3(d, mul6(pr.pinv, d));   // gaussian.hpp:82-85, as kld6 computes it
-                                in = !(smd > pr.smdMax);
-                            }
+                for (int step = 32; step > 0; step >>= 1) {
+                    const int probe = row | step;
+                    row = __shfl(pre, probe) <= cc ? probe : row;
+                }
+                const int rs = __shfl(s, row), rp = __shfl(pre, row);
+                const int k = rs + (cc - rp);
+                if (IRR) jj[u] = act ? (int)a.ipos[k] : pr.js;
+                else jj[u] = act ? k : pr.js;            // inactive lanes load a valid dummy record: an UNCONDITIONAL
+                ca[u] = a.A[jj[u]];                      // load lets the SEL_U loads overlap (a branch per load would
+            }                                            // make hipcc wait vmcnt(0) after each one)
+#pragma unroll
+            for (int u = 0; u < SEL_U; ++u) {
+                if (actm[u] == 0ull) continue;
+                bool in = false;
+                if ((actm[u] >> lane) & 1ull) {
+                    const f3 cm = {ca[u].x, ca[u].y, ca[u].z};
+                    const f3 dq = sub3(pm, cm);                   // query - point (pointindex.cpp:137)
+                    in = dot3(dq, dq) < pr.R2;
+                    if (!IRR) {
+                        in = in && (__float_as_uint(ca[u].w) & 2u);   // irregular children belong to pass B
+                        if (in) {                                     // regular child: Mahalanobis pre-reject
+                            const f3 d = sub3(cm, pm);
+                            const float smd = dot3(d, mul6(pr.pinv, d));   // gaussian.hpp:82-85, as kld6 computes it
+                            in = !(smd > pr.smdMax);
                         }
                     }
-                    const unsigned long long m = __ballot(in);
-                    if (m == 0ull) continue;
-                    if (in) q[(qh + qn + __popcll(m & ((1ull << lane) - 1ull))) & (SEL_QCAP - 1)] = (unsigned)jj[u];
-                    qn += __popcll(m);
                 }
-                // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
-                __builtin_amdgcn_wave_barrier();
-                while (qn >= 64) {
-                    select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base, q3);
-                    qh = (qh + 64) & (SEL_QCAP - 1);
-                    qn -= 64;
-                }
-                __builtin_amdgcn_wave_barrier();
+                const unsigned long long m = __ballot(in);
+                if (m == 0ull) continue;
+                if (in) q[(qh + qn + __popcll(m & ((1ull << lane) - 1ull))) & (SEL_QCAP - 1)] = (unsigned)jj[u];
+                qn += __popcll(m);
             }
+            // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
+            __builtin_amdgcn_wave_barrier();
+            while (qn >= 64) {
+                select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base, q3);
+                qh = (qh + 64) & (SEL_QCAP - 1);
+                qn -= 64;
+            }
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (writing && lane == 0) a.rown[p] = (unsigned)written;
