@@ -3,7 +3,7 @@
 # One SQ counter pass over a short script; prints the per-launch averages of the kernels whose name contains the substring.
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; KSUB=$2; shift; shift
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $OUT -- python3 "$@" > $OUT.log 2>&1; tail -3 $OUT.log
+rocprofv3 --kernel-trace --pmc ${PMC:-SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS} --output-format csv -d $OUT -- python3 "$@" > $OUT.log 2>&1; tail -3 $OUT.log
 cd $GRAFT_REPO_ROOT
 python3 - "$OUT" "$KSUB" <<'PY'
 import csv, glob, sys, collections
