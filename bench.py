@@ -108,6 +108,22 @@ def pmc_traffic(kernel_prefix):
     return None, None
 
 
+def pmc_valu(kernel_prefix):
+    """VALU instructions per launch of the dominant kernel and the share of the launch they occupy (SQ_INSTS_VALU x 4
+    cycles / 1024 SIMDs against SQ_WAVE-independent wall cycles at 2.4 GHz), from the newest committed PMC summary."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename)
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        for k, v in d.items():
+            if k.startswith(kernel_prefix) and "SQ_INSTS_VALU_per_launch" in v:
+                return float(v["SQ_INSTS_VALU_per_launch"]), os.path.basename(f)
+    return None, None
+
+
 def cpu_baseline():
     """The reference's own extension (or the oracle port) on this box's host cores, bounded sample."""
     from gaussiansplattingregistration_amd import synth
@@ -260,6 +276,9 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src,
                          "avg_launch_ms": avg_ms, "launches": int(len(fill_ms)), "avg_units_per_launch": float(n_in.mean()),
                          "bytes_per_unit": B_GEOM,
+                         "valu": (lambda vi: None if vi[0] is None else {
+                             "insts_per_launch": vi[0], "source": vi[1],
+                             "busy_frac_at_2.4GHz": vi[0] * 4.0 / 1024.0 / (avg_ms * 1e-3 * 2.4e9)})(pmc_valu("gsr::k_select<2")),
                          "note": "VALU-bound neighbour evaluation (about 240 candidate tests and 80 KL divergences per splat; PMC: VALUBusy 94 %), not HBM-bound: see DESIGN.md section 4",
                          "level1": {"algorithmic_bytes": float(lvl_bytes), "ms": float(lvl_ms),
                                     "achieved_GBps": float(lvl_bytes / (lvl_ms * 1e-3) / 1e9),
