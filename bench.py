@@ -56,7 +56,7 @@ def hot_path_step(ctxs, lru, PointCloud, src, tgt, device, sync):
     m.set_rng("glibc", 1, 0)                       # a fresh reference process: cloud 1 then cloud 2 on one stream
     for c in (src, tgt):
         lv = [PointCloud(xyz32=c["xyz"], cov6=c["cov6"])]
-        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"], borrow=True)     # inputs resident in HBM: read in place
         for _ in range(LEVELS):
             m.run_level()
             st = m.stats()

@@ -1431,6 +1431,9 @@ struct gsr_hem_ctx {
     unsigned rng_base[31];          // y_{-31..-1} of the seeded glibc stream
     bool rng_ready = false;
     Level cur, nxt, tmp;
+    // level 0 borrowed from the caller (gsr_hem_set_level0, on_device = 2): `spare` keeps cur's own five big buffers meanwhile
+    bool cur_borrowed = false;
+    DevBuf spare[5];
     bool have_level = false;
     // workspace
     DevBuf hist, iflag, irank, ipos, rng_blocks, rowcap, rowoff, rown, rows;
@@ -1579,6 +1582,21 @@ int bits_for(int64_t n) {
 
 }  // namespace
 
+
+namespace {
+// cur.{xyz,color,cov6,opacity,sh} <-> the caller's arrays (borrowed) / the context's own buffers (spare)
+inline DevBuf* level_big(Level& L, int i) { DevBuf* b[5] = {&L.xyz, &L.color, &L.cov6, &L.opacity, &L.sh}; return b[i]; }
+void unborrow_level0(gsr_hem_ctx* c) {
+    if (!c->cur_borrowed) return;
+    for (int i = 0; i < 5; ++i) {
+        DevBuf* b = level_big(c->cur, i);
+        b->p = nullptr; b->cap = 0;                 // the caller's memory: never freed here
+        b->swap(c->spare[i]);
+    }
+    c->cur_borrowed = false;
+}
+}  // namespace
+
 extern "C" {
 
 const char* gsr_last_error(void) { return last_error().c_str(); }
@@ -1629,6 +1647,8 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
 int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
+    unborrow_level0(c);
+    for (DevBuf& b : c->spare) b.release();
     c->cur.release(); c->nxt.release(); c->tmp.release();
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
@@ -1677,7 +1697,27 @@ int32_t gsr_hem_set_level0(gsr_hem_ctx* c, const float* xyz, const float* color,
     if (n > 0 && (!xyz || !color || !cov6 || !opacity || (F > 0 && !sh)))
         return fail(GSR_E_INVALID, "gsr_hem_set_level0: NULL array");
     GSR_HIP(hipSetDevice(c->device));
+    unborrow_level0(c);
     Level& L = c->cur;
+    if (on_device == 2 && n > 0) {
+        // borrow: no copy of the five big arrays (1.19 GB at 5 M splats); they must stay valid and unchanged until the
+        // next gsr_hem_run_level returns.  cap = SIZE_MAX makes every later reserve() on them a no-op.
+        const void* src[5] = {xyz, color, cov6, opacity, F > 0 ? sh : xyz};
+        for (int i = 0; i < 5; ++i) {
+            DevBuf* b = level_big(L, i);
+            b->swap(c->spare[i]);
+            b->p = const_cast<void*>(src[i]); b->cap = (size_t)-1;
+        }
+        c->cur_borrowed = true;
+        const size_t mm = (size_t)n;
+        GSR_TRY(L.weight.reserve(mm * 4)); GSR_TRY(L.is_parent.reserve(mm));
+        L.n = n; L.F = F;
+        hipLaunchKernelGGL(k_fill_const<float>, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, L.weight.as<float>(), 1.0f);
+        GSR_TRY(draw_flags(c, L));
+        GSR_HIP(hipStreamSynchronize(c->stream));
+        c->have_level = true;
+        return GSR_OK;
+    }
     GSR_TRY(L.reserve(n, F));
     L.n = n; L.F = F;
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
@@ -2154,6 +2194,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_CHECKPOINT("flags + validity");
     GSR_HIP(hipEventRecord(c->ev[5], st));
     GSR_HIP(hipStreamSynchronize(st));
+    unborrow_level0(c);                 // a borrowed level 0 goes back to the caller; cur gets its own buffers again
     c->cur.swap(c->nxt);
     c->stats[3] = dropped;
     c->stats[7] = c->cur.n;

@@ -56,6 +56,7 @@ class HemMixture:
         h = C.c_void_p()
         _lib.check(self._L.gsr_hem_create(C.byref(h), self.device, C.c_void_p(stream or 0)), "gsr_hem_create")
         self._h = h
+        self._borrowed = None
         _lib.check(self._L.gsr_hem_set_params(h, hem_reduction, distance_delta, color_delta, decay_rate), "gsr_hem_set_params")
         mode = {"glibc": _lib.GSR_RNG_GLIBC, "hash": _lib.GSR_RNG_HASH}[rng_mode]
         _lib.check(self._L.gsr_hem_set_rng(h, mode, rng_seed, rng_skip), "gsr_hem_set_rng")
@@ -112,8 +113,11 @@ class HemMixture:
         _lib.check(self._L.gsr_hem_set_shard(self._h, int(rank), int(world), self._shard_cb, None), "gsr_hem_set_shard")
 
     # -- level 0 -----------------------------------------------------------------------------------
-    def set_level0(self, xyz, colors, opacities, covariance, features):
-        """``MixtureLevel.CreateMixtureLevel`` argument order (``mixturelevel.hpp:17-22``)."""
+    def set_level0(self, xyz, colors, opacities, covariance, features, borrow=False):
+        """``MixtureLevel.CreateMixtureLevel`` argument order (``mixturelevel.hpp:17-22``).
+        ``borrow=True`` (device tensors only): the library reads the caller's tensors in place instead of copying them
+        (1.19 GB at 5 M splats); they must not change until the next ``run_level`` has returned -- this object keeps
+        references to them until then."""
         n = int(xyz.shape[0]) if hasattr(xyz, "shape") else len(xyz)
         if n == 0:
             F = 0
@@ -133,7 +137,9 @@ class HemMixture:
             raise RuntimeError("all level-0 arrays must live in the same place (all host or all device)")
         if dx and torch is not None:
             torch.cuda.current_stream(self.device).synchronize()
-        _lib.check(self._L.gsr_hem_set_level0(self._h, px, pc, pv, po, ps, n, F, 1 if dx else 0), "gsr_hem_set_level0")
+        mode = (2 if borrow else 1) if dx else 0
+        _lib.check(self._L.gsr_hem_set_level0(self._h, px, pc, pv, po, ps, n, F, mode), "gsr_hem_set_level0")
+        self._borrowed = (kx, kc, kv, ko, ks) if mode == 2 else None
         del kx, kc, kv, ko, ks
 
     def set_state(self, parent_mask=None, weight=None):
@@ -147,6 +153,7 @@ class HemMixture:
         """One ``createClusterLevel``.  Returns ``(n_out, n_dropped)``."""
         n_out, n_drop = C.c_int64(0), C.c_int64(0)
         _lib.check(self._L.gsr_hem_run_level(self._h, C.byref(n_out), C.byref(n_drop)), "gsr_hem_run_level")
+        self._borrowed = None                       # a borrowed level 0 has been consumed
         return int(n_out.value), int(n_drop.value)
 
     @property

@@ -76,7 +76,9 @@ int32_t gsr_hem_get_rng_position(gsr_hem_ctx* ctx, uint64_t* draws);
 
 /* Level 0: xyz[n*3], color[n*3] (SH DC), cov6[n*6] (xx,xy,xz,yy,yz,zz), opacity[n] (RAW logit),
  * sh[n*F] (SH rest, coefficient-major); float32.  Sets weight = 1 and draws the n initial parent
- * flags (Mixture::initMixture, mixture.cpp:287-333).  F may be 0 (sh may then be NULL). */
+ * flags (Mixture::initMixture, mixture.cpp:287-333).  F may be 0 (sh may then be NULL).
+ * on_device: 0 = host arrays (copied), 1 = device arrays (copied), 2 = device arrays BORROWED without a copy: they must
+ * stay valid and unchanged until the next gsr_hem_run_level (or gsr_hem_set_level0 / destroy) returns. */
 int32_t gsr_hem_set_level0(gsr_hem_ctx* ctx, const float* xyz, const float* color, const float* cov6,
                            const float* opacity, const float* sh, int64_t n, int32_t F, int32_t on_device);
 /* Override internal per-component state of the CURRENT level (either may be NULL):

@@ -427,3 +427,31 @@ def test_random_parameter_sweep_vs_oracle(oracle, seed):
                 _check_level(got, want[k], tag)
             else:
                 _check_level_mostly(got, want[k], tag)
+
+
+@pytest.mark.gpu
+def test_borrowed_level0_equals_copied():
+    """set_level0(borrow=True) reads the caller's device tensors in place: identical levels to the copying path, the
+    caller's tensors untouched, and the context still usable afterwards (its own buffers come back after the level)."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud_torch(300000, seed=9)
+    ref = {k: c[k].clone() for k in ("xyz", "color", "opacity", "cov6", "sh")}
+    outs = []
+    for borrow in (False, True, True):
+        with hem.HemMixture() as m:
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"], borrow=borrow)
+            lv = []
+            for _ in range(2):
+                m.run_level()
+                lv.append(m.get_level())
+            # the same context takes another (copied) cloud afterwards
+            m.set_rng("glibc", 1, 0)
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+            m.run_level()
+            lv.append(m.get_level())
+        outs.append(lv)
+    for k in ("xyz", "color", "opacity", "cov6", "sh"):
+        assert torch.equal(c[k], ref[k])
+        for lvl in range(3):
+            assert np.array_equal(outs[0][lvl][k], outs[1][lvl][k]) and np.array_equal(outs[1][lvl][k], outs[2][lvl][k])
+    assert np.array_equal(outs[0][0]["xyz"], outs[0][2]["xyz"])          # the re-run after reset reproduces level 1
