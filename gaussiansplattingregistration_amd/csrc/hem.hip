@@ -1004,6 +1004,105 @@ __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restr
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Per-child sums of wL without sorting the pairs (the 3-pass radix sort of 10^8 pairs cost 2.4 of a level's 17 ms).
+// Children are grouped in buckets of SUM_BUCKET consecutive sorted positions.  k_bucket_hist / k_bucket_scatter
+// partition the pairs by bucket (a counting sort; the order INSIDE a bucket is whatever the atomics make it), then one
+// workgroup per bucket accumulates its pairs in LDS.  The sums are nevertheless deterministic: every child's terms
+// are added as 64-bit integers on a per-child fixed-point scale (2^38 steps of the child's largest term, found by a
+// first pass of LDS max operations), and integer addition does not care about order.  Terms below 2^-38 of the
+// largest are lost (the float32 sequential sum of the reference loses them below 2^-24); the total is rounded to
+// float32 once.  Non-finite terms: the sum is NaN if any term is NaN or both infinities occur, else that infinity.
+// ------------------------------------------------------------------------------------------------
+#define SUM_BUCKET_SHIFT 13
+#define SUM_BUCKET (1 << SUM_BUCKET_SHIFT)        // children per bucket: 8192 x (4 + 8) bytes = 96 KiB of LDS
+#define SUM_TILE 16384                            // pairs per workgroup of the partition kernels
+
+__global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, const unsigned* __restrict__ child, int nb, unsigned* __restrict__ hist) {
+    extern __shared__ unsigned s_h[];
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s_h[b] = 0u;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * SUM_TILE, hi = lo + SUM_TILE < M ? lo + SUM_TILE : M;
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_h[child[k] >> SUM_BUCKET_SHIFT], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += blockDim.x)
+        if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
+}
+// bucket offsets are 64-bit (10^9 pairs at 40 M splats); cursor[b] starts at the bucket's first slot
+__global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, const unsigned* __restrict__ child, const float* __restrict__ wl, int nb,
+                                                        unsigned long long* __restrict__ cursor, unsigned* __restrict__ o_child,
+                                                        float* __restrict__ o_wl) {
+    extern __shared__ unsigned s_h[];              // [nb] counts, then [nb] (lo, hi) words of the reserved base
+    unsigned* s_cnt = s_h;
+    unsigned long long* s_base = (unsigned long long*)(s_h + ((nb + 1) & ~1));
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s_cnt[b] = 0u;
+    __syncthreads();
+    const int64_t lo = (int64_t)blockIdx.x * SUM_TILE, hi = lo + SUM_TILE < M ? lo + SUM_TILE : M;
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_cnt[child[k] >> SUM_BUCKET_SHIFT], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+        const unsigned cnt = s_cnt[b];
+        s_base[b] = cnt ? atomicAdd(&cursor[b], (unsigned long long)cnt) : 0ull;      // this workgroup's run in bucket b
+        s_cnt[b] = 0u;
+    }
+    __syncthreads();
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
+        const unsigned ch = child[k];
+        const int b = (int)(ch >> SUM_BUCKET_SHIFT);
+        const unsigned long long pos = s_base[b] + atomicAdd(&s_cnt[b], 1u);
+        o_child[pos] = ch;
+        o_wl[pos] = wl[k];
+    }
+}
+__global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, const unsigned long long* __restrict__ bstart, const unsigned* __restrict__ child,
+                                                     const float* __restrict__ wl, float* __restrict__ sumLw, int* __restrict__ orphan_flag) {
+    extern __shared__ unsigned long long s_acc[];  // [SUM_BUCKET] int64 accumulators, then [SUM_BUCKET] max bit patterns
+    unsigned* s_max = (unsigned*)(s_acc + SUM_BUCKET);
+    const int b = blockIdx.x;
+    const int64_t c0 = (int64_t)b << SUM_BUCKET_SHIFT;
+    const int nc = (int)(n - c0 < SUM_BUCKET ? n - c0 : SUM_BUCKET);
+    for (int i = threadIdx.x; i < SUM_BUCKET; i += blockDim.x) { s_acc[i] = 0ull; s_max[i] = 0u; }
+    __syncthreads();
+    const unsigned long long k0 = bstart[b], k1 = bstart[b + 1];
+    for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x)
+        atomicMax(&s_max[child[k] - (unsigned)c0], __float_as_uint(wl[k]) & 0x7fffffffu);        // |wL| as an ordered integer
+    __syncthreads();
+    for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+        const unsigned i = child[k] - (unsigned)c0;
+        const float w = wl[k];
+        const unsigned mb = s_max[i];
+        if (mb >= 0x7f800000u) {                   // a non-finite term somewhere: collect flags (1 +inf, 2 -inf, 4 NaN)
+            const unsigned wb = __float_as_uint(w);
+            const unsigned long long f = (wb & 0x7fffffffu) > 0x7f800000u ? 4ull : (wb == 0x7f800000u ? 1ull : (wb == 0xff800000u ? 2ull : 0ull));
+            if (f) atomicOr(&s_acc[i], f);
+            continue;
+        }
+        int e = (int)(mb >> 23);
+        e = e < 1 ? 1 : e;                         // subnormal maximum: the scale of the smallest normal exponent
+        const int k2 = 38 - (e - 127);             // q = w * 2^k2,  |q| <= 2^39
+        const double scale = __longlong_as_double((long long)(1023 + k2) << 52);
+        const long long q = __double2ll_rn((double)w * scale);
+        atomicAdd(&s_acc[i], (unsigned long long)q);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) {
+        const unsigned mb = s_max[i];
+        float sres;
+        if (mb >= 0x7f800000u) {
+            const unsigned long long f = s_acc[i];
+            sres = (f & 4ull) || ((f & 1ull) && (f & 2ull)) ? __builtin_nanf("") : ((f & 1ull) ? __builtin_inff() : -__builtin_inff());
+        } else {
+            int e = (int)(mb >> 23);
+            e = e < 1 ? 1 : e;
+            const int k2 = 38 - (e - 127);
+            const double inv = __longlong_as_double((long long)(1023 - k2) << 52);
+            sres = (float)((double)(long long)s_acc[i] * inv);
+        }
+        sumLw[c0 + i] = sres;
+        orphan_flag[c0 + i] = sres == 0.0f ? 1 : 0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_orphan_flags(int64_t n, const float* __restrict__ sumLw, int* __restrict__ orphan_flag) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
         orphan_flag[j] = sumLw[j] == 0.0f ? 1 : 0;
@@ -1436,7 +1535,8 @@ struct gsr_hem_ctx {
     DevBuf spare[5];
     bool have_level = false;
     // workspace
-    DevBuf hist, iflag, irank, ipos, rng_blocks, rowcap, rowoff, rown, rows;
+    DevBuf hist, iflag, irank, ipos, rng_blocks, rowcap, rowoff, rown, rows, bhist, bstart, bcursor;
+    bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
     unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, morder, nparts, vstart, vparent, vpart, vcap, vcnt;
@@ -1636,6 +1736,8 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_MORTON")) c->use_morton = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_XCD")) c->use_xcd = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
+    (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_BUCKET * 12);
     if (const char* s = getenv("GSR_HEM_ROWCACHE")) c->use_rowcache = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->wpb = v; }
     if (const char* s = getenv("GSR_HEM_WPB_M")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb_m = v; }
@@ -1653,7 +1755,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->rowcap, &c->rowoff, &c->rown, &c->rows, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->rowcap, &c->rowoff, &c->rown, &c->rows, &c->bhist, &c->bstart, &c->bcursor, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -2064,15 +2166,32 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 
     // ---- 3. per-child sums of wL (deterministic: stable sort by child, sequential sum) ----------
     GSR_TRY(c->cstart.reserve(((size_t)n + 1) * 8)); GSR_TRY(c->sumLw.reserve(n * 4)); GSR_TRY(c->oflag.reserve(n * 4));
-    if (M > 0) {
-        GSR_TRY(sort_pairs<float>(c, c->pair_child.as<unsigned>(), c->spair_child.as<unsigned>(), c->pair_wl.as<float>(),
-                                  c->spair_wl.as<float>(), M, bits_for(n)));
-        GSR_CHECKPOINT("pair sort");
-        hipLaunchKernelGGL(k_run_starts<int64_t>, dim3(stride_grid(M)), blk, 0, st, M, c->spair_child.as<unsigned>(), n, c->cstart.as<int64_t>());
+    const int nbuckets = (int)((n + SUM_BUCKET - 1) >> SUM_BUCKET_SHIFT);
+    if (c->sum_bucket && M > 0 && nbuckets <= 8192) {
+        // partition by bucket (counting sort), then one workgroup per bucket sums in LDS on a fixed-point scale
+        GSR_TRY(c->bhist.reserve(((size_t)nbuckets + 1) * 4)); GSR_TRY(c->bstart.reserve(((size_t)nbuckets + 1) * 8));
+        GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
+        GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
+        const int ntiles = (int)((M + SUM_TILE - 1) / SUM_TILE);
+        hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, c->pair_child.as<unsigned>(), nbuckets, c->bhist.as<unsigned>());
+        GSR_TRY(widen_scan(c->bhist.as<unsigned>(), (int64_t*)c->bstart.p, nbuckets + 1));
+        GSR_HIP(hipMemcpyAsync(c->bcursor.p, c->bstart.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)(((nbuckets + 1) & ~1) * 4 + nbuckets * 8), st, M, c->pair_child.as<unsigned>(),
+                           c->pair_wl.as<float>(), nbuckets, c->bcursor.as<unsigned long long>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
+        GSR_CHECKPOINT("pair partition");
+        hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(1024), (size_t)SUM_BUCKET * 12, st, n, c->bstart.as<unsigned long long>(),
+                           c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
     } else {
-        hipLaunchKernelGGL(k_fill_const<int64_t>, grd, blk, 0, st, n + 1, c->cstart.as<int64_t>(), (int64_t)0);
+        if (M > 0) {
+            GSR_TRY(sort_pairs<float>(c, c->pair_child.as<unsigned>(), c->spair_child.as<unsigned>(), c->pair_wl.as<float>(),
+                                      c->spair_wl.as<float>(), M, bits_for(n)));
+            GSR_CHECKPOINT("pair sort");
+            hipLaunchKernelGGL(k_run_starts<int64_t>, dim3(stride_grid(M)), blk, 0, st, M, c->spair_child.as<unsigned>(), n, c->cstart.as<int64_t>());
+        } else {
+            hipLaunchKernelGGL(k_fill_const<int64_t>, grd, blk, 0, st, n + 1, c->cstart.as<int64_t>(), (int64_t)0);
+        }
+        hipLaunchKernelGGL(k_sumlw, dim3(stride_grid(n * 8)), blk, 0, st, n, c->cstart.as<int64_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
     }
-    hipLaunchKernelGGL(k_sumlw, dim3(stride_grid(n * 8)), blk, 0, st, n, c->cstart.as<int64_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
     if (sharded) {
         // exchange 1: every rank holds the sums over ITS parents; the total decides responsibilities and orphans
         GSR_HIP(hipStreamSynchronize(st));

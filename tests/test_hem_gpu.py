@@ -455,3 +455,40 @@ def test_borrowed_level0_equals_copied():
         for lvl in range(3):
             assert np.array_equal(outs[0][lvl][k], outs[1][lvl][k]) and np.array_equal(outs[1][lvl][k], outs[2][lvl][k])
     assert np.array_equal(outs[0][0]["xyz"], outs[0][2]["xyz"])          # the re-run after reset reproduces level 1
+
+
+@pytest.mark.gpu
+def test_bucketed_sums_equal_sorted_sums(monkeypatch):
+    """The per-child sums of wL by bucket partition + LDS fixed point (default) against the radix-sort path
+    (GSR_HEM_SUMLW=sort): same discrete outcome, components equal to float32 summation noise -- including children
+    whose parents carry zero, tiny, huge, infinite and NaN weights -- and bit-identical from run to run."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(120000, seed=12, h=1.6, sh_degree=1)
+    rng = np.random.default_rng(3)
+    w = np.ones(120000, np.float32)
+    idx = rng.permutation(120000)
+    w[idx[:200]] = 0.0
+    w[idx[200:400]] = 1e-30
+    w[idx[400:600]] = 1e30
+    w[idx[600:620]] = np.inf
+    w[idx[620:640]] = np.nan
+    w[idx[640:660]] = -1.0                       # garbage input: negative weights
+    res = {}
+    for mode in ("bucket", "sort", "bucket"):
+        monkeypatch.setenv("GSR_HEM_SUMLW", mode)
+        with hem.HemMixture() as m:
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+            m.set_state(weight=w)
+            m.run_level()
+            st = m.stats()
+            res.setdefault(mode, []).append((st, m.get_level(with_state=True)))
+    (sa, a), (sb, b), (sa2, a2) = res["bucket"][0], res["sort"][0], res["bucket"][1]
+    for k in ("parents", "pairs", "orphans", "dropped", "n_out"):
+        assert sa[k] == sb[k] == sa2[k], k
+    for k in ("xyz", "color", "cov6", "opacity", "sh", "weight"):
+        assert np.array_equal(a[k], a2[k], equal_nan=True), k                      # run-to-run: bit-identical
+        x, y = a[k].astype(np.float64), b[k].astype(np.float64)
+        assert np.array_equal(np.isnan(x), np.isnan(y)) and np.array_equal(np.isinf(x), np.isinf(y)), k
+        ok = np.isfinite(x)
+        scale = np.abs(y[ok]).max() + 1e-30
+        assert np.abs(x[ok] - y[ok]).max() <= 2e-5 * scale, (k, np.abs(x[ok] - y[ok]).max() / scale)
