@@ -2179,8 +2179,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)(((nbuckets + 1) & ~1) * 4 + nbuckets * 8), st, M, c->pair_child.as<unsigned>(),
                            c->pair_wl.as<float>(), nbuckets, c->bcursor.as<unsigned long long>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
         GSR_CHECKPOINT("pair partition");
+        (void)hipGetLastError();
         hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(1024), (size_t)SUM_BUCKET * 12, st, n, c->bstart.as<unsigned long long>(),
                            c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
+        if (hipGetLastError() != hipSuccess) {      // 96 KiB of dynamic LDS refused: never seen on gfx950, but do not compute garbage
+            c->sum_bucket = false;
+            return fail(GSR_E_HIP, "k_bucket_sum could not be launched (dynamic LDS); set GSR_HEM_SUMLW=sort");
+        }
     } else {
         if (M > 0) {
             GSR_TRY(sort_pairs<float>(c, c->pair_child.as<unsigned>(), c->spair_child.as<unsigned>(), c->pair_wl.as<float>(),
