@@ -1536,6 +1536,7 @@ struct gsr_hem_ctx {
     bool have_level = false;
     // workspace
     DevBuf hist, iflag, irank, ipos, rng_blocks, rowcap, rowoff, rown, rows, bhist, bstart, bcursor;
+    bool reuse_order = true, morder_is_porder = false;      // GSR_HEM_REUSE_ORDER=0: the M-step sorts its own order
     bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
     unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
@@ -1737,6 +1738,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_XCD")) c->use_xcd = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
+    if (const char* s = getenv("GSR_HEM_REUSE_ORDER")) c->reuse_order = atoi(s) != 0;
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_BUCKET * 12);
     if (const char* s = getenv("GSR_HEM_ROWCACHE")) c->use_rowcache = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->wpb = v; }
@@ -2146,7 +2148,12 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         }
         c->sparse_path = sparse;
         // M-step processing order: heavy parents (by accepted pairs) first, the rest in Z-order
-        if (c->use_lpt && M > 0) {
+        c->morder_is_porder = false;
+        if (c->use_lpt && M > 0 && c->reuse_order && sparse && !split) {
+            // the selection's order (heavy by candidates scanned, then Z-order) serves the M-step too: parents with many
+            // candidates are the ones with many pairs; saves a key pass, a 32-bit sort and a count per level
+            c->morder_is_porder = true;
+        } else if (c->use_lpt && M > 0) {
             const unsigned thr = (unsigned)(8.0 * (double)M / (double)P) + 1u;
             hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcnt.as<unsigned>(), thr, c->plist.as<unsigned>(),
                                (const unsigned*)nullptr, c->A.as<float4>(), c->gparams.as<GridParams>(), c->use_morton ? 1 : 0,
@@ -2245,9 +2252,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
         ma.own_lo = own_lo; ma.own_hi = own_hi;
-        ma.porder = (c->use_lpt && M > 0) ? c->morder.as<unsigned>() : nullptr;
+        ma.porder = (c->use_lpt && M > 0) ? (c->morder_is_porder ? c->porder.as<unsigned>() : c->morder.as<unsigned>()) : nullptr;
         ma.xcd = (c->use_xcd && ma.porder) ? 1 : 0;
-        ma.nheavy = c->counters.as<int>() + 9;
+        ma.nheavy = c->counters.as<int>() + (c->morder_is_porder ? 8 : 9);
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
         switch (c->wpb_m) {
