@@ -615,7 +615,7 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float*
         const double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
         acc[0] += 1.0;
         acc[1] += d2;
-        if (KIND == 0) {
+        if constexpr (KIND == 0) {
             const double ax = px - g.cx, ay = py - g.cy, az = pz - g.cz;
             const double bx = qx - g.cx, by = qy - g.cy, bz = qz - g.cz;
             acc[2] += ax; acc[3] += ay; acc[4] += az;
@@ -623,9 +623,9 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float*
             acc[8] += ax * bx; acc[9] += ax * by; acc[10] += ax * bz;
             acc[11] += ay * bx; acc[12] += ay * by; acc[13] += ay * bz;
             acc[14] += az * bx; acc[15] += az * by; acc[16] += az * bz;
-        } else if (KIND == 2) {
+        } else if constexpr (KIND == 2) {
             icp_gicp_rows<NACC>(acc, T.m, px, py, pz, qx, qy, qz, Sc + 6 * i, Tn + 6 * (int64_t)j, loss, kparam);
-        } else if (KIND == 3) {
+        } else if constexpr (KIND == 3) {
             icp_colored_rows<NACC>(acc, ca, px, py, pz, qx, qy, qz, Tn[3 * (int64_t)j], Tn[3 * (int64_t)j + 1], Tn[3 * (int64_t)j + 2], i, j, loss, kparam);
         } else {
             const double nx = Tn[3 * (int64_t)j], ny = Tn[3 * (int64_t)j + 1], nz = Tn[3 * (int64_t)j + 2];
@@ -952,7 +952,7 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
         const double d2 = ddx * ddx + ddy * ddy + ddz * ddz;
         acc[0] += 1.0;
         acc[1] += d2;
-        if (KIND == 0) {
+        if constexpr (KIND == 0) {
             const double ax = px - g.cx, ay = py - g.cy, az = pz - g.cz;
             const double bx = qx - g.cx, by = qy - g.cy, bz = qz - g.cz;
             acc[2] += ax; acc[3] += ay; acc[4] += az;
@@ -960,9 +960,9 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
             acc[8] += ax * bx; acc[9] += ax * by; acc[10] += ax * bz;
             acc[11] += ay * bx; acc[12] += ay * by; acc[13] += ay * bz;
             acc[14] += az * bx; acc[15] += az * by; acc[16] += az * bz;
-        } else if (KIND == 2) {
+        } else if constexpr (KIND == 2) {
             icp_gicp_rows<NACC>(acc, T, px, py, pz, qx, qy, qz, Sc + 6 * i, Tn + 6 * (int64_t)j, loss, kparam);
-        } else if (KIND == 3) {
+        } else if constexpr (KIND == 3) {
             icp_colored_rows<NACC>(acc, ca, px, py, pz, qx, qy, qz, Tn[3 * (int64_t)j], Tn[3 * (int64_t)j + 1], Tn[3 * (int64_t)j + 2], i, j, loss, kparam);
         } else {
             const double nx = Tn[3 * (int64_t)j], ny = Tn[3 * (int64_t)j + 1], nz = Tn[3 * (int64_t)j + 2];
