@@ -13,19 +13,25 @@
 //       Rs[j] query radius, shs[j][F] SH rest, cellStart[cells+1] prefix table of a dense uniform grid
 //   pair list (parent-major CSR): pair_child[M] (sorted position), pair_wl[M] (w_s * clamp(L_si))
 //
-// Kernels (HBM-bound streaming unless noted):
-//   k_prep            det, query radius (closed-form eigenvalue, f64 trig), bounding box
+// Kernels of one level (DESIGN.md section 4 has the measurements):
+//   k_prep            det, regular flag, one packed 64-byte record per component (input order), bounding box partials
+//   k_hist / k_grid_params   robust grid box (0.1 % trimmed per side), ~8 components per cell
 //   k_keys / sort     cell key per component, radix sort (rocPRIM) -> order[]
-//   k_gather / k_gather_sh   build the sorted working set
-//   k_select<COUNT|FILL>   one wavefront per parent: row spans of the grid that meet the query
-//                     sphere, exact radius test, colour gate, KL gate (bit-exact float32 maths, see
-//                     gsr_math.h), parent rule; FILL also evaluates the likelihood.  VALU-bound.
-//   sort pairs by child (rocPRIM, stable) + k_sumlw: per-child sum of wL in parent order --
-//                     deterministic, no float atomics
-//   k_mstep           one wavefront per parent: responsibilities, wave-shuffle reductions of the
-//                     1+3+3+6+1 moment sums, lane-per-coefficient accumulation of the SH rows
+//   k_gather / k_gather_sh   the cell-sorted working set (+ parent radius: closed-form eigenvalue, f64 trig)
+//   k_spans           candidates every parent will scan (capacity of its output segment, LPT work estimate)
+//   k_select<SPARSE|COUNT|FILL>   one wavefront per parent: grid rows clipped to the pre-reject ellipsoid, flattened
+//                     candidate stream -> stage 1 (radius test, Mahalanobis pre-reject) -> LDS ring -> stage 2 (colour
+//                     gate, KL gate, parent rule; bit-exact float32 maths, gsr_math.h) -> LDS queue -> stage 3
+//                     (likelihood, pair records).  VALU bound.
+//   k_compact_pairs   sparse segments -> parent-major CSR
+//   k_bucket_hist / k_bucket_scatter / k_bucket_sum   per-child sums of wL: counting sort into buckets of 8192
+//                     children, then LDS accumulation on a per-child fixed-point scale -- deterministic without a sort
+//                     (GSR_HEM_SUMLW=sort: rocPRIM stable sort by child + k_sumlw)
+//   k_mstep           one wavefront per parent: responsibilities, wave-shuffle reductions of the 1+3+3+6+1 moment
+//                     sums, SH rows fetched four children per load (16 lanes x float4 per row)
 //   k_orphans*, k_valid, k_compact   orphans, validity erase, output in the reference's order
 //                     (parents by ascending input index, then orphans by ascending input index)
+//   k_rng_block_state / k_flags_glibc   the next level's parent flags from the libc rand() stream
 //
 // Any conservative neighbour search is legal: the reference's candidate set is exactly
 // { i : |mu_i - mu_s|^2 < R_s^2 } (its 27-cell scan with cell >= R_s loses nothing), and that test
