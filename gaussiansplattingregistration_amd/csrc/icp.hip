@@ -16,8 +16,14 @@
 //                           partials; k_icp_finalize sums the partials in a fixed order.
 //                           No per-point writes; algorithmic bytes 24 (point-to-point) or
 //                           48 (point-to-plane, float64 normals) per source point.
-//   host (this file)        3x3 Jacobi SVD (Umeyama) or 6x6 LDL^T solve in float64 on 32 doubles,
-//                           convergence test, optional all-reduce callback for multi-GPU source splits.
+//   k_icp_nn                the search alone (thread per point, 56 VGPRs): used with a streaming accumulate kernel
+//                           for sources of >= 10^6 points, where occupancy decides (the search is latency bound)
+//   estimators              point-to-point (Umeyama), point-to-plane, generalized ICP (W = (Ct + R Cs R^T)^-1/2 per
+//                           pair, float64 Jacobi), colored ICP (k_icp_color_gradient prepares the target: 30 nearest
+//                           neighbours within 2 max_corr, tangent-plane intensity gradient); robust kernel weights
+//   k_icp_step              device-resident loop: reduces the partials, tests convergence, solves (3x3 Jacobi SVD /
+//                           6x6 LDL^T) and updates T; the host enqueues chunks of iterations
+//   host (this file)        the same solve for the multi-GPU source split (all-reduce callback of 32 doubles).
 //
 // Accumulator layout (GSR_ICP_ACC_LEN = 32 doubles), see include/gsr_hip.h.
 #include "gsr_common.h"
