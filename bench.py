@@ -236,6 +236,23 @@ def main():
     else:
         hem_s, icp_s = sum(r["hem_s"] for r in runs), sum(r["icp_s"] for r in runs)
 
+    # measured device-copy bandwidth of this very GPU (SURVEY 8d asks for the fraction of both the nominal and a measured
+    # figure): 1 GiB device-to-device, read + write traffic
+    copy_gbs = None
+    if rank == 0:
+        try:
+            src_t = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+            dst_t = torch.empty_like(src_t)
+            dst_t.copy_(src_t); sync()
+            tc = time.perf_counter()
+            for _ in range(5):
+                dst_t.copy_(src_t)
+            sync()
+            copy_gbs = 5 * 2.0 * src_t.numel() * 4 / (time.perf_counter() - tc) / 1e9
+            del src_t, dst_t
+        except Exception:
+            copy_gbs = None
+
     if rank == 0:
         hem_gauss = sum(r["hem_gaussians"] for r in runs) * world
         icp_iters = sum(r["icp_iters"] for r in runs) * world
@@ -274,6 +291,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "k_select<SPARSE> (child selection + likelihood, one wavefront per parent)",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
                          "avg_launch_ms": avg_ms, "launches": int(len(fill_ms)), "avg_units_per_launch": float(n_in.mean()),
                          "bytes_per_unit": B_GEOM,
                          "valu": (lambda vi: None if vi[0] is None else {
