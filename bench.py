@@ -128,7 +128,7 @@ def cpu_baseline():
     """The reference's own extension (or the oracle port) on this box's host cores, bounded sample."""
     from gaussiansplattingregistration_amd import synth
     cores = os.cpu_count() or 1
-    n = 50000
+    n = 500000                     # ~10-20 s on the host cores (the reference slows down per splat as clouds grow)
     cloud = synth.make_cloud(n, seed=0)
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     have_ref = os.path.isdir(ref_dir) and any(f.startswith("mixture_bind") for f in os.listdir(ref_dir))
