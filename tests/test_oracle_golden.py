@@ -67,3 +67,15 @@ def test_oracle_stats_and_conservation(oracle):
     orph = lv1["xyz"][P:]
     assert all(any(np.array_equal(x, y) for y in lv0["xyz"]) for x in orph[:5])
     o.close()
+
+
+def test_survey_known_answers_of_the_reference(oracle):
+    """Numbers the survey measured on the reference's own extension: 100 k splats in the +-1.5 box ->
+    33 142 components (33 120 parents, 3 889 315 accepted pairs); 20 k splats in the +-5 box -> 16 177 / 13 719."""
+    from gaussiansplattingregistration_amd import synth
+    ka = json.load(open(os.path.join(GOLDEN, "known_answers.json")))
+    w, st = oracle.hem(synth.make_cloud(100000, seed=0, h=1.5), 1)
+    s8 = ka["survey_8c"]["n100000_h1.5_seed0"]
+    assert (w[0]["xyz"].shape[0], st[0]["parents"], st[0]["pairs"]) == (s8["n_out"], s8["parents"], s8["pairs"])
+    w, _ = oracle.hem(synth.make_cloud(20000, seed=0, h=5.0), 2)
+    assert [x["xyz"].shape[0] for x in w] == ka["counts_only"]["n20000_h5.0_seed0"]
