@@ -67,8 +67,12 @@ SIGNATURES = {
     "gsr_normals_from_cov": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     "gsr_icp_solve": (_i32, [_vp, _i32, _vp, _vp]),
     "gsr_icp_get_centre": (_i32, [_vp, _vp]),
+}
+# private test hooks (csrc/gsr_test_hooks.h): exported by the library, not part of the public header
+TEST_HOOKS = {
     "gsr_debug_logf": (_i32, [_vp, _i64, _vp, _i32]),
     "gsr_debug_kld": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32]),
+    "gsr_debug_kl_gate": (_i32, [_vp, _vp, _i64, _f32, _vp, _vp, _vp, _i32]),
 }
 
 _lib = None
@@ -86,7 +90,7 @@ def load(require_device: bool = False):
             lib = C.CDLL(LIB_PATH)
         except OSError as e:  # pragma: no cover - depends on the machine
             raise RuntimeError(f"HIP extension failed to load ({LIB_PATH}): {e}.  This backend has no CPU fallback.") from e
-        for name, (res, args) in SIGNATURES.items():
+        for name, (res, args) in list(SIGNATURES.items()) + list(TEST_HOOKS.items()):
             fn = getattr(lib, name)          # AttributeError here = header/library mismatch
             fn.restype = res
             fn.argtypes = args

@@ -38,6 +38,7 @@
 // is re-evaluated here with the same float expression.
 #include "gsr_common.h"
 #include "gsr_math.h"
+#include "gsr_test_hooks.h"
 
 #include <float.h>
 #include <math.h>
@@ -417,20 +418,29 @@ __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __re
 // ------------------------------------------------------------------------------------------------
 // k_select: child selection (mixture.cpp:102-137) and wL_si (mixture.cpp:140-164), one wavefront per parent
 //
-//   rows      the grid rows (fixed y,z cell) that meet the query sphere; lane r of a 64-row batch
-//             computes the contiguous span [s,e) of sorted components of its row, x-clipped to the sphere
-//   stream    a row's span is contiguous in the sorted arrays: groups of 16/32/64 lanes (chosen per
-//             batch from the mean row length) each walk one row with strided indices, 4/2/1 rows in
-//             flight -- no per-candidate search, coalesced 16-byte loads
-//   stage 1   exact radius test  d2 < R^2  (pointindex.cpp:137); survivors are compacted (ballot +
-//             popcount) into a per-wave LDS queue
-//   stage 2   whenever the queue holds >= 64 survivors: colour gate, KL gate, parent rule on 64
-//             survivors at once (the expensive part runs on full waves), likelihood for the accepted
+//   rows      the grid rows (fixed y,z cell) that meet the parent's search region; lane r of a 64-row batch computes
+//             the contiguous span [s, s+len) of sorted components of its row (x-clipped to the sphere, and to the
+//             pre-reject ellipsoid for a regular parent)
+//   stream    the spans of a batch form one flattened index space [0, total); lane l of chunk c0 handles candidate
+//             c0 + l.  Its row comes from a BIT MASK in LDS (bit p set <=> a row starts at flat position p): one
+//             broadcast 8-byte LDS read per chunk and two v_mbcnt give every lane the number of row starts at or
+//             before it, one ds_bpermute fetches that row's (start - prefix).  (The six-step binary search by lane
+//             shuffles this replaces was a chain of six DEPENDENT ds_bpermute per chunk: 24 cycles of LDS-pipe issue
+//             each, scripts/micro/valu_issue.hip.)
+//   stage 1   a conservative filter, not a decision: for a regular parent the squared Mahalanobis distance in
+//             whitened form |U d|^2 (U = Cholesky factor of P^-1, nine fused multiply-adds) against the pre-reject
+//             bound + 1 %; for an irregular parent, and for the irregular children (pass B), the reference's own
+//             radius test.  Survivors are compacted (ballot + mbcnt) into a per-wave LDS ring.
+//   stage 2   on full batches of 64 survivors, the reference's float32 expressions bit for bit: radius test
+//             d2 < R^2 (pointindex.cpp:137), colour gate, KL gate, parent rule (mixture.cpp:122-133).  The KL gate's
+//             logf is decided with the hardware v_log_f32 when the result is farther from the threshold than its
+//             error bound, and with glibc's own algorithm (gsr_math.h) otherwise -- the decision is the reference's
+//             in both cases.  Accepted pairs go to a second LDS queue.
+//   stage 3   likelihood (mixture.cpp:54-64) on full batches of 64 accepted pairs, pair records out.
 //   modes     COUNT  only counts accepted pairs (first pass of the two-pass fallback)
 //             FILL   writes pairs at poff[p]  (second pass of the fallback)
-//             SPARSE single pass: writes pairs at coff[p] (capacity = candidates scanned, from
-//                    k_select<SPANS>), count to pcnt[p]; k_compact_pairs then packs them
-//             SPANS  only sums the span lengths (capacity for SPARSE)
+//             SPARSE single pass: writes pairs at coff[p] (capacity = candidates scanned, from k_spans), count to
+//                    pcnt[p]; k_compact_pairs then packs them
 // ------------------------------------------------------------------------------------------------
 struct SelectArgs {
     const float4 *A, *B, *C, *D;
@@ -439,21 +449,9 @@ struct SelectArgs {
     const unsigned* porder;         // processing order of the parents (heavy ones first), or NULL = natural order
     int xcd;                        // 1 = light parents are dealt to the XCDs in contiguous chunks (block_slot)
     const int* nheavy;              // device: number of heavy parents at the head of porder
-    // Work items.  A heavy parent is split into several items, each taking every nparts-th batch of 64 grid
-    // rows; NI items in all (NI == P and vparent == NULL when nothing is split).  pcap / pcnt / poff are
-    // indexed by ITEM in the SPANS / SPARSE / COUNT / FILL modes.
-    int NI;
     int own_lo, own_hi;             // sharded level: this rank evaluates parents [own_lo, own_hi) of plist only
-    const unsigned* vparent;        // item -> parent index (into plist)
-    const unsigned* vpart;          // item -> part | (nparts << 16)
     const int* cellStart;
-    // Row cache: the first SPANS launch (rows_write = 1) stores the non-empty grid rows (start, length) of every
-    // parent's regular pass; every later launch of the level reads them back instead of recomputing the clipping.
     const double* logtab;           // glibc logf table (LDS copy)
-    int2* rows;                     // NULL = no cache (rows are recomputed by every launch)
-    const int64_t* rowoff;          // parent -> first slot in rows
-    unsigned* rown;                 // parent -> number of cached rows
-    int rows_write;
     const int* irank;               // irank[j] = number of irregular components among sorted positions [0, j)   (n + 1 entries)
     const unsigned* ipos;           // sorted positions of the irregular components, ascending
     int n_irr;
@@ -462,27 +460,53 @@ struct SelectArgs {
     int P;
     float colorThr, kldThr, tau2;
     unsigned* pcnt;                 // COUNT / SPARSE out: accepted pairs per parent
-    unsigned* pcap;                 // SPANS out: candidates scanned per parent
+    unsigned* pcap;                 // k_spans out: candidates scanned per parent
     const int64_t* poff;            // FILL: compact offsets;  SPARSE: capacity offsets
     unsigned* pair_child;
     float* pair_wl;
 };
 
-enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2, SEL_SPANS = 3 };
+enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
 #define SEL_QCAP 512          // survivor ring (power of two >= 64 + SEL_U*64)
-#define SEL_U 4            // row steps whose candidate loads are in flight together
+#define SEL_U 4               // chunks whose candidate loads are in flight together
+#define SEL_MCAP 2048         // flat positions covered by the row-start bit mask at a time
+#define SEL_PAD (64 * SEL_U)  // entries the sorted A array is padded by: the inactive lanes of a batch's last chunks read past the last row
 
 struct ParentRec {
     f3 pm, pcol;
     s6 pinv;
     float det_p, pweight, R2;
-    float smdMax;      // stage-1 pre-reject bound on the squared Mahalanobis distance (+inf = disabled)
+    float white;       // 1.0f = stage 1 uses the whitened Mahalanobis filter (regular parent)
+    float u00, u01, u02, u11, u12, u22;   // upper Cholesky factor of pinv
+    float T1;          // filter bound on |U d|^2: the pre-reject bound + 1 %
     int js;
 };
 
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }       // v_sqrt_f32, 1 ulp: clipping margins only
+
+// popc(mask & lanes below this one) + base, two VALU instructions
+__device__ __forceinline__ int mbcnt64(unsigned long long mask, int base) {
+    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)base));
+}
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+           (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
+// inclusive prefix sum over the 64 lanes by DPP row shifts / row broadcasts (six VALU instructions, no LDS traffic);
+// every lane must be active
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2, 3
+    return v;
+}
+
 // Third-stage queue (per wave, in LDS): the accepted pairs wait here until 64 of them fill a wavefront, so that
 // the likelihood (two expf, two sqrtf, two IEEE divisions) runs on full waves instead of the ~26 % of the lanes
-// that pass the KL gate.  (The kernel is VALU bound: 94 % VALUBusy in the PMC pass of round r01b.)
+// that pass the KL gate.
 #define SEL_Q3CAP 128
 struct Q3 {
     unsigned* j;
@@ -507,8 +531,31 @@ __device__ __forceinline__ void select_stage3(const SelectArgs& a, const ParentR
     q3.n -= cnt;
 }
 
-// stage 2 on up to 64 queued survivors (lane < cnt holds one): colour gate, KL gate, parent rule; accepted pairs
-// go to the third-stage queue.
+// KL gate decision  KLD(child, parent) > thr  (gaussian.hpp:106-109, mixture.cpp:126-129) with
+//     k = 0.5f * (((smd + tr) - 3.0f) - logf(q)),   q = det_c / det_p,   s2 = (smd + tr) - 3.0f  as the reference rounds it.
+// v_log_f32 (1 ulp of log2 q, plus the rounding of the product with ln 2) puts lf within 3e-7 (1 + |ln q|) of ln q and
+// glibc's logf within 1 ulp of it, so k computed with lf differs from the reference's k by less than
+// 0.5 (4e-7 (1 + |lf|) + 2 ulp(s2 - lf)) < 1e-6 (1 + |lf| + |s2|) / 2: outside that margin around thr both give the same
+// decision; inside it (and for q not a positive normal number, or s2 not finite) the exact algorithm runs.
+// tests/test_hem_gpu.py::test_fast_log_margin checks the bound on the device.
+__device__ __forceinline__ bool kl_gate_rejects(float s2, float qd, float thr, const double* logtab, float* lf_out = nullptr,
+                                                bool* exact_out = nullptr) {
+    const float lf = __builtin_amdgcn_logf(qd) * 0.6931471805599453f;
+    const float kf = 0.5f * (s2 - lf);
+    const float margin = 1e-6f * (1.0f + fabsf(lf) + fabsf(s2));
+    bool reject = kf > thr;
+    const bool need_exact = !(qd >= FLT_MIN && qd <= FLT_MAX) || !(fabsf(s2) <= FLT_MAX) || !(fabsf(kf - thr) > margin);
+    if (need_exact) {
+        const float k = 0.5f * (s2 - glibc_logf_tab(qd, logtab));
+        reject = k > thr;
+    }
+    if (lf_out) *lf_out = lf;
+    if (exact_out) *exact_out = need_exact;
+    return reject;
+}
+
+// stage 2 on up to 64 queued survivors (lane < cnt holds one): radius test, colour gate, KL gate, parent rule -- the
+// reference's decisions, every expression in its operand order; accepted pairs go to the third-stage queue.
 template <int MODE>
 __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, const unsigned* q, int qh,
                                               unsigned& count, int64_t& base, Q3& q3) {
@@ -520,19 +567,18 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
         const float4 ca = a.A[j], cb = a.B[j], cc = a.C[j], cd = a.D[j];   // all four up front: one round trip
         const f3 cm = {ca.x, ca.y, ca.z};
         const f3 ccol = {cc.z, cc.w, cd.x};
+        const f3 d = sub3(cm, pr.pm);
+        d2 = dot3(d, d);                                      // == dot(pm - cm, pm - cm) bit for bit (pointindex.cpp:137)
         const f3 dc = sub3(ccol, pr.pcol);                    // ColorDelta(child, parent), gaussian.hpp:111-114
         cdiff = sqrtf(dot3(dc, dc));
-        if (!(cdiff > a.colorThr)) {                          // mixture.cpp:122-124
+        if (d2 < pr.R2 && !(cdiff > a.colorThr)) {            // radiusSearch (strict), mixture.cpp:122-124
             const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
             det_c = cd.w;
             op = cd.y;
-            const f3 d = sub3(cm, pr.pm);
-            d2 = dot3(d, d);                                  // == dot(pm - cm, pm - cm) bit for bit
             const float smd = dot3(d, mul6(pr.pinv, d));      // gaussian.hpp:82-85
             const float tr = trace_prod6(pr.pinv, ccov);
-            const float k = 0.5f * (smd + tr - 3.0f - glibc_logf_tab(det_c / pr.det_p, a.logtab));   // gaussian.hpp:106-109
-            const bool pass = !(k > a.kldThr);                // mixture.cpp:126-129 (NaN passes)
-            if (pass) {
+            const float s2 = smd + tr - 3.0f;                 // gaussian.hpp:106-109: 0.5f * (smd + tr - 3.0f - log(q))
+            if (!kl_gate_rejects(s2, det_c / pr.det_p, a.kldThr, a.logtab)) {      // mixture.cpp:126-129 (NaN passes)
                 const bool child_is_parent = (__float_as_uint(ca.w) & 1u) != 0u;
                 acc = !(child_is_parent && j != pr.js);       // mixture.cpp:131-133
             }
@@ -543,7 +589,7 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     count += (unsigned)na;
     if (MODE == SEL_COUNT || na == 0) return;
     if (acc) {
-        const int k = (q3.h + q3.n + __popcll(m & ((1ull << lane) - 1ull))) & (SEL_Q3CAP - 1);
+        const int k = mbcnt64(m, q3.h + q3.n) & (SEL_Q3CAP - 1);
         q3.j[k] = (unsigned)j; q3.d2[k] = d2; q3.cd[k] = cdiff; q3.op[k] = op; q3.det[k] = det_c;
     }
     q3.n += na;
@@ -553,7 +599,7 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
 }
 
 // Row clipping by the parent's pre-reject ellipsoid E = { x : (x-mu)^T P^-1 (x-mu) <= T }.  A regular child outside E
-// fails the stage-1 pre-reject anyway, so for a regular parent only the grid cells E touches need scanning (E is
+// fails the stage-1 filter anyway, so for a regular parent only the grid cells E touches need scanning (E is
 // inscribed in the query sphere and typically holds 1/3 of its volume).  For a row (= the slab dy in [cy-hy, cy+hy],
 // dz in [cz-hz, cz+hz] relative to the parent) write  smd = M00 (dx - xc(dy,dz))^2 + S(dy,dz)  with xc linear and
 // S the Schur-complement form K; sqrt(S) is a norm, so over the slab  sqrt(S) >= sqrt(S(c)) - sqrt(lmax(K)) |h|,
@@ -567,6 +613,7 @@ struct EllClip {
 // The span (first sorted position, length) of one grid row (ry, rz) for a parent at pm: the row's cells within the
 // sphere of radius sqrt(Ra2), clipped to the pre-reject ellipsoid when `clip`.  IRR: positions in the irregular list.
 // ONE definition shared by k_select (every mode) and k_spans: the capacities must equal what the passes scan.
+// (The square roots are the hardware's 1-ulp v_sqrt_f32: every one of them sits behind a margin of 1e-5 or more.)
 template <bool IRR>
 __device__ __forceinline__ void select_row_span(const SelectArgs& a, const GridParams& g, const f3& pm, const EllClip& ec, bool clip,
                                                 float Ra2, int x0, int x1, int ry, int rz, int& s, int& len) {
@@ -579,18 +626,18 @@ __device__ __forceinline__ void select_row_span(const SelectArgs& a, const GridP
     const float dz = fmaxf(0.0f, fmaxf(zlo - pm.z, pm.z - zhi));
     const float rem = Ra2 - dy * dy - dz * dz;
     if (rem >= 0.0f) {
-        const float hx = sqrtf(rem) * 1.00001f + g.slack;
+        const float hx = fast_sqrt(rem) * 1.00001f + g.slack;
         float lo = -hx, hi = hx;                                   // x interval relative to the parent
         if (clip && !edge) {
             const float cy = 0.5f * (ylo + yhi) - pm.y, cz = 0.5f * (zlo + zhi) - pm.z;
             const float hy = 0.5f * (yhi - ylo), hz = 0.5f * (zhi - zlo);
-            const float sc = sqrtf(fmaxf(0.0f, ec.k11 * cy * cy + 2.0f * ec.k12 * cy * cz + ec.k22 * cz * cz));
-            const float smin = fmaxf(0.0f, sc * 0.999f - ec.kr * sqrtf(hy * hy + hz * hz));
+            const float sc = fast_sqrt(fmaxf(0.0f, ec.k11 * cy * cy + 2.0f * ec.k12 * cy * cz + ec.k22 * cz * cz));
+            const float smin = fmaxf(0.0f, sc * 0.999f - ec.kr * fast_sqrt(hy * hy + hz * hz));
             const float rem2 = ec.T - smin * smin;
             if (rem2 < 0.0f) {
                 lo = 1.0f; hi = -1.0f;                             // the row misses the ellipsoid
             } else {
-                const float w = sqrtf(rem2 * ec.im00) * 1.001f;
+                const float w = fast_sqrt(rem2 * ec.im00) * 1.001f;
                 const float xc = -(ec.m01 * cy + ec.m02 * cz) * ec.im00;
                 const float dl = (fabsf(ec.m01) * hy + fabsf(ec.m02) * hz) * ec.im00 * 1.001f;
                 const float pad = g.slack + 1e-5f * fabsf(xc);
@@ -626,188 +673,158 @@ __device__ __forceinline__ EllClip make_ellclip(const s6& M, float smdMax, int e
     return ec;
 }
 
+// Whitened form of the stage-1 filter: M = U^T U (upper Cholesky factor), so d^T M d = |U d|^2 in nine fused
+// multiply-adds instead of the twenty multiplies and adds of the reference's expression.  Both evaluate the same
+// quadratic form of an SPD matrix with kappa < 80 to < 1e-3 relative, and the filter bound carries 1 % (the margin the
+// row clipping above already relies on), so nothing the exact KL gate of stage 2 could accept is dropped here.
+__device__ __forceinline__ void make_whitening(const s6& M, float smdMax, ParentRec& pr) {
+    const float u00 = sqrtf(M.e00), i00 = 1.0f / u00;
+    const float u01 = M.e01 * i00, u02 = M.e02 * i00;
+    const float t11 = M.e11 - u01 * u01;
+    const float u11 = sqrtf(t11), i11 = 1.0f / u11;
+    const float u12 = (M.e12 - u01 * u02) * i11;
+    const float t22 = M.e22 - u02 * u02 - u12 * u12;
+    const float u22 = sqrtf(t22);
+    const bool ok = smdMax < FLT_MAX && M.e00 > 0.0f && t11 > 0.0f && t22 > 0.0f && u00 < FLT_MAX && u11 < FLT_MAX && u22 < FLT_MAX &&
+                    i00 < FLT_MAX && i11 < FLT_MAX;
+    pr.u00 = u00; pr.u01 = u01; pr.u02 = u02; pr.u11 = u11; pr.u12 = u12; pr.u22 = u22;
+    pr.T1 = smdMax * 1.01f;
+    pr.white = ok ? 1.0f : 0.0f;
+}
+
 // One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
-// REGULAR ones (stage 1: radius test + Mahalanobis pre-reject); IRR = true scans the list of irregular components
-// (ipos, addressed through irank at the cell boundaries) with the radius test only.  Survivors go to the LDS ring.
-template <int MODE, bool IRR, bool CACHED>
+// REGULAR ones; IRR = true scans the list of irregular components (ipos, addressed through irank at the cell
+// boundaries).  Survivors of the stage-1 filter go to the LDS ring.
+template <int MODE, bool IRR>
 __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const EllClip& ec, float R,
-                                            int lane, int p, int part, int nparts, unsigned* q, int& qh, int& qn, unsigned& count,
-                                            unsigned long long& scanned, int64_t& base, Q3& q3) {
+                                            int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count,
+                                            int64_t& base, Q3& q3) {
     const f3 pm = pr.pm;
-    const bool writing = !IRR && !CACHED && MODE == SEL_SPANS && a.rows != nullptr && a.rows_write != 0;
-    constexpr bool cached = !IRR && CACHED;           // compile-time: the cached kernels carry no clipping code
-    int64_t rbase = 0;                                          // wave-uniform: keep it in SGPRs
-    if (!IRR && (CACHED || writing)) {
-        const int64_t v = a.rowoff[p];
-        rbase = ((int64_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-    }
-    int written = 0;
     const float Ra = fabsf(R) * 1.00001f + g.slack;             // conservative search extent
     const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
     const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
     const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-    const int nrows = __builtin_amdgcn_readfirstlane(cached ? (int)a.rown[p] : ny * nz);
+    const int nrows = __builtin_amdgcn_readfirstlane(ny * nz);
     const float Ra2 = Ra * Ra;
     const bool clip = !IRR && ec.on != 0.0f;
+    const bool white = !IRR && pr.white != 0.0f;                // wave-uniform
     for (int rb = 0; rb < nrows; rb += 64) {
-        if (nparts > 1 && ((rb >> 6) % nparts) != part) continue;      // this batch of rows belongs to another item
         const int r = rb + lane;
         int s = 0, len = 0;
-        if (cached) {
-            if (r < nrows) { const int2 v = a.rows[rbase + r]; s = v.x; len = v.y; }
-        } else if (r < nrows) {
-            select_row_span<IRR>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
-        }
-        // pack the non-empty rows to the front of the wave (the ellipsoid misses many rows of the bounding square)
+        if (r < nrows) select_row_span<IRR>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
+        len = len > 0 ? len : 0;
         const unsigned long long nz_m = __ballot(len > 0);
+        if (nz_m == 0ull) continue;
+        // flattened candidate space of the batch: row r covers flat positions [pre, pre + len)
+        const int incl = wave_incl_scan(len);
+        const int pre = incl - len;
+        const int total = __builtin_amdgcn_readlane(incl, 63);
+        // (start - prefix) of the q-th non-empty row goes to lane q (the empty rows take the lanes behind them: a permutation)
         const int nrb = __popcll(nz_m);
-        if (nrb == 0) continue;
-        if (!cached) {
-            const unsigned long long lt = (1ull << lane) - 1ull;
-            const int dst = len > 0 ? __popcll(nz_m & lt) : nrb + __popcll(~nz_m & lt);
-            s = __builtin_amdgcn_ds_permute(dst << 2, s);
-            len = __builtin_amdgcn_ds_permute(dst << 2, len);
-        }
-        if (writing) {
-            if (lane < nrb) a.rows[rbase + written + lane] = make_int2(s, len);
-            written += nrb;
-        }
-        int total = len;                                   // candidates of this batch of rows
-        for (int o = 32; o > 0; o >>= 1) total += __shfl_xor(total, o);
-        scanned += (unsigned long long)total;
-        if (MODE == SEL_SPANS) continue;
-        // Flattened streaming: the candidates of the batch's rows form one index space [0, total); lane l of chunk t
-        // handles candidate c = t + l and finds its row by a binary search over the rows' exclusive prefix sums (six
-        // lane shuffles).  Every lane of every chunk but the last is busy.  (Measured: with one lane group per row and
-        // the loop bounded by the LONGEST row of the batch, rows + stage 1 took 4.85 of the kernel's 7.05 ms at 5 M -- the
-        // ellipsoid's edge rows are short and 9 of 10 lane slots were idle.)  The loads of SEL_U consecutive chunks are
-        // issued back to back before any is consumed.
-        int pre = len;                                      // inclusive prefix over the lanes (rows are packed to the front)
-        for (int o = 1; o < 64; o <<= 1) {
-            const int t = __shfl_up(pre, o);
-            if (lane >= o) pre += t;
-        }
-        pre -= len;                                         // exclusive; rows >= nrb hold `total`
-        for (int t0 = 0; t0 < total; t0 += 64 * SEL_U) {
-            float4 ca[SEL_U];
-            int jj[SEL_U];
-            unsigned long long actm[SEL_U];
+        const int below = mbcnt64(nz_m, 0);
+        const int dst = len > 0 ? below : nrb + (lane - below);
+        const int delta = __builtin_amdgcn_ds_permute(dst << 2, s - pre);
+        for (int seg0 = 0; seg0 < total; seg0 += SEL_MCAP) {
+            const int rel = pre - seg0;
+            const bool mine = len > 0 && rel >= 0 && rel < SEL_MCAP;
+            if (mine) atomicOr(&bits[rel >> 6], 1ull << (rel & 63));
+            int rows_before = __popcll(__ballot(len > 0 && rel < 0));      // rows that start before this segment (uniform)
+            __builtin_amdgcn_wave_barrier();
+            const int seg_end = total < seg0 + SEL_MCAP ? total : seg0 + SEL_MCAP;
+            for (int t0 = seg0; t0 < seg_end; t0 += 64 * SEL_U) {
+                float4 ca[SEL_U];
+                int jj[SEL_U];
+                int left[SEL_U];                                              // active lanes of each chunk (uniform)
 #pragma unroll
-            for (int u = 0; u < SEL_U; ++u) {
-                const int c = t0 + 64 * u + lane;
-                const bool act = c < total;
-                actm[u] = __ballot(act);
-                const int cc = act ? c : 0;
-                int row = 0;                                // largest row with pre[row] <= cc
-#pragma unroll
-                for (int step = 32; step > 0; step >>= 1) {
-                    const int probe = row | step;
-                    row = __shfl(pre, probe) <= cc ? probe : row;
+                for (int u = 0; u < SEL_U; ++u) {
+                    const int c0 = t0 + 64 * u;                               // uniform
+                    // row of candidate c0 + lane = (row starts at flat positions <= c0 + lane) - 1
+                    const unsigned long long word = uniform64(bits[(c0 - seg0) >> 6]);     // broadcast read; the words behind the segment are zero
+                    const int row = mbcnt64(word >> 1, rows_before - 1 + (int)(word & 1ull));
+                    rows_before += __popcll(word);
+                    left[u] = seg_end - c0;
+                    const int k = c0 + lane + __builtin_amdgcn_ds_bpermute(row << 2, delta);
+                    // the inactive lanes behind the batch's last candidate read on past the last row: the sorted A array is
+                    // padded by SEL_PAD entries, so the load stays unconditional (a load under a branch would make hipcc
+                    // wait vmcnt(0) after each one instead of overlapping the SEL_U loads)
+                    if (IRR) jj[u] = lane < left[u] ? (int)a.ipos[k] : pr.js;
+                    else jj[u] = k;
+                    ca[u] = a.A[jj[u]];
                 }
-                const int rs = __shfl(s, row), rp = __shfl(pre, row);
-                const int k = rs + (cc - rp);
-                if (IRR) jj[u] = act ? (int)a.ipos[k] : pr.js;
-                else jj[u] = act ? k : pr.js;            // inactive lanes load a valid dummy record: an UNCONDITIONAL
-                ca[u] = a.A[jj[u]];                      // load lets the SEL_U loads overlap (a branch per load would
-            }                                            // make hipcc wait vmcnt(0) after each one)
 #pragma unroll
-            for (int u = 0; u < SEL_U; ++u) {
-                if (actm[u] == 0ull) continue;
-                bool in = false;
-                if ((actm[u] >> lane) & 1ull) {
+                for (int u = 0; u < SEL_U; ++u) {
+                    if (left[u] <= 0) continue;
                     const f3 cm = {ca[u].x, ca[u].y, ca[u].z};
-                    const f3 dq = sub3(pm, cm);                   // query - point (pointindex.cpp:137)
-                    in = dot3(dq, dq) < pr.R2;
-                    if (!IRR) {
-                        in = in && (__float_as_uint(ca[u].w) & 2u);   // irregular children belong to pass B
-                        if (in) {                                     // regular child: Mahalanobis pre-reject
-                            const f3 d = sub3(cm, pm);
-                            const float smd = dot3(d, mul6(pr.pinv, d));   // gaussian.hpp:82-85, as kld6 computes it
-                            in = !(smd > pr.smdMax);
-                        }
+                    bool in;
+                    if (white) {                                              // regular parent, regular children
+                        const f3 d = sub3(cm, pm);
+                        const float y2 = pr.u22 * d.z;
+                        const float y1 = __builtin_fmaf(pr.u11, d.y, pr.u12 * d.z);
+                        const float y0 = __builtin_fmaf(pr.u00, d.x, __builtin_fmaf(pr.u01, d.y, pr.u02 * d.z));
+                        const float smd = __builtin_fmaf(y0, y0, __builtin_fmaf(y1, y1, y2 * y2));
+                        in = !(smd > pr.T1);
+                    } else {                                                  // the reference's radius test (pointindex.cpp:137)
+                        const f3 dq = sub3(pm, cm);
+                        in = dot3(dq, dq) < pr.R2;
                     }
+                    if (!IRR) in = in && (__float_as_uint(ca[u].w) & 2u);     // irregular children belong to pass B
+                    in = in && lane < left[u];
+                    const unsigned long long m = __ballot(in);
+                    if (m == 0ull) continue;
+                    if (in) q[mbcnt64(m, qh + qn) & (SEL_QCAP - 1)] = (unsigned)jj[u];
+                    qn += __popcll(m);
                 }
-                const unsigned long long m = __ballot(in);
-                if (m == 0ull) continue;
-                if (in) q[(qh + qn + __popcll(m & ((1ull << lane) - 1ull))) & (SEL_QCAP - 1)] = (unsigned)jj[u];
-                qn += __popcll(m);
+                // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
+                __builtin_amdgcn_wave_barrier();
+                while (qn >= 64) {
+                    select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base, q3);
+                    qh = (qh + 64) & (SEL_QCAP - 1);
+                    qn -= 64;
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
-            __builtin_amdgcn_wave_barrier();
-            while (qn >= 64) {
-                select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base, q3);
-                qh = (qh + 64) & (SEL_QCAP - 1);
-                qn -= 64;
-            }
+            if (mine) bits[rel >> 6] = 0ull;                                  // leave the mask clean for the next segment / batch
             __builtin_amdgcn_wave_barrier();
         }
     }
-    if (writing && lane == 0) a.rown[p] = (unsigned)written;
 }
 
-// Upper bound of the grid rows a parent's search touches (the bounding square of its sphere): sizes the row cache.
-__device__ __forceinline__ int parent_row_bound(const GridParams& g, const f3& pm, float R) {
-    const bool pm_finite = fabsf(pm.x) <= FLT_MAX && fabsf(pm.y) <= FLT_MAX && fabsf(pm.z) <= FLT_MAX;
-    if (!(R * R > 0.0f) || !pm_finite) return 0;
-    const float Ra = fabsf(R) * 1.00001f + g.slack;
-    const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
-    const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
-    return (y1 - y0 + 1) * (z1 - z0 + 1);
-}
-__global__ __launch_bounds__(256) void k_rowcap(int P, const unsigned* __restrict__ plist, const float4* __restrict__ A,
-                                                const float* __restrict__ Rs, const GridParams* __restrict__ gpp, unsigned* __restrict__ rowcap) {
-    const GridParams g = *gpp;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const int js = (int)plist[p];
-        const float4 a = A[js];
-        const f3 pm = {a.x, a.y, a.z};
-        rowcap[p] = (unsigned)parent_row_bound(g, pm, Rs[js]);
-    }
-}
-
-// WPB = wavefronts (= parents) per workgroup (runtime choice, GSR_HEM_WPB).
-template <int MODE, int WPB, bool CACHED>
+// WPB = wavefronts (= parents) per workgroup.
+template <int MODE, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     __shared__ unsigned s_q[WPB][SEL_QCAP];
     __shared__ double s_logtab[32];
     __shared__ unsigned s_q3j[WPB][SEL_Q3CAP];
     __shared__ float s_q3f[WPB][4][SEL_Q3CAP];
+    __shared__ unsigned long long s_bits[WPB][SEL_MCAP / 64 + SEL_U];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (MODE != SEL_SPANS) {                       // every wave writes the same 32 values: no barrier needed
-        if (lane < 32) s_logtab[lane] = k_logf_tab[lane];
-        a.logtab = s_logtab;
-    }
-    const int nblk = (a.NI + WPB - 1) / WPB;
+    if (lane < 32) s_logtab[lane] = k_logf_tab[lane];       // every wave writes the same 32 values: no barrier needed
+    a.logtab = s_logtab;
+    if (lane < SEL_MCAP / 64 + SEL_U) s_bits[wv][lane] = 0ull;
+    const int nblk = (a.P + WPB - 1) / WPB;
     const int hb = a.nheavy ? (((*a.nheavy + WPB - 1) / WPB + 7) & ~7) : 0;
     const int bid = block_slot((int)blockIdx.x, nblk, hb < nblk ? hb : nblk, a.xcd);
     if (bid < 0) return;
     const int slot = bid * WPB + wv;
-    if (slot >= a.NI) return;
-    const int item = a.porder ? (int)a.porder[slot] : slot;
-    const int p = __builtin_amdgcn_readfirstlane(a.vparent ? (int)a.vparent[item] : item);
-    const unsigned vpi = a.vpart ? a.vpart[item] : (1u << 16);
-    const int part = (int)(vpi & 0xffffu), nparts = (int)(vpi >> 16);
+    if (slot >= a.P) return;
+    const int p = __builtin_amdgcn_readfirstlane(a.porder ? (int)a.porder[slot] : slot);
     if (p < a.own_lo || p >= a.own_hi) {          // another rank's parent: no work, no pairs
-        if (lane == 0) {
-            if (MODE == SEL_SPANS) { a.pcap[item] = 0u; if (a.rows && a.rows_write) a.rown[p] = 0u; }
-            else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[item] = 0u;
-        }
+        if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p] = 0u;
         return;
     }
     const GridParams g = *a.gp;
     ParentRec pr;
     pr.js = (int)a.plist[p];
+    float smdMax;
     {
         const float4 pa = a.A[pr.js], pb = a.B[pr.js], pc = a.C[pr.js], pd = a.D[pr.js];
         pr.pm = {pa.x, pa.y, pa.z};
         pr.det_p = pd.w;
-        // Stage-1 pre-reject (exactness argument in DESIGN.md "KL gate pre-reject"): for a regular parent
-        // and a regular child, tr(P^-1 C) - 3 - ln(|C|/|P|) >= 0 in exact arithmetic and the reference's
-        // float32 evaluation of it is >= -0.15, so  smd > 2*thr + 0.2 (+0.1%)  implies  KLD_float32 > thr:
-        // the pair is rejected by the reference too, and no NaN can arise.  smd itself is the SAME
-        // float32 expression the KL gate evaluates.
-        pr.smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * a.kldThr + 0.2f) * 1.001f : __builtin_inff();
+        // Pre-reject bound (exactness argument in DESIGN.md "KL gate pre-reject"): for a regular parent and a regular
+        // child, tr(P^-1 C) - 3 - ln(|C|/|P|) >= 0 in exact arithmetic and the reference's float32 evaluation of it is
+        // >= -0.15, so  smd > 2*thr + 0.2 (+0.1%)  implies  KLD_float32 > thr: the pair is rejected by the reference too.
+        smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * a.kldThr + 0.2f) * 1.001f : __builtin_inff();
         const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
         pr.pcol = {pc.z, pc.w, pd.x};
         pr.pweight = pd.z;
@@ -815,51 +832,45 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     }
     const float R = a.Rs[pr.js];
     pr.R2 = R * R;
-    EllClip ec = make_ellclip(pr.pinv, pr.smdMax, a.ell);
-    // the parent record is wave-uniform: pin it in SGPRs (frees ~17 VGPRs -> one more wave per SIMD)
+    EllClip ec = make_ellclip(pr.pinv, smdMax, a.ell);
+    make_whitening(pr.pinv, smdMax, pr);
+    // the parent record is wave-uniform: pin it in SGPRs
 #define GSR_UNI(x) x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)))
     GSR_UNI(pr.pm.x); GSR_UNI(pr.pm.y); GSR_UNI(pr.pm.z); GSR_UNI(pr.pcol.x); GSR_UNI(pr.pcol.y); GSR_UNI(pr.pcol.z);
     GSR_UNI(pr.pinv.e00); GSR_UNI(pr.pinv.e01); GSR_UNI(pr.pinv.e02); GSR_UNI(pr.pinv.e11); GSR_UNI(pr.pinv.e12); GSR_UNI(pr.pinv.e22);
-    GSR_UNI(pr.det_p); GSR_UNI(pr.pweight); GSR_UNI(pr.R2); GSR_UNI(pr.smdMax);
+    GSR_UNI(pr.det_p); GSR_UNI(pr.pweight); GSR_UNI(pr.R2); GSR_UNI(pr.white); GSR_UNI(pr.T1);
+    GSR_UNI(pr.u00); GSR_UNI(pr.u01); GSR_UNI(pr.u02); GSR_UNI(pr.u11); GSR_UNI(pr.u12); GSR_UNI(pr.u22);
     GSR_UNI(ec.on); GSR_UNI(ec.k11); GSR_UNI(ec.k12); GSR_UNI(ec.k22); GSR_UNI(ec.kr); GSR_UNI(ec.im00); GSR_UNI(ec.m01); GSR_UNI(ec.m02); GSR_UNI(ec.T);
 #undef GSR_UNI
     pr.js = __builtin_amdgcn_readfirstlane(pr.js);
 
     unsigned count = 0;                 // accepted pairs (uniform across the wave)
-    unsigned long long scanned = 0;     // candidates scanned (uniform)
-    int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[item] : 0;
+    int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
     int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
     unsigned* q = s_q[wv];
     Q3 q3 = {s_q3j[wv], s_q3f[wv][0], s_q3f[wv][1], s_q3f[wv][2], s_q3f[wv][3], 0, 0};
+    __builtin_amdgcn_wave_barrier();
 
     // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
     const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
     if (pr.R2 > 0.0f && pm_finite) {
         // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
         // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
-        select_scan<MODE, false, CACHED>(a, g, pr, ec, R, lane, p, part, nparts, q, qh, qn, count, scanned, base, q3);
-        if (a.n_irr > 0) select_scan<MODE, true, CACHED>(a, g, pr, ec, R, lane, p, part, nparts, q, qh, qn, count, scanned, base, q3);
-        if (MODE != SEL_SPANS && qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base, q3);
+        select_scan<MODE, false>(a, g, pr, ec, R, lane, s_bits[wv], q, qh, qn, count, base, q3);
+        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, ec, R, lane, s_bits[wv], q, qh, qn, count, base, q3);
+        if (qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base, q3);
         if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, pr, lane, q3.n, q3, base);
-    } else if (MODE == SEL_SPANS && a.rows && a.rows_write && lane == 0) {
-        a.rown[p] = 0u;
     }
-    if (lane == 0) {       // no global atomics here: one hot address serialises 10^6 waves (totals come from the scans)
-        if (MODE == SEL_SPANS) a.pcap[item] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
-        else if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[item] = count;
-    }
+    if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p] = count;      // no global atomics: totals come from the scans
 }
 
-// Capacities only (what k_select<SPANS> computes), with 16 lanes per work item instead of a wavefront: the pass has no
-// candidate work, so its cost is the per-parent set-up, which four items per wavefront now share (1.6 -> 0.7 ms at
-// 5 M).  Same row spans as k_select by construction (select_row_span).
+// Capacities (candidates every parent's passes will scan), with 16 lanes per parent instead of a wavefront: the pass has no
+// candidate work, so its cost is the per-parent set-up, which four parents per wavefront share.  Same row spans as k_select
+// by construction (select_row_span).
 __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
     const int sub = threadIdx.x & 15;
-    const int item = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
-    if (item >= a.NI) return;
-    const int p = a.vparent ? (int)a.vparent[item] : item;
-    const unsigned vpi = a.vpart ? a.vpart[item] : (1u << 16);
-    const int part = (int)(vpi & 0xffffu), nparts = (int)(vpi >> 16);
+    const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    if (p >= a.P) return;
     unsigned long long scanned = 0;
     if (p >= a.own_lo && p < a.own_hi) {
         const GridParams g = *a.gp;
@@ -880,7 +891,6 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
             const int nrows = ny * nz;
             const float Ra2 = Ra * Ra;
             for (int r = sub; r < nrows; r += 16) {
-                if (nparts > 1 && ((r >> 6) % nparts) != part) continue;      // k_select deals the rows in batches of 64
                 int s = 0, len = 0;
                 select_row_span<false>(a, g, pm, ec, ec.on != 0.0f, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
                 scanned += (unsigned long long)(len > 0 ? len : 0);
@@ -893,7 +903,7 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
         }
     }
     for (int o = 8; o > 0; o >>= 1) scanned += __shfl_xor(scanned, o);
-    if (sub == 0) a.pcap[item] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
+    if (sub == 0) a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
 }
 
 // Longest-processing-time-first: work per parent is heavy-tailed (a few parents scan 10^5 candidates), so the
@@ -912,9 +922,8 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {      // 10 bits -> ev
 // the children / candidates they share stay in L2 (the x-fastest linear order of the arrays makes the
 // in-flight set a full-width slab of the scene, which does not fit).
 __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __restrict__ work, unsigned thr,
-                                                    const unsigned* __restrict__ plist, const unsigned* __restrict__ vparent,
-                                                    const float4* __restrict__ A, const GridParams* __restrict__ gpp, int use_morton,
-                                                    unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
+                                                    const unsigned* __restrict__ plist, const float4* __restrict__ A,
+                                                    const GridParams* __restrict__ gpp, unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
     const GridParams g = *gpp;
     int gm = g.gx > g.gy ? g.gx : g.gy;
     gm = gm > g.gz ? gm : g.gz;
@@ -924,40 +933,12 @@ __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __res
         const unsigned w = work[p];
         // classes: 0 = >= 64 thr, 1 = >= 8 thr, 2 = >= thr, 3 = light
         const unsigned cls = w >= 64u * thr ? 0u : (w >= 8u * thr ? 1u : (w >= thr ? 2u : 3u));
-        unsigned m = 0;
-        if (use_morton) {
-            const float4 a = A[plist[vparent ? vparent[p] : (unsigned)p]];
-            const unsigned cx = (unsigned)cell_of(a.x, g.ox, g.inv_c, g.gx) >> sh;
-            const unsigned cy = (unsigned)cell_of(a.y, g.oy, g.inv_c, g.gy) >> sh;
-            const unsigned cz = (unsigned)cell_of(a.z, g.oz, g.inv_c, g.gz) >> sh;
-            m = spread10(cx) | (spread10(cy) << 1) | (spread10(cz) << 2);
-        }
-        keys[p] = (cls << 30) | m;
+        const float4 a = A[plist[p]];
+        const unsigned cx = (unsigned)cell_of(a.x, g.ox, g.inv_c, g.gx) >> sh;
+        const unsigned cy = (unsigned)cell_of(a.y, g.oy, g.inv_c, g.gy) >> sh;
+        const unsigned cz = (unsigned)cell_of(a.z, g.oz, g.inv_c, g.gz) >> sh;
+        keys[p] = (cls << 30) | spread10(cx) | (spread10(cy) << 1) | (spread10(cz) << 2);
         idx[p] = (unsigned)p;
-    }
-}
-
-// split heavy parents: parts = ceil(candidates / part_cap), at most 64
-__global__ __launch_bounds__(256) void k_nparts(int P, const unsigned* __restrict__ pcap, unsigned part_cap, int* __restrict__ nparts) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        unsigned n = (pcap[p] + part_cap - 1) / part_cap;
-        nparts[p] = (int)(n < 1u ? 1u : (n > 64u ? 64u : n));
-    }
-}
-__global__ __launch_bounds__(256) void k_fill_items(int P, const int* __restrict__ nparts, const int* __restrict__ vstart,
-                                                    unsigned* __restrict__ vparent, unsigned* __restrict__ vpart) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const int n = nparts[p], v0 = vstart[p];
-        for (int k = 0; k < n; ++k) { vparent[v0 + k] = (unsigned)p; vpart[v0 + k] = (unsigned)k | ((unsigned)n << 16); }
-    }
-}
-// accepted pairs of a parent = sum over its items
-__global__ __launch_bounds__(256) void k_sum_parts(int P, const int* __restrict__ nparts, const int* __restrict__ vstart,
-                                                   const unsigned* __restrict__ vcnt, unsigned* __restrict__ pcnt) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        unsigned s = 0;
-        for (int k = 0, v0 = vstart[p]; k < nparts[p]; ++k) s += vcnt[v0 + k];
-        pcnt[p] = s;
     }
 }
 
@@ -967,24 +948,17 @@ __global__ void k_count_heavy(int P, const unsigned* __restrict__ sorted_keys, i
     *out = lo;
 }
 
-// pack the sparse per-item segments [coff[v], coff[v]+vcnt[v]) into the compact per-parent CSR [poff[p], ...):
-// the items of a parent are concatenated in part order (deterministic)
-__global__ __launch_bounds__(256) void k_compact_pairs(int P, const int* __restrict__ nparts, const int* __restrict__ vstart,
-                                                       const int64_t* __restrict__ coff, const unsigned* __restrict__ vcnt,
+// pack the sparse per-parent segments [coff[p], coff[p]+pcnt[p]) into the compact parent-major CSR [poff[p], ...)
+__global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __restrict__ coff, const unsigned* __restrict__ pcnt,
                                                        const int64_t* __restrict__ poff, const unsigned* __restrict__ sc,
                                                        const float* __restrict__ sw, unsigned* __restrict__ dc, float* __restrict__ dw) {
     // 16 lanes per parent (a parent has ~65 pairs): four parents per wavefront share the per-wave latency chain
     const int sub = threadIdx.x & 15;
     const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
     if (p >= P) return;
-    int64_t dof = poff[p];
-    const int v0 = nparts ? vstart[p] : p, n = nparts ? nparts[p] : 1;
-    for (int k = 0; k < n; ++k) {
-        const int64_t so = coff[v0 + k];
-        const unsigned cnt = vcnt[v0 + k];
-        for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[so + i]; dw[dof + i] = sw[so + i]; }
-        dof += cnt;
-    }
+    const int64_t dof = poff[p], so = coff[p];
+    const unsigned cnt = pcnt[p];
+    for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[so + i]; dw[dof + i] = sw[so + i]; }
 }
 
 // per-child sum of wL_si, sequential in the (stable) sorted pair order (mixture.cpp:162)
@@ -1023,6 +997,7 @@ __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restr
 #define SUM_BUCKET_SHIFT 13
 #define SUM_BUCKET (1 << SUM_BUCKET_SHIFT)        // children per bucket: 8192 x (4 + 8) bytes = 96 KiB of LDS
 #define SUM_TILE 16384                            // pairs per workgroup of the partition kernels
+#define SUM_MAX_BUCKETS 8192                      // 12 bytes of LDS per bucket in k_bucket_scatter: 96 KiB (n <= 67 M components)
 
 __global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, const unsigned* __restrict__ child, int nb, unsigned* __restrict__ hist) {
     extern __shared__ unsigned s_h[];
@@ -1500,6 +1475,17 @@ __global__ void k_debug_kld(int64_t n, const float* __restrict__ cm, const float
     }
 }
 
+__global__ void k_debug_kl_gate(int64_t n, const float* __restrict__ s2, const float* __restrict__ q, float thr, uint8_t* __restrict__ reject,
+                                float* __restrict__ lf, uint8_t* __restrict__ need_exact) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        float l;
+        bool ex;
+        reject[i] = kl_gate_rejects(s2[i], q[i], thr, k_logf_tab, &l, &ex) ? 1 : 0;
+        lf[i] = l;
+        need_exact[i] = ex ? 1 : 0;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -1541,19 +1527,15 @@ struct gsr_hem_ctx {
     DevBuf spare[5];
     bool have_level = false;
     // workspace
-    DevBuf hist, iflag, irank, ipos, rng_blocks, rowcap, rowoff, rown, rows, bhist, bstart, bcursor;
-    bool reuse_order = true, morder_is_porder = false;      // GSR_HEM_REUSE_ORDER=0: the M-step sorts its own order
+    DevBuf hist, iflag, irank, ipos, rng_blocks, bhist, bstart, bcursor;
     bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
     unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
-    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, morder, nparts, vstart, vparent, vpart, vcap, vcnt;
-    int part_cap = 0;               // candidates per work item when a heavy parent is split; 0 = never (measured: 8192 cuts
-                                    // the select kernel by 4% and costs as much in the extra SPANS pass and scans)
-    bool use_lpt = true, use_morton = true, use_xcd = true, use_ell = true, use_rowcache = false;   // row cache: measured neutral on MI355X (kernel -1.5 %, phase +1 %)
+    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx;
+    bool use_ell = true;            // GSR_HEM_ELL=0: no ellipsoid row clipping (test knob: the pair set must not change)
     int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
     gsr_allreduce_dev_fn shard_allreduce = nullptr;
     void* shard_user = nullptr;
-    int mstep_lds = 0;              // extra dynamic LDS per k_mstep workgroup: caps waves per CU (experiment knob)
     bool sparse_path = false;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
@@ -1561,9 +1543,7 @@ struct gsr_hem_ctx {
     float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of k_select<COUNT> and k_select<FILL>
-    float cell_target = 8.0f;
-    int wpb = 2, wpb_m = 1;      // parents per workgroup in k_select / k_mstep (measured on MI355X: work per parent is
-                                 // heavy-tailed, small workgroups free their CU slot sooner; 4/8/16 were 10-120% slower)
+    float cell_target = 8.0f;       // components per grid cell (GSR_HEM_CELL_TARGET; the result does not depend on it)
     int max_cells = 1 << 24;
 };
 
@@ -1737,19 +1717,13 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         hipError_t e = hipHostMalloc((void**)&c->host_rb, 64, hipHostMallocDefault);
         if (e != hipSuccess) { c->host_rb = nullptr; delete c; return fail(GSR_E_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
     }
-    if (const char* s = getenv("GSR_HEM_MSTEP_LDS")) c->mstep_lds = atoi(s);
-    if (const char* s = getenv("GSR_HEM_PART_CAP")) c->part_cap = atoi(s);
-    if (const char* s = getenv("GSR_HEM_LPT")) c->use_lpt = atoi(s) != 0;
-    if (const char* s = getenv("GSR_HEM_MORTON")) c->use_morton = atoi(s) != 0;
-    if (const char* s = getenv("GSR_HEM_XCD")) c->use_xcd = atoi(s) != 0;
+    // Environment knobs (all of them): none changes a result, each is exercised by a test.
     if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
-    if (const char* s = getenv("GSR_HEM_REUSE_ORDER")) c->reuse_order = atoi(s) != 0;
-    (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_BUCKET * 12);
-    if (const char* s = getenv("GSR_HEM_ROWCACHE")) c->use_rowcache = atoi(s) != 0;
-    if (const char* s = getenv("GSR_HEM_WPB")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4) c->wpb = v; }
-    if (const char* s = getenv("GSR_HEM_WPB_M")) { int v = atoi(s); if (v == 1 || v == 2 || v == 4 || v == 8 || v == 16) c->wpb_m = v; }
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
+    (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_BUCKET * 12);
+    (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
+    (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 12 + 8);
     *out = c;
     return GSR_OK;
 }
@@ -1763,7 +1737,9 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
                      &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
-                     &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->rowcap, &c->rowoff, &c->rown, &c->rows, &c->bhist, &c->bstart, &c->bcursor, &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->morder, &c->nparts, &c->vstart, &c->vparent, &c->vpart, &c->vcap, &c->vcnt, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot, &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
+                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
+                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -1956,7 +1932,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->cellStart.reserve(((size_t)gp.ncells + 1) * 4));
     hipLaunchKernelGGL(k_run_starts<int>, grd, blk, 0, st, n, c->skeys.as<unsigned>(), (int64_t)gp.ncells, c->cellStart.as<int>());
 
-    GSR_TRY(c->A.reserve(n * 16)); GSR_TRY(c->B.reserve(n * 16)); GSR_TRY(c->C.reserve(n * 16)); GSR_TRY(c->D.reserve(n * 16));
+    GSR_TRY(c->A.reserve((n + SEL_PAD) * 16)); GSR_TRY(c->B.reserve(n * 16)); GSR_TRY(c->C.reserve(n * 16)); GSR_TRY(c->D.reserve(n * 16));
     GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4));
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
     // row stride of the sorted SH rows.  Padding rows to 64 bytes (Fp = 48 for F = 45) was measured: k_mstep -1.5 %,
@@ -1988,12 +1964,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_HIP(hipEventRecord(c->ev[1], st));
 
     // ---- 2. selection ------------------------------------------------------------------------------
-    // Fast path (SPARSE): one evaluation pass.  k_select<SPANS> sums the span lengths per parent (an
-    // upper bound of its child count); heavy parents are split into work items of <= ~8k candidates
-    // (work per parent is heavy-tailed: R^3 is log-normal); every item writes its pairs at the head of a
-    // segment of its capacity; k_compact_pairs packs them per parent.  The sparse buffers cost 8 bytes
-    // per candidate scanned; when that exceeds the budget (GSR_HEM_SPARSE_GB, default 45 % of free HBM)
-    // the two-pass COUNT + FILL fallback runs instead (same device code, evaluates every candidate twice).
+    // Fast path (SPARSE): one evaluation pass.  k_spans sums the span lengths per parent (an upper bound of
+    // its child count); every parent writes its pairs at the head of a segment of that capacity;
+    // k_compact_pairs packs them.  The sparse buffers cost 8 bytes per candidate scanned; when that exceeds
+    // the budget (GSR_HEM_SPARSE_GB, default 45 % of free HBM) the two-pass COUNT + FILL fallback runs
+    // instead (same device code, evaluates every candidate twice).
     const size_t Pm = (size_t)(P > 0 ? P : 1);
     GSR_TRY(c->pcnt.reserve(Pm * 4)); GSR_TRY(c->pcap.reserve(Pm * 4)); GSR_TRY(c->poff.reserve((Pm + 1) * 8));
     GSR_TRY(c->scratch.reserve((Pm * 2 + 128) * 8));
@@ -2001,7 +1976,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     memset(&sa, 0, sizeof(sa));
     sa.A = c->A.as<float4>(); sa.B = c->B.as<float4>(); sa.C = c->C.as<float4>(); sa.D = c->D.as<float4>();
     sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
-    sa.gp = c->gparams.as<GridParams>(); sa.P = P; sa.NI = P;
+    sa.gp = c->gparams.as<GridParams>(); sa.P = P;
     sa.irank = c->irank.as<int>(); sa.ipos = c->ipos.as<unsigned>(); sa.n_irr = n_irr; sa.ell = c->use_ell ? 1 : 0;
     // work sharding: rank r of W evaluates the contiguous run [P r / W, P (r+1) / W) of the cell-sorted parents
     const bool sharded = c->shard_world > 1 && c->shard_allreduce != nullptr;
@@ -2014,16 +1989,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.pcnt = c->pcnt.as<unsigned>();
     sa.pcap = c->pcap.as<unsigned>();
     int64_t M = 0;
-    const int wpb = c->wpb;
-#define GSR_LAUNCH_SELECT_C(MODE, NITEMS, CACHED)                                                                                    \
-    switch (wpb) {                                                                                                                   \
-        case 1: hipLaunchKernelGGL((k_select<MODE, 1, CACHED>), dim3(8 * ceil_div((NITEMS), 8)), dim3(64), 0, st, sa); break;         \
-        case 2: hipLaunchKernelGGL((k_select<MODE, 2, CACHED>), dim3(8 * ceil_div(ceil_div((NITEMS), 2), 8)), dim3(128), 0, st, sa); break; \
-        default: hipLaunchKernelGGL((k_select<MODE, 4, CACHED>), dim3(8 * ceil_div(ceil_div((NITEMS), 4), 8)), dim3(256), 0, st, sa); break; \
-    }
-    // the first SPANS launch of a level fills the row cache; every later launch reads it (kernels without clipping code)
-#define GSR_LAUNCH_SELECT(MODE, NITEMS)                                                                                              \
-    if (sa.rows != nullptr && !sa.rows_write) { GSR_LAUNCH_SELECT_C(MODE, NITEMS, true) } else { GSR_LAUNCH_SELECT_C(MODE, NITEMS, false) }
+    constexpr int WPB = 2;      // parents per workgroup (work per parent is heavy-tailed: small workgroups free their CU slot sooner)
+#define GSR_LAUNCH_SELECT(MODE) \
+    hipLaunchKernelGGL((k_select<MODE, WPB>), dim3(8 * ceil_div(ceil_div(P, WPB), 8)), dim3(64 * WPB), 0, st, sa)
     auto widen_scan = [&](const unsigned* cnt, int64_t* off, int64_t count) -> int32_t {      // off = exclusive scan of cnt (int64)
         GSR_TRY(c->scratch.reserve(((size_t)count + 128) * 8));
         int64_t* cnt64 = c->scratch.as<int64_t>();
@@ -2042,70 +2010,23 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     };
     c->sparse_path = false;
     if (P > 0) {
-        // row cache (8 bytes per grid row of every parent's bounding square), when it fits the budget
-        if (c->use_rowcache) {
-            GSR_TRY(c->rowcap.reserve(Pm * 4)); GSR_TRY(c->rowoff.reserve((Pm + 1) * 8)); GSR_TRY(c->rown.reserve(Pm * 4));
-            hipLaunchKernelGGL(k_rowcap, dim3(stride_grid(P)), blk, 0, st, P, c->plist.as<unsigned>(), c->A.as<float4>(), c->Rs.as<float>(),
-                               c->gparams.as<GridParams>(), c->rowcap.as<unsigned>());
-            GSR_TRY(widen_scan(c->rowcap.as<unsigned>(), c->rowoff.as<int64_t>(), P));
-            int64_t nrows_total = 0;
-            GSR_TRY(total_of(c->rowoff.as<int64_t>(), c->rowcap.as<unsigned>(), P, &nrows_total));
-            size_t free_b = 0, total_b = 0;
-            (void)hipMemGetInfo(&free_b, &total_b);
-            if ((size_t)nrows_total * 8 <= (free_b + c->rows.cap) / 8) {
-                GSR_TRY(c->rows.reserve((size_t)(nrows_total > 0 ? nrows_total : 1) * 8));
-                sa.rows = c->rows.as<int2>(); sa.rowoff = c->rowoff.as<int64_t>(); sa.rown = c->rown.as<unsigned>();
-            }
-        }
-        sa.rows_write = 1;
-        if (sa.rows != nullptr) { GSR_LAUNCH_SELECT(SEL_SPANS, P); }      // the wave-per-parent form also fills the row cache
-        else hipLaunchKernelGGL(k_spans, dim3(ceil_div(P, 16)), dim3(256), 0, st, sa);      // candidates scanned per parent
-        sa.rows_write = 0;
-        // work items: split the heavy parents
-        int V = P;
-        bool split = false;
-        GSR_TRY(c->nparts.reserve(Pm * 4)); GSR_TRY(c->vstart.reserve((Pm + 1) * 4));
-        if (c->part_cap > 0) {
-            hipLaunchKernelGGL(k_nparts, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), (unsigned)c->part_cap, c->nparts.as<int>());
-            GSR_TRY(exclusive_scan<int>(c, c->nparts.as<int>(), c->vstart.as<int>(), P));
-            Collect q;
-            q.n = 2;
-            q.src[0] = c->vstart.as<int>() + (P - 1); q.src[1] = c->nparts.as<int>() + (P - 1);
-            q.bytes[0] = q.bytes[1] = 4;
-            unsigned long long w[8];
-            GSR_TRY(read_back(c, q, w));
-            V = (int)w[0] + (int)w[1];
-            split = V > P;
-        }
-        const size_t Vm = (size_t)V;
-        GSR_TRY(c->coff.reserve((Vm + 1) * 8));
-        const unsigned* icap = c->pcap.as<unsigned>();            // capacity per item
-        if (split) {
-            GSR_TRY(c->vparent.reserve(Vm * 4)); GSR_TRY(c->vpart.reserve(Vm * 4)); GSR_TRY(c->vcap.reserve(Vm * 4)); GSR_TRY(c->vcnt.reserve(Vm * 4));
-            hipLaunchKernelGGL(k_fill_items, dim3(stride_grid(P)), blk, 0, st, P, c->nparts.as<int>(), c->vstart.as<int>(), c->vparent.as<unsigned>(),
-                               c->vpart.as<unsigned>());
-            sa.NI = V; sa.vparent = c->vparent.as<unsigned>(); sa.vpart = c->vpart.as<unsigned>();
-            sa.pcap = c->vcap.as<unsigned>();
-            if (sa.rows != nullptr) { GSR_LAUNCH_SELECT(SEL_SPANS, V); }  // exact capacity of every item
-            else hipLaunchKernelGGL(k_spans, dim3(ceil_div(V, 16)), dim3(256), 0, st, sa);
-            icap = c->vcap.as<unsigned>();
-        }
-        GSR_TRY(widen_scan(icap, c->coff.as<int64_t>(), V));
+        hipLaunchKernelGGL(k_spans, dim3(ceil_div(P, 16)), dim3(256), 0, st, sa);      // candidates scanned per parent
+        GSR_TRY(c->coff.reserve((Pm + 1) * 8));
+        GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>(), P));
         int64_t cand_i = 0;
-        GSR_TRY(total_of(c->coff.as<int64_t>(), icap, V, &cand_i));
+        GSR_TRY(total_of(c->coff.as<int64_t>(), c->pcap.as<unsigned>(), P, &cand_i));
         const unsigned long long cand = (unsigned long long)cand_i;
         c->stats[4] = (int64_t)cand;
-        // processing order: heavy items first, the light ones along a Z-order curve
-        GSR_TRY(c->porder.reserve(Vm * 4)); GSR_TRY(c->pkeys.reserve(Vm * 4)); GSR_TRY(c->pkeys2.reserve(Vm * 4)); GSR_TRY(c->pidx.reserve(Vm * 4));
+        // processing order: heavy parents first (LPT), the light ones along a Z-order curve
+        GSR_TRY(c->porder.reserve(Pm * 4)); GSR_TRY(c->pkeys.reserve(Pm * 4)); GSR_TRY(c->pkeys2.reserve(Pm * 4)); GSR_TRY(c->pidx.reserve(Pm * 4));
         {
-            const unsigned thr = (unsigned)(8.0 * (double)cand / (double)V) + 1u;      // "heavy" = 8x the mean
-            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(V)), blk, 0, st, V, icap, thr, c->plist.as<unsigned>(),
-                               split ? c->vparent.as<unsigned>() : (const unsigned*)nullptr, c->A.as<float4>(),
-                               c->gparams.as<GridParams>(), c->use_morton ? 1 : 0, c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
-            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), V, 32));
-            hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, V, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
-            sa.porder = c->use_lpt ? c->porder.as<unsigned>() : nullptr;
-            sa.xcd = (c->use_xcd && c->use_lpt) ? 1 : 0;
+            const unsigned thr = (unsigned)(8.0 * (double)cand / (double)P) + 1u;      // "heavy" = 8x the mean
+            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), thr, c->plist.as<unsigned>(),
+                               c->A.as<float4>(), c->gparams.as<GridParams>(), c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
+            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 32));
+            hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
+            sa.porder = c->porder.as<unsigned>();
+            sa.xcd = 1;
             sa.nheavy = c->counters.as<int>() + 8;
         }
         size_t free_b = 0, total_b = 0;
@@ -2117,21 +2038,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             const size_t Cm = (size_t)(cand > 0 ? cand : 1);
             GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
             sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
-            sa.pcnt = split ? c->vcnt.as<unsigned>() : c->pcnt.as<unsigned>();
             GSR_HIP(hipEventRecord(c->evk[2], st));
             GSR_CHECKPOINT("spans + ordering");
-            GSR_LAUNCH_SELECT(SEL_SPARSE, V);
+            GSR_LAUNCH_SELECT(SEL_SPARSE);
             GSR_CHECKPOINT("k_select<SPARSE>");
             GSR_HIP(hipEventRecord(c->evk[3], st));
-            if (split)
-                hipLaunchKernelGGL(k_sum_parts, dim3(stride_grid(P)), blk, 0, st, P, c->nparts.as<int>(), c->vstart.as<int>(), c->vcnt.as<unsigned>(),
-                                   c->pcnt.as<unsigned>());
         } else {
-            // fallback: whole parents, two passes
-            sa.NI = P; sa.vparent = nullptr; sa.vpart = nullptr; sa.porder = nullptr; sa.xcd = 0; sa.nheavy = nullptr;
-            sa.pcnt = c->pcnt.as<unsigned>();
             GSR_HIP(hipEventRecord(c->evk[0], st));
-            GSR_LAUNCH_SELECT(SEL_COUNT, P);
+            GSR_LAUNCH_SELECT(SEL_COUNT);
             GSR_HIP(hipEventRecord(c->evk[1], st));
         }
         GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), P));
@@ -2141,38 +2055,21 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
         if (M > 0) {
             if (sparse) {
-                hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 16)), blk, 0, st, P, split ? c->nparts.as<int>() : (const int*)nullptr,
-                                   split ? c->vstart.as<int>() : (const int*)nullptr, c->coff.as<int64_t>(),
-                                   split ? c->vcnt.as<unsigned>() : c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), c->sp_child.as<unsigned>(),
-                                   c->sp_wl.as<float>(), c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
+                hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 16)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(),
+                                   c->poff.as<int64_t>(), c->sp_child.as<unsigned>(), c->sp_wl.as<float>(), c->pair_child.as<unsigned>(),
+                                   c->pair_wl.as<float>());
             } else {
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
                 GSR_HIP(hipEventRecord(c->evk[2], st));
-                GSR_LAUNCH_SELECT(SEL_FILL, P);
+                GSR_LAUNCH_SELECT(SEL_FILL);
                 GSR_HIP(hipEventRecord(c->evk[3], st));
             }
         }
         c->sparse_path = sparse;
-        // M-step processing order: heavy parents (by accepted pairs) first, the rest in Z-order
-        c->morder_is_porder = false;
-        if (c->use_lpt && M > 0 && c->reuse_order && sparse && !split) {
-            // the selection's order (heavy by candidates scanned, then Z-order) serves the M-step too: parents with many
-            // candidates are the ones with many pairs; saves a key pass, a 32-bit sort and a count per level
-            c->morder_is_porder = true;
-        } else if (c->use_lpt && M > 0) {
-            const unsigned thr = (unsigned)(8.0 * (double)M / (double)P) + 1u;
-            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcnt.as<unsigned>(), thr, c->plist.as<unsigned>(),
-                               (const unsigned*)nullptr, c->A.as<float4>(), c->gparams.as<GridParams>(), c->use_morton ? 1 : 0,
-                               c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
-            GSR_TRY(c->morder.reserve(Pm * 4));
-            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->morder.as<unsigned>(), P, 32));
-            hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 9);
-        }
     } else {
         GSR_TRY(c->pair_child.reserve(4)); GSR_TRY(c->pair_wl.reserve(4)); GSR_TRY(c->spair_child.reserve(4)); GSR_TRY(c->spair_wl.reserve(4));
     }
 #undef GSR_LAUNCH_SELECT
-#undef GSR_LAUNCH_SELECT_C
     c->stats[1] = M;
     GSR_CHECKPOINT("selection");
     GSR_HIP(hipEventRecord(c->ev[2], st));
@@ -2180,25 +2077,26 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // ---- 3. per-child sums of wL (deterministic: stable sort by child, sequential sum) ----------
     GSR_TRY(c->cstart.reserve(((size_t)n + 1) * 8)); GSR_TRY(c->sumLw.reserve(n * 4)); GSR_TRY(c->oflag.reserve(n * 4));
     const int nbuckets = (int)((n + SUM_BUCKET - 1) >> SUM_BUCKET_SHIFT);
-    if (c->sum_bucket && M > 0 && nbuckets <= 8192) {
-        // partition by bucket (counting sort), then one workgroup per bucket sums in LDS on a fixed-point scale
+    if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
+        // partition by bucket (counting sort), then one workgroup per bucket sums in LDS on a fixed-point scale.  The
+        // partition kernels keep per-bucket counters in dynamic LDS (12 bytes per bucket, raised above the 64 KiB default
+        // in gsr_hem_create); levels with more than SUM_MAX_BUCKETS buckets (n > 67 M) take the sort path below.
         GSR_TRY(c->bhist.reserve(((size_t)nbuckets + 1) * 4)); GSR_TRY(c->bstart.reserve(((size_t)nbuckets + 1) * 8));
         GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
         GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
         const int ntiles = (int)((M + SUM_TILE - 1) / SUM_TILE);
+        (void)hipGetLastError();
         hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, c->pair_child.as<unsigned>(), nbuckets, c->bhist.as<unsigned>());
+        GSR_HIP(hipGetLastError());
         GSR_TRY(widen_scan(c->bhist.as<unsigned>(), (int64_t*)c->bstart.p, nbuckets + 1));
         GSR_HIP(hipMemcpyAsync(c->bcursor.p, c->bstart.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)(((nbuckets + 1) & ~1) * 4 + nbuckets * 8), st, M, c->pair_child.as<unsigned>(),
                            c->pair_wl.as<float>(), nbuckets, c->bcursor.as<unsigned long long>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
+        GSR_HIP(hipGetLastError());
         GSR_CHECKPOINT("pair partition");
-        (void)hipGetLastError();
         hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(1024), (size_t)SUM_BUCKET * 12, st, n, c->bstart.as<unsigned long long>(),
                            c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
-        if (hipGetLastError() != hipSuccess) {      // 96 KiB of dynamic LDS refused: never seen on gfx950, but do not compute garbage
-            c->sum_bucket = false;
-            return fail(GSR_E_HIP, "k_bucket_sum could not be launched (dynamic LDS); set GSR_HEM_SUMLW=sort");
-        }
+        GSR_HIP(hipGetLastError());
     } else {
         if (M > 0) {
             GSR_TRY(sort_pairs<float>(c, c->pair_child.as<unsigned>(), c->spair_child.as<unsigned>(), c->pair_wl.as<float>(),
@@ -2258,18 +2156,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
         ma.own_lo = own_lo; ma.own_hi = own_hi;
-        ma.porder = (c->use_lpt && M > 0) ? (c->morder_is_porder ? c->porder.as<unsigned>() : c->morder.as<unsigned>()) : nullptr;
-        ma.xcd = (c->use_xcd && ma.porder) ? 1 : 0;
-        ma.nheavy = c->counters.as<int>() + (c->morder_is_porder ? 8 : 9);
+        // processing order: the selection's (heavy parents by candidates scanned first, then Z-order) -- parents with many
+        // candidates are the ones with many pairs
+        ma.porder = M > 0 ? c->porder.as<unsigned>() : nullptr;
+        ma.xcd = ma.porder ? 1 : 0;
+        ma.nheavy = c->counters.as<int>() + 8;
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
-        switch (c->wpb_m) {
-            case 1: if (F <= 64) hipLaunchKernelGGL((k_mstep<1, 0>), dim3(8 * ceil_div(P, 8)), dim3(64), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<1, 4>), dim3(8 * ceil_div(P, 8)), dim3(64), c->mstep_lds, st, ma); break;
-            case 2: if (F <= 64) hipLaunchKernelGGL((k_mstep<2, 0>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<2, 4>), dim3(8 * ceil_div(ceil_div(P, 2), 8)), dim3(128), c->mstep_lds, st, ma); break;
-            case 4: if (F <= 64) hipLaunchKernelGGL((k_mstep<4, 0>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<4, 4>), dim3(8 * ceil_div(ceil_div(P, 4), 8)), dim3(256), c->mstep_lds, st, ma); break;
-            case 8: if (F <= 64) hipLaunchKernelGGL((k_mstep<8, 0>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<8, 4>), dim3(8 * ceil_div(ceil_div(P, 8), 8)), dim3(512), c->mstep_lds, st, ma); break;
-            default: if (F <= 64) hipLaunchKernelGGL((k_mstep<16, 0>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), c->mstep_lds, st, ma); else hipLaunchKernelGGL((k_mstep<16, 4>), dim3(8 * ceil_div(ceil_div(P, 16), 8)), dim3(1024), c->mstep_lds, st, ma); break;
-        }
+        if (F <= 64) hipLaunchKernelGGL((k_mstep<1, 0>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, ma);
+        else hipLaunchKernelGGL((k_mstep<1, 4>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, ma);
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
@@ -2389,6 +2284,33 @@ int32_t gsr_debug_kld(const float* cm, const float* cc, const float* pm, const f
     for (int i = 0; i < 5; ++i) b[i].release();
     if (r != GSR_OK) return r;
     if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_debug_kld: %s", hipGetErrorString(e));
+    return GSR_OK;
+}
+
+int32_t gsr_debug_kl_gate(const float* s2, const float* q, int64_t n, float thr, uint8_t* reject, float* fast_log, uint8_t* need_exact,
+                          int32_t device) {
+    if (n < 0 || (n > 0 && (!s2 || !q || !reject || !fast_log || !need_exact))) return fail(GSR_E_INVALID, "gsr_debug_kl_gate: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GSR_E_NO_DEVICE, "gsr_debug_kl_gate: no HIP device visible");
+    if (n == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    DevBuf b[5];
+    const size_t sz[5] = {(size_t)n * 4, (size_t)n * 4, (size_t)n, (size_t)n * 4, (size_t)n};
+    int32_t r = GSR_OK;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 5 && r == GSR_OK; ++i) r = b[i].reserve(sz[i]);
+    if (r == GSR_OK) e = hipMemcpy(b[0].p, s2, sz[0], hipMemcpyHostToDevice);
+    if (r == GSR_OK && e == hipSuccess) e = hipMemcpy(b[1].p, q, sz[1], hipMemcpyHostToDevice);
+    if (r == GSR_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_kl_gate, dim3(stride_grid(n)), dim3(256), 0, nullptr, n, b[0].as<float>(), b[1].as<float>(), thr,
+                           b[2].as<uint8_t>(), b[3].as<float>(), b[4].as<uint8_t>());
+        e = hipMemcpy(reject, b[2].p, sz[2], hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(fast_log, b[3].p, sz[3], hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(need_exact, b[4].p, sz[4], hipMemcpyDeviceToHost);
+    }
+    for (int i = 0; i < 5; ++i) b[i].release();
+    if (r != GSR_OK) return r;
+    if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_debug_kl_gate: %s", hipGetErrorString(e));
     return GSR_OK;
 }
 

@@ -202,14 +202,6 @@ int32_t gsr_icp_solve(const double* acc, int32_t kind, const double* centre, dou
 /* The centre used by the context's point-to-point sums (target bounding-box centre). */
 int32_t gsr_icp_get_centre(gsr_icp_ctx* ctx, double* centre3);
 
-/* ------------------------------------------------------------------------------- test hooks (device) */
-/* out[i] = the kernels' logf (glibc-compatible, gsr_math.h) of x[i]; host pointers. */
-int32_t gsr_debug_logf(const float* x, int64_t n, float* out, int32_t device);
-/* out[i] = KL gate value of child i against parent i as the selection kernel computes it; host pointers,
- * child_mean/parent_mean [n*3], child_cov6/parent_cov6 [n*6]. */
-int32_t gsr_debug_kld(const float* child_mean, const float* child_cov6, const float* parent_mean,
-                      const float* parent_cov6, int64_t n, float* out, int32_t device);
-
 /* ------------------------------------------------------------------------------ voxel down-sampling */
 
 /* PointCloud::VoxelDownSample (Open3D 0.16.0 PointCloud.cpp), the first step of the reference's voxel multiscale

@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: scripts/build_variant.sh NAME "sed-expr" [more sed-exprs...]   -> variants/NAME.so (hem.hip patched by sed, icp.o reused)
-set -e
+set -euo pipefail
+mkdir -p variants
 NAME=$1; shift
 C=gaussiansplattingregistration_amd/csrc
 cp $C/hem.hip /tmp/hem_$NAME.hip

@@ -10,8 +10,8 @@ import pytest
 from conftest import ROOT
 
 
-def _declared_symbols():
-    text = open(os.path.join(ROOT, "include", "gsr_hip.h")).read()
+def _declared_symbols(path=("include", "gsr_hip.h")):
+    text = open(os.path.join(ROOT, *path)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(gsr_[a-z0-9_]+)\s*\(", text)) - {"gsr_allreduce_fn"})
 
@@ -24,6 +24,12 @@ def test_header_symbols_all_exported(hip_lib):
         assert hasattr(hip_lib, s), f"{s} declared in include/gsr_hip.h but not exported"
     # and the Python binding table covers exactly the header
     assert sorted(_lib.SIGNATURES) == syms
+    # the private test hooks live in their own header and binding table
+    assert not any(s.startswith("gsr_debug") for s in syms)
+    hooks = _declared_symbols(("gaussiansplattingregistration_amd", "csrc", "gsr_test_hooks.h"))
+    assert sorted(_lib.TEST_HOOKS) == hooks
+    for s in hooks:
+        assert hasattr(hip_lib, s)
 
 
 def test_version_and_no_device_behaviour(hip_lib):
