@@ -7,17 +7,20 @@
 //   level arrays (HBM, row-major, as the C ABI hands them over)
 //       xyz[n][3] color[n][3] cov6[n][6] opacity[n] weight[n] sh[n][F] is_parent[n]
 //   per-level working set, all in CELL-SORTED order (j = sorted position, order[j] = input index)
-//       A[j] = {x, y, z, flags}          B[j] = {c00, c01, c02, c11}
-//       C[j] = {c12, c22, col_r, col_g}  D[j] = {col_b, opacity, weight, det}       (float4 each:
-//       one 16-byte load per lane, 1 KiB per wave instruction, candidates of a cell row contiguous)
-//       Rs[j] query radius, shs[j][F] SH rest, cellStart[cells+1] prefix table of a dense uniform grid
+//       A[j] = {x, y, z, flags}   compact float4 array: what stage 1 of k_select streams (16 bytes per candidate,
+//                                 candidates of a cell row contiguous, 1 KiB per wave instruction)
+//       geo[j][4]                 one 64-byte record per component (half a cache line, one round trip):
+//                                 {x, y, z, flags} {c00, c01, c02, c11} {c12, c22, col_r, col_g} {col_b, opacity, weight, det}
+//                                 -- what stage 2 of k_select, the parents' set-up and the M-step moments gather
+//       shs[j][RSH]               SH rest, rows padded to whole float4 (RSH = F rounded up to 4)
+//       Rs[j] query radius, cellStart[cells+1] prefix table of a dense uniform grid
 //   pair list (parent-major CSR): pair_child[M] (sorted position), pair_wl[M] (w_s * clamp(L_si))
 //
 // Kernels of one level (DESIGN.md section 4 has the measurements):
 //   k_prep            det, regular flag, one packed 64-byte record per component (input order), bounding box partials
 //   k_hist / k_grid_params   robust grid box (0.1 % trimmed per side), ~8 components per cell
 //   k_keys / sort     cell key per component, radix sort (rocPRIM) -> order[]
-//   k_gather / k_gather_sh   the cell-sorted working set (+ parent radius: closed-form eigenvalue, f64 trig)
+//   k_gather / k_gather_sh   the cell-sorted working set: A, geo, shs (+ parent radius: closed-form eigenvalue, f64 trig)
 //   k_spans           candidates every parent will scan (capacity of its output segment, LPT work estimate)
 //   k_select<SPARSE|COUNT|FILL>   one wavefront per parent: grid rows clipped to the pre-reject ellipsoid, flattened
 //                     candidate stream -> stage 1 (radius test, Mahalanobis pre-reject) -> LDS ring -> stage 2 (colour
@@ -27,8 +30,8 @@
 //   k_bucket_hist / k_bucket_scatter / k_bucket_sum   per-child sums of wL: counting sort into buckets of 8192
 //                     children, then LDS accumulation on a per-child fixed-point scale -- deterministic without a sort
 //                     (GSR_HEM_SUMLW=sort: rocPRIM stable sort by child + k_sumlw)
-//   k_mstep           one wavefront per parent: responsibilities, wave-shuffle reductions of the 1+3+3+6+1 moment
-//                     sums, SH rows fetched four children per load (16 lanes x float4 per row)
+//   k_mstep           one wavefront per parent: responsibilities and moment sums with a lane per pair, SH rows with a lane
+//                     group per child (3 float4 per lane); reductions by DPP rotations and v_permlane swaps (no LDS traffic)
 //   k_orphans*, k_valid, k_compact   orphans, validity erase, output in the reference's order
 //                     (parents by ascending input index, then orphans by ascending input index)
 //   k_rng_block_state / k_flags_glibc   the next level's parent flags from the libc rand() stream
@@ -140,6 +143,34 @@ __device__ __forceinline__ float wave_max(float v) {
 }
 __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+// Sums across lanes WITHOUT the LDS crossbar (a ds_bpermute costs a SIMD 24 cycles of LDS-pipe issue, scripts/micro/
+// valu_issue.hip; the 14 butterfly sums of the first M-step were 84 of them per parent): rotations inside a row of 16
+// lanes by DPP, rows by gfx950's v_permlane16_swap / v_permlane32_swap.  Every lane must be active.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float swap16_sum(float v) {          // v[l] + v[l ^ 16]
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float swap32_sum(float v) {          // v[l] + v[l ^ 32]
+    const unsigned u = __builtin_bit_cast(unsigned, v);
+    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// sum over the lanes l' == l (mod G), G a power of two: every lane ends with the total of its residue class
+template <int G>
+__device__ __forceinline__ float class_sum(float v) {
+    if (G <= 8) v += dpp_f<0x128>(v);        // row_ror:8
+    if (G <= 4) v += dpp_f<0x124>(v);        // row_ror:4
+    if (G <= 2) v += dpp_f<0x122>(v);        // row_ror:2
+    if (G <= 1) v += dpp_f<0x121>(v);        // row_ror:1
+    if (G <= 16) v = swap16_sum(v);
+    if (G <= 32) v = swap32_sum(v);
     return v;
 }
 
@@ -373,14 +404,15 @@ __global__ void k_fill_const(int64_t n, OffT* p, OffT v) {
 // Sorted working set.
 //   radius = delta * sqrtf(lambda_max) for the parents                       (mixture.cpp:88)
 __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __restrict__ order, const float4* __restrict__ rec, float delta,
-                                                float4* __restrict__ A, float4* __restrict__ B, float4* __restrict__ C,
-                                                float4* __restrict__ D, float* __restrict__ Rs, int* __restrict__ pflag, int* __restrict__ iflag) {
+                                                float4* __restrict__ A, float4* __restrict__ geo, float* __restrict__ Rs,
+                                                int* __restrict__ pflag, int* __restrict__ iflag) {
     if (blockIdx.x == 0 && threadIdx.x == 0) iflag[n] = 0;       // the scan runs over n + 1 entries: irank[n] = total
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = order[j];
         const float4 a = rec[4 * i], b = rec[4 * i + 1], cc = rec[4 * i + 2], d = rec[4 * i + 3];
         const unsigned fl = __float_as_uint(a.w);
-        A[j] = a; B[j] = b; C[j] = cc; D[j] = d;
+        A[j] = a;
+        geo[4 * j] = a; geo[4 * j + 1] = b; geo[4 * j + 2] = cc; geo[4 * j + 3] = d;
         float R = 0.0f;
         if (fl & 1u) {
             const s6 cov = {b.x, b.y, b.z, b.w, cc.x, cc.y};
@@ -391,22 +423,19 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
         iflag[j] = (fl & 2u) ? 0 : 1;
     }
 }
-// shs rows have a stride of Fp >= F floats (pad = zeros; Fp == F today, see gsr_hem_run_level).
-__global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, int Fp, const unsigned* __restrict__ order,
+// shs rows: the F SH-rest coefficients of the component, zero padded to RSH = whole float4.  One thread per float4.
+__global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, int RSH, const unsigned* __restrict__ order,
                                                    const float* __restrict__ sh, float* __restrict__ shs) {
-    const int64_t total = n * Fp;
-    if (total < ((int64_t)1 << 31)) {              // 32-bit index arithmetic: a 64-bit division per element costs ~80 instructions
-        const unsigned tot = (unsigned)total, step = gridDim.x * blockDim.x, uF = (unsigned)Fp;
-        for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += step) {
-            const unsigned j = t / uF, f = t - j * uF;
-            shs[t] = f < (unsigned)F ? sh[(int64_t)order[j] * F + f] : 0.0f;
-        }
-        return;
-    }
+    const int Q = RSH >> 2;
+    const int64_t total = n * Q;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        int64_t j = t / Fp;
-        int f = (int)(t - j * Fp);
-        shs[t] = f < F ? sh[(int64_t)order[j] * F + f] : 0.0f;
+        const int64_t j = total < ((int64_t)1 << 31) ? (int64_t)((unsigned)t / (unsigned)Q) : t / Q;      // 32-bit division when it fits
+        const int q = (int)(t - j * Q);
+        const float* src = sh + (int64_t)order[j] * F + 4 * q;
+        const int left = F - 4 * q;
+        float4 v;
+        v.x = left > 0 ? src[0] : 0.0f; v.y = left > 1 ? src[1] : 0.0f; v.z = left > 2 ? src[2] : 0.0f; v.w = left > 3 ? src[3] : 0.0f;
+        reinterpret_cast<float4*>(shs + j * RSH)[q] = v;
     }
 }
 __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __restrict__ flag, const int* __restrict__ pos,
@@ -443,7 +472,8 @@ __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __re
 //                    pcnt[p]; k_compact_pairs then packs them
 // ------------------------------------------------------------------------------------------------
 struct SelectArgs {
-    const float4 *A, *B, *C, *D;
+    const float4* A;                // compact {x, y, z, flags}
+    const float4* geo;              // 64-byte records {A, B, C, D}
     const float* Rs;
     const unsigned* plist;
     const unsigned* porder;         // processing order of the parents (heavy ones first), or NULL = natural order
@@ -564,7 +594,8 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     float d2 = 0.0f, cdiff = 0.0f, op = 0.0f, det_c = 0.0f;
     if (lane < cnt) {
         j = (int)q[(qh + lane) & (SEL_QCAP - 1)];
-        const float4 ca = a.A[j], cb = a.B[j], cc = a.C[j], cd = a.D[j];   // all four up front: one round trip
+        const float4* row = a.geo + 4 * (int64_t)j;
+        const float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];   // 64 contiguous bytes, all four up front: one round trip
         const f3 cm = {ca.x, ca.y, ca.z};
         const f3 ccol = {cc.z, cc.w, cd.x};
         const f3 d = sub3(cm, pr.pm);
@@ -818,7 +849,8 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     pr.js = (int)a.plist[p];
     float smdMax;
     {
-        const float4 pa = a.A[pr.js], pb = a.B[pr.js], pc = a.C[pr.js], pd = a.D[pr.js];
+        const float4* prow = a.geo + 4 * (int64_t)pr.js;
+        const float4 pa = prow[0], pb = prow[1], pc = prow[2], pd = prow[3];
         pr.pm = {pa.x, pa.y, pa.z};
         pr.det_p = pd.w;
         // Pre-reject bound (exactness argument in DESIGN.md "KL gate pre-reject"): for a regular parent and a regular
@@ -875,7 +907,8 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
     if (p >= a.own_lo && p < a.own_hi) {
         const GridParams g = *a.gp;
         const int js = (int)a.plist[p];
-        const float4 pa = a.A[js], pb = a.B[js], pc = a.C[js], pd = a.D[js];
+        const float4* prow = a.geo + 4 * (int64_t)js;
+        const float4 pa = prow[0], pb = prow[1], pc = prow[2], pd = prow[3];
         const f3 pm = {pa.x, pa.y, pa.z};
         const float smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * a.kldThr + 0.2f) * 1.001f : __builtin_inff();
         const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
@@ -1102,12 +1135,20 @@ __global__ __launch_bounds__(256) void k_flags_to_input_order(int64_t n, const u
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_mstep: responsibilities and moment-matching update (mixture.cpp:167-247), one wavefront per parent
+// k_mstep: responsibilities and moment-matching update (mixture.cpp:167-247), one wavefront per parent.
+//
+//   part 1   lane <-> pair: w = (wL_si / sumLw_i) * weight_i (mixture.cpp:196-197), the 14 moment sums in the
+//            reference's expressions; w and the child index go to LDS.  All gathers of a pair (sumLw and the 64-byte
+//            geometry record) are issued together and unconditionally.
+//   part 2   lane group <-> child: G lanes x 3 float4 cover one SH row, so one round of three load instructions
+//            fetches the rows of 64/G children (16 at SH degree 3), MSTEP_U rounds in flight.
+//   sums     across lanes by DPP row rotations and v_permlane16/32_swap (class_sum): no LDS-crossbar traffic.  (The
+//            first version folded 14 values through six ds_bpermute steps each: 84 LDS-pipe instructions per parent.)
 // ------------------------------------------------------------------------------------------------
 struct MstepArgs {
-    const float4 *A, *B, *C, *D;
+    const float4* geo;
     const float* shs;
-    int Fp;                         // row stride of shs (F rounded up to 16)
+    int RSH;                   // row stride of shs in floats (F rounded up to 4)
     const float* sumLw;
     const unsigned* plist;
     const unsigned* porder;    // processing order (heavy parents first) or NULL
@@ -1125,60 +1166,53 @@ struct MstepArgs {
 };
 
 #define MSTEP_CHUNK 256
-#define MSTEP_U 8             // SH rows whose loads are in flight together
-#define MSTEP_U4 4            // F <= 64: load instructions in flight, each fetching the rows of four children
-struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };      // 4-byte aligned float4 (SH rows are 4 F bytes apart)
+#define MSTEP_U 2             // rounds of SH row loads in flight (each: 3 float4 per lane)
+#define MSTEP_NV 3            // float4 per lane and row
 
-// NQ = SH coefficients per lane (1 when F <= 64 -- the usual case, SH degree <= 3 has F = 45 -- else 4)
-template <int WPB, int NQ>
-__global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
-    __shared__ float s_w[WPB][MSTEP_CHUNK];
-    __shared__ unsigned s_j[WPB][MSTEP_CHUNK];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int nblk_ = (a.P + WPB - 1) / WPB;
-    const int hb_ = a.nheavy ? (((*a.nheavy + WPB - 1) / WPB + 7) & ~7) : 0;
-    const int bid_ = block_slot((int)blockIdx.x, nblk_, hb_ < nblk_ ? hb_ : nblk_, a.xcd);
-    if (bid_ < 0) return;
-    const int slot_ = bid_ * WPB + wv;
-    if (slot_ >= a.P) return;
+// G = lanes per SH row (power of two, G * MSTEP_NV float4 >= RSH / 4); G == 0: no SH at all
+template <int G>
+__global__ __launch_bounds__(64) void k_mstep(MstepArgs a) {
+    __shared__ float s_w[MSTEP_CHUNK];
+    __shared__ unsigned s_j[MSTEP_CHUNK];
+    constexpr int GG = G > 0 ? G : 1;
+    constexpr int CPR = 64 / GG;                                // children per round
+    const int lane = threadIdx.x;
+    const int gl = lane & (GG - 1), grp = lane / GG;
+    const int hb = a.nheavy ? ((*a.nheavy + 7) & ~7) : 0;
+    const int slot_ = block_slot((int)blockIdx.x, a.P, hb < a.P ? hb : a.P, a.xcd);
+    if (slot_ < 0) return;
     const int p = a.porder ? (int)a.porder[slot_] : slot_;
     if (p < a.own_lo || p >= a.own_hi) return;
     const int js = (int)a.plist[p];
-    const float4 pa = a.A[js];
+    const float4 pa = a.geo[4 * (int64_t)js];
     const f3 pm = {pa.x, pa.y, pa.z};
     const int64_t off = a.poff[p];
     const unsigned cnt = a.pcnt[p];
+    const int64_t slot = a.prank_in[a.order[js]];               // output row: issued early, needed last
 
     float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
     float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
-    // SH accumulators: lane f owns coefficients f, f+64, ... (F <= 256 supported per pass)
-    // NQ == 0 (F <= 64): 16 lanes x float4 cover one SH row, so ONE load instruction fetches the rows of FOUR
-    // children (lane group g = lane / 16 <-> child k0 + 4 u + g); the four group sums are folded at the end.
-    // The per-child bookkeeping (LDS reads, address arithmetic) was the cost of this part: the kernel is VALU bound.
-    constexpr int NQA = NQ > 0 ? NQ : 1;
-    float shacc[NQA];
+    const int nq = a.RSH >> 2;                                  // float4 per SH row
+    int qi[MSTEP_NV];                                           // float4 slots of this lane (slots beyond the row: re-read slot 0, discarded)
 #pragma unroll
-    for (int q = 0; q < NQA; ++q) shacc[q] = 0.0f;
-    float4 acc4 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const int gl = lane & 15, g4 = lane >> 4;
-    const int nl = (a.F + 3) >> 2;                              // lanes of a group that hold coefficients
-    const int glc = gl < nl ? gl : 0;                           // idle lanes re-read the first float4 (discarded)
+    for (int v = 0; v < MSTEP_NV; ++v) qi[v] = gl + GG * v < nq ? gl + GG * v : 0;
+    float4 acc[MSTEP_NV];
+#pragma unroll
+    for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
     for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
         const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
-        // part 1: lane <-> pair; moment partial sums.  All gathers of a pair are issued together and
-        // unconditionally (a load under `if (sumLw != 0)` would cost an extra dependent round trip).
+        // part 1
         for (unsigned k = lane; k < cn; k += 64) {
             const unsigned j = a.pair_child[off + c0 + k];
             const float wl = a.pair_wl[off + c0 + k];
             const float sl = a.sumLw[j];
-            const float4 ca = a.A[j], cb = a.B[j], cc = a.C[j], cd = a.D[j];
+            const float4* row = a.geo + 4 * (int64_t)j;
+            const float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];
             float w = 0.0f;
-            unsigned jj = 0xffffffffu;                         // marks "skip" (sumLw == 0, mixture.cpp:190)
-            if (sl != 0.0f) {
+            if (sl != 0.0f) {                                  // sumLw == 0: skipped (mixture.cpp:190)
                 const float r_is = wl / sl;                    // mixture.cpp:196
                 w = r_is * cd.z;                               // * child.weight (:197)
-                jj = j;
                 const f3 cm = {ca.x, ca.y, ca.z};
                 const f3 d = sub3(cm, pm);
                 w_s += w;
@@ -1188,72 +1222,45 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                 v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
                 so += w * cd.y;
             }
-            s_w[wv][k] = w;
-            s_j[wv][k] = jj;
+            s_w[k] = w;
+            s_j[k] = j;
         }
         __builtin_amdgcn_wave_barrier();
-        // part 2: lane <-> SH coefficient; children in pair order, MSTEP_U rows in flight at a time.
-        // Skipped children load the parent's own row (a valid address) and are masked out of the sum.
-        if (NQ == 0) {
-            if (a.F > 0) {
-                for (unsigned k0 = 0; k0 < cn; k0 += 4 * MSTEP_U4) {
-                    f4u rowv[MSTEP_U4];
-                    float wv_[MSTEP_U4];
-#pragma unroll
-                    for (int u = 0; u < MSTEP_U4; ++u) {
-                        const unsigned k = k0 + 4 * u + g4;
-                        const unsigned kc = k < cn ? k : cn - 1;   // unconditional LDS reads (a branch per read serialises them)
-                        const unsigned j = s_j[wv][kc];
-                        const float wk = s_w[wv][kc];
-                        const bool ok = k < cn && j != 0xffffffffu;
-                        wv_[u] = ok ? wk : 0.0f;
-                        rowv[u] = *(const f4u*)(a.shs + (int64_t)(ok ? j : (unsigned)js) * a.Fp + 4 * glc);
-                        if (!ok) rowv[u] = f4u{0.0f, 0.0f, 0.0f, 0.0f};
-                    }
-#pragma unroll
-                    for (int u = 0; u < MSTEP_U4; ++u) {
-                        acc4.x += rowv[u].x * wv_[u]; acc4.y += rowv[u].y * wv_[u];
-                        acc4.z += rowv[u].z * wv_[u]; acc4.w += rowv[u].w * wv_[u];
-                    }
-                }
-            }
-        } else if (a.F > 0) {
-            for (unsigned k0 = 0; k0 < cn; k0 += MSTEP_U) {
-                float rowv[MSTEP_U][NQA];
-                float wv_[MSTEP_U];
-                bool ok[MSTEP_U];
+        // part 2: children in pair order; a skipped child has w = 0 (its row is loaded all the same: no branch per load)
+        if (G > 0) {
+            for (unsigned k0 = 0; k0 < cn; k0 += CPR * MSTEP_U) {
+                float4 rowv[MSTEP_U][MSTEP_NV];
+                float wv[MSTEP_U];
 #pragma unroll
                 for (int u = 0; u < MSTEP_U; ++u) {
-                    const unsigned k = k0 + u;
-                    const unsigned j = k < cn ? s_j[wv][k] : 0xffffffffu;
-                    ok[u] = j != 0xffffffffu;
-                    wv_[u] = k < cn ? s_w[wv][k] : 0.0f;
-                    const float* row = a.shs + (int64_t)(ok[u] ? j : (unsigned)js) * a.Fp;
+                    const unsigned k = k0 + CPR * u + grp;
+                    const unsigned kc = k < cn ? k : cn - 1;    // unconditional LDS reads and loads
+                    const unsigned j = s_j[kc];
+                    wv[u] = k < cn ? s_w[kc] : 0.0f;
+                    const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
 #pragma unroll
-                    for (int q = 0; q < NQA; ++q) {
-                        const int f = lane + 64 * q;
-                        rowv[u][q] = f < a.F ? row[f] : 0.0f;
-                    }
+                    for (int v = 0; v < MSTEP_NV; ++v) rowv[u][v] = row[qi[v]];
                 }
 #pragma unroll
                 for (int u = 0; u < MSTEP_U; ++u) {
 #pragma unroll
-                    for (int q = 0; q < NQA; ++q)
-                        if (ok[u]) shacc[q] += rowv[u][q] * wv_[u];
+                    for (int v = 0; v < MSTEP_NV; ++v) {
+                        acc[v].x += rowv[u][v].x * wv[u]; acc[v].y += rowv[u][v].y * wv[u];
+                        acc[v].z += rowv[u][v].z * wv[u]; acc[v].w += rowv[u][v].w * wv[u];
+                    }
                 }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    w_s = wave_sum(w_s);
-    smx = wave_sum(smx); smy = wave_sum(smy); smz = wave_sum(smz);
-    scx = wave_sum(scx); scy = wave_sum(scy); scz = wave_sum(scz);
-    v00 = wave_sum(v00); v01 = wave_sum(v01); v02 = wave_sum(v02);
-    v11 = wave_sum(v11); v12 = wave_sum(v12); v22 = wave_sum(v22);
-    so = wave_sum(so);
+    w_s = class_sum<1>(w_s);
+    smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
+    scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
+    v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
+    v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
+    so = class_sum<1>(so);
 
     const float inv_w = 1.0f / w_s;                            // mixture.cpp:209
-    const int64_t slot = a.prank_in[a.order[js]];
     if (lane == 0) {
         const float mx = smx * inv_w, my = smy * inv_w, mz = smz * inv_w;
         const float dx = mx - pm.x, dy = my - pm.y, dz = mz - pm.z;
@@ -1268,23 +1275,21 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         a.o_opacity[slot] = inv_w * so;
         a.o_weight[slot] = w_s;
     }
-    if (NQ == 0) {
-        float v[4] = {acc4.x, acc4.y, acc4.z, acc4.w};
+    if (G > 0) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            v[c] += __shfl_xor(v[c], 16);
-            v[c] += __shfl_xor(v[c], 32);
+        for (int v = 0; v < MSTEP_NV; ++v) {
+            acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
+            acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
         }
-        if (g4 == 0 && gl < nl) {
+        if (grp == 0) {
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-                if (4 * gl + c < a.F) a.o_sh[slot * a.F + 4 * gl + c] = v[c] * inv_w;
-        }
-    } else {
+            for (int v = 0; v < MSTEP_NV; ++v) {
+                const int f0 = 4 * (gl + GG * v);               // first SH coefficient of this lane's float4
+                const float vals[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
 #pragma unroll
-        for (int q = 0; q < NQA; ++q) {
-            const int f = lane + 64 * q;
-            if (f < a.F) a.o_sh[slot * a.F + f] = shacc[q] * inv_w;
+                for (int c = 0; c < 4; ++c)
+                    if (f0 + c < a.F) a.o_sh[slot * a.F + f0 + c] = vals[c] * inv_w;
+            }
         }
     }
 }
@@ -1292,15 +1297,14 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
 // orphans: components no parent addressed (sumLw == 0) are copied unchanged after all parents
 __global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigned* __restrict__ order,
                                                  const int* __restrict__ oflag_sorted, const int* __restrict__ orank_in,
-                                                 const float4* __restrict__ A, const float4* __restrict__ B,
-                                                 const float4* __restrict__ C, const float4* __restrict__ D,
+                                                 const float4* __restrict__ geo,
                                                  float* o_xyz, float* o_color, float* o_cov6, float* o_opacity,
                                                  float* o_weight, int64_t* __restrict__ oslot_sorted) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         int64_t slot = -1;
         if (oflag_sorted[j]) {
             slot = (int64_t)P + orank_in[order[j]];
-            const float4 a = A[j], b = B[j], c = C[j], d = D[j];
+            const float4 a = geo[4 * j], b = geo[4 * j + 1], c = geo[4 * j + 2], d = geo[4 * j + 3];
             o_xyz[3 * slot] = a.x; o_xyz[3 * slot + 1] = a.y; o_xyz[3 * slot + 2] = a.z;
             o_color[3 * slot] = c.z; o_color[3 * slot + 1] = c.w; o_color[3 * slot + 2] = d.x;
             o_cov6[6 * slot] = b.x; o_cov6[6 * slot + 1] = b.y; o_cov6[6 * slot + 2] = b.z;
@@ -1311,7 +1315,7 @@ __global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigne
         oslot_sorted[j] = slot;
     }
 }
-__global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int Fp, const int64_t* __restrict__ oslot_sorted,
+__global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int RSH, const int64_t* __restrict__ oslot_sorted,
                                                     const float* __restrict__ shs, float* __restrict__ o_sh) {
     const int64_t total = n * F;
     if (total < ((int64_t)1 << 31)) {
@@ -1319,14 +1323,14 @@ __global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int Fp, co
         for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += step) {
             const unsigned j = t / uF, f = t - j * uF;
             const int64_t slot = oslot_sorted[j];
-            if (slot >= 0) o_sh[slot * F + f] = shs[(int64_t)j * Fp + f];
+            if (slot >= 0) o_sh[slot * F + f] = shs[(int64_t)j * RSH + f];
         }
         return;
     }
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t j = t / F;
         const int64_t slot = oslot_sorted[j];
-        if (slot >= 0) o_sh[slot * F + (t - j * F)] = shs[j * Fp + (t - j * F)];
+        if (slot >= 0) o_sh[slot * F + (t - j * F)] = shs[j * RSH + (t - j * F)];
     }
 }
 
@@ -1530,7 +1534,7 @@ struct gsr_hem_ctx {
     DevBuf hist, iflag, irank, ipos, rng_blocks, bhist, bstart, bcursor;
     bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
     unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
-    DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, B, C, D, Rs, shs, pflag, ppos, plist;
+    DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx;
     bool use_ell = true;            // GSR_HEM_ELL=0: no ellipsoid row clipping (test knob: the pair set must not change)
     int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
@@ -1734,8 +1738,8 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     unborrow_level0(c);
     for (DevBuf& b : c->spare) b.release();
     c->cur.release(); c->nxt.release(); c->tmp.release();
-    DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->B,
-                     &c->C, &c->D, &c->Rs, &c->shs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
+    DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->geo, &c->shs,
+                     &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
                      &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
@@ -1932,17 +1936,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->cellStart.reserve(((size_t)gp.ncells + 1) * 4));
     hipLaunchKernelGGL(k_run_starts<int>, grd, blk, 0, st, n, c->skeys.as<unsigned>(), (int64_t)gp.ncells, c->cellStart.as<int>());
 
-    GSR_TRY(c->A.reserve((n + SEL_PAD) * 16)); GSR_TRY(c->B.reserve(n * 16)); GSR_TRY(c->C.reserve(n * 16)); GSR_TRY(c->D.reserve(n * 16));
+    const int RSH = (F + 3) & ~3;                               // SH rows padded to whole float4 (SH degree 3: 45 -> 48 floats)
+    GSR_TRY(c->A.reserve((n + SEL_PAD) * 16)); GSR_TRY(c->geo.reserve((size_t)n * 64)); GSR_TRY(c->shs.reserve((size_t)n * (RSH > 0 ? RSH : 1) * 4));
     GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4));
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
-    // row stride of the sorted SH rows.  Padding rows to 64 bytes (Fp = 48 for F = 45) was measured: k_mstep -1.5 %,
-    // k_gather_sh +50 % -> not worth it; rows stay packed and k_mstep reads them as 4-byte aligned float4.
-    const int Fp = F;
-    GSR_TRY(c->shs.reserve((size_t)n * (Fp > 0 ? Fp : 1) * 4 + 16));      // +16: the float4 reads of k_mstep may run past the last row
-    hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), c->rec.as<float4>(), c->delta, c->A.as<float4>(), c->B.as<float4>(),
-                       c->C.as<float4>(), c->D.as<float4>(), c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
+    hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), c->rec.as<float4>(), c->delta, c->A.as<float4>(), c->geo.as<float4>(),
+                       c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
     if (F > 0)
-        hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * Fp)), blk, 0, st, n, F, Fp, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
+        hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * (RSH >> 2))), blk, 0, st, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
     // the irregular components (never pre-rejected): their sorted positions, and their rank at every position
@@ -1974,7 +1975,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->scratch.reserve((Pm * 2 + 128) * 8));
     SelectArgs sa;
     memset(&sa, 0, sizeof(sa));
-    sa.A = c->A.as<float4>(); sa.B = c->B.as<float4>(); sa.C = c->C.as<float4>(); sa.D = c->D.as<float4>();
+    sa.A = c->A.as<float4>(); sa.geo = c->geo.as<float4>();
     sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
     sa.gp = c->gparams.as<GridParams>(); sa.P = P;
     sa.irank = c->irank.as<int>(); sa.ipos = c->ipos.as<unsigned>(); sa.n_irr = n_irr; sa.ell = c->use_ell ? 1 : 0;
@@ -2150,8 +2151,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (P > 0) {
         MstepArgs ma;
         memset(&ma, 0, sizeof(ma));
-        ma.A = c->A.as<float4>(); ma.B = c->B.as<float4>(); ma.C = c->C.as<float4>(); ma.D = c->D.as<float4>();
-        ma.shs = c->shs.as<float>(); ma.Fp = Fp; ma.sumLw = c->sumLw.as<float>(); ma.plist = c->plist.as<unsigned>(); ma.order = c->order.as<unsigned>();
+        ma.geo = c->geo.as<float4>(); ma.shs = c->shs.as<float>(); ma.RSH = RSH;
+        ma.sumLw = c->sumLw.as<float>(); ma.plist = c->plist.as<unsigned>(); ma.order = c->order.as<unsigned>();
         ma.prank_in = c->prank_in.as<int>(); ma.poff = c->poff.as<int64_t>(); ma.pcnt = c->pcnt.as<unsigned>();
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
@@ -2163,14 +2164,21 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.nheavy = c->counters.as<int>() + 8;
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
-        if (F <= 64) hipLaunchKernelGGL((k_mstep<1, 0>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, ma);
-        else hipLaunchKernelGGL((k_mstep<1, 4>), dim3(8 * ceil_div(P, 8)), dim3(64), 0, st, ma);
+        const dim3 mg(8 * ceil_div(P, 8));
+        const int nq = RSH >> 2;                                // float4 per SH row; a lane covers MSTEP_NV of them
+        if (nq == 0) hipLaunchKernelGGL((k_mstep<0>), mg, dim3(64), 0, st, ma);
+        else if (nq <= 1 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<1>), mg, dim3(64), 0, st, ma);
+        else if (nq <= 2 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<2>), mg, dim3(64), 0, st, ma);
+        else if (nq <= 4 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<4>), mg, dim3(64), 0, st, ma);
+        else if (nq <= 8 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<8>), mg, dim3(64), 0, st, ma);
+        else if (nq <= 16 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<16>), mg, dim3(64), 0, st, ma);
+        else hipLaunchKernelGGL((k_mstep<32>), mg, dim3(64), 0, st, ma);      // F <= 384
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
-                       c->A.as<float4>(), c->B.as<float4>(), c->C.as<float4>(), c->D.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
+                       c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
                        O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>());
     if (F > 0 && n_orph > 0)
-        hipLaunchKernelGGL(k_orphans_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, Fp, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
+        hipLaunchKernelGGL(k_orphans_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
     if (sharded && P > 0) {
         // exchange 2: the P merged components (every row written by exactly one rank, zero elsewhere, so the
         // sum is exact); the orphan rows behind them are computed identically on every rank
