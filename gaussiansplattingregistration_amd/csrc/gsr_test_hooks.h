@@ -13,10 +13,11 @@ int32_t gsr_debug_logf(const float* x, int64_t n, float* out, int32_t device);
  * child_mean/parent_mean [n*3], child_cov6/parent_cov6 [n*6]. */
 int32_t gsr_debug_kld(const float* child_mean, const float* child_cov6, const float* parent_mean,
                       const float* parent_cov6, int64_t n, float* out, int32_t device);
-/* The KL gate decision of k_select for (s2[i], q[i]) against thr: reject[i] = the kernel's decision (1 = KLD > thr),
- * fast_log[i] = v_log_f32(q) * ln 2, need_exact[i] = 1 where the decision fell back to the glibc algorithm.  Host pointers. */
-int32_t gsr_debug_kl_gate(const float* s2, const float* q, int64_t n, float thr, uint8_t* reject, float* fast_log,
-                          uint8_t* need_exact, int32_t device);
+/* The KL gate decision of k_select for s2[i] = (smd + tr) - 3 and q = det_c[i] / det_p[i] against thr: reject[i] = the
+ * kernel's decision (1 = KLD > thr), fast_log[i] = v_log_f32(det_c * (1 / det_p)) * ln 2, need_exact[i] = 1 where the decision
+ * fell back to the IEEE division + glibc logf.  Host pointers. */
+int32_t gsr_debug_kl_gate(const float* s2, const float* det_c, const float* det_p, int64_t n, float thr, uint8_t* reject,
+                          float* fast_log, uint8_t* need_exact, int32_t device);
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,8 @@
 //                                 candidates of a cell row contiguous, 1 KiB per wave instruction)
 //       geo[j][4]                 one 64-byte record per component (half a cache line, one round trip):
 //                                 {x, y, z, flags} {c00, c01, c02, c11} {c12, c22, col_r, col_g} {col_b, opacity, weight, det}
-//                                 -- what stage 2 of k_select, the parents' set-up and the M-step moments gather
+//                                 -- what stage 2 of k_select, the parents' set-up and the M-step moments gather; after the
+//                                 selection the det slot is overwritten with the child's sumLw (one gather less per pair)
 //       shs[j][RSH]               SH rest, rows padded to whole float4 (RSH = F rounded up to 4)
 //       Rs[j] query radius, cellStart[cells+1] prefix table of a dense uniform grid
 //   pair list (parent-major CSR): pair_child[M] (sorted position), pair_wl[M] (w_s * clamp(L_si))
@@ -471,6 +472,7 @@ __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __re
 //             SPARSE single pass: writes pairs at coff[p] (capacity = candidates scanned, from k_spans), count to
 //                    pcnt[p]; k_compact_pairs then packs them
 // ------------------------------------------------------------------------------------------------
+struct ParentRec;
 struct SelectArgs {
     const float4* A;                // compact {x, y, z, flags}
     const float4* geo;              // 64-byte records {A, B, C, D}
@@ -488,7 +490,9 @@ struct SelectArgs {
     int ell;                        // 1 = clip the grid rows of a regular parent to its Mahalanobis ellipsoid
     const GridParams* gp;
     int P;
-    float colorThr, kldThr, tau2;
+    float colorThr2;                // largest float x with sqrtf(x) <= kappa^2 / 2: the colour gate on the squared colour distance
+    float kldThr, tau2;
+    const ParentRec* prec;          // [P] per-parent records (k_parent_prep)
     unsigned* pcnt;                 // COUNT / SPARSE out: accepted pairs per parent
     unsigned* pcap;                 // k_spans out: candidates scanned per parent
     const int64_t* poff;            // FILL: compact offsets;  SPARSE: capacity offsets
@@ -502,15 +506,26 @@ enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
 #define SEL_MCAP 2048         // flat positions covered by the row-start bit mask at a time
 #define SEL_PAD (64 * SEL_U)  // entries the sorted A array is padded by: the inactive lanes of a batch's last chunks read past the last row
 
-struct ParentRec {
+// Everything k_select / k_spans need to know about a parent, computed ONCE per parent by k_parent_prep (one thread each)
+// and fetched by the selection waves with scalar loads: the cofactor inverse, the clipping and whitening constants cost
+// ~300 vector instructions, which every one of the 64 lanes of a wave used to repeat for its parent (17 % of k_select).
+struct EllClip {
+    float on;                 // 1.0f = clip (regular parent with a sane Schur complement)
+    float k11, k12, k22, kr, im00, m01, m02, T;
+};
+struct ParentRec {            // 40 dwords
     f3 pm, pcol;
     s6 pinv;
-    float det_p, pweight, R2;
-    float white;       // 1.0f = stage 1 uses the whitened Mahalanobis filter (regular parent)
+    float det_p, inv_det_p, pweight, R, R2;
+    float white;              // 1.0f = stage 1 uses the whitened Mahalanobis filter (regular parent)
     float u00, u01, u02, u11, u12, u22;   // upper Cholesky factor of pinv
-    float T1;          // filter bound on |U d|^2: the pre-reject bound + 1 %
+    float T1;                 // filter bound on |U d|^2: the pre-reject bound + 1 %
+    EllClip ec;
     int js;
+    int active;               // 0: zero / NaN radius or non-finite mean -> no children at all
+    int pad[4];
 };
+static_assert(sizeof(ParentRec) == 160, "ParentRec is fetched as 40 dwords");
 
 __device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }       // v_sqrt_f32, 1 ulp: clipping margins only
 
@@ -549,7 +564,7 @@ __device__ __forceinline__ void select_stage3(const SelectArgs& a, const ParentR
     if (lane < cnt) {
         const int k = (q3.h + lane) & (SEL_Q3CAP - 1);
         const float distanceDiff = sqrtf(q3.d2[k]);
-        const float cdiff = q3.cd[k];
+        const float cdiff = sqrtf(q3.cd[k]);                  // ColorDelta (gaussian.hpp:111-114); the queue holds its square
         const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
         const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
         const float L = distWeight * q3.op[k] * colorInfluence * sqrtf(q3.det[k]);
@@ -563,20 +578,22 @@ __device__ __forceinline__ void select_stage3(const SelectArgs& a, const ParentR
 
 // KL gate decision  KLD(child, parent) > thr  (gaussian.hpp:106-109, mixture.cpp:126-129) with
 //     k = 0.5f * (((smd + tr) - 3.0f) - logf(q)),   q = det_c / det_p,   s2 = (smd + tr) - 3.0f  as the reference rounds it.
-// v_log_f32 (1 ulp of log2 q, plus the rounding of the product with ln 2) puts lf within 3e-7 (1 + |ln q|) of ln q and
-// glibc's logf within 1 ulp of it, so k computed with lf differs from the reference's k by less than
-// 0.5 (4e-7 (1 + |lf|) + 2 ulp(s2 - lf)) < 1e-6 (1 + |lf| + |s2|) / 2: outside that margin around thr both give the same
-// decision; inside it (and for q not a positive normal number, or s2 not finite) the exact algorithm runs.
-// tests/test_hem_gpu.py::test_fast_log_margin checks the bound on the device.
-__device__ __forceinline__ bool kl_gate_rejects(float s2, float qd, float thr, const double* logtab, float* lf_out = nullptr,
-                                                bool* exact_out = nullptr) {
-    const float lf = __builtin_amdgcn_logf(qd) * 0.6931471805599453f;
+// Fast path: q' = det_c * (1 / det_p) (within 1.2e-7 of q) and v_log_f32 (1 ulp of log2 q', plus the rounding of the
+// product with ln 2) put lf within 4.2e-7 (1 + |ln q|) of ln q, glibc's logf is within 1 ulp of it, so k computed with lf
+// differs from the reference's k by less than 0.5 (4.8e-7 (1 + |lf|) + 2 ulp(s2 - lf)) < 1e-6 (1 + |lf| + |s2|) / 2:
+// outside that margin around thr both give the same decision; inside it (and for q' not a comfortably normal positive
+// number, or s2 not finite) the exact expression runs: IEEE division and glibc's own logf algorithm.
+// tests/test_hem_gpu.py::test_fast_log_margin checks the bound and the decisions on the device.
+__device__ __forceinline__ bool kl_gate_rejects(float s2, float det_c, float det_p, float inv_det_p, float thr, const double* logtab,
+                                                float* lf_out = nullptr, bool* exact_out = nullptr) {
+    const float qf = det_c * inv_det_p;
+    const float lf = __builtin_amdgcn_logf(qf) * 0.6931471805599453f;
     const float kf = 0.5f * (s2 - lf);
     const float margin = 1e-6f * (1.0f + fabsf(lf) + fabsf(s2));
     bool reject = kf > thr;
-    const bool need_exact = !(qd >= FLT_MIN && qd <= FLT_MAX) || !(fabsf(s2) <= FLT_MAX) || !(fabsf(kf - thr) > margin);
+    const bool need_exact = !(qf >= 4.0f * FLT_MIN && qf <= 0.25f * FLT_MAX) || !(fabsf(s2) <= FLT_MAX) || !(fabsf(kf - thr) > margin);
     if (need_exact) {
-        const float k = 0.5f * (s2 - glibc_logf_tab(qd, logtab));
+        const float k = 0.5f * (s2 - glibc_logf_tab(det_c / det_p, logtab));
         reject = k > thr;
     }
     if (lf_out) *lf_out = lf;
@@ -601,15 +618,15 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
         const f3 d = sub3(cm, pr.pm);
         d2 = dot3(d, d);                                      // == dot(pm - cm, pm - cm) bit for bit (pointindex.cpp:137)
         const f3 dc = sub3(ccol, pr.pcol);                    // ColorDelta(child, parent), gaussian.hpp:111-114
-        cdiff = sqrtf(dot3(dc, dc));
-        if (d2 < pr.R2 && !(cdiff > a.colorThr)) {            // radiusSearch (strict), mixture.cpp:122-124
+        cdiff = dot3(dc, dc);                                 // its square; sqrtf(x) > colorThr  <=>  x > colorThr2 (a.colorThr2, host)
+        if (d2 < pr.R2 && !(cdiff > a.colorThr2)) {           // radiusSearch (strict), mixture.cpp:122-124
             const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
             det_c = cd.w;
             op = cd.y;
             const float smd = dot3(d, mul6(pr.pinv, d));      // gaussian.hpp:82-85
             const float tr = trace_prod6(pr.pinv, ccov);
             const float s2 = smd + tr - 3.0f;                 // gaussian.hpp:106-109: 0.5f * (smd + tr - 3.0f - log(q))
-            if (!kl_gate_rejects(s2, det_c / pr.det_p, a.kldThr, a.logtab)) {      // mixture.cpp:126-129 (NaN passes)
+            if (!kl_gate_rejects(s2, det_c, pr.det_p, pr.inv_det_p, a.kldThr, a.logtab)) {      // mixture.cpp:126-129 (NaN passes)
                 const bool child_is_parent = (__float_as_uint(ca.w) & 1u) != 0u;
                 acc = !(child_is_parent && j != pr.js);       // mixture.cpp:131-133
             }
@@ -629,17 +646,13 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     __builtin_amdgcn_wave_barrier();
 }
 
-// Row clipping by the parent's pre-reject ellipsoid E = { x : (x-mu)^T P^-1 (x-mu) <= T }.  A regular child outside E
-// fails the stage-1 filter anyway, so for a regular parent only the grid cells E touches need scanning (E is
+// Row clipping by the parent's pre-reject ellipsoid E = { x : (x-mu)^T P^-1 (x-mu) <= T } (struct EllClip).  A regular child
+// outside E fails the stage-1 filter anyway, so for a regular parent only the grid cells E touches need scanning (E is
 // inscribed in the query sphere and typically holds 1/3 of its volume).  For a row (= the slab dy in [cy-hy, cy+hy],
 // dz in [cz-hz, cz+hz] relative to the parent) write  smd = M00 (dx - xc(dy,dz))^2 + S(dy,dz)  with xc linear and
 // S the Schur-complement form K; sqrt(S) is a norm, so over the slab  sqrt(S) >= sqrt(S(c)) - sqrt(lmax(K)) |h|,
 // lmax(K) <= tr K, and |xc - xc(c)| <= (|M01| hy + |M02| hz) / M00: a conservative x interval in ~40 flops.
 // T carries 1% over smdMax: the float32 rounding of smd and of K is < 1e-3 relative for kappa(P) < 80.
-struct EllClip {
-    float on;                 // 1.0f = clip (regular parent with a sane Schur complement)
-    float k11, k12, k22, kr, im00, m01, m02, T;
-};
 
 // The span (first sorted position, length) of one grid row (ry, rz) for a parent at pm: the row's cells within the
 // sphere of radius sqrt(Ra2), clipped to the pre-reject ellipsoid when `clip`.  IRR: positions in the irregular list.
@@ -723,15 +736,47 @@ __device__ __forceinline__ void make_whitening(const s6& M, float smdMax, Parent
     pr.white = ok ? 1.0f : 0.0f;
 }
 
+// One thread per parent: the record the selection kernels read (see struct ParentRec).
+__global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __restrict__ plist, const float4* __restrict__ geo,
+                                                     const float* __restrict__ Rs, float kldThr, int ell, ParentRec* __restrict__ prec) {
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        ParentRec pr;
+        pr.js = (int)plist[p];
+        const float4* prow = geo + 4 * (int64_t)pr.js;
+        const float4 pa = prow[0], pb = prow[1], pc = prow[2], pd = prow[3];
+        pr.pm = {pa.x, pa.y, pa.z};
+        pr.det_p = pd.w;
+        pr.inv_det_p = 1.0f / pd.w;
+        // Pre-reject bound (exactness argument in DESIGN.md "KL gate pre-reject"): for a regular parent and a regular
+        // child, tr(P^-1 C) - 3 - ln(|C|/|P|) >= 0 in exact arithmetic and the reference's float32 evaluation of it is
+        // >= -0.15, so  smd > 2*thr + 0.2 (+0.1%)  implies  KLD_float32 > thr: the pair is rejected by the reference too.
+        const float smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * kldThr + 0.2f) * 1.001f : __builtin_inff();
+        const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
+        pr.pcol = {pc.z, pc.w, pd.x};
+        pr.pweight = pd.z;
+        pr.pinv = inverse6(pcov, pr.det_p);
+        pr.R = Rs[pr.js];
+        pr.R2 = pr.R * pr.R;
+        pr.ec = make_ellclip(pr.pinv, smdMax, ell);
+        make_whitening(pr.pinv, smdMax, pr);
+        // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
+        const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
+        pr.active = (pr.R2 > 0.0f && pm_finite) ? 1 : 0;
+        pr.pad[0] = pr.pad[1] = pr.pad[2] = pr.pad[3] = 0;
+        prec[p] = pr;
+    }
+}
+
 // One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
 // REGULAR ones; IRR = true scans the list of irregular components (ipos, addressed through irank at the cell
 // boundaries).  Survivors of the stage-1 filter go to the LDS ring.
 template <int MODE, bool IRR>
-__device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const EllClip& ec, float R,
-                                            int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count,
+__device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr,
+                                            const float (&vc)[11], int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count,
                                             int64_t& base, Q3& q3) {
     const f3 pm = pr.pm;
-    const float Ra = fabsf(R) * 1.00001f + g.slack;             // conservative search extent
+    const EllClip& ec = pr.ec;
+    const float Ra = fabsf(pr.R) * 1.00001f + g.slack;             // conservative search extent
     const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
     const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
     const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
@@ -789,12 +834,13 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
                     const f3 cm = {ca[u].x, ca[u].y, ca[u].z};
                     bool in;
                     if (white) {                                              // regular parent, regular children
-                        const f3 d = sub3(cm, pm);
-                        const float y2 = pr.u22 * d.z;
-                        const float y1 = __builtin_fmaf(pr.u11, d.y, pr.u12 * d.z);
-                        const float y0 = __builtin_fmaf(pr.u00, d.x, __builtin_fmaf(pr.u01, d.y, pr.u02 * d.z));
+                        // vc = {pm, U, T1} in VECTOR registers: a VALU instruction with an SGPR operand issues at half rate
+                        const float dx = cm.x - vc[0], dy = cm.y - vc[1], dz = cm.z - vc[2];
+                        const float y2 = vc[8] * dz;
+                        const float y1 = __builtin_fmaf(vc[6], dy, vc[7] * dz);
+                        const float y0 = __builtin_fmaf(vc[3], dx, __builtin_fmaf(vc[4], dy, vc[5] * dz));
                         const float smd = __builtin_fmaf(y0, y0, __builtin_fmaf(y1, y1, y2 * y2));
-                        in = !(smd > pr.T1);
+                        in = !(smd > vc[9]);
                     } else {                                                  // the reference's radius test (pointindex.cpp:137)
                         const f3 dq = sub3(pm, cm);
                         in = dot3(dq, dq) < pr.R2;
@@ -845,36 +891,14 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
         return;
     }
     const GridParams g = *a.gp;
-    ParentRec pr;
-    pr.js = (int)a.plist[p];
-    float smdMax;
+    const ParentRec pr = a.prec[p];     // uniform address: scalar loads, the record lives in SGPRs
+    // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs once per parent)
+    float vc[11];
     {
-        const float4* prow = a.geo + 4 * (int64_t)pr.js;
-        const float4 pa = prow[0], pb = prow[1], pc = prow[2], pd = prow[3];
-        pr.pm = {pa.x, pa.y, pa.z};
-        pr.det_p = pd.w;
-        // Pre-reject bound (exactness argument in DESIGN.md "KL gate pre-reject"): for a regular parent and a regular
-        // child, tr(P^-1 C) - 3 - ln(|C|/|P|) >= 0 in exact arithmetic and the reference's float32 evaluation of it is
-        // >= -0.15, so  smd > 2*thr + 0.2 (+0.1%)  implies  KLD_float32 > thr: the pair is rejected by the reference too.
-        smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * a.kldThr + 0.2f) * 1.001f : __builtin_inff();
-        const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
-        pr.pcol = {pc.z, pc.w, pd.x};
-        pr.pweight = pd.z;
-        pr.pinv = inverse6(pcov, pr.det_p);
+        const float src[11] = {pr.pm.x, pr.pm.y, pr.pm.z, pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 11; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vc[i]) : "s"(src[i]));
     }
-    const float R = a.Rs[pr.js];
-    pr.R2 = R * R;
-    EllClip ec = make_ellclip(pr.pinv, smdMax, a.ell);
-    make_whitening(pr.pinv, smdMax, pr);
-    // the parent record is wave-uniform: pin it in SGPRs
-#define GSR_UNI(x) x = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x)))
-    GSR_UNI(pr.pm.x); GSR_UNI(pr.pm.y); GSR_UNI(pr.pm.z); GSR_UNI(pr.pcol.x); GSR_UNI(pr.pcol.y); GSR_UNI(pr.pcol.z);
-    GSR_UNI(pr.pinv.e00); GSR_UNI(pr.pinv.e01); GSR_UNI(pr.pinv.e02); GSR_UNI(pr.pinv.e11); GSR_UNI(pr.pinv.e12); GSR_UNI(pr.pinv.e22);
-    GSR_UNI(pr.det_p); GSR_UNI(pr.pweight); GSR_UNI(pr.R2); GSR_UNI(pr.white); GSR_UNI(pr.T1);
-    GSR_UNI(pr.u00); GSR_UNI(pr.u01); GSR_UNI(pr.u02); GSR_UNI(pr.u11); GSR_UNI(pr.u12); GSR_UNI(pr.u22);
-    GSR_UNI(ec.on); GSR_UNI(ec.k11); GSR_UNI(ec.k12); GSR_UNI(ec.k22); GSR_UNI(ec.kr); GSR_UNI(ec.im00); GSR_UNI(ec.m01); GSR_UNI(ec.m02); GSR_UNI(ec.T);
-#undef GSR_UNI
-    pr.js = __builtin_amdgcn_readfirstlane(pr.js);
 
     unsigned count = 0;                 // accepted pairs (uniform across the wave)
     int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
@@ -883,13 +907,11 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     Q3 q3 = {s_q3j[wv], s_q3f[wv][0], s_q3f[wv][1], s_q3f[wv][2], s_q3f[wv][3], 0, 0};
     __builtin_amdgcn_wave_barrier();
 
-    // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
-    const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
-    if (pr.R2 > 0.0f && pm_finite) {
+    if (pr.active) {
         // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
         // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
-        select_scan<MODE, false>(a, g, pr, ec, R, lane, s_bits[wv], q, qh, qn, count, base, q3);
-        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, ec, R, lane, s_bits[wv], q, qh, qn, count, base, q3);
+        select_scan<MODE, false>(a, g, pr, vc, lane, s_bits[wv], q, qh, qn, count, base, q3);
+        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, vc, lane, s_bits[wv], q, qh, qn, count, base, q3);
         if (qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base, q3);
         if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, pr, lane, q3.n, q3, base);
     }
@@ -906,17 +928,11 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
     unsigned long long scanned = 0;
     if (p >= a.own_lo && p < a.own_hi) {
         const GridParams g = *a.gp;
-        const int js = (int)a.plist[p];
-        const float4* prow = a.geo + 4 * (int64_t)js;
-        const float4 pa = prow[0], pb = prow[1], pc = prow[2], pd = prow[3];
-        const f3 pm = {pa.x, pa.y, pa.z};
-        const float smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * a.kldThr + 0.2f) * 1.001f : __builtin_inff();
-        const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
-        const EllClip ec = make_ellclip(inverse6(pcov, pd.w), smdMax, a.ell);
-        const float R = a.Rs[js];
-        const bool pm_finite = fabsf(pm.x) <= FLT_MAX && fabsf(pm.y) <= FLT_MAX && fabsf(pm.z) <= FLT_MAX;
-        if (R * R > 0.0f && pm_finite) {
-            const float Ra = fabsf(R) * 1.00001f + g.slack;
+        const ParentRec* rp = a.prec + p;
+        const f3 pm = rp->pm;
+        const EllClip ec = rp->ec;
+        if (rp->active) {
+            const float Ra = fabsf(rp->R) * 1.00001f + g.slack;
             const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
             const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
             const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
@@ -997,7 +1013,7 @@ __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __r
 // per-child sum of wL_si, sequential in the (stable) sorted pair order (mixture.cpp:162)
 __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restrict__ cstart,
                                                const float* __restrict__ wl_sorted, float* __restrict__ sumLw,
-                                               int* __restrict__ orphan_flag) {
+                                               int* __restrict__ orphan_flag, float* __restrict__ geo_sl) {
     // 8 lanes per child (a child has ~22 pairs, contiguous after the sort): lane s adds elements s, s+8, ... in order and
     // the eight partial sums are folded in a fixed tree -- deterministic, and the wave reads contiguous memory
     // (thread-per-child read 64 scattered segments per load: 0.59 -> 0.2 ms at 5 M).
@@ -1012,6 +1028,7 @@ __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restr
         s += __shfl_xor(s, 1);
         if (sub == 0) {
             sumLw[j] = s;
+            geo_sl[16 * j] = s;
             orphan_flag[j] = s == 0.0f ? 1 : 0;
         }
     }
@@ -1069,7 +1086,8 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, const unsigne
     }
 }
 __global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, const unsigned long long* __restrict__ bstart, const unsigned* __restrict__ child,
-                                                     const float* __restrict__ wl, float* __restrict__ sumLw, int* __restrict__ orphan_flag) {
+                                                     const float* __restrict__ wl, float* __restrict__ sumLw, int* __restrict__ orphan_flag,
+                                                     float* __restrict__ geo_sl) {
     extern __shared__ unsigned long long s_acc[];  // [SUM_BUCKET] int64 accumulators, then [SUM_BUCKET] max bit patterns
     unsigned* s_max = (unsigned*)(s_acc + SUM_BUCKET);
     const int b = blockIdx.x;
@@ -1113,13 +1131,16 @@ __global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, const unsigned l
             sres = (float)((double)(long long)s_acc[i] * inv);
         }
         sumLw[c0 + i] = sres;
+        geo_sl[16 * (c0 + i)] = sres;                  // also into the 64-byte geometry record (in place of det, which only the selection used)
         orphan_flag[c0 + i] = sres == 0.0f ? 1 : 0;
     }
 }
 
-__global__ __launch_bounds__(256) void k_orphan_flags(int64_t n, const float* __restrict__ sumLw, int* __restrict__ orphan_flag) {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+__global__ __launch_bounds__(256) void k_orphan_flags(int64_t n, const float* __restrict__ sumLw, int* __restrict__ orphan_flag, float* __restrict__ geo_sl) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         orphan_flag[j] = sumLw[j] == 0.0f ? 1 : 0;
+        geo_sl[16 * j] = sumLw[j];
+    }
 }
 
 // flags back to INPUT order, where the output ranks are defined (mixture.cpp:169,250-253)
@@ -1135,161 +1156,254 @@ __global__ __launch_bounds__(256) void k_flags_to_input_order(int64_t n, const u
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_mstep: responsibilities and moment-matching update (mixture.cpp:167-247), one wavefront per parent.
+// k_mstep: responsibilities and moment-matching update (mixture.cpp:167-247).
 //
+// One wavefront handles MSTEP_K consecutive parents of the processing order.  Their headers (pair offset and count,
+// output row, parent mean) were laid out in that order by k_mstep_headers, so a wave fetches them with scalar loads at
+// its start; the pair records of parent i+1 are prefetched while parent i is being reduced.  Per parent:
 //   part 1   lane <-> pair: w = (wL_si / sumLw_i) * weight_i (mixture.cpp:196-197), the 14 moment sums in the
-//            reference's expressions; w and the child index go to LDS.  All gathers of a pair (sumLw and the 64-byte
-//            geometry record) are issued together and unconditionally.
+//            reference's expressions; child index and w go to LDS.  All gathers of a pair (sumLw and the 64-byte
+//            geometry record) are issued together and unconditionally, and the first round of SH row loads is issued
+//            BEFORE they are consumed (it needs the child indices only).
 //   part 2   lane group <-> child: G lanes x 3 float4 cover one SH row, so one round of three load instructions
-//            fetches the rows of 64/G children (16 at SH degree 3), MSTEP_U rounds in flight.
-//   sums     across lanes by DPP row rotations and v_permlane16/32_swap (class_sum): no LDS-crossbar traffic.  (The
-//            first version folded 14 values through six ds_bpermute steps each: 84 LDS-pipe instructions per parent.)
+//            fetches the rows of 64/G children (16 at SH degree 3).
+//   sums     across lanes by DPP row rotations and v_permlane16/32_swap (class_sum): no LDS-crossbar traffic.
+//   output   the SH row leaves through LDS as one coalesced store.
+// (History: one parent per wave with a dependent round trip per phase, SH rows four children per load and butterfly sums by
+// ds_bpermute: 4.0 ms at 5 M.)
 // ------------------------------------------------------------------------------------------------
+struct MstepHeader {           // 32 bytes, one per processing slot
+    long long off;             // first pair of the parent in the CSR
+    unsigned cnt;              // its pairs
+    int oslot;                 // output row (-1: parent of another rank, nothing to do)
+    float px, py, pz;          // parent mean
+    int js;                    // sorted position of the parent
+};
 struct MstepArgs {
     const float4* geo;
     const float* shs;
     int RSH;                   // row stride of shs in floats (F rounded up to 4)
-    const float* sumLw;
-    const unsigned* plist;
-    const unsigned* porder;    // processing order (heavy parents first) or NULL
+    const MstepHeader* hdr;    // [P], processing order
     int xcd;
     const int* nheavy;
-    int own_lo, own_hi;        // sharded level: parents of other ranks are skipped (their output rows stay zero)
-    const unsigned* order;
-    const int* prank_in;       // exclusive scan of the parent flags in input order
-    const int64_t* poff;
-    const unsigned* pcnt;
     const unsigned* pair_child;
     const float* pair_wl;
     int P, F;
     float *o_xyz, *o_color, *o_cov6, *o_opacity, *o_weight, *o_sh;
 };
+__global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __restrict__ porder, const unsigned* __restrict__ plist,
+                                                       const int64_t* __restrict__ poff, const unsigned* __restrict__ pcnt,
+                                                       const unsigned* __restrict__ order, const int* __restrict__ prank_in,
+                                                       const float4* __restrict__ A, int own_lo, int own_hi, MstepHeader* __restrict__ hdr) {
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < P; s += gridDim.x * blockDim.x) {
+        const int p = porder ? (int)porder[s] : s;
+        const int js = (int)plist[p];
+        const float4 a = A[js];
+        MstepHeader h;
+        h.off = poff[p]; h.cnt = pcnt[p]; h.js = js;
+        h.oslot = (p >= own_lo && p < own_hi) ? prank_in[order[js]] : -1;
+        h.px = a.x; h.py = a.y; h.pz = a.z;
+        hdr[s] = h;
+    }
+}
 
 #define MSTEP_CHUNK 256
-#define MSTEP_U 2             // rounds of SH row loads in flight (each: 3 float4 per lane)
-#define MSTEP_NV 3            // float4 per lane and row
+#define MSTEP_NV 3            // float4 per lane and SH row
+#define MSTEP_K 4             // parents per wavefront
+#define MSTEP_PF 2            // pair records per lane prefetched for the next parent (covers 128 pairs)
 
 // G = lanes per SH row (power of two, G * MSTEP_NV float4 >= RSH / 4); G == 0: no SH at all
-template <int G>
-__global__ __launch_bounds__(64) void k_mstep(MstepArgs a) {
-    __shared__ float s_w[MSTEP_CHUNK];
-    __shared__ unsigned s_j[MSTEP_CHUNK];
+template <int G, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
+    __shared__ float s_w_[WPB][MSTEP_CHUNK];
+    __shared__ unsigned s_j_[WPB][MSTEP_CHUNK];
+    __shared__ float4 s_acc_[WPB][MSTEP_NV * 64];               // per-lane SH partial sums of a parent with more than MSTEP_CHUNK pairs
     constexpr int GG = G > 0 ? G : 1;
     constexpr int CPR = 64 / GG;                                // children per round
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    float* s_w = s_w_[wv];
+    unsigned* s_j = s_j_[wv];
+    float4* s_acc = s_acc_[wv];
+    float* s_out = reinterpret_cast<float*>(s_acc);             // at the end of a parent: its SH row on the way out
     const int gl = lane & (GG - 1), grp = lane / GG;
-    const int hb = a.nheavy ? ((*a.nheavy + 7) & ~7) : 0;
-    const int slot_ = block_slot((int)blockIdx.x, a.P, hb < a.P ? hb : a.P, a.xcd);
-    if (slot_ < 0) return;
-    const int p = a.porder ? (int)a.porder[slot_] : slot_;
-    if (p < a.own_lo || p >= a.own_hi) return;
-    const int js = (int)a.plist[p];
-    const float4 pa = a.geo[4 * (int64_t)js];
-    const f3 pm = {pa.x, pa.y, pa.z};
-    const int64_t off = a.poff[p];
-    const unsigned cnt = a.pcnt[p];
-    const int64_t slot = a.prank_in[a.order[js]];               // output row: issued early, needed last
-
-    float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
-    float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
+    constexpr int KB = MSTEP_K * WPB;                           // parents per workgroup: consecutive slots, neighbours in space
+    const int nblk = (a.P + KB - 1) / KB;
+    const int hbk = a.nheavy ? (((*a.nheavy + KB - 1) / KB + 7) & ~7) : 0;
+    const int bid = block_slot((int)blockIdx.x, nblk, hbk < nblk ? hbk : nblk, a.xcd);
+    if (bid < 0) return;
+    const int s0 = bid * KB + wv * MSTEP_K;
+    if (s0 >= a.P) return;
+    const int ns = a.P - s0 < MSTEP_K ? a.P - s0 : MSTEP_K;     // parents of this wave
     const int nq = a.RSH >> 2;                                  // float4 per SH row
     int qi[MSTEP_NV];                                           // float4 slots of this lane (slots beyond the row: re-read slot 0, discarded)
 #pragma unroll
     for (int v = 0; v < MSTEP_NV; ++v) qi[v] = gl + GG * v < nq ? gl + GG * v : 0;
-    float4 acc[MSTEP_NV];
-#pragma unroll
-    for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
 
-    for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
-        const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
-        // part 1
-        for (unsigned k = lane; k < cn; k += 64) {
-            const unsigned j = a.pair_child[off + c0 + k];
-            const float wl = a.pair_wl[off + c0 + k];
-            const float sl = a.sumLw[j];
-            const float4* row = a.geo + 4 * (int64_t)j;
-            const float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];
-            float w = 0.0f;
-            if (sl != 0.0f) {                                  // sumLw == 0: skipped (mixture.cpp:190)
-                const float r_is = wl / sl;                    // mixture.cpp:196
-                w = r_is * cd.z;                               // * child.weight (:197)
-                const f3 cm = {ca.x, ca.y, ca.z};
-                const f3 d = sub3(cm, pm);
-                w_s += w;
-                smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
-                scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
-                v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
-                v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
-                so += w * cd.y;
-            }
-            s_w[k] = w;
-            s_j[k] = j;
+    // pair records of the first parent
+    unsigned pfj[MSTEP_PF];
+    float pfw[MSTEP_PF];
+    {
+        const MstepHeader h = a.hdr[s0];
+#pragma unroll
+        for (int t = 0; t < MSTEP_PF; ++t) {
+            const unsigned k = lane + 64 * t;
+            const unsigned kc = h.oslot >= 0 && k < h.cnt ? k : 0u;
+            pfj[t] = h.cnt > 0 ? a.pair_child[h.off + kc] : 0u;
+            pfw[t] = h.cnt > 0 ? a.pair_wl[h.off + kc] : 0.0f;
         }
-        __builtin_amdgcn_wave_barrier();
-        // part 2: children in pair order; a skipped child has w = 0 (its row is loaded all the same: no branch per load)
-        if (G > 0) {
-            for (unsigned k0 = 0; k0 < cn; k0 += CPR * MSTEP_U) {
-                float4 rowv[MSTEP_U][MSTEP_NV];
-                float wv[MSTEP_U];
+    }
+    for (int it = 0; it < ns; ++it) {
+        const MstepHeader h = a.hdr[s0 + it];                   // uniform address: scalar loads
+        const f3 pm = {h.px, h.py, h.pz};
+        const unsigned cnt = h.oslot >= 0 ? h.cnt : 0u;
+        unsigned curj[MSTEP_PF];
+        float curw[MSTEP_PF];
 #pragma unroll
-                for (int u = 0; u < MSTEP_U; ++u) {
-                    const unsigned k = k0 + CPR * u + grp;
-                    const unsigned kc = k < cn ? k : cn - 1;    // unconditional LDS reads and loads
-                    const unsigned j = s_j[kc];
-                    wv[u] = k < cn ? s_w[kc] : 0.0f;
-                    const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
+        for (int t = 0; t < MSTEP_PF; ++t) { curj[t] = pfj[t]; curw[t] = pfw[t]; }
+        if (it + 1 < ns) {                                      // prefetch the next parent's pairs (wave-uniform branch)
+            const MstepHeader hn = a.hdr[s0 + it + 1];
 #pragma unroll
-                    for (int v = 0; v < MSTEP_NV; ++v) rowv[u][v] = row[qi[v]];
+            for (int t = 0; t < MSTEP_PF; ++t) {
+                const unsigned k = lane + 64 * t;
+                const unsigned kc = hn.oslot >= 0 && k < hn.cnt ? k : 0u;
+                pfj[t] = hn.cnt > 0 ? a.pair_child[hn.off + kc] : 0u;
+                pfw[t] = hn.cnt > 0 ? a.pair_wl[hn.off + kc] : 0.0f;
+            }
+        }
+        if (h.oslot < 0) continue;
+
+        float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
+        float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
+        // SH sums: local to a chunk of pairs (so that they occupy no registers during part 1); a parent with more than
+        // MSTEP_CHUNK pairs (rare) carries its per-lane partial sums from chunk to chunk in LDS
+        float4 acc[MSTEP_NV];
+        const bool multi = cnt > MSTEP_CHUNK;
+
+        for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
+            const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
+            // child indices to LDS first: the SH row loads need nothing else
+#pragma nounroll
+            for (unsigned k = lane, t = 0; k < cn; k += 64, ++t) {
+                unsigned j;
+                if (c0 == 0 && t < MSTEP_PF) j = t == 0 ? curj[0] : curj[MSTEP_PF - 1];
+                else j = a.pair_child[h.off + c0 + k];
+                s_j[k] = j;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // first round of SH rows in flight while part 1 runs
+            float4 rowv[MSTEP_NV];
+            if (G > 0) {
+                const unsigned k = grp;
+                const unsigned j = s_j[k < cn ? k : cn - 1];
+                const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
+#pragma unroll
+                for (int v = 0; v < MSTEP_NV; ++v) rowv[v] = row[qi[v]];
+            }
+            // part 1
+#pragma nounroll
+            for (unsigned k = lane, t = 0; k < cn; k += 64, ++t) {
+                const unsigned j = s_j[k];
+                float wl;
+                if (c0 == 0 && t < MSTEP_PF) wl = t == 0 ? curw[0] : curw[MSTEP_PF - 1];
+                else wl = a.pair_wl[h.off + c0 + k];
+                const float4* row = a.geo + 4 * (int64_t)j;
+                const float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];
+                const float sl = cd.w;                         // sumLw_i: k_bucket_sum stored it in the record (in place of det)
+                float w = 0.0f;
+                if (sl != 0.0f) {                              // sumLw == 0: skipped (mixture.cpp:190)
+                    const float r_is = wl / sl;                // mixture.cpp:196
+                    w = r_is * cd.z;                           // * child.weight (:197)
+                    const f3 cm = {ca.x, ca.y, ca.z};
+                    const f3 d = sub3(cm, pm);
+                    w_s += w;
+                    smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
+                    scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
+                    v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
+                    v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
+                    so += w * cd.y;
                 }
+                s_w[k] = w;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // part 2: children in pair order; a skipped child has w = 0 (its row is loaded all the same: no branch per load)
+            if (G > 0) {
 #pragma unroll
-                for (int u = 0; u < MSTEP_U; ++u) {
+                for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (multi && c0 > 0) {
+#pragma unroll
+                    for (int v = 0; v < MSTEP_NV; ++v) acc[v] = s_acc[v * 64 + lane];
+                }
+                for (unsigned k0 = 0; k0 < cn; k0 += CPR) {
+                    const unsigned k = k0 + grp;
+                    const float wk = k < cn ? s_w[k < cn ? k : cn - 1] : 0.0f;
+                    float4 cur[MSTEP_NV];
+#pragma unroll
+                    for (int v = 0; v < MSTEP_NV; ++v) cur[v] = rowv[v];
+                    if (k0 + CPR < cn) {                        // next round's rows (wave-uniform branch)
+                        const unsigned kn = k + CPR;
+                        const unsigned j = s_j[kn < cn ? kn : cn - 1];
+                        const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
+#pragma unroll
+                        for (int v = 0; v < MSTEP_NV; ++v) rowv[v] = row[qi[v]];
+                    }
 #pragma unroll
                     for (int v = 0; v < MSTEP_NV; ++v) {
-                        acc[v].x += rowv[u][v].x * wv[u]; acc[v].y += rowv[u][v].y * wv[u];
-                        acc[v].z += rowv[u][v].z * wv[u]; acc[v].w += rowv[u][v].w * wv[u];
+                        acc[v].x = __builtin_fmaf(cur[v].x, wk, acc[v].x); acc[v].y = __builtin_fmaf(cur[v].y, wk, acc[v].y);
+                        acc[v].z = __builtin_fmaf(cur[v].z, wk, acc[v].z); acc[v].w = __builtin_fmaf(cur[v].w, wk, acc[v].w);
                     }
                 }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-    w_s = class_sum<1>(w_s);
-    smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
-    scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
-    v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
-    v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
-    so = class_sum<1>(so);
-
-    const float inv_w = 1.0f / w_s;                            // mixture.cpp:209
-    if (lane == 0) {
-        const float mx = smx * inv_w, my = smy * inv_w, mz = smz * inv_w;
-        const float dx = mx - pm.x, dy = my - pm.y, dz = mz - pm.z;
-        a.o_xyz[3 * slot] = mx; a.o_xyz[3 * slot + 1] = my; a.o_xyz[3 * slot + 2] = mz;
-        a.o_color[3 * slot] = scx * inv_w; a.o_color[3 * slot + 1] = scy * inv_w; a.o_color[3 * slot + 2] = scz * inv_w;
-        a.o_cov6[6 * slot] = v00 * inv_w - dx * dx;
-        a.o_cov6[6 * slot + 1] = v01 * inv_w - dx * dy;
-        a.o_cov6[6 * slot + 2] = v02 * inv_w - dx * dz;
-        a.o_cov6[6 * slot + 3] = v11 * inv_w - dy * dy;
-        a.o_cov6[6 * slot + 4] = v12 * inv_w - dy * dz;
-        a.o_cov6[6 * slot + 5] = v22 * inv_w - dz * dz;
-        a.o_opacity[slot] = inv_w * so;
-        a.o_weight[slot] = w_s;
-    }
-    if (G > 0) {
+                if (multi && c0 + MSTEP_CHUNK < cnt) {
 #pragma unroll
-        for (int v = 0; v < MSTEP_NV; ++v) {
-            acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
-            acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
+                    for (int v = 0; v < MSTEP_NV; ++v) s_acc[v * 64 + lane] = acc[v];
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
         }
-        if (grp == 0) {
+        w_s = class_sum<1>(w_s);
+        smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
+        scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
+        v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
+        v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
+        so = class_sum<1>(so);
+
+        const float inv_w = 1.0f / w_s;                        // mixture.cpp:209
+        const int64_t slot = h.oslot;
+        if (lane == 0) {
+            const float mx = smx * inv_w, my = smy * inv_w, mz = smz * inv_w;
+            const float dx = mx - pm.x, dy = my - pm.y, dz = mz - pm.z;
+            a.o_xyz[3 * slot] = mx; a.o_xyz[3 * slot + 1] = my; a.o_xyz[3 * slot + 2] = mz;
+            a.o_color[3 * slot] = scx * inv_w; a.o_color[3 * slot + 1] = scy * inv_w; a.o_color[3 * slot + 2] = scz * inv_w;
+            a.o_cov6[6 * slot] = v00 * inv_w - dx * dx;
+            a.o_cov6[6 * slot + 1] = v01 * inv_w - dx * dy;
+            a.o_cov6[6 * slot + 2] = v02 * inv_w - dx * dz;
+            a.o_cov6[6 * slot + 3] = v11 * inv_w - dy * dy;
+            a.o_cov6[6 * slot + 4] = v12 * inv_w - dy * dz;
+            a.o_cov6[6 * slot + 5] = v22 * inv_w - dz * dz;
+            a.o_opacity[slot] = inv_w * so;
+            a.o_weight[slot] = w_s;
+        }
+        if (G > 0) {
+            if (cnt == 0) {                                     // no child at all (zero or NaN radius): 0 / 0 like the reference
+#pragma unroll
+                for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
 #pragma unroll
             for (int v = 0; v < MSTEP_NV; ++v) {
-                const int f0 = 4 * (gl + GG * v);               // first SH coefficient of this lane's float4
-                const float vals[4] = {acc[v].x, acc[v].y, acc[v].z, acc[v].w};
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (f0 + c < a.F) a.o_sh[slot * a.F + f0 + c] = vals[c] * inv_w;
+                acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
+                acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
             }
+            // the row leaves through LDS: F consecutive floats, one coalesced store per 64
+            if (grp == 0) {
+#pragma unroll
+                for (int v = 0; v < MSTEP_NV; ++v) {
+                    const int f0 = 4 * (gl + GG * v);
+                    s_out[f0] = acc[v].x * inv_w; s_out[f0 + 1] = acc[v].y * inv_w;
+                    s_out[f0 + 2] = acc[v].z * inv_w; s_out[f0 + 3] = acc[v].w * inv_w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            for (int f = lane; f < a.F; f += 64) a.o_sh[slot * a.F + f] = s_out[f];
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -1479,12 +1593,12 @@ __global__ void k_debug_kld(int64_t n, const float* __restrict__ cm, const float
     }
 }
 
-__global__ void k_debug_kl_gate(int64_t n, const float* __restrict__ s2, const float* __restrict__ q, float thr, uint8_t* __restrict__ reject,
-                                float* __restrict__ lf, uint8_t* __restrict__ need_exact) {
+__global__ void k_debug_kl_gate(int64_t n, const float* __restrict__ s2, const float* __restrict__ det_c, const float* __restrict__ det_p, float thr,
+                                uint8_t* __restrict__ reject, float* __restrict__ lf, uint8_t* __restrict__ need_exact) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         float l;
         bool ex;
-        reject[i] = kl_gate_rejects(s2[i], q[i], thr, k_logf_tab, &l, &ex) ? 1 : 0;
+        reject[i] = kl_gate_rejects(s2[i], det_c[i], det_p[i], 1.0f / det_p[i], thr, k_logf_tab, &l, &ex) ? 1 : 0;
         lf[i] = l;
         need_exact[i] = ex ? 1 : 0;
     }
@@ -1535,7 +1649,7 @@ struct gsr_hem_ctx {
     bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
     unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
-    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx;
+    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec;
     bool use_ell = true;            // GSR_HEM_ELL=0: no ellipsoid row clipping (test knob: the pair set must not change)
     int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
     gsr_allreduce_dev_fn shard_allreduce = nullptr;
@@ -1742,7 +1856,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
-                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
+                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
                      &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
@@ -1984,7 +2098,21 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     const int own_lo = sharded ? (int)((int64_t)P * c->shard_rank / c->shard_world) : 0;
     const int own_hi = sharded ? (int)((int64_t)P * (c->shard_rank + 1) / c->shard_world) : P;
     sa.own_lo = own_lo; sa.own_hi = own_hi;
-    sa.colorThr = c->kappa * c->kappa * 0.5f;     // mixture.cpp:123
+    {   // colour gate  sqrtf(x) > kappa^2/2  (mixture.cpp:123) as a test on x: sqrtf is correctly rounded and monotone, so the
+        // gate is  x > x*,  x* = the largest float whose square root does not exceed the threshold
+        const float t = c->kappa * c->kappa * 0.5f;
+        float x;
+        if (t != t) x = t;                               // NaN threshold: never rejects
+        else if (t < 0.0f) x = -1.0f;                    // every distance exceeds it
+        else if (t > FLT_MAX) x = t;                     // +inf: never rejects
+        else {
+            x = t * t;
+            if (x > FLT_MAX) x = FLT_MAX;
+            while (x < FLT_MAX && sqrtf(nextafterf(x, INFINITY)) <= t) x = nextafterf(x, INFINITY);
+            while (x > 0.0f && sqrtf(x) > t) x = nextafterf(x, -INFINITY);
+        }
+        sa.colorThr2 = x;
+    }
     sa.kldThr = c->delta * c->delta * 0.5f;       // mixture.cpp:128
     sa.tau2 = c->tau * c->tau;                    // mixture.cpp:58,61
     sa.pcnt = c->pcnt.as<unsigned>();
@@ -2011,6 +2139,10 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     };
     c->sparse_path = false;
     if (P > 0) {
+        GSR_TRY(c->prec.reserve(Pm * sizeof(ParentRec)));
+        hipLaunchKernelGGL(k_parent_prep, dim3(stride_grid(P)), blk, 0, st, P, c->plist.as<unsigned>(), c->geo.as<float4>(), c->Rs.as<float>(),
+                           sa.kldThr, sa.ell, c->prec.as<ParentRec>());
+        sa.prec = c->prec.as<ParentRec>();
         hipLaunchKernelGGL(k_spans, dim3(ceil_div(P, 16)), dim3(256), 0, st, sa);      // candidates scanned per parent
         GSR_TRY(c->coff.reserve((Pm + 1) * 8));
         GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>(), P));
@@ -2096,7 +2228,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipGetLastError());
         GSR_CHECKPOINT("pair partition");
         hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(1024), (size_t)SUM_BUCKET * 12, st, n, c->bstart.as<unsigned long long>(),
-                           c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
+                           c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
         GSR_HIP(hipGetLastError());
     } else {
         if (M > 0) {
@@ -2107,13 +2239,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         } else {
             hipLaunchKernelGGL(k_fill_const<int64_t>, grd, blk, 0, st, n + 1, c->cstart.as<int64_t>(), (int64_t)0);
         }
-        hipLaunchKernelGGL(k_sumlw, dim3(stride_grid(n * 8)), blk, 0, st, n, c->cstart.as<int64_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>());
+        hipLaunchKernelGGL(k_sumlw, dim3(stride_grid(n * 8)), blk, 0, st, n, c->cstart.as<int64_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
     }
     if (sharded) {
         // exchange 1: every rank holds the sums over ITS parents; the total decides responsibilities and orphans
         GSR_HIP(hipStreamSynchronize(st));
         if (c->shard_allreduce(c->sumLw.p, n, c->shard_user) != 0) return fail(GSR_E_INVALID, "gsr_hem_run_level: all-reduce callback failed (sumLw)");
-        hipLaunchKernelGGL(k_orphan_flags, grd, blk, 0, st, n, c->sumLw.as<float>(), c->oflag.as<int>());
+        hipLaunchKernelGGL(k_orphan_flags, grd, blk, 0, st, n, c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
     }
     GSR_CHECKPOINT("per-child sums");
     GSR_HIP(hipEventRecord(c->ev[3], st));
@@ -2152,27 +2284,32 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         MstepArgs ma;
         memset(&ma, 0, sizeof(ma));
         ma.geo = c->geo.as<float4>(); ma.shs = c->shs.as<float>(); ma.RSH = RSH;
-        ma.sumLw = c->sumLw.as<float>(); ma.plist = c->plist.as<unsigned>(); ma.order = c->order.as<unsigned>();
-        ma.prank_in = c->prank_in.as<int>(); ma.poff = c->poff.as<int64_t>(); ma.pcnt = c->pcnt.as<unsigned>();
         ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
         ma.P = P; ma.F = F;
-        ma.own_lo = own_lo; ma.own_hi = own_hi;
         // processing order: the selection's (heavy parents by candidates scanned first, then Z-order) -- parents with many
-        // candidates are the ones with many pairs
-        ma.porder = M > 0 ? c->porder.as<unsigned>() : nullptr;
-        ma.xcd = ma.porder ? 1 : 0;
-        ma.nheavy = c->counters.as<int>() + 8;
+        // candidates are the ones with many pairs.  The per-parent headers are laid out in that order.
+        const unsigned* mporder = M > 0 ? c->porder.as<unsigned>() : nullptr;
+        ma.xcd = mporder ? 1 : 0;
+        ma.nheavy = mporder ? c->counters.as<int>() + 8 : nullptr;
+        GSR_TRY(c->mhdr.reserve(Pm * sizeof(MstepHeader)));
+        hipLaunchKernelGGL(k_mstep_headers, dim3(stride_grid(P)), blk, 0, st, P, mporder, c->plist.as<unsigned>(), c->poff.as<int64_t>(),
+                           c->pcnt.as<unsigned>(), c->order.as<unsigned>(), c->prank_in.as<int>(), c->A.as<float4>(), own_lo, own_hi,
+                           c->mhdr.as<MstepHeader>());
+        ma.hdr = c->mhdr.as<MstepHeader>();
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
-        const dim3 mg(8 * ceil_div(P, 8));
+        // one wavefront per workgroup: consecutive parents on one CU share no cache lines in time (2 / 4 / 8 waves per workgroup
+        // were measured 1 / 10 / 24 % slower)
         const int nq = RSH >> 2;                                // float4 per SH row; a lane covers MSTEP_NV of them
-        if (nq == 0) hipLaunchKernelGGL((k_mstep<0>), mg, dim3(64), 0, st, ma);
-        else if (nq <= 1 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<1>), mg, dim3(64), 0, st, ma);
-        else if (nq <= 2 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<2>), mg, dim3(64), 0, st, ma);
-        else if (nq <= 4 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<4>), mg, dim3(64), 0, st, ma);
-        else if (nq <= 8 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<8>), mg, dim3(64), 0, st, ma);
-        else if (nq <= 16 * MSTEP_NV) hipLaunchKernelGGL((k_mstep<16>), mg, dim3(64), 0, st, ma);
-        else hipLaunchKernelGGL((k_mstep<32>), mg, dim3(64), 0, st, ma);      // F <= 384
+#define GSR_LAUNCH_MSTEP(G) hipLaunchKernelGGL((k_mstep<G, 1>), dim3(8 * ceil_div(ceil_div(P, MSTEP_K), 8)), dim3(64), 0, st, ma);
+        if (nq == 0) { GSR_LAUNCH_MSTEP(0) }
+        else if (nq <= 1 * MSTEP_NV) { GSR_LAUNCH_MSTEP(1) }
+        else if (nq <= 2 * MSTEP_NV) { GSR_LAUNCH_MSTEP(2) }
+        else if (nq <= 4 * MSTEP_NV) { GSR_LAUNCH_MSTEP(4) }
+        else if (nq <= 8 * MSTEP_NV) { GSR_LAUNCH_MSTEP(8) }
+        else if (nq <= 16 * MSTEP_NV) { GSR_LAUNCH_MSTEP(16) }
+        else { GSR_LAUNCH_MSTEP(32) }      // F <= 384
+#undef GSR_LAUNCH_MSTEP
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
@@ -2295,28 +2432,28 @@ int32_t gsr_debug_kld(const float* cm, const float* cc, const float* pm, const f
     return GSR_OK;
 }
 
-int32_t gsr_debug_kl_gate(const float* s2, const float* q, int64_t n, float thr, uint8_t* reject, float* fast_log, uint8_t* need_exact,
-                          int32_t device) {
-    if (n < 0 || (n > 0 && (!s2 || !q || !reject || !fast_log || !need_exact))) return fail(GSR_E_INVALID, "gsr_debug_kl_gate: bad argument");
+int32_t gsr_debug_kl_gate(const float* s2, const float* det_c, const float* det_p, int64_t n, float thr, uint8_t* reject, float* fast_log,
+                          uint8_t* need_exact, int32_t device) {
+    if (n < 0 || (n > 0 && (!s2 || !det_c || !det_p || !reject || !fast_log || !need_exact))) return fail(GSR_E_INVALID, "gsr_debug_kl_gate: bad argument");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GSR_E_NO_DEVICE, "gsr_debug_kl_gate: no HIP device visible");
     if (n == 0) return GSR_OK;
     GSR_HIP(hipSetDevice(device));
-    DevBuf b[5];
-    const size_t sz[5] = {(size_t)n * 4, (size_t)n * 4, (size_t)n, (size_t)n * 4, (size_t)n};
+    DevBuf b[6];
+    const size_t sz[6] = {(size_t)n * 4, (size_t)n * 4, (size_t)n * 4, (size_t)n, (size_t)n * 4, (size_t)n};
+    const float* src[3] = {s2, det_c, det_p};
     int32_t r = GSR_OK;
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 5 && r == GSR_OK; ++i) r = b[i].reserve(sz[i]);
-    if (r == GSR_OK) e = hipMemcpy(b[0].p, s2, sz[0], hipMemcpyHostToDevice);
-    if (r == GSR_OK && e == hipSuccess) e = hipMemcpy(b[1].p, q, sz[1], hipMemcpyHostToDevice);
+    for (int i = 0; i < 6 && r == GSR_OK; ++i) r = b[i].reserve(sz[i]);
+    for (int i = 0; i < 3 && r == GSR_OK && e == hipSuccess; ++i) e = hipMemcpy(b[i].p, src[i], sz[i], hipMemcpyHostToDevice);
     if (r == GSR_OK && e == hipSuccess) {
-        hipLaunchKernelGGL(k_debug_kl_gate, dim3(stride_grid(n)), dim3(256), 0, nullptr, n, b[0].as<float>(), b[1].as<float>(), thr,
-                           b[2].as<uint8_t>(), b[3].as<float>(), b[4].as<uint8_t>());
-        e = hipMemcpy(reject, b[2].p, sz[2], hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(fast_log, b[3].p, sz[3], hipMemcpyDeviceToHost);
-        if (e == hipSuccess) e = hipMemcpy(need_exact, b[4].p, sz[4], hipMemcpyDeviceToHost);
+        hipLaunchKernelGGL(k_debug_kl_gate, dim3(stride_grid(n)), dim3(256), 0, nullptr, n, b[0].as<float>(), b[1].as<float>(), b[2].as<float>(), thr,
+                           b[3].as<uint8_t>(), b[4].as<float>(), b[5].as<uint8_t>());
+        e = hipMemcpy(reject, b[3].p, sz[3], hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(fast_log, b[4].p, sz[4], hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(need_exact, b[5].p, sz[5], hipMemcpyDeviceToHost);
     }
-    for (int i = 0; i < 5; ++i) b[i].release();
+    for (int i = 0; i < 6; ++i) b[i].release();
     if (r != GSR_OK) return r;
     if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_debug_kl_gate: %s", hipGetErrorString(e));
     return GSR_OK;

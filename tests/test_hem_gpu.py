@@ -287,48 +287,50 @@ def test_grid_cell_size_changes_nothing(monkeypatch):
 
 
 def test_fast_log_margin(hip_lib, oracle):
-    """k_select decides the KL gate with the hardware v_log_f32 when the value is farther from the threshold than the
-    error bound of that logarithm, and with glibc's algorithm otherwise.  Check on the device (i) the bound the
-    margin assumes -- |v_log_f32(q) ln2 - logf(q)| < 4e-7 (1 + |logf(q)|) -- and (ii) that the decision equals the
-    reference's float32 expression 0.5f * (s2 - logf(q)) > thr on random and on adversarial inputs (values placed
-    within a few ulp of the threshold), and (iii) that the exact fallback is rare on ordinary inputs."""
+    """k_select decides the KL gate with det_c * (1 / det_p) and the hardware v_log_f32 when the value is farther from the
+    threshold than the error bound of that path, and with the IEEE division + glibc's logf otherwise.  Check on the
+    device (i) the bound the margin assumes -- |fast log - logf(det_c / det_p)| < 5e-7 (1 + |logf|) -- and (ii) that the
+    decision equals the reference's float32 expression 0.5f * (s2 - logf(det_c / det_p)) > thr on random and on
+    adversarial inputs (values placed within a few ulp of the threshold), and (iii) that the fallback is rare on ordinary
+    inputs."""
     rng = np.random.default_rng(11)
-    n = 400_000
-    q = np.concatenate([np.exp(rng.uniform(-60, 60, n // 2)), np.exp(rng.normal(0, 2, n // 2))]).astype(np.float32)
+    n, m = 400_000, 50_000
+    det_p = np.exp(rng.normal(-14, 4, n)).astype(np.float32)
+    det_c = (det_p * np.concatenate([np.exp(rng.uniform(-40, 40, n // 2)), np.exp(rng.normal(0, 2, n // 2))])).astype(np.float32)
     with np.errstate(all="ignore"):
-        lq = np.array([oracle.logf(float(v)) for v in q[:50000]], np.float32)
+        q = (det_c / det_p).astype(np.float32)               # IEEE float32 division, as the reference does it
+        lq = np.array([oracle.logf(float(v)) for v in q[:m]], np.float32)
     lq_all = np.log(q.astype(np.float64)).astype(np.float32)
-    lq_all[:50000] = lq                                      # libm on the first 50 k, correctly rounded log elsewhere
+    lq_all[:m] = lq                                          # libm on the first 50 k, correctly rounded log elsewhere
     thr = np.float32(4.5)
     s2 = (2 * thr + lq_all + rng.normal(0, 3, n)).astype(np.float32)
-    # adversarial quarter: k = 0.5 (s2 - log q) within a few ulp of thr
-    adv = slice(0, 50000)
-    s2[adv] = (np.float32(2) * thr + lq[: 50000]).astype(np.float32)
-    s2[adv] = np.nextafter(s2[adv], np.float32(np.inf) * rng.choice([-1, 1], 50000).astype(np.float32)).astype(np.float32)
-    special_q = np.float32([0.0, -1.0, np.inf, np.nan, 1e-45, 3e-39, 1.0, 1.0])
+    # adversarial part: k = 0.5 (s2 - log q) within a few ulp of thr
+    s2[:m] = (np.float32(2) * thr + lq).astype(np.float32)
+    s2[:m] = np.nextafter(s2[:m], (np.inf * rng.choice([-1.0, 1.0], m)).astype(np.float32)).astype(np.float32)
+    special_c = np.float32([0.0, -1.0, np.inf, np.nan, 1e-45, 3e-39, 1.0, 1.0])
     special_s = np.float32([1.0, 1.0, 1.0, 1.0, 9.0, 9.0, np.inf, np.nan])
-    q = np.concatenate([q, special_q]); s2 = np.concatenate([s2, special_s])
-    rej = np.empty(q.size, np.uint8); lf = np.empty(q.size, np.float32); ex = np.empty(q.size, np.uint8)
-    assert hip_lib.gsr_debug_kl_gate(s2.ctypes.data, q.ctypes.data, q.size, float(thr), rej.ctypes.data, lf.ctypes.data,
-                                     ex.ctypes.data, 0) == 0
-    # (i) error bound of the fast logarithm, against libm where it was evaluated
-    err = np.abs(lf[:50000].astype(np.float64) - lq.astype(np.float64))
-    assert (err < 4e-7 * (1 + np.abs(lq))).all(), float((err / (1 + np.abs(lq))).max())
+    det_c = np.concatenate([det_c, special_c]); det_p = np.concatenate([det_p, np.ones(8, np.float32)]); s2 = np.concatenate([s2, special_s])
+    N = s2.size
+    rej = np.empty(N, np.uint8); lf = np.empty(N, np.float32); ex = np.empty(N, np.uint8)
+    assert hip_lib.gsr_debug_kl_gate(s2.ctypes.data, det_c.ctypes.data, det_p.ctypes.data, N, float(thr), rej.ctypes.data,
+                                     lf.ctypes.data, ex.ctypes.data, 0) == 0
+    # (i) error bound of the fast path, against libm where it was evaluated
+    ok = np.isfinite(lq) & (q[:m] >= 4 * np.finfo(np.float32).tiny)
+    err = np.abs(lf[:m].astype(np.float64) - lq.astype(np.float64))
+    assert (err[ok] < 5e-7 * (1 + np.abs(lq[ok]))).all(), float((err[ok] / (1 + np.abs(lq[ok]))).max())
     # (ii) decisions: the reference's float32 expression with libm's logf
     with np.errstate(all="ignore"):
-        k = np.float32(0.5) * (s2[:50000] - lq)
-    want = (k > thr).astype(np.uint8)
-    assert np.array_equal(rej[:50000], want)
-    assert ex[:50000].mean() > 0.9                           # the adversarial values do take the exact path
+        k = np.float32(0.5) * (s2[:m] - lq)
+    assert np.array_equal(rej[:m], (k > thr).astype(np.uint8))
+    assert ex[:m].mean() > 0.9                               # the adversarial values do take the exact path
     with np.errstate(all="ignore"):
-        k2 = np.float32(0.5) * (s2[50000:n] - lq_all[50000:n])
+        k2 = np.float32(0.5) * (s2[m:n] - lq_all[m:n])
     far = np.abs(k2 - thr) > 1e-4                            # away from the threshold any correct logf decides alike
-    assert np.array_equal(rej[50000:n][far], (k2 > thr).astype(np.uint8)[far])
+    assert np.array_equal(rej[m:n][far], (k2 > thr).astype(np.uint8)[far])
     # (iii) ordinary inputs: the fallback is rare
-    assert ex[50000:n].mean() < 1e-3
+    assert ex[m:n].mean() < 1e-3
     # special values: log(0) = -inf -> k = +inf -> reject; q < 0 or NaN -> NaN -> passes; s2 = inf -> reject; s2 NaN -> passes
     assert list(rej[n:]) == [1, 0, 0, 0, 1, 1, 1, 0] and ex[n:].all()
-
 
 def test_sh_wider_than_a_wavefront(oracle):
     """F = 72 feature floats (> 64 lanes) exercises the multi-coefficient-per-lane M-step instantiation."""
