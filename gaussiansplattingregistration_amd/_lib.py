@@ -65,6 +65,7 @@ SIGNATURES = {
     "gsr_icp_correspondences": (_i32, [_vp, _vp, _vp, _vp]),
     "gsr_icp_get_timing": (_i32, [_vp, C.POINTER(_f32)]),
     "gsr_normals_from_cov": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
+    "gsr_normals_knn": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp]),
     "gsr_icp_solve": (_i32, [_vp, _i32, _vp, _vp]),
     "gsr_icp_get_centre": (_i32, [_vp, _vp]),
 }

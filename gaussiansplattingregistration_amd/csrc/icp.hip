@@ -732,54 +732,148 @@ __device__ void eigvec1_d(const double A[3][3], const double e0[3], double ev1, 
         } else for (int i = 0; i < 3; ++i) out[i] = U[i];
     }
 }
-__global__ __launch_bounds__(256) void k_normals_from_cov(int64_t n, const float* __restrict__ cov6, double* __restrict__ out) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const double c00 = cov6[6 * i], c01 = cov6[6 * i + 1], c02 = cov6[6 * i + 2], c11 = cov6[6 * i + 3], c12 = cov6[6 * i + 4], c22 = cov6[6 * i + 5];
-        double v[3] = {0, 0, 0};
-        double mx = fmax(fmax(fmax(c00, c01), fmax(c02, c11)), fmax(c12, c22));
-        if (mx != 0 && mx == mx) {
-            double A[3][3] = {{c00 / mx, c01 / mx, c02 / mx}, {c01 / mx, c11 / mx, c12 / mx}, {c02 / mx, c12 / mx, c22 / mx}};
-            const double norm = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
-            if (norm > 0) {
-                const double q = (A[0][0] + A[1][1] + A[2][2]) / 3;
-                const double b00 = A[0][0] - q, b11 = A[1][1] - q, b22 = A[2][2] - q;
-                const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2) / 6);
-                const double k00 = b11 * b22 - A[1][2] * A[1][2];
-                const double k01 = A[0][1] * b22 - A[1][2] * A[0][2];
-                const double k02 = A[0][1] * A[1][2] - b11 * A[0][2];
-                const double det = (b00 * k00 - A[0][1] * k01 + A[0][2] * k02) / (p * p * p);
-                const double half_det = fmin(fmax(det * 0.5, -1.0), 1.0);
-                const double angle = acos(half_det) / 3.0;
-                const double two_thirds_pi = 2.09439510239319549;
-                const double beta2 = cos(angle) * 2, beta0 = cos(angle + two_thirds_pi) * 2, beta1 = -(beta0 + beta2);
-                const double ev[3] = {q + p * beta0, q + p * beta1, q + p * beta2};
-                double e0[3], e1[3], e2[3];
-                if (half_det >= 0) {
-                    eigvec0_d(A, ev[2], e2);
-                    if (ev[2] < ev[0] && ev[2] < ev[1]) { v[0] = e2[0]; v[1] = e2[1]; v[2] = e2[2]; }
-                    else {
-                        eigvec1_d(A, e2, ev[1], e1);
-                        if (ev[1] < ev[0] && ev[1] < ev[2]) { v[0] = e1[0]; v[1] = e1[1]; v[2] = e1[2]; }
-                        else cross3d(e1, e2, v);
-                    }
-                } else {
-                    eigvec0_d(A, ev[0], e0);
-                    if (ev[0] < ev[1] && ev[0] < ev[2]) { v[0] = e0[0]; v[1] = e0[1]; v[2] = e0[2]; }
-                    else {
-                        eigvec1_d(A, e0, ev[1], e1);
-                        if (ev[1] < ev[0] && ev[1] < ev[2]) { v[0] = e1[0]; v[1] = e1[1]; v[2] = e1[2]; }
-                        else cross3d(e0, e1, v);
-                    }
+// normal of a covariance: eigenvector of its smallest eigenvalue (Open3D ComputeNormal with FastEigen3x3), (0, 0, 1) when
+// that comes out as the zero vector or NaN
+__device__ void normal_of_cov_d(double c00, double c01, double c02, double c11, double c12, double c22, double v[3]) {
+    v[0] = v[1] = v[2] = 0;
+    double mx = fmax(fmax(fmax(c00, c01), fmax(c02, c11)), fmax(c12, c22));
+    if (mx != 0 && mx == mx) {
+        double A[3][3] = {{c00 / mx, c01 / mx, c02 / mx}, {c01 / mx, c11 / mx, c12 / mx}, {c02 / mx, c12 / mx, c22 / mx}};
+        const double norm = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        if (norm > 0) {
+            const double q = (A[0][0] + A[1][1] + A[2][2]) / 3;
+            const double b00 = A[0][0] - q, b11 = A[1][1] - q, b22 = A[2][2] - q;
+            const double p = sqrt((b00 * b00 + b11 * b11 + b22 * b22 + norm * 2) / 6);
+            const double k00 = b11 * b22 - A[1][2] * A[1][2];
+            const double k01 = A[0][1] * b22 - A[1][2] * A[0][2];
+            const double k02 = A[0][1] * A[1][2] - b11 * A[0][2];
+            const double det = (b00 * k00 - A[0][1] * k01 + A[0][2] * k02) / (p * p * p);
+            const double half_det = fmin(fmax(det * 0.5, -1.0), 1.0);
+            const double angle = acos(half_det) / 3.0;
+            const double two_thirds_pi = 2.09439510239319549;
+            const double beta2 = cos(angle) * 2, beta0 = cos(angle + two_thirds_pi) * 2, beta1 = -(beta0 + beta2);
+            const double ev[3] = {q + p * beta0, q + p * beta1, q + p * beta2};
+            double e0[3], e1[3], e2[3];
+            if (half_det >= 0) {
+                eigvec0_d(A, ev[2], e2);
+                if (ev[2] < ev[0] && ev[2] < ev[1]) { v[0] = e2[0]; v[1] = e2[1]; v[2] = e2[2]; }
+                else {
+                    eigvec1_d(A, e2, ev[1], e1);
+                    if (ev[1] < ev[0] && ev[1] < ev[2]) { v[0] = e1[0]; v[1] = e1[1]; v[2] = e1[2]; }
+                    else cross3d(e1, e2, v);
                 }
             } else {
-                if (A[0][0] < A[1][1] && A[0][0] < A[2][2]) v[0] = 1;
-                else if (A[1][1] < A[0][0] && A[1][1] < A[2][2]) v[1] = 1;
-                else v[2] = 1;
+                eigvec0_d(A, ev[0], e0);
+                if (ev[0] < ev[1] && ev[0] < ev[2]) { v[0] = e0[0]; v[1] = e0[1]; v[2] = e0[2]; }
+                else {
+                    eigvec1_d(A, e0, ev[1], e1);
+                    if (ev[1] < ev[0] && ev[1] < ev[2]) { v[0] = e1[0]; v[1] = e1[1]; v[2] = e1[2]; }
+                    else cross3d(e0, e1, v);
+                }
             }
+        } else {
+            if (A[0][0] < A[1][1] && A[0][0] < A[2][2]) v[0] = 1;
+            else if (A[1][1] < A[0][0] && A[1][1] < A[2][2]) v[1] = 1;
+            else v[2] = 1;
         }
-        const double nn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-        if (nn == 0.0 || nn != nn) { v[0] = 0; v[1] = 0; v[2] = 1; }
+    }
+    const double nn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    if (nn == 0.0 || nn != nn) { v[0] = 0; v[1] = 0; v[2] = 1; }
+}
+__global__ __launch_bounds__(256) void k_normals_from_cov(int64_t n, const float* __restrict__ cov6, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v[3];
+        normal_of_cov_d(cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5], v);
         out[3 * i] = v[0]; out[3 * i + 1] = v[1]; out[3 * i + 2] = v[2];
+    }
+}
+
+// Normals of a cloud WITHOUT covariances: Open3D EstimateNormals(KDTreeSearchParamKNN(knn)) -- what the reference does to a
+// sparse input cloud (src/utils/point_cloud_converter.py:9-28, default knn = 30).  One thread per point: its knn nearest
+// points (itself included) by (distance, input index) through the same expanding-ring search as the colour gradients;
+// with >= 3 of them the covariance by cumulants (Open3D ComputeCovariance), else the identity; normal_of_cov_d.
+// Output in the CALLER's point order (order[j] = input index of sorted point j).
+__global__ __launch_bounds__(256) void k_knn_normals(int64_t nt, IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
+                                                     const unsigned* __restrict__ order, int knn, double* __restrict__ out) {
+    for (int64_t jq = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; jq < nt; jq += (int64_t)gridDim.x * blockDim.x) {
+        const float4 qv = Tq[jq];
+        const double px = (double)qv.x, py = (double)qv.y, pz = (double)qv.z;
+        double* o = out + 3 * (int64_t)order[jq];
+        o[0] = 0.0; o[1] = 0.0; o[2] = 1.0;
+        if (!(px == px) || !(py == py) || !(pz == pz)) continue;
+        double kd[ICP_KNN];
+        int kj[ICP_KNN];
+        unsigned ki[ICP_KNN];
+        int cnt = 0;
+        const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
+        const double eps = 1e-13 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.ox) + fabs(g.oy) + fabs(g.oz) + g.c * (double)(g.gx + g.gy + g.gz));
+        const int rmax = (g.gx > g.gy ? g.gx : g.gy) > g.gz ? (g.gx > g.gy ? g.gx : g.gy) : g.gz;
+        for (int r = 0; r <= rmax; ++r) {
+            for (int dz = -r; dz <= r; ++dz) {
+                const int z = cz + dz;
+                if (z < 0 || z >= g.gz) continue;
+                const int adz = dz < 0 ? -dz : dz;
+                for (int dy = -r; dy <= r; ++dy) {
+                    const int y = cy + dy;
+                    if (y < 0 || y >= g.gy) continue;
+                    const int ady = dy < 0 ? -dy : dy;
+                    const int rowbase = (z * g.gy + y) * g.gx;
+                    int spans[2][2];
+                    int nsp = 0;
+                    if (adz == r || ady == r) {
+                        const int xa = cx - r > 0 ? cx - r : 0, xb = cx + r < g.gx - 1 ? cx + r : g.gx - 1;
+                        if (xa <= xb) { spans[0][0] = rowbase + xa; spans[0][1] = rowbase + xb; nsp = 1; }
+                    } else {
+                        if (cx - r >= 0) { spans[nsp][0] = spans[nsp][1] = rowbase + cx - r; ++nsp; }
+                        if (cx + r < g.gx) { spans[nsp][0] = spans[nsp][1] = rowbase + cx + r; ++nsp; }
+                    }
+                    for (int sidx = 0; sidx < nsp; ++sidx) {
+                        const int s0 = cellStart[spans[sidx][0]], e0 = cellStart[spans[sidx][1] + 1];
+                        for (int j = s0; j < e0; ++j) {
+                            const float4 q = Tq[j];
+                            const double dx = px - (double)q.x, dy2 = py - (double)q.y, dz2 = pz - (double)q.z;
+                            const double d2 = dx * dx + dy2 * dy2 + dz2 * dz2;
+                            const unsigned qi = __float_as_uint(q.w);
+                            if (!(d2 == d2)) continue;
+                            if (cnt == knn && !(d2 < kd[cnt - 1] || (d2 == kd[cnt - 1] && qi < ki[cnt - 1]))) continue;
+                            int pos = cnt < knn ? cnt : knn - 1;             // insertion into the list sorted by (d2, index)
+                            while (pos > 0 && (d2 < kd[pos - 1] || (d2 == kd[pos - 1] && qi < ki[pos - 1]))) {
+                                kd[pos] = kd[pos - 1]; kj[pos] = kj[pos - 1]; ki[pos] = ki[pos - 1];
+                                --pos;
+                            }
+                            kd[pos] = d2; kj[pos] = j; ki[pos] = qi;
+                            if (cnt < knn) ++cnt;
+                        }
+                    }
+                }
+            }
+            // an unseen point lies at least `reach` away: done when the list is full and its worst entry is strictly closer
+            double reach = 1.0 / 0.0;
+            if (cx - r > 0) reach = fmin(reach, px - (g.ox + (double)(cx - r) * g.c));
+            if (cx + r < g.gx - 1) reach = fmin(reach, (g.ox + (double)(cx + r + 1) * g.c) - px);
+            if (cy - r > 0) reach = fmin(reach, py - (g.oy + (double)(cy - r) * g.c));
+            if (cy + r < g.gy - 1) reach = fmin(reach, (g.oy + (double)(cy + r + 1) * g.c) - py);
+            if (cz - r > 0) reach = fmin(reach, pz - (g.oz + (double)(cz - r) * g.c));
+            if (cz + r < g.gz - 1) reach = fmin(reach, (g.oz + (double)(cz + r + 1) * g.c) - pz);
+            reach = reach * 0.999999999 - eps;
+            if (reach > 0.0 && cnt == knn && kd[cnt - 1] < reach * reach) break;
+        }
+        double c00 = 1, c01 = 0, c02 = 0, c11 = 1, c12 = 0, c22 = 1;        // fewer than 3 neighbours: identity
+        if (cnt >= 3) {
+            double m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < cnt; ++i) {
+                const float4 q = Tq[kj[i]];
+                const double x = (double)q.x, y = (double)q.y, z = (double)q.z;
+                m[0] += x; m[1] += y; m[2] += z;
+                m[3] += x * x; m[4] += x * y; m[5] += x * z; m[6] += y * y; m[7] += y * z; m[8] += z * z;
+            }
+            for (int k = 0; k < 9; ++k) m[k] /= (double)cnt;
+            c00 = m[3] - m[0] * m[0]; c11 = m[6] - m[1] * m[1]; c22 = m[8] - m[2] * m[2];
+            c01 = m[4] - m[0] * m[1]; c02 = m[5] - m[0] * m[2]; c12 = m[7] - m[1] * m[2];
+        }
+        double v[3];
+        normal_of_cov_d(c00, c01, c02, c11, c12, c22, v);
+        o[0] = v[0]; o[1] = v[1]; o[2] = v[2];
     }
 }
 
@@ -1548,6 +1642,30 @@ int32_t gsr_normals_from_cov(const float* cov6, int64_t n, double* normals, int3
     in.release(); out.release();
     if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_normals_from_cov: %s", hipGetErrorString(e));
     return GSR_OK;
+}
+
+int32_t gsr_normals_knn(const float* xyz, int64_t n, int32_t knn, double* normals, int32_t on_device, int32_t device, void* stream) {
+    if (n < 0 || (n > 0 && (!xyz || !normals))) return fail(GSR_E_INVALID, "gsr_normals_knn: bad argument");
+    if (knn < 1 || knn > ICP_KNN) return fail(GSR_E_INVALID, "gsr_normals_knn: knn must lie in [1, %d] (got %d)", ICP_KNN, knn);
+    if (n == 0) return GSR_OK;
+    gsr_icp_ctx* c = nullptr;
+    GSR_TRY(gsr_icp_create(&c, device, stream));
+    // the grid of the ICP target index (about two points per cell); the correspondence distance plays no role here
+    int32_t r = gsr_icp_set_target(c, xyz, nullptr, n, 1e-300, on_device);
+    if (r == GSR_OK) {
+        DevBuf out;
+        r = out.reserve((size_t)n * 24);
+        if (r == GSR_OK) {
+            hipLaunchKernelGGL(k_knn_normals, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(),
+                               c->order.as<unsigned>(), (int)knn, out.as<double>());
+            hipError_t e = hipMemcpyAsync(normals, out.p, (size_t)n * 24, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) r = fail(GSR_E_HIP, "gsr_normals_knn: %s", hipGetErrorString(e));
+        }
+        out.release();
+    }
+    (void)gsr_icp_destroy(c);
+    return r;
 }
 
 }  // extern "C"

@@ -1,0 +1,177 @@
+// model.hip -- level export glue on the device: scaling / rotation of every component of a mixture level
+// from its covariance, behind gsr_decompose_cov (include/gsr_hip.h).
+//
+// Replaces GaussianModel.decompose_covariance_matrix + matrices_to_quaternions of the reference
+// (src/models/gaussian_model.py:151-153,242-265, src/utils/general_utils.py:94-100), which run a batched
+// torch.linalg.eigh, three gathers / scatters and a stack of element-wise kernels on "cuda:0" after every HEM level.
+// One thread per component: float64 cyclic Jacobi on the symmetric 3x3 in registers (the covariances are float32; the
+// decomposition is exact to float32 output precision), then
+//
+//   GSR_DECOMP_REFERENCE   the reference's arithmetic, bug for bug: eigenvalues ascending; eigenpair k claims the axis
+//       its eigenvector is most aligned with (arg-max of |v_k|, first maximum on ties); the eigenVALUE k goes to that
+//       slot of `scaling` and ROW k of the eigenvector matrix V (columns = eigenvectors; the reference scatters rows of
+//       the tensor eigh returns, gaussian_model.py:262) goes to that row of the "rotation" matrix; two claims of one
+//       slot overwrite in eigenvalue order (torch's CPU scatter_: the last one wins), an unclaimed slot stays zero;
+//       quaternion (w, x, y, z) by the trace formula w = sqrt(1 + tr) / 2 without any branch (NaN when 1 + tr < 0, as
+//       there).  The "scaling" is the eigenvalue itself -- not its square root, not a logarithm.
+//   GSR_DECOMP_EXACT       what save_ply of a down-sampled model actually needs (the reference's own comment calls its
+//       version unused): scaling = log of the standard deviations (0.5 log lambda_k, lambda clamped at 1e-30), rotation =
+//       the proper rotation [v_0 v_1 v_2] (third column flipped if the determinant is negative) as a unit quaternion by
+//       Shepperd's branch on the largest diagonal term, so that R diag(exp(scaling))^2 R^T reproduces the covariance.
+//
+// Sign convention of the eigenvectors (torch.linalg.eigh leaves it to the LAPACK / rocSOLVER build): the component of
+// largest magnitude of every eigenvector is positive (first maximum on ties).  Everything the reference path derives from
+// V is invariant under column sign flips except the signs inside the scattered rows; tests compare up to those.
+#include "gsr_common.h"
+
+#include <float.h>
+#include <math.h>
+
+namespace gsr {
+
+// cyclic Jacobi for a symmetric 3x3: A = V diag(lam) V^T, eigenvalues ascending, columns of V = eigenvectors
+__device__ void sym_eig3_d(const double Ain[3][3], double V[3][3], double lam[3]) {
+    double A[3][3];
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { A[i][j] = Ain[i][j]; V[i][j] = i == j ? 1.0 : 0.0; }
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        const double off = A[0][1] * A[0][1] + A[0][2] * A[0][2] + A[1][2] * A[1][2];
+        const double diag = A[0][0] * A[0][0] + A[1][1] * A[1][1] + A[2][2] * A[2][2];
+        if (!(off > 1e-34 * diag) || !(off == off)) break;
+        for (int p = 0; p < 2; ++p)
+            for (int q = p + 1; q < 3; ++q) {
+                if (A[p][q] == 0.0) continue;
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+                const double t = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+                const double c = 1.0 / sqrt(t * t + 1.0), s = t * c;
+                for (int k = 0; k < 3; ++k) {           // A <- A J
+                    const double akp = A[k][p], akq = A[k][q];
+                    A[k][p] = c * akp - s * akq; A[k][q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < 3; ++k) {           // A <- J^T A
+                    const double apk = A[p][k], aqk = A[q][k];
+                    A[p][k] = c * apk - s * aqk; A[q][k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < 3; ++k) {           // V <- V J
+                    const double vkp = V[k][p], vkq = V[k][q];
+                    V[k][p] = c * vkp - s * vkq; V[k][q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    lam[0] = A[0][0]; lam[1] = A[1][1]; lam[2] = A[2][2];
+    // ascending order (three compare-exchanges on the columns)
+    for (int pass = 0; pass < 3; ++pass) {
+        const int a = pass == 1 ? 1 : 0, b = pass == 0 ? 1 : 2;
+        if (lam[b] < lam[a]) {
+            const double t = lam[a]; lam[a] = lam[b]; lam[b] = t;
+            for (int k = 0; k < 3; ++k) { const double v = V[k][a]; V[k][a] = V[k][b]; V[k][b] = v; }
+        }
+    }
+    // sign convention: the component of largest magnitude of every eigenvector is positive
+    for (int c = 0; c < 3; ++c) {
+        int m = 0;
+        if (fabs(V[1][c]) > fabs(V[m][c])) m = 1;
+        if (fabs(V[2][c]) > fabs(V[m][c])) m = 2;
+        if (V[m][c] < 0.0) for (int k = 0; k < 3; ++k) V[k][c] = -V[k][c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_decompose_cov(int64_t n, const float* __restrict__ cov6, int mode, float* __restrict__ scaling,
+                                                       float* __restrict__ quat, float* __restrict__ mat) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double c00 = cov6[6 * i], c01 = cov6[6 * i + 1], c02 = cov6[6 * i + 2], c11 = cov6[6 * i + 3], c12 = cov6[6 * i + 4], c22 = cov6[6 * i + 5];
+        const double A[3][3] = {{c00, c01, c02}, {c01, c11, c12}, {c02, c12, c22}};
+        double V[3][3], lam[3];
+        sym_eig3_d(A, V, lam);
+        float M[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        float sc[3] = {0, 0, 0};
+        float q[4];
+        if (mode == GSR_DECOMP_REFERENCE) {
+            for (int k = 0; k < 3; ++k) {                       // ascending eigenvalue: the later claim of a slot wins
+                int slot = 0;                                   // arg-max of |v_k| = row k of |V^T| (gaussian_model.py:251-254)
+                if (fabs(V[1][k]) > fabs(V[slot][k])) slot = 1;
+                if (fabs(V[2][k]) > fabs(V[slot][k])) slot = 2;
+                sc[slot] = (float)lam[k];
+                for (int c = 0; c < 3; ++c) M[slot][c] = (float)V[k][c];      // ROW k of the eigenvector matrix, as the reference scatters it
+            }
+            const float w = sqrtf(1.0f + (M[0][0] + M[1][1] + M[2][2])) / 2.0f;      // general_utils.py:94-100
+            q[0] = w;
+            q[1] = (M[2][1] - M[1][2]) / (4.0f * w);
+            q[2] = (M[0][2] - M[2][0]) / (4.0f * w);
+            q[3] = (M[1][0] - M[0][1]) / (4.0f * w);
+        } else {
+            double R[3][3];
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) R[r][c] = V[r][c];
+            const double det = R[0][0] * (R[1][1] * R[2][2] - R[1][2] * R[2][1]) - R[0][1] * (R[1][0] * R[2][2] - R[1][2] * R[2][0]) +
+                               R[0][2] * (R[1][0] * R[2][1] - R[1][1] * R[2][0]);
+            if (det < 0.0) for (int r = 0; r < 3; ++r) R[r][2] = -R[r][2];
+            for (int k = 0; k < 3; ++k) sc[k] = (float)(0.5 * log(lam[k] > 1e-30 ? lam[k] : 1e-30));
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) M[r][c] = (float)R[r][c];
+            // Shepperd: pick the largest of w^2, x^2, y^2, z^2
+            const double tr = R[0][0] + R[1][1] + R[2][2];
+            double w, x, y, z;
+            if (tr > 0.0) {
+                const double s = sqrt(tr + 1.0) * 2.0;
+                w = 0.25 * s; x = (R[2][1] - R[1][2]) / s; y = (R[0][2] - R[2][0]) / s; z = (R[1][0] - R[0][1]) / s;
+            } else if (R[0][0] > R[1][1] && R[0][0] > R[2][2]) {
+                const double s = sqrt(1.0 + R[0][0] - R[1][1] - R[2][2]) * 2.0;
+                w = (R[2][1] - R[1][2]) / s; x = 0.25 * s; y = (R[0][1] + R[1][0]) / s; z = (R[0][2] + R[2][0]) / s;
+            } else if (R[1][1] > R[2][2]) {
+                const double s = sqrt(1.0 + R[1][1] - R[0][0] - R[2][2]) * 2.0;
+                w = (R[0][2] - R[2][0]) / s; x = (R[0][1] + R[1][0]) / s; y = 0.25 * s; z = (R[1][2] + R[2][1]) / s;
+            } else {
+                const double s = sqrt(1.0 + R[2][2] - R[0][0] - R[1][1]) * 2.0;
+                w = (R[1][0] - R[0][1]) / s; x = (R[0][2] + R[2][0]) / s; y = (R[1][2] + R[2][1]) / s; z = 0.25 * s;
+            }
+            const double nq = sqrt(w * w + x * x + y * y + z * z);
+            if (w < 0.0) { w = -w; x = -x; y = -y; z = -z; }
+            q[0] = (float)(w / nq); q[1] = (float)(x / nq); q[2] = (float)(y / nq); q[3] = (float)(z / nq);
+        }
+        scaling[3 * i] = sc[0]; scaling[3 * i + 1] = sc[1]; scaling[3 * i + 2] = sc[2];
+        quat[4 * i] = q[0]; quat[4 * i + 1] = q[1]; quat[4 * i + 2] = q[2]; quat[4 * i + 3] = q[3];
+        if (mat)
+            for (int r = 0; r < 3; ++r) for (int c = 0; c < 3; ++c) mat[9 * i + 3 * r + c] = M[r][c];
+    }
+}
+
+}  // namespace gsr
+
+using namespace gsr;
+
+extern "C" int32_t gsr_decompose_cov(const float* cov6, int64_t n, int32_t mode, float* scaling, float* rotation, float* matrix,
+                                     int32_t on_device, int32_t device, void* stream) {
+    if (n < 0 || (n > 0 && (!cov6 || !scaling || !rotation))) return fail(GSR_E_INVALID, "gsr_decompose_cov: bad argument");
+    if (mode != GSR_DECOMP_REFERENCE && mode != GSR_DECOMP_EXACT) return fail(GSR_E_INVALID, "gsr_decompose_cov: unknown mode %d", mode);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GSR_E_NO_DEVICE, "gsr_decompose_cov: no HIP device visible (this backend has no CPU fallback)");
+    if (n == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (on_device) {
+        hipLaunchKernelGGL(k_decompose_cov, dim3(stride_grid(n)), dim3(256), 0, st, n, cov6, (int)mode, scaling, rotation, matrix);
+        GSR_HIP(hipGetLastError());
+        GSR_HIP(hipStreamSynchronize(st));
+        return GSR_OK;
+    }
+    DevBuf in, sc, q, m;
+    int32_t r = in.reserve((size_t)n * 24);
+    if (r == GSR_OK) r = sc.reserve((size_t)n * 12);
+    if (r == GSR_OK) r = q.reserve((size_t)n * 16);
+    if (r == GSR_OK && matrix) r = m.reserve((size_t)n * 36);
+    hipError_t e = hipSuccess;
+    if (r == GSR_OK) {
+        e = hipMemcpyAsync(in.p, cov6, (size_t)n * 24, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_decompose_cov, dim3(stride_grid(n)), dim3(256), 0, st, n, in.as<float>(), (int)mode, sc.as<float>(), q.as<float>(),
+                               matrix ? m.as<float>() : (float*)nullptr);
+            e = hipMemcpyAsync(scaling, sc.p, (size_t)n * 12, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(rotation, q.p, (size_t)n * 16, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess && matrix) e = hipMemcpyAsync(matrix, m.p, (size_t)n * 36, hipMemcpyDeviceToHost, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    in.release(); sc.release(); q.release(); m.release();
+    if (r != GSR_OK) return r;
+    if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_decompose_cov: %s", hipGetErrorString(e));
+    return GSR_OK;
+}

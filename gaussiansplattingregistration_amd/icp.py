@@ -250,3 +250,21 @@ def normals_from_cov(cov6, device=0):
     out = np.empty((n, 3), np.float64)
     _lib.check(L.gsr_normals_from_cov(a.ctypes.data, n, out.ctypes.data, 0, int(device), None), "gsr_normals_from_cov")
     return out
+
+
+def normals_knn(xyz, knn=30, device=0):
+    """float64 unit normals (n,3) of a cloud without covariances: Open3D ``estimate_normals()`` with its default
+    ``KDTreeSearchParamKNN(30)`` (what the reference does to a sparse input cloud, ``point_cloud_converter.py:9-28``)."""
+    L = _lib.load(require_device=True)
+    n = int(xyz.shape[0])
+    if _is_tensor(xyz) and xyz.is_cuda:
+        t = xyz.detach().to(torch.float32).reshape(n, 3).contiguous()
+        out = torch.empty((n, 3), dtype=torch.float64, device=t.device)
+        torch.cuda.current_stream(t.device.index).synchronize()
+        _lib.check(L.gsr_normals_knn(t.data_ptr(), n, int(knn), out.data_ptr(), 1, t.device.index,
+                                     C.c_void_p(torch.cuda.current_stream(t.device.index).cuda_stream)), "gsr_normals_knn")
+        return out
+    a = np.ascontiguousarray(xyz.detach().cpu().numpy() if _is_tensor(xyz) else xyz, dtype=np.float32).reshape(n, 3)
+    out = np.empty((n, 3), np.float64)
+    _lib.check(L.gsr_normals_knn(a.ctypes.data, n, int(knn), out.ctypes.data, 0, int(device), None), "gsr_normals_knn")
+    return out

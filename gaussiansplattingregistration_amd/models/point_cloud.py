@@ -58,13 +58,16 @@ class PointCloud:
     def has_covariances(self):
         return self.cov6 is not None
 
-    def estimate_normals(self):
-        """Open3D ``estimate_normals()`` on a cloud whose covariances are set: smallest-eigenvalue
-        eigenvector of each covariance (``point_cloud_converter.py:40-43``), on the GPU."""
-        if self.cov6 is None:
-            raise RuntimeError("estimate_normals: this backend derives normals from splat covariances; none are set")
+    def estimate_normals(self, knn=30):
+        """Open3D ``estimate_normals()``, on the GPU.  A cloud whose covariances are set (every splat cloud,
+        ``point_cloud_converter.py:40-43``) gets the smallest-eigenvalue eigenvector of each covariance; a cloud
+        without covariances (a sparse input cloud, ``point_cloud_converter.py:9-28``) gets Open3D's default: the
+        covariance of each point's ``knn`` = 30 nearest neighbours."""
         from .. import icp
-        self.normals = icp.normals_from_cov(self.cov6, device=self.device_index)
+        if self.cov6 is None:
+            self.normals = icp.normals_knn(self.xyz32, knn=knn, device=self.device_index)
+        else:
+            self.normals = icp.normals_from_cov(self.cov6, device=self.device_index)
         return self
 
     def voxel_down_sample(self, voxel_size):

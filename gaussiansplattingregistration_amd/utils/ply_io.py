@@ -114,3 +114,28 @@ def save_gaussian_ply(path, xyz, colors, sh, opacity, scale, rot):
             f.write(f"property float {nme}\n".encode())
         f.write(b"end_header\n")
         data.tofile(f)
+
+
+def save_input_ply(path, xyz, rgb, normals=None):
+    """A sparse *input* cloud as COLMAP / the 3DGS pipeline store it (``points3D.ply``): float ``x y z`` (+ ``nx ny nz``),
+    uchar ``red green blue``, binary little endian -- the file type ``file_loader.check_point_cloud_type`` calls INPUT."""
+    xyz = np.asarray(xyz, np.float32)
+    P = xyz.shape[0]
+    fields = [("x", "<f4"), ("y", "<f4"), ("z", "<f4")]
+    if normals is not None:
+        fields += [("nx", "<f4"), ("ny", "<f4"), ("nz", "<f4")]
+    fields += [("red", "u1"), ("green", "u1"), ("blue", "u1")]
+    v = np.empty(P, dtype=fields)
+    v["x"], v["y"], v["z"] = xyz[:, 0], xyz[:, 1], xyz[:, 2]
+    if normals is not None:
+        nrm = np.asarray(normals, np.float32)
+        v["nx"], v["ny"], v["nz"] = nrm[:, 0], nrm[:, 1], nrm[:, 2]
+    rgb = np.asarray(rgb)
+    v["red"], v["green"], v["blue"] = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+    with open(path, "wb") as f:
+        f.write(b"ply\nformat binary_little_endian 1.0\n")
+        f.write(f"element vertex {P}\n".encode())
+        for name, t in fields:
+            f.write(f"property {'uchar' if t == 'u1' else 'float'} {name}\n".encode())
+        f.write(b"end_header\n")
+        v.tofile(f)

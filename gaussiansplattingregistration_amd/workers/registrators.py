@@ -69,6 +69,27 @@ class MultiScaleRegistratorMixture:
             return False
         return True
 
+    def _register_sparse_point_clouds(self):         # qt_multiscale_registrator.py:74-90
+        """Pre-registration on the two sparse input clouds (``x y z red green blue`` .ply, e.g. COLMAP's) with the first
+        correspondence distance and iteration count of the lists; its transformation seeds the multiscale loop."""
+        from ..utils.file_loader import load_sparse_pc
+        sparse_pc1 = load_sparse_pc(self.sparse_first_path)
+        sparse_pc2 = load_sparse_pc(self.sparse_second_path)
+        if not sparse_pc1 or not sparse_pc2:
+            self.errors.append("Point clouds provided as sparse were of a different type")
+            return None
+        try:
+            sparse_result = do_icp_registration(sparse_pc1, sparse_pc2, self.init_trans, self.registration_type,
+                                                self.voxel_values[0], self.relative_fitness, self.relative_rmse,
+                                                self.iter_values[0], self.rejection_type, self.k_value)
+        except RuntimeError as e:
+            self.errors.append(f"{e}\nSource: \"{sparse_pc1}\"\nTarget: \"{sparse_pc2}\"")
+            return None
+        self.sparse_result = sparse_result
+        if self._progress:
+            self._progress(int(1 / (len(self.iter_values) + 1) * 100))
+        return sparse_result.transformation
+
     def _register_main_point_clouds(self, initial_transformation):   # :197-236
         current_trans = initial_transformation
         results = None
@@ -95,10 +116,14 @@ class MultiScaleRegistratorMixture:
     def run(self):
         if self._check_valid_data() is False:
             return None
-        if self.use_corresponding:
-            self.errors.append("sparse pre-registration needs the .ply loader (SURVEY.md 8f N3); not available")
+        current_trans = copy.deepcopy(self.init_trans)
+        if self.use_corresponding:                      # qt_multiscale_registrator.py:45-46
+            current_trans = self._register_sparse_point_clouds()
+            if current_trans is None:
+                return None
+        if self.signal_cancel:
             return None
-        results = self._register_main_point_clouds(copy.deepcopy(self.init_trans))
+        results = self._register_main_point_clouds(current_trans)
         if results is None:
             return None
         data = MultiScaleRegistrationData(registration_type=self.registration_type.instance_name,

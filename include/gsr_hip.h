@@ -202,6 +202,13 @@ int32_t gsr_icp_solve(const double* acc, int32_t kind, const double* centre, dou
 /* The centre used by the context's point-to-point sums (target bounding-box centre). */
 int32_t gsr_icp_get_centre(gsr_icp_ctx* ctx, double* centre3);
 
+/* Normals of a cloud that has NO covariances -- a sparse (COLMAP) input cloud of the multiscale worker's sparse
+ * pre-registration (src/gui/workers/registration/qt_multiscale_registrator.py:74-90, src/utils/file_loader.py:20-30):
+ * replaces the estimate_normals() call of convert_input_pc_to_open3d_pc (src/utils/point_cloud_converter.py:9-28), i.e.
+ * Open3D's default KDTreeSearchParamKNN(knn = 30) + covariance of the neighbourhood + FastEigen3x3.
+ * xyz[n*3] float32, normals[n*3] float64 (host or device as on_device says), knn in [1, 30]. */
+int32_t gsr_normals_knn(const float* xyz, int64_t n, int32_t knn, double* normals, int32_t on_device, int32_t device, void* stream);
+
 /* ------------------------------------------------------------------------------ voxel down-sampling */
 
 /* PointCloud::VoxelDownSample (Open3D 0.16.0 PointCloud.cpp), the first step of the reference's voxel multiscale

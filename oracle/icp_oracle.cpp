@@ -844,4 +844,43 @@ void gsr_oracle_normals_from_cov(const double* cov3x3, int64_t n, double* out) {
     }
 }
 
+// Open3D PointCloud::EstimateNormals(KDTreeSearchParamKNN(knn), fast_normal_computation = true) on a cloud WITHOUT
+// covariances -- what convert_input_pc_to_open3d_pc does to a sparse (COLMAP) input cloud
+// (src/utils/point_cloud_converter.py:26, default knn = 30) [upstream-recall of Open3D 0.16 EstimateNormals.cpp]:
+// per point the knn nearest points (itself included, ordered by (distance, index)); with >= 3 of them the covariance by
+// cumulants (ComputeCovariance: means of x, y, z, xx, xy, ... then E[xy] - E[x] E[y]) else the identity; normal = the
+// FastEigen3x3 eigenvector of the smallest eigenvalue, (0, 0, 1) if that is the zero vector.  No orientation step.
+void gsr_oracle_normals_knn(const double* pts_, int64_t n, int32_t knn, int32_t threads, double* out) {
+    std::vector<P3> pts(n);
+    std::memcpy(pts.data(), pts_, sizeof(P3) * n);
+    KdTree tree;
+    tree.create(pts.data(), n);
+#ifdef _OPENMP
+    if (threads > 0) omp_set_num_threads(threads);
+#endif
+#pragma omp parallel for schedule(dynamic, 256)
+    for (int64_t i = 0; i < n; ++i) {
+        std::vector<KdTree::DI> heap;
+        tree.knn(pts[i], 0, (size_t)knn, heap);
+        std::sort(heap.begin(), heap.end());
+        double C[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        if (heap.size() >= 3) {
+            double c[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+            for (const KdTree::DI& e : heap) {
+                const P3& p = pts[e.second];
+                c[0] += p.x; c[1] += p.y; c[2] += p.z;
+                c[3] += p.x * p.x; c[4] += p.x * p.y; c[5] += p.x * p.z; c[6] += p.y * p.y; c[7] += p.y * p.z; c[8] += p.z * p.z;
+            }
+            for (int k = 0; k < 9; ++k) c[k] /= (double)heap.size();
+            C[0][0] = c[3] - c[0] * c[0]; C[1][1] = c[6] - c[1] * c[1]; C[2][2] = c[8] - c[2] * c[2];
+            C[0][1] = C[1][0] = c[4] - c[0] * c[1]; C[0][2] = C[2][0] = c[5] - c[0] * c[2]; C[1][2] = C[2][1] = c[7] - c[1] * c[2];
+        }
+        double v[3];
+        fast_eigen_min(C, v);
+        const double nn = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        if (nn == 0.0 || nn != nn) { v[0] = 0; v[1] = 0; v[2] = 1; }
+        out[3 * i] = v[0]; out[3 * i + 1] = v[1]; out[3 * i + 2] = v[2];
+    }
+}
+
 }  // extern "C"

@@ -312,3 +312,14 @@ def normals_from_cov(cov3x3):
     out = np.empty((c.shape[0], 3), np.float64)
     lib().gsr_oracle_normals_from_cov(c, c.shape[0], out)
     return out
+
+
+def normals_knn(points, knn=30, threads=0):
+    """Open3D ``estimate_normals()`` with its default ``KDTreeSearchParamKNN(30)`` on a cloud without covariances."""
+    p = _c(points, np.float64).reshape(-1, 3)
+    out = np.empty_like(p)
+    fn = lib().gsr_oracle_normals_knn
+    fn.restype = None
+    fn.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
+    fn(p.ctypes.data, p.shape[0], int(knn), int(threads), out.ctypes.data)
+    return out

@@ -96,6 +96,9 @@ int gsr_oracle_icp_correspond(const double* src, int64_t ns, const double* tgt, 
                               int64_t* out_idx, double* out_d2);
 // Smallest-eigenvalue eigenvector of each 3x3 covariance (Open3D EstimateNormals with covariances set).
 void gsr_oracle_normals_from_cov(const double* cov3x3, int64_t n, double* out_normals);
+// Open3D EstimateNormals(KDTreeSearchParamKNN(knn)) on a cloud without covariances (a sparse input cloud,
+// src/utils/point_cloud_converter.py:9-28).
+void gsr_oracle_normals_knn(const double* pts, int64_t n, int32_t knn, int32_t threads, double* out_normals);
 
 #ifdef __cplusplus
 }

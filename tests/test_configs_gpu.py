@@ -1,0 +1,241 @@
+"""BASELINE.json configs C2 (2 x 1 M splats, 3 HEM levels + point-to-plane ICP) and C3 (2 x 5 M splats, SH degree 3,
+4-level coarse-to-fine registration) end to end on one MI355X, through the same front end bench.py drives.
+
+C2 is small enough for the CPU oracle to run beside it: level 1 must equal the oracle's discrete outcome exactly
+(parents, accepted pairs, orphans) and its components to 1e-4; levels 2-3 are compared cascade-free (every level
+recomputed from the ORACLE's previous level) and end to end through the global moments of the mixture; the ICP chain on
+the GPU's own level lists is compared with the oracle's chain on the same arrays (final transform <= 1e-5 Frobenius).
+C3 is checked through size-independent properties per level, the distance to the ground-truth motion, and the oracle's
+ICP on the two coarsest levels.
+
+Tolerances (BASELINE.json north_star): mixture moments 1e-4 relative, transforms 1e-5 Frobenius.  "Relative" for a
+mean of zero-mean fields (colour, SH) is taken against the RMS magnitude of the field, for the weighted mean position
+against the cloud's extent, for the covariance against its largest entry.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HEM_PARAMS = dict(hem_reduction=3.0, distance_delta=3.0, color_delta=2.5, decay_rate=1.0)
+ITER_VALUES = [50, 30, 20, 10]
+MAX_CORR = [0.5, 0.3, 0.2, 0.1]
+
+
+def _np(a):
+    return a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+
+
+def global_moments(lv):
+    """Global moments of a mixture level: sum of weights, weighted mean, total (within + between) weighted covariance,
+    weighted mean colour / opacity / SH, and the RMS magnitudes the relative errors refer to."""
+    w = _np(lv["weight"]).astype(np.float64)
+    W = w.sum()
+    x = _np(lv["xyz"]).astype(np.float64)
+    c6 = _np(lv["cov6"]).astype(np.float64)
+    mean = (w[:, None] * x).sum(0) / W
+    d = x - mean
+    outer = np.stack([d[:, 0] * d[:, 0], d[:, 0] * d[:, 1], d[:, 0] * d[:, 2], d[:, 1] * d[:, 1], d[:, 1] * d[:, 2], d[:, 2] * d[:, 2]], 1)
+    cov = (w[:, None] * (c6 + outer)).sum(0) / W
+    col = _np(lv["color"]).astype(np.float64)
+    op = _np(lv["opacity"]).astype(np.float64)
+    sh = _np(lv["sh"]).astype(np.float64)
+    return {"W": W, "mean": mean, "cov": cov,
+            "color": (w[:, None] * col).sum(0) / W, "opacity": (w * op).sum() / W, "sh": (w[:, None] * sh).sum(0) / W,
+            "rms_color": np.sqrt((w[:, None] * col * col).sum() / W / 3), "rms_opacity": np.sqrt((w * op * op).sum() / W),
+            "rms_sh": np.sqrt((w[:, None] * sh * sh).sum() / W / max(1, sh.shape[1])), "extent": np.abs(x).max()}
+
+
+def assert_moments_close(got, want, tag, tol=1e-4):
+    g, o = global_moments(got), global_moments(want)
+    assert abs(g["W"] - o["W"]) <= tol * o["W"], (tag, "sum of weights", g["W"], o["W"])
+    assert np.abs(g["mean"] - o["mean"]).max() <= tol * o["extent"], (tag, "weighted mean", g["mean"], o["mean"])
+    assert np.abs(g["cov"] - o["cov"]).max() <= tol * np.abs(o["cov"]).max(), (tag, "weighted covariance", g["cov"], o["cov"])
+    assert np.abs(g["color"] - o["color"]).max() <= tol * o["rms_color"], (tag, "mean colour", g["color"], o["color"])
+    assert abs(g["opacity"] - o["opacity"]) <= tol * o["rms_opacity"], (tag, "mean opacity", g["opacity"], o["opacity"])
+    assert np.abs(g["sh"] - o["sh"]).max() <= tol * o["rms_sh"], (tag, "mean SH", float(np.abs(g["sh"] - o["sh"]).max()), o["rms_sh"])
+
+
+def _rel(a, b):
+    a, b = _np(a).astype(np.float64), _np(b).astype(np.float64)
+    return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30)) if a.size else 0.0
+
+
+def level_properties(prev, cur, st, dropped, h, tag):
+    """Size-independent properties of one level: bookkeeping, weight conservation, mean preservation by moment matching,
+    finite values, positive-definite covariances."""
+    n_in = prev["xyz"].shape[0]
+    assert st["parents"] == int(_np(prev["is_parent"]).sum()), tag
+    assert cur["xyz"].shape[0] == st["parents"] + st["orphans"] - dropped, tag
+    assert abs(st["parents"] - n_in / 3) < 0.02 * n_in, (tag, st["parents"], n_in)          # parent probability 1 / rho
+    wp, wc = prev["weight"].double(), cur["weight"].double()
+    assert abs(float(wc.sum()) - float(wp.sum())) <= 1e-4 * float(wp.sum()), (tag, float(wc.sum()), float(wp.sum()))
+    m0 = (wp[:, None] * prev["xyz"].double()).sum(0) / wp.sum()
+    m1 = (wc[:, None] * cur["xyz"].double()).sum(0) / wc.sum()
+    assert float((m0 - m1).abs().max()) <= 1e-4 * h, (tag, m0, m1)
+    for f in ("xyz", "color", "cov6", "opacity", "sh", "weight"):
+        assert bool(torch.isfinite(cur[f]).all()), (tag, f)
+    c = cur["cov6"].double()
+    det = (-c[:, 2] * c[:, 2] * c[:, 3] + 2 * c[:, 1] * c[:, 2] * c[:, 4] - c[:, 0] * c[:, 4] * c[:, 4]
+           - c[:, 1] * c[:, 1] * c[:, 5] + c[:, 0] * c[:, 3] * c[:, 5])
+    assert bool((det > 0).all()), tag
+
+
+def gpu_level_lists(src, tgt, levels=3):
+    """What bench.py's step does for the HEM half: cloud 1 then cloud 2 on ONE libc rand() stream (a fresh reference
+    process, qt_gaussian_mixture.py:55,79).  Returns per cloud the list [level 0, level 1, ...] with state, and the stats."""
+    from gaussiansplattingregistration_amd import hem
+    out, stats = [], []
+    with hem.HemMixture(rng_mode="glibc", **HEM_PARAMS) as m:
+        m.set_rng("glibc", 1, 0)
+        for c in (src, tgt):
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+            lv, st = [m.get_level(as_torch=True, with_state=True)], []
+            for _ in range(levels):
+                _, dropped = m.run_level()
+                s = m.stats()
+                s["dropped_now"] = dropped
+                st.append(s)
+                lv.append(m.get_level(as_torch=True, with_state=True))
+            out.append(lv)
+            stats.append(st)
+    return out, stats
+
+
+def gpu_multiscale(lists_src, lists_tgt, kind_plane=True):
+    """Coarse-to-fine ICP over the level lists (qt_multiscale_registrator.py:197-236).  Returns the per-level results."""
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+    from gaussiansplattingregistration_amd.utils import local_registration_util as lru
+    est = lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Plane if kind_plane else lru.LocalRegistrationType.ICP_Point_To_Point,
+                             lru.RobustLoss(0))
+    T = np.eye(4)
+    res, clouds = [], []
+    for k in range(len(ITER_VALUES)):
+        s_l, t_l = lists_src[-(k + 1)], lists_tgt[-(k + 1)]
+        s = PointCloud(xyz32=s_l["xyz"], cov6=s_l["cov6"])
+        t = PointCloud(xyz32=t_l["xyz"], cov6=t_l["cov6"])
+        t.estimate_normals()
+        r = lru.registration_icp(s, t, MAX_CORR[k], T, est, lru.get_convergence_criteria(1e-6, 1e-6, ITER_VALUES[k]))
+        res.append((T.copy(), r))
+        clouds.append((s, t))
+        T = r.transformation
+    return res, clouds
+
+
+def make_pair_torch(n, seed, angle_deg, shift):
+    """target = synthetic cloud (SURVEY 8d generator, on the device), source = inv(T_gt) * target + 0.002 jitter."""
+    from gaussiansplattingregistration_amd import synth
+    dev = torch.device("cuda", 0)
+    tgt = synth.make_cloud_torch(n, seed=seed, device=dev)
+    T_gt = synth.rigid_transform(angle_deg, (1, 1, 1), shift * tgt["h"] * np.array([1.0, -1.0, 0.5]))
+    src = synth.apply_rigid_torch(tgt, np.linalg.inv(T_gt))
+    gen = torch.Generator(device=dev).manual_seed(7)
+    src["xyz"] = src["xyz"] + torch.randn(src["xyz"].shape, device=dev, generator=gen) * 0.002
+    src = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in src.items()}
+    return src, tgt, T_gt
+
+
+def test_c2_2x1m_three_levels_and_point_to_plane_icp(oracle):
+    """BASELINE configs[1]: 2 x 1 M splats, 3 HEM mixture levels + point-to-plane ICP, one MI355X."""
+    from gaussiansplattingregistration_amd import hem
+    n = 1_000_000
+    src, tgt, T_gt = make_pair_torch(n, seed=100, angle_deg=2.0, shift=0.01)
+    lists, stats = gpu_level_lists(src, tgt)
+    h = tgt["h"]
+    for ci in range(2):
+        for k in range(3):
+            level_properties(lists[ci][k], lists[ci][k + 1], stats[ci][k], stats[ci][k]["dropped_now"], h, ("C2", ci, k))
+    sizes = [lv["xyz"].shape[0] for lv in lists[0]]
+    assert sizes[0] == n and all(0.30 * a < b < 0.37 * a for a, b in zip(sizes, sizes[1:])), sizes
+
+    # ---- HEM against the oracle on the first cloud (the one that starts the rand() stream)
+    host = {k: _np(src[k]) for k in ("xyz", "color", "cov6", "opacity", "sh")}
+    o = oracle.HemOracle(host["xyz"], host["color"], host["cov6"], host["opacity"], host["sh"])
+    olv, ost = [o.level(0)], []
+    for k in range(3):
+        o.run_level()
+        ost.append(o.stats())
+        olv.append(o.level(k + 1))
+    o.close()
+    # level 0 state: the same parent flags
+    assert np.array_equal(_np(lists[0][0]["is_parent"]), olv[0]["is_parent"])
+    # level 1: the discrete outcome is exact, the components agree to 1e-4
+    g1, s1 = lists[0][1], stats[0][0]
+    assert (s1["parents"], s1["pairs"], s1["orphans"], s1["dropped_now"]) == (ost[0]["parents"], ost[0]["pairs"], ost[0]["orphans"], ost[0]["dropped"])
+    assert g1["xyz"].shape[0] == olv[1]["xyz"].shape[0]
+    for f in ("xyz", "color", "cov6", "opacity", "sh", "weight"):
+        assert _rel(g1[f], olv[1][f]) < 1e-4, ("C2 level 1", f, _rel(g1[f], olv[1][f]))
+    assert np.array_equal(_np(g1["is_parent"]), olv[1]["is_parent"])
+    # levels 1-3 end to end: counts within 0.1 % (a pair within 1e-7 of a gate threshold may flip after level 1) and the
+    # global moments of the mixture to 1e-4 -- unconditionally
+    for k in (1, 2, 3):
+        ng, no = lists[0][k]["xyz"].shape[0], olv[k]["xyz"].shape[0]
+        assert abs(ng - no) <= max(1, no // 1000), ("C2 count", k, ng, no)
+        assert_moments_close(lists[0][k], olv[k], ("C2 end to end", k))
+    # levels 2 and 3 cascade-free: the GPU level computed from the ORACLE's previous level (arrays, weights, flags)
+    for k in (2, 3):
+        prev = olv[k - 1]
+        with hem.HemMixture(**HEM_PARAMS) as m:
+            m.set_level0(prev["xyz"], prev["color"], prev["opacity"], prev["cov6"], prev["sh"])
+            m.set_state(parent_mask=prev["is_parent"], weight=prev["weight"])
+            _, dropped = m.run_level()
+            st = m.stats()
+            got = m.get_level(with_state=True)
+        assert (st["parents"], st["pairs"], st["orphans"], dropped) == (ost[k - 1]["parents"], ost[k - 1]["pairs"], ost[k - 1]["orphans"], ost[k - 1]["dropped"]), ("C2 cascade-free", k)
+        for f in ("xyz", "color", "cov6", "opacity", "sh", "weight"):
+            assert _rel(got[f], olv[k][f]) < 1e-4, ("C2 cascade-free", k, f, _rel(got[f], olv[k][f]))
+
+    # ---- point-to-plane ICP, coarse to fine, against the oracle's chain on the same level lists
+    res, clouds = gpu_multiscale(lists[0], lists[1])
+    T_final = res[-1][1].transformation
+    assert np.linalg.norm(T_final - T_gt) < 1e-3, (T_final, T_gt)
+    T = np.eye(4)
+    for k, (s, t) in enumerate(clouds):
+        nrm = oracle.normals_from_cov(t.covariances)
+        w = oracle.icp(s.points, t.points, nrm, T, kind=1, max_corr=MAX_CORR[k], max_iter=ITER_VALUES[k])
+        g = res[k][1]
+        assert np.linalg.norm(g.transformation - w["transformation"]) < 1e-5, ("C2 ICP level", k, g.transformation, w["transformation"])
+        assert g.iterations == w["iterations"] and abs(g.fitness - w["fitness"]) < 1e-9 and abs(g.inlier_rmse - w["inlier_rmse"]) < 1e-7
+        T = w["transformation"]
+
+
+def test_c3_2x5m_four_level_coarse_to_fine(oracle):
+    """BASELINE configs[2] -- what bench.py runs: 2 x 5 M splats (SH degree 3), 3 HEM levels per cloud on one libc rand()
+    stream, 4-entry coarse-to-fine point-to-plane ICP.  Properties per level, distance to the ground-truth motion, and the
+    oracle's ICP on the two coarsest levels."""
+    n = 5_000_000
+    src, tgt, T_gt = make_pair_torch(n, seed=100, angle_deg=1.0, shift=0.004)
+    lists, stats = gpu_level_lists(src, tgt)
+    h = tgt["h"]
+    for ci in range(2):
+        for k in range(3):
+            level_properties(lists[ci][k], lists[ci][k + 1], stats[ci][k], stats[ci][k]["dropped_now"], h, ("C3", ci, k))
+        sizes = [lv["xyz"].shape[0] for lv in lists[ci]]
+        assert sizes[0] == n and all(0.30 * a < b < 0.37 * a for a, b in zip(sizes, sizes[1:])), sizes
+    # the two clouds share one rand() stream: the second cloud's flags continue where the first cloud's levels stopped
+    draws = stats[1][-1]["rng_draws"]
+    assert draws == sum(lv["xyz"].shape[0] + s["dropped_now"] for c in range(2) for lv, s in zip(lists[c][1:], stats[c])) + 2 * n
+    # level 0 flags of the first cloud = the reference's first n draws
+    assert np.array_equal(_np(lists[0][0]["is_parent"][:200000]), oracle.parent_flags(200000, 3.0))
+    # the mixture keeps the scene: global mean and total covariance of every level equal level 0's (moment matching)
+    for ci in range(2):
+        base = global_moments(lists[ci][0])
+        for k in (1, 2, 3):
+            g = global_moments(lists[ci][k])
+            assert abs(g["W"] - base["W"]) <= 1e-4 * base["W"]
+            assert np.abs(g["mean"] - base["mean"]).max() <= 1e-4 * base["extent"]
+    res, clouds = gpu_multiscale(lists[0], lists[1])
+    T_final = res[-1][1].transformation
+    assert np.linalg.norm(T_final - T_gt) < 1e-4, (T_final, T_gt)
+    assert res[-1][1].fitness > 0.99
+    # oracle ICP on the two coarsest levels (185 k and 556 k points), chained like the driver does
+    T = np.eye(4)
+    for k in range(2):
+        s, t = clouds[k]
+        nrm = oracle.normals_from_cov(t.covariances)
+        w = oracle.icp(s.points, t.points, nrm, T, kind=1, max_corr=MAX_CORR[k], max_iter=ITER_VALUES[k])
+        g = res[k][1]
+        assert np.linalg.norm(g.transformation - w["transformation"]) < 1e-5, ("C3 ICP level", k)
+        assert g.iterations == w["iterations"]
+        T = w["transformation"]
