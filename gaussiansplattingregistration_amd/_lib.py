@@ -23,6 +23,9 @@ GSR_RNG_HASH = 1
 
 GSR_ICP_ACC_LEN = 32
 
+GSR_DECOMP_REFERENCE = 0
+GSR_DECOMP_EXACT = 1
+
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
 ALLREDUCE_DEV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
 
@@ -66,6 +69,7 @@ SIGNATURES = {
     "gsr_icp_get_timing": (_i32, [_vp, C.POINTER(_f32)]),
     "gsr_normals_from_cov": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     "gsr_normals_knn": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp]),
+    "gsr_decompose_cov": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "gsr_icp_solve": (_i32, [_vp, _i32, _vp, _vp]),
     "gsr_icp_get_centre": (_i32, [_vp, _vp]),
 }

@@ -60,7 +60,7 @@ __device__ void sym_eig3_d(const double Ain[3][3], double V[3][3], double lam[3]
     lam[0] = A[0][0]; lam[1] = A[1][1]; lam[2] = A[2][2];
     // ascending order (three compare-exchanges on the columns)
     for (int pass = 0; pass < 3; ++pass) {
-        const int a = pass == 1 ? 1 : 0, b = pass == 0 ? 1 : 2;
+        const int a = pass == 1 ? 1 : 0, b = a + 1;             // (0,1) (1,2) (0,1)
         if (lam[b] < lam[a]) {
             const double t = lam[a]; lam[a] = lam[b]; lam[b] = t;
             for (int k = 0; k < 3; ++k) { const double v = V[k][a]; V[k][a] = V[k][b]; V[k][b] = v; }

@@ -8,14 +8,15 @@ Kept (same names / shapes): ``get_xyz (N,3)`` ``:56-57``, ``get_colors (N,3)`` `
 reader/writer in ``utils/ply_io.py``, ``plyfile`` is not needed).  ``from_arrays`` builds level 0 from raw arrays.
 
 ``from_mixture`` runs the reference's scaling/rotation rebuild (``:151-153,242-265``: batched ``eigh``, axis matching,
-quaternions; the reference's own comment calls it unused) only when asked (``decompose=True``): registration only
-consumes xyz / covariance, and the rebuild is what ``save_ply`` of a down-sampled model needs.
+quaternions; the reference's own comment calls it unused) only when asked (``decompose=True`` / ``"reference"`` /
+``"exact"``): registration only consumes xyz / covariance.  The rebuild is one device kernel (``csrc/model.hip``).
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 
+from .. import _lib
 from .gaussian_mixture_level import GaussianMixtureModel
 
 
@@ -48,6 +49,14 @@ class GaussianModel:
         self._covariance = torch.empty(0)
 
     # -- accessors (reference names) -------------------------------------------------------------
+    @property
+    def get_scaling(self):
+        return torch.exp(self._scaling)                              # gaussian_model.py:48-50
+
+    @property
+    def get_rotation(self):
+        return torch.nn.functional.normalize(self._rotation)          # gaussian_model.py:52-54
+
     @property
     def get_xyz(self):
         return self._xyz
@@ -120,37 +129,57 @@ class GaussianModel:
         ply_io.save_gaussian_ply(path, c(self._xyz), c(self.get_colors), c(self.get_spherical_harmonics), c(self._opacity),
                                  c(self._scaling), c(self._rotation))
 
-    def from_mixture(self, gaussian_mixture: GaussianMixtureModel, sh_degree: int, decompose: bool = False):
+    def from_mixture(self, gaussian_mixture: GaussianMixtureModel, sh_degree: int, decompose=False):
+        """``GaussianModel.from_mixture`` (``gaussian_model.py:141-153``).  ``decompose``: ``False`` skips the scaling /
+        rotation rebuild (registration consumes xyz / covariance only); ``True`` or ``"reference"`` runs it with the
+        reference's arithmetic, ``"exact"`` with a decomposition that really reproduces the covariance (what
+        ``save_ply`` of a down-sampled model needs) -- both on the GPU (``csrc/model.hip``)."""
         self.sh_degree = sh_degree
         k = (sh_degree + 1) ** 2 - 1
         self._xyz = _t(gaussian_mixture.xyz, self.device_name)
         n = int(self._xyz.shape[0])
-        self._features_dc = _t(gaussian_mixture.colors, self.device_name).view(-1, 1, 3)
-        self._features_rest = _t(gaussian_mixture.features, self.device_name).view(-1, k, 3)
+        self._features_dc = _t(gaussian_mixture.colors, self.device_name).view(n, 1, 3)
+        self._features_rest = _t(gaussian_mixture.features, self.device_name).view(n, k, 3)
         self._opacity = _t(gaussian_mixture.opacities, self.device_name)
         self._covariance = _t(gaussian_mixture.covariance, self.device_name).view(n, 6)
         if decompose:
-            self._scaling, evec = self.decompose_covariance_matrix()
-            self._rotation = _matrices_to_quaternions(evec)
+            mode = "exact" if decompose == "exact" else "reference"
+            if mode == "reference":
+                self._scaling, evec = self.decompose_covariance_matrix()
+                self._rotation = self._last_quaternions
+            else:
+                self._scaling, self._rotation, _ = self._decompose(_lib.GSR_DECOMP_EXACT)
         return self
 
+    def _decompose(self, mode):
+        """-> (scaling (N,3), quaternions (N,4), matrices (N,3,3)) of ``gsr_decompose_cov`` on the model's covariances."""
+        import ctypes as C
+        L = _lib.load(require_device=True)
+        cov = self._covariance.detach().to(torch.float32).contiguous()
+        n = int(cov.shape[0])
+        if cov.is_cuda:
+            sc = torch.empty((n, 3), dtype=torch.float32, device=cov.device)
+            q = torch.empty((n, 4), dtype=torch.float32, device=cov.device)
+            mat = torch.empty((n, 3, 3), dtype=torch.float32, device=cov.device)
+            torch.cuda.current_stream(cov.device.index).synchronize()
+            _lib.check(L.gsr_decompose_cov(cov.data_ptr(), n, mode, sc.data_ptr(), q.data_ptr(), mat.data_ptr(), 1, cov.device.index,
+                                           C.c_void_p(torch.cuda.current_stream(cov.device.index).cuda_stream)), "gsr_decompose_cov")
+            return sc, q, mat
+        a = np.ascontiguousarray(cov.numpy())
+        sc, q, mat = np.empty((n, 3), np.float32), np.empty((n, 4), np.float32), np.empty((n, 3, 3), np.float32)
+        _lib.check(L.gsr_decompose_cov(a.ctypes.data, n, mode, sc.ctypes.data, q.ctypes.data, mat.ctypes.data, 0, 0, None), "gsr_decompose_cov")
+        return torch.from_numpy(sc), torch.from_numpy(q), torch.from_numpy(mat)
+
     def decompose_covariance_matrix(self):
-        """Scaling / rotation of every component from its covariance (reference ``gaussian_model.py:242-265``): a batched
-        symmetric eigendecomposition, then eigenpair k goes to the slot of the coordinate axis its eigenvector is most
-        aligned with (row k of |V^T|, arg-max).  Two eigenvectors claiming the same axis overwrite each other in
-        eigenvalue order (the reference's ``scatter_`` leaves that case to the device; here it is deterministic), and an
-        unclaimed slot stays zero, as there.  Returns (values (N,3), vectors (N,3,3)); like the reference's, the
-        "scaling" is the eigenvalue itself, not its square root or logarithm."""
-        full = self.get_full_covariance()
-        ev, evec = torch.linalg.eigh(full)
-        slot = evec.transpose(1, 2).abs().argmax(dim=2)            # (N,3): axis claimed by eigenpair k
-        vals = torch.zeros_like(ev)
-        vecs = torch.zeros_like(evec)
-        rows = torch.arange(ev.shape[0], device=ev.device)
-        for k in range(3):                                         # ascending eigenvalue: the later claim wins
-            vals[rows, slot[:, k]] = ev[:, k]
-            vecs[rows, slot[:, k], :] = evec[:, k, :]
-        return vals, vecs
+        """Scaling / rotation of every component from its covariance with the reference's arithmetic
+        (``gaussian_model.py:242-265``), in ONE device kernel (``gsr_decompose_cov``, ``GSR_DECOMP_REFERENCE``) instead of
+        a batched ``torch.linalg.eigh`` plus scatters: eigenpair k goes to the slot of the coordinate axis its eigenvector
+        is most aligned with; two claims of one slot overwrite in eigenvalue order, an unclaimed slot stays zero.
+        Returns (values (N,3), vectors (N,3,3)); like the reference's, the "scaling" is the eigenvalue itself, not its
+        square root or logarithm.  The quaternions of the same call are kept in ``_last_quaternions``."""
+        sc, q, mat = self._decompose(_lib.GSR_DECOMP_REFERENCE)
+        self._last_quaternions = q
+        return sc, mat
 
     # -- rigid motion and merge (reference ``gaussian_model.py:198-222,267-290``) ---------------------------------
     def transform_gaussian_model(self, transformation_matrix):

@@ -209,6 +209,24 @@ int32_t gsr_icp_get_centre(gsr_icp_ctx* ctx, double* centre3);
  * xyz[n*3] float32, normals[n*3] float64 (host or device as on_device says), knn in [1, 30]. */
 int32_t gsr_normals_knn(const float* xyz, int64_t n, int32_t knn, double* normals, int32_t on_device, int32_t device, void* stream);
 
+/* ------------------------------------------------------------------------------------ level export */
+
+/* Scaling / rotation of every component from its covariance, on the device: replaces
+ * GaussianModel.decompose_covariance_matrix + matrices_to_quaternions, which GaussianModel.from_mixture runs on every
+ * HEM level (src/models/gaussian_model.py:141-153,242-265; src/utils/general_utils.py:94-100).
+ *   GSR_DECOMP_REFERENCE  the reference's arithmetic, bug for bug: scaling[k] = the eigenVALUE whose eigenvector is most
+ *                         aligned with axis k (0 if none claims it, the larger eigenvalue if two do), rotation = the
+ *                         trace-formula quaternion (w, x, y, z) of the matrix whose row k is the claiming ROW of eigh's
+ *                         eigenvector matrix (csrc/model.hip spells it out).
+ *   GSR_DECOMP_EXACT      scaling = log standard deviations, rotation = unit quaternion of a proper rotation, such that
+ *                         R diag(exp(scaling))^2 R^T reproduces the covariance (what save_ply of a level needs).
+ * cov6[n*6] (xx,xy,xz,yy,yz,zz), scaling[n*3], rotation[n*4], matrix[n*9] or NULL (the 3x3 the quaternion was taken from,
+ * row-major); float32, all host or all device as on_device says. */
+#define GSR_DECOMP_REFERENCE 0
+#define GSR_DECOMP_EXACT     1
+int32_t gsr_decompose_cov(const float* cov6, int64_t n, int32_t mode, float* scaling, float* rotation, float* matrix,
+                          int32_t on_device, int32_t device, void* stream);
+
 /* ------------------------------------------------------------------------------ voxel down-sampling */
 
 /* PointCloud::VoxelDownSample (Open3D 0.16.0 PointCloud.cpp), the first step of the reference's voxel multiscale

@@ -323,3 +323,36 @@ def normals_knn(points, knn=30, threads=0):
     fn.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]
     fn(p.ctypes.data, p.shape[0], int(knn), int(threads), out.ctypes.data)
     return out
+
+
+def decompose_reference(cov6):
+    """CPU restatement (numpy, float64 eigh) of GaussianModel.decompose_covariance_matrix + matrices_to_quaternions
+    (reference src/models/gaussian_model.py:242-265, src/utils/general_utils.py:94-100), pinned against
+    tests/golden/from_mixture.npz (generated by running the reference's own functions, tests/golden/make_golden_from_mixture.py).
+    Eigenvector sign convention: largest-magnitude component positive (the reference inherits LAPACK's, which is
+    unspecified).  -> (sorted_eigenvalues (N,3), sorted_eigenvectors (N,3,3), quaternions (N,4)) float32."""
+    c = _c(cov6, np.float64).reshape(-1, 6)
+    n = c.shape[0]
+    full = np.stack([c[:, [0, 1, 2]], c[:, [1, 3, 4]], c[:, [2, 4, 5]]], 1)
+    ev, V = np.linalg.eigh(full)                                   # ascending; columns = eigenvectors
+    m = np.abs(V).argmax(1)                                        # per column: row of the largest |component| (first on ties)
+    sgn = np.sign(V[np.arange(n)[:, None], m, np.arange(3)[None, :]])
+    sgn[sgn == 0] = 1
+    V = V * sgn[:, None, :]
+    corr = np.abs(V.transpose(0, 2, 1)).argmax(2)                  # (N,3): axis claimed by eigenvector k (gaussian_model.py:251-254)
+    vals = np.zeros((n, 3), np.float32)
+    vecs = np.zeros((n, 3, 3), np.float32)
+    rows = np.arange(n)
+    for k in range(3):                                             # scatter_ on the CPU: the later index wins
+        vals[rows, corr[:, k]] = ev[:, k].astype(np.float32)
+        vecs[rows, corr[:, k], :] = V[:, k, :].astype(np.float32)  # ROW k of the eigenvector matrix (gaussian_model.py:262)
+    return vals, vecs, quaternions_reference(vecs)
+
+
+def quaternions_reference(M):
+    """matrices_to_quaternions (general_utils.py:94-100) in float32: w = sqrt(1 + trace) / 2, no branch."""
+    M = np.asarray(M, np.float32)
+    with np.errstate(all="ignore"):
+        w = np.sqrt(np.float32(1) + (M[:, 0, 0] + M[:, 1, 1] + M[:, 2, 2])) / np.float32(2)
+        d = np.float32(4) * w
+        return np.stack([w, (M[:, 2, 1] - M[:, 1, 2]) / d, (M[:, 0, 2] - M[:, 2, 0]) / d, (M[:, 1, 0] - M[:, 0, 1]) / d], -1).astype(np.float32)

@@ -1,5 +1,6 @@
 """3DGS .ply round trip (own reader/writer; the reference uses plyfile: gaussian_model.py:98-139,169-185)."""
 import numpy as np
+import pytest
 import torch
 
 from gaussiansplattingregistration_amd import synth
@@ -52,9 +53,11 @@ def test_ascii_ply_and_rejects(tmp_path):
         ply_io.load_gaussian_arrays(p)
 
 
+@pytest.mark.gpu
 def test_from_mixture_decompose_and_save(tmp_path):
     """from_mixture(decompose=True): eigenpairs matched to the coordinate axes and quaternions (reference
-    gaussian_model.py:151-153,242-265), enough to save a down-sampled model."""
+    gaussian_model.py:151-153,242-265) by the device kernel, enough to save a down-sampled model.  Compared with a
+    torch.linalg.eigh restatement up to the sign of the eigenvectors (which eigh leaves to LAPACK)."""
     c = synth.make_cloud(400, seed=4, sh_degree=1)
 
     class Mix:
@@ -65,16 +68,18 @@ def test_from_mixture_decompose_and_save(tmp_path):
     vals, vecs = g.decompose_covariance_matrix()
     full = g.get_full_covariance()
     ev, evec = torch.linalg.eigh(full)
+    a = evec.transpose(1, 2).abs().sort(dim=2).values
+    clear = ((a[:, :, 2] - a[:, :, 1]) > 0.05).all(dim=1)                           # stable arg-max
     claimed = evec.transpose(1, 2).abs().argmax(dim=2)
-    distinct = (claimed.sort(dim=1).values == torch.arange(3)).all(dim=1)          # every axis claimed exactly once
-    assert distinct.float().mean() > 0.5
+    distinct = (claimed.sort(dim=1).values == torch.arange(3)).all(dim=1) & clear   # every axis claimed exactly once
+    assert distinct.float().mean() > 0.3
     # where the matching is a permutation: the same eigenvalues, and eigenvalue k / ROW k of eigh's matrix sit in the
     # slot of the claimed axis (the reference scatters rows, gaussian_model.py:260-261)
-    assert torch.allclose(vals[distinct].sort(dim=1).values, ev[distinct], atol=1e-7)
+    assert torch.allclose(vals[distinct].sort(dim=1).values, ev[distinct], rtol=1e-5, atol=1e-9)
     rows = torch.arange(400)
     for k in range(3):
-        assert torch.equal(vals[rows, claimed[:, k]][distinct], ev[:, k][distinct])
-        assert torch.equal(vecs[rows, claimed[:, k], :][distinct], evec[:, k, :][distinct])
+        assert torch.allclose(vals[rows, claimed[:, k]][distinct], ev[:, k][distinct], rtol=1e-5, atol=1e-9)
+        assert torch.allclose(vecs[rows, claimed[:, k], :][distinct].abs(), evec[:, k, :][distinct].abs(), atol=2e-4)
     assert g._scaling.shape == (400, 3) and g._rotation.shape == (400, 4)
     out = tmp_path / "mix.ply"
     g.save_ply(str(out))
