@@ -28,6 +28,7 @@ GSR_DECOMP_EXACT = 1
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_void_p)
 ALLREDUCE_DEV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
+ALLGATHER_DEV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
 # name -> (restype, argtypes); mirrors include/gsr_hip.h one to one (tests/test_abi.py checks it)
 _vp, _i32, _i64, _u32, _u64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
@@ -40,7 +41,7 @@ SIGNATURES = {
     "gsr_hem_set_params": (_i32, [_vp, _f32, _f32, _f32, _f32]),
     "gsr_hem_set_rng": (_i32, [_vp, _i32, _u32, _u64]),
     "gsr_hem_get_rng_position": (_i32, [_vp, C.POINTER(_u64)]),
-    "gsr_hem_set_shard": (_i32, [_vp, _i32, _i32, ALLREDUCE_DEV_FN, _vp]),
+    "gsr_hem_set_shard": (_i32, [_vp, _i32, _i32, ALLREDUCE_DEV_FN, ALLGATHER_DEV_FN, _vp]),
     "gsr_hem_set_level0": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "gsr_hem_set_state": (_i32, [_vp, _vp, _vp]),
     "gsr_hem_run_level": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
@@ -62,6 +63,7 @@ SIGNATURES = {
     "gsr_icp_set_lambda_geometric": (_i32, [_vp, _f64]),
     "gsr_icp_get_color_gradient": (_i32, [_vp, _vp]),
     "gsr_icp_set_allreduce": (_i32, [_vp, ALLREDUCE_FN, _vp, _i64]),
+    "gsr_icp_set_allreduce_dev": (_i32, [_vp, ALLREDUCE_DEV_FN, _vp, _i64]),
     "gsr_icp_accumulate": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp]),
     "gsr_icp_register": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _i32, _vp, C.POINTER(_f64), C.POINTER(_f64),
                                 C.POINTER(_i32)]),

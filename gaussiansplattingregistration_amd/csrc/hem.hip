@@ -1552,6 +1552,25 @@ __global__ __launch_bounds__(256) void k_flags_hash(int64_t n, unsigned seed, un
     }
 }
 
+// Work-sharded level: the merged components of the parents [lo, lo + cnt) of the cell-sorted parent list as packed rows
+// {xyz 3, color 3, cov6 6, opacity, weight, sh F} (PACK) -- one all-gather of equal chunks moves them -- and back into the
+// output rows of their owners' slots (UNPACK, for every rank's chunk).  slot = rank of the parent in input order.
+template <bool PACK>
+__global__ __launch_bounds__(256) void k_shard_rows(int lo, int cnt, int F, const unsigned* __restrict__ plist, const unsigned* __restrict__ order,
+                                                    const int* __restrict__ prank_in, float* __restrict__ packed, float* o_xyz, float* o_color,
+                                                    float* o_cov6, float* o_opacity, float* o_weight, float* o_sh) {
+    const int RW = 14 + F;
+    const int64_t total = (int64_t)cnt * RW;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(t / RW), f = (int)(t - (int64_t)i * RW);
+        const int64_t slot = prank_in[order[plist[lo + i]]];
+        float* dst = f < 3 ? o_xyz + 3 * slot + f : f < 6 ? o_color + 3 * slot + (f - 3) : f < 12 ? o_cov6 + 6 * slot + (f - 6)
+                     : f == 12 ? o_opacity + slot : f == 13 ? o_weight + slot : o_sh + slot * F + (f - 14);
+        if (PACK) packed[t] = *dst;
+        else *dst = packed[t];
+    }
+}
+
 // validity (mixture.cpp:262-282): keep iff !(isnan(mean) || isnan(det) || det <= 0)
 __global__ __launch_bounds__(256) void k_valid(int64_t n, const float* __restrict__ xyz, const float* __restrict__ cov6,
                                                int* __restrict__ keep) {
@@ -1653,7 +1672,9 @@ struct gsr_hem_ctx {
     bool use_ell = true;            // GSR_HEM_ELL=0: no ellipsoid row clipping (test knob: the pair set must not change)
     int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
     gsr_allreduce_dev_fn shard_allreduce = nullptr;
+    gsr_allgather_dev_fn shard_allgather = nullptr;
     void* shard_user = nullptr;
+    DevBuf shard_send, shard_recv;
     bool sparse_path = false;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
@@ -1856,7 +1877,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
-                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
+                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
                      &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
@@ -1884,11 +1905,11 @@ int32_t gsr_hem_get_rng_position(gsr_hem_ctx* c, uint64_t* draws) {
     return GSR_OK;
 }
 
-int32_t gsr_hem_set_shard(gsr_hem_ctx* c, int32_t rank, int32_t world, gsr_allreduce_dev_fn fn, void* user) {
+int32_t gsr_hem_set_shard(gsr_hem_ctx* c, int32_t rank, int32_t world, gsr_allreduce_dev_fn allreduce, gsr_allgather_dev_fn allgather, void* user) {
     if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_shard: NULL context");
     if (world < 1 || rank < 0 || rank >= world) return fail(GSR_E_INVALID, "gsr_hem_set_shard: rank %d of %d", rank, world);
-    if (world > 1 && !fn) return fail(GSR_E_INVALID, "gsr_hem_set_shard: world > 1 needs an all-reduce callback");
-    c->shard_rank = rank; c->shard_world = world; c->shard_allreduce = fn; c->shard_user = user;
+    if (world > 1 && (!allreduce || !allgather)) return fail(GSR_E_INVALID, "gsr_hem_set_shard: world > 1 needs the all-reduce and the all-gather callback");
+    c->shard_rank = rank; c->shard_world = world; c->shard_allreduce = allreduce; c->shard_allgather = allgather; c->shard_user = user;
     return GSR_OK;
 }
 
@@ -2274,12 +2295,6 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     Level& O = c->nxt;
     GSR_TRY(O.reserve(n_pre, F));
     O.n = n_pre; O.F = F;
-    if (sharded && P > 0) {          // rows of the other ranks' parents stay zero and are filled in by the all-reduce
-        GSR_HIP(hipMemsetAsync(O.xyz.p, 0, (size_t)P * 12, st)); GSR_HIP(hipMemsetAsync(O.color.p, 0, (size_t)P * 12, st));
-        GSR_HIP(hipMemsetAsync(O.cov6.p, 0, (size_t)P * 24, st)); GSR_HIP(hipMemsetAsync(O.opacity.p, 0, (size_t)P * 4, st));
-        GSR_HIP(hipMemsetAsync(O.weight.p, 0, (size_t)P * 4, st));
-        if (F > 0) GSR_HIP(hipMemsetAsync(O.sh.p, 0, (size_t)P * F * 4, st));
-    }
     if (P > 0) {
         MstepArgs ma;
         memset(&ma, 0, sizeof(ma));
@@ -2317,16 +2332,29 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (F > 0 && n_orph > 0)
         hipLaunchKernelGGL(k_orphans_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
     if (sharded && P > 0) {
-        // exchange 2: the P merged components (every row written by exactly one rank, zero elsewhere, so the
-        // sum is exact); the orphan rows behind them are computed identically on every rank
+        // exchange 2: the merged components.  Every rank packs the rows of ITS parents, ONE all-gather of equal chunks
+        // (ceil(P / world) rows of 14 + F floats) moves them, and every rank scatters every chunk into the output rows
+        // of the owners' slots: P (14 + F) 4 bytes per rank received in all, no floating-point arithmetic in the exchange.
+        const int W = c->shard_world, RW = 14 + F;
+        const int chunk = (P + W - 1) / W + 1;                    // rows per rank (the ranges differ by at most one)
+        const size_t chunk_bytes = (size_t)chunk * RW * 4;
+        GSR_TRY(c->shard_send.reserve(chunk_bytes)); GSR_TRY(c->shard_recv.reserve(chunk_bytes * W));
+        const int own_cnt = own_hi - own_lo;
+        if (own_cnt > 0)
+            hipLaunchKernelGGL((k_shard_rows<true>), dim3(stride_grid((int64_t)own_cnt * RW)), blk, 0, st, own_lo, own_cnt, F, c->plist.as<unsigned>(),
+                               c->order.as<unsigned>(), c->prank_in.as<int>(), c->shard_send.as<float>(), O.xyz.as<float>(), O.color.as<float>(),
+                               O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>());
         GSR_HIP(hipStreamSynchronize(st));
-        int rc = c->shard_allreduce(O.xyz.p, (int64_t)P * 3, c->shard_user);
-        if (rc == 0) rc = c->shard_allreduce(O.color.p, (int64_t)P * 3, c->shard_user);
-        if (rc == 0) rc = c->shard_allreduce(O.cov6.p, (int64_t)P * 6, c->shard_user);
-        if (rc == 0) rc = c->shard_allreduce(O.opacity.p, (int64_t)P, c->shard_user);
-        if (rc == 0) rc = c->shard_allreduce(O.weight.p, (int64_t)P, c->shard_user);
-        if (rc == 0 && F > 0) rc = c->shard_allreduce(O.sh.p, (int64_t)P * F, c->shard_user);
-        if (rc != 0) return fail(GSR_E_INVALID, "gsr_hem_run_level: all-reduce callback failed (outputs)");
+        if (c->shard_allgather(c->shard_send.p, c->shard_recv.p, (int64_t)chunk_bytes, c->shard_user) != 0)
+            return fail(GSR_E_INVALID, "gsr_hem_run_level: all-gather callback failed (merged components)");
+        for (int r = 0; r < W; ++r) {
+            if (r == c->shard_rank) continue;
+            const int lo = (int)((int64_t)P * r / W), hi = (int)((int64_t)P * (r + 1) / W);
+            if (hi > lo)
+                hipLaunchKernelGGL((k_shard_rows<false>), dim3(stride_grid((int64_t)(hi - lo) * RW)), blk, 0, st, lo, hi - lo, F, c->plist.as<unsigned>(),
+                                   c->order.as<unsigned>(), c->prank_in.as<int>(), c->shard_recv.as<float>() + (size_t)r * chunk * RW, O.xyz.as<float>(),
+                                   O.color.as<float>(), O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>());
+        }
     }
     GSR_CHECKPOINT("M-step + orphans");
     GSR_HIP(hipEventRecord(c->ev[4], st));

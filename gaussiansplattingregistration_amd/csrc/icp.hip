@@ -1082,15 +1082,23 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
     block_reduce_store<NACC>(acc, partials);
 }
 
-__global__ __launch_bounds__(1024) void k_icp_step(int nblocks, const double* __restrict__ partials, IcpState* __restrict__ st) {
+// `reduced` == NULL: fold the block partials here (single GPU).  Multi-GPU source split: k_icp_reduce folds them into a
+// device vector, the all-reduce callback sums that vector over the ranks (RCCL, on this stream), and this kernel starts
+// from the reduced vector -- every rank then takes the identical decision and the identical update.
+__global__ __launch_bounds__(1024) void k_icp_step(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced,
+                                                   IcpState* __restrict__ st) {
     __shared__ double s_acc[GSR_ICP_ACC_LEN];
     if (st->done) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;         // 16 wavefronts, 2 accumulators each
-    for (int k = wv; k < GSR_ICP_ACC_LEN; k += 16) {
-        double s = 0.0;
-        for (int b = lane; b < nblocks; b += 64) s += partials[(int64_t)b * GSR_ICP_ACC_LEN + k];
-        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-        if (lane == 0) s_acc[k] = s;
+    if (reduced) {
+        if (threadIdx.x < GSR_ICP_ACC_LEN) s_acc[threadIdx.x] = reduced[threadIdx.x];
+    } else {
+        for (int k = wv; k < GSR_ICP_ACC_LEN; k += 16) {
+            double s = 0.0;
+            for (int b = lane; b < nblocks; b += 64) s += partials[(int64_t)b * GSR_ICP_ACC_LEN + k];
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) s_acc[k] = s;
+        }
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
@@ -1108,6 +1116,21 @@ __global__ __launch_bounds__(1024) void k_icp_step(int nblocks, const double* __
     mat4_mul(update, T, T);
     for (int i = 0; i < 16; ++i) st->T[i] = T[i];
     st->iters += 1;
+}
+
+// rank-local accumulator vector of one iteration (same fixed summation order as k_icp_finalize); zeros once converged, so
+// that the ranks keep calling the collective in step
+__global__ __launch_bounds__(1024) void k_icp_reduce(int nblocks, const double* __restrict__ partials, const IcpState* __restrict__ st,
+                                                     double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const bool done = st->done != 0;
+    for (int k = wv; k < GSR_ICP_ACC_LEN; k += 16) {
+        double s = 0.0;
+        if (!done)
+            for (int b = lane; b < nblocks; b += 64) s += partials[(int64_t)b * GSR_ICP_ACC_LEN + k];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) out[k] = s;
+    }
 }
 
 }  // namespace gsr
@@ -1137,6 +1160,8 @@ struct gsr_icp_ctx {
     DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
     gsr_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
+    gsr_allreduce_dev64_fn allreduce_dev = nullptr;      // device-resident loop with a stream-ordered collective per iteration
+    void* allreduce_dev_user = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     float ms_build = 0, ms_iter = 0;
     int n_iter_kernels = 0;
@@ -1337,13 +1362,16 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
 
 int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t on_device) {
     if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_source: NULL context");
-    if (n <= 0 || !xyz) return fail(GSR_E_PRECONDITION, "gsr_icp_set_source: empty source cloud");
+    if (n < 0 || (n > 0 && !xyz)) return fail(GSR_E_PRECONDITION, "gsr_icp_set_source: empty source cloud");
     if (n >= ((int64_t)1 << 31) - 1) return fail(GSR_E_INVALID, "gsr_icp_set_source: n too large");
     GSR_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    GSR_TRY(c->src.reserve((size_t)n * 12));
+    GSR_TRY(c->src.reserve((size_t)(n > 0 ? n : 1) * 12));
     c->src_sorted = false;
-    if (c->have_target) {
+    if (n == 0) {
+        // an empty shard of a multi-GPU source split (fewer points than ranks): it contributes zero sums and still joins
+        // every collective; a registration without an all-reduce refuses it (gsr_icp_register)
+    } else if (c->have_target) {
         // sort the source by the TARGET grid's cell (rigid motions keep neighbours neighbours): lanes of a
         // wave then walk the same target cells, and the per-point ring searches share cache lines
         GSR_TRY(c->src_raw.reserve((size_t)n * 12));
@@ -1365,7 +1393,7 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t 
     }
     GSR_HIP(hipStreamSynchronize(st));
     c->ns = n; c->have_source = true; c->have_scov = false; c->have_scol = false;
-    if (!c->allreduce) c->ns_global = n;
+    if (!c->allreduce && !c->allreduce_dev) c->ns_global = n;
     return GSR_OK;
 }
 
@@ -1459,9 +1487,17 @@ int32_t gsr_icp_get_color_gradient(gsr_icp_ctx* c, double* out) {
     return GSR_OK;
 }
 
+int32_t gsr_icp_set_allreduce_dev(gsr_icp_ctx* c, gsr_allreduce_dev64_fn fn, void* user, int64_t n_source_global) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_allreduce_dev: NULL context");
+    c->allreduce_dev = fn; c->allreduce_dev_user = user;
+    if (fn) { c->allreduce = nullptr; c->allreduce_user = nullptr; }
+    c->ns_global = fn ? n_source_global : c->ns;
+    return GSR_OK;
+}
 int32_t gsr_icp_set_allreduce(gsr_icp_ctx* c, gsr_allreduce_fn fn, void* user, int64_t n_source_global) {
     if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_allreduce: NULL context");
     c->allreduce = fn; c->allreduce_user = user;
+    if (fn) { c->allreduce_dev = nullptr; c->allreduce_dev_user = nullptr; }
     c->ns_global = fn ? n_source_global : c->ns;
     return GSR_OK;
 }
@@ -1477,8 +1513,11 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
     if (!c || !init_T || !out_T) return fail(GSR_E_INVALID, "gsr_icp_register: NULL argument");
     GSR_HIP(hipSetDevice(c->device));
     c->ms_iter = 0; c->n_iter_kernels = 0;
-    if (!c->allreduce && c->device_loop) {
-        // device-resident loop (single rank): no per-iteration host round trip
+    if (!c->allreduce && !c->allreduce_dev && c->have_source && c->ns == 0)
+        return fail(GSR_E_PRECONDITION, "gsr_icp_register: empty source cloud");
+    if (!c->allreduce && (c->device_loop || c->allreduce_dev)) {
+        // device-resident loop: no per-iteration host round trip.  With a device all-reduce (multi-GPU source split) the
+        // only addition per iteration is one stream-ordered collective on 32 doubles between the reduction and the solve.
         if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
         if (kind < GSR_ICP_POINT_TO_POINT || kind > GSR_ICP_COLORED) return fail(GSR_E_INVALID, "icp: unknown estimation kind %d", kind);
         if (kind == GSR_ICP_POINT_TO_PLANE && !c->have_normals)
@@ -1492,7 +1531,7 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         memset(&hs, 0, sizeof(hs));
         memcpy(hs.T, init_T, sizeof(hs.T));
         hs.ctr[0] = c->grid.cx; hs.ctr[1] = c->grid.cy; hs.ctr[2] = c->grid.cz;
-        hs.nsg = (double)c->ns; hs.rel_fit = rel_fitness; hs.rel_rmse = rel_rmse;
+        hs.nsg = (double)(c->allreduce_dev ? c->ns_global : c->ns); hs.rel_fit = rel_fitness; hs.rel_rmse = rel_rmse;
         hs.max_iter = max_iter < 0 ? 0 : max_iter; hs.kind = kind;
         GSR_TRY(c->state.reserve(sizeof(IcpState)));
         GSR_HIP(hipMemcpyAsync(c->state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
@@ -1500,7 +1539,8 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         if ((int64_t)nb * 256 > c->ns) nb = (int)((c->ns + 255) / 256);
         if (nb < 1) nb = 1;
         GSR_TRY(c->partials.reserve((size_t)nb * GSR_ICP_ACC_LEN * 8));
-        GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
+        GSR_TRY(c->nn_j.reserve((size_t)(c->ns > 0 ? c->ns : 1) * 4));
+        GSR_TRY(c->acc_dev.reserve(GSR_ICP_ACC_LEN * 8));
         GSR_HIP(hipMemsetAsync(c->partials.p, 0, (size_t)nb * GSR_ICP_ACC_LEN * 8, st));
         const double mc2 = c->max_corr * c->max_corr;
         const ColorArgs cargs = {c->Ti.as<double>(), c->Tg.as<double>(), c->Si.as<double>(), sqrt(c->lambda_geometric), sqrt(1.0 - c->lambda_geometric)};
@@ -1533,7 +1573,14 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
                     hipLaunchKernelGGL(k_icp_accumulate_dev<2>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
                                        c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tc.as<double>(), c->Sc.as<double>(), cargs, mc2, loss, k,
                                        c->partials.as<double>());
-                hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>());
+                if (c->allreduce_dev) {
+                    hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>(), c->acc_dev.as<double>());
+                    const int32_t rc = c->allreduce_dev(c->acc_dev.p, GSR_ICP_ACC_LEN, c->allreduce_dev_user);
+                    if (rc != 0) return fail(GSR_E_INVALID, "icp: device all-reduce callback returned %d", rc);
+                    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>(), c->state.as<IcpState>());
+                } else {
+                    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), (const double*)nullptr, c->state.as<IcpState>());
+                }
             }
             issued += chunk;
             GSR_HIP(hipMemcpyAsync(&hs, c->state.p, sizeof(hs), hipMemcpyDeviceToHost, st));

@@ -84,23 +84,24 @@ class HemMixture:
         m = {"glibc": _lib.GSR_RNG_GLIBC, "hash": _lib.GSR_RNG_HASH}[mode]
         _lib.check(self._L.gsr_hem_set_rng(self._h, m, seed, skip), "gsr_hem_set_rng")
 
-    def set_shard(self, rank, world, allreduce=None):
+    def set_shard(self, rank, world, allreduce=None, allgather=None):
         """Work-sharded levels: this context evaluates the parents of slab ``rank`` of ``world``.
-        ``allreduce(tensor)`` must sum a float32 CUDA tensor over the ranks in place (e.g.
-        ``torch.distributed.all_reduce``); see ``parallel.hem_sharded``."""
-        if allreduce is None or world <= 1:
+        ``allreduce(tensor)`` must sum a float32 CUDA tensor over the ranks in place (``torch.distributed.all_reduce``);
+        ``allgather(send, recv)`` must fill the uint8 CUDA tensor ``recv`` (world x len(send)) with every rank's ``send``
+        (``torch.distributed.all_gather_into_tensor``); see ``parallel.hem_sharded``."""
+        if allreduce is None or allgather is None or world <= 1:
             self._shard_cb = None
-            _lib.check(self._L.gsr_hem_set_shard(self._h, 0, 1, _lib.ALLREDUCE_DEV_FN(), None), "gsr_hem_set_shard")
+            _lib.check(self._L.gsr_hem_set_shard(self._h, 0, 1, _lib.ALLREDUCE_DEV_FN(), _lib.ALLGATHER_DEV_FN(), None), "gsr_hem_set_shard")
             return
         dev = self.device
 
-        class _Ptr:       # expose the raw device buffer to torch without a copy
-            def __init__(self, ptr, count):
-                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f4", "data": (ptr, False), "version": 3}
+        class _Ptr:       # expose a raw device buffer to torch without a copy
+            def __init__(self, ptr, count, typestr):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": typestr, "data": (ptr, False), "version": 3}
 
-        def _tramp(ptr, count, _user):
+        def _reduce(ptr, count, _user):
             try:
-                t = torch.as_tensor(_Ptr(int(ptr), int(count)), device=torch.device("cuda", dev))
+                t = torch.as_tensor(_Ptr(int(ptr), int(count), "<f4"), device=torch.device("cuda", dev))
                 allreduce(t)
                 torch.cuda.synchronize(dev)
                 return 0
@@ -109,8 +110,20 @@ class HemMixture:
                 traceback.print_exc()
                 return 1
 
-        self._shard_cb = _lib.ALLREDUCE_DEV_FN(_tramp)
-        _lib.check(self._L.gsr_hem_set_shard(self._h, int(rank), int(world), self._shard_cb, None), "gsr_hem_set_shard")
+        def _gather(send, recv, nbytes, _user):
+            try:
+                s = torch.as_tensor(_Ptr(int(send), int(nbytes), "|u1"), device=torch.device("cuda", dev))
+                r = torch.as_tensor(_Ptr(int(recv), int(nbytes) * int(world), "|u1"), device=torch.device("cuda", dev))
+                allgather(s, r)
+                torch.cuda.synchronize(dev)
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._shard_cb = (_lib.ALLREDUCE_DEV_FN(_reduce), _lib.ALLGATHER_DEV_FN(_gather))
+        _lib.check(self._L.gsr_hem_set_shard(self._h, int(rank), int(world), self._shard_cb[0], self._shard_cb[1], None), "gsr_hem_set_shard")
 
     # -- level 0 -----------------------------------------------------------------------------------
     def set_level0(self, xyz, colors, opacities, covariance, features, borrow=False):

@@ -104,6 +104,10 @@ class IcpContext:
 
     def set_source(self, xyz):
         n = int(xyz.shape[0])
+        if n == 0:                         # an empty shard of a multi-GPU source split
+            _lib.check(self._L.gsr_icp_set_source(self._h, None, 0, 0), "gsr_icp_set_source")
+            self.n_source = 0
+            return
         px, kx, dx = _prep(xyz, (n, 3), np.float32, self.device)
         if dx:
             self._sync_torch()
@@ -180,6 +184,32 @@ class IcpContext:
 
         self._cb = _lib.ALLREDUCE_FN(_tramp)
         _lib.check(self._L.gsr_icp_set_allreduce(self._h, self._cb, None, int(n_source_global)), "gsr_icp_set_allreduce")
+
+    def set_allreduce_device(self, fn, n_source_global):
+        """``fn(tensor float64[32] on this device) -> None`` must sum the vector over all ranks in place, ordered on the
+        current stream (``torch.distributed.all_reduce`` is).  The iteration loop stays device resident; every rank
+        solves from the identical reduced vector.  ``fn = None`` restores the single-GPU loop."""
+        if fn is None:
+            self._cb_dev = None
+            _lib.check(self._L.gsr_icp_set_allreduce_dev(self._h, _lib.ALLREDUCE_DEV_FN(), None, 0), "gsr_icp_set_allreduce_dev")
+            return
+        dev = self.device
+
+        class _Ptr:
+            def __init__(self, ptr, count):
+                self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+        def _tramp(ptr, count, _user):
+            try:
+                fn(torch.as_tensor(_Ptr(int(ptr), int(count)), device=torch.device("cuda", dev)))
+                return 0
+            except Exception:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        self._cb_dev = _lib.ALLREDUCE_DEV_FN(_tramp)
+        _lib.check(self._L.gsr_icp_set_allreduce_dev(self._h, self._cb_dev, None, int(n_source_global)), "gsr_icp_set_allreduce_dev")
 
     def accumulate(self, T, kind=0, loss=0, k=0.0):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)

@@ -5,15 +5,16 @@ ROCm, ``gloo`` on CPU test boxes).  The reference has no distributed code at all
 * **Two clouds, HEM** -- the clouds are independent: cloud ``A`` on rank 0, cloud ``B`` on rank 1, no
   data-path collective (``assign_clouds``).
 * **ICP, any size** -- the target (and its grid) is replicated on every rank, the source points are
-  split evenly (``shard_range``); each rank's fused kernel produces a rank-local accumulator vector
-  (32 float64) and ONE all-reduce(sum) of that vector per iteration is the only exchange
-  (``make_allreduce``).  It is latency-bound (256 bytes), so xGMI link bandwidth is irrelevant;
-  every rank then solves the same 3x3 SVD / 6x6 system and stops on the same reduced fitness/RMSE.
+  split evenly (``shard_range``); each rank's kernels produce a rank-local accumulator vector
+  (32 float64 on the device) and ONE all-reduce(sum) of that device vector per iteration is the only exchange
+  (``make_allreduce_device``: RCCL on the tensor where it lies, stream ordered, no host bounce).  It is latency-bound
+  (256 bytes), so xGMI link bandwidth is irrelevant; every rank then solves the same 3x3 SVD / 6x6 system ON THE DEVICE
+  and stops on the same reduced fitness/RMSE -- the iteration loop stays device resident.
 * **One large cloud, HEM** -- work-sharded levels (``hem_sharded``): the level data is replicated, the
   cell-sorted parents are split into ``world`` contiguous runs (spatial slabs), and a level makes two
-  all-reduces: the per-child sums of wL (float32[n]) and the merged components (each row written by one
-  rank, zeros elsewhere, so the sum is exact).  Flags, orphans and the validity erase are computed
-  identically on every rank.
+  exchanges: an all-reduce of the per-child sums of wL (float32[n]) and ONE all-gather of the merged components
+  (packed rows of 14 + F floats, scattered into the owners' slots on arrival: no arithmetic in the exchange).  Flags,
+  orphans and the validity erase are computed identically on every rank.
 """
 from __future__ import annotations
 
@@ -28,7 +29,8 @@ except Exception:  # pragma: no cover
     torch = None
     dist = None
 
-__all__ = ["init_distributed", "shard_range", "make_allreduce", "assign_clouds", "registration_icp_sharded", "hem_sharded"]
+__all__ = ["init_distributed", "shard_range", "make_allreduce", "make_allreduce_device", "make_allgather_device", "assign_clouds",
+           "registration_icp_sharded", "hem_sharded"]
 
 
 def init_distributed(backend: str | None = None):
@@ -55,7 +57,8 @@ def shard_range(n: int, rank: int, world: int):
 
 
 def make_allreduce(group=None, device=None):
-    """-> ``fn(buf: np.ndarray[float64])`` that replaces ``buf`` by its sum over the group, in place."""
+    """-> ``fn(buf: np.ndarray[float64])`` that replaces ``buf`` by its sum over the group, in place (host buffers: the
+    host-driven ICP loop, kept for callers without device tensors)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return None
     use_cuda = dist.get_backend(group) == "nccl"
@@ -70,42 +73,78 @@ def make_allreduce(group=None, device=None):
     return fn
 
 
+def make_allreduce_device(group=None):
+    """-> ``fn(t: CUDA tensor)`` that replaces ``t`` by its sum over the group, in place.  With the ``nccl`` (= RCCL) backend
+    the collective runs on the tensor where it lies, ordered on the current stream -- no host round trip.  With ``gloo``
+    (CPU test boxes, several ranks sharing one GPU) the tensor is bounced through host memory."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return None
+    if dist.get_backend(group) == "nccl":
+        def fn(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    else:
+        def fn(t):
+            h = t.cpu()
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=group)
+            t.copy_(h)
+    return fn
+
+
+def make_allgather_device(group=None):
+    """-> ``fn(send, recv)``: ``recv`` (world x len(send), CUDA uint8) receives every rank's ``send``."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return None
+    if dist.get_backend(group) == "nccl":
+        def fn(send, recv):
+            dist.all_gather_into_tensor(recv, send, group=group)
+    else:
+        def fn(send, recv):
+            w = dist.get_world_size(group)
+            parts = [torch.empty(send.numel(), dtype=send.dtype) for _ in range(w)]
+            dist.all_gather(parts, send.cpu(), group=group)
+            recv.copy_(torch.cat(parts))
+    return fn
+
+
 def assign_clouds(n_clouds: int, rank: int, world: int):
     """Indices of the independent clouds this rank downsamples (round-robin)."""
     return [i for i in range(n_clouds) if i % world == rank]
 
 
 def registration_icp_sharded(source, target, max_correspondence_distance, init, estimation_method, criteria,
-                             rank: int, world: int, device=None, group=None):
+                             rank: int, world: int, device=None, group=None, ctx=None):
     """``registration_icp`` with the source split over the ranks of ``group`` and the target replicated.
 
-    ``source`` / ``target`` are the FULL clouds on every rank (``PointCloud`` records); each rank keeps
-    its ``shard_range`` of the source.  Returns the same ``RegistrationResult`` on every rank."""
+    ``source`` / ``target`` are the FULL clouds on every rank (``PointCloud`` records); each rank keeps its
+    ``shard_range`` of the source points (and of their covariances / colours).  The only exchange is one all-reduce of
+    32 float64 per iteration, on the device; every rank solves from the reduced vector.  A rank whose shard is empty
+    (fewer points than ranks) contributes zeros.  Returns the same ``RegistrationResult`` on every rank."""
     from .models.point_cloud import PointCloud
     from .utils.local_registration_util import registration_icp
 
     n = len(source)
     lo, hi = shard_range(n, rank, world)
-    local = PointCloud(xyz32=source.xyz32[lo:hi])
-    ar = make_allreduce(group, None if device is None else torch.device("cuda", device))
+    cut = lambda a: None if a is None else a[lo:hi]
+    local = PointCloud(xyz32=source.xyz32[lo:hi], colors=cut(source.colors), cov6=cut(source.cov6))
+    ar = make_allreduce_device(group)
     return registration_icp(local, target, max_correspondence_distance, init, estimation_method, criteria,
-                            device=device, allreduce=ar, n_source_global=n)
+                            device=device, allreduce_device=ar, n_source_global=n, ctx=ctx)
 
 
-def hem_sharded(cloud: dict, cluster_level: int, rank: int, world: int, device=None, group=None, allreduce=None,
+def hem_sharded(cloud: dict, cluster_level: int, rank: int, world: int, device=None, group=None, allreduce=None, allgather=None,
                 as_torch=False, **hem_params):
     """``MixtureCreator.CreateMixture`` of ONE large cloud with the work of every level split over ``world``
     GPUs (BASELINE config 5).  Every rank passes the same full ``cloud`` (replicated data); rank r evaluates
-    the r-th spatial slab of parents; two RCCL all-reduces per level (per-child sums, merged components).
-    Every rank returns the identical list of levels.  ``allreduce(tensor)`` defaults to
-    ``torch.distributed.all_reduce`` on ``group``."""
+    the r-th spatial slab of parents; two exchanges per level: an all-reduce of the per-child sums (float32[n]) and one
+    all-gather of the merged components (packed rows).  Every rank returns the identical list of levels."""
     from . import hem as _hem
     if allreduce is None and world > 1:
-        def allreduce(t):
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        allreduce = make_allreduce_device(group)
+    if allgather is None and world > 1:
+        allgather = make_allgather_device(group)
     dev = device if device is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
     with _hem.HemMixture(device=dev, **hem_params) as m:
-        m.set_shard(rank, world, allreduce)
+        m.set_shard(rank, world, allreduce, allgather)
         m.set_level0(cloud["xyz"], cloud["color"], cloud["opacity"], cloud["cov6"], cloud["sh"])
         levels, stats = [], []
         for _ in range(int(cluster_level)):

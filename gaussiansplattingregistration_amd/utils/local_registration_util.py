@@ -122,7 +122,7 @@ def get_rejection_loss(rejection_type, k_value, registration_type):
 
 
 def registration_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, device=None,
-                     allreduce=None, n_source_global=None, ctx=None):
+                     allreduce=None, n_source_global=None, ctx=None, allreduce_device=None):
     """``o3d.pipelines.registration.registration_icp`` on ``PointCloud`` records (see ``point_cloud.py``)."""
     if not (max_correspondence_distance > 0.0):
         raise RuntimeError("[Open3D Error] Invalid max_correspondence_distance.")
@@ -151,8 +151,12 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
         if estimation_method.kind == _icp.KIND_COLORED:
             ctx.set_target_color(target.colors)
             ctx.set_source_color(source.colors)
-        if allreduce is not None:
-            ctx.set_allreduce(allreduce, n_source_global)
+        # always (re)install the callbacks: a reused context must not keep a stale one from an earlier sharded call
+        if allreduce_device is not None:
+            ctx.set_allreduce_device(allreduce_device, n_source_global)
+        else:
+            ctx.set_allreduce_device(None, 0)
+            ctx.set_allreduce(allreduce, n_source_global if allreduce is not None else 0)
         r = ctx.register(np.asarray(init, dtype=np.float64), estimation_method.kind, loss.code, loss.k,
                          criteria.relative_fitness, criteria.relative_rmse, criteria.max_iteration)
         res = _icp.RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], r["iterations"])

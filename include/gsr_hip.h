@@ -88,12 +88,17 @@ int32_t gsr_hem_set_state(gsr_hem_ctx* ctx, const uint8_t* parent_mask, const fl
 /* Work-sharded levels for ONE large cloud on several GPUs (the reference has no such
  * thing).  Every rank holds the full level (replicated data, deterministic replicated grid); rank r of
  * `world` evaluates the contiguous run [P r/world, P (r+1)/world) of the cell-sorted parents -- a spatial
- * slab -- and the level makes two exchanges through `fn`: the per-child sums of wL (float32[n]) and the
- * P merged components (every row written by exactly one rank, zero elsewhere).  `fn(dev_ptr, count,
- * user)` must replace the float32 DEVICE buffer by its element-wise sum over the ranks (RCCL all-reduce in
- * the host language) and return 0.  world == 1 / fn == NULL restores the single-GPU level. */
+ * slab -- and the level makes two exchanges:
+ *   allreduce(dev_f32, count, user)   the per-child sums of wL: replace the float32 DEVICE buffer (n values) by its
+ *                                     element-wise sum over the ranks (RCCL all-reduce in the host language);
+ *   allgather(send, recv, bytes, user) the merged components: every rank contributes `bytes` bytes at `send` (device),
+ *                                     `recv` (device, world * bytes) receives rank r's contribution at offset r * bytes.
+ * Both must have completed (or be ordered on the context's stream) when they return 0.
+ * world == 1 / NULL callbacks restore the single-GPU level. */
 typedef int32_t (*gsr_allreduce_dev_fn)(void* dev_f32, int64_t count, void* user);
-int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_allreduce_dev_fn fn, void* user);
+typedef int32_t (*gsr_allgather_dev_fn)(const void* dev_send, void* dev_recv, int64_t bytes_per_rank, void* user);
+int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_allreduce_dev_fn allreduce,
+                          gsr_allgather_dev_fn allgather, void* user);
 
 /* One clustering level on the current level (Mixture::createClusterLevel, mixture.cpp:66-285).
  * n_out = components of the new level (after the validity erase); n_dropped = components erased by
@@ -164,6 +169,13 @@ int32_t gsr_icp_get_color_gradient(gsr_icp_ctx* ctx, double* out);
  * host language).  NULL = single rank.  n_source_global = source points over all ranks. */
 typedef int32_t (*gsr_allreduce_fn)(double* buf, int32_t len, void* user);
 int32_t gsr_icp_set_allreduce(gsr_icp_ctx* ctx, gsr_allreduce_fn fn, void* user, int64_t n_source_global);
+/* The same with a DEVICE buffer: `fn(dev_f64, count, user)` must replace the float64 device vector by its sum over the
+ * ranks, ordered on the context's stream (an RCCL all-reduce enqueued on that stream, or a synchronous one).  The
+ * iteration loop then stays device resident: per iteration one reduction kernel, the collective on 32 doubles, one
+ * kernel that tests convergence and solves on EVERY rank from the identical reduced vector.  A rank may hold an empty
+ * shard (gsr_icp_set_source with n = 0).  Installing one kind of callback removes the other; NULL restores single-GPU. */
+typedef int32_t (*gsr_allreduce_dev64_fn)(void* dev_f64, int64_t count, void* user);
+int32_t gsr_icp_set_allreduce_dev(gsr_icp_ctx* ctx, gsr_allreduce_dev64_fn fn, void* user, int64_t n_source_global);
 
 /* One correspondence evaluation + accumulator reduction at transform T (row-major 4x4 float64):
  * acc[0]=count, acc[1]=sum d^2, then for point-to-point acc[2..4]=sum p, [5..7]=sum q, [8..16]=sum p q^T

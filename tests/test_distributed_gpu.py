@@ -1,0 +1,111 @@
+"""The N > 1 paths with the REAL kernels: two processes (torch.distributed, gloo) share the one GPU of the test box.
+
+* ``parallel.registration_icp_sharded`` -- source split, device all-reduce of the 32-double accumulator inside the
+  device-resident iteration loop, every rank solving on the device -- against the single-process registration.
+* ``parallel.hem_sharded`` -- parents split into spatial slabs, all-reduce of the per-child sums, ONE all-gather of the
+  merged components -- against the single-context mixture.
+(The rank-local arithmetic is the same on RCCL; there the collectives run on the device buffers without the host bounce
+gloo needs.)"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, q, what):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+    from gaussiansplattingregistration_amd import parallel, synth
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+    from gaussiansplattingregistration_amd.utils import local_registration_util as lru
+    parallel.init_distributed("gloo")
+    torch.cuda.set_device(0)
+    out = {}
+    if what == "icp":
+        src, tgt, _ = synth.make_pair(60000, seed=3, sh_degree=0)
+        s = PointCloud(xyz32=torch.from_numpy(src["xyz"]).cuda(), cov6=torch.from_numpy(src["cov6"]).cuda())
+        t = PointCloud(xyz32=torch.from_numpy(tgt["xyz"]).cuda(), cov6=torch.from_numpy(tgt["cov6"]).cuda()).estimate_normals()
+        crit = lru.get_convergence_criteria(1e-7, 1e-7, 25)
+        for name, kind in (("p2p", lru.LocalRegistrationType.ICP_Point_To_Point), ("plane", lru.LocalRegistrationType.ICP_Point_To_Plane),
+                           ("gicp", lru.LocalRegistrationType.ICP_General)):
+            est = lru.get_estimation(kind, lru.RobustLoss(0))
+            r = parallel.registration_icp_sharded(s, t, 0.25, np.eye(4), est, crit, rank, world, device=0)
+            out[name] = (r.transformation, r.fitness, r.inlier_rmse, r.iterations)
+        # more ranks than points on one side: rank 1 holds an empty shard
+        tiny = PointCloud(xyz32=s.xyz32[:1])
+        r = parallel.registration_icp_sharded(tiny, t, 0.25, np.eye(4), lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Point, None),
+                                              lru.get_convergence_criteria(1e-7, 1e-7, 3), rank, world, device=0)
+        out["tiny"] = (r.transformation, r.fitness, r.inlier_rmse, r.iterations)
+    else:
+        c = synth.make_cloud(40000, seed=51, sh_degree=1)
+        levels, st = parallel.hem_sharded(c, 2, rank, world, device=0)
+        out["levels"] = levels
+        out["pairs"] = [s["pairs"] for s in st]
+        out["parents"] = [s["parents"] for s in st]
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(what, world=2):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + (7 if what == "icp" else 13)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, what)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    res.sort(key=lambda x: x[0])
+    return [r[1] for r in res]
+
+
+def test_two_process_sharded_icp_equals_single_process():
+    from gaussiansplattingregistration_amd import synth
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+    from gaussiansplattingregistration_amd.utils import local_registration_util as lru
+    res = _run("icp")
+    src, tgt, T_gt = synth.make_pair(60000, seed=3, sh_degree=0)
+    s = PointCloud(xyz32=src["xyz"], cov6=src["cov6"])
+    t = PointCloud(xyz32=tgt["xyz"], cov6=tgt["cov6"]).estimate_normals()
+    crit = lru.get_convergence_criteria(1e-7, 1e-7, 25)
+    for name, kind in (("p2p", lru.LocalRegistrationType.ICP_Point_To_Point), ("plane", lru.LocalRegistrationType.ICP_Point_To_Plane),
+                       ("gicp", lru.LocalRegistrationType.ICP_General)):
+        want = lru.registration_icp(s, t, 0.25, np.eye(4), lru.get_estimation(kind, lru.RobustLoss(0)), crit)
+        for r in range(2):
+            T, fit, rmse, it = res[r][name]
+            assert np.linalg.norm(T - want.transformation) < 1e-9, (name, r)
+            assert it == want.iterations and abs(fit - want.fitness) < 1e-12 and abs(rmse - want.inlier_rmse) < 1e-9
+        assert np.array_equal(res[0][name][0], res[1][name][0])                  # every rank holds the identical transform
+        assert np.linalg.norm(res[0][name][0] - T_gt) < 5e-3
+    tiny = PointCloud(xyz32=src["xyz"][:1])
+    want = lru.registration_icp(tiny, t, 0.25, np.eye(4), lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Point, None),
+                                lru.get_convergence_criteria(1e-7, 1e-7, 3))
+    for r in range(2):
+        assert np.allclose(res[r]["tiny"][0], want.transformation, atol=1e-12) and res[r]["tiny"][1] == want.fitness
+
+
+def test_two_process_sharded_hem_equals_single_context():
+    from gaussiansplattingregistration_amd import hem, synth
+    res = _run("hem")
+    c = synth.make_cloud(40000, seed=51, sh_degree=1)
+    want, wst = hem.create_mixture(c, 2)
+    for r in range(2):
+        assert res[r]["parents"][0] == wst[0]["parents"] and res[r]["pairs"][0] < wst[0]["pairs"]
+        for k in range(2):
+            assert res[r]["levels"][k]["xyz"].shape == want[k]["xyz"].shape
+            for f in ("xyz", "color", "cov6", "opacity", "sh"):
+                a, b = res[r]["levels"][k][f].astype(np.float64), want[k][f].astype(np.float64)
+                assert np.abs(a - b).max() / (np.abs(b).max() + 1e-30) < 1e-5, (r, k, f)
+                assert np.array_equal(res[r]["levels"][k][f], res[0]["levels"][k][f])        # identical on every rank
+    assert res[0]["pairs"][0] + res[1]["pairs"][0] == wst[0]["pairs"]

@@ -343,8 +343,9 @@ def test_sh_wider_than_a_wavefront(oracle):
 
 
 def test_work_sharded_level_equals_single_gpu():
-    """parallel.hem_sharded with 3 simulated ranks (threads sharing one GPU, an in-process all-reduce standing in
-    for RCCL) against the single-context result: equal counts, components within 1e-5."""
+    """parallel.hem_sharded with 3 simulated ranks (threads sharing one GPU, an in-process all-reduce / all-gather standing
+    in for RCCL) against the single-context result: equal counts, components within 1e-5.  (The multi-PROCESS version over
+    torch.distributed is tests/test_distributed_gpu.py.)"""
     import threading
     from gaussiansplattingregistration_amd import hem, parallel, synth
     c = synth.make_cloud(40000, seed=51, sh_degree=1)
@@ -367,12 +368,21 @@ def test_work_sharded_level_equals_single_gpu():
                 t.copy_(total)
             return fn
 
+        def make_gather(self, rank):
+            def fn(send, recv):
+                self.parts[rank] = send.clone()
+                self.bar.wait()
+                allp = torch.cat([self.parts[r] for r in range(W)])
+                self.bar.wait()
+                recv.copy_(allp)
+            return fn
+
     far = FakeAllReduce()
     out, errs = [None] * W, []
 
     def run(rank):
         try:
-            out[rank] = parallel.hem_sharded(c, 2, rank, W, device=0, allreduce=far.make(rank))
+            out[rank] = parallel.hem_sharded(c, 2, rank, W, device=0, allreduce=far.make(rank), allgather=far.make_gather(rank))
         except Exception as e:      # pragma: no cover
             errs.append(e)
             far.bar.abort()
