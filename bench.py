@@ -1,25 +1,33 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: HEM mixture levels + coarse-to-fine ICP on a synthetic splat pair.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--n SPLATS] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--splats n] [--mode replicas|c4|c5] [--no-cpu-baseline]
 
 One STEP = one pass of the whole hot path over one pair of clouds that is already resident in HBM:
   3 HEM levels on the source cloud and on the target cloud (rho=3, delta=3, kappa=2.5, tau=1 --
   src/params/merge_parameters.py:5-10), covariance normals for every level, then the 4-entry
   coarse-to-fine point-to-plane ICP (iter_values [50,30,20,10], max_corr [0.5,0.3,0.2,0.1]).
-Workload at N=1 = BASELINE.json configs[2] (the configuration the metric is quoted on): 2 x 5M splats,
-SH degree 3.  With --gpus N > 1 (launched by torch.distributed.run, one rank per GPU) every rank
-runs its own pair -- the path shards by independent clouds with no data-path collective (weak
-scaling); timing is barrier-bracketed and the MAX over ranks is taken.
+Workload at N=1 = BASELINE.json configs[2] (the configuration the metric is quoted on): 2 x 5M splats, SH degree 3.
 
-Prints ONE JSON line on rank 0.  `value` = level-input Gaussians per second through the HEM levels
-(whole job); `icp_iters_per_sec` rides along; `roofline` is for the dominant kernel of the step,
-`cpu_baseline` is the reference's own compiled extension (oracle/_ref) -- or the oracle port when
-that is absent -- timed on this box's host cores on a bounded sample.
+Modes (one process per GPU, launched by torch.distributed.run for N > 1):
+  replicas (default, what the driver measures)  every rank runs its own pair -- the path shards by independent clouds with
+            no data-path collective (weak scaling); timing is barrier-bracketed and the MAX over ranks is taken.
+  c4        BASELINE configs[3]: cloud A's HEM on rank 0, cloud B's on rank 1, the level lists exchanged once
+            (broadcast), then ICP with the source split over ALL ranks and one RCCL all-reduce of the 32-double
+            accumulator per iteration (strong scaling: the work is fixed).
+  c5        BASELINE configs[4]: ONE large source cloud (--splats, 40 M on 8 GPUs) against a target of --target-splats
+            (5 M): work-sharded HEM levels (all-reduce of the per-child sums + one all-gather of the merged components per
+            level), ICP source split over all ranks (strong scaling).
+
+Prints ONE JSON line on rank 0.  `value` = level-input Gaussians per second through the HEM levels (whole job);
+`icp_iters_per_sec` rides along; `roofline` is for the dominant kernel of the step (algorithmic bytes of SURVEY.md 8(d));
+`cpu_baseline` is the reference's own compiled extension (oracle/_ref) -- or the oracle port when that is absent --
+timed on this box's host cores on a bounded ladder of sizes.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import subprocess
@@ -37,7 +45,10 @@ LEVELS = 3
 ITER_VALUES = [50, 30, 20, 10]
 MAX_CORR = [0.5, 0.3, 0.2, 0.1]
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
-B_GEOM = 57                    # bytes/component the selection kernel must read once: xyz 12 color 12 cov 24 opacity 4 weight 4 flag 1
+# measured on MI355X (profiles/r02_valu_issue_microbench.txt): cycles a SIMD needs per wave64 VALU instruction with >= 2 waves resident
+VALU_CYCLES = {"full_rate (v_fma/mul/add/and/or with VGPR or constant operands)": 2.2,
+               "half_rate (any SGPR operand, v_cmp, v_cndmask, v_bcnt/mbcnt, shifts, cvt, DPP, pk_*, f64)": 4.1,
+               "transcendental": 8.1, "one wave alone": 4.9}
 
 
 def bytes_level(n_in, n_out, F):
@@ -46,127 +57,248 @@ def bytes_level(n_in, n_out, F):
     return n_in * (B + 16) + n_out * B
 
 
-def hot_path_step(ctxs, lru, PointCloud, src, tgt, device, sync):
-    """One pass over one pair.  `ctxs` holds the long-lived library contexts (their workspaces are
-    reused from step to step: no allocation in steady state)."""
-    out = {"hem_gaussians": 0, "hem_s": 0.0, "icp_s": 0.0, "icp_iters": 0, "levels": [], "kern": []}
+def kernel_build_id():
+    """Identifies the kernel sources a PMC summary belongs to (profiles/*_pmc.json carry it)."""
+    h = hashlib.sha256()
+    for f in ("hem.hip", "icp.hip", "gsr_math.h"):
+        h.update(open(os.path.join(ROOT, "gaussiansplattingregistration_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def pmc_summary(kernel_prefix):
+    """Counters of the dominant kernel from the newest committed PMC summary (profiles/*_pmc.json: separate
+    `rocprofv3 --pmc` passes of scripts/prof_hem.py 5000000 1, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950) -- only when that summary was taken with THESE kernel sources; otherwise (None, reason)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename)
+    build = kernel_build_id()
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except Exception:
+            continue
+        if d.get("kernel_build") != build:
+            continue
+        for k, v in d.items():
+            if isinstance(v, dict) and k.startswith(kernel_prefix):
+                return dict(v, source=os.path.basename(f)), None
+    return None, "no profiles/*_pmc.json taken with the current kernel sources (kernel_build %s)" % build
+
+
+def hem_levels(m, cloud, borrow=True):
+    """3 HEM levels of one cloud on context m; returns (level list for ICP, per-level stats)."""
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+    lv = [PointCloud(xyz32=cloud["xyz"], cov6=cloud["cov6"])]
+    m.set_level0(cloud["xyz"], cloud["color"], cloud["opacity"], cloud["cov6"], cloud["sh"], borrow=borrow)     # resident in HBM: read in place
+    stats = []
+    for _ in range(LEVELS):
+        m.run_level()
+        stats.append(m.stats())
+        d = m.get_level(as_torch=True)
+        lv.append(PointCloud(xyz32=d["xyz"], cov6=d["cov6"]))
+    return lv, stats
+
+
+def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None):
+    """4-entry coarse-to-fine ICP over the level lists (qt_multiscale_registrator.py:197-236).  sharded = (rank, world)
+    splits every level's source over the ranks."""
+    from gaussiansplattingregistration_amd import parallel
+    T = np.eye(4)
+    est = lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Plane, lru.RobustLoss(0))
+    out = {"icp_iters": 0, "levels": []}
+    for k in range(LEVELS + 1):
+        s, t = clouds_src[-(k + 1)], clouds_tgt[-(k + 1)]
+        t.estimate_normals()
+        crit = lru.get_convergence_criteria(1e-6, 1e-6, ITER_VALUES[k])
+        if sharded:
+            r = parallel.registration_icp_sharded(s, t, MAX_CORR[k], T, est, crit, sharded[0], sharded[1], device=device, ctx=ctx)
+        else:
+            r = lru.registration_icp(s, t, MAX_CORR[k], T, est, crit, device=device, ctx=ctx)
+        T = r.transformation
+        out["icp_iters"] += r.iterations
+        out["levels"].append({"ns": len(s), "nt": len(t), "iterations": r.iterations, "ms_iters": r.timing["ms_iters"],
+                              "evals": r.timing["iter_kernels"], "ms_build": r.timing["ms_build"]})
+    out["T"], out["fitness"], out["rmse"] = T, r.fitness, r.inlier_rmse
+    return out
+
+
+def step_replicas(ctxs, lru, src, tgt, device, sync):
+    """One pass over one pair on this rank.  `ctxs` holds the long-lived library contexts (their workspaces are reused
+    from step to step: no allocation in steady state)."""
+    out = {"hem_gaussians": 0, "kern": []}
     clouds = []
     t0 = time.perf_counter()
     m = ctxs["hem"]
     m.set_rng("glibc", 1, 0)                       # a fresh reference process: cloud 1 then cloud 2 on one stream
     for c in (src, tgt):
-        lv = [PointCloud(xyz32=c["xyz"], cov6=c["cov6"])]
-        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"], borrow=True)     # inputs resident in HBM: read in place
-        for _ in range(LEVELS):
-            m.run_level()
-            st = m.stats()
-            out["hem_gaussians"] += st["n_in"]
-            out["kern"].append(st)
-            d = m.get_level(as_torch=True)
-            lv.append(PointCloud(xyz32=d["xyz"], cov6=d["cov6"]))
+        lv, st = hem_levels(m, c)
+        out["hem_gaussians"] += sum(s["n_in"] for s in st)
+        out["kern"] += st
         clouds.append(lv)
     sync()
     t1 = time.perf_counter()
     out["hem_s"] = t1 - t0
-    out["levels"] = [len(p) for p in clouds[0]]
-    # coarse-to-fine ICP over the level lists (qt_multiscale_registrator.py:197-236)
-    T = np.eye(4)
-    est = lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Plane, lru.RobustLoss(0))
-    icp_kernel_ms, icp_kernels = 0.0, 0
-    for k in range(LEVELS + 1):
-        s, t = clouds[0][-(k + 1)], clouds[1][-(k + 1)]
-        t.estimate_normals()
-        crit = lru.get_convergence_criteria(1e-6, 1e-6, ITER_VALUES[k])
-        r = lru.registration_icp(s, t, MAX_CORR[k], T, est, crit, device=device, ctx=ctxs["icp"])
-        T = r.transformation
-        out["icp_iters"] += r.iterations
-        icp_kernel_ms += r.timing["ms_iters"]
-        icp_kernels += r.timing["iter_kernels"]
-        out["icp_finest"] = {"ns": len(s), "ms": r.timing["ms_iters"], "kernels": r.timing["iter_kernels"]}
+    out["level_sizes"] = [len(p) for p in clouds[0]]
+    out.update(coarse_to_fine(lru, ctxs["icp"], clouds[0], clouds[1], device))
     sync()
     out["icp_s"] = time.perf_counter() - t1
-    out["T"] = T
-    out["fitness"], out["rmse"] = r.fitness, r.inlier_rmse
-    out["icp_kernel_ms"], out["icp_kernels"] = icp_kernel_ms, icp_kernels
     return out
 
 
-def pmc_traffic(kernel_prefix):
-    """HBM bytes per launch of the dominant kernel from the newest committed PMC summary (profiles/*_pmc.json,
-    written by scripts/summarize_profiles.py from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE`
-    passes of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950)."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename)
-    for f in reversed(files):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        for k, v in d.items():
-            if k.startswith(kernel_prefix) and "hbm_read_bytes_per_launch_x2_corrected" in v:
-                return v["hbm_read_bytes_per_launch_x2_corrected"] + v.get("hbm_write_bytes_per_launch", 0.0), os.path.basename(f)
-    return None, None
+def step_c4(ctxs, lru, src, tgt, device, sync, rank, world):
+    """configs[3]: cloud A's HEM on rank 0, cloud B's on rank 1 (no collective), one exchange of the level lists, ICP with
+    the source split over all ranks and the accumulator all-reduce."""
+    import torch
+    import torch.distributed as dist
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+    out = {"hem_gaussians": 0, "kern": []}
+    t0 = time.perf_counter()
+    mine = None
+    if rank < 2:
+        m = ctxs["hem"]
+        m.set_rng("glibc", 1, 0)                   # context-local stream: the two clouds are independent
+        mine, st = hem_levels(m, src if rank == 0 else tgt)
+        out["kern"] = st
+        out["hem_gaussians"] = sum(s["n_in"] for s in st)
+    sync()
+    dist.barrier()
+    t1 = time.perf_counter()
+    out["hem_s"] = t1 - t0
+    # exchange: every level of A (from rank 0) and of B (from rank 1) to every rank -- xyz and cov6 only, what ICP consumes
+    dev = torch.device("cuda", device)
+    nccl = dist.get_backend() == "nccl"
+
+    def bcast(t, root):
+        if nccl:
+            dist.broadcast(t, root)
+        else:
+            h = t.cpu()
+            dist.broadcast(h, root)
+            t.copy_(h)
+
+    lists = []
+    for root in (0, 1):
+        sizes = torch.tensor([len(p) for p in mine] if rank == root else [0] * (LEVELS + 1), dtype=torch.int64, device=dev)
+        bcast(sizes, root)
+        lv = []
+        for k, n in enumerate(sizes.tolist()):
+            if rank == root:
+                xyz, cov = mine[k].xyz32.contiguous(), mine[k].cov6.contiguous()
+            else:
+                xyz, cov = torch.empty((n, 3), dtype=torch.float32, device=dev), torch.empty((n, 6), dtype=torch.float32, device=dev)
+            bcast(xyz, root)
+            bcast(cov, root)
+            lv.append(PointCloud(xyz32=xyz, cov6=cov))
+        lists.append(lv)
+    sync()
+    t2 = time.perf_counter()
+    out["exchange_s"] = t2 - t1
+    out["level_sizes"] = [len(p) for p in lists[0]]
+    out.update(coarse_to_fine(lru, ctxs["icp"], lists[0], lists[1], device, sharded=(rank, world)))
+    sync()
+    out["icp_s"] = time.perf_counter() - t2
+    return out
 
 
-def pmc_valu(kernel_prefix):
-    """VALU instructions per launch of the dominant kernel and the share of the launch they occupy (SQ_INSTS_VALU x 4
-    cycles / 1024 SIMDs against SQ_WAVE-independent wall cycles at 2.4 GHz), from the newest committed PMC summary."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc.json")), key=os.path.basename)
-    for f in reversed(files):
-        try:
-            d = json.load(open(f))
-        except Exception:
-            continue
-        for k, v in d.items():
-            if k.startswith(kernel_prefix) and "SQ_INSTS_VALU_per_launch" in v:
-                return float(v["SQ_INSTS_VALU_per_launch"]), os.path.basename(f)
-    return None, None
+def step_c5(lru, ctxs, big, tgt, device, sync, rank, world):
+    """configs[4]: one large source cloud against a smaller target: work-sharded HEM levels of both (every rank ends with the
+    complete level lists), ICP with the source split over all ranks."""
+    from gaussiansplattingregistration_amd import hem, parallel
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+    out = {"hem_gaussians": 0, "kern": []}
+    t0 = time.perf_counter()
+    lists = []
+    for c in (big, tgt):
+        if world > 1:
+            lv, st = parallel.hem_sharded(c, LEVELS, rank, world, device=device, as_torch=True, rng_mode="glibc", **HEM_PARAMS)
+        else:
+            lv, st = hem.create_mixture(c, LEVELS, device=device, as_torch=True, **HEM_PARAMS)
+        out["kern"] += st
+        out["hem_gaussians"] += sum(s["n_in"] for s in st)
+        lists.append([PointCloud(xyz32=c["xyz"], cov6=c["cov6"])] + [PointCloud(xyz32=l["xyz"], cov6=l["cov6"]) for l in lv])
+    sync()
+    t1 = time.perf_counter()
+    out["hem_s"] = t1 - t0
+    out["level_sizes"] = [len(p) for p in lists[0]]
+    out.update(coarse_to_fine(lru, ctxs["icp"], lists[0], lists[1], device, sharded=(rank, world) if world > 1 else None))
+    sync()
+    out["icp_s"] = time.perf_counter() - t1
+    return out
 
 
-def cpu_baseline():
-    """The reference's own extension (or the oracle port) on this box's host cores, bounded sample."""
+def cpu_baseline(gpu_level1_rate, gpu_icp_coarse):
+    """The reference's own extension (or the oracle port) on this box's host cores: one HEM level at 50 k / 200 k / 500 k splats
+    of the bench density with all cores (and 50 k with one thread), inside a time budget; ICP iterations per second of the
+    oracle port on a 185 k-point level, tree build excluded.  gpu_level1_rate(n) -> the GPU's Gaussians/s for one level at
+    the same n (measured here, same generator)."""
     from gaussiansplattingregistration_amd import synth
+    from oracle import oracle as O
     cores = os.cpu_count() or 1
-    n = 500000                     # ~10-20 s on the host cores (the reference slows down per splat as clouds grow)
-    cloud = synth.make_cloud(n, seed=0)
     ref_dir = os.path.join(ROOT, "oracle", "_ref")
     have_ref = os.path.isdir(ref_dir) and any(f.startswith("mixture_bind") for f in os.listdir(ref_dir))
-    res = {"unit": "Gaussians/s", "cores": cores}
-    if have_ref:
-        try:
+    res = {"unit": "Gaussians/s", "cores": cores, "kind": "reference" if have_ref else "port", "ladder": []}
+    budget_s, spent = 75.0, 0.0
+
+    def run_one(n, threads):
+        cloud = synth.make_cloud(n, seed=0)
+        t_all = time.perf_counter()
+        if have_ref:
             with tempfile.TemporaryDirectory() as td:
                 inp, outp = os.path.join(td, "i.npz"), os.path.join(td, "o.npz")
-                np.savez(inp, levels=1, rho=3.0, delta=3.0, kappa=2.5, tau=1.0,
-                         **{k: cloud[k] for k in ("xyz", "color", "opacity", "cov6", "sh")})
-                subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "run_ref.py"), inp, outp, "--threads", str(cores)],
-                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=600)
-                o = np.load(outp)
-                wall = float(o["wall_s"])
-            res.update(value=n / wall, kind="reference",
-                       sample=f"reference cpp_ext (oracle/_ref) CreateMixture, 1 level, {n} splats SH deg 3 at bench density, "
-                              f"{cores} OpenMP threads, list marshalling excluded; wall {wall:.2f} s")
+                np.savez(inp, levels=1, rho=3.0, delta=3.0, kappa=2.5, tau=1.0, **{k: cloud[k] for k in ("xyz", "color", "opacity", "cov6", "sh")})
+                subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "run_ref.py"), inp, outp, "--threads", str(threads)],
+                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=900)
+                wall = float(np.load(outp)["wall_s"])
+        else:
+            t = time.perf_counter()
+            O.hem(cloud, 1, threads=threads)
+            wall = time.perf_counter() - t
+        return wall, time.perf_counter() - t_all
+
+    plan = [(50_000, cores), (50_000, 1), (200_000, cores), (500_000, cores)]
+    for n, threads in plan:
+        if spent > budget_s:
+            res["ladder"].append({"n": n, "threads": threads, "skipped": "time budget"})
+            continue
+        try:
+            wall, total = run_one(n, threads)
         except Exception as e:  # pragma: no cover
-            have_ref = False
-            res["ref_error"] = str(e)[:200]
-    from oracle import oracle as O
-    if not have_ref:
+            res["ladder"].append({"n": n, "threads": threads, "error": str(e)[:120]})
+            continue
+        spent += total
+        row = {"n": n, "threads": threads, "wall_s": wall, "gaussians_per_s": n / wall}
+        if threads == cores:
+            g = gpu_level1_rate(n)
+            row["gpu_gaussians_per_s_same_n"] = g
+            row["speedup"] = g / (n / wall)
+        res["ladder"].append(row)
+    full = [r for r in res["ladder"] if r.get("threads") == cores and "wall_s" in r]
+    if full:
+        top = max(full, key=lambda r: r["n"])
+        res.update(value=top["gaussians_per_s"], speedup_like_for_like=top["speedup"],
+                   sample=f"{'reference cpp_ext (oracle/_ref)' if have_ref else 'oracle port'} CreateMixture, 1 level, {top['n']} splats SH deg 3 at "
+                          f"bench density, {cores} OpenMP threads, list marshalling excluded; wall {top['wall_s']:.2f} s; the GPU figure beside it is one "
+                          "level of the SAME cloud")
+    # ICP: the oracle port (Open3D absent) -- KD-tree ICP, point-to-plane, on a level of the size the coarsest bench level has;
+    # iterations per second = extra iterations / extra time, so the tree build and the first evaluation cancel
+    try:
+        ns = 185000
+        src, tgt, _ = synth.make_pair(ns, seed=1, sh_degree=0, angle_deg=1.0)
+        C = tgt["cov6"].astype(np.float64)
+        nrm = O.normals_from_cov(np.stack([C[:, [0, 1, 2]], C[:, [1, 3, 4]], C[:, [2, 4, 5]]], 1))
         t = time.perf_counter()
-        O.hem(cloud, 1, threads=cores)
-        wall = time.perf_counter() - t
-        res.update(value=n / wall, kind="port",
-                   sample=f"oracle port (oracle/hem_oracle.cpp), 1 level, {n} splats SH deg 3, {cores} OpenMP threads; wall {wall:.2f} s")
-    # ICP: the oracle port (Open3D absent) -- KD-tree ICP, point-to-plane
-    ns = 200000
-    src, tgt, _ = synth.make_pair(ns, seed=1, sh_degree=0, angle_deg=1.0)
-    C = tgt["cov6"].astype(np.float64)
-    nrm = O.normals_from_cov(np.stack([C[:, [0, 1, 2]], C[:, [1, 3, 4]], C[:, [2, 4, 5]]], 1))
-    t = time.perf_counter()
-    r = O.icp(src["xyz"], tgt["xyz"], nrm, np.eye(4), kind=1, max_corr=0.1, max_iter=5, rel_fitness=0, rel_rmse=0, threads=cores)
-    wall = time.perf_counter() - t
-    res.update(icp_iters_per_sec=r["iterations"] / wall, icp_kind="port",
-               icp_sample=f"oracle KD-tree ICP (point-to-plane), {ns} source x {ns} target points, 5 iterations, {cores} threads; wall {wall:.2f} s "
-                          "(tree build included)")
+        O.icp(src["xyz"], tgt["xyz"], nrm, np.eye(4), kind=1, max_corr=0.5, max_iter=1, rel_fitness=0, rel_rmse=0, threads=cores)
+        t1 = time.perf_counter() - t
+        t = time.perf_counter()
+        r = O.icp(src["xyz"], tgt["xyz"], nrm, np.eye(4), kind=1, max_corr=0.5, max_iter=11, rel_fitness=0, rel_rmse=0, threads=cores)
+        t11 = time.perf_counter() - t
+        rate = (r["iterations"] - 1) / max(1e-9, t11 - t1)
+        res.update(icp_iters_per_sec=rate, icp_kind="port",
+                   icp_sample=f"oracle KD-tree ICP (point-to-plane), {ns} x {ns} points, {cores} threads: 10 extra iterations took {t11 - t1:.2f} s "
+                              f"(tree build + first evaluation {t1:.2f} s excluded)",
+                   icp_gpu_iters_per_sec_same_size=gpu_icp_coarse, icp_speedup_like_for_like=(gpu_icp_coarse / rate) if gpu_icp_coarse else None)
+    except Exception as e:  # pragma: no cover
+        res["icp_error"] = str(e)[:120]
     return res
 
 
@@ -175,7 +307,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--splats", "--n", dest="n", type=int, default=5_000_000, help="splats per cloud (use --splats under torchrun: its parser claims --n)")
+    ap.add_argument("--splats", "--n", dest="n", type=int, default=None, help="splats per cloud (c5: of the LARGE cloud); use --splats under torchrun")
+    ap.add_argument("--target-splats", type=int, default=5_000_000, help="c5: splats of the target cloud")
+    ap.add_argument("--mode", choices=["replicas", "c4", "c5"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -188,12 +322,13 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     from gaussiansplattingregistration_amd import hem, icp as icp_mod, synth
-    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
     from gaussiansplattingregistration_amd.utils import local_registration_util as lru
     if a.gpus != world and world > 1:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: this backend has no CPU fallback")
+    if a.mode == "c4" and world < 2:
+        raise SystemExit("--mode c4 needs at least 2 ranks (cloud A on rank 0, cloud B on rank 1)")
     device = local_rank if world > 1 else 0
     if os.environ.get("GSR_BENCH_SAME_DEVICE"):          # test hook: several ranks on one GPU (with GSR_DIST_BACKEND=gloo)
         device = 0
@@ -208,33 +343,54 @@ def main():
             torch.distributed.barrier()
 
     # synthetic pair, resident in HBM before the timed region: target = cloud, source = inv(T_gt) * cloud + jitter
-    n = a.n
-    tgt = synth.make_cloud_torch(n, seed=100 + rank, device=dev)
-    T_gt = synth.rigid_transform(1.0, (1, 1, 1), 0.004 * tgt["h"] * np.array([1.0, -1.0, 0.5]))
-    src = synth.apply_rigid_torch(tgt, np.linalg.inv(T_gt))
-    gen = torch.Generator(device=dev).manual_seed(7 + rank)
-    src["xyz"] = src["xyz"] + torch.randn(src["xyz"].shape, device=dev, generator=gen) * 0.002
-    src = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in src.items()}
+    n = a.n if a.n is not None else (40_000_000 if a.mode == "c5" else 5_000_000)
+    seed = 100 + (rank if a.mode == "replicas" else 0)     # c4 / c5: every rank holds the same data (replicated inputs)
+    if a.mode == "c5":
+        big = synth.make_cloud_torch(n, seed=seed, device=dev)
+        T_gt = synth.rigid_transform(1.0, (1, 1, 1), 0.004 * big["h"] * np.array([1.0, -1.0, 0.5]))
+        # the target: the first --target-splats of the large cloud, moved (a sub-sample of the same scene)
+        nt = min(a.target_splats, n)
+        sub = {k: (v[:nt].contiguous() if isinstance(v, torch.Tensor) else v) for k, v in big.items()}
+        tgt = synth.apply_rigid_torch(sub, T_gt)
+        tgt = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in tgt.items()}
+        src = big
+    else:
+        tgt = synth.make_cloud_torch(n, seed=seed, device=dev)
+        T_gt = synth.rigid_transform(1.0, (1, 1, 1), 0.004 * tgt["h"] * np.array([1.0, -1.0, 0.5]))
+        src = synth.apply_rigid_torch(tgt, np.linalg.inv(T_gt))
+        gen = torch.Generator(device=dev).manual_seed(7 + (rank if a.mode == "replicas" else 0))
+        src["xyz"] = src["xyz"] + torch.randn(src["xyz"].shape, device=dev, generator=gen) * 0.002
+        src = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in src.items()}
     sync()
 
     ctxs = {"hem": hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS), "icp": icp_mod.IcpContext(device=device)}
+
+    def one_step():
+        if a.mode == "c4":
+            return step_c4(ctxs, lru, src, tgt, device, sync, rank, world)
+        if a.mode == "c5":
+            return step_c5(lru, ctxs, src, tgt, device, sync, rank, world)
+        return step_replicas(ctxs, lru, src, tgt, device, sync)
+
     for _ in range(a.warmup):
-        hot_path_step(ctxs, lru, PointCloud, src, tgt, device, sync)
+        one_step()
     sync(); barrier()
     t0 = time.perf_counter()
-    runs = [hot_path_step(ctxs, lru, PointCloud, src, tgt, device, sync) for _ in range(a.steps)]
+    runs = [one_step() for _ in range(a.steps)]
     sync(); barrier()
     elapsed = time.perf_counter() - t0
+    hem_s, icp_s = sum(r["hem_s"] for r in runs), sum(r["icp_s"] for r in runs)
+    hem_gauss = sum(r["hem_gaussians"] for r in runs)
     if world > 1:
         rdev = dev if torch.distributed.get_backend() == "nccl" else torch.device("cpu")
-        t = torch.tensor([elapsed], dtype=torch.float64, device=rdev)
+        t = torch.tensor([elapsed, hem_s, icp_s], dtype=torch.float64, device=rdev)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
-        agg = torch.tensor([sum(r["hem_s"] for r in runs), sum(r["icp_s"] for r in runs)], dtype=torch.float64, device=rdev)
-        torch.distributed.all_reduce(agg, op=torch.distributed.ReduceOp.MAX)
-        hem_s, icp_s = float(agg[0]), float(agg[1])
-    else:
-        hem_s, icp_s = sum(r["hem_s"] for r in runs), sum(r["icp_s"] for r in runs)
+        elapsed, hem_s, icp_s = (float(v) for v in t)
+        tg = torch.tensor([float(hem_gauss)], dtype=torch.float64, device=rdev)
+        torch.distributed.all_reduce(tg, op=torch.distributed.ReduceOp.SUM)
+        # replicas / c4: every rank's level inputs are different work; c5: the ranks share the SAME levels (count them once)
+        hem_gauss = float(tg) / (world if a.mode == "c5" else 1)
+    icp_iters = sum(r["icp_iters"] for r in runs) * (world if a.mode == "replicas" else 1)
 
     # measured device-copy bandwidth of this very GPU (SURVEY 8d asks for the fraction of both the nominal and a measured
     # figure): 1 GiB device-to-device, read + write traffic
@@ -254,60 +410,104 @@ def main():
             copy_gbs = None
 
     if rank == 0:
-        hem_gauss = sum(r["hem_gaussians"] for r in runs) * world
-        icp_iters = sum(r["icp_iters"] for r in runs) * world
         F = 45
-        # dominant kernel of the step: k_select<FILL> (selection + likelihood), timed by hipEvent pairs on the
-        # library's stream around every launch (gsr_hem_get_phase_ms[7])
+        last = runs[-1]
         kern = [k for r in runs for k in r["kern"]]
-        phases = {p: sum(k[p] for k in kern) for p in ("ms_grid", "ms_select", "ms_sumlw", "ms_mstep", "ms_flags", "ms_level",
-                                                         "ms_k_select_count", "ms_k_select_fill")}
-        fill_ms = np.array([k["ms_k_select_fill"] for k in kern])
+        phases = {p: sum(k[p] for k in kern) / a.steps for p in ("ms_grid", "ms_select", "ms_sumlw", "ms_mstep", "ms_flags", "ms_level",
+                                                                  "ms_k_select_count", "ms_k_select_fill")}
+        # dominant kernel: k_select<SPARSE> (selection + likelihood), timed by hipEvent pairs on the library's stream around
+        # every launch (gsr_hem_get_phase_ms[7]).  Algorithmic bytes of a launch = SURVEY 8(d)'s bytes_level of ITS level.
+        sel_ms = np.array([k["ms_k_select_fill"] for k in kern])
+        lvl_b = np.array([bytes_level(k["n_in"], k["n_out"], F) for k in kern], dtype=np.float64)
         n_in = np.array([k["n_in"] for k in kern], dtype=np.float64)
-        avg_ms = float(fill_ms.mean())
-        achieved = float(n_in.mean()) * B_GEOM / (avg_ms * 1e-3) / 1e9
-        lvl1 = [k for k in kern if k["n_in"] == n]
-        lvl_bytes = np.mean([bytes_level(k["n_in"], k["n_out"], F) for k in lvl1])
-        lvl_ms = np.mean([k["ms_level"] for k in lvl1])
-        traffic, traffic_src = pmc_traffic("gsr::k_select<2")
+        avg_ms = float(sel_ms.mean()) if len(sel_ms) else 0.0
+        achieved = float(lvl_b.mean() / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else 0.0
+        big_n = max(k["n_in"] for k in kern) if kern else n
+        lvl1 = [k for k in kern if k["n_in"] == big_n]
+        l1_bytes = float(np.mean([bytes_level(k["n_in"], k["n_out"], F) for k in lvl1])) if lvl1 else 0.0
+        l1_ms = float(np.mean([k["ms_level"] for k in lvl1])) if lvl1 else 0.0
+        l1_sel = float(np.mean([k["ms_k_select_fill"] for k in lvl1])) if lvl1 else 0.0
+        pmc, pmc_note = pmc_summary("gsr::k_select<2")
+        roof = {"bound": "hbm", "kernel": "k_select<SPARSE> (child selection + likelihood, one wavefront per parent)",
+                "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "bytes_model": "SURVEY 8(d) bytes_level = n_in (57 + 4F + 16) + n_out (57 + 4F) of the launch's level, / launch duration",
+                "avg_launch_ms": avg_ms, "launches": int(len(sel_ms)), "avg_units_per_launch": float(n_in.mean()) if len(n_in) else 0.0,
+                "avg_algorithmic_bytes_per_launch": float(lvl_b.mean()) if len(lvl_b) else 0.0,
+                "traffic": None, "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
+                "level1": {"n_in": int(big_n), "algorithmic_bytes": l1_bytes, "ms_level": l1_ms, "ms_k_select": l1_sel,
+                           "level_GBps": l1_bytes / (l1_ms * 1e-3) / 1e9 if l1_ms else None,
+                           "level_frac": l1_bytes / (l1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if l1_ms else None,
+                           "k_select_GBps": l1_bytes / (l1_sel * 1e-3) / 1e9 if l1_sel else None,
+                           "k_select_frac": l1_bytes / (l1_sel * 1e-3) / 1e9 / HBM_PEAK_GBS if l1_sel else None},
+                "why_not_hbm_bound": "the level evaluates ~240 candidate tests and ~80 KL divergences per input splat (neighbour work the 8(d) "
+                                     "byte model does not count): k_select is bound by VALU issue and L2 request rate, see valu / DESIGN.md 4"}
+        if pmc:
+            roof["traffic"] = pmc.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) + pmc.get("hbm_write_bytes_per_launch", 0.0)
+            roof["traffic_source"] = pmc["source"] + " (level-1 launch at 5 M; FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+            vi, va = pmc.get("SQ_INSTS_VALU_per_launch"), pmc.get("SQ_ACTIVE_INST_VALU_per_launch")
+            busy = pmc.get("SQ_BUSY_CYCLES_per_launch")
+            roof["valu"] = {"insts_per_launch": vi, "active_quad_cycles_per_launch": va,
+                            "measured_cycles_per_inst": (4.0 * va / vi) if vi and va else None,
+                            "valu_busy_frac": (4.0 * va / 1024.0) / (busy / 32.0) if va and busy else None,
+                            "issue_cost_cycles_microbench": VALU_CYCLES, "source": pmc["source"]}
+        else:
+            roof["traffic_note"] = pmc_note
+            roof["valu"] = {"issue_cost_cycles_microbench": VALU_CYCLES, "note": pmc_note}
+        fin = last["levels"][-1]
+        per_eval = fin["ms_iters"] / max(1, fin["evals"])
+        roof["icp_finest"] = {"ns": fin["ns"], "nt": fin["nt"], "ms_per_iteration": per_eval, "iterations_per_sec": 1e3 / per_eval if per_eval else None,
+                              "algorithmic_bytes_per_iteration": 36.0 * fin["ns"],
+                              "achieved_GBps": 36.0 * fin["ns"] / (per_eval * 1e-3) / 1e9 if per_eval else None,
+                              "frac": 36.0 * fin["ns"] / (per_eval * 1e-3) / 1e9 / HBM_PEAK_GBS if per_eval else None}
+        coarse = last["levels"][0]
+        gpu_icp_coarse = coarse["evals"] / (coarse["ms_iters"] * 1e-3) if coarse["ms_iters"] else None
+        par = {"replicas": f"{world} independent pair(s), one per GPU, no data-path collective",
+               "c4": f"cloud A HEM on rank 0, cloud B on rank 1, levels broadcast once, ICP source split over {world} ranks + all-reduce of 32 doubles per iteration",
+               "c5": f"work-sharded HEM levels over {world} rank(s) (all-reduce of per-child sums + one all-gather of merged components per level), "
+                     f"ICP source split over {world} rank(s)"}[a.mode]
         line = {
             "metric": "Gaussians/sec through HEM level + ICP iters/sec, 2x5M-splat pair",
             "value": hem_gauss / hem_s,
             "unit": "Gaussians/s",
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": elapsed / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if a.mode == "replicas" else "strong", "vs_baseline": None,
             "dtype": "f32 (HEM) / f64 (ICP)", "data": "synthetic",
-            "config": {"workload": f"2x{n} synthetic splats (SH deg 3) per GPU: 3 HEM levels per cloud + 4-level coarse-to-fine "
-                                   "point-to-plane ICP (BASELINE configs[2])",
-                       "hem_params": HEM_PARAMS, "iter_values": ITER_VALUES, "max_corr": MAX_CORR, "level_sizes": runs[-1]["levels"],
-                       "parallelism": f"{world} independent pair(s), one per GPU, no data-path collective"},
+            "config": {"workload": (f"2x{n} synthetic splats (SH deg 3) per GPU: 3 HEM levels per cloud + 4-level coarse-to-fine point-to-plane ICP "
+                                    "(BASELINE configs[2])") if a.mode == "replicas" else
+                                   (f"2x{n} splats, clouds one per GPU + ICP source split (BASELINE configs[3])" if a.mode == "c4" else
+                                    f"one {n}-splat cloud vs a {min(a.target_splats, n)}-splat target, sharded HEM + split ICP (BASELINE configs[4])"),
+                       "mode": a.mode, "hem_params": HEM_PARAMS, "iter_values": ITER_VALUES, "max_corr": MAX_CORR, "level_sizes": last["level_sizes"],
+                       "parallelism": par},
             "icp_iters_per_sec": icp_iters / icp_s,
-            "icp_iterations_per_step": runs[-1]["icp_iters"],
+            "icp_iterations_per_step": last["icp_iters"],
+            "icp_per_level": [{"ns": l["ns"], "iterations": l["iterations"], "ms_per_iteration": l["ms_iters"] / max(1, l["evals"]),
+                               "ms_target_index_build": l["ms_build"]} for l in last["levels"]],
+            "icp_note": "the blended icp_iters_per_sec is dominated by the coarse levels (launch floor ~70 us per iteration); the finest level's "
+                        "rate is roofline.icp_finest.  The synthetic pair is an easy case (1 degree / 0.4 % misalignment): the loops stop well "
+                        "inside their iteration budgets",
             "hem_s_per_step": hem_s / a.steps, "icp_s_per_step": icp_s / a.steps,
-            "icp_result": {"fitness": runs[-1]["fitness"], "inlier_rmse": runs[-1]["rmse"],
-                           "T_err_vs_ground_truth_F": float(np.linalg.norm(runs[-1]["T"] - T_gt))},
-            "hem_phase_ms_per_step": {k: v / a.steps for k, v in phases.items()},
-            "roofline": {"bound": "hbm", "kernel": "k_select<SPARSE> (child selection + likelihood, one wavefront per parent)",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_source": traffic_src,
-                         "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
-                         "avg_launch_ms": avg_ms, "launches": int(len(fill_ms)), "avg_units_per_launch": float(n_in.mean()),
-                         "bytes_per_unit": B_GEOM,
-                         "valu": (lambda vi: None if vi[0] is None else {
-                             "insts_per_launch": vi[0], "source": vi[1],
-                             "busy_frac_at_2.4GHz": vi[0] * 4.0 / 1024.0 / (avg_ms * 1e-3 * 2.4e9)})(pmc_valu("gsr::k_select<2")),
-                         "note": "VALU-bound neighbour evaluation (about 240 candidate tests and 80 KL divergences per splat; PMC: VALUBusy 94 %), not HBM-bound: see DESIGN.md section 4",
-                         "level1": {"algorithmic_bytes": float(lvl_bytes), "ms": float(lvl_ms),
-                                    "achieved_GBps": float(lvl_bytes / (lvl_ms * 1e-3) / 1e9),
-                                    "frac": float(lvl_bytes / (lvl_ms * 1e-3) / 1e9 / HBM_PEAK_GBS)},
-                         "icp_finest": {"ns": runs[-1]["icp_finest"]["ns"],
-                                        "avg_ms": runs[-1]["icp_finest"]["ms"] / max(1, runs[-1]["icp_finest"]["kernels"]),
-                                        "achieved_GBps": 48.0 * runs[-1]["icp_finest"]["ns"] /
-                                        (runs[-1]["icp_finest"]["ms"] / max(1, runs[-1]["icp_finest"]["kernels"]) * 1e-3) / 1e9}},
+            "icp_result": {"fitness": last["fitness"], "inlier_rmse": last["rmse"], "T_err_vs_ground_truth_F": float(np.linalg.norm(last["T"] - T_gt))},
+            "hem_phase_ms_per_step": phases,
+            "roofline": roof,
         }
-        if world == 1 and not a.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline()
+        if "exchange_s" in last:
+            line["exchange_s_per_step"] = sum(r["exchange_s"] for r in runs) / a.steps
+        if world == 1 and a.mode == "replicas" and not a.no_cpu_baseline:
+            def gpu_level1_rate(nn):
+                c = synth.make_cloud(nn, seed=0)
+                dc = {k: torch.from_numpy(v).to(dev) for k, v in c.items() if isinstance(v, np.ndarray)}
+                m = ctxs["hem"]
+                best = None
+                for _ in range(3):
+                    m.set_rng("glibc", 1, 0)
+                    m.set_level0(dc["xyz"], dc["color"], dc["opacity"], dc["cov6"], dc["sh"])
+                    sync(); t = time.perf_counter()
+                    m.run_level()
+                    sync(); dt = time.perf_counter() - t
+                    best = dt if best is None else min(best, dt)
+                return nn / best
+            line["cpu_baseline"] = cpu_baseline(gpu_level1_rate, gpu_icp_coarse)
         print(json.dumps(line), flush=True)
     barrier()
     if world > 1:

@@ -1,5 +1,8 @@
 #!/usr/bin/env python3
 """Condense the rocprofv3 output of scripts/gpu_round.sh into the small tracked files under profiles/.
+The kernel-stats table comes from the bench.py run; the PMC passes profile scripts/prof_hem.py 5000000 1 (level 1 of a 5 M
+cloud alone), and the summary records the hash of the kernel sources it was taken with (bench.py only quotes it when the
+sources still match).
 
 usage: python scripts/summarize_profiles.py gpurun_out/r01 profiles/r01
 Writes <dst>_kernel_stats.csv (the --stats summary, kernel names shortened), <dst>_pmc.json (per-kernel
@@ -43,7 +46,7 @@ if f:
 
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(int)
-for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
+for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2", "pmc_tc"):
     for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
@@ -54,7 +57,10 @@ for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq"):
             key = (d, k, r["Dispatch_Id"])
             if d == "pmc_fetch" and key not in seen:
                 seen.add(key); launches[k] += 1
-out = {}
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench  # noqa: E402  (kernel_build_id: the kernel sources these counters belong to)
+out = {"kernel_build": bench.kernel_build_id(),
+       "command": "scripts/prof_hem.py 5000000 1 2  (ONE level of a 5 M-splat cloud, SH degree 3: the level-1 launch alone; per-launch averages)"}
 for k, v in pmc.items():
     n = max(1, launches.get(k, 1))
     e = {"launches_in_pass": n}
