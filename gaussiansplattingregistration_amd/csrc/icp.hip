@@ -243,70 +243,14 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
     return best;
 }
 
-// ---- cooperative search: ICP_LPP lanes per source point -------------------------------------------------
-// A per-thread ring search is a chain of ~10 dependent (cellStart -> candidates) round trips; with 8 lanes
-// per point each lane walks 1-2 row spans and the group's best is combined with 3 xor-shuffles, so the
-// chain is ~5x shorter and the (latency-bound) search kernel needs few registers.  Same result as
-// icp_nearest: exact nearest neighbour, ties to the lowest input index.
-#define ICP_LPP 8
-__device__ __forceinline__ void icp_group_min(double& bd, int& best, unsigned& best_i) {
-#pragma unroll
-    for (int o = 1; o < ICP_LPP; o <<= 1) {
-        const double od = __shfl_xor(bd, o);
-        const int ob = __shfl_xor(best, o);
-        const unsigned oi = __shfl_xor(best_i, o);
-        if (od < bd || (od == bd && oi < best_i)) { bd = od; best = ob; best_i = oi; }
-    }
-}
-
-__device__ __forceinline__ int icp_nearest_group(const IcpGrid& g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
-                                                 double px, double py, double pz, int sub, double& best_d2) {
-    int best = -1;
-    unsigned best_i = 0xffffffffu;
-    double bd = 1.0 / 0.0;
-    if (!(px == px) || !(py == py) || !(pz == pz)) { best_d2 = bd; return -1; }
-    const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
-    // rings 0 and 1 together: the 3x3x3 block as 9 row spans of 3 cells; lane `sub` takes rows sub and sub+8
-    {
-        const int xa = cx > 0 ? cx - 1 : 0, xb = cx < g.gx - 1 ? cx + 1 : g.gx - 1;
-        for (int t = sub; t < 9; t += ICP_LPP) {
-            const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
-            if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) continue;
-            const int rowbase = (z * g.gy + y) * g.gx;
-            icp_scan_span(cellStart, Tq, rowbase + xa, rowbase + xb, px, py, pz, bd, best, best_i);
-        }
-        icp_group_min(bd, best, best_i);
-    }
-    for (int r = 2; r <= g.rings; ++r) {
-        const double reach = (double)(r - 1) * g.c * 0.999999999;      // everything inside ring r-1 has been seen
-        if (bd < reach * reach) break;
-        const int w = 2 * r + 1;
-        for (int t = sub; t < w * w; t += ICP_LPP) {
-            const int dz = t / w - r, dy = t % w - r;
-            const int z = cz + dz, y = cy + dy;
-            if (z < 0 || z >= g.gz || y < 0 || y >= g.gy) continue;
-            const int rowbase = (z * g.gy + y) * g.gx;
-            const int adz = dz < 0 ? -dz : dz, ady = dy < 0 ? -dy : dy;
-            if (adz == r || ady == r) {
-                const int xa = cx - r > 0 ? cx - r : 0, xb = cx + r < g.gx - 1 ? cx + r : g.gx - 1;
-                icp_scan_span(cellStart, Tq, rowbase + xa, rowbase + xb, px, py, pz, bd, best, best_i);
-            } else {
-                if (cx - r >= 0) icp_scan_span(cellStart, Tq, rowbase + cx - r, rowbase + cx - r, px, py, pz, bd, best, best_i);
-                if (cx + r < g.gx) icp_scan_span(cellStart, Tq, rowbase + cx + r, rowbase + cx + r, px, py, pz, bd, best, best_i);
-            }
-        }
-        icp_group_min(bd, best, best_i);
-    }
-    best_d2 = bd;
-    return best;
-}
-
 struct IcpState;
 __device__ __forceinline__ bool icp_state_done(const IcpState* st);
 __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]);
 
-// nn_j[i] = sorted target position of the accepted nearest neighbour of source point i, or -1
-template <bool FROM_STATE, bool COOP>
+// nn_j[i] = sorted target position of the accepted nearest neighbour of source point i, or -1.  One thread per source
+// point: a search kernel with few registers (56 VGPRs, 8 waves per SIMD) in front of a streaming accumulate kernel.
+// (Measured and rejected: eight lanes per point with shuffle-combined partial searches -- 1.5x slower.)
+template <bool FROM_STATE>
 __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restrict__ src, Xform X, const IcpState* __restrict__ st,
                                                 IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
                                                 double max_corr2, int* __restrict__ nn_j) {
@@ -318,28 +262,14 @@ __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restr
 #pragma unroll
         for (int i = 0; i < 12; ++i) T[i] = X.m[i];
     }
-    if (!COOP) {                                    // one thread per source point: a search kernel with few registers
-        for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
-            const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
-            const double px = T[0] * x + T[1] * y + T[2] * z + T[3];
-            const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
-            const double pz = T[8] * x + T[9] * y + T[10] * z + T[11];
-            double d2;
-            const int j = icp_nearest(g, cellStart, Tq, px, py, pz, d2);
-            nn_j[i] = (j >= 0 && d2 < max_corr2) ? j : -1;
-        }
-        return;
-    }
-    const int sub = threadIdx.x & (ICP_LPP - 1);
-    const int64_t stride = (int64_t)gridDim.x * (blockDim.x / ICP_LPP);
-    for (int64_t i = (int64_t)blockIdx.x * (blockDim.x / ICP_LPP) + (threadIdx.x / ICP_LPP); i < ns; i += stride) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
         const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
         const double px = T[0] * x + T[1] * y + T[2] * z + T[3];
         const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
         const double pz = T[8] * x + T[9] * y + T[10] * z + T[11];
         double d2;
-        const int j = icp_nearest_group(g, cellStart, Tq, px, py, pz, sub, d2);
-        if (sub == 0) nn_j[i] = (j >= 0 && d2 < max_corr2) ? j : -1;
+        const int j = icp_nearest(g, cellStart, Tq, px, py, pz, d2);
+        nn_j[i] = (j >= 0 && d2 < max_corr2) ? j : -1;
     }
 }
 
@@ -1152,9 +1082,10 @@ struct gsr_icp_ctx {
     // Search / accumulate split (GSR_ICP_NN_KERNEL): 0 = one fused kernel (120 VGPRs with the 30 float64 accumulators:
     // 4 waves per SIMD); 2 = a thread-per-point search kernel (56 VGPRs, 8 waves per SIMD) writes nn_j and a streaming
     // kernel accumulates -- the search is latency bound, so occupancy wins: 21 % faster at 5 M points, equal at 0.5 M,
-    // 8 % slower at 0.2 M (one more launch).  -1 = choose by size.  1 = eight lanes per point (1.5x slower, kept as a switch).
+    // 8 % slower at 0.2 M (one more launch).  -1 = choose by size (the default).  Same results either way
+    // (tests/test_icp_gpu.py::test_icp_knobs_change_nothing).
     int nn_kernel = -1;
-    int nn_mode() const { return nn_kernel >= 0 ? nn_kernel : (ns >= 1000000 ? 2 : 0); }
+    int nn_mode() const { return nn_kernel >= 0 ? (nn_kernel ? 2 : 0) : (ns >= 1000000 ? 2 : 0); }
     double cell_target = 2.0;       // target points per grid cell (GSR_ICP_CELL_TARGET).  Measured at 5M x 5M: 0.5 makes a
                                     // converged iteration 1.7x faster but a cold start (offsets ~ max_corr) 1.6x slower: keep 2
     DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
@@ -1171,15 +1102,8 @@ struct gsr_icp_ctx {
 
 namespace {
 
-// grid of the cooperative search kernel: 256 / ICP_LPP points per block, capped (grid-stride loop)
-inline int nn_grid1(int64_t ns) {      // one thread per point
+inline int nn_grid1(int64_t ns) {      // grid of the search kernel: one thread per point, capped (grid-stride loop)
     int64_t g = (ns + 255) / 256;
-    if (g < 1) g = 1;
-    if (g > 16384) g = 16384;
-    return (int)g;
-}
-inline int nn_grid(int64_t ns) {
-    int64_t g = (ns * ICP_LPP + 255) / 256;
     if (g < 1) g = 1;
     if (g > 16384) g = 16384;
     return (int)g;
@@ -1208,12 +1132,8 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     const int* nnj = nullptr;
     if (c->nn_mode()) {
         GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-        if (c->nn_mode() == 2)
-            hipLaunchKernelGGL((k_icp_nn<false, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                               c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
-        else
-            hipLaunchKernelGGL((k_icp_nn<false, true>), dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                               c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+        hipLaunchKernelGGL((k_icp_nn<false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                           c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
         nnj = c->nn_j.as<int>();
     }
     const ColorArgs cargs = {c->Ti.as<double>(), c->Tg.as<double>(), c->Si.as<double>(), sqrt(c->lambda_geometric), sqrt(1.0 - c->lambda_geometric)};
@@ -1262,6 +1182,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     c->device = device;
     c->stream = (hipStream_t)stream;
     if (hipEventCreate(&c->e0) != hipSuccess || hipEventCreate(&c->e1) != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate failed"); }
+    // Environment knobs (all of them): none changes a result, tests/test_icp_gpu.py::test_icp_knobs_change_nothing
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_NN_KERNEL")) c->nn_kernel = atoi(e);
     if (const char* e = getenv("GSR_ICP_CELL_TARGET")) { double v = atof(e); if (v > 0.01 && v < 1000) c->cell_target = v; }
@@ -1551,11 +1472,8 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
             const int chunk = total_evals - issued < 8 ? total_evals - issued : 8;
             const int* nnj = c->nn_mode() ? c->nn_j.as<int>() : (const int*)nullptr;
             for (int i = 0; i < chunk; ++i) {
-                if (c->nn_mode() == 2)
-                    hipLaunchKernelGGL((k_icp_nn<true, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
-                                       c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
-                else if (c->nn_mode())
-                    hipLaunchKernelGGL((k_icp_nn<true, true>), dim3(nn_grid(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
+                if (c->nn_mode())
+                    hipLaunchKernelGGL((k_icp_nn<true>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
                                        c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
                 if (kind == GSR_ICP_COLORED)
                     hipLaunchKernelGGL(k_icp_accumulate_dev<3>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
@@ -1628,12 +1546,8 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
     GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-    if (c->nn_mode() == 1)      // same search as the registration loop uses
-        hipLaunchKernelGGL((k_icp_nn<false, true>), dim3(nn_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                           c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
-    else
-        hipLaunchKernelGGL((k_icp_nn<false, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                           c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
+    hipLaunchKernelGGL((k_icp_nn<false>), dim3(nn_grid1(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
     hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->nn_j.as<int>(),
                        c->Tq.as<float4>(), c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->corr_idx.as<int64_t>(),
                        c->corr_d2.as<double>());
