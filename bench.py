@@ -227,8 +227,8 @@ def step_c5(lru, ctxs, big, tgt, device, sync, rank, world):
 
 
 def cpu_baseline(gpu_level1_rate, gpu_icp_coarse):
-    """The reference's own extension (or the oracle port) on this box's host cores: one HEM level at 50 k / 200 k / 500 k splats
-    of the bench density with all cores (and 50 k with one thread), inside a time budget; ICP iterations per second of the
+    """The reference's own extension (or the oracle port) on this box's host cores: one HEM level at 50 k / 200 k / 500 k / 1 M splats
+    of the bench density with all cores (50 k and 200 k also with one thread), inside a time budget; ICP iterations per second of the
     oracle port on a 185 k-point level, tree build excluded.  gpu_level1_rate(n) -> the GPU's Gaussians/s for one level at
     the same n (measured here, same generator)."""
     from gaussiansplattingregistration_amd import synth
@@ -255,7 +255,7 @@ def cpu_baseline(gpu_level1_rate, gpu_icp_coarse):
             wall = time.perf_counter() - t
         return wall, time.perf_counter() - t_all
 
-    plan = [(50_000, cores), (50_000, 1), (200_000, cores), (500_000, cores)]
+    plan = [(50_000, cores), (50_000, 1), (200_000, cores), (200_000, 1), (500_000, cores), (1_000_000, cores)]
     for n, threads in plan:
         if spent > budget_s:
             res["ladder"].append({"n": n, "threads": threads, "skipped": "time budget"})
