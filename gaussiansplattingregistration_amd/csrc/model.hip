@@ -26,6 +26,9 @@
 
 #include <float.h>
 #include <math.h>
+#include <string.h>
+
+#include <vector>
 
 namespace gsr {
 
@@ -133,9 +136,118 @@ __global__ __launch_bounds__(256) void k_decompose_cov(int64_t n, const float* _
     }
 }
 
+// ---- RANSAC plane fitting: the data-parallel inner part of _fit_single_plane of the reference
+// (src/utils/plane_fitting_util.py:38-69).  The reference evaluates its `iterations` candidate planes one after the
+// other, each with five full-size torch kernels on the CPU; here ALL candidates of a plane search are scored in one
+// pass over the points: a thread per point, the candidates broadcast from LDS, inliers counted per candidate by
+// ballot + popcount (one LDS atomic per wave and candidate).
+//   distance  = (x n'_0 + y n'_1 + z n'_2 + d) / |n'|      n' = the plane normal re-normalised in float32 (:91-96)
+//   inlier   <=> |distance| < distance_threshold  and  |<point normal, plane normal>| > normal_threshold   (:54-61)
+// float32 throughout, dot products as fused multiply-add chains in index order (what the host BLAS does for K = 3).
+struct PlaneCand { float n0, n1, n2, d, m0, m1, m2, nn; };      // n' (re-normalised), d, plane normal as sampled, |n'|
+
+__device__ __forceinline__ bool plane_inlier(const PlaneCand& c, float x, float y, float z, float nx, float ny, float nz, float dist_thr, float nrm_thr) {
+    const float dot = __builtin_fmaf(z, c.n2, __builtin_fmaf(y, c.n1, x * c.n0));
+    const float dist = (dot + c.d) / c.nn;
+    const float al = __builtin_fmaf(nz, c.m2, __builtin_fmaf(ny, c.m1, nx * c.m0));
+    return fabsf(dist) < dist_thr && fabsf(al) > nrm_thr;
+}
+
+#define PLANE_CHUNK 256
+__global__ __launch_bounds__(256) void k_plane_score(int64_t n, const float* __restrict__ xyz, const float* __restrict__ nrm, int P,
+                                                     const PlaneCand* __restrict__ cand, float dist_thr, float nrm_thr, unsigned* __restrict__ counts) {
+    __shared__ PlaneCand s_c[PLANE_CHUNK];
+    __shared__ unsigned s_n[PLANE_CHUNK];
+    const int lane = threadIdx.x & 63;
+    for (int p0 = 0; p0 < P; p0 += PLANE_CHUNK) {
+        const int pn = P - p0 < PLANE_CHUNK ? P - p0 : PLANE_CHUNK;
+        __syncthreads();
+        if ((int)threadIdx.x < pn) { s_c[threadIdx.x] = cand[p0 + threadIdx.x]; s_n[threadIdx.x] = 0u; }
+        __syncthreads();
+        for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = i0 + threadIdx.x;
+            const bool live = i < n;
+            const int64_t ii = live ? i : 0;
+            const float x = xyz[3 * ii], y = xyz[3 * ii + 1], z = xyz[3 * ii + 2];
+            const float nx = nrm[3 * ii], ny = nrm[3 * ii + 1], nz = nrm[3 * ii + 2];
+            for (int p = 0; p < pn; ++p) {
+                const bool in = live && plane_inlier(s_c[p], x, y, z, nx, ny, nz, dist_thr, nrm_thr);
+                const unsigned long long m = __ballot(in);
+                if (m != 0ull && lane == 0) atomicAdd(&s_n[p], (unsigned)__popcll(m));
+            }
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < pn && s_n[threadIdx.x]) atomicAdd(&counts[p0 + threadIdx.x], s_n[threadIdx.x]);
+    }
+}
+__global__ __launch_bounds__(256) void k_plane_mask(int64_t n, const float* __restrict__ xyz, const float* __restrict__ nrm, PlaneCand c,
+                                                    float dist_thr, float nrm_thr, uint8_t* __restrict__ mask) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        mask[i] = plane_inlier(c, xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], nrm[3 * i], nrm[3 * i + 1], nrm[3 * i + 2], dist_thr, nrm_thr) ? 1 : 0;
+}
+
 }  // namespace gsr
 
 using namespace gsr;
+
+extern "C" int32_t gsr_plane_score(const float* xyz, const float* normals, int64_t n, const float* candidates, int32_t n_candidates,
+                                   float distance_threshold, float normal_threshold, uint32_t* counts, uint8_t* best_mask, int32_t* best,
+                                   int32_t on_device, int32_t device, void* stream) {
+    if (n < 0 || n_candidates < 0 || (n > 0 && (!xyz || !normals)) || (n_candidates > 0 && (!candidates || !counts)) || !best)
+        return fail(GSR_E_INVALID, "gsr_plane_score: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GSR_E_NO_DEVICE, "gsr_plane_score: no HIP device visible (this backend has no CPU fallback)");
+    *best = -1;
+    if (n == 0 || n_candidates == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    static_assert(sizeof(PlaneCand) == 32, "candidates are 8 floats");
+    DevBuf dx, dn, dc, dcnt, dmask;
+    const float* px = xyz;
+    const float* pn = normals;
+    int32_t r = dc.reserve((size_t)n_candidates * 32);
+    if (r == GSR_OK) r = dcnt.reserve((size_t)n_candidates * 4);
+    if (r == GSR_OK && !on_device) { r = dx.reserve((size_t)n * 12); if (r == GSR_OK) r = dn.reserve((size_t)n * 12); }
+    if (r == GSR_OK && best_mask && !on_device) r = dmask.reserve((size_t)n);
+    hipError_t e = hipSuccess;
+    std::vector<uint32_t> hc((size_t)n_candidates);
+    if (r == GSR_OK) {
+        if (!on_device) {
+            e = hipMemcpyAsync(dx.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(dn.p, normals, (size_t)n * 12, hipMemcpyHostToDevice, st);
+            px = dx.as<float>(); pn = dn.as<float>();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(dc.p, candidates, (size_t)n_candidates * 32, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipMemsetAsync(dcnt.p, 0, (size_t)n_candidates * 4, st);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_plane_score, dim3(stride_grid(n)), dim3(256), 0, st, n, px, pn, (int)n_candidates, dc.as<PlaneCand>(), distance_threshold,
+                               normal_threshold, dcnt.as<unsigned>());
+            e = hipMemcpyAsync(hc.data(), dcnt.p, (size_t)n_candidates * 4, hipMemcpyDeviceToHost, st);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+    }
+    if (r == GSR_OK && e == hipSuccess) {
+        // the reference keeps the FIRST candidate with the strictly largest count (plane_fitting_util.py:63-66)
+        uint32_t mx = 0;
+        for (int32_t p = 0; p < n_candidates; ++p) {
+            counts[p] = hc[(size_t)p];
+            if (hc[(size_t)p] > mx) { mx = hc[(size_t)p]; *best = p; }
+        }
+        if (*best >= 0 && best_mask) {
+            PlaneCand c;
+            memcpy(&c, candidates + 8 * (size_t)*best, sizeof(c));
+            uint8_t* dm = on_device ? best_mask : dmask.as<uint8_t>();
+            hipLaunchKernelGGL(k_plane_mask, dim3(stride_grid(n)), dim3(256), 0, st, n, px, pn, c, distance_threshold, normal_threshold, dm);
+            if (!on_device) e = hipMemcpyAsync(best_mask, dm, (size_t)n, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+        }
+    }
+    dx.release(); dn.release(); dc.release(); dcnt.release(); dmask.release();
+    if (r != GSR_OK) return r;
+    if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_plane_score: %s", hipGetErrorString(e));
+    return GSR_OK;
+}
 
 extern "C" int32_t gsr_decompose_cov(const float* cov6, int64_t n, int32_t mode, float* scaling, float* rotation, float* matrix,
                                      int32_t on_device, int32_t device, void* stream) {

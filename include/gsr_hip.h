@@ -239,6 +239,17 @@ int32_t gsr_normals_knn(const float* xyz, int64_t n, int32_t knn, double* normal
 int32_t gsr_decompose_cov(const float* cov6, int64_t n, int32_t mode, float* scaling, float* rotation, float* matrix,
                           int32_t on_device, int32_t device, void* stream);
 
+/* RANSAC plane search, the data-parallel part: scores ALL candidate planes of one
+ * _fit_single_plane call of the reference (src/utils/plane_fitting_util.py:38-69) in one pass over the points.
+ * candidates[n_candidates*8] = {n'_0, n'_1, n'_2, d, m_0, m_1, m_2, |n'|}: the plane normal re-normalised as
+ * project_point_onto_plane does (:91-96), the offset d, the normal as sampled (used for the alignment test :57-58).
+ * counts[c] = points with |distance| < distance_threshold and |<normal_i, m>| > normal_threshold; *best = the first candidate
+ * with the strictly largest count (-1 if none has an inlier); best_mask[n] (or NULL) = its inlier mask.
+ * xyz / normals[n*3] float32 and best_mask on the host or the device as on_device says; candidates, counts, best: host. */
+int32_t gsr_plane_score(const float* xyz, const float* normals, int64_t n, const float* candidates, int32_t n_candidates,
+                        float distance_threshold, float normal_threshold, uint32_t* counts, uint8_t* best_mask, int32_t* best,
+                        int32_t on_device, int32_t device, void* stream);
+
 /* ------------------------------------------------------------------------------ voxel down-sampling */
 
 /* PointCloud::VoxelDownSample (Open3D 0.16.0 PointCloud.cpp), the first step of the reference's voxel multiscale
