@@ -1159,14 +1159,15 @@ __global__ __launch_bounds__(256) void k_flags_to_input_order(int64_t n, const u
 // k_mstep: responsibilities and moment-matching update (mixture.cpp:167-247).
 //
 // One wavefront handles MSTEP_K consecutive parents of the processing order.  Their headers (pair offset and count,
-// output row, parent mean) were laid out in that order by k_mstep_headers, so a wave fetches them with scalar loads at
-// its start; the pair records of parent i+1 are prefetched while parent i is being reduced.  Per parent:
+// output row, parent mean) were laid out in that order by k_mstep_headers, so a wave fetches them with scalar loads.
+// Per parent:
 //   part 1   lane <-> pair: w = (wL_si / sumLw_i) * weight_i (mixture.cpp:196-197), the 14 moment sums in the
-//            reference's expressions; child index and w go to LDS.  All gathers of a pair (sumLw and the 64-byte
-//            geometry record) are issued together and unconditionally, and the first round of SH row loads is issued
-//            BEFORE they are consumed (it needs the child indices only).
+//            reference's expressions; child index and w go to LDS.  The gathers of a pair (the 64-byte geometry record,
+//            which also carries sumLw) are issued together and unconditionally.  The sums are folded over the lanes and
+//            parked in LDS straight away, so that their registers are free for
 //   part 2   lane group <-> child: G lanes x 3 float4 cover one SH row, so one round of three load instructions
-//            fetches the rows of 64/G children (16 at SH degree 3).
+//            fetches the rows of 64/G children (16 at SH degree 3); MSTEP_U rounds are in flight together (with a single
+//            round the loop was a chain of dependent L2 round trips: five per 66-child parent, measured 1.3 ms of 3.4).
 //   sums     across lanes by DPP row rotations and v_permlane16/32_swap (class_sum): no LDS-crossbar traffic.
 //   output   the SH row leaves through LDS as one coalesced store.
 // (History: one parent per wave with a dependent round trip per phase, SH rows four children per load and butterfly sums by
@@ -1210,7 +1211,7 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
 #define MSTEP_CHUNK 256
 #define MSTEP_NV 3            // float4 per lane and SH row
 #define MSTEP_K 4             // parents per wavefront
-#define MSTEP_PF 2            // pair records per lane prefetched for the next parent (covers 128 pairs)
+#define MSTEP_U 3             // rounds of SH row loads in flight (each: MSTEP_NV float4 per lane, 64/G children)
 
 // G = lanes per SH row (power of two, G * MSTEP_NV float4 >= RSH / 4); G == 0: no SH at all
 template <int G, int WPB>
@@ -1218,12 +1219,14 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ float s_w_[WPB][MSTEP_CHUNK];
     __shared__ unsigned s_j_[WPB][MSTEP_CHUNK];
     __shared__ float4 s_acc_[WPB][MSTEP_NV * 64];               // per-lane SH partial sums of a parent with more than MSTEP_CHUNK pairs
+    __shared__ float s_mom_[WPB][16];                           // the 14 moment sums of the parent
     constexpr int GG = G > 0 ? G : 1;
     constexpr int CPR = 64 / GG;                                // children per round
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* s_w = s_w_[wv];
     unsigned* s_j = s_j_[wv];
     float4* s_acc = s_acc_[wv];
+    float* s_mom = s_mom_[wv];
     float* s_out = reinterpret_cast<float*>(s_acc);             // at the end of a parent: its SH row on the way out
     const int gl = lane & (GG - 1), grp = lane / GG;
     constexpr int KB = MSTEP_K * WPB;                           // parents per workgroup: consecutive slots, neighbours in space
@@ -1239,117 +1242,88 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
 #pragma unroll
     for (int v = 0; v < MSTEP_NV; ++v) qi[v] = gl + GG * v < nq ? gl + GG * v : 0;
 
-    // pair records of the first parent
-    unsigned pfj[MSTEP_PF];
-    float pfw[MSTEP_PF];
-    {
-        const MstepHeader h = a.hdr[s0];
-#pragma unroll
-        for (int t = 0; t < MSTEP_PF; ++t) {
-            const unsigned k = lane + 64 * t;
-            const unsigned kc = h.oslot >= 0 && k < h.cnt ? k : 0u;
-            pfj[t] = h.cnt > 0 ? a.pair_child[h.off + kc] : 0u;
-            pfw[t] = h.cnt > 0 ? a.pair_wl[h.off + kc] : 0.0f;
-        }
-    }
     for (int it = 0; it < ns; ++it) {
         const MstepHeader h = a.hdr[s0 + it];                   // uniform address: scalar loads
-        const f3 pm = {h.px, h.py, h.pz};
-        const unsigned cnt = h.oslot >= 0 ? h.cnt : 0u;
-        unsigned curj[MSTEP_PF];
-        float curw[MSTEP_PF];
-#pragma unroll
-        for (int t = 0; t < MSTEP_PF; ++t) { curj[t] = pfj[t]; curw[t] = pfw[t]; }
-        if (it + 1 < ns) {                                      // prefetch the next parent's pairs (wave-uniform branch)
-            const MstepHeader hn = a.hdr[s0 + it + 1];
-#pragma unroll
-            for (int t = 0; t < MSTEP_PF; ++t) {
-                const unsigned k = lane + 64 * t;
-                const unsigned kc = hn.oslot >= 0 && k < hn.cnt ? k : 0u;
-                pfj[t] = hn.cnt > 0 ? a.pair_child[hn.off + kc] : 0u;
-                pfw[t] = hn.cnt > 0 ? a.pair_wl[hn.off + kc] : 0.0f;
-            }
-        }
         if (h.oslot < 0) continue;
-
-        float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
-        float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
-        // SH sums: local to a chunk of pairs (so that they occupy no registers during part 1); a parent with more than
-        // MSTEP_CHUNK pairs (rare) carries its per-lane partial sums from chunk to chunk in LDS
+        const f3 pm = {h.px, h.py, h.pz};
+        const unsigned cnt = h.cnt;
+        if (lane < 16) s_mom[lane] = 0.0f;
+        // SH sums: local to a chunk of pairs (they occupy no registers during part 1); a parent with more than MSTEP_CHUNK
+        // pairs (rare) carries its per-lane partial sums from chunk to chunk in LDS
         float4 acc[MSTEP_NV];
+#pragma unroll
+        for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         const bool multi = cnt > MSTEP_CHUNK;
 
         for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
             const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
-            // child indices to LDS first: the SH row loads need nothing else
-#pragma nounroll
-            for (unsigned k = lane, t = 0; k < cn; k += 64, ++t) {
-                unsigned j;
-                if (c0 == 0 && t < MSTEP_PF) j = t == 0 ? curj[0] : curj[MSTEP_PF - 1];
-                else j = a.pair_child[h.off + c0 + k];
-                s_j[k] = j;
-            }
-            __builtin_amdgcn_wave_barrier();
-            // first round of SH rows in flight while part 1 runs
-            float4 rowv[MSTEP_NV];
-            if (G > 0) {
-                const unsigned k = grp;
-                const unsigned j = s_j[k < cn ? k : cn - 1];
-                const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
-#pragma unroll
-                for (int v = 0; v < MSTEP_NV; ++v) rowv[v] = row[qi[v]];
-            }
             // part 1
+            {
+                float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
+                float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
 #pragma nounroll
-            for (unsigned k = lane, t = 0; k < cn; k += 64, ++t) {
-                const unsigned j = s_j[k];
-                float wl;
-                if (c0 == 0 && t < MSTEP_PF) wl = t == 0 ? curw[0] : curw[MSTEP_PF - 1];
-                else wl = a.pair_wl[h.off + c0 + k];
-                const float4* row = a.geo + 4 * (int64_t)j;
-                const float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];
-                const float sl = cd.w;                         // sumLw_i: k_bucket_sum stored it in the record (in place of det)
-                float w = 0.0f;
-                if (sl != 0.0f) {                              // sumLw == 0: skipped (mixture.cpp:190)
-                    const float r_is = wl / sl;                // mixture.cpp:196
-                    w = r_is * cd.z;                           // * child.weight (:197)
-                    const f3 cm = {ca.x, ca.y, ca.z};
-                    const f3 d = sub3(cm, pm);
-                    w_s += w;
-                    smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
-                    scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
-                    v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
-                    v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
-                    so += w * cd.y;
+                for (unsigned k = lane; k < cn; k += 64) {
+                    const unsigned j = a.pair_child[h.off + c0 + k];
+                    const float wl = a.pair_wl[h.off + c0 + k];
+                    const float4* row = a.geo + 4 * (int64_t)j;
+                    const float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];
+                    const float sl = cd.w;                     // sumLw_i: k_bucket_sum stored it in the record (in place of det)
+                    float w = 0.0f;
+                    if (sl != 0.0f) {                          // sumLw == 0: skipped (mixture.cpp:190)
+                        const float r_is = wl / sl;            // mixture.cpp:196
+                        w = r_is * cd.z;                       // * child.weight (:197)
+                        const f3 cm = {ca.x, ca.y, ca.z};
+                        const f3 d = sub3(cm, pm);
+                        w_s += w;
+                        smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
+                        scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
+                        v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
+                        v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
+                        so += w * cd.y;
+                    }
+                    s_w[k] = w;
+                    s_j[k] = j;
                 }
-                s_w[k] = w;
+                // the chunk's 14 sums over the lanes, then out of the registers (part 2 needs them for its row loads)
+                w_s = class_sum<1>(w_s);
+                smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
+                scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
+                v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
+                v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
+                so = class_sum<1>(so);
+                if (lane == 0) {
+                    s_mom[0] += w_s; s_mom[1] += smx; s_mom[2] += smy; s_mom[3] += smz; s_mom[4] += scx; s_mom[5] += scy; s_mom[6] += scz;
+                    s_mom[7] += v00; s_mom[8] += v01; s_mom[9] += v02; s_mom[10] += v11; s_mom[11] += v12; s_mom[12] += v22; s_mom[13] += so;
+                }
             }
             __builtin_amdgcn_wave_barrier();
-            // part 2: children in pair order; a skipped child has w = 0 (its row is loaded all the same: no branch per load)
+            // part 2: children in pair order, MSTEP_U rounds of row loads in flight; a skipped child has w = 0 (its row is
+            // loaded all the same: no branch per load)
             if (G > 0) {
-#pragma unroll
-                for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 if (multi && c0 > 0) {
 #pragma unroll
                     for (int v = 0; v < MSTEP_NV; ++v) acc[v] = s_acc[v * 64 + lane];
                 }
-                for (unsigned k0 = 0; k0 < cn; k0 += CPR) {
-                    const unsigned k = k0 + grp;
-                    const float wk = k < cn ? s_w[k < cn ? k : cn - 1] : 0.0f;
-                    float4 cur[MSTEP_NV];
+                for (unsigned k0 = 0; k0 < cn; k0 += CPR * MSTEP_U) {
+                    float4 rowv[MSTEP_U][MSTEP_NV];
+                    float wv_[MSTEP_U];
 #pragma unroll
-                    for (int v = 0; v < MSTEP_NV; ++v) cur[v] = rowv[v];
-                    if (k0 + CPR < cn) {                        // next round's rows (wave-uniform branch)
-                        const unsigned kn = k + CPR;
-                        const unsigned j = s_j[kn < cn ? kn : cn - 1];
+                    for (int u = 0; u < MSTEP_U; ++u) {
+                        const unsigned k = k0 + CPR * u + grp;
+                        const unsigned kc = k < cn ? k : cn - 1;    // unconditional LDS reads and loads
+                        const unsigned j = s_j[kc];
+                        wv_[u] = k < cn ? s_w[kc] : 0.0f;
                         const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
 #pragma unroll
-                        for (int v = 0; v < MSTEP_NV; ++v) rowv[v] = row[qi[v]];
+                        for (int v = 0; v < MSTEP_NV; ++v) rowv[u][v] = row[qi[v]];
                     }
 #pragma unroll
-                    for (int v = 0; v < MSTEP_NV; ++v) {
-                        acc[v].x = __builtin_fmaf(cur[v].x, wk, acc[v].x); acc[v].y = __builtin_fmaf(cur[v].y, wk, acc[v].y);
-                        acc[v].z = __builtin_fmaf(cur[v].z, wk, acc[v].z); acc[v].w = __builtin_fmaf(cur[v].w, wk, acc[v].w);
+                    for (int u = 0; u < MSTEP_U; ++u) {
+#pragma unroll
+                        for (int v = 0; v < MSTEP_NV; ++v) {
+                            acc[v].x = __builtin_fmaf(rowv[u][v].x, wv_[u], acc[v].x); acc[v].y = __builtin_fmaf(rowv[u][v].y, wv_[u], acc[v].y);
+                            acc[v].z = __builtin_fmaf(rowv[u][v].z, wv_[u], acc[v].z); acc[v].w = __builtin_fmaf(rowv[u][v].w, wv_[u], acc[v].w);
+                        }
                     }
                 }
                 if (multi && c0 + MSTEP_CHUNK < cnt) {
@@ -1359,40 +1333,36 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
         }
-        w_s = class_sum<1>(w_s);
-        smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
-        scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
-        v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
-        v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
-        so = class_sum<1>(so);
-
+        const float w_s = s_mom[0];
         const float inv_w = 1.0f / w_s;                        // mixture.cpp:209
         const int64_t slot = h.oslot;
-        if (lane == 0) {
-            const float mx = smx * inv_w, my = smy * inv_w, mz = smz * inv_w;
+        {
+            // the 14 geometry outputs leave with ONE store instruction: lane t < 14 computes output t and stores it to its own
+            // array (a vector-memory instruction costs the CU ~30 cycles whatever its lane count; 14 one-lane stores per
+            // parent were a third of this kernel's memory instructions)
+            const float mx = s_mom[1] * inv_w, my = s_mom[2] * inv_w, mz = s_mom[3] * inv_w;
             const float dx = mx - pm.x, dy = my - pm.y, dz = mz - pm.z;
-            a.o_xyz[3 * slot] = mx; a.o_xyz[3 * slot + 1] = my; a.o_xyz[3 * slot + 2] = mz;
-            a.o_color[3 * slot] = scx * inv_w; a.o_color[3 * slot + 1] = scy * inv_w; a.o_color[3 * slot + 2] = scz * inv_w;
-            a.o_cov6[6 * slot] = v00 * inv_w - dx * dx;
-            a.o_cov6[6 * slot + 1] = v01 * inv_w - dx * dy;
-            a.o_cov6[6 * slot + 2] = v02 * inv_w - dx * dz;
-            a.o_cov6[6 * slot + 3] = v11 * inv_w - dy * dy;
-            a.o_cov6[6 * slot + 4] = v12 * inv_w - dy * dz;
-            a.o_cov6[6 * slot + 5] = v22 * inv_w - dz * dz;
-            a.o_opacity[slot] = inv_w * so;
-            a.o_weight[slot] = w_s;
+            float val = w_s;                                                         // lane 13: weight
+            float* dst = a.o_weight + slot;
+            if (lane < 3) { val = lane == 0 ? mx : (lane == 1 ? my : mz); dst = a.o_xyz + 3 * slot + lane; }
+            else if (lane < 6) { val = s_mom[4 + (lane - 3)] * inv_w; dst = a.o_color + 3 * slot + (lane - 3); }
+            else if (lane < 12) {
+                const int t = lane - 6;                                              // xx xy xz yy yz zz
+                const float da = t < 3 ? dx : (t < 5 ? dy : dz);
+                const float db = t == 0 ? dx : (t == 1 || t == 3 ? dy : dz);
+                val = s_mom[7 + t] * inv_w - da * db;                                // mixture.cpp:211-212,236-238
+                dst = a.o_cov6 + 6 * slot + t;
+            } else if (lane == 12) { val = inv_w * s_mom[13]; dst = a.o_opacity + slot; }
+            if (lane < 14) *dst = val;
         }
         if (G > 0) {
-            if (cnt == 0) {                                     // no child at all (zero or NaN radius): 0 / 0 like the reference
-#pragma unroll
-                for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            }
 #pragma unroll
             for (int v = 0; v < MSTEP_NV; ++v) {
                 acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
                 acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
             }
             // the row leaves through LDS: F consecutive floats, one coalesced store per 64
+            __builtin_amdgcn_wave_barrier();
             if (grp == 0) {
 #pragma unroll
                 for (int v = 0; v < MSTEP_NV; ++v) {
@@ -1403,8 +1373,8 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
             }
             __builtin_amdgcn_wave_barrier();
             for (int f = lane; f < a.F; f += 64) a.o_sh[slot * a.F + f] = s_out[f];
-            __builtin_amdgcn_wave_barrier();
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -1429,22 +1399,14 @@ __global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigne
         oslot_sorted[j] = slot;
     }
 }
+// SH rows of the orphans: one thread per component (orphans are rare -- 0.04 % at the bench density -- so a thread per
+// (component, coefficient) spent its time finding out that there was nothing to copy)
 __global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int RSH, const int64_t* __restrict__ oslot_sorted,
                                                     const float* __restrict__ shs, float* __restrict__ o_sh) {
-    const int64_t total = n * F;
-    if (total < ((int64_t)1 << 31)) {
-        const unsigned tot = (unsigned)total, step = gridDim.x * blockDim.x, uF = (unsigned)F;
-        for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < tot; t += step) {
-            const unsigned j = t / uF, f = t - j * uF;
-            const int64_t slot = oslot_sorted[j];
-            if (slot >= 0) o_sh[slot * F + f] = shs[(int64_t)j * RSH + f];
-        }
-        return;
-    }
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t j = t / F;
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = oslot_sorted[j];
-        if (slot >= 0) o_sh[slot * F + (t - j * F)] = shs[j * RSH + (t - j * F)];
+        if (slot < 0) continue;
+        for (int f = 0; f < F; ++f) o_sh[slot * F + f] = shs[j * RSH + f];
     }
 }
 
@@ -2330,7 +2292,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                        c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
                        O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>());
     if (F > 0 && n_orph > 0)
-        hipLaunchKernelGGL(k_orphans_sh, dim3(stride_grid(n * F)), blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
+        hipLaunchKernelGGL(k_orphans_sh, grd, blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
     if (sharded && P > 0) {
         // exchange 2: the merged components.  Every rank packs the rows of ITS parents, ONE all-gather of equal chunks
         // (ceil(P / world) rows of 14 + F floats) moves them, and every rank scatters every chunk into the output rows
