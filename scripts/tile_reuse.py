@@ -5,7 +5,7 @@ For the bench cloud (SURVEY 8(d) generator, constant density) at level 1: parent
 parents along the Z-order curve the kernel already processes them in; a tile's LDS image would hold the UNION of the
 candidate sets (all components within the query radius R_s = delta sqrt(lambda_max) of some parent of the tile, what
 stage 1 streams).  Reported per tile size: the union (records and bytes at 16 B), the sum of the per-parent sets, and
-their ratio = how often a staged record would be re-used.  CPU only (scipy cKDTree); run on a sub-box of the cloud.
+their ratio = how often a staged record would be re-used; then the same for the ACCEPTED children (the M-step's gathers).  CPU only (scipy cKDTree); run on a sub-box of the cloud.
 
     python scripts/tile_reuse.py [n_splats=400000]  > profiles/r02_tile_reuse.txt
 """
@@ -43,6 +43,24 @@ def spread(v):
 key = spread(q[:, 0]) | (spread(q[:, 1]) << 1) | (spread(q[:, 2]) << 2)
 pz = pidx[np.argsort(key, kind="stable")]
 rng = np.random.default_rng(0)
+def accepted_sets(ps):
+    """Children parent s accepts (float64 restatement of the gates of mixture.cpp:102-137: radius, colour, KL, parent rule)."""
+    out = []
+    C = np.stack([c["cov6"][:, [0, 1, 2]], c["cov6"][:, [1, 3, 4]], c["cov6"][:, [2, 4, 5]]], 1).astype(np.float64)
+    col = c["color"].astype(np.float64)
+    for p in ps:
+        cand = np.array(tree.query_ball_point(xyz[p], R[p]))
+        cand = cand[np.linalg.norm(xyz[cand] - xyz[p], axis=1) < R[p]]
+        Pinv = np.linalg.inv(C[p])
+        d = xyz[cand] - xyz[p]
+        smd = np.einsum("ni,ij,nj->n", d, Pinv, d)
+        tr = np.einsum("ij,nji->n", Pinv, C[cand])
+        kld = 0.5 * (smd + tr - 3 - np.log(np.linalg.det(C[cand]) / np.linalg.det(C[p])))
+        ok = (np.linalg.norm(col[cand] - col[p], axis=1) <= 2.5 ** 2 / 2) & (kld <= 4.5) & (~par[cand] | (cand == p))
+        out.append(set(cand[ok].tolist()))
+    return out
+
+
 print(f"# {n} splats, {len(pidx)} parents, density {n / (2 * h) ** 3:.0f} / unit^3, mean R {R[par].mean():.3f}, "
       f"median {np.median(R[par]):.3f}, 99th pct {np.percentile(R[par], 99):.3f}")
 print("# tile = T consecutive parents in Z-order; union / sum of the parents' candidate sets (sphere of radius R_s)")
@@ -59,3 +77,16 @@ for T in (4, 8, 16, 32, 64, 128, 256):
     fits = (unions * 16 <= 160 * 1024).mean()
     print(f"{T:5d} {sums.mean():12.0f} {unions.mean():9.0f} {sums.mean() / unions.mean():7.2f} {unions.mean() * 16:27.0f} "
           f"{'yes' if unions.mean() * 16 <= 160 * 1024 else 'no':>13} {100 * fits:22.0f}%")
+
+print()
+print("# the same for the ACCEPTED children (what the M-step gathers: one 64-B geometry record + one 192-B SH row per pair)")
+print(f"{'T':>5} {'pairs':>9} {'distinct':>9} {'re-use':>7} {'LDS bytes (256 B per child)':>28}")
+for T in (8, 16, 32, 64):
+    starts = rng.choice(max(1, len(pz) - T), size=40, replace=False)
+    sums, unions = [], []
+    for s0 in starts:
+        sets = accepted_sets(pz[s0:s0 + T])
+        sums.append(sum(len(x) for x in sets))
+        unions.append(len(set().union(*sets)))
+    sums, unions = np.array(sums), np.array(unions)
+    print(f"{T:5d} {sums.mean():9.0f} {unions.mean():9.0f} {sums.mean() / unions.mean():7.2f} {unions.mean() * 256:28.0f}")
