@@ -1185,7 +1185,6 @@ struct MstepArgs {
     const float* shs;
     int RSH;                   // row stride of shs in floats (F rounded up to 4)
     const MstepHeader* hdr;    // [P], processing order
-    int slot0, nslots;         // this launch handles processing slots [slot0, slot0 + nslots)
     int xcd;
     const int* nheavy;
     const unsigned* pair_child;
@@ -1231,14 +1230,13 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     float* s_out = reinterpret_cast<float*>(s_acc);             // at the end of a parent: its SH row on the way out
     const int gl = lane & (GG - 1), grp = lane / GG;
     constexpr int KB = MSTEP_K * WPB;                           // parents per workgroup: consecutive slots, neighbours in space
-    const int nblk = (a.nslots + KB - 1) / KB;
+    const int nblk = (a.P + KB - 1) / KB;
     const int hbk = a.nheavy ? (((*a.nheavy + KB - 1) / KB + 7) & ~7) : 0;
     const int bid = block_slot((int)blockIdx.x, nblk, hbk < nblk ? hbk : nblk, a.xcd);
     if (bid < 0) return;
-    const int sl = bid * KB + wv * MSTEP_K;
-    if (sl >= a.nslots) return;
-    const int s0 = a.slot0 + sl;
-    const int ns = a.nslots - sl < MSTEP_K ? a.nslots - sl : MSTEP_K;     // parents of this wave
+    const int s0 = bid * KB + wv * MSTEP_K;
+    if (s0 >= a.P) return;
+    const int ns = a.P - s0 < MSTEP_K ? a.P - s0 : MSTEP_K;     // parents of this wave
     const int nq = a.RSH >> 2;                                  // float4 per SH row
     int qi[MSTEP_NV];                                           // float4 slots of this lane (slots beyond the row: re-read slot 0, discarded)
 #pragma unroll
@@ -1376,255 +1374,6 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
             __builtin_amdgcn_wave_barrier();
             for (int f = lane; f < a.F; f += 64) a.o_sh[slot * a.F + f] = s_out[f];
         }
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_mstep_tile: the M-step with the children of a TILE of neighbouring parents staged in LDS (SH degree <= 3).
-//
-// Neighbouring parents claim the same children: 16 consecutive parents of the Z-order have 974 pairs on 436 distinct
-// children (scripts/tile_reuse.py), and k_mstep is bound by the L2 -> CU bandwidth of its 256 bytes per PAIR.  Here one
-// workgroup takes a tile of MT_T parents and
-//   A  inserts the child index of every pair into an LDS hash set (atomicCAS, linear probing), remembering the slot per pair;
-//   B  numbers the occupied slots (block-wide scan): row index per slot, child per row;
-//   C  stages the 256-byte record of every distinct child -- the 64-byte geometry record and the SH row -- into LDS ONCE
-//      (16 lanes per row, all loads independent);
-//   D  runs parts 1 and 2 of k_mstep with every gather served from LDS.
-// Children beyond the LDS capacity, and pairs beyond MT_PAIRS of one parent, fall back to the global loads of k_mstep.
-// Heavy parents (the head of the processing order) stay with k_mstep.
-// ------------------------------------------------------------------------------------------------
-#define MT_PP 2                 // parents per wavefront
-#define MT_PAIRS 256            // pairs per parent whose row slot is remembered in LDS
-#define MT_H 1024               // hash slots
-#define MT_ROWF 68              // floats per staged row: 64 + 4 of padding (rows start 4 banks apart)
-#define MT_EMPTY 0xffffffffu
-static constexpr size_t mstep_tile_lds(int tw, int cap) {
-    return (size_t)cap * MT_ROWF * 4 + MT_H * 4 * 2 + (size_t)tw * MT_PAIRS * 4 + tw * 16 * 4 + tw * 64 * 4 + 16 * 4 + MT_H * 2 +
-           (size_t)tw * MT_PP * MT_PAIRS * 2 + tw * MT_PAIRS * 2;
-}
-
-template <int TW>               // wavefronts per workgroup; tile = TW * MT_PP parents
-__global__ __launch_bounds__(64 * TW) void k_mstep_tile(MstepArgs a, int cap_rows) {
-    // every LDS array lives in the dynamic region, carved at multiples of 16 bytes: static arrays in front of it would
-    // shift its base off 16 bytes and every ds_read_b128 of a row would be replayed
-    extern __shared__ __attribute__((aligned(16))) char s_tile[];
-    float* s_rows = reinterpret_cast<float*>(s_tile);                                   // [cap_rows][MT_ROWF]
-    unsigned* s_key = reinterpret_cast<unsigned*>(s_rows + (size_t)cap_rows * MT_ROWF); // [MT_H]
-    unsigned* s_rowj = s_key + MT_H;                                                    // [MT_H]
-    float* s_w_all = reinterpret_cast<float*>(s_rowj + MT_H);                           // [TW][MT_PAIRS]
-    float* s_mom_all = s_w_all + TW * MT_PAIRS;                                         // [TW][16]
-    float* s_out_all = s_mom_all + TW * 16;                                             // [TW][64]
-    int* s_wtot = reinterpret_cast<int*>(s_out_all + TW * 64);                          // [16]
-    unsigned short* s_ridx = reinterpret_cast<unsigned short*>(s_wtot + 16);            // [MT_H]
-    unsigned short* s_pslot_all = s_ridx + MT_H;                                        // [TW][MT_PP][MT_PAIRS]
-    unsigned short* s_r_all = s_pslot_all + TW * MT_PP * MT_PAIRS;                      // [TW][MT_PAIRS]
-    constexpr int T = TW * MT_PP;
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    const int gl = lane & 3, grp = lane >> 2;
-    const int ntile = (a.nslots + T - 1) / T;
-    const int tb = xcd_remap((int)blockIdx.x, ntile);
-    if (tb < 0) return;
-    const int t0 = a.slot0 + tb * T;
-    const int tn = a.slot0 + a.nslots - t0 < T ? a.slot0 + a.nslots - t0 : T;       // parents of this tile
-
-    for (int i = tid; i < MT_H; i += 64 * TW) s_key[i] = MT_EMPTY;
-    __syncthreads();
-    // A: hash set of the tile's children
-    for (int q = 0; q < MT_PP; ++q) {
-        const int pi = wv * MT_PP + q;
-        if (pi >= tn) break;
-        const MstepHeader h = a.hdr[t0 + pi];
-        if (h.oslot < 0) continue;
-        const unsigned cn = h.cnt < MT_PAIRS ? h.cnt : MT_PAIRS;
-        for (unsigned k = lane; k < cn; k += 64) {
-            const unsigned j = a.pair_child[h.off + k];
-            unsigned hs = (j * 2654435761u) >> 22;              // 10 bits
-            unsigned slot = 0xffffu;
-            for (int probe = 0; probe < 24; ++probe) {
-                const unsigned old = atomicCAS(&s_key[hs], MT_EMPTY, j);
-                if (old == MT_EMPTY || old == j) { slot = hs; break; }
-                hs = (hs + 1) & (MT_H - 1);
-            }
-            s_pslot_all[(wv * MT_PP + q) * MT_PAIRS + k] = (unsigned short)slot;
-        }
-    }
-    __syncthreads();
-    // B: number the occupied slots
-    {
-        constexpr int PER = MT_H / (64 * TW);                   // slots per thread (a contiguous run)
-        int occ = 0;
-        for (int i = 0; i < PER; ++i) occ += s_key[tid * PER + i] != MT_EMPTY ? 1 : 0;
-        int incl = occ;                                         // wave-inclusive scan by DPP
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, false);
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, false);
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xf, false);
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xf, false);
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, false);
-        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, false);
-        if (lane == 63) s_wtot[wv] = incl;
-        __syncthreads();
-        int base = 0;
-        for (int w = 0; w < wv; ++w) base += s_wtot[w];
-        int r = base + incl - occ;
-        for (int i = 0; i < PER; ++i) {
-            const int sidx = tid * PER + i;
-            const unsigned j = s_key[sidx];
-            if (j != MT_EMPTY) {
-                if (r < cap_rows) { s_ridx[sidx] = (unsigned short)r; s_rowj[r] = j; }
-                else s_ridx[sidx] = 0xffffu;
-                ++r;
-            } else s_ridx[sidx] = 0xffffu;
-        }
-        if (tid == 64 * TW - 1) s_wtot[TW] = r < cap_rows ? r : cap_rows;
-    }
-    __syncthreads();
-    // C: stage the rows (16 lanes per row: float4 0..3 = geometry record, 4..15 = SH row)
-    {
-        const int nrows = s_wtot[TW];
-        const int sub = lane & 15, rl = lane >> 4;
-        for (int r0 = wv * 4; r0 < nrows; r0 += TW * 4 * 4) {
-            float4 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * TW * 4 + rl;
-                const unsigned j = s_rowj[r < nrows ? r : 0];
-                const float4* src = sub < 4 ? a.geo + 4 * (int64_t)j + sub : reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH) + (sub - 4);
-                v[u] = *src;
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = r0 + u * TW * 4 + rl;
-                if (r < nrows) *reinterpret_cast<float4*>(s_rows + r * MT_ROWF + 4 * sub) = v[u];
-            }
-        }
-    }
-    __syncthreads();
-    // D: the M-step of this wave's parents
-    float* s_w = s_w_all + wv * MT_PAIRS;
-    unsigned short* s_r = s_r_all + wv * MT_PAIRS;
-    float* s_mom = s_mom_all + wv * 16;
-    float* s_out = s_out_all + wv * 64;
-    for (int q = 0; q < MT_PP; ++q) {
-        const int pi = wv * MT_PP + q;
-        if (pi >= tn) break;
-        const MstepHeader h = a.hdr[t0 + pi];
-        if (h.oslot < 0) continue;
-        const f3 pm = {h.px, h.py, h.pz};
-        const unsigned cnt = h.cnt;
-        if (lane < 16) s_mom[lane] = 0.0f;
-        float4 acc[3];
-#pragma unroll
-        for (int v = 0; v < 3; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        for (unsigned c0 = 0; c0 < cnt; c0 += MT_PAIRS) {
-            const unsigned cn = (cnt - c0) < MT_PAIRS ? (cnt - c0) : MT_PAIRS;
-            {
-                float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
-                float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
-#pragma nounroll
-                for (unsigned k = lane; k < cn; k += 64) {
-                    const float wl = a.pair_wl[h.off + c0 + k];
-                    unsigned r = 0xffffu;
-                    if (c0 == 0) { const unsigned ps = s_pslot_all[(wv * MT_PP + q) * MT_PAIRS + k]; if (ps != 0xffffu) r = s_ridx[ps]; }
-                    float4 ca, cb, cc, cd;
-                    unsigned jg = 0;
-                    if (r != 0xffffu) {
-                        const float4* row = reinterpret_cast<const float4*>(s_rows + r * MT_ROWF);
-                        ca = row[0]; cb = row[1]; cc = row[2]; cd = row[3];
-                    } else {                                    // not staged: the global gather of k_mstep
-                        jg = a.pair_child[h.off + c0 + k];
-                        const float4* row = a.geo + 4 * (int64_t)jg;
-                        ca = row[0]; cb = row[1]; cc = row[2]; cd = row[3];
-                    }
-                    const float sl = cd.w;                     // sumLw_i
-                    float w = 0.0f;
-                    if (sl != 0.0f) {
-                        const float r_is = wl / sl;            // mixture.cpp:196
-                        w = r_is * cd.z;                       // * child.weight (:197)
-                        const f3 cm = {ca.x, ca.y, ca.z};
-                        const f3 d = sub3(cm, pm);
-                        w_s += w;
-                        smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
-                        scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
-                        v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
-                        v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
-                        so += w * cd.y;
-                    }
-                    s_w[k] = w;
-                    s_r[k] = (unsigned short)r;
-                }
-                w_s = class_sum<1>(w_s);
-                smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
-                scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
-                v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
-                v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
-                so = class_sum<1>(so);
-                if (lane == 0) {
-                    s_mom[0] += w_s; s_mom[1] += smx; s_mom[2] += smy; s_mom[3] += smz; s_mom[4] += scx; s_mom[5] += scy; s_mom[6] += scz;
-                    s_mom[7] += v00; s_mom[8] += v01; s_mom[9] += v02; s_mom[10] += v11; s_mom[11] += v12; s_mom[12] += v22; s_mom[13] += so;
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-            // part 2: 4 lanes x 3 float4 per child, 16 children per round
-            for (unsigned k0 = 0; k0 < cn; k0 += 16) {
-                const unsigned k = k0 + grp;
-                const unsigned kc = k < cn ? k : cn - 1;
-                const float wk = k < cn ? s_w[kc] : 0.0f;
-                const unsigned r = s_r[kc];
-                float4 rv[3];
-                if (r != 0xffffu) {
-                    const float4* row = reinterpret_cast<const float4*>(s_rows + r * MT_ROWF + 16);
-#pragma unroll
-                    for (int v = 0; v < 3; ++v) rv[v] = row[gl + 4 * v];
-                } else {
-                    const unsigned jg = a.pair_child[h.off + c0 + kc];
-                    const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)jg * a.RSH);
-#pragma unroll
-                    for (int v = 0; v < 3; ++v) rv[v] = row[gl + 4 * v];
-                }
-#pragma unroll
-                for (int v = 0; v < 3; ++v) {
-                    acc[v].x = __builtin_fmaf(rv[v].x, wk, acc[v].x); acc[v].y = __builtin_fmaf(rv[v].y, wk, acc[v].y);
-                    acc[v].z = __builtin_fmaf(rv[v].z, wk, acc[v].z); acc[v].w = __builtin_fmaf(rv[v].w, wk, acc[v].w);
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        const float w_s = s_mom[0];
-        const float inv_w = 1.0f / w_s;                        // mixture.cpp:209
-        const int64_t slot = h.oslot;
-        {
-            const float mx = s_mom[1] * inv_w, my = s_mom[2] * inv_w, mz = s_mom[3] * inv_w;
-            const float dx = mx - pm.x, dy = my - pm.y, dz = mz - pm.z;
-            float val = w_s;
-            float* dst = a.o_weight + slot;
-            if (lane < 3) { val = lane == 0 ? mx : (lane == 1 ? my : mz); dst = a.o_xyz + 3 * slot + lane; }
-            else if (lane < 6) { val = s_mom[4 + (lane - 3)] * inv_w; dst = a.o_color + 3 * slot + (lane - 3); }
-            else if (lane < 12) {
-                const int t = lane - 6;
-                const float da = t < 3 ? dx : (t < 5 ? dy : dz);
-                const float db = t == 0 ? dx : (t == 1 || t == 3 ? dy : dz);
-                val = s_mom[7 + t] * inv_w - da * db;
-                dst = a.o_cov6 + 6 * slot + t;
-            } else if (lane == 12) { val = inv_w * s_mom[13]; dst = a.o_opacity + slot; }
-            if (lane < 14) *dst = val;
-        }
-#pragma unroll
-        for (int v = 0; v < 3; ++v) {
-            acc[v].x = class_sum<4>(acc[v].x); acc[v].y = class_sum<4>(acc[v].y);
-            acc[v].z = class_sum<4>(acc[v].z); acc[v].w = class_sum<4>(acc[v].w);
-        }
-        __builtin_amdgcn_wave_barrier();
-        if (grp == 0) {
-#pragma unroll
-            for (int v = 0; v < 3; ++v) {
-                const int f0 = 4 * (gl + 4 * v);
-                s_out[f0] = acc[v].x * inv_w; s_out[f0 + 1] = acc[v].y * inv_w;
-                s_out[f0 + 2] = acc[v].z * inv_w; s_out[f0 + 3] = acc[v].w * inv_w;
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        for (int f = lane; f < a.F; f += 64) a.o_sh[slot * a.F + f] = s_out[f];
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -2074,9 +1823,6 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_BUCKET * 12);
-    (void)hipFuncSetAttribute((const void*)k_mstep_tile<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mstep_tile_lds(8, 448));
-    (void)hipFuncSetAttribute((const void*)k_mstep_tile<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mstep_tile_lds(4, 208));
-    (void)hipFuncSetAttribute((const void*)k_mstep_tile<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)mstep_tile_lds(2, 112));
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 12 + 8);
     *out = c;
@@ -2364,17 +2110,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(rocprim::transform(cnt, cnt64, (size_t)count, [] __device__(unsigned v) { return (int64_t)v; }, st));
         return exclusive_scan<int64_t>(c, cnt64, off, count);
     };
-    int nheavy_host = 0;
     auto total_of = [&](const int64_t* off, const unsigned* cnt, int64_t count, int64_t* out) -> int32_t {
         Collect q;
-        q.n = 3;
+        q.n = 2;
         q.src[0] = off + (count - 1); q.bytes[0] = 8;
         q.src[1] = cnt + (count - 1); q.bytes[1] = 4;
-        q.src[2] = c->counters.as<int>() + 8; q.bytes[2] = 4;       // heavy parents at the head of the processing order
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
         *out = (int64_t)w[0] + (int64_t)(unsigned)w[1];
-        nheavy_host = (int)(unsigned)w[2];
         return GSR_OK;
     };
     c->sparse_path = false;
@@ -2535,14 +2278,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         // one wavefront per workgroup: consecutive parents on one CU share no cache lines in time (2 / 4 / 8 waves per workgroup
         // were measured 1 / 10 / 24 % slower)
         const int nq = RSH >> 2;                                // float4 per SH row; a lane covers MSTEP_NV of them
-        int tile_mode = 0;
-        if (const char* e = getenv("GSR_HEM_MSTEP_TILE")) tile_mode = atoi(e);
-        const bool tiled = tile_mode > 0 && nq == 12 && mporder != nullptr && !sharded;
-        int head = P;                                           // slots [0, head): k_mstep; [head, P): k_mstep_tile
-        if (tiled) { head = (nheavy_host + 7) & ~7; if (head > P) head = P; }
-        ma.slot0 = 0; ma.nslots = head;
-        if (tiled) { ma.xcd = 0; ma.nheavy = nullptr; }
-#define GSR_LAUNCH_MSTEP(G) if (ma.nslots > 0) hipLaunchKernelGGL((k_mstep<G, 1>), dim3(8 * ceil_div(ceil_div(ma.nslots, MSTEP_K), 8)), dim3(64), 0, st, ma);
+#define GSR_LAUNCH_MSTEP(G) hipLaunchKernelGGL((k_mstep<G, 1>), dim3(8 * ceil_div(ceil_div(P, MSTEP_K), 8)), dim3(64), 0, st, ma);
         if (nq == 0) { GSR_LAUNCH_MSTEP(0) }
         else if (nq <= 1 * MSTEP_NV) { GSR_LAUNCH_MSTEP(1) }
         else if (nq <= 2 * MSTEP_NV) { GSR_LAUNCH_MSTEP(2) }
@@ -2551,16 +2287,6 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         else if (nq <= 16 * MSTEP_NV) { GSR_LAUNCH_MSTEP(16) }
         else { GSR_LAUNCH_MSTEP(32) }      // F <= 384
 #undef GSR_LAUNCH_MSTEP
-        if (tiled && head < P) {
-            ma.slot0 = head; ma.nslots = P - head;
-#define GSR_LAUNCH_TILE(TW, CAP) { const int nt = ceil_div(ma.nslots, TW * MT_PP); \
-            hipLaunchKernelGGL((k_mstep_tile<TW>), dim3(8 * ceil_div(nt, 8)), dim3(64 * TW), mstep_tile_lds(TW, CAP), st, ma, CAP); }
-            if (tile_mode == 3) GSR_LAUNCH_TILE(2, 112)         // 2 waves x 2 parents, four workgroups per CU
-            else if (tile_mode == 2) GSR_LAUNCH_TILE(4, 208)    // 4 waves x 2 parents, two workgroups per CU
-            else GSR_LAUNCH_TILE(8, 448)                        // 8 waves x 2 parents, one workgroup per CU
-#undef GSR_LAUNCH_TILE
-            GSR_HIP(hipGetLastError());
-        }
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
