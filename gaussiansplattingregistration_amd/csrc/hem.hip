@@ -1044,10 +1044,11 @@ __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restr
 // largest are lost (the float32 sequential sum of the reference loses them below 2^-24); the total is rounded to
 // float32 once.  Non-finite terms: the sum is NaN if any term is NaN or both infinities occur, else that infinity.
 // ------------------------------------------------------------------------------------------------
-#define SUM_BUCKET_SHIFT 13
-#define SUM_BUCKET (1 << SUM_BUCKET_SHIFT)        // children per bucket: 8192 x (4 + 8) bytes = 96 KiB of LDS
+#define SUM_BUCKET_SHIFT 12
+#define SUM_BUCKET (1 << SUM_BUCKET_SHIFT)        // children per bucket: 4096 x (4 + 8) bytes = 48 KiB of LDS, two workgroups per CU
+                                                  // (phase 3 at 5 M: 8192 children 1.53 ms, 4096 1.31, 2048 1.45)
 #define SUM_TILE 16384                            // pairs per workgroup of the partition kernels
-#define SUM_MAX_BUCKETS 8192                      // 12 bytes of LDS per bucket in k_bucket_scatter: 96 KiB (n <= 67 M components)
+#define SUM_MAX_BUCKETS 13000                     // 12 bytes of LDS per bucket in k_bucket_scatter: 152 KiB (n <= 53 M components)
 
 __global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, const unsigned* __restrict__ child, int nb, unsigned* __restrict__ hist) {
     extern __shared__ unsigned s_h[];
@@ -2196,7 +2197,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
         // partition by bucket (counting sort), then one workgroup per bucket sums in LDS on a fixed-point scale.  The
         // partition kernels keep per-bucket counters in dynamic LDS (12 bytes per bucket, raised above the 64 KiB default
-        // in gsr_hem_create); levels with more than SUM_MAX_BUCKETS buckets (n > 67 M) take the sort path below.
+        // in gsr_hem_create); levels with more than SUM_MAX_BUCKETS buckets (n > 53 M) take the sort path below.
         GSR_TRY(c->bhist.reserve(((size_t)nbuckets + 1) * 4)); GSR_TRY(c->bstart.reserve(((size_t)nbuckets + 1) * 8));
         GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
         GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
