@@ -498,9 +498,18 @@ struct SelectArgs {
     const int64_t* poff;            // FILL: compact offsets;  SPARSE: capacity offsets
     unsigned* pair_child;
     float* pair_wl;
+    // heavy parents (the first *nheavy slots of porder) are cut into work items of SEL_PART candidates of their flat
+    // candidate space; a fixed number of workgroups at the head of the launch pulls the items from a queue
+    const uint2* hitem;             // item -> (slot in porder, part)
+    const int* hfirst;              // [P] first item of a heavy parent, -1 for the others
+    unsigned* part_cnt;             // accepted pairs per item (COUNT / SPARSE out, FILL in)
+    int* hq;                        // hq[0] = number of items, hq[1] = queue cursor
+    int heavy_blocks;               // workgroups at the head of the launch that serve the queue (0 = no splitting)
 };
 
 enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
+#define SEL_PART 8192         // candidates per work item of a heavy parent
+#define SEL_HEAVY_BLOCKS 2048  // workgroups at the head of k_select that serve the queue of heavy work items (a multiple of 8)
 #define SEL_QCAP 512          // survivor ring (power of two >= 64 + SEL_U*64)
 #define SEL_U 4               // chunks whose candidate loads are in flight together
 #define SEL_MCAP 2048         // flat positions covered by the row-start bit mask at a time
@@ -773,7 +782,7 @@ __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __re
 template <int MODE, bool IRR>
 __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr,
                                             const float (&vc)[11], int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count,
-                                            int64_t& base, Q3& q3) {
+                                            int64_t& base, Q3& q3, unsigned& cum, unsigned lo, unsigned hi) {
     const f3 pm = pr.pm;
     const EllClip& ec = pr.ec;
     const float Ra = fabsf(pr.R) * 1.00001f + g.slack;             // conservative search extent
@@ -796,18 +805,25 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
         const int incl = wave_incl_scan(len);
         const int pre = incl - len;
         const int total = __builtin_amdgcn_readlane(incl, 63);
+        // this work item's part [lo, hi) of the parent's flat candidate space (cum = candidates of the batches before this
+        // one; a parent that is not split has lo = 0, hi = 2^32 - 1)
+        const unsigned cum0 = cum;
+        cum += (unsigned)total;
+        if (hi <= cum0 || lo >= cum) continue;
+        const int b_lo = lo > cum0 ? (int)(lo - cum0) : 0;
+        const int b_hi = hi - cum0 < (unsigned)total ? (int)(hi - cum0) : total;
         // (start - prefix) of the q-th non-empty row goes to lane q (the empty rows take the lanes behind them: a permutation)
         const int nrb = __popcll(nz_m);
         const int below = mbcnt64(nz_m, 0);
         const int dst = len > 0 ? below : nrb + (lane - below);
         const int delta = __builtin_amdgcn_ds_permute(dst << 2, s - pre);
-        for (int seg0 = 0; seg0 < total; seg0 += SEL_MCAP) {
+        for (int seg0 = b_lo; seg0 < b_hi; seg0 += SEL_MCAP) {
             const int rel = pre - seg0;
             const bool mine = len > 0 && rel >= 0 && rel < SEL_MCAP;
             if (mine) atomicOr(&bits[rel >> 6], 1ull << (rel & 63));
             int rows_before = __popcll(__ballot(len > 0 && rel < 0));      // rows that start before this segment (uniform)
             __builtin_amdgcn_wave_barrier();
-            const int seg_end = total < seg0 + SEL_MCAP ? total : seg0 + SEL_MCAP;
+            const int seg_end = b_hi < seg0 + SEL_MCAP ? b_hi : seg0 + SEL_MCAP;
             for (int t0 = seg0; t0 < seg_end; t0 += 64 * SEL_U) {
                 float4 ca[SEL_U];
                 int jj[SEL_U];
@@ -867,8 +883,39 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
     }
 }
 
-// WPB = wavefronts (= parents) per workgroup.
-template <int MODE, int WPB>
+// One work item: parent p, part [lo, hi) of its flat candidate space (the whole parent: 0, 2^32 - 1).  Returns the number of
+// accepted pairs; writes them from `base` on (FILL / SPARSE).
+template <int MODE>
+__device__ __forceinline__ unsigned select_item(const SelectArgs& a, const GridParams& g, int p, unsigned lo, unsigned hi, int64_t base, int lane,
+                                                unsigned* q, unsigned long long* bits, Q3 q3) {
+    const ParentRec pr = a.prec[p];     // uniform address: scalar loads, the record lives in SGPRs
+    // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs once per parent)
+    float vc[11];
+    {
+        const float src[11] = {pr.pm.x, pr.pm.y, pr.pm.z, pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 11; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vc[i]) : "s"(src[i]));
+    }
+    unsigned count = 0;                 // accepted pairs (uniform across the wave)
+    int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
+    unsigned cum = 0;                   // flat candidates of the batches behind the scan
+    if (pr.active) {
+        // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
+        // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
+        select_scan<MODE, false>(a, g, pr, vc, lane, bits, q, qh, qn, count, base, q3, cum, lo, hi);
+        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, vc, lane, bits, q, qh, qn, count, base, q3, cum, lo, hi);
+        if (qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base, q3);
+        if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, pr, lane, q3.n, q3, base);
+    }
+    return count;
+}
+
+// WPB = wavefronts (= parents) per workgroup.  QUEUE = false: one light parent per wave in the processing order (the heavy
+// slots at its head are skipped when a.heavy_blocks > 0).  QUEUE = true, launched beside it on a second stream with
+// a.heavy_blocks workgroups: every wave serves the queue of heavy work items (item <its index> first, then it pulls).
+// Two kernels rather than one: the item loop's uniform state does not fit the scalar registers beside the parent record,
+// and the spills would cost the light parents, 99.7 % of the work, two waves per SIMD.
+template <int MODE, int WPB, bool QUEUE>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     __shared__ unsigned s_q[WPB][SEL_QCAP];
     __shared__ double s_logtab[32];
@@ -879,43 +926,93 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     if (lane < 32) s_logtab[lane] = k_logf_tab[lane];       // every wave writes the same 32 values: no barrier needed
     a.logtab = s_logtab;
     if (lane < SEL_MCAP / 64 + SEL_U) s_bits[wv][lane] = 0ull;
-    const int nblk = (a.P + WPB - 1) / WPB;
-    const int hb = a.nheavy ? (((*a.nheavy + WPB - 1) / WPB + 7) & ~7) : 0;
-    const int bid = block_slot((int)blockIdx.x, nblk, hb < nblk ? hb : nblk, a.xcd);
-    if (bid < 0) return;
-    const int slot = bid * WPB + wv;
-    if (slot >= a.P) return;
-    const int p = __builtin_amdgcn_readfirstlane(a.porder ? (int)a.porder[slot] : slot);
-    if (p < a.own_lo || p >= a.own_hi) {          // another rank's parent: no work, no pairs
-        if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p] = 0u;
-        return;
-    }
-    const GridParams g = *a.gp;
-    const ParentRec pr = a.prec[p];     // uniform address: scalar loads, the record lives in SGPRs
-    // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs once per parent)
-    float vc[11];
-    {
-        const float src[11] = {pr.pm.x, pr.pm.y, pr.pm.z, pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
-#pragma unroll
-        for (int i = 0; i < 11; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vc[i]) : "s"(src[i]));
-    }
-
-    unsigned count = 0;                 // accepted pairs (uniform across the wave)
-    int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
-    int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
     unsigned* q = s_q[wv];
-    Q3 q3 = {s_q3j[wv], s_q3f[wv][0], s_q3f[wv][1], s_q3f[wv][2], s_q3f[wv][3], 0, 0};
+    const Q3 q3 = {s_q3j[wv], s_q3f[wv][0], s_q3f[wv][1], s_q3f[wv][2], s_q3f[wv][3], 0, 0};
     __builtin_amdgcn_wave_barrier();
+    const GridParams g = *a.gp;
 
-    if (pr.active) {
-        // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
-        // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
-        select_scan<MODE, false>(a, g, pr, vc, lane, s_bits[wv], q, qh, qn, count, base, q3);
-        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, vc, lane, s_bits[wv], q, qh, qn, count, base, q3);
-        if (qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base, q3);
-        if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, pr, lane, q3.n, q3, base);
+    if constexpr (QUEUE) {
+        const int n_items = a.hq[0];
+        int item = (int)blockIdx.x * WPB + wv;
+        while (item < n_items) {
+            const uint2 it = a.hitem[item];
+            const int p = __builtin_amdgcn_readfirstlane((int)a.porder[it.x]);
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.y * (unsigned)SEL_PART));
+            const unsigned hi = lo + (unsigned)SEL_PART > lo ? lo + (unsigned)SEL_PART : 0xffffffffu;
+            int64_t base = 0;
+            if (MODE == SEL_SPARSE) base = a.poff[p] + lo;          // accepted <= candidates of the part: the parts cannot collide
+            if (MODE == SEL_FILL) {
+                base = a.poff[p];
+                for (int k = a.hfirst[p]; k < item; ++k) base += a.part_cnt[k];
+            }
+            const unsigned count = select_item<MODE>(a, g, p, lo, hi, base, lane, q, s_bits[wv], q3);
+            if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) {
+                a.part_cnt[item] = count;
+                atomicAdd(&a.pcnt[p], count);                       // integer sum: the order of the parts does not matter
+            }
+            int nxt = 0;
+            if (lane == 0) nxt = atomicAdd(&a.hq[1], 1);
+            item = __builtin_amdgcn_readfirstlane(nxt);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        const int nheavy = a.nheavy ? *a.nheavy : 0;
+        const int nblk = (a.P + WPB - 1) / WPB;
+        const int hb = ((nheavy + WPB - 1) / WPB + 7) & ~7;
+        const int bid = block_slot((int)blockIdx.x, nblk, hb < nblk ? hb : nblk, a.xcd);
+        if (bid < 0) return;
+        const int slot = bid * WPB + wv;
+        if (slot >= a.P) return;
+        if (a.heavy_blocks > 0 && slot < nheavy) return;          // a heavy parent: the queue has it
+        const int p = __builtin_amdgcn_readfirstlane(a.porder ? (int)a.porder[slot] : slot);
+        if (p < a.own_lo || p >= a.own_hi) {          // another rank's parent: no work, no pairs
+            if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p] = 0u;
+            return;
+        }
+        const int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
+        const unsigned count = select_item<MODE>(a, g, p, 0u, 0xffffffffu, base, lane, q, s_bits[wv], q3);
+        if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p] = count;      // no global atomics: totals come from the scans
     }
-    if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p] = count;      // no global atomics: totals come from the scans
+}
+
+// The work items of the heavy parents (the first *nheavy slots of the processing order): parts of SEL_PART candidates.
+// ONE workgroup: the heavy parents are a few thousand.  hq[0] = number of items, hq[1] = the queue cursor, which starts
+// behind the items the waves of the serving workgroups take without asking (see k_select).
+__global__ __launch_bounds__(1024) void k_heavy_items(const int* __restrict__ nheavy_p, const unsigned* __restrict__ porder,
+                                                      const unsigned* __restrict__ pcap, int own_lo, int own_hi, int first_pull, int max_items,
+                                                      uint2* __restrict__ hitem, int* __restrict__ hfirst, unsigned* __restrict__ pcnt,
+                                                      int* __restrict__ hq) {
+    __shared__ int s_wsum[16];
+    __shared__ int s_base;
+    const int nheavy = *nheavy_p;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int h0 = 0; h0 < nheavy; h0 += 1024) {
+        const int h = h0 + (int)threadIdx.x;
+        int p = -1, np = 0;
+        if (h < nheavy) {
+            p = (int)porder[h];
+            if (p >= own_lo && p < own_hi) { const unsigned c = pcap[p]; np = (int)((c + SEL_PART - 1) / SEL_PART); np = np < 1 ? 1 : np; }
+        }
+        int incl = np;
+        for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) s_wsum[wv] = incl;
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wv; ++w) off += s_wsum[w];
+        off += incl - np;
+        if (p >= 0) {
+            const bool fits = off + np <= max_items;                 // cannot fail: max_items bounds sum(ceil(cap / SEL_PART))
+            hfirst[p] = np > 0 && fits ? off : -1;
+            pcnt[p] = 0u;
+            if (fits) for (int k = 0; k < np; ++k) hitem[off + k] = make_uint2((unsigned)h, (unsigned)k);
+        }
+        __syncthreads();
+        if (threadIdx.x == 1023) s_base = off + np;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { hq[0] = s_base < max_items ? s_base : max_items; hq[1] = first_pull; }
 }
 
 // Capacities (candidates every parent's passes will scan), with 16 lanes per parent instead of a wavefront: the pass has no
@@ -997,17 +1094,32 @@ __global__ void k_count_heavy(int P, const unsigned* __restrict__ sorted_keys, i
     *out = lo;
 }
 
-// pack the sparse per-parent segments [coff[p], coff[p]+pcnt[p]) into the compact parent-major CSR [poff[p], ...)
+// pack the sparse per-parent segments [coff[p], coff[p]+pcnt[p]) into the compact parent-major CSR [poff[p], ...); the parts
+// of a split parent (hfirst[p] >= 0: segments SEL_PART apart, part_cnt pairs each) are concatenated in part order
 __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __restrict__ coff, const unsigned* __restrict__ pcnt,
-                                                       const int64_t* __restrict__ poff, const unsigned* __restrict__ sc,
-                                                       const float* __restrict__ sw, unsigned* __restrict__ dc, float* __restrict__ dw) {
+                                                       const int64_t* __restrict__ poff, const int* __restrict__ hfirst,
+                                                       const unsigned* __restrict__ part_cnt, const unsigned* __restrict__ pcap,
+                                                       const unsigned* __restrict__ sc, const float* __restrict__ sw,
+                                                       unsigned* __restrict__ dc, float* __restrict__ dw) {
     // 16 lanes per parent (a parent has ~65 pairs): four parents per wavefront share the per-wave latency chain
     const int sub = threadIdx.x & 15;
     const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
     if (p >= P) return;
-    const int64_t dof = poff[p], so = coff[p];
-    const unsigned cnt = pcnt[p];
-    for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[so + i]; dw[dof + i] = sw[so + i]; }
+    int64_t dof = poff[p];
+    const int64_t so = coff[p];
+    const int h = hfirst ? hfirst[p] : -1;
+    if (h < 0) {
+        const unsigned cnt = pcnt[p];
+        for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[so + i]; dw[dof + i] = sw[so + i]; }
+        return;
+    }
+    const int np = (int)((pcap[p] + SEL_PART - 1) / SEL_PART);
+    for (int k = 0; k < (np < 1 ? 1 : np); ++k) {
+        const unsigned cnt = part_cnt[h + k];
+        const int64_t sk = so + (int64_t)k * SEL_PART;
+        for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[sk + i]; dw[dof + i] = sw[sk + i]; }
+        dof += cnt;
+    }
 }
 
 // per-child sum of wL_si, sequential in the (stable) sorted pair order (mixture.cpp:162)
@@ -1615,6 +1727,8 @@ using namespace gsr;
 struct gsr_hem_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;      // second stream: the queue of heavy work items runs beside the light parents
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float rho = 3.0f, delta = 3.0f, kappa = 2.5f, tau = 1.0f;
     int rng_mode = GSR_RNG_GLIBC;
     uint32_t rng_seed = 1;
@@ -1628,6 +1742,7 @@ struct gsr_hem_ctx {
     bool have_level = false;
     // workspace
     DevBuf hist, iflag, irank, ipos, rng_blocks, bhist, bstart, bcursor;
+    bool split_heavy = true;        // heavy parents are cut into work items of SEL_PART candidates (GSR_HEM_SPLIT=0: one wave per parent)
     bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
     unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
@@ -1639,6 +1754,7 @@ struct gsr_hem_ctx {
     void* shard_user = nullptr;
     DevBuf shard_send, shard_recv;
     bool sparse_path = false;
+    DevBuf hitem, hfirst, part_cnt;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1816,12 +1932,19 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
     {
+        hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "second stream: %s", hipGetErrorString(e)); }
+    }
+    {
         hipError_t e = hipHostMalloc((void**)&c->host_rb, 64, hipHostMallocDefault);
         if (e != hipSuccess) { c->host_rb = nullptr; delete c; return fail(GSR_E_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
     }
     // Environment knobs (all of them): none changes a result, each is exercised by a test.
     if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
+    if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_BUCKET * 12);
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
@@ -1837,7 +1960,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     for (DevBuf& b : c->spare) b.release();
     c->cur.release(); c->nxt.release(); c->tmp.release();
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->geo, &c->shs,
-                     &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
+                     &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
                      &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
@@ -1846,6 +1969,9 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->aux) (void)hipStreamDestroy(c->aux);
     delete c;
     return GSR_OK;
 }
@@ -2103,8 +2229,16 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.pcap = c->pcap.as<unsigned>();
     int64_t M = 0;
     constexpr int WPB = 2;      // parents per workgroup (work per parent is heavy-tailed: small workgroups free their CU slot sooner)
-#define GSR_LAUNCH_SELECT(MODE) \
-    hipLaunchKernelGGL((k_select<MODE, WPB>), dim3(8 * ceil_div(ceil_div(P, WPB), 8)), dim3(64 * WPB), 0, st, sa)
+    // the queue-serving kernel runs beside the light parents' on the context's second stream (fork / join by events)
+#define GSR_LAUNCH_SELECT(MODE) do { \
+        if (sa.heavy_blocks) { \
+            GSR_HIP(hipEventRecord(c->ev_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0)); \
+            hipLaunchKernelGGL((k_select<MODE, WPB, true>), dim3(sa.heavy_blocks), dim3(64 * WPB), 0, c->aux, sa); \
+            GSR_HIP(hipEventRecord(c->ev_join, c->aux)); \
+        } \
+        hipLaunchKernelGGL((k_select<MODE, WPB, false>), dim3(8 * ceil_div(ceil_div(P, WPB), 8)), dim3(64 * WPB), 0, st, sa); \
+        if (sa.heavy_blocks) GSR_HIP(hipStreamWaitEvent(st, c->ev_join, 0)); \
+    } while (0)
     auto widen_scan = [&](const unsigned* cnt, int64_t* off, int64_t count) -> int32_t {      // off = exclusive scan of cnt (int64)
         GSR_TRY(c->scratch.reserve(((size_t)count + 128) * 8));
         int64_t* cnt64 = c->scratch.as<int64_t>();
@@ -2145,6 +2279,18 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             sa.porder = c->porder.as<unsigned>();
             sa.xcd = 1;
             sa.nheavy = c->counters.as<int>() + 8;
+            // work items of the heavy parents: sum(ceil(cap / SEL_PART)) <= cand / SEL_PART + P
+            if (c->split_heavy) {
+                const int max_items = (int)std::min<unsigned long long>(cand / SEL_PART + (unsigned long long)P + 1ull, 0x7fffffffull);
+                GSR_TRY(c->hitem.reserve((size_t)max_items * sizeof(uint2))); GSR_TRY(c->hfirst.reserve(Pm * 4));
+                GSR_TRY(c->part_cnt.reserve((size_t)max_items * 4));
+                GSR_HIP(hipMemsetAsync(c->hfirst.p, 0xff, Pm * 4, st));
+                sa.heavy_blocks = SEL_HEAVY_BLOCKS;
+                sa.hitem = c->hitem.as<uint2>(); sa.hfirst = c->hfirst.as<int>(); sa.part_cnt = c->part_cnt.as<unsigned>();
+                sa.hq = c->counters.as<int>() + 10;
+                hipLaunchKernelGGL(k_heavy_items, dim3(1), dim3(1024), 0, st, sa.nheavy, sa.porder, c->pcap.as<unsigned>(), own_lo, own_hi,
+                                   SEL_HEAVY_BLOCKS * WPB, max_items, c->hitem.as<uint2>(), c->hfirst.as<int>(), c->pcnt.as<unsigned>(), sa.hq);
+            }
         }
         size_t free_b = 0, total_b = 0;
         (void)hipMemGetInfo(&free_b, &total_b);
@@ -2173,10 +2319,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         if (M > 0) {
             if (sparse) {
                 hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 16)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(),
-                                   c->poff.as<int64_t>(), c->sp_child.as<unsigned>(), c->sp_wl.as<float>(), c->pair_child.as<unsigned>(),
-                                   c->pair_wl.as<float>());
+                                   c->poff.as<int64_t>(), sa.heavy_blocks ? sa.hfirst : (const int*)nullptr, sa.part_cnt, c->pcap.as<unsigned>(),
+                                   c->sp_child.as<unsigned>(), c->sp_wl.as<float>(), c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
             } else {
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
+                if (sa.heavy_blocks) {                       // the queue cursor back behind the statically assigned items
+                    const int first_pull = SEL_HEAVY_BLOCKS * WPB;
+                    GSR_HIP(hipMemcpyAsync(sa.hq + 1, &first_pull, 4, hipMemcpyHostToDevice, st));
+                }
                 GSR_HIP(hipEventRecord(c->evk[2], st));
                 GSR_LAUNCH_SELECT(SEL_FILL);
                 GSR_HIP(hipEventRecord(c->evk[3], st));

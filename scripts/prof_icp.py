@@ -1,19 +1,43 @@
-"""Where does an ICP call spend its time?  (5M x 5M, point-to-plane)"""
+"""Where the coarse-to-fine ICP of the bench spends its time: per level, the pieces of one registration_icp call."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-from gaussiansplattingregistration_amd import icp, synth
+from gaussiansplattingregistration_amd import hem, icp as icp_mod, synth
+from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+from gaussiansplattingregistration_amd.utils import local_registration_util as lru
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
-tgt = synth.make_cloud_torch(n, seed=100)
-T_gt = synth.rigid_transform(1.0, (1, 1, 1), 0.004 * tgt["h"] * np.array([1.0, -1.0, 0.5]))
-src = synth.apply_rigid_torch(tgt, np.linalg.inv(T_gt))
-src["xyz"] = (src["xyz"] + torch.randn_like(src["xyz"]) * 0.002).contiguous()
-def t(f, *a, **k):
-    torch.cuda.synchronize(); t0 = time.perf_counter(); r = f(*a, **k); torch.cuda.synchronize(); return r, (time.perf_counter() - t0) * 1e3
-c = icp.IcpContext()
-for rep in range(3):
-    nrm, tn = t(icp.normals_from_cov, tgt["cov6"])
-    _, tt = t(c.set_target, tgt["xyz"], nrm, 0.1)
-    _, ts = t(c.set_source, src["xyz"])
-    r, tr = t(c.register, np.eye(4), 1, 0, 0.0, 1e-6, 1e-6, 10)
-    print(f"rep{rep}: normals {tn:.2f} ms, set_target {tt:.2f}, set_source {ts:.2f}, register {tr:.2f} ms ({r['iterations']} iters), timing {c.timing()}")
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+dev = "cuda:0"
+sync = torch.cuda.synchronize
+src = synth.make_cloud_torch(n, seed=100)
+tgt = synth.apply_rigid_torch(src, synth.rigid_transform(1.0, translation=(0.004, -0.002, 0.003)))
+m = hem.HemMixture()
+def levels(c):
+    lv = [PointCloud(xyz32=c["xyz"], cov6=c["cov6"])]
+    m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+    for _ in range(3):
+        m.run_level(); d = m.get_level(as_torch=True); lv.append(PointCloud(xyz32=d["xyz"], cov6=d["cov6"]))
+    return lv
+m.set_rng("glibc", 1, 0)
+S, Tg = levels(src), levels(tgt)
+ctx = icp_mod.IcpContext(device=0)
+est = lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Plane, lru.RobustLoss(0))
+ITER = [50, 30, 20, 10]; MC = [0.5, 0.3, 0.2, 0.1]
+def tm(f):
+    sync(); t = time.perf_counter(); r = f(); sync(); return (time.perf_counter() - t) * 1e3, r
+for rep in range(reps):
+    T = np.eye(4); tot = 0.0
+    for k in range(4):
+        s, t = S[-(k + 1)], Tg[-(k + 1)]
+        t.normals = None
+        a, _ = tm(lambda: t.estimate_normals())
+        b, _ = tm(lambda: ctx.set_target(t.xyz32, t.normals, MC[k]))
+        c, _ = tm(lambda: ctx.set_source(s.xyz32))
+        d0, _ = tm(lambda: (ctx.set_allreduce_device(None, 0), ctx.set_allreduce(None, 0)))
+        d, r = tm(lambda: ctx.register(T, est.kind, 0, 0.0, 1e-6, 1e-6, ITER[k]))
+        tmg = ctx.timing()
+        T = r["transformation"]; tot += a + b + c + d + d0
+        print(f"rep{rep} ns={len(s):8d} normals {a:.3f} set_target {b:.3f} (build {tmg['ms_build']:.3f}) set_source {c:.3f} callbacks {d0:.3f} "
+              f"register {d:.3f} (iters {r['iterations']}, kernels {tmg['ms_iters']:.3f})", flush=True)
+    print(f"rep{rep} total {tot:.3f} ms", flush=True)

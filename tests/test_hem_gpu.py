@@ -270,6 +270,26 @@ def test_two_pass_fallback_equals_sparse_path(monkeypatch):
             assert _rel(a[k][f], b[k][f]) < 1e-5, (k, f)
 
 
+def test_heavy_parent_work_items_change_nothing(monkeypatch):
+    """Heavy parents are cut into work items of 8192 candidates served from a queue (GSR_HEM_SPLIT=0: one wave per parent).
+    The parts are concatenated in order, so the pair list -- and with it every sum of the level -- is the same bit for bit,
+    on the one-pass path and on the COUNT + FILL fallback."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(200000, seed=35, sh_degree=1)
+    monkeypatch.setenv("GSR_HEM_SPLIT", "0")
+    ref, rst = hem.create_mixture(c, 2)
+    assert max(s["candidates"] for s in rst) > 0
+    for budget in (None, "0"):
+        monkeypatch.setenv("GSR_HEM_SPLIT", "1")
+        if budget is not None:
+            monkeypatch.setenv("GSR_HEM_SPARSE_GB", budget)
+        got, st = hem.create_mixture(c, 2)
+        for k in range(2):
+            assert (st[k]["parents"], st[k]["pairs"], st[k]["orphans"]) == (rst[k]["parents"], rst[k]["pairs"], rst[k]["orphans"])
+            for f in ("xyz", "color", "cov6", "sh", "opacity"):
+                assert np.array_equal(got[k][f], ref[k][f]), (budget, k, f)
+
+
 def test_grid_cell_size_changes_nothing(monkeypatch):
     """Any conservative neighbour search is legal: with 2 or 40 components per grid cell instead of 8
     (GSR_HEM_CELL_TARGET) a level accepts exactly the same pairs -- only the candidates scanned differ."""
