@@ -503,14 +503,43 @@ __global__ __launch_bounds__(256) void k_icp_intensity(int64_t n, const unsigned
     }
 }
 
+// Sum of a double over the 64 lanes (every lane gets it) in a fixed order, without the LDS crossbar: four DPP row rotations
+// and the two permlane swaps, on the two dwords of the value.  (30 accumulators x 6 steps of __shfl_xor were 360
+// ds_bpermute per wave, 24 LDS-pipe cycles each: a third of the accumulate kernel on a 185 k-point level.)
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const int lo = __builtin_amdgcn_update_dpp(0, (int)b, CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+template <bool HALF>        // HALF: lanes l and l ^ 32, else l and l ^ 16
+__device__ __forceinline__ double swap_sum_d(double v) {
+    const long long b = __builtin_bit_cast(long long, v);
+    const unsigned lo = (unsigned)b, hi = (unsigned)(b >> 32);
+    const auto rl = HALF ? __builtin_amdgcn_permlane32_swap(lo, lo, false, false) : __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+    const auto rh = HALF ? __builtin_amdgcn_permlane32_swap(hi, hi, false, false) : __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    const double a = __builtin_bit_cast(double, ((long long)(unsigned)rh[0] << 32) | (unsigned)rl[0]);
+    const double c = __builtin_bit_cast(double, ((long long)(unsigned)rh[1] << 32) | (unsigned)rl[1]);
+    return a + c;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+    v += dpp_d<0x128>(v);       // row_ror:8
+    v += dpp_d<0x124>(v);       // row_ror:4
+    v += dpp_d<0x122>(v);       // row_ror:2
+    v += dpp_d<0x121>(v);       // row_ror:1
+    v = swap_sum_d<false>(v);
+    v = swap_sum_d<true>(v);
+    return v;
+}
+
 template <int NACC>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ partials) {
     __shared__ double s_red[4][NACC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
     for (int k = 0; k < NACC; ++k) {
-        double v = acc[k];
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const double v = wave_sum_d(acc[k]);
         if (lane == 0) s_red[wv][k] = v;
     }
     __syncthreads();
@@ -860,29 +889,69 @@ __host__ __device__ static double det3(const double m[3][3]) {
     return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
            m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
 }
+// x = A^-1 b by LDL^T with diagonal pivoting (what Eigen's LDLT, which Open3D's solvers call, does).  Every index below
+// is a compile-time constant once the loops are unrolled -- the pivot's row / column exchange is a chain of tests against
+// the constant candidates -- so on the device the 36 + 15 + 18 doubles live in registers: with run-time indices the
+// arrays went to scratch memory (720 bytes per lane) and the single-thread solve of k_icp_step took ~15 us.
 __host__ __device__ static void solve6(const double A_[6][6], const double b_[6], double x[6]) {
-    double A[6][6], b[6], L[6][6] = {{0}}, D[6];
+    double A[6][6], L[6][6], D[6], bp[6];
     int perm[6];
-    for (int i = 0; i < 6; ++i) { perm[i] = i; b[i] = b_[i]; for (int j = 0; j < 6; ++j) A[i][j] = A_[i][j]; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        perm[i] = i; bp[i] = b_[i];
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { A[i][j] = A_[i][j]; L[i][j] = 0.0; }
+    }
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         int piv = k;
-        for (int i = k + 1; i < 6; ++i) if (fabs(A[i][i]) > fabs(A[piv][piv])) piv = i;
-        if (piv != k) {
-            for (int j = 0; j < 6; ++j) { double t = A[k][j]; A[k][j] = A[piv][j]; A[piv][j] = t; }
-            for (int i = 0; i < 6; ++i) { double t = A[i][k]; A[i][k] = A[i][piv]; A[i][piv] = t; }
-            for (int j = 0; j < k; ++j) { double t = L[k][j]; L[k][j] = L[piv][j]; L[piv][j] = t; }
-            int t = perm[k]; perm[k] = perm[piv]; perm[piv] = t;
+        double best = fabs(A[k][k]);
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) { const double v = fabs(A[i][i]); if (v > best) { best = v; piv = i; } }
+#pragma unroll
+        for (int c = k + 1; c < 6; ++c) {
+            if (piv == c) {
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const double t = A[k][j]; A[k][j] = A[c][j]; A[c][j] = t; }
+#pragma unroll
+                for (int i = 0; i < 6; ++i) { const double t = A[i][k]; A[i][k] = A[i][c]; A[i][c] = t; }
+#pragma unroll
+                for (int j = 0; j < k; ++j) { const double t = L[k][j]; L[k][j] = L[c][j]; L[c][j] = t; }
+                const int t = perm[k]; perm[k] = perm[c]; perm[c] = t;
+                const double tb = bp[k]; bp[k] = bp[c]; bp[c] = tb;        // bp[i] == b[perm[i]] throughout
+            }
         }
         D[k] = A[k][k];
         L[k][k] = 1;
+#pragma unroll
         for (int i = k + 1; i < 6; ++i) L[i][k] = A[i][k] / D[k];
-        for (int i = k + 1; i < 6; ++i) for (int j = k + 1; j < 6; ++j) A[i][j] -= L[i][k] * D[k] * L[j][k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i)
+#pragma unroll
+            for (int j = k + 1; j < 6; ++j) A[i][j] -= L[i][k] * D[k] * L[j][k];
     }
     double y[6], z[6];
-    for (int i = 0; i < 6; ++i) { double s = b[perm[i]]; for (int j = 0; j < i; ++j) s -= L[i][j] * y[j]; y[i] = s; }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        double s = bp[i];
+#pragma unroll
+        for (int j = 0; j < i; ++j) s -= L[i][j] * y[j];
+        y[i] = s;
+    }
+#pragma unroll
     for (int i = 0; i < 6; ++i) y[i] /= D[i];
-    for (int i = 5; i >= 0; --i) { double s = y[i]; for (int j = i + 1; j < 6; ++j) s -= L[j][i] * z[j]; z[i] = s; }
-    for (int i = 0; i < 6; ++i) x[perm[i]] = z[i];
+#pragma unroll
+    for (int i = 5; i >= 0; --i) {
+        double s = y[i];
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) s -= L[j][i] * z[j];
+        z[i] = s;
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int c = 0; c < 6; ++c)
+            if (perm[i] == c) x[c] = z[i];
 }
 __host__ __device__ static void mat4_identity(double T[16]) { for (int i = 0; i < 16; ++i) T[i] = (i % 5 == 0) ? 1.0 : 0.0; }
 __host__ __device__ static void mat4_mul(const double A[16], const double B[16], double C[16]) {
@@ -916,7 +985,11 @@ __host__ __device__ static void estimate_update(const double ctr[3], int kind, c
     } else {                                                 // x = solve(JTJ, -JTr); Rz(x2) Ry(x1) Rx(x0), t = x3..5
         double JTJ[6][6], nb[6], x[6];
         int t = 2;
-        for (int a = 0; a < 6; ++a) for (int b = a; b < 6; ++b) { JTJ[a][b] = acc[t]; JTJ[b][a] = acc[t]; ++t; }
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b) { JTJ[a][b] = acc[t]; JTJ[b][a] = acc[t]; ++t; }
+#pragma unroll
         for (int a = 0; a < 6; ++a) nb[a] = -acc[23 + a];
         solve6(JTJ, nb, x);
         const double ca = cos(x[0]), sa = sin(x[0]), cb = cos(x[1]), sb = sin(x[1]), cg = cos(x[2]), sg = sin(x[2]);
@@ -1015,37 +1088,69 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
 // `reduced` == NULL: fold the block partials here (single GPU).  Multi-GPU source split: k_icp_reduce folds them into a
 // device vector, the all-reduce callback sums that vector over the ranks (RCCL, on this stream), and this kernel starts
 // from the reduced vector -- every rank then takes the identical decision and the identical update.
-__global__ __launch_bounds__(1024) void k_icp_step(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced,
+// 512 threads: the single-thread solve behind the reduction needs ~150 registers (a 1024-thread launch bound allows 128: it
+// spilled to scratch).  The reduction keeps k_icp_finalize's summation ORDER per accumulator k -- s_l = sum over the blocks
+// b = l, l + 64, ... ascending, then the butterfly s_l + s_(l ^ 32), + (l ^ 16), ... down to lane 0 -- but reads the
+// partials as rows: thread (g = t / 32, k = t % 32) forms s_g, s_(g+16), s_(g+32), s_(g+48) of accumulator k (32 threads
+// read one 256-byte row per load; the old wave-per-accumulator loop read 8 bytes of 64 different rows), folds the two
+// butterfly steps it holds both operands of, and an LDS tree over g does the remaining four.
+#define ICP_STEP_THREADS 512
+__global__ __launch_bounds__(ICP_STEP_THREADS) void k_icp_step(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced,
                                                    IcpState* __restrict__ st) {
-    __shared__ double s_acc[GSR_ICP_ACC_LEN];
-    if (st->done) return;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;         // 16 wavefronts, 2 accumulators each
+    __shared__ double s_x[16][GSR_ICP_ACC_LEN];
+    __shared__ IcpState s_st;
+    static_assert(GSR_ICP_ACC_LEN == 32 && sizeof(IcpState) % 4 == 0, "k_icp_step layout");
+    if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
+    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
     if (reduced) {
-        if (threadIdx.x < GSR_ICP_ACC_LEN) s_acc[threadIdx.x] = reduced[threadIdx.x];
+        if (g == 0) s_x[0][k] = reduced[k];
+        __syncthreads();
     } else {
-        for (int k = wv; k < GSR_ICP_ACC_LEN; k += 16) {
-            double s = 0.0;
-            for (int b = lane; b < nblocks; b += 64) s += partials[(int64_t)b * GSR_ICP_ACC_LEN + k];
-            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-            if (lane == 0) s_acc[k] = s;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        // four rounds of loads in flight (16 independent loads) before the adds that consume them, in block order
+        for (int b0 = g; b0 < nblocks; b0 += 256) {
+            double v[4][4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int b = b0 + 64 * u + 16 * j;
+                    v[u][j] = b < nblocks ? partials[(int64_t)b * GSR_ICP_ACC_LEN + k] : 0.0;
+                }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int b = b0 + 64 * u;
+                if (b < nblocks) s0 += v[u][0];
+                if (b + 16 < nblocks) s1 += v[u][1];
+                if (b + 32 < nblocks) s2 += v[u][2];
+                if (b + 48 < nblocks) s3 += v[u][3];
+            }
+        }
+        s_x[g][k] = (s0 + s2) + (s1 + s3);                 // lane g of the butterfly after its steps 32 and 16
+        __syncthreads();
+        for (int o = 8; o > 0; o >>= 1) {
+            if (g < o) s_x[g][k] = s_x[g][k] + s_x[g + o][k];
+            __syncthreads();
         }
     }
-    __syncthreads();
-    if (threadIdx.x != 0) return;
+    if (threadIdx.x != 0 || s_st.done) return;
     double acc[GSR_ICP_ACC_LEN];
-    for (int k = 0; k < GSR_ICP_ACC_LEN; ++k) acc[k] = s_acc[k];
-    const double fit = acc[0] > 0 ? acc[0] / st->nsg : 0.0, rmse = acc[0] > 0 ? sqrt(acc[1] / acc[0]) : 0.0;
-    const bool first = st->evals == 0;
-    const bool stop = !first && fabs(st->fit - fit) < st->rel_fit && fabs(st->rmse - rmse) < st->rel_rmse;
+#pragma unroll
+    for (int i = 0; i < GSR_ICP_ACC_LEN; ++i) acc[i] = s_x[0][i];
+    const double fit = acc[0] > 0 ? acc[0] / s_st.nsg : 0.0, rmse = acc[0] > 0 ? sqrt(acc[1] / acc[0]) : 0.0;
+    const bool first = s_st.evals == 0;
+    const bool stop = !first && fabs(s_st.fit - fit) < s_st.rel_fit && fabs(s_st.rmse - rmse) < s_st.rel_rmse;
     st->fit = fit; st->rmse = rmse;
-    st->evals += 1;
-    if (stop || st->iters >= st->max_iter) { st->done = 1; return; }
+    st->evals = s_st.evals + 1;
+    if (stop || s_st.iters >= s_st.max_iter) { st->done = 1; return; }
     double update[16], T[16];
-    estimate_update(st->ctr, st->kind, acc, update);
-    for (int i = 0; i < 16; ++i) T[i] = st->T[i];
+    estimate_update(s_st.ctr, s_st.kind, acc, update);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) T[i] = s_st.T[i];
     mat4_mul(update, T, T);
+#pragma unroll
     for (int i = 0; i < 16; ++i) st->T[i] = T[i];
-    st->iters += 1;
+    st->iters = s_st.iters + 1;
 }
 
 // rank-local accumulator vector of one iteration (same fixed summation order as k_icp_finalize); zeros once converged, so
@@ -1495,9 +1600,9 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
                     hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>(), c->acc_dev.as<double>());
                     const int32_t rc = c->allreduce_dev(c->acc_dev.p, GSR_ICP_ACC_LEN, c->allreduce_dev_user);
                     if (rc != 0) return fail(GSR_E_INVALID, "icp: device all-reduce callback returned %d", rc);
-                    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>(), c->state.as<IcpState>());
+                    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ICP_STEP_THREADS), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>(), c->state.as<IcpState>());
                 } else {
-                    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), (const double*)nullptr, c->state.as<IcpState>());
+                    hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ICP_STEP_THREADS), 0, st, nb, c->partials.as<double>(), (const double*)nullptr, c->state.as<IcpState>());
                 }
             }
             issued += chunk;
