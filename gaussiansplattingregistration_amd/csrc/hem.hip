@@ -50,6 +50,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -1744,7 +1745,9 @@ struct gsr_hem_ctx {
     DevBuf hist, iflag, irank, ipos, rng_blocks, bhist, bstart, bcursor;
     bool split_heavy = true;        // heavy parents are cut into work items of SEL_PART candidates (GSR_HEM_SPLIT=0: one wave per parent)
     bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
-    unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into
+    unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into (16 words; [15] = sequence number)
+    unsigned long long rb_seq = 0;
+    bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec;
     bool use_ell = true;            // GSR_HEM_ELL=0: no ellipsoid row clipping (test knob: the pair set must not change)
@@ -1850,14 +1853,34 @@ struct Collect {
     int bytes[8];          // 4 or 8
     int n;
 };
-__global__ void k_collect(Collect q, unsigned long long* __restrict__ dst) {
+// The values first, a system-scope fence, then the sequence number of the round trip into dst[15]: the host does not call
+// hipStreamSynchronize (20-75 us until the thread is awake again) but polls that word in its own memory (~5 us).
+__global__ void k_collect(Collect q, unsigned long long* __restrict__ dst, unsigned long long seq) {
     const int t = threadIdx.x;
-    if (t < q.n) dst[t] = q.bytes[t] == 8 ? *(const unsigned long long*)q.src[t] : (unsigned long long)*(const unsigned*)q.src[t];
+    if (t < q.n) {
+        const unsigned long long v = q.bytes[t] == 8 ? *(const unsigned long long*)q.src[t] : (unsigned long long)*(const unsigned*)q.src[t];
+        __hip_atomic_store(dst + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(dst + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 int32_t read_back(gsr_hem_ctx* c, const Collect& q, unsigned long long* out) {
-    hipLaunchKernelGGL(k_collect, dim3(1), dim3(8), 0, c->stream, q, c->host_rb);
-    GSR_HIP(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < q.n; ++i) out[i] = c->host_rb[i];
+    const unsigned long long seq = ++c->rb_seq;
+    hipLaunchKernelGGL(k_collect, dim3(1), dim3(8), 0, c->stream, q, c->host_rb, seq);
+    GSR_HIP(hipGetLastError());
+    bool seen = false;
+    if (c->rb_poll) {
+        (void)hipStreamQuery(c->stream);                        // makes sure the queue is submitted
+        volatile unsigned long long* flag = c->host_rb + 15;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 1; !(seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq); ++spins) {
+            if ((spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // a fault upstream: let the
+            __builtin_ia32_pause();                                                                                       // synchronisation report it
+        }
+    }
+    if (!seen) GSR_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < q.n; ++i) out[i] = __atomic_load_n(c->host_rb + i, __ATOMIC_RELAXED);
     return GSR_OK;
 }
 
@@ -1938,13 +1961,15 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "second stream: %s", hipGetErrorString(e)); }
     }
     {
-        hipError_t e = hipHostMalloc((void**)&c->host_rb, 64, hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void**)&c->host_rb, 128, hipHostMallocDefault);
         if (e != hipSuccess) { c->host_rb = nullptr; delete c; return fail(GSR_E_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
+        memset(c->host_rb, 0, 128);
     }
     // Environment knobs (all of them): none changes a result, each is exercised by a test.
     if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_BUCKET * 12);
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);

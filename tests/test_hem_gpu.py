@@ -290,6 +290,20 @@ def test_heavy_parent_work_items_change_nothing(monkeypatch):
                 assert np.array_equal(got[k][f], ref[k][f]), (budget, k, f)
 
 
+def test_read_back_poll_changes_nothing(monkeypatch):
+    """The host reads counts back by polling a sequence word the device writes into pinned memory; GSR_HEM_RB_POLL=0 waits with
+    hipStreamSynchronize instead.  Same values either way."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(20000, seed=36, h=1.1, sh_degree=1)
+    a, sa = hem.create_mixture(c, 2)
+    monkeypatch.setenv("GSR_HEM_RB_POLL", "0")
+    b, sb = hem.create_mixture(c, 2)
+    for k in range(2):
+        assert (sa[k]["parents"], sa[k]["pairs"], sa[k]["orphans"]) == (sb[k]["parents"], sb[k]["pairs"], sb[k]["orphans"])
+        for f in ("xyz", "color", "cov6", "sh", "opacity"):
+            assert np.array_equal(a[k][f], b[k][f]), (k, f)
+
+
 def test_grid_cell_size_changes_nothing(monkeypatch):
     """Any conservative neighbour search is legal: with 2 or 40 components per grid cell instead of 8
     (GSR_HEM_CELL_TARGET) a level accepts exactly the same pairs -- only the candidates scanned differ."""
