@@ -427,7 +427,7 @@ def main():
         l1_bytes = float(np.mean([bytes_level(k["n_in"], k["n_out"], F) for k in lvl1])) if lvl1 else 0.0
         l1_ms = float(np.mean([k["ms_level"] for k in lvl1])) if lvl1 else 0.0
         l1_sel = float(np.mean([k["ms_k_select_fill"] for k in lvl1])) if lvl1 else 0.0
-        pmc, pmc_note = pmc_summary("gsr::k_select<2")
+        pmc, pmc_note = pmc_summary("gsr::k_select<2, 2, false>")
         roof = {"bound": "hbm", "kernel": "k_select<SPARSE> (child selection + likelihood, one wavefront per parent)",
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "bytes_model": "SURVEY 8(d) bytes_level = n_in (57 + 4F + 16) + n_out (57 + 4F) of the launch's level, / launch duration",
