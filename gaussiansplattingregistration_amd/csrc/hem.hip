@@ -506,10 +506,11 @@ struct SelectArgs {
     unsigned* part_cnt;             // accepted pairs per item (COUNT / SPARSE out, FILL in)
     int* hq;                        // hq[0] = number of items, hq[1] = queue cursor
     int heavy_blocks;               // workgroups at the head of the launch that serve the queue (0 = no splitting)
+    unsigned part;                  // candidates per work item (<= SEL_PART; smaller on small levels, where an item is the critical path)
 };
 
 enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
-#define SEL_PART 8192         // candidates per work item of a heavy parent
+#define SEL_PART 8192         // candidates per work item of a heavy parent, at most (SelectArgs::part)
 #define SEL_HEAVY_BLOCKS 2048  // workgroups at the head of k_select that serve the queue of heavy work items (a multiple of 8)
 #define SEL_QCAP 512          // survivor ring (power of two >= 64 + SEL_U*64)
 #define SEL_U 4               // chunks whose candidate loads are in flight together
@@ -938,8 +939,8 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
         while (item < n_items) {
             const uint2 it = a.hitem[item];
             const int p = __builtin_amdgcn_readfirstlane((int)a.porder[it.x]);
-            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.y * (unsigned)SEL_PART));
-            const unsigned hi = lo + (unsigned)SEL_PART > lo ? lo + (unsigned)SEL_PART : 0xffffffffu;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.y * a.part));
+            const unsigned hi = lo + a.part > lo ? lo + a.part : 0xffffffffu;
             int64_t base = 0;
             if (MODE == SEL_SPARSE) base = a.poff[p] + lo;          // accepted <= candidates of the part: the parts cannot collide
             if (MODE == SEL_FILL) {
@@ -980,7 +981,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
 // ONE workgroup: the heavy parents are a few thousand.  hq[0] = number of items, hq[1] = the queue cursor, which starts
 // behind the items the waves of the serving workgroups take without asking (see k_select).
 __global__ __launch_bounds__(1024) void k_heavy_items(const int* __restrict__ nheavy_p, const unsigned* __restrict__ porder,
-                                                      const unsigned* __restrict__ pcap, int own_lo, int own_hi, int first_pull, int max_items,
+                                                      const unsigned* __restrict__ pcap, unsigned part, int own_lo, int own_hi, int first_pull, int max_items,
                                                       uint2* __restrict__ hitem, int* __restrict__ hfirst, unsigned* __restrict__ pcnt,
                                                       int* __restrict__ hq) {
     __shared__ int s_wsum[16];
@@ -994,7 +995,7 @@ __global__ __launch_bounds__(1024) void k_heavy_items(const int* __restrict__ nh
         int p = -1, np = 0;
         if (h < nheavy) {
             p = (int)porder[h];
-            if (p >= own_lo && p < own_hi) { const unsigned c = pcap[p]; np = (int)((c + SEL_PART - 1) / SEL_PART); np = np < 1 ? 1 : np; }
+            if (p >= own_lo && p < own_hi) { const unsigned c = pcap[p]; np = (int)(c / part + (c % part ? 1u : 0u)); np = np < 1 ? 1 : np; }
         }
         int incl = np;
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
@@ -1099,7 +1100,7 @@ __global__ void k_count_heavy(int P, const unsigned* __restrict__ sorted_keys, i
 // of a split parent (hfirst[p] >= 0: segments SEL_PART apart, part_cnt pairs each) are concatenated in part order
 __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __restrict__ coff, const unsigned* __restrict__ pcnt,
                                                        const int64_t* __restrict__ poff, const int* __restrict__ hfirst,
-                                                       const unsigned* __restrict__ part_cnt, const unsigned* __restrict__ pcap,
+                                                       const unsigned* __restrict__ part_cnt, const unsigned* __restrict__ pcap, unsigned part,
                                                        const unsigned* __restrict__ sc, const float* __restrict__ sw,
                                                        unsigned* __restrict__ dc, float* __restrict__ dw) {
     // 16 lanes per parent (a parent has ~65 pairs): four parents per wavefront share the per-wave latency chain
@@ -1114,10 +1115,10 @@ __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __r
         for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[so + i]; dw[dof + i] = sw[so + i]; }
         return;
     }
-    const int np = (int)((pcap[p] + SEL_PART - 1) / SEL_PART);
+    const int np = (int)(pcap[p] / part + (pcap[p] % part ? 1u : 0u));
     for (int k = 0; k < (np < 1 ? 1 : np); ++k) {
         const unsigned cnt = part_cnt[h + k];
-        const int64_t sk = so + (int64_t)k * SEL_PART;
+        const int64_t sk = so + (int64_t)k * part;
         for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[sk + i]; dw[dof + i] = sw[sk + i]; }
         dof += cnt;
     }
@@ -1163,18 +1164,18 @@ __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restr
 #define SUM_TILE 16384                            // pairs per workgroup of the partition kernels
 #define SUM_MAX_BUCKETS 13000                     // 12 bytes of LDS per bucket in k_bucket_scatter: 152 KiB (n <= 53 M components)
 
-__global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, const unsigned* __restrict__ child, int nb, unsigned* __restrict__ hist) {
+__global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, const unsigned* __restrict__ child, int nb, int shift, unsigned* __restrict__ hist) {
     extern __shared__ unsigned s_h[];
     for (int b = threadIdx.x; b < nb; b += blockDim.x) s_h[b] = 0u;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * SUM_TILE, hi = lo + SUM_TILE < M ? lo + SUM_TILE : M;
-    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_h[child[k] >> SUM_BUCKET_SHIFT], 1u);
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_h[child[k] >> shift], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += blockDim.x)
         if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
 }
 // bucket offsets are 64-bit (10^9 pairs at 40 M splats); cursor[b] starts at the bucket's first slot
-__global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, const unsigned* __restrict__ child, const float* __restrict__ wl, int nb,
+__global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, const unsigned* __restrict__ child, const float* __restrict__ wl, int nb, int shift,
                                                         unsigned long long* __restrict__ cursor, unsigned* __restrict__ o_child,
                                                         float* __restrict__ o_wl) {
     extern __shared__ unsigned s_h[];              // [nb] counts, then [nb] (lo, hi) words of the reserved base
@@ -1183,7 +1184,7 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, const unsigne
     for (int b = threadIdx.x; b < nb; b += blockDim.x) s_cnt[b] = 0u;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * SUM_TILE, hi = lo + SUM_TILE < M ? lo + SUM_TILE : M;
-    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_cnt[child[k] >> SUM_BUCKET_SHIFT], 1u);
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_cnt[child[k] >> shift], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += blockDim.x) {
         const unsigned cnt = s_cnt[b];
@@ -1193,21 +1194,22 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, const unsigne
     __syncthreads();
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         const unsigned ch = child[k];
-        const int b = (int)(ch >> SUM_BUCKET_SHIFT);
+        const int b = (int)(ch >> shift);
         const unsigned long long pos = s_base[b] + atomicAdd(&s_cnt[b], 1u);
         o_child[pos] = ch;
         o_wl[pos] = wl[k];
     }
 }
-__global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, const unsigned long long* __restrict__ bstart, const unsigned* __restrict__ child,
+__global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, int shift, const unsigned long long* __restrict__ bstart, const unsigned* __restrict__ child,
                                                      const float* __restrict__ wl, float* __restrict__ sumLw, int* __restrict__ orphan_flag,
                                                      float* __restrict__ geo_sl) {
-    extern __shared__ unsigned long long s_acc[];  // [SUM_BUCKET] int64 accumulators, then [SUM_BUCKET] max bit patterns
-    unsigned* s_max = (unsigned*)(s_acc + SUM_BUCKET);
+    extern __shared__ unsigned long long s_acc[];  // [bucket] int64 accumulators, then [bucket] max bit patterns
+    const int bucket = 1 << shift;
+    unsigned* s_max = (unsigned*)(s_acc + bucket);
     const int b = blockIdx.x;
-    const int64_t c0 = (int64_t)b << SUM_BUCKET_SHIFT;
-    const int nc = (int)(n - c0 < SUM_BUCKET ? n - c0 : SUM_BUCKET);
-    for (int i = threadIdx.x; i < SUM_BUCKET; i += blockDim.x) { s_acc[i] = 0ull; s_max[i] = 0u; }
+    const int64_t c0 = (int64_t)b << shift;
+    const int nc = (int)(n - c0 < bucket ? n - c0 : bucket);
+    for (int i = threadIdx.x; i < bucket; i += blockDim.x) { s_acc[i] = 0ull; s_max[i] = 0u; }
     __syncthreads();
     const unsigned long long k0 = bstart[b], k1 = bstart[b + 1];
     for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x)
@@ -2306,14 +2308,19 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             sa.nheavy = c->counters.as<int>() + 8;
             // work items of the heavy parents: sum(ceil(cap / SEL_PART)) <= cand / SEL_PART + P
             if (c->split_heavy) {
-                const int max_items = (int)std::min<unsigned long long>(cand / SEL_PART + (unsigned long long)P + 1ull, 0x7fffffffull);
+                // part size: ~4 items per wave slot of the chip, between 2048 and SEL_PART candidates (on a small level one
+                // item of 8192 candidates outlasts the whole light launch)
+                unsigned part = SEL_PART;
+                while (part > 2048u && (unsigned long long)part * 4ull * 7168ull > cand) part >>= 1;
+                sa.part = part;
+                const int max_items = (int)std::min<unsigned long long>(cand / part + (unsigned long long)P + 1ull, 0x7fffffffull);
                 GSR_TRY(c->hitem.reserve((size_t)max_items * sizeof(uint2))); GSR_TRY(c->hfirst.reserve(Pm * 4));
                 GSR_TRY(c->part_cnt.reserve((size_t)max_items * 4));
                 GSR_HIP(hipMemsetAsync(c->hfirst.p, 0xff, Pm * 4, st));
                 sa.heavy_blocks = SEL_HEAVY_BLOCKS;
                 sa.hitem = c->hitem.as<uint2>(); sa.hfirst = c->hfirst.as<int>(); sa.part_cnt = c->part_cnt.as<unsigned>();
                 sa.hq = c->counters.as<int>() + 10;
-                hipLaunchKernelGGL(k_heavy_items, dim3(1), dim3(1024), 0, st, sa.nheavy, sa.porder, c->pcap.as<unsigned>(), own_lo, own_hi,
+                hipLaunchKernelGGL(k_heavy_items, dim3(1), dim3(1024), 0, st, sa.nheavy, sa.porder, c->pcap.as<unsigned>(), sa.part, own_lo, own_hi,
                                    SEL_HEAVY_BLOCKS * WPB, max_items, c->hitem.as<uint2>(), c->hfirst.as<int>(), c->pcnt.as<unsigned>(), sa.hq);
             }
         }
@@ -2344,7 +2351,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         if (M > 0) {
             if (sparse) {
                 hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 16)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(),
-                                   c->poff.as<int64_t>(), sa.heavy_blocks ? sa.hfirst : (const int*)nullptr, sa.part_cnt, c->pcap.as<unsigned>(),
+                                   c->poff.as<int64_t>(), sa.heavy_blocks ? sa.hfirst : (const int*)nullptr, sa.part_cnt, c->pcap.as<unsigned>(), sa.part ? sa.part : SEL_PART,
                                    c->sp_child.as<unsigned>(), c->sp_wl.as<float>(), c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
             } else {
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
@@ -2368,7 +2375,10 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 
     // ---- 3. per-child sums of wL (deterministic: stable sort by child, sequential sum) ----------
     GSR_TRY(c->cstart.reserve(((size_t)n + 1) * 8)); GSR_TRY(c->sumLw.reserve(n * 4)); GSR_TRY(c->oflag.reserve(n * 4));
-    const int nbuckets = (int)((n + SUM_BUCKET - 1) >> SUM_BUCKET_SHIFT);
+    // children per bucket: SUM_BUCKET on large levels; on small ones fewer, so that the bucket kernel still has ~2 workgroups per CU
+    int bshift = SUM_BUCKET_SHIFT;
+    while (bshift > 6 && (n >> bshift) < 512) --bshift;
+    const int nbuckets = (int)((n + (1 << bshift) - 1) >> bshift);
     if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
         // partition by bucket (counting sort), then one workgroup per bucket sums in LDS on a fixed-point scale.  The
         // partition kernels keep per-bucket counters in dynamic LDS (12 bytes per bucket, raised above the 64 KiB default
@@ -2378,15 +2388,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
         const int ntiles = (int)((M + SUM_TILE - 1) / SUM_TILE);
         (void)hipGetLastError();
-        hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, c->pair_child.as<unsigned>(), nbuckets, c->bhist.as<unsigned>());
+        hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, c->pair_child.as<unsigned>(), nbuckets, bshift, c->bhist.as<unsigned>());
         GSR_HIP(hipGetLastError());
         GSR_TRY(widen_scan(c->bhist.as<unsigned>(), (int64_t*)c->bstart.p, nbuckets + 1));
         GSR_HIP(hipMemcpyAsync(c->bcursor.p, c->bstart.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, st));
         hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)(((nbuckets + 1) & ~1) * 4 + nbuckets * 8), st, M, c->pair_child.as<unsigned>(),
-                           c->pair_wl.as<float>(), nbuckets, c->bcursor.as<unsigned long long>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
+                           c->pair_wl.as<float>(), nbuckets, bshift, c->bcursor.as<unsigned long long>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
         GSR_HIP(hipGetLastError());
         GSR_CHECKPOINT("pair partition");
-        hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(1024), (size_t)SUM_BUCKET * 12, st, n, c->bstart.as<unsigned long long>(),
+        hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, c->bstart.as<unsigned long long>(),
                            c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
         GSR_HIP(hipGetLastError());
     } else {
