@@ -183,6 +183,22 @@ __device__ __forceinline__ double icp_slab_dist(double v, double o, double c, in
     return d > 0.0 ? d : 0.0;
 }
 
+__device__ __forceinline__ void icp_consider(const float4 q, int j, double px, double py, double pz, double& bd, int& best, unsigned& best_i) {
+    const double dx = px - (double)q.x, dy = py - (double)q.y, dz = pz - (double)q.z;
+    const double d2 = dx * dx + dy * dy + dz * dz;
+    const unsigned qi = __float_as_uint(q.w);
+    if (d2 < bd || (d2 == bd && qi < best_i)) { bd = d2; best = j; best_i = qi; }
+}
+
+// BLOCK: rings 0 and 1 as ONE block of 3 x 3 rows of three cells, for the levels whose correspondence distance spans two or
+// more cells (the coarse levels of a multiscale run): there the neighbour is rarely in the query's own cell, and the ring
+// loop is a chain of dependent loads -- a row's cell bounds, then its points one by one: ~65 round trips to L2 for ~55
+// candidates -- with nothing else for the thread to do.  The block loads its 18 cell bounds together and the points four
+// at a time (index clamped to the row's last point: a point seen twice changes nothing); any scan order finds the same
+// minimum of (d^2, input index), and the ring loop continues at ring 2 when the bound of ring 1 does not close.
+// Coarse-to-fine pair of the bench: -11 % at 185 k points, -13 % at 1.67 M.  On a converged fine level (max_corr ~ one
+// cell) the neighbour sits in the own cell and the block costs 2.3x: BLOCK = false keeps the ring loop from ring 0.
+template <bool BLOCK>
 __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restrict__ cellStart,
                                            const float4* __restrict__ Tq, double px, double py, double pz, double& best_d2) {
     int best = -1;
@@ -192,7 +208,43 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
     const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
     // absolute slack of every geometric bound: ~500 ulp of the largest coordinate involved
     const double eps = 1e-13 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.ox) + fabs(g.oy) + fabs(g.oz) + g.c * (double)(g.gx + g.gy + g.gz));
-    for (int r = 0; r <= g.rings; ++r) {
+    int r0 = 0;
+    if (BLOCK && g.rings >= 1) {
+        int rs[9], re[9];
+        const int xa = cx - 1 > 0 ? cx - 1 : 0, xb = cx + 1 < g.gx - 1 ? cx + 1 : g.gx - 1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int z = cz + t / 3 - 1, y = cy + t % 3 - 1;
+            const bool ok = z >= 0 && z < g.gz && y >= 0 && y < g.gy;
+            const int rowbase = ok ? (z * g.gy + y) * g.gx : 0;
+            rs[t] = ok ? cellStart[rowbase + xa] : 0;
+            re[t] = ok ? cellStart[rowbase + xb + 1] : 0;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            for (int j = rs[t]; j < re[t]; j += 4) {
+                const int l = re[t] - 1;
+                const int j1 = j + 1 < l ? j + 1 : l, j2 = j + 2 < l ? j + 2 : l, j3 = j + 3 < l ? j + 3 : l;
+                const float4 q0 = Tq[j], q1 = Tq[j1], q2 = Tq[j2], q3 = Tq[j3];
+                icp_consider(q0, j, px, py, pz, bd, best, best_i);
+                icp_consider(q1, j1, px, py, pz, bd, best, best_i);
+                icp_consider(q2, j2, px, py, pz, bd, best, best_i);
+                icp_consider(q3, j3, px, py, pz, bd, best, best_i);
+            }
+        }
+        double reach = 1.0 / 0.0;
+        if (cx - 1 > 0) reach = fmin(reach, px - (g.ox + (double)(cx - 1) * g.c));
+        if (cx + 1 < g.gx - 1) reach = fmin(reach, (g.ox + (double)(cx + 2) * g.c) - px);
+        if (cy - 1 > 0) reach = fmin(reach, py - (g.oy + (double)(cy - 1) * g.c));
+        if (cy + 1 < g.gy - 1) reach = fmin(reach, (g.oy + (double)(cy + 2) * g.c) - py);
+        if (cz - 1 > 0) reach = fmin(reach, pz - (g.oz + (double)(cz - 1) * g.c));
+        if (cz + 1 < g.gz - 1) reach = fmin(reach, (g.oz + (double)(cz + 2) * g.c) - pz);
+        reach = reach * 0.999999999 - eps;
+        reach = reach > 0.0 ? reach : 0.0;
+        if (bd < reach * reach) { best_d2 = bd; return best; }
+        r0 = 2;
+    }
+    for (int r = r0; r <= g.rings; ++r) {
         for (int dz = -r; dz <= r; ++dz) {
             const int z = cz + dz;
             if (z < 0 || z >= g.gz) continue;
@@ -250,7 +302,7 @@ __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]);
 // nn_j[i] = sorted target position of the accepted nearest neighbour of source point i, or -1.  One thread per source
 // point: a search kernel with few registers (56 VGPRs, 8 waves per SIMD) in front of a streaming accumulate kernel.
 // (Measured and rejected: eight lanes per point with shuffle-combined partial searches -- 1.5x slower.)
-template <bool FROM_STATE>
+template <bool FROM_STATE, bool BLOCK>
 __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restrict__ src, Xform X, const IcpState* __restrict__ st,
                                                 IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
                                                 double max_corr2, int* __restrict__ nn_j) {
@@ -268,7 +320,7 @@ __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restr
         const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
         const double pz = T[8] * x + T[9] * y + T[10] * z + T[11];
         double d2;
-        const int j = icp_nearest(g, cellStart, Tq, px, py, pz, d2);
+        const int j = icp_nearest<BLOCK>(g, cellStart, Tq, px, py, pz, d2);
         nn_j[i] = (j >= 0 && d2 < max_corr2) ? j : -1;
     }
 }
@@ -571,7 +623,7 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float*
             if (j < 0) continue;
         } else {
             double dd;
-            j = icp_nearest(g, cellStart, Tq, px, py, pz, dd);
+            j = icp_nearest<false>(g, cellStart, Tq, px, py, pz, dd);
             if (j < 0 || !(dd < max_corr2)) continue;
         }
         const float4 q = Tq[j];
@@ -1021,7 +1073,7 @@ __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]) {
     for (int i = 0; i < 12; ++i) T[i] = st->T[i];
 }
 
-template <int KIND>
+template <int KIND, bool BLOCK>
 __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, const IcpState* __restrict__ st,
                                                             IcpGrid g, const int* __restrict__ cellStart, const int* __restrict__ nn_j,
                                                             const float4* __restrict__ Tq, const double* __restrict__ Tn,
@@ -1046,7 +1098,7 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
             if (j < 0) continue;
         } else {
             double dd;
-            j = icp_nearest(g, cellStart, Tq, px, py, pz, dd);
+            j = icp_nearest<BLOCK>(g, cellStart, Tq, px, py, pz, dd);
             if (j < 0 || !(dd < max_corr2)) continue;
         }
         const float4 q = Tq[j];
@@ -1184,6 +1236,7 @@ struct gsr_icp_ctx {
     double lambda_geometric = 0.968;            // Open3D TransformationEstimationForColoredICP default
     bool src_sorted = false;
     bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
+    bool block_search = true;       // GSR_ICP_BLOCK_SEARCH=0: always the ring loop from ring 0
     // Search / accumulate split (GSR_ICP_NN_KERNEL): 0 = one fused kernel (120 VGPRs with the 30 float64 accumulators:
     // 4 waves per SIMD); 2 = a thread-per-point search kernel (56 VGPRs, 8 waves per SIMD) writes nn_j and a streaming
     // kernel accumulates -- the search is latency bound, so occupancy wins: 21 % faster at 5 M points, equal at 0.5 M,
@@ -1237,7 +1290,7 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     const int* nnj = nullptr;
     if (c->nn_mode()) {
         GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-        hipLaunchKernelGGL((k_icp_nn<false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+        hipLaunchKernelGGL((k_icp_nn<false, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
                            c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
         nnj = c->nn_j.as<int>();
     }
@@ -1289,6 +1342,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     if (hipEventCreate(&c->e0) != hipSuccess || hipEventCreate(&c->e1) != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate failed"); }
     // Environment knobs (all of them): none changes a result, tests/test_icp_gpu.py::test_icp_knobs_change_nothing
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_NN_KERNEL")) c->nn_kernel = atoi(e);
     if (const char* e = getenv("GSR_ICP_CELL_TARGET")) { double v = atof(e); if (v > 0.01 && v < 1000) c->cell_target = v; }
     if (const char* e = getenv("GSR_ICP_MAX_CELLS")) { int v = atoi(e); if (v >= 1024) c->max_cells = v; }
@@ -1571,31 +1625,36 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         const double mc2 = c->max_corr * c->max_corr;
         const ColorArgs cargs = {c->Ti.as<double>(), c->Tg.as<double>(), c->Si.as<double>(), sqrt(c->lambda_geometric), sqrt(1.0 - c->lambda_geometric)};
         const int total_evals = hs.max_iter + 1;
+        // the first 27 cells of the search as one block of batched loads when max_corr spans two or more cells (icp_nearest)
+        const bool blockf = c->block_search && c->grid.rings >= 2;
         int issued = 0;
         GSR_HIP(hipEventRecord(c->e0, st));
         while (issued < total_evals) {
             const int chunk = total_evals - issued < 8 ? total_evals - issued : 8;
             const int* nnj = c->nn_mode() ? c->nn_j.as<int>() : (const int*)nullptr;
             for (int i = 0; i < chunk; ++i) {
-                if (c->nn_mode())
-                    hipLaunchKernelGGL((k_icp_nn<true>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(), c->state.as<IcpState>(),
-                                       c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
-                if (kind == GSR_ICP_COLORED)
-                    hipLaunchKernelGGL(k_icp_accumulate_dev<3>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, cargs, mc2, loss, k,
-                                       c->partials.as<double>());
-                else if (kind == GSR_ICP_POINT_TO_POINT)
-                    hipLaunchKernelGGL(k_icp_accumulate_dev<0>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), (const double*)nullptr, (const double*)nullptr, cargs, mc2, loss, k,
-                                       c->partials.as<double>());
-                else if (kind == GSR_ICP_POINT_TO_PLANE)
-                    hipLaunchKernelGGL(k_icp_accumulate_dev<1>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tn.as<double>(), (const double*)nullptr, cargs, mc2, loss, k,
-                                       c->partials.as<double>());
-                else
-                    hipLaunchKernelGGL(k_icp_accumulate_dev<2>, dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), c->grid,
-                                       c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), c->Tc.as<double>(), c->Sc.as<double>(), cargs, mc2, loss, k,
-                                       c->partials.as<double>());
+#define GSR_ICP_ACC(KIND, TN, SC)                                                                                                    \
+    do {                                                                                                                             \
+        if (blockf)                                                                                                                  \
+            hipLaunchKernelGGL((k_icp_accumulate_dev<KIND, true>), dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), \
+                               c->grid, c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), TN, SC, cargs, mc2, loss, k, c->partials.as<double>()); \
+        else                                                                                                                         \
+            hipLaunchKernelGGL((k_icp_accumulate_dev<KIND, false>), dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), \
+                               c->grid, c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), TN, SC, cargs, mc2, loss, k, c->partials.as<double>()); \
+    } while (0)
+                if (c->nn_mode()) {
+                    if (blockf)
+                        hipLaunchKernelGGL((k_icp_nn<true, true>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
+                                           c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+                    else
+                        hipLaunchKernelGGL((k_icp_nn<true, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
+                                           c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+                }
+                if (kind == GSR_ICP_COLORED) GSR_ICP_ACC(3, c->Tn.as<double>(), (const double*)nullptr);
+                else if (kind == GSR_ICP_POINT_TO_POINT) GSR_ICP_ACC(0, (const double*)nullptr, (const double*)nullptr);
+                else if (kind == GSR_ICP_POINT_TO_PLANE) GSR_ICP_ACC(1, c->Tn.as<double>(), (const double*)nullptr);
+                else GSR_ICP_ACC(2, c->Tc.as<double>(), c->Sc.as<double>());
+#undef GSR_ICP_ACC
                 if (c->allreduce_dev) {
                     hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>(), c->acc_dev.as<double>());
                     const int32_t rc = c->allreduce_dev(c->acc_dev.p, GSR_ICP_ACC_LEN, c->allreduce_dev_user);
@@ -1651,7 +1710,7 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
     GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-    hipLaunchKernelGGL((k_icp_nn<false>), dim3(nn_grid1(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+    hipLaunchKernelGGL((k_icp_nn<false, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
                        c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
     hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->nn_j.as<int>(),
                        c->Tq.as<float4>(), c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->corr_idx.as<int64_t>(),
