@@ -1874,6 +1874,7 @@ int32_t read_back(gsr_hem_ctx* c, const Collect& q, unsigned long long* out) {
     bool seen = false;
     if (c->rb_poll) {
         (void)hipStreamQuery(c->stream);                        // makes sure the queue is submitted
+        (void)hipGetLastError();                                // (hipErrorNotReady is not an error here)
         volatile unsigned long long* flag = c->host_rb + 15;
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 1; !(seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq); ++spins) {
