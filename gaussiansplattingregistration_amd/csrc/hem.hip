@@ -1164,18 +1164,18 @@ __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restr
 #define SUM_TILE 16384                            // pairs per workgroup of the partition kernels
 #define SUM_MAX_BUCKETS 13000                     // 12 bytes of LDS per bucket in k_bucket_scatter: 152 KiB (n <= 53 M components)
 
-__global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, const unsigned* __restrict__ child, int nb, int shift, unsigned* __restrict__ hist) {
+__global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, int tile, const unsigned* __restrict__ child, int nb, int shift, unsigned* __restrict__ hist) {
     extern __shared__ unsigned s_h[];
     for (int b = threadIdx.x; b < nb; b += blockDim.x) s_h[b] = 0u;
     __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * SUM_TILE, hi = lo + SUM_TILE < M ? lo + SUM_TILE : M;
+    const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < M ? lo + tile : M;
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_h[child[k] >> shift], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += blockDim.x)
         if (s_h[b]) atomicAdd(&hist[b], s_h[b]);
 }
 // bucket offsets are 64-bit (10^9 pairs at 40 M splats); cursor[b] starts at the bucket's first slot
-__global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, const unsigned* __restrict__ child, const float* __restrict__ wl, int nb, int shift,
+__global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, int tile, const unsigned* __restrict__ child, const float* __restrict__ wl, int nb, int shift,
                                                         unsigned long long* __restrict__ cursor, unsigned* __restrict__ o_child,
                                                         float* __restrict__ o_wl) {
     extern __shared__ unsigned s_h[];              // [nb] counts, then [nb] (lo, hi) words of the reserved base
@@ -1183,7 +1183,7 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, const unsigne
     unsigned long long* s_base = (unsigned long long*)(s_h + ((nb + 1) & ~1));
     for (int b = threadIdx.x; b < nb; b += blockDim.x) s_cnt[b] = 0u;
     __syncthreads();
-    const int64_t lo = (int64_t)blockIdx.x * SUM_TILE, hi = lo + SUM_TILE < M ? lo + SUM_TILE : M;
+    const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < M ? lo + tile : M;
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_cnt[child[k] >> shift], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += blockDim.x) {
@@ -1974,7 +1974,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
-    (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_BUCKET * 12);
+    (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 12 + 8);
     *out = c;
@@ -2379,6 +2379,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // children per bucket: SUM_BUCKET on large levels; on small ones fewer, so that the bucket kernel still has ~2 workgroups per CU
     int bshift = SUM_BUCKET_SHIFT;
     while (bshift > 6 && (n >> bshift) < 512) --bshift;
+    while (bshift < 13 && (n >> bshift) > 2500) ++bshift;       // very large levels: too many buckets scatter the partition's writes
     const int nbuckets = (int)((n + (1 << bshift) - 1) >> bshift);
     if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
         // partition by bucket (counting sort), then one workgroup per bucket sums in LDS on a fixed-point scale.  The
@@ -2387,13 +2388,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(c->bhist.reserve(((size_t)nbuckets + 1) * 4)); GSR_TRY(c->bstart.reserve(((size_t)nbuckets + 1) * 8));
         GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
         GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
-        const int ntiles = (int)((M + SUM_TILE - 1) / SUM_TILE);
+        const int tile = SUM_TILE;      // (x4 on levels with > 2000 buckets: measured, no gain)
+        const int ntiles = (int)((M + tile - 1) / tile);
         (void)hipGetLastError();
-        hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, c->pair_child.as<unsigned>(), nbuckets, bshift, c->bhist.as<unsigned>());
+        hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, tile, c->pair_child.as<unsigned>(), nbuckets, bshift, c->bhist.as<unsigned>());
         GSR_HIP(hipGetLastError());
         GSR_TRY(widen_scan(c->bhist.as<unsigned>(), (int64_t*)c->bstart.p, nbuckets + 1));
         GSR_HIP(hipMemcpyAsync(c->bcursor.p, c->bstart.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)(((nbuckets + 1) & ~1) * 4 + nbuckets * 8), st, M, c->pair_child.as<unsigned>(),
+        hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)(((nbuckets + 1) & ~1) * 4 + nbuckets * 8), st, M, tile, c->pair_child.as<unsigned>(),
                            c->pair_wl.as<float>(), nbuckets, bshift, c->bcursor.as<unsigned long long>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
         GSR_HIP(hipGetLastError());
         GSR_CHECKPOINT("pair partition");
