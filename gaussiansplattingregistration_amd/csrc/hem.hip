@@ -23,16 +23,19 @@
 //   k_keys / sort     cell key per component, radix sort (rocPRIM) -> order[]
 //   k_gather / k_gather_sh   the cell-sorted working set: A, geo, shs (+ parent radius: closed-form eigenvalue, f64 trig)
 //   k_spans           candidates every parent will scan (capacity of its output segment, LPT work estimate)
-//   k_select<SPARSE|COUNT|FILL>   one wavefront per parent: grid rows clipped to the pre-reject ellipsoid, flattened
-//                     candidate stream -> stage 1 (radius test, Mahalanobis pre-reject) -> LDS ring -> stage 2 (colour
-//                     gate, KL gate, parent rule; bit-exact float32 maths, gsr_math.h) -> LDS queue -> stage 3
-//                     (likelihood, pair records).  VALU bound.
-//   k_compact_pairs   sparse segments -> parent-major CSR
-//   k_bucket_hist / k_bucket_scatter / k_bucket_sum   per-child sums of wL: counting sort into buckets of 8192
-//                     children, then LDS accumulation on a per-child fixed-point scale -- deterministic without a sort
-//                     (GSR_HEM_SUMLW=sort: rocPRIM stable sort by child + k_sumlw)
-//   k_mstep           one wavefront per parent: responsibilities and moment sums with a lane per pair, SH rows with a lane
-//                     group per child (3 float4 per lane); reductions by DPP rotations and v_permlane swaps (no LDS traffic)
+//   k_select<SPARSE|COUNT|FILL, WPB, QUEUE>   one wavefront per parent: grid rows clipped to the pre-reject ellipsoid,
+//                     flattened candidate stream -> stage 1 (radius test, Mahalanobis pre-reject) -> LDS ring -> stage 2
+//                     (colour gate, KL gate, parent rule; bit-exact float32 maths, gsr_math.h) -> LDS queue -> stage 3
+//                     (likelihood, pair records).  VALU issue + its chain of dependent loads.
+//   k_heavy_items + k_select<.., QUEUE = true>   the heavy parents (capacity > 8x the mean) cut into work items of <= 8192
+//                     candidates, served from a queue by a second launch beside the light parents' (second stream):
+//                     one wave per parent made the heaviest parents the kernel's critical path
+//   k_compact_pairs   sparse segments (the parts of a split parent in order) -> parent-major CSR
+//   k_bucket_hist / k_bucket_scatter / k_bucket_sum   per-child sums of wL: counting sort into buckets of 64 ... 8192
+//                     children (4096 at 5 M), then LDS accumulation on a per-child fixed-point scale -- deterministic
+//                     without a sort (GSR_HEM_SUMLW=sort: rocPRIM stable sort by child + k_sumlw)
+//   k_mstep           one wavefront per four parents: responsibilities and moment sums with a lane per pair, SH rows with a
+//                     lane group per child (3 float4 per lane); reductions by DPP rotations and v_permlane swaps
 //   k_orphans*, k_valid, k_compact   orphans, validity erase, output in the reference's order
 //                     (parents by ascending input index, then orphans by ascending input index)
 //   k_rng_block_state / k_flags_glibc   the next level's parent flags from the libc rand() stream
