@@ -1165,7 +1165,7 @@ __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restr
 #define SUM_BUCKET (1 << SUM_BUCKET_SHIFT)        // children per bucket: 4096 x (4 + 8) bytes = 48 KiB of LDS, two workgroups per CU
                                                   // (phase 3 at 5 M: 8192 children 1.53 ms, 4096 1.31, 2048 1.45)
 #define SUM_TILE 16384                            // pairs per workgroup of the partition kernels
-#define SUM_MAX_BUCKETS 13000                     // 12 bytes of LDS per bucket in k_bucket_scatter: 152 KiB (n <= 53 M components)
+#define SUM_MAX_BUCKETS 32768                     // 4 bytes of LDS per bucket in the partition kernels: 128 KiB (n <= 268 M components)
 
 __global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, int tile, const unsigned* __restrict__ child, int nb, int shift, unsigned* __restrict__ hist) {
     extern __shared__ unsigned s_h[];
@@ -1179,26 +1179,26 @@ __global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, int tile, const 
 }
 // bucket offsets are 64-bit (10^9 pairs at 40 M splats); cursor[b] starts at the bucket's first slot
 __global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, int tile, const unsigned* __restrict__ child, const float* __restrict__ wl, int nb, int shift,
-                                                        unsigned long long* __restrict__ cursor, unsigned* __restrict__ o_child,
-                                                        float* __restrict__ o_wl) {
-    extern __shared__ unsigned s_h[];              // [nb] counts, then [nb] (lo, hi) words of the reserved base
-    unsigned* s_cnt = s_h;
-    unsigned long long* s_base = (unsigned long long*)(s_h + ((nb + 1) & ~1));
-    for (int b = threadIdx.x; b < nb; b += blockDim.x) s_cnt[b] = 0u;
+                                                        const unsigned long long* __restrict__ bstart, unsigned long long* __restrict__ cursor,
+                                                        unsigned* __restrict__ o_child, float* __restrict__ o_wl) {
+    // ONE 32-bit word of LDS per bucket (4 883 buckets at 40 M components: 20 KB; with a count and a 64-bit base per bucket
+    // it was 59 KB = two workgroups per CU): first the tile's count, then the next free slot of the tile's run in the bucket,
+    // relative to the bucket's first slot bstart[b]
+    extern __shared__ unsigned s_h[];
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s_h[b] = 0u;
     __syncthreads();
     const int64_t lo = (int64_t)blockIdx.x * tile, hi = lo + tile < M ? lo + tile : M;
-    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_cnt[child[k] >> shift], 1u);
+    for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) atomicAdd(&s_h[child[k] >> shift], 1u);
     __syncthreads();
     for (int b = threadIdx.x; b < nb; b += blockDim.x) {
-        const unsigned cnt = s_cnt[b];
-        s_base[b] = cnt ? atomicAdd(&cursor[b], (unsigned long long)cnt) : 0ull;      // this workgroup's run in bucket b
-        s_cnt[b] = 0u;
+        const unsigned cnt = s_h[b];
+        if (cnt) s_h[b] = (unsigned)(atomicAdd(&cursor[b], (unsigned long long)cnt) - bstart[b]);      // this workgroup's run in bucket b
     }
     __syncthreads();
     for (int64_t k = lo + threadIdx.x; k < hi; k += blockDim.x) {
         const unsigned ch = child[k];
         const int b = (int)(ch >> shift);
-        const unsigned long long pos = s_base[b] + atomicAdd(&s_cnt[b], 1u);
+        const unsigned long long pos = bstart[b] + atomicAdd(&s_h[b], 1u);
         o_child[pos] = ch;
         o_wl[pos] = wl[k];
     }
@@ -1979,7 +1979,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
-    (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 12 + 8);
+    (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     *out = c;
     return GSR_OK;
 }
@@ -2387,7 +2387,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
         // partition by bucket (counting sort), then one workgroup per bucket sums in LDS on a fixed-point scale.  The
         // partition kernels keep per-bucket counters in dynamic LDS (12 bytes per bucket, raised above the 64 KiB default
-        // in gsr_hem_create); levels with more than SUM_MAX_BUCKETS buckets (n > 53 M) take the sort path below.
+        // in gsr_hem_create); levels with more than SUM_MAX_BUCKETS buckets (n > 268 M) take the sort path below.
         GSR_TRY(c->bhist.reserve(((size_t)nbuckets + 1) * 4)); GSR_TRY(c->bstart.reserve(((size_t)nbuckets + 1) * 8));
         GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
         GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
@@ -2398,8 +2398,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipGetLastError());
         GSR_TRY(widen_scan(c->bhist.as<unsigned>(), (int64_t*)c->bstart.p, nbuckets + 1));
         GSR_HIP(hipMemcpyAsync(c->bcursor.p, c->bstart.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)(((nbuckets + 1) & ~1) * 4 + nbuckets * 8), st, M, tile, c->pair_child.as<unsigned>(),
-                           c->pair_wl.as<float>(), nbuckets, bshift, c->bcursor.as<unsigned long long>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
+        hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, tile, c->pair_child.as<unsigned>(),
+                           c->pair_wl.as<float>(), nbuckets, bshift, c->bstart.as<unsigned long long>(), c->bcursor.as<unsigned long long>(),
+                           c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
         GSR_HIP(hipGetLastError());
         GSR_CHECKPOINT("pair partition");
         hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, c->bstart.as<unsigned long long>(),
