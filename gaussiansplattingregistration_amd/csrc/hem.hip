@@ -867,6 +867,10 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
                         in = dot3(dq, dq) < pr.R2;
                     }
                     if (!IRR) in = in && (__float_as_uint(ca[u].w) & 2u);     // irregular children belong to pass B
+                    // the parent rule (mixture.cpp:131-133) needs only the flag that rides in the candidate record: a child that
+                    // is a parent itself is claimed by no parent but itself.  A third of the candidates are parents: dropped here
+                    // they never reach the exact gates of stage 2 (the conjunction does not care about the order of its tests)
+                    in = in && (!(__float_as_uint(ca[u].w) & 1u) || jj[u] == pr.js);
                     in = in && lane < left[u];
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull) continue;
