@@ -449,6 +449,24 @@ __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __re
         if (flag[j]) list[pos[j]] = (unsigned)j;
 }
 
+// The candidate stream of pass A: the non-parent components in cell order, the sorted position packed beside the two flag bits
+// (n < 2^30), and the grid's prefix table counted over them (cellStartC[c] = children before cell c = cellStart[c] - parents
+// before it).  ppos = exclusive scan of pflag; P = its total.
+__global__ __launch_bounds__(256) void k_child_stream(int64_t n, int64_t cells, int P, const float4* __restrict__ A, const int* __restrict__ pflag,
+                                                      const int* __restrict__ ppos, const int* __restrict__ cellStart,
+                                                      float4* __restrict__ Ac, int* __restrict__ cellStartC) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t j = t0; j < n; j += stride) {
+        if (pflag[j]) continue;
+        const float4 a = A[j];
+        Ac[j - ppos[j]] = make_float4(a.x, a.y, a.z, __uint_as_float(((unsigned)j << 2) | (__float_as_uint(a.w) & 3u)));
+    }
+    for (int64_t cidx = t0; cidx <= cells; cidx += stride) {
+        const int sidx = cellStart[cidx];
+        cellStartC[cidx] = sidx - (sidx < n ? ppos[sidx] : P);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // k_select: child selection (mixture.cpp:102-137) and wL_si (mixture.cpp:140-164), one wavefront per parent
 //
@@ -487,6 +505,11 @@ struct SelectArgs {
     const int* nheavy;              // device: number of heavy parents at the head of porder
     int own_lo, own_hi;             // sharded level: this rank evaluates parents [own_lo, own_hi) of plist only
     const int* cellStart;
+    // pass A streams the NON-PARENT components only (a parent can be claimed by no parent but itself, mixture.cpp:131-133, and
+    // that pair is queued directly): Ac = their {x, y, z, (sorted position << 2) | flags} in cell order, cellStartC = the grid's
+    // prefix table counted over them.  A third of the components are parents.
+    const float4* Ac;
+    const int* cellStartC;
     const double* logtab;           // glibc logf table (LDS copy)
     const int* irank;               // irank[j] = number of irregular components among sorted positions [0, j)   (n + 1 entries)
     const unsigned* ipos;           // sorted positions of the irregular components, ascending
@@ -537,7 +560,8 @@ struct ParentRec {            // 40 dwords
     EllClip ec;
     int js;
     int active;               // 0: zero / NaN radius or non-finite mean -> no children at all
-    int pad[4];
+    int selfq;                // 1: regular parent -- it is not in the stream of pass A and queues itself (flat candidate 0)
+    int pad[3];
 };
 static_assert(sizeof(ParentRec) == 160, "ParentRec is fetched as 40 dwords");
 
@@ -708,9 +732,9 @@ __device__ __forceinline__ void select_row_span(const SelectArgs& a, const GridP
             xa = xa < x0 ? x0 : xa;
             xb = xb > x1 ? x1 : xb;
             const int rowbase = (rz * g.gy + ry) * g.gx;
-            s = a.cellStart[rowbase + xa];
-            int e = a.cellStart[rowbase + xb + 1];
-            if (IRR) { s = a.irank[s]; e = a.irank[e]; }
+            int e;
+            if (IRR) { s = a.irank[a.cellStart[rowbase + xa]]; e = a.irank[a.cellStart[rowbase + xb + 1]]; }
+            else { s = a.cellStartC[rowbase + xa]; e = a.cellStartC[rowbase + xb + 1]; }      // positions in the children's stream
             len = e - s;
         }
     }
@@ -776,7 +800,8 @@ __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __re
         // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
         const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
         pr.active = (pr.R2 > 0.0f && pm_finite) ? 1 : 0;
-        pr.pad[0] = pr.pad[1] = pr.pad[2] = pr.pad[3] = 0;
+        pr.selfq = (pr.active && (__float_as_uint(pa.w) & 2u)) ? 1 : 0;
+        pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
         prec[p] = pr;
     }
 }
@@ -845,9 +870,8 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
                     // the inactive lanes behind the batch's last candidate read on past the last row: the sorted A array is
                     // padded by SEL_PAD entries, so the load stays unconditional (a load under a branch would make hipcc
                     // wait vmcnt(0) after each one instead of overlapping the SEL_U loads)
-                    if (IRR) jj[u] = lane < left[u] ? (int)a.ipos[k] : pr.js;
-                    else jj[u] = k;
-                    ca[u] = a.A[jj[u]];
+                    if (IRR) { jj[u] = lane < left[u] ? (int)a.ipos[k] : pr.js; ca[u] = a.A[jj[u]]; }
+                    else { jj[u] = k; ca[u] = a.Ac[k]; }                      // pass A: jj becomes the sorted position below
                 }
 #pragma unroll
                 for (int u = 0; u < SEL_U; ++u) {
@@ -866,11 +890,14 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
                         const f3 dq = sub3(pm, cm);
                         in = dot3(dq, dq) < pr.R2;
                     }
-                    if (!IRR) in = in && (__float_as_uint(ca[u].w) & 2u);     // irregular children belong to pass B
-                    // the parent rule (mixture.cpp:131-133) needs only the flag that rides in the candidate record: a child that
-                    // is a parent itself is claimed by no parent but itself.  A third of the candidates are parents: dropped here
-                    // they never reach the exact gates of stage 2 (the conjunction does not care about the order of its tests)
-                    in = in && (!(__float_as_uint(ca[u].w) & 1u) || jj[u] == pr.js);
+                    if (!IRR) {
+                        in = in && (__float_as_uint(ca[u].w) & 2u);           // irregular children belong to pass B
+                        jj[u] = (int)(__float_as_uint(ca[u].w) >> 2);         // the stream carries the sorted position
+                    } else {
+                        // the parent rule (mixture.cpp:131-133): a component that is a parent itself is claimed by no parent but
+                        // itself.  Pass A's stream holds no parents at all; the irregular list does
+                        in = in && (!(__float_as_uint(ca[u].w) & 1u) || jj[u] == pr.js);
+                    }
                     in = in && lane < left[u];
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull) continue;
@@ -908,6 +935,11 @@ __device__ __forceinline__ unsigned select_item(const SelectArgs& a, const GridP
     unsigned count = 0;                 // accepted pairs (uniform across the wave)
     int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
     unsigned cum = 0;                   // flat candidates of the batches behind the scan
+    if (pr.selfq) {                     // the parent itself: flat candidate 0, straight into the survivor ring (stage 2 decides)
+        cum = 1u;
+        if (lo == 0u) { if (lane == 0) q[0] = (unsigned)pr.js; qn = 1; }
+        __builtin_amdgcn_wave_barrier();
+    }
     if (pr.active) {
         // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
         // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
@@ -1058,6 +1090,7 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
         }
     }
     for (int o = 8; o > 0; o >>= 1) scanned += __shfl_xor(scanned, o);
+    if (p >= a.own_lo && p < a.own_hi && a.prec[p].selfq) scanned += 1ull;      // the parent itself is flat candidate 0
     if (sub == 0) a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
 }
 
@@ -1766,7 +1799,7 @@ struct gsr_hem_ctx {
     void* shard_user = nullptr;
     DevBuf shard_send, shard_recv;
     bool sparse_path = false;
-    DevBuf hitem, hfirst, part_cnt;
+    DevBuf hitem, hfirst, part_cnt, Ac, cellStartC;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1995,7 +2028,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     for (DevBuf& b : c->spare) b.release();
     c->cur.release(); c->nxt.release(); c->tmp.release();
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->geo, &c->shs,
-                     &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
+                     &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->Ac, &c->cellStartC, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
                      &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
@@ -2220,6 +2253,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     }
     const int P = last_pos + last_flag;
     c->stats[0] = P;
+    // the candidate stream of pass A (non-parents only) and its prefix table
+    GSR_TRY(c->Ac.reserve(((size_t)(n - P) + SEL_PAD) * 16)); GSR_TRY(c->cellStartC.reserve(((size_t)gp.ncells + 1) * 4));
+    GSR_HIP(hipMemsetAsync((char*)c->Ac.p + (size_t)(n - P) * 16, 0, (size_t)SEL_PAD * 16, st));      // the pad k_select reads past the last row
+    hipLaunchKernelGGL(k_child_stream, grd, blk, 0, st, n, (int64_t)gp.ncells, P, c->A.as<float4>(), c->pflag.as<int>(), c->ppos.as<int>(),
+                       c->cellStart.as<int>(), c->Ac.as<float4>(), c->cellStartC.as<int>());
     GSR_CHECKPOINT("grid + gather");
     GSR_HIP(hipEventRecord(c->ev[1], st));
 
@@ -2237,6 +2275,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.A = c->A.as<float4>(); sa.geo = c->geo.as<float4>();
     sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
     sa.gp = c->gparams.as<GridParams>(); sa.P = P;
+    sa.Ac = c->Ac.as<float4>(); sa.cellStartC = c->cellStartC.as<int>();
     sa.irank = c->irank.as<int>(); sa.ipos = c->ipos.as<unsigned>(); sa.n_irr = n_irr; sa.ell = c->use_ell ? 1 : 0;
     // work sharding: rank r of W evaluates the contiguous run [P r / W, P (r+1) / W) of the cell-sorted parents
     const bool sharded = c->shard_world > 1 && c->shard_allreduce != nullptr;
