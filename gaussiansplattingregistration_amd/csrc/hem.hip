@@ -2187,6 +2187,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     const int F = L.F;
     memset(c->stats, 0, sizeof(c->stats));
     c->stats[6] = n;
+    if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld components (the candidate records carry the sorted position in 30 bits)", (long long)n);
     if (n == 0) {
         if (n_out) *n_out = 0;
         if (n_dropped) *n_dropped = 0;
