@@ -561,7 +561,8 @@ struct ParentRec {            // 40 dwords
     int js;
     int active;               // 0: zero / NaN radius or non-finite mean -> no children at all
     int selfq;                // 1: regular parent -- it is not in the stream of pass A and queues itself (flat candidate 0)
-    int pad[3];
+    float ey, ez;             // half extents of the pre-reject ellipsoid along y and z (+0.1 %): no row of pass A lies beyond them
+    int pad[1];
 };
 static_assert(sizeof(ParentRec) == 160, "ParentRec is fetched as 40 dwords");
 
@@ -801,7 +802,10 @@ __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __re
         const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
         pr.active = (pr.R2 > 0.0f && pm_finite) ? 1 : 0;
         pr.selfq = (pr.active && (__float_as_uint(pa.w) & 2u)) ? 1 : 0;
-        pr.pad[0] = pr.pad[1] = pr.pad[2] = 0;
+        // extent of { d : d^T P^-1 d <= T } along an axis = sqrt(T * P_axis,axis)  (P = the parent's covariance)
+        pr.ey = sqrtf(fmaxf(0.0f, pr.ec.T * pb.w)) * 1.001f;
+        pr.ez = sqrtf(fmaxf(0.0f, pr.ec.T * pc.y)) * 1.001f;
+        pr.pad[0] = 0;
         prec[p] = pr;
     }
 }
@@ -816,13 +820,16 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
     const f3 pm = pr.pm;
     const EllClip& ec = pr.ec;
     const float Ra = fabsf(pr.R) * 1.00001f + g.slack;             // conservative search extent
+    const bool clip = !IRR && ec.on != 0.0f;
+    // rows: the sphere's box, cut down to the pre-reject ellipsoid's box when the rows are clipped to it (rows beyond its y / z
+    // extent would come out empty one by one)
+    const float Ry = clip ? fminf(Ra, pr.ey + g.slack) : Ra, Rz = clip ? fminf(Ra, pr.ez + g.slack) : Ra;
     const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
-    const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
-    const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
+    const int y0 = cell_of(pm.y - Ry, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ry, g.oy, g.inv_c, g.gy);
+    const int z0 = cell_of(pm.z - Rz, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Rz, g.oz, g.inv_c, g.gz);
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
     const int nrows = __builtin_amdgcn_readfirstlane(ny * nz);
     const float Ra2 = Ra * Ra;
-    const bool clip = !IRR && ec.on != 0.0f;
     const bool white = !IRR && pr.white != 0.0f;                // wave-uniform
     for (int rb = 0; rb < nrows; rb += 64) {
         const int r = rb + lane;
@@ -1071,18 +1078,26 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
         const EllClip ec = rp->ec;
         if (rp->active) {
             const float Ra = fabsf(rp->R) * 1.00001f + g.slack;
-            const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
-            const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
-            const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
-            const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-            const int nrows = ny * nz;
             const float Ra2 = Ra * Ra;
-            for (int r = sub; r < nrows; r += 16) {
-                int s = 0, len = 0;
-                select_row_span<false>(a, g, pm, ec, ec.on != 0.0f, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
-                scanned += (unsigned long long)(len > 0 ? len : 0);
-                if (a.n_irr > 0) {
-                    s = 0; len = 0;
+            const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
+            {   // pass A (the same rows as select_scan<.., false>)
+                const bool clip = ec.on != 0.0f;
+                const float Ry = clip ? fminf(Ra, rp->ey + g.slack) : Ra, Rz = clip ? fminf(Ra, rp->ez + g.slack) : Ra;
+                const int y0 = cell_of(pm.y - Ry, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ry, g.oy, g.inv_c, g.gy);
+                const int z0 = cell_of(pm.z - Rz, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Rz, g.oz, g.inv_c, g.gz);
+                const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+                for (int r = sub; r < nrows; r += 16) {
+                    int s = 0, len = 0;
+                    select_row_span<false>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
+                    scanned += (unsigned long long)(len > 0 ? len : 0);
+                }
+            }
+            if (a.n_irr > 0) {      // pass B: the irregular list over the sphere's rows
+                const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
+                const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
+                const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+                for (int r = sub; r < nrows; r += 16) {
+                    int s = 0, len = 0;
                     select_row_span<true>(a, g, pm, ec, false, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
                     scanned += (unsigned long long)(len > 0 ? len : 0);
                 }

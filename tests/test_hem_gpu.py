@@ -159,12 +159,12 @@ def test_full_size_properties_5m():
 
 
 @pytest.mark.gpu
-def test_large_cloud_27m_properties():
-    """27 M splats, one level: past 2^24 components and 2^32 scanned candidates (64-bit offsets everywhere), the same
-    size-independent properties as the 5 M test.  (SH degree 1 keeps the footprint at ~35 GB.)"""
+def test_large_cloud_30m_properties():
+    """30 M splats, one level: past 2^24 components and 2^32 scanned candidates (64-bit offsets everywhere), the same
+    size-independent properties as the 5 M test.  (SH degree 1 keeps the footprint at ~40 GB.)"""
     import torch
     from gaussiansplattingregistration_amd import hem, synth
-    n = 27_000_000
+    n = 30_000_000
     c = synth.make_cloud_torch(n, seed=3, sh_degree=1)
     with hem.HemMixture(rng_mode="hash", rng_seed=11) as m:
         m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
