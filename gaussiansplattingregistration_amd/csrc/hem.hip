@@ -19,7 +19,7 @@
 //
 // Kernels of one level (DESIGN.md section 4 has the measurements):
 //   k_prep            det, regular flag, one packed 64-byte record per component (input order), bounding box partials
-//   k_hist / k_grid_params   robust grid box (0.1 % trimmed per side), ~8 components per cell
+//   k_hist / k_grid_params   robust grid box (0.1 % trimmed per side), ~16 components per cell
 //   k_keys / sort     cell key per component, radix sort (rocPRIM) -> order[]
 //   k_gather / k_gather_sh   the cell-sorted working set: A, geo, shs (+ parent radius: closed-form eigenvalue, f64 trig)
 //   k_spans           candidates every parent will scan (capacity of its output segment, LPT work estimate)
@@ -1821,7 +1821,8 @@ struct gsr_hem_ctx {
     float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of k_select<COUNT> and k_select<FILL>
-    float cell_target = 8.0f;       // components per grid cell (GSR_HEM_CELL_TARGET; the result does not depend on it)
+    float cell_target = 16.0f;      // components per grid cell (GSR_HEM_CELL_TARGET; the result does not depend on it).  Swept at 5 M after the parents left
+                                    // the candidate stream: 5 -> 13.15 ms per level, 8 -> 12.87, 12 -> 12.70, 16 -> 12.61, 24 -> 12.60, 32 -> 12.68 (fewer, longer rows)
     int max_cells = 1 << 24;
 };
 
