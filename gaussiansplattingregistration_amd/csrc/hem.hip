@@ -539,7 +539,7 @@ enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
 #define SEL_PART 8192         // candidates per work item of a heavy parent, at most (SelectArgs::part)
 #define SEL_HEAVY_BLOCKS 2048  // workgroups at the head of k_select that serve the queue of heavy work items (a multiple of 8)
 #define SEL_QCAP 512          // survivor ring (power of two >= 64 + SEL_U*64)
-#define SEL_U 4               // chunks whose candidate loads are in flight together
+#define SEL_U 3               // chunks whose candidate loads are in flight together (2 or 3: equal, 4: +1 %, 6: +2 %, 8: +14 % -- registers)
 #define SEL_MCAP 2048         // flat positions covered by the row-start bit mask at a time
 #define SEL_PAD (64 * SEL_U)  // entries the sorted A array is padded by: the inactive lanes of a batch's last chunks read past the last row
 
