@@ -58,9 +58,10 @@ def bytes_level(n_in, n_out, F):
 
 
 def kernel_build_id():
-    """Identifies the kernel sources a PMC summary belongs to (profiles/*_pmc.json carry it)."""
+    """Identifies the kernel sources a PMC summary belongs to (profiles/*_pmc.json carry it): the counter passes run
+    scripts/prof_hem.py, the HEM level alone, so the HEM sources."""
     h = hashlib.sha256()
-    for f in ("hem.hip", "icp.hip", "gsr_math.h"):
+    for f in ("hem.hip", "gsr_math.h", "gsr_common.h"):
         h.update(open(os.path.join(ROOT, "gaussiansplattingregistration_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -1454,10 +1454,14 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t 
     } else if (c->have_target) {
         // sort the source by the TARGET grid's cell (rigid motions keep neighbours neighbours): lanes of a
         // wave then walk the same target cells, and the per-point ring searches share cache lines
-        GSR_TRY(c->src_raw.reserve((size_t)n * 12));
-        GSR_HIP(hipMemcpyAsync(c->src_raw.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+        const float* raw = xyz;                       // device arrays are read in place (this call returns synchronised)
+        if (!on_device) {
+            GSR_TRY(c->src_raw.reserve((size_t)n * 12));
+            GSR_HIP(hipMemcpyAsync(c->src_raw.p, xyz, (size_t)n * 12, hipMemcpyHostToDevice, st));
+            raw = c->src_raw.as<float>();
+        }
         GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->src_order.reserve(n * 4));
-        hipLaunchKernelGGL(k_icp_keys, dim3(stride_grid(n)), dim3(256), 0, st, n, c->src_raw.as<float>(), c->grid, c->keys.as<unsigned>(), c->idx.as<unsigned>());
+        hipLaunchKernelGGL(k_icp_keys, dim3(stride_grid(n)), dim3(256), 0, st, n, raw, c->grid, c->keys.as<unsigned>(), c->idx.as<unsigned>());
         int bits = 1;
         while (bits < 32 && ((int64_t)1 << bits) < c->grid.ncells) ++bits;
         size_t bytes = 0;
@@ -1466,7 +1470,7 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t 
         GSR_TRY(c->rocprim_tmp.reserve(bytes));
         GSR_HIP(rocprim::radix_sort_pairs(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
                                           c->src_order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
-        hipLaunchKernelGGL(k_icp_gather_source, dim3(stride_grid(n)), dim3(256), 0, st, n, c->src_order.as<unsigned>(), c->src_raw.as<float>(), c->src.as<float>());
+        hipLaunchKernelGGL(k_icp_gather_source, dim3(stride_grid(n)), dim3(256), 0, st, n, c->src_order.as<unsigned>(), raw, c->src.as<float>());
         c->src_sorted = true;
     } else {
         GSR_HIP(hipMemcpyAsync(c->src.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
