@@ -32,6 +32,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <chrono>
 #include <vector>
 
 #include <rocprim/rocprim.hpp>
@@ -1237,6 +1238,8 @@ struct gsr_icp_ctx {
     bool src_sorted = false;
     bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
     bool block_search = true;       // GSR_ICP_BLOCK_SEARCH=0: always the ring loop from ring 0
+    unsigned* host_rb = nullptr;    // pinned host memory for small read-backs: 256 words + the sequence flag
+    unsigned long long rb_seq = 0;
     // Search / accumulate split (GSR_ICP_NN_KERNEL): 0 = one fused kernel (120 VGPRs with the 30 float64 accumulators:
     // 4 waves per SIMD); 2 = a thread-per-point search kernel (56 VGPRs, 8 waves per SIMD) writes nn_j and a streaming
     // kernel accumulates -- the search is latency bound, so occupancy wins: 21 % faster at 5 M points, equal at 0.5 M,
@@ -1328,6 +1331,40 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
 
 extern "C" {
 
+// Small device results the host waits for (the bounding box, the loop state) are copied by one tiny kernel into pinned host
+// memory, the sequence number of the round trip last, and the host polls that word: a hipMemcpyAsync into pageable memory
+// plus hipStreamSynchronize costs 30-50 us per round trip (hem.hip does the same).
+__global__ void k_icp_publish(const unsigned* __restrict__ src, int nwords, unsigned* __restrict__ host, unsigned long long* __restrict__ flag,
+                              unsigned long long seq) {
+    for (int t = threadIdx.x; t < nwords; t += blockDim.x) __hip_atomic_store(host + t, src[t], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(flag, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+static int32_t icp_fetch(gsr_icp_ctx* c, const void* dev, void* out, size_t bytes) {
+    hipStream_t st = c->stream;
+    if (!c->host_rb || bytes > 1024 || (bytes & 3)) {
+        GSR_HIP(hipMemcpyAsync(out, dev, bytes, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        return GSR_OK;
+    }
+    const unsigned long long seq = ++c->rb_seq;
+    unsigned long long* flag = reinterpret_cast<unsigned long long*>(c->host_rb + 256);
+    hipLaunchKernelGGL(k_icp_publish, dim3(1), dim3(64), 0, st, (const unsigned*)dev, (int)(bytes >> 2), c->host_rb, flag, seq);
+    GSR_HIP(hipGetLastError());
+    (void)hipStreamQuery(st);
+    (void)hipGetLastError();
+    bool seen = false;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 1; !(seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq); ++spins) {
+        if ((spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
+        __builtin_ia32_pause();
+    }
+    if (!seen) GSR_HIP(hipStreamSynchronize(st));
+    memcpy(out, (const void*)c->host_rb, bytes);
+    return GSR_OK;
+}
+
 int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     if (!out) return fail(GSR_E_INVALID, "gsr_icp_create: out is NULL");
     *out = nullptr;
@@ -1343,6 +1380,8 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     // Environment knobs (all of them): none changes a result, tests/test_icp_gpu.py::test_icp_knobs_change_nothing
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
+    if (hipHostMalloc((void**)&c->host_rb, 1024 + 64, hipHostMallocDefault) == hipSuccess) memset(c->host_rb, 0, 1024 + 64);
+    else { c->host_rb = nullptr; (void)hipGetLastError(); }
     if (const char* e = getenv("GSR_ICP_NN_KERNEL")) c->nn_kernel = atoi(e);
     if (const char* e = getenv("GSR_ICP_CELL_TARGET")) { double v = atof(e); if (v > 0.01 && v < 1000) c->cell_target = v; }
     if (const char* e = getenv("GSR_ICP_MAX_CELLS")) { int v = atoi(e); if (v >= 1024) c->max_cells = v; }
@@ -1358,6 +1397,7 @@ int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
     for (DevBuf* b : all) b->release();
     if (c->e0) (void)hipEventDestroy(c->e0);
     if (c->e1) (void)hipEventDestroy(c->e1);
+    if (c->host_rb) (void)hipHostFree(c->host_rb);
     delete c;
     return GSR_OK;
 }
@@ -1388,8 +1428,7 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     hipLaunchKernelGGL(k_icp_bbox, dim3(nbb), dim3(256), 0, st, n, dxyz, c->bbox.as<float>() + 16);
     hipLaunchKernelGGL(k_icp_bbox_reduce, dim3(1), dim3(256), 0, st, nbb, c->bbox.as<float>() + 16, c->bbox.as<float>());
     float hb[6];
-    GSR_HIP(hipMemcpyAsync(hb, c->bbox.p, sizeof(hb), hipMemcpyDeviceToHost, st));
-    GSR_HIP(hipStreamSynchronize(st));
+    GSR_TRY(icp_fetch(c, c->bbox.p, hb, sizeof(hb)));
     double mn[3], mx[3];
     for (int k = 0; k < 3; ++k) { mn[k] = hb[k]; mx[k] = hb[3 + k]; }
     IcpGrid g;
@@ -1669,8 +1708,7 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
                 }
             }
             issued += chunk;
-            GSR_HIP(hipMemcpyAsync(&hs, c->state.p, sizeof(hs), hipMemcpyDeviceToHost, st));
-            GSR_HIP(hipStreamSynchronize(st));
+            GSR_TRY(icp_fetch(c, c->state.p, &hs, sizeof(hs)));
             if (hs.done) break;
         }
         GSR_HIP(hipEventRecord(c->e1, st));
