@@ -7,8 +7,11 @@
 //   level arrays (HBM, row-major, as the C ABI hands them over)
 //       xyz[n][3] color[n][3] cov6[n][6] opacity[n] weight[n] sh[n][F] is_parent[n]
 //   per-level working set, all in CELL-SORTED order (j = sorted position, order[j] = input index)
-//       A[j] = {x, y, z, flags}   compact float4 array: what stage 1 of k_select streams (16 bytes per candidate,
-//                                 candidates of a cell row contiguous, 1 KiB per wave instruction)
+//       A[j] = {x, y, z, flags}   compact float4 array of all components (parents' positions, the irregular list of pass B)
+//       Ac[k] = {x, y, z, (j << 2) | flags}   the NON-PARENT components only, in cell order: what stage 1 of k_select
+//                                 streams (16 bytes per candidate, candidates of a cell row contiguous, 1 KiB per wave
+//                                 instruction) + cellStartC[cells+1], the grid's prefix table counted over them.  A parent
+//                                 can be a child of no parent but itself: it queues itself
 //       geo[j][4]                 one 64-byte record per component (half a cache line, one round trip):
 //                                 {x, y, z, flags} {c00, c01, c02, c11} {c12, c22, col_r, col_g} {col_b, opacity, weight, det}
 //                                 -- what stage 2 of k_select, the parents' set-up and the M-step moments gather; after the
@@ -22,6 +25,7 @@
 //   k_hist / k_grid_params   robust grid box (0.1 % trimmed per side), ~16 components per cell
 //   k_keys / sort     cell key per component, radix sort (rocPRIM) -> order[]
 //   k_gather / k_gather_sh   the cell-sorted working set: A, geo, shs (+ parent radius: closed-form eigenvalue, f64 trig)
+//   k_child_stream    Ac and cellStartC from A, the parent flags and their scan
 //   k_spans           candidates every parent will scan (capacity of its output segment, LPT work estimate)
 //   k_select<SPARSE|COUNT|FILL, WPB, QUEUE>   one wavefront per parent: grid rows clipped to the pre-reject ellipsoid,
 //                     flattened candidate stream -> stage 1 (radius test, Mahalanobis pre-reject) -> LDS ring -> stage 2
@@ -1158,23 +1162,23 @@ __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __r
                                                        const unsigned* __restrict__ part_cnt, const unsigned* __restrict__ pcap, unsigned part,
                                                        const unsigned* __restrict__ sc, const float* __restrict__ sw,
                                                        unsigned* __restrict__ dc, float* __restrict__ dw) {
-    // 16 lanes per parent (a parent has ~65 pairs): four parents per wavefront share the per-wave latency chain
-    const int sub = threadIdx.x & 15;
-    const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
+    // 32 lanes per parent (a parent has ~65 pairs): two parents per wavefront (8 lanes: +9 % of the pass, 16: +3 %)
+    const int sub = threadIdx.x & 31;
+    const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5);
     if (p >= P) return;
     int64_t dof = poff[p];
     const int64_t so = coff[p];
     const int h = hfirst ? hfirst[p] : -1;
     if (h < 0) {
         const unsigned cnt = pcnt[p];
-        for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[so + i]; dw[dof + i] = sw[so + i]; }
+        for (unsigned i = sub; i < cnt; i += 32) { dc[dof + i] = sc[so + i]; dw[dof + i] = sw[so + i]; }
         return;
     }
     const int np = (int)(pcap[p] / part + (pcap[p] % part ? 1u : 0u));
     for (int k = 0; k < (np < 1 ? 1 : np); ++k) {
         const unsigned cnt = part_cnt[h + k];
         const int64_t sk = so + (int64_t)k * part;
-        for (unsigned i = sub; i < cnt; i += 16) { dc[dof + i] = sc[sk + i]; dw[dof + i] = sw[sk + i]; }
+        for (unsigned i = sub; i < cnt; i += 32) { dc[dof + i] = sc[sk + i]; dw[dof + i] = sw[sk + i]; }
         dof += cnt;
     }
 }
@@ -2414,7 +2418,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
         if (M > 0) {
             if (sparse) {
-                hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 16)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(),
+                hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 8)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(),
                                    c->poff.as<int64_t>(), sa.heavy_blocks ? sa.hfirst : (const int*)nullptr, sa.part_cnt, c->pcap.as<unsigned>(), sa.part ? sa.part : SEL_PART,
                                    c->sp_child.as<unsigned>(), c->sp_wl.as<float>(), c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
             } else {
