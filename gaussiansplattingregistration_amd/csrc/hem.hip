@@ -1395,6 +1395,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ unsigned s_j_[WPB][MSTEP_CHUNK];
     __shared__ float4 s_acc_[WPB][MSTEP_NV * 64];               // per-lane SH partial sums of a parent with more than MSTEP_CHUNK pairs
     __shared__ float s_mom_[WPB][16];                           // the 14 moment sums of the parent
+    __shared__ float4 s_rec_[WPB][64 * 5];                      // part 1: the batch's geometry records on their way to the pairs' lanes (80-byte stride)
     constexpr int GG = G > 0 ? G : 1;
     constexpr int CPR = 64 / GG;                                // children per round
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1402,6 +1403,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     unsigned* s_j = s_j_[wv];
     float4* s_acc = s_acc_[wv];
     float* s_mom = s_mom_[wv];
+    float4* s_rec = s_rec_[wv];
     float* s_out = reinterpret_cast<float*>(s_acc);             // at the end of a parent: its SH row on the way out
     const int gl = lane & (GG - 1), grp = lane / GG;
     constexpr int KB = MSTEP_K * WPB;                           // parents per workgroup: consecutive slots, neighbours in space
@@ -1437,14 +1439,28 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                 float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
                 float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
 #pragma nounroll
-                for (unsigned k = lane; k < cn; k += 64) {
-                    const unsigned j = a.pair_child[h.off + c0 + k];
-                    const float wl = a.pair_wl[h.off + c0 + k];
-                    const float4* row = a.geo + 4 * (int64_t)j;
-                    const float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];
+                for (unsigned k0 = 0; k0 < cn; k0 += 64) {
+                    const unsigned k = k0 + lane;
+                    const bool live = k < cn;
+                    const unsigned j = a.pair_child[h.off + c0 + (live ? k : cn - 1)];
+                    const float wl = a.pair_wl[h.off + c0 + (live ? k : cn - 1)];
+                    // the 64-byte records of the batch's 64 children, fetched by FOUR lanes per record (a wave instruction then
+                    // touches 16 cache lines instead of 64: one piece of 64 different records per instruction kept the CU's
+                    // address pipeline busy four times as long) and handed to the pair's lane through LDS
+                    s_j[k0 + lane] = j;
+                    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int r = (lane >> 2) + 16 * u;
+                        const unsigned jr = s_j[k0 + r];
+                        s_rec[r * 5 + (lane & 3)] = a.geo[4 * (int64_t)jr + (lane & 3)];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const float4 ca = s_rec[lane * 5], cb = s_rec[lane * 5 + 1], cc = s_rec[lane * 5 + 2], cd = s_rec[lane * 5 + 3];
+                    __builtin_amdgcn_wave_barrier();
                     const float sl = cd.w;                     // sumLw_i: k_bucket_sum stored it in the record (in place of det)
                     float w = 0.0f;
-                    if (sl != 0.0f) {                          // sumLw == 0: skipped (mixture.cpp:190)
+                    if (live && sl != 0.0f) {                  // sumLw == 0: skipped (mixture.cpp:190)
                         const float r_is = wl / sl;            // mixture.cpp:196
                         w = r_is * cd.z;                       // * child.weight (:197)
                         const f3 cm = {ca.x, ca.y, ca.z};
@@ -1456,8 +1472,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                         v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
                         so += w * cd.y;
                     }
-                    s_w[k] = w;
-                    s_j[k] = j;
+                    if (live) s_w[k] = w;
                 }
                 // the chunk's 14 sums over the lanes, then out of the registers (part 2 needs them for its row loads)
                 w_s = class_sum<1>(w_s);
