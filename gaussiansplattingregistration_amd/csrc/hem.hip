@@ -219,21 +219,36 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
     // The four float4 of a component (the A/B/C/D layout of the working set) are packed here, in INPUT order and
     // with coalesced reads, so that the gather into cell order fetches one 64-byte record per component instead
     // of touching nine arrays at a random index (9 x 128-byte lines -> 0.9 ms at 5 M; one line -> 0.3 ms).
+    // A lane builds the record of its component; the wave then writes its 64 records as 4 KiB of contiguous memory (through LDS,
+    // four lanes per record): four float4 stores per lane straight to rec[4 i + u] touched 64 cache lines per instruction.
+    __shared__ float4 s_t[4][64 * 5];
+    float4* st = s_t[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        s6 c = {cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5]};
-        const float dt = det6(c);
-        float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
-        const unsigned fl = (is_parent[i] ? 1u : 0u) | (is_regular(c, dt, x, y, z) ? 2u : 0u);   // bit 0 parent, bit 1 regular
-        rec[4 * i] = make_float4(x, y, z, __uint_as_float(fl));
-        rec[4 * i + 1] = make_float4(c.e00, c.e01, c.e02, c.e11);
-        rec[4 * i + 2] = make_float4(c.e12, c.e22, color[3 * i], color[3 * i + 1]);
-        rec[4 * i + 3] = make_float4(color[3 * i + 2], opacity[i], weight[i], dt);
-        if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX) {   // finite only
-            mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
-            mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
-            mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t i = base + lane;
+        if (i < n) {
+            s6 c = {cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5]};
+            const float dt = det6(c);
+            float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
+            const unsigned fl = (is_parent[i] ? 1u : 0u) | (is_regular(c, dt, x, y, z) ? 2u : 0u);   // bit 0 parent, bit 1 regular
+            st[lane * 5] = make_float4(x, y, z, __uint_as_float(fl));
+            st[lane * 5 + 1] = make_float4(c.e00, c.e01, c.e02, c.e11);
+            st[lane * 5 + 2] = make_float4(c.e12, c.e22, color[3 * i], color[3 * i + 1]);
+            st[lane * 5 + 3] = make_float4(color[3 * i + 2], opacity[i], weight[i], dt);
+            if (fabsf(x) <= FLT_MAX && fabsf(y) <= FLT_MAX && fabsf(z) <= FLT_MAX) {   // finite only
+                mn[0] = fminf(mn[0], x); mx[0] = fmaxf(mx[0], x);
+                mn[1] = fminf(mn[1], y); mx[1] = fmaxf(mx[1], y);
+                mn[2] = fminf(mn[2], z); mx[2] = fmaxf(mx[2], z);
+            }
         }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = (lane >> 2) + 16 * u;
+            if (base + r < n) rec[4 * (base + r) + (lane & 3)] = st[r * 5 + (lane & 3)];
+        }
+        __builtin_amdgcn_wave_barrier();
     }
     // per-block partial box, no atomics: 10^4 same-address atomics cost ~0.5 ms on this part (they serialise
     // across the XCDs); k_bbox_reduce folds the partials
@@ -415,21 +430,41 @@ __global__ void k_fill_const(int64_t n, OffT* p, OffT v) {
 __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __restrict__ order, const float4* __restrict__ rec, float delta,
                                                 float4* __restrict__ A, float4* __restrict__ geo, float* __restrict__ Rs,
                                                 int* __restrict__ pflag, int* __restrict__ iflag) {
+    // The 64-byte records move with FOUR lanes per record: a load instruction touches 16 records' lines and a store
+    // instruction writes 1 KiB of contiguous memory (a lane per record: 64 lines per instruction, both ways).  The lane that
+    // owns sorted position j then reads its record back from LDS for the radius and the flags.
+    __shared__ float4 s_t[4][64 * 5];
+    float4* st = s_t[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) iflag[n] = 0;       // the scan runs over n + 1 entries: irank[n] = total
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = order[j];
-        const float4 a = rec[4 * i], b = rec[4 * i + 1], cc = rec[4 * i + 2], d = rec[4 * i + 3];
-        const unsigned fl = __float_as_uint(a.w);
-        A[j] = a;
-        geo[4 * j] = a; geo[4 * j + 1] = b; geo[4 * j + 2] = cc; geo[4 * j + 3] = d;
-        float R = 0.0f;
-        if (fl & 1u) {
-            const s6 cov = {b.x, b.y, b.z, b.w, cc.x, cc.y};
-            R = delta * sqrtf(eig_max6(cov));
+    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = base + lane;
+        const unsigned oi = j < n ? order[j] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = (lane >> 2) + 16 * u;
+            const unsigned i = (unsigned)__shfl((int)oi, r, 64);
+            if (base + r < n) {
+                const float4 v = rec[4 * (int64_t)i + (lane & 3)];
+                geo[4 * (base + r) + (lane & 3)] = v;
+                st[r * 5 + (lane & 3)] = v;
+            }
         }
-        Rs[j] = R;
-        pflag[j] = (int)(fl & 1u);
-        iflag[j] = (fl & 2u) ? 0 : 1;
+        __builtin_amdgcn_wave_barrier();
+        if (j < n) {
+            const float4 a = st[lane * 5], b = st[lane * 5 + 1], cc = st[lane * 5 + 2];
+            const unsigned fl = __float_as_uint(a.w);
+            A[j] = a;
+            float R = 0.0f;
+            if (fl & 1u) {
+                const s6 cov = {b.x, b.y, b.z, b.w, cc.x, cc.y};
+                R = delta * sqrtf(eig_max6(cov));
+            }
+            Rs[j] = R;
+            pflag[j] = (int)(fl & 1u);
+            iflag[j] = (fl & 2u) ? 0 : 1;
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 // shs rows: the F SH-rest coefficients of the component, zero padded to RSH = whole float4.  One thread per float4.
