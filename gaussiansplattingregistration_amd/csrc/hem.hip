@@ -817,7 +817,13 @@ __device__ __forceinline__ void make_whitening(const s6& M, float smdMax, Parent
 // One thread per parent: the record the selection kernels read (see struct ParentRec).
 __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __restrict__ plist, const float4* __restrict__ geo,
                                                      const float* __restrict__ Rs, float kldThr, int ell, ParentRec* __restrict__ prec) {
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+    // a wave's 64 records leave as 10 KiB of contiguous memory (through LDS): a lane storing its own 160-byte record wrote 16
+    // bytes of 64 different records per instruction
+    __shared__ ParentRec s_pr[4][64];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int base = blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < P; base += gridDim.x * blockDim.x) {
+        const int p = base + lane;
+        if (p < P) {
         ParentRec pr;
         pr.js = (int)plist[p];
         const float4* prow = geo + 4 * (int64_t)pr.js;
@@ -845,7 +851,14 @@ __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __re
         pr.ey = sqrtf(fmaxf(0.0f, pr.ec.T * pb.w)) * 1.001f;
         pr.ez = sqrtf(fmaxf(0.0f, pr.ec.T * pc.y)) * 1.001f;
         pr.pad[0] = 0;
-        prec[p] = pr;
+        s_pr[wv][lane] = pr;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const int nrec = P - base < 64 ? P - base : 64;
+        const float4* src = reinterpret_cast<const float4*>(s_pr[wv]);
+        float4* dst = reinterpret_cast<float4*>(prec + base);
+        for (int t = lane; t < nrec * (int)(sizeof(ParentRec) / 16); t += 64) dst[t] = src[t];
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
