@@ -1854,6 +1854,9 @@ struct gsr_hem_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;      // second stream: the queue of heavy work items runs beside the light parents
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t aux2 = nullptr;     // third stream: the SH rows are gathered into cell order (an HBM stream only the M-step needs)
+    hipEvent_t ev_sh_fork = nullptr, ev_sh_join = nullptr;      // beside the selection (VALU / latency bound)
+    bool sh_overlap = true;         // GSR_HEM_SH_OVERLAP=0: k_gather_sh in line on the main stream
     float rho = 3.0f, delta = 3.0f, kappa = 2.5f, tau = 1.0f;
     int rng_mode = GSR_RNG_GLIBC;
     uint32_t rng_seed = 1;
@@ -1885,6 +1888,7 @@ struct gsr_hem_ctx {
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t stats_ex[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of k_select<COUNT> and k_select<FILL>
@@ -2084,6 +2088,9 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sh_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sh_join, hipEventDisableTiming);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "second stream: %s", hipGetErrorString(e)); }
     }
     {
@@ -2096,6 +2103,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
@@ -2122,7 +2130,10 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    if (c->ev_sh_fork) (void)hipEventDestroy(c->ev_sh_fork);
+    if (c->ev_sh_join) (void)hipEventDestroy(c->ev_sh_join);
     if (c->aux) (void)hipStreamDestroy(c->aux);
+    if (c->aux2) (void)hipStreamDestroy(c->aux2);
     delete c;
     return GSR_OK;
 }
@@ -2243,6 +2254,11 @@ int32_t gsr_hem_get_stats(gsr_hem_ctx* c, int64_t* out8) {
     memcpy(out8, c->stats, sizeof(c->stats));
     return GSR_OK;
 }
+int32_t gsr_hem_get_stats_ex(gsr_hem_ctx* c, int64_t* out8) {
+    if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_stats_ex: NULL argument");
+    memcpy(out8, c->stats_ex, sizeof(c->stats_ex));
+    return GSR_OK;
+}
 int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out8) {
     if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_phase_ms: NULL argument");
     memcpy(out8, c->phase_ms, sizeof(c->phase_ms));
@@ -2269,6 +2285,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     const int64_t n = L.n;
     const int F = L.F;
     memset(c->stats, 0, sizeof(c->stats));
+    memset(c->stats_ex, 0, sizeof(c->stats_ex));
     c->stats[6] = n;
     if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld components (the candidate records carry the sorted position in 30 bits)", (long long)n);
     if (n == 0) {
@@ -2318,8 +2335,19 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
     hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), c->rec.as<float4>(), c->delta, c->A.as<float4>(), c->geo.as<float4>(),
                        c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
-    if (F > 0)
-        hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * (RSH >> 2))), blk, 0, st, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
+    bool sh_pending = false;
+    if (F > 0) {
+        // only the M-step reads the sorted SH rows: the gather (1.9 GB of HBM traffic at 5 M) runs on its own stream beside the
+        // selection, which is bound by VALU issue and load latency, and is joined in front of the M-step
+        hipStream_t sst = st;
+        if (c->sh_overlap) {
+            GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
+            sst = c->aux2;
+            sh_pending = true;
+        }
+        hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * (RSH >> 2))), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
+        if (sh_pending) GSR_HIP(hipEventRecord(c->ev_sh_join, c->aux2));
+    }
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
     // the irregular components (never pre-rejected): their sorted positions, and their rank at every position
@@ -2337,6 +2365,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     }
     const int P = last_pos + last_flag;
     c->stats[0] = P;
+    c->stats_ex[0] = n_irr;
     // the candidate stream of pass A (non-parents only) and its prefix table
     GSR_TRY(c->Ac.reserve(((size_t)(n - P) + SEL_PAD) * 16)); GSR_TRY(c->cellStartC.reserve(((size_t)gp.ncells + 1) * 4));
     GSR_HIP(hipMemsetAsync((char*)c->Ac.p + (size_t)(n - P) * 16, 0, (size_t)SEL_PAD * 16, st));      // the pad k_select reads past the last row
@@ -2496,6 +2525,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             }
         }
         c->sparse_path = sparse;
+        c->stats_ex[1] = sparse ? 1 : 0;
     } else {
         GSR_TRY(c->pair_child.reserve(4)); GSR_TRY(c->pair_wl.reserve(4)); GSR_TRY(c->spair_child.reserve(4)); GSR_TRY(c->spair_wl.reserve(4));
     }
@@ -2577,6 +2607,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     Level& O = c->nxt;
     GSR_TRY(O.reserve(n_pre, F));
     O.n = n_pre; O.F = F;
+    if (sh_pending) { GSR_HIP(hipStreamWaitEvent(st, c->ev_sh_join, 0)); sh_pending = false; }      // the sorted SH rows are needed from here on
     if (P > 0) {
         MstepArgs ma;
         memset(&ma, 0, sizeof(ma));

@@ -44,9 +44,45 @@ def _quat_to_rot(q: np.ndarray) -> np.ndarray:
     return R
 
 
+# --- the anisotropic ("surfel") workload -------------------------------------------------------------------------
+# Trained 3DGS scenes are dominated by flat discs lying on surfaces and by needles along edges, with covariance
+# condition numbers of 1e2 ... 1e5, and neighbouring splats share their orientation.  shape="aniso" draws that:
+#   60 % discs    the local z axis squashed by 10^U(-2.5, -1)   (sigma ratio 10 ... 316)
+#   15 % needles  the local y and z axes squashed by 10^U(-1.5, -0.7) (sigma ratio 5 ... 32)
+#   25 % as the isotropic recipe
+# and orients the local z axis along a smooth unit normal field n(x) (three plane waves of wavelength ANISO_WAVELEN scene
+# units, + N(0, 0.05) jitter), so that nearby discs are nearly coplanar -- random orientations would make every KL
+# divergence huge and nothing would merge.  Same sigma_max distribution as the isotropic recipe: the search radii, and
+# with them the candidates per parent, stay comparable.
+ANISO_WAVELEN = 4.0
+_ANISO_DIRS = np.array([[0.8, 0.36, 0.48], [-0.28, 0.9, 0.32], [0.1, -0.5, 0.86]])
+_ANISO_PHASE = np.array([0.3, 1.7, 4.1])
+_ANISO_AMP = np.array([1.0, 0.8, 0.6])
+
+
+def _aniso_frames(xyz: np.ndarray, jitter: np.ndarray, psi: np.ndarray, needle: np.ndarray) -> np.ndarray:
+    """Rotation matrices (n,3,3), columns = the splats' local x, y, z axes: z along the normal field, x along a coherent
+    tangent (needles) or turned by psi about the normal (everything else)."""
+    w = (2.0 * np.pi / ANISO_WAVELEN) * (_ANISO_DIRS / np.linalg.norm(_ANISO_DIRS, axis=1, keepdims=True))
+    ph = xyz.astype(np.float64) @ w.T + _ANISO_PHASE                       # (n, 3 waves)
+    nrm = (np.cos(ph) * _ANISO_AMP) @ w + np.array([0.0, 0.0, 0.35]) + jitter
+    nrm /= np.linalg.norm(nrm, axis=1, keepdims=True)
+    e = np.where((np.abs(nrm[:, 0]) > 0.9)[:, None], np.array([0.0, 1.0, 0.0]), np.array([1.0, 0.0, 0.0]))
+    t1 = np.cross(nrm, e)
+    t1 /= np.linalg.norm(t1, axis=1, keepdims=True)
+    t2 = np.cross(nrm, t1)
+    c, sn = np.cos(psi)[:, None], np.sin(psi)[:, None]
+    c = np.where(needle[:, None], 1.0, c)
+    sn = np.where(needle[:, None], 0.0, sn)
+    x = c * t1 + sn * t2
+    y = -sn * t1 + c * t2
+    return np.stack([x, y, nrm], 2)
+
+
 def make_cloud(n: int, seed: int = 0, h: float | None = None, sh_degree: int = 3,
-               chunk: int = 1 << 20) -> dict:
-    """Return the five level-0 arrays the HEM boundary takes, as float32 numpy arrays."""
+               chunk: int = 1 << 20, shape: str = "iso") -> dict:
+    """Return the five level-0 arrays the HEM boundary takes, as float32 numpy arrays.  shape: "iso"  or
+    "aniso" (discs and needles on a smooth orientation field, see above)."""
     if h is None:
         h = half_extent(n)
     F = 3 * ((sh_degree + 1) ** 2 - 1)
@@ -55,10 +91,24 @@ def make_cloud(n: int, seed: int = 0, h: float | None = None, sh_degree: int = 3
     s = np.exp(rng.normal(-2.5, 0.5, (n, 3))).astype(np.float32)
     q = rng.normal(size=(n, 4))
     q /= np.linalg.norm(q, axis=1, keepdims=True)
+    frames = None
+    if shape == "aniso":
+        arng = np.random.default_rng(seed + 104729)          # its own stream: the "iso" draws above stay what they were
+        u = arng.random(n)
+        disc, needle = u < 0.60, (u >= 0.60) & (u < 0.75)
+        s = s.astype(np.float64)
+        s[:, 2] *= np.where(disc, 10.0 ** arng.uniform(-2.5, -1.0, n), 1.0)
+        f = 10.0 ** arng.uniform(-1.5, -0.7, n)
+        s[:, 1] *= np.where(needle, f, 1.0)
+        s[:, 2] *= np.where(needle, f, 1.0)
+        s = s.astype(np.float32)
+        frames = (arng.normal(0, 0.05, (n, 3)), arng.uniform(0, 2 * np.pi, n), needle)
+    elif shape != "iso":
+        raise ValueError(f"unknown cloud shape {shape!r}")
     cov6 = np.empty((n, 6), dtype=np.float32)
     for a in range(0, n, chunk):           # chunked: the (n,3,3) float64 temporaries are large at 5M
         b = min(n, a + chunk)
-        R = _quat_to_rot(q[a:b])
+        R = _quat_to_rot(q[a:b]) if frames is None else _aniso_frames(xyz[a:b], frames[0][a:b], frames[1][a:b], frames[2][a:b])
         L = R * s[a:b, None, :].astype(np.float64)
         C = (L @ L.transpose(0, 2, 1)).astype(np.float32)
         cov6[a:b] = C[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
@@ -66,7 +116,7 @@ def make_cloud(n: int, seed: int = 0, h: float | None = None, sh_degree: int = 3
     op = rng.normal(0, 2.0, (n,)).astype(np.float32)
     sh = rng.normal(0, 0.1, (n, F)).astype(np.float32)
     return {"xyz": xyz, "color": col, "opacity": op, "cov6": cov6, "sh": sh,
-            "sh_degree": sh_degree, "h": float(h)}
+            "sh_degree": sh_degree, "h": float(h), "shape": shape}
 
 
 def rigid_transform(angle_deg: float = 5.0, axis=(1.0, 1.0, 1.0), translation=(0.0, 0.0, 0.0)) -> np.ndarray:
@@ -115,7 +165,7 @@ def make_pair(n: int, seed: int = 0, sh_degree: int = 3, jitter: float = 0.002,
     return source, target, T_gt
 
 
-def make_cloud_torch(n: int, seed: int = 0, device="cuda:0", sh_degree: int = 3, h: float | None = None):
+def make_cloud_torch(n: int, seed: int = 0, device="cuda:0", sh_degree: int = 3, h: float | None = None, shape: str = "iso"):
     """Same distributions as ``make_cloud`` drawn directly on the GPU with torch's generator (for the
     5M-splat benchmark / full-size tests: no host staging).  Not the same stream as the NumPy recipe."""
     import torch
@@ -126,10 +176,39 @@ def make_cloud_torch(n: int, seed: int = 0, device="cuda:0", sh_degree: int = 3,
     xyz = (torch.rand((n, 3), device=device, generator=g) * 2 - 1) * h
     s = torch.exp(torch.randn((n, 3), device=device, generator=g) * 0.5 - 2.5)
     q = torch.nn.functional.normalize(torch.randn((n, 4), device=device, generator=g), dim=1)
-    w, x, y, z = q.unbind(1)
-    R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
-                     2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
-                     2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).view(n, 3, 3)
+    if shape == "aniso":                        # the recipe of make_cloud(shape="aniso"), in float64 on the device
+        ag = torch.Generator(device=device).manual_seed(seed + 104729)
+        u = torch.rand((n,), device=device, generator=ag)
+        disc, needle = u < 0.60, (u >= 0.60) & (u < 0.75)
+        one = torch.ones((), device=device)
+        s = s.clone()
+        s[:, 2] *= torch.where(disc, 10.0 ** (torch.rand((n,), device=device, generator=ag) * 1.5 - 2.5), one)
+        f = 10.0 ** (torch.rand((n,), device=device, generator=ag) * 0.8 - 1.5)
+        s[:, 1] *= torch.where(needle, f, one)
+        s[:, 2] *= torch.where(needle, f, one)
+        jit = torch.randn((n, 3), device=device, generator=ag, dtype=torch.float64) * 0.05
+        psi = torch.rand((n,), device=device, generator=ag, dtype=torch.float64) * (2 * np.pi)
+        dirs = torch.as_tensor(_ANISO_DIRS / np.linalg.norm(_ANISO_DIRS, axis=1, keepdims=True), device=device)
+        wv = (2.0 * np.pi / ANISO_WAVELEN) * dirs
+        ph = xyz.double() @ wv.T + torch.as_tensor(_ANISO_PHASE, device=device)
+        nrm = (torch.cos(ph) * torch.as_tensor(_ANISO_AMP, device=device)) @ wv + torch.tensor([0.0, 0.0, 0.35], device=device, dtype=torch.float64) + jit
+        nrm = torch.nn.functional.normalize(nrm, dim=1)
+        ex = torch.tensor([1.0, 0.0, 0.0], device=device, dtype=torch.float64).expand(n, 3)
+        ey = torch.tensor([0.0, 1.0, 0.0], device=device, dtype=torch.float64).expand(n, 3)
+        e = torch.where((nrm[:, 0].abs() > 0.9)[:, None], ey, ex)
+        t1 = torch.nn.functional.normalize(torch.linalg.cross(nrm, e), dim=1)
+        t2 = torch.linalg.cross(nrm, t1)
+        c = torch.where(needle, torch.ones_like(psi), torch.cos(psi))[:, None]
+        sn = torch.where(needle, torch.zeros_like(psi), torch.sin(psi))[:, None]
+        R = torch.stack([c * t1 + sn * t2, -sn * t1 + c * t2, nrm], 2).float()       # columns = local x, y, z
+        del jit, psi, ph, nrm, e, t1, t2, c, sn
+    elif shape != "iso":
+        raise ValueError(f"unknown cloud shape {shape!r}")
+    else:
+        w, x, y, z = q.unbind(1)
+        R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+                         2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+                         2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], 1).view(n, 3, 3)
     # Sigma = R diag(s^2) R^T written out element-wise: a batched matmul (torch.bmm) with more than 2^24 batches faults
     # on this ROCm build, and the large-cloud runs (20 M, 40 M splats) go past that
     s2 = s * s
@@ -139,7 +218,7 @@ def make_cloud_torch(n: int, seed: int = 0, device="cuda:0", sh_degree: int = 3,
     col = torch.randn((n, 3), device=device, generator=g) * 0.5
     op = torch.randn((n,), device=device, generator=g) * 2.0
     sh = torch.randn((n, F), device=device, generator=g) * 0.1
-    return {"xyz": xyz, "color": col, "opacity": op, "cov6": cov6, "sh": sh, "sh_degree": sh_degree, "h": float(h)}
+    return {"xyz": xyz, "color": col, "opacity": op, "cov6": cov6, "sh": sh, "sh_degree": sh_degree, "h": float(h), "shape": shape}
 
 
 def apply_rigid_torch(cloud: dict, T):

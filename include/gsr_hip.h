@@ -115,6 +115,10 @@ int32_t gsr_hem_get_level(gsr_hem_ctx* ctx, float* xyz, float* color, float* cov
  *  [0] parents  [1] accepted (parent,child) pairs  [2] orphans  [3] dropped  [4] candidates scanned
  *  [5] grid cells  [6] components in  [7] components out */
 int32_t gsr_hem_get_stats(gsr_hem_ctx* ctx, int64_t* out8);
+/* More counters of the most recent level:  [0] components outside the stage-1 filter's precondition ("irregular": not
+ * verified symmetric positive definite with an accurate float32 determinant -- they take the exact gates only)
+ * [1] 1 = the one-pass selection ran, 0 = the COUNT + FILL fallback  [2..7] reserved (0). */
+int32_t gsr_hem_get_stats_ex(gsr_hem_ctx* ctx, int64_t* out8);
 /* Device time of the phases of the most recent level, in milliseconds (hipEvent pairs on the
  * context's stream):  [0] prep+grid  [1] selection (count+scan+fill)  [2] per-child sums
  * [3] M-step + orphans  [4] flags+validity  [5] whole level

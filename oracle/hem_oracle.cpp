@@ -215,7 +215,9 @@ struct Grid {
         for (int dz = -1; dz <= 1; ++dz)
             for (int dy = -1; dy <= 1; ++dy)
                 for (int dx = -1; dx <= 1; ++dx) {
-                    I3 n = {c.x + dx, c.y + dy, c.z + dz};
+                    // a NaN query coordinate converts to INT_MIN (cvttss2si), and the reference's vec3i addition then wraps; the
+                    // same wrap here in unsigned arithmetic (defined behaviour: found by UBSan, scripts/sanitize_oracle.sh)
+                    I3 n = {(int)((unsigned)c.x + (unsigned)dx), (int)((unsigned)c.y + (unsigned)dy), (int)((unsigned)c.z + (unsigned)dz)};
                     auto it = cells.find(n);
                     if (it == cells.end()) continue;
                     for (unsigned k = it->second.first; k < it->second.second; ++k) {
@@ -364,7 +366,7 @@ struct gsr_oracle_hem {
                 sv.e12 += (cv.e12 + d.y * d.z) * w;
                 sv.e22 += (cv.e22 + d.z * d.z) * w;
                 so += w * P.opacity[i];
-                const float* f = &P.sh[(size_t)i * F];
+                const float* f = P.sh.data() + (size_t)i * F;      // (F may be 0: no element to take the address of -- UBSan)
                 for (int k = 0; k < F; ++k) sumF[k] += f[k] * w;
             }
             float inv_w = 1.0f / w_s;

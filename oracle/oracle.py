@@ -16,7 +16,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libgsr_oracle.so")
+_LIB_PATH = os.environ.get("GSR_ORACLE_LIB") or os.path.join(_HERE, "libgsr_oracle.so")      # GSR_ORACLE_LIB: the sanitizer build
 _lib = None
 
 _f32p = np.ctypeslib.ndpointer(dtype=np.float32, flags="C_CONTIGUOUS")
@@ -29,6 +29,8 @@ _i64p = np.ctypeslib.ndpointer(dtype=np.int64, flags="C_CONTIGUOUS")
 def build(force: bool = False) -> str:
     """Compile oracle/libgsr_oracle.so (g++, a few seconds)."""
     srcs = [os.path.join(_HERE, f) for f in ("hem_oracle.cpp", "icp_oracle.cpp", "glibc_rand.h", "oracle_api.h")]
+    if os.environ.get("GSR_ORACLE_LIB"):
+        return _LIB_PATH
     if force or not os.path.exists(_LIB_PATH) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in srcs):
         subprocess.check_call(["make", "-C", _HERE, "oracle"], stdout=subprocess.DEVNULL)
     return _LIB_PATH

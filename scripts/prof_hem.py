@@ -7,7 +7,8 @@ from gaussiansplattingregistration_amd import hem, synth
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 5_000_000
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
-c = synth.make_cloud_torch(n, seed=100)
+shape = sys.argv[4] if len(sys.argv) > 4 else "iso"
+c = synth.make_cloud_torch(n, seed=100, shape=shape)
 m = hem.HemMixture()
 for rep in range(reps):
     m.set_rng("glibc", 1, 0)
