@@ -82,6 +82,7 @@ TEST_HOOKS = {
     "gsr_debug_logf": (_i32, [_vp, _i64, _vp, _i32]),
     "gsr_debug_kld": (_i32, [_vp, _vp, _vp, _vp, _i64, _vp, _i32]),
     "gsr_debug_kl_gate": (_i32, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _i32]),
+    "gsr_debug_stage1": (_i32, [_vp, _vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
 }
 
 _lib = None

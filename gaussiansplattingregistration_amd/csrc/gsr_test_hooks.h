@@ -18,6 +18,13 @@ int32_t gsr_debug_kld(const float* child_mean, const float* child_cov6, const fl
  * fell back to the IEEE division + glibc logf.  Host pointers. */
 int32_t gsr_debug_kl_gate(const float* s2, const float* det_c, const float* det_p, int64_t n, float thr, uint8_t* reject,
                           float* fast_log, uint8_t* need_exact, int32_t device);
+/* The stage-1 filter of k_select on n independent (parent, child) pairs, by the device functions the kernels use: the
+ * "regular" predicate of both (is_regular), the parent's filter record (make_filter: white = filter certified, T1 = its bound,
+ * clip_on = grid rows clipped to the ellipsoid) and reject[i] = 1 where stage 1 would drop the pair without the exact gates.
+ * Host pointers; means [n*3], cov6 [n*6]. */
+int32_t gsr_debug_stage1(const float* parent_mean, const float* parent_cov6, const float* child_mean, const float* child_cov6, int64_t n,
+                         float kld_thr, uint8_t* parent_regular, uint8_t* child_regular, uint8_t* white, uint8_t* reject, float* T1,
+                         uint8_t* clip_on, int32_t device);
 #ifdef __cplusplus
 }
 #endif

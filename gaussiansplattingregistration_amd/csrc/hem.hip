@@ -187,29 +187,34 @@ __device__ __forceinline__ float class_sum(float v) {
 // k_prep: det, parent query radius, bounding box of the finite centres
 //   radius = delta * sqrtf(lambda_max)                       (mixture.cpp:88)
 // ------------------------------------------------------------------------------------------------
-// Is this component "regular" for the stage-1 Mahalanobis pre-reject of k_select?  Finite, positive
-// definite (Sylvester), sane magnitudes and condition number <= ~80, judged on float32 closed-form
-// eigenvalues (accuracy ~1e-4 lambda_max is ample for a threshold at lambda_min > 0.0125 lambda_max).
+// Is this component "regular", i.e. may the stage-1 filter of k_select judge it?  The filter's exactness argument
+// ("stage-1 bound") needs, of a CHILD: its covariance (the float32 entries read as real numbers) is
+// symmetric positive definite, and the float32 determinant the reference computes for it (det6, vec.hpp:863-866) is
+// within DET_TOL of the true one; and of both children and parents a determinant inside [1e-18, 1e18], so that the
+// quotient det_c / det_p of the KL gate is a normal float32 number (an overflowing quotient makes the reference ACCEPT
+// the pair through log(inf); nothing in front of the exact gates may then drop it).  All of it is VERIFIED here in
+// float64 on the component's own numbers -- no bound on the condition number: a flat disc with axis ratio 300 passes,
+// a needle whose float32 determinant is cancellation noise does not, and takes the exact gates only (pass B).
+//   products of two float32 values are exact in float64; the 2x2 minor and the cofactor expansion then carry a few
+//   float64 roundings of their largest term, so "minor > 1e-12 a00 a11" and "det > 1e-9 (sum of |terms|)" certify positive
+//   definiteness (Sylvester) and a determinant good to 1e-6 relative.
+#define GSR_DET_TOL 0.04           // |det_float32 / det - 1| allowed for a regular component (enters the filter bound as is)
+__device__ __forceinline__ bool spd_det64(double a00, double a01, double a02, double a11, double a12, double a22, double& det) {
+    const double m2 = a00 * a11 - a01 * a01;
+    const double t1 = a00 * (a11 * a22 - a12 * a12), t2 = a01 * (a01 * a22 - a12 * a02), t3 = a02 * (a01 * a12 - a11 * a02);
+    det = t1 - t2 + t3;
+    const double mag = fabs(a00) * (fabs(a11 * a22) + a12 * a12) + fabs(a01) * (fabs(a01 * a22) + fabs(a12 * a02)) +
+                       fabs(a02) * (fabs(a01 * a12) + fabs(a11 * a02));
+    return a00 > 0.0 && a11 > 0.0 && a22 > 0.0 && m2 > 1e-12 * a00 * a11 && det > 1e-9 * mag && mag < 1e300;
+}
 __device__ __forceinline__ bool is_regular(const s6& c, float det, float x, float y, float z) {
     const float big = 1e12f;
     if (!(fabsf(x) < big && fabsf(y) < big && fabsf(z) < big)) return false;
     if (!(fabsf(c.e00) < big && fabsf(c.e01) < big && fabsf(c.e02) < big && fabsf(c.e11) < big && fabsf(c.e12) < big && fabsf(c.e22) < big)) return false;
-    const float m2 = c.e00 * c.e11 - c.e01 * c.e01;
-    if (!(c.e00 > 1e-12f && m2 > 0.0f && det > 1e-36f)) return false;
-    // eigenvalues of the symmetric 3x3 (trigonometric form, float32)
-    const float q = (c.e00 + c.e11 + c.e22) * (1.0f / 3.0f);
-    const float b00 = c.e00 - q, b11 = c.e11 - q, b22 = c.e22 - q;
-    const float p2 = b00 * b00 + b11 * b11 + b22 * b22 + 2.0f * (c.e01 * c.e01 + c.e02 * c.e02 + c.e12 * c.e12);
-    const float pp = sqrtf(p2 * (1.0f / 6.0f));
-    if (!(pp > 0.0f)) return true;                      // isotropic: kappa = 1
-    const float ip = 1.0f / pp;
-    const float a00 = b00 * ip, a11 = b11 * ip, a22 = b22 * ip, a01 = c.e01 * ip, a02 = c.e02 * ip, a12 = c.e12 * ip;
-    float hd = 0.5f * (a00 * (a11 * a22 - a12 * a12) - a01 * (a01 * a22 - a12 * a02) + a02 * (a01 * a12 - a11 * a02));
-    hd = fminf(fmaxf(hd, -1.0f), 1.0f);
-    const float phi = acosf(hd) * (1.0f / 3.0f);
-    const float lmax = q + 2.0f * pp * cosf(phi);
-    const float lmin = q + 2.0f * pp * cosf(phi + 2.0943951023931953f);
-    return lmin > 0.0125f * lmax && lmax > 0.0f;
+    if (!(det >= 1e-18f && det <= 1e18f)) return false;
+    double det64;
+    if (!spd_det64((double)c.e00, (double)c.e01, (double)c.e02, (double)c.e11, (double)c.e12, (double)c.e22, det64)) return false;
+    return fabs((double)det - det64) <= GSR_DET_TOL * det64;
 }
 
 __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict__ xyz, const float* __restrict__ color,
@@ -724,13 +729,9 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     __builtin_amdgcn_wave_barrier();
 }
 
-// Row clipping by the parent's pre-reject ellipsoid E = { x : (x-mu)^T P^-1 (x-mu) <= T } (struct EllClip).  A regular child
-// outside E fails the stage-1 filter anyway, so for a regular parent only the grid cells E touches need scanning (E is
-// inscribed in the query sphere and typically holds 1/3 of its volume).  For a row (= the slab dy in [cy-hy, cy+hy],
-// dz in [cz-hz, cz+hz] relative to the parent) write  smd = M00 (dx - xc(dy,dz))^2 + S(dy,dz)  with xc linear and
-// S the Schur-complement form K; sqrt(S) is a norm, so over the slab  sqrt(S) >= sqrt(S(c)) - sqrt(lmax(K)) |h|,
-// lmax(K) <= tr K, and |xc - xc(c)| <= (|M01| hy + |M02| hz) / M00: a conservative x interval in ~40 flops.
-// T carries 1% over smdMax: the float32 rounding of smd and of K is < 1e-3 relative for kappa(P) < 80.
+// Row clipping by the parent's filter ellipsoid E = { d : d^T M d <= T_clip } (struct EllClip, filled by make_filter, which
+// also carries the argument): a regular child outside E fails the stage-1 filter anyway, so only the grid cells E touches need
+// scanning (E is inscribed in the query sphere; for a flat disc it holds a few percent of its volume).
 
 // The span (first sorted position, length) of one grid row (ry, rz) for a parent at pm: the row's cells within the
 // sphere of radius sqrt(Ra2), clipped to the pre-reject ellipsoid when `clip`.  IRR: positions in the irregular list.
@@ -760,9 +761,11 @@ __device__ __forceinline__ void select_row_span(const SelectArgs& a, const GridP
                 lo = 1.0f; hi = -1.0f;                             // the row misses the ellipsoid
             } else {
                 const float w = fast_sqrt(rem2 * ec.im00) * 1.001f;
-                const float xc = -(ec.m01 * cy + ec.m02 * cz) * ec.im00;
+                const float t1 = ec.m01 * cy, t2 = ec.m02 * cz;
+                const float xc = -(t1 + t2) * ec.im00;
                 const float dl = (fabsf(ec.m01) * hy + fabsf(ec.m02) * hz) * ec.im00 * 1.001f;
-                const float pad = g.slack + 1e-5f * fabsf(xc);
+                // the two terms of xc may cancel (a thin disc tilted against the axes): its rounding error is relative to them, not to xc
+                const float pad = g.slack + 1e-5f * fabsf(xc) + 1e-6f * (fabsf(t1) + fabsf(t2)) * ec.im00;
                 lo = fmaxf(lo, xc - dl - w - pad);
                 hi = fminf(hi, xc + dl + w + pad);
             }
@@ -780,38 +783,86 @@ __device__ __forceinline__ void select_row_span(const SelectArgs& a, const GridP
     }
 }
 
-__device__ __forceinline__ EllClip make_ellclip(const s6& M, float smdMax, int ell) {
+// The stage-1 filter of a regular parent, and the row clipping that goes with it (one thread per parent, float64).
+//
+// What the reference decides (gaussian.hpp:106-109, mixture.cpp:126-129), with M = its float32 cofactor inverse of the
+// parent's covariance (pr.pinv, the very numbers stage 2 uses), d = the float32 mean difference, C the child:
+//     reject  <=>  fl(0.5 (s2 - lf)) > thr,   s2 = fl(fl(smd + tr) - 3),  smd = fl(d^T M d),  tr = fl(tr(M C)),  lf = logf(fl(det_c / det_p)).
+// Stage 1 may drop a pair only when that is CERTAIN.  With u = 2^-24, S = d^T M d and Tr = tr(M C) in real arithmetic
+// on the float32 data, K >= tr(M) / lambda_min(M), and a regular child (is_regular: C positive definite, its float32
+// determinant within DET_TOL of det C, quotient of determinants a normal number):
+//     smd >= S (1 - 6.1 u K),  tr >= Tr (1 - 5.1 u K)                       (dot products of length 3 + 3 / 3 + 2, |M|:|C| <= K Tr)
+//     s2 - lf >= (S + Tr)(1 - theta) - 3 - ln(det_c / det_p) - 1.5e-5,     theta = 6.1 u K + 2 u
+//     Tr (1 - theta) - ln det C >= 3 + ln det((1 - theta) M)               (M positive definite: minimum over all SPD C)
+//  => s2 - lf >= S (1 - theta) + 3 ln(1 - theta) - G - DET_TOL - 2e-5,     G = -ln(det M * det_p)   (0 for an exact inverse)
+// so the pair is rejected for certain when S > S_min = (2 thr + G + DET_TOL + 3.2 theta + 4e-5) / (1 - theta).  The filter
+// evaluates S as |U d|^2 with the float32-rounded Cholesky factor U of M (nine fused multiply-adds): that value is below
+// S (1 + 4.1 u sqrt(K))^2 (1 + 3.1 u), which the factor (1 + theta)^2 on the bound covers.  Everything a parent needs
+// for it -- M positive definite, K, G -- is computed HERE from M's float32 entries in float64; a parent for which it
+// cannot be certified (theta > 1/4: condition number beyond ~3e5; M not positive definite; |G| > 1) scans its search
+// sphere with the reference's radius test instead (white = 0), like every parent did before round 1's pre-reject.
+// tests/test_hem_gpu.py::test_stage1_filter_never_rejects_an_accepted_pair attacks the bound on the device.
+//
+// Row clipping: only the grid rows the ellipsoid E = { d : S <= T_clip } meets need scanning, T_clip = T1 (1 + theta)^2 (1 + 1e-4)
+// (beyond it the filter's own float32 value exceeds T1).  For a row = the slab dy in [cy - hy, cy + hy], dz in [cz - hz, cz + hz]:
+// S = M00 (dx - xc(dy, dz))^2 + q(dy, dz), q the quadratic form of the Schur complement Ks of M; sqrt(q) is a norm, so over the
+// slab sqrt(q) >= sqrt(q(c)) - sqrt(lmax(Ks)) |h|, lmax(Ks) <= tr Ks, and xc is linear: a conservative x interval in ~45
+// flops (select_row_span).  The constants are float64 values rounded to float32 with the margins folded in: Ks scaled
+// down by (1 - 4 theta - 2e-3) -- the float32 evaluation of q loses up to 12 u tr(Ks) / lmin(Ks) <= 4 theta of it --
+// T_clip and 1 / M00 rounded up.
+__device__ __forceinline__ void make_filter(const s6& Mf, float det_p, float kldThr, int ell, bool parent_regular, ParentRec& pr) {
     EllClip ec;
-    ec.im00 = 1.0f / M.e00;
-    ec.m01 = M.e01; ec.m02 = M.e02;
-    ec.k11 = M.e11 - M.e01 * M.e01 * ec.im00;
-    ec.k12 = M.e12 - M.e01 * M.e02 * ec.im00;
-    ec.k22 = M.e22 - M.e02 * M.e02 * ec.im00;
-    ec.kr = sqrtf(ec.k11 + ec.k22) * 1.001f;
-    ec.T = smdMax * 1.01f;
-    const bool ok = ell && smdMax < FLT_MAX && M.e00 > 0.0f && ec.im00 < FLT_MAX && ec.k11 > 0.0f && ec.k22 > 0.0f &&
-                    ec.k11 * ec.k22 > ec.k12 * ec.k12 && ec.kr < FLT_MAX;
-    ec.on = ok ? 1.0f : 0.0f;
-    return ec;
-}
-
-// Whitened form of the stage-1 filter: M = U^T U (upper Cholesky factor), so d^T M d = |U d|^2 in nine fused
-// multiply-adds instead of the twenty multiplies and adds of the reference's expression.  Both evaluate the same
-// quadratic form of an SPD matrix with kappa < 80 to < 1e-3 relative, and the filter bound carries 1 % (the margin the
-// row clipping above already relies on), so nothing the exact KL gate of stage 2 could accept is dropped here.
-__device__ __forceinline__ void make_whitening(const s6& M, float smdMax, ParentRec& pr) {
-    const float u00 = sqrtf(M.e00), i00 = 1.0f / u00;
-    const float u01 = M.e01 * i00, u02 = M.e02 * i00;
-    const float t11 = M.e11 - u01 * u01;
-    const float u11 = sqrtf(t11), i11 = 1.0f / u11;
-    const float u12 = (M.e12 - u01 * u02) * i11;
-    const float t22 = M.e22 - u02 * u02 - u12 * u12;
-    const float u22 = sqrtf(t22);
-    const bool ok = smdMax < FLT_MAX && M.e00 > 0.0f && t11 > 0.0f && t22 > 0.0f && u00 < FLT_MAX && u11 < FLT_MAX && u22 < FLT_MAX &&
-                    i00 < FLT_MAX && i11 < FLT_MAX;
-    pr.u00 = u00; pr.u01 = u01; pr.u02 = u02; pr.u11 = u11; pr.u12 = u12; pr.u22 = u22;
-    pr.T1 = smdMax * 1.01f;
-    pr.white = ok ? 1.0f : 0.0f;
+    ec.on = 0.0f; ec.k11 = ec.k12 = ec.k22 = ec.kr = ec.im00 = ec.m01 = ec.m02 = 0.0f; ec.T = __builtin_inff();
+    pr.white = 0.0f;
+    pr.u00 = pr.u01 = pr.u02 = pr.u11 = pr.u12 = pr.u22 = 0.0f;
+    pr.T1 = __builtin_inff();
+    pr.ey = pr.ez = __builtin_inff();
+    const double thr2 = 2.0 * (double)kldThr;
+    if (parent_regular && thr2 >= 0.0 && thr2 < 1e30) {
+        const double m00 = Mf.e00, m01 = Mf.e01, m02 = Mf.e02, m11 = Mf.e11, m12 = Mf.e12, m22 = Mf.e22;
+        double detM;
+        const bool finite = fabs(m00) < 1e30 && fabs(m01) < 1e30 && fabs(m02) < 1e30 && fabs(m11) < 1e30 && fabs(m12) < 1e30 && fabs(m22) < 1e30;
+        if (finite && spd_det64(m00, m01, m02, m11, m12, m22, detM)) {
+            const double trM = m00 + m11 + m22;
+            const double e2 = (m00 * m11 - m01 * m01) + (m00 * m22 - m02 * m02) + (m11 * m22 - m12 * m12);   // >= lmax * lmid
+            const double K = trM * e2 / detM * 1.000001;                 // >= tr(M) / lambda_min(M)
+            const double u = 5.9604644775390625e-8;
+            const double theta = 6.1 * u * K + 2.0 * u;
+            const double G = -(log(detM) + log((double)det_p)) + 2e-6;
+            if (theta <= 0.25 && fabs(G) <= 1.0) {
+                const double smin = (thr2 * (1.0 + 2.0 * u) + G + (double)GSR_DET_TOL + 3.2 * theta / (1.0 - theta) + 4e-5) / (1.0 - theta);
+                const double T1 = smin * (1.0 + theta) * (1.0 + theta) * (1.0 + 1e-5);
+                if (T1 > 0.0 && T1 < 1e30) {
+                    // Cholesky factor of M (upper), float64, rounded to float32
+                    const double u00 = sqrt(m00), u01 = m01 / u00, u02 = m02 / u00;
+                    const double t11 = m11 - u01 * u01, u11 = sqrt(t11), u12 = (m12 - u01 * u02) / u11;
+                    const double t22 = m22 - u02 * u02 - u12 * u12, u22 = sqrt(t22);
+                    if (t11 > 0.0 && t22 > 0.0) {
+                        pr.u00 = (float)u00; pr.u01 = (float)u01; pr.u02 = (float)u02; pr.u11 = (float)u11; pr.u12 = (float)u12; pr.u22 = (float)u22;
+                        pr.T1 = (float)(T1 * (1.0 + 2.0 * u));
+                        pr.white = 1.0f;
+                        if (ell) {
+                            const double Tc = T1 * (1.0 + theta) * (1.0 + theta) * (1.0 + 1e-4);
+                            const double fk = 1.0 - 4.0 * theta - 2e-3;                       // > 0 for theta <= 1/4... only just: see `ok`
+                            const double im00 = 1.0 / m00;
+                            const double k11 = (m11 - m01 * m01 * im00) * fk, k12 = (m12 - m01 * m02 * im00) * fk, k22 = (m22 - m02 * m02 * im00) * fk;
+                            ec.k11 = (float)k11; ec.k12 = (float)k12; ec.k22 = (float)k22;
+                            ec.kr = (float)(sqrt((k11 + k22) / fk) * 1.001);
+                            ec.im00 = (float)(im00 * (1.0 + 4.0 * u));
+                            ec.m01 = (float)m01; ec.m02 = (float)m02;
+                            ec.T = (float)(Tc * (1.0 + 2.0 * u));
+                            const bool ok = fk > 0.5 && k11 > 0.0 && k22 > 0.0 && k11 * k22 > k12 * k12 && ec.kr < FLT_MAX && ec.im00 < FLT_MAX && ec.T < FLT_MAX;
+                            ec.on = ok ? 1.0f : 0.0f;
+                            // extent of E along y / z = sqrt(T_clip (M^-1)_yy / zz), M^-1 from M itself
+                            pr.ey = (float)(sqrt(fmax(0.0, Tc * (m00 * m22 - m02 * m02) / detM)) * 1.001);
+                            pr.ez = (float)(sqrt(fmax(0.0, Tc * (m00 * m11 - m01 * m01) / detM)) * 1.001);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    pr.ec = ec;
 }
 
 // One thread per parent: the record the selection kernels read (see struct ParentRec).
@@ -831,25 +882,17 @@ __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __re
         pr.pm = {pa.x, pa.y, pa.z};
         pr.det_p = pd.w;
         pr.inv_det_p = 1.0f / pd.w;
-        // Pre-reject bound (exactness argument in DESIGN.md "KL gate pre-reject"): for a regular parent and a regular
-        // child, tr(P^-1 C) - 3 - ln(|C|/|P|) >= 0 in exact arithmetic and the reference's float32 evaluation of it is
-        // >= -0.15, so  smd > 2*thr + 0.2 (+0.1%)  implies  KLD_float32 > thr: the pair is rejected by the reference too.
-        const float smdMax = (__float_as_uint(pa.w) & 2u) ? (2.0f * kldThr + 0.2f) * 1.001f : __builtin_inff();
         const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
         pr.pcol = {pc.z, pc.w, pd.x};
         pr.pweight = pd.z;
         pr.pinv = inverse6(pcov, pr.det_p);
         pr.R = Rs[pr.js];
         pr.R2 = pr.R * pr.R;
-        pr.ec = make_ellclip(pr.pinv, smdMax, ell);
-        make_whitening(pr.pinv, smdMax, pr);
+        make_filter(pr.pinv, pr.det_p, kldThr, ell, (__float_as_uint(pa.w) & 2u) != 0u, pr);
         // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
         const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
         pr.active = (pr.R2 > 0.0f && pm_finite) ? 1 : 0;
         pr.selfq = (pr.active && (__float_as_uint(pa.w) & 2u)) ? 1 : 0;
-        // extent of { d : d^T P^-1 d <= T } along an axis = sqrt(T * P_axis,axis)  (P = the parent's covariance)
-        pr.ey = sqrtf(fmaxf(0.0f, pr.ec.T * pb.w)) * 1.001f;
-        pr.ez = sqrtf(fmaxf(0.0f, pr.ec.T * pc.y)) * 1.001f;
         pr.pad[0] = 0;
         s_pr[wv][lane] = pr;
         }
@@ -860,6 +903,15 @@ __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __re
         for (int t = lane; t < nrec * (int)(sizeof(ParentRec) / 16); t += 64) dst[t] = src[t];
         __builtin_amdgcn_wave_barrier();
     }
+}
+
+// The stage-1 filter value |U d|^2 (make_filter): vc = {parent mean, u00, u01, u02, u11, u12, u22, T1}; nine fused multiply-adds
+__device__ __forceinline__ float white_smd(const float (&vc)[11], float cx, float cy, float cz) {
+    const float dx = cx - vc[0], dy = cy - vc[1], dz = cz - vc[2];
+    const float y2 = vc[8] * dz;
+    const float y1 = __builtin_fmaf(vc[6], dy, vc[7] * dz);
+    const float y0 = __builtin_fmaf(vc[3], dx, __builtin_fmaf(vc[4], dy, vc[5] * dz));
+    return __builtin_fmaf(y0, y0, __builtin_fmaf(y1, y1, y2 * y2));
 }
 
 // One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
@@ -939,12 +991,7 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
                     bool in;
                     if (white) {                                              // regular parent, regular children
                         // vc = {pm, U, T1} in VECTOR registers: a VALU instruction with an SGPR operand issues at half rate
-                        const float dx = cm.x - vc[0], dy = cm.y - vc[1], dz = cm.z - vc[2];
-                        const float y2 = vc[8] * dz;
-                        const float y1 = __builtin_fmaf(vc[6], dy, vc[7] * dz);
-                        const float y0 = __builtin_fmaf(vc[3], dx, __builtin_fmaf(vc[4], dy, vc[5] * dz));
-                        const float smd = __builtin_fmaf(y0, y0, __builtin_fmaf(y1, y1, y2 * y2));
-                        in = !(smd > vc[9]);
+                        in = !(white_smd(vc, cm.x, cm.y, cm.z) > vc[9]);
                     } else {                                                  // the reference's radius test (pointindex.cpp:137)
                         const f3 dq = sub3(pm, cm);
                         in = dot3(dq, dq) < pr.R2;
@@ -1231,6 +1278,98 @@ __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __r
     }
 }
 
+// The parts of a split (heavy) parent lie `part` slots apart in its sparse segment, part_cnt pairs each: slide them together
+// IN PLACE, in part order, so that every parent's pairs are ONE contiguous run [coff[p], coff[p] + pcnt[p]) -- what the
+// partition pass and the M-step walk.  One workgroup per heavy parent; a chunk is read whole (registers), then written behind a
+// barrier: the destination never runs ahead of the source (dst <= src), so no pair is overwritten before it has been read.
+__global__ __launch_bounds__(256) void k_join_parts(const int* __restrict__ nheavy_p, const unsigned* __restrict__ porder, const int64_t* __restrict__ coff,
+                                                    const int* __restrict__ hfirst, const unsigned* __restrict__ part_cnt,
+                                                    const unsigned* __restrict__ pcap, unsigned part, unsigned* __restrict__ sc, float* __restrict__ sw) {
+    const int nheavy = *nheavy_p;
+    for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
+        const int p = (int)porder[h];
+        const int h0 = hfirst[p];
+        if (h0 < 0) continue;
+        const int np = (int)(pcap[p] / part + (pcap[p] % part ? 1u : 0u));
+        int64_t dst = coff[p] + part_cnt[h0];
+        for (int k = 1; k < np; ++k) {
+            const unsigned cnt = part_cnt[h0 + k];
+            const int64_t src = coff[p] + (int64_t)k * part;
+            if (dst != src) {
+                for (unsigned i0 = 0; i0 < cnt; i0 += 256) {
+                    const unsigned i = i0 + threadIdx.x;
+                    unsigned vc = 0; float vw = 0.0f;
+                    if (i < cnt) { vc = sc[src + i]; vw = sw[src + i]; }
+                    __syncthreads();
+                    if (i < cnt) { sc[dst + i] = vc; sw[dst + i] = vw; }
+                    __syncthreads();
+                }
+            }
+            dst += cnt;
+        }
+    }
+}
+
+// The pairs of the per-parent segments [seg[p], seg[p] + pcnt[p]) -- the sparse capacity layout of the one-pass selection, or
+// the compact layout of the two-pass fallback -- straight into per-bucket regions of FIXED capacity `cap` (bucket b owns
+// [b cap, (b + 1) cap) of o_child / o_wl): no histogram pass, no scan and no compacted copy of the pair list in between.
+// A workgroup takes PART_PPW consecutive parents, lays their pair counts out as a prefix table in LDS and strides over the
+// FLAT space of their pairs (a lane finds its pair's parent by binary search in that table: every lane is busy whether the
+// parents hold 7 pairs each or one of them 10^5), counts the pairs per bucket in LDS, reserves a run in every bucket it
+// touches with ONE global atomic each, and places the pairs on a second walk (L2 resident).  A bucket that overflows raises
+// *overflow; the caller then takes the exact path (histogram + scan of a compacted copy).
+#define PART_PPW 128
+__global__ __launch_bounds__(256) void k_partition(int P, const int64_t* __restrict__ seg, const unsigned* __restrict__ pcnt,
+                                                   const unsigned* __restrict__ sc, const float* __restrict__ sw, int nb, int shift, unsigned cap,
+                                                   unsigned* __restrict__ cursor, unsigned* __restrict__ o_child, float* __restrict__ o_wl,
+                                                   int* __restrict__ overflow) {
+    extern __shared__ unsigned s_h[];
+    __shared__ unsigned long long s_off[PART_PPW + 1];       // exclusive prefix of the parents' pair counts (a heavy level: > 2^32 in one chunk is impossible, 64 bits anyway)
+    __shared__ long long s_seg[PART_PPW];
+    __shared__ unsigned long long s_w0;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) s_h[b] = 0u;
+    const int p0 = (int)blockIdx.x * PART_PPW;
+    const int np = P - p0 < PART_PPW ? P - p0 : PART_PPW;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x < PART_PPW) {
+        const int t = (int)threadIdx.x;
+        unsigned long long cnt = t < np ? (unsigned long long)pcnt[p0 + t] : 0ull;
+        if (t < np) s_seg[t] = seg[p0 + t];
+        unsigned long long incl = cnt;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned long long v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (wv == 0 && lane == 63) s_w0 = incl;
+        s_off[t + 1] = incl;                                  // wave 1's entries still lack wave 0's total
+    }
+    if (threadIdx.x == 0) s_off[0] = 0ull;
+    __syncthreads();
+    if (threadIdx.x >= 64 && threadIdx.x < PART_PPW) s_off[threadIdx.x + 1] += s_w0;
+    __syncthreads();
+    const unsigned long long total = s_off[PART_PPW];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (unsigned long long f = threadIdx.x; f < total; f += blockDim.x) {
+            int a = 0, b = PART_PPW;                           // last parent with s_off[parent] <= f
+            while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= f) a = m; else b = m; }
+            const long long at = s_seg[a] + (long long)(f - s_off[a]);
+            const unsigned ch = sc[at];
+            const int bk = (int)(ch >> shift);
+            const unsigned slot = atomicAdd(&s_h[bk], 1u);
+            if (pass == 1 && slot < cap) { const size_t pos = (size_t)bk * cap + slot; o_child[pos] = ch; o_wl[pos] = sw[at]; }
+        }
+        __syncthreads();
+        if (pass == 0) {
+            for (int b = threadIdx.x; b < nb; b += blockDim.x) {
+                const unsigned cnt = s_h[b];
+                if (cnt) {
+                    const unsigned base = atomicAdd(&cursor[b], cnt);
+                    if (base + cnt > cap || base + cnt < base) *overflow = 1;
+                    s_h[b] = base;
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // per-child sum of wL_si, sequential in the (stable) sorted pair order (mixture.cpp:162)
 __global__ __launch_bounds__(256) void k_sumlw(int64_t n, const int64_t* __restrict__ cstart,
                                                const float* __restrict__ wl_sorted, float* __restrict__ sumLw,
@@ -1307,7 +1446,9 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, int tile, con
         o_wl[pos] = wl[k];
     }
 }
-__global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, int shift, const unsigned long long* __restrict__ bstart, const unsigned* __restrict__ child,
+// bstart != NULL: bucket b holds the pairs [bstart[b], bstart[b + 1]) (exact partition); else its region [b cap, b cap + cursor[b])
+__global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, int shift, const unsigned long long* __restrict__ bstart, unsigned cap,
+                                                     const unsigned* __restrict__ cursor, const unsigned* __restrict__ child,
                                                      const float* __restrict__ wl, float* __restrict__ sumLw, int* __restrict__ orphan_flag,
                                                      float* __restrict__ geo_sl) {
     extern __shared__ unsigned long long s_acc[];  // [bucket] int64 accumulators, then [bucket] max bit patterns
@@ -1318,7 +1459,9 @@ __global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, int shift, const
     const int nc = (int)(n - c0 < bucket ? n - c0 : bucket);
     for (int i = threadIdx.x; i < bucket; i += blockDim.x) { s_acc[i] = 0ull; s_max[i] = 0u; }
     __syncthreads();
-    const unsigned long long k0 = bstart[b], k1 = bstart[b + 1];
+    unsigned long long k0, k1;
+    if (bstart) { k0 = bstart[b]; k1 = bstart[b + 1]; }
+    else { const unsigned cnt = cursor[b]; k0 = (unsigned long long)b * cap; k1 = k0 + (cnt < cap ? cnt : cap); }
     for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x)
         atomicMax(&s_max[child[k] - (unsigned)c0], __float_as_uint(wl[k]) & 0x7fffffffu);        // |wL| as an ordered integer
     __syncthreads();
@@ -1424,7 +1567,7 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
         const int js = (int)plist[p];
         const float4 a = A[js];
         MstepHeader h;
-        h.off = poff[p]; h.cnt = pcnt[p]; h.js = js;
+        h.off = poff[p]; h.cnt = pcnt[p]; h.js = js;          // poff = first pair of the parent's run (sparse segment or compact CSR)
         h.oslot = (p >= own_lo && p < own_hi) ? prank_in[order[js]] : -1;
         h.px = a.x; h.py = a.y; h.pz = a.z;
         hdr[s] = h;
@@ -1637,14 +1780,33 @@ __global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigne
         oslot_sorted[j] = slot;
     }
 }
-// SH rows of the orphans: one thread per component (orphans are rare -- 0.04 % at the bench density -- so a thread per
-// (component, coefficient) spent its time finding out that there was nothing to copy)
+// SH rows of the orphans.  Rare orphans (0.04 % of an isotropic level): one thread per component -- a thread per (component,
+// coefficient) would spend its time finding out that there is nothing to copy.  Many orphans (half of a level of thin discs
+// that merge with nothing): one thread per float4 of a padded row, so that a row's reads coalesce.
 __global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int RSH, const int64_t* __restrict__ oslot_sorted,
                                                     const float* __restrict__ shs, float* __restrict__ o_sh) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         const int64_t slot = oslot_sorted[j];
         if (slot < 0) continue;
         for (int f = 0; f < F; ++f) o_sh[slot * F + f] = shs[j * RSH + f];
+    }
+}
+__global__ __launch_bounds__(256) void k_orphans_sh_wide(int64_t n, int F, int RSH, const int64_t* __restrict__ oslot_sorted,
+                                                         const float* __restrict__ shs, float* __restrict__ o_sh) {
+    const int Q = RSH >> 2;
+    const int64_t total = n * Q;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = total < ((int64_t)1 << 31) ? (int64_t)((unsigned)t / (unsigned)Q) : t / Q;
+        const int64_t slot = oslot_sorted[j];
+        if (slot < 0) continue;
+        const int q = (int)(t - j * Q);
+        const float4 v = reinterpret_cast<const float4*>(shs + j * RSH)[q];
+        float* dst = o_sh + slot * F + 4 * q;
+        const int left = F - 4 * q;
+        if (left > 0) dst[0] = v.x;
+        if (left > 1) dst[1] = v.y;
+        if (left > 2) dst[2] = v.z;
+        if (left > 3) dst[3] = v.w;
     }
 }
 
@@ -1812,6 +1974,26 @@ __global__ void k_debug_kld(int64_t n, const float* __restrict__ cm, const float
     }
 }
 
+// test hook: the regular predicate, the per-parent filter record and the stage-1 decision, by the device functions k_select uses
+__global__ void k_debug_stage1(int64_t n, const float* __restrict__ pm, const float* __restrict__ pc, const float* __restrict__ cm,
+                               const float* __restrict__ cc, float thr, uint8_t* __restrict__ preg, uint8_t* __restrict__ creg,
+                               uint8_t* __restrict__ white, uint8_t* __restrict__ reject, float* __restrict__ T1, uint8_t* __restrict__ clip) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const s6 P = {pc[6 * i], pc[6 * i + 1], pc[6 * i + 2], pc[6 * i + 3], pc[6 * i + 4], pc[6 * i + 5]};
+        const s6 Cc = {cc[6 * i], cc[6 * i + 1], cc[6 * i + 2], cc[6 * i + 3], cc[6 * i + 4], cc[6 * i + 5]};
+        const float dp = det6(P), dc = det6(Cc);
+        const bool pr_ok = is_regular(P, dp, pm[3 * i], pm[3 * i + 1], pm[3 * i + 2]);
+        const bool cr_ok = is_regular(Cc, dc, cm[3 * i], cm[3 * i + 1], cm[3 * i + 2]);
+        ParentRec pr;
+        pr.pinv = inverse6(P, dp);
+        make_filter(pr.pinv, dp, thr, 1, pr_ok, pr);
+        const float vc[11] = {pm[3 * i], pm[3 * i + 1], pm[3 * i + 2], pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
+        const bool rej = pr.white != 0.0f && cr_ok && white_smd(vc, cm[3 * i], cm[3 * i + 1], cm[3 * i + 2]) > pr.T1;
+        preg[i] = pr_ok ? 1 : 0; creg[i] = cr_ok ? 1 : 0; white[i] = pr.white != 0.0f ? 1 : 0; reject[i] = rej ? 1 : 0;
+        T1[i] = pr.T1; clip[i] = pr.ec.on != 0.0f ? 1 : 0;
+    }
+}
+
 __global__ void k_debug_kl_gate(int64_t n, const float* __restrict__ s2, const float* __restrict__ det_c, const float* __restrict__ det_p, float thr,
                                 uint8_t* __restrict__ reject, float* __restrict__ lf, uint8_t* __restrict__ need_exact) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -1872,6 +2054,9 @@ struct gsr_hem_ctx {
     DevBuf hist, iflag, irank, ipos, rng_blocks, bhist, bstart, bcursor;
     bool split_heavy = true;        // heavy parents are cut into work items of SEL_PART candidates (GSR_HEM_SPLIT=0: one wave per parent)
     bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
+    bool partition_fixed = true;    // bucket regions of fixed capacity filled straight from the segments (GSR_HEM_PARTITION=exact: histogram + scan)
+    bool partition_overflowed = false;      // a region overflowed once: this context uses the exact partition from then on
+    double partition_factor = 0.0;  // GSR_HEM_PARTITION_FACTOR: region capacity in multiples of the mean (test knob: < 1 forces the overflow path)
     unsigned long long* host_rb = nullptr;      // pinned host memory the device writes read-backs into (16 words; [15] = sequence number)
     unsigned long long rb_seq = 0;
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
@@ -2104,10 +2289,13 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_PARTITION")) c->partition_fixed = strcmp(s, "exact") != 0;
+    if (const char* s = getenv("GSR_HEM_PARTITION_FACTOR")) c->partition_factor = atof(s);
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
+    (void)hipFuncSetAttribute((const void*)k_partition, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     *out = c;
     return GSR_OK;
 }
@@ -2506,19 +2694,18 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), P));
         GSR_TRY(total_of(c->poff.as<int64_t>(), c->pcnt.as<unsigned>(), P, &M));
         const size_t Mm = (size_t)(M > 0 ? M : 1);
-        GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
-        GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
         if (M > 0) {
             if (sparse) {
-                hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 8)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(),
-                                   c->poff.as<int64_t>(), sa.heavy_blocks ? sa.hfirst : (const int*)nullptr, sa.part_cnt, c->pcap.as<unsigned>(), sa.part ? sa.part : SEL_PART,
-                                   c->sp_child.as<unsigned>(), c->sp_wl.as<float>(), c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
+                // the pairs stay where the selection wrote them (segments of capacity pcap[p] at coff[p]): the partition pass and the
+                // M-step walk the segments.  Only the parts of the split parents are slid together (in place).
+                if (sa.heavy_blocks)
+                    hipLaunchKernelGGL(k_join_parts, dim3(1024), blk, 0, st, sa.nheavy, sa.porder, c->coff.as<int64_t>(), sa.hfirst, sa.part_cnt,
+                                       c->pcap.as<unsigned>(), sa.part, c->sp_child.as<unsigned>(), c->sp_wl.as<float>());
             } else {
+                GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
-                if (sa.heavy_blocks) {                       // the queue cursor back behind the statically assigned items
-                    const int first_pull = SEL_HEAVY_BLOCKS * WPB;
-                    GSR_HIP(hipMemcpyAsync(sa.hq + 1, &first_pull, 4, hipMemcpyHostToDevice, st));
-                }
+                if (sa.heavy_blocks)                         // the queue cursor back behind the statically assigned items
+                    hipLaunchKernelGGL(k_fill_const<int>, dim3(1), dim3(1), 0, st, (int64_t)1, sa.hq + 1, (int)(SEL_HEAVY_BLOCKS * WPB));
                 GSR_HIP(hipEventRecord(c->evk[2], st));
                 GSR_LAUNCH_SELECT(SEL_FILL);
                 GSR_HIP(hipEventRecord(c->evk[3], st));
@@ -2526,30 +2713,68 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         }
         c->sparse_path = sparse;
         c->stats_ex[1] = sparse ? 1 : 0;
-    } else {
-        GSR_TRY(c->pair_child.reserve(4)); GSR_TRY(c->pair_wl.reserve(4)); GSR_TRY(c->spair_child.reserve(4)); GSR_TRY(c->spair_wl.reserve(4));
     }
 #undef GSR_LAUNCH_SELECT
     c->stats[1] = M;
     GSR_CHECKPOINT("selection");
     GSR_HIP(hipEventRecord(c->ev[2], st));
 
-    // ---- 3. per-child sums of wL (deterministic: stable sort by child, sequential sum) ----------
+    // ---- 3. per-child sums of wL (deterministic whatever the order: LDS fixed point, k_bucket_sum) ----------
+    // The pairs of parent p are the run [seg[p], seg[p] + pcnt[p]) of (pc, pw): the sparse segments of the one-pass selection or
+    // the compact CSR of the two-pass fallback.
+    const int64_t* seg = c->sparse_path ? c->coff.as<int64_t>() : c->poff.as<int64_t>();
+    const unsigned* pc = c->sparse_path ? c->sp_child.as<unsigned>() : c->pair_child.as<unsigned>();
+    const float* pw = c->sparse_path ? c->sp_wl.as<float>() : c->pair_wl.as<float>();
     GSR_TRY(c->cstart.reserve(((size_t)n + 1) * 8)); GSR_TRY(c->sumLw.reserve(n * 4)); GSR_TRY(c->oflag.reserve(n * 4));
     // children per bucket: SUM_BUCKET on large levels; on small ones fewer, so that the bucket kernel still has ~2 workgroups per CU
     int bshift = SUM_BUCKET_SHIFT;
     while (bshift > 6 && (n >> bshift) < 512) --bshift;
     while (bshift < 13 && (n >> bshift) > 2500) ++bshift;       // very large levels: too many buckets scatter the partition's writes
     const int nbuckets = (int)((n + (1 << bshift) - 1) >> bshift);
-    if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
-        // partition by bucket (counting sort), then one workgroup per bucket sums in LDS on a fixed-point scale.  The
-        // partition kernels keep per-bucket counters in dynamic LDS (12 bytes per bucket, raised above the 64 KiB default
-        // in gsr_hem_create); levels with more than SUM_MAX_BUCKETS buckets (n > 268 M) take the sort path below.
+    const int tile = SUM_TILE;      // (x4 on levels with > 2000 buckets: measured, no gain)
+    const int ntiles = (int)((M + tile - 1) / tile);
+    int* overflow_flag = c->counters.as<int>() + 12;
+    // a compact copy of the pair list: only the exact partition (histogram + scan) and the sort path read one
+    auto compact_pairs = [&]() -> int32_t {
+        if (!c->sparse_path) return GSR_OK;
+        const size_t Mm = (size_t)(M > 0 ? M : 1);
+        GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
+        hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 8)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(), c->poff.as<int64_t>(),
+                           (const int*)nullptr, (const unsigned*)nullptr, c->pcap.as<unsigned>(), SEL_PART, c->sp_child.as<unsigned>(), c->sp_wl.as<float>(),
+                           c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
+        return GSR_OK;
+    };
+    // fixed-capacity partition: bucket regions of `cap` pairs (6x the mean, 8x on small levels), straight from the segments
+    bool fixed_tried = false;
+    auto sums_fixed = [&]() -> int32_t {
+        const double mean = (double)M / (double)nbuckets;
+        double capd = mean * (c->partition_factor > 0.0 ? c->partition_factor : (M < (1 << 24) ? 8.0 : 6.0)) + (c->partition_factor > 0.0 ? 64.0 : 4096.0);
+        if (capd > 4.0e9) return GSR_E_INVALID;                  // (not an error: the caller takes the exact path)
+        const unsigned cap = (unsigned)capd;
+        GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * 4)); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
+        GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
+        GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(k_partition, dim3(ceil_div(P, PART_PPW)), blk, (size_t)nbuckets * 4, st, P, seg, c->pcnt.as<unsigned>(), pc, pw,
+                           nbuckets, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
+        GSR_HIP(hipGetLastError());
+        GSR_CHECKPOINT("pair partition (fixed capacity)");
+        hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, (const unsigned long long*)nullptr, cap,
+                           c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
+                           c->geo.as<float>() + 15);
+        GSR_HIP(hipGetLastError());
+        fixed_tried = true;
+        return GSR_OK;
+    };
+    auto sums_exact = [&]() -> int32_t {
+        // histogram + scan + scatter of a compact pair list, then one workgroup per bucket sums in LDS on a fixed-point scale.  The
+        // partition kernels keep per-bucket counters in dynamic LDS (raised above the 64 KiB default in gsr_hem_create)
+        GSR_TRY(compact_pairs());
+        const size_t Mm = (size_t)(M > 0 ? M : 1);
+        GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
         GSR_TRY(c->bhist.reserve(((size_t)nbuckets + 1) * 4)); GSR_TRY(c->bstart.reserve(((size_t)nbuckets + 1) * 8));
         GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
         GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
-        const int tile = SUM_TILE;      // (x4 on levels with > 2000 buckets: measured, no gain)
-        const int ntiles = (int)((M + tile - 1) / tile);
         (void)hipGetLastError();
         hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, tile, c->pair_child.as<unsigned>(), nbuckets, bshift, c->bhist.as<unsigned>());
         GSR_HIP(hipGetLastError());
@@ -2560,11 +2785,25 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                            c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
         GSR_HIP(hipGetLastError());
         GSR_CHECKPOINT("pair partition");
-        hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, c->bstart.as<unsigned long long>(),
-                           c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
+        hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, c->bstart.as<unsigned long long>(), 0u,
+                           (const unsigned*)nullptr, c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
+                           c->geo.as<float>() + 15);
         GSR_HIP(hipGetLastError());
+        return GSR_OK;
+    };
+    if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
+        if (c->partition_fixed && !c->partition_overflowed) {
+            const int32_t r = sums_fixed();
+            if (r == GSR_E_INVALID && !fixed_tried) GSR_TRY(sums_exact()); else GSR_TRY(r);
+        } else {
+            if (c->partition_overflowed) c->stats_ex[2] = 1;
+            GSR_TRY(sums_exact());
+        }
     } else {
         if (M > 0) {
+            GSR_TRY(compact_pairs());
+            const size_t Mm = (size_t)M;
+            GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
             GSR_TRY(sort_pairs<float>(c, c->pair_child.as<unsigned>(), c->spair_child.as<unsigned>(), c->pair_wl.as<float>(),
                                       c->spair_wl.as<float>(), M, bits_for(n)));
             GSR_CHECKPOINT("pair sort");
@@ -2572,6 +2811,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         } else {
             hipLaunchKernelGGL(k_fill_const<int64_t>, grd, blk, 0, st, n + 1, c->cstart.as<int64_t>(), (int64_t)0);
         }
+        GSR_TRY(c->spair_wl.reserve(4));
         hipLaunchKernelGGL(k_sumlw, dim3(stride_grid(n * 8)), blk, 0, st, n, c->cstart.as<int64_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
     }
     if (sharded) {
@@ -2586,19 +2826,27 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // ---- 4. output ranks in input order; M-step; orphans -----------------------------------------
     GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
     GSR_TRY(c->oslot.reserve(n * 8));
-    hipLaunchKernelGGL(k_flags_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), c->pflag.as<int>(), c->oflag.as<int>(),
-                       c->pflag_in.as<int>(), c->oflag_in.as<int>());
-    GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
-    GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
     int o_last = 0, o_flag = 0;
-    {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        hipLaunchKernelGGL(k_flags_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), c->pflag.as<int>(), c->oflag.as<int>(),
+                           c->pflag_in.as<int>(), c->oflag_in.as<int>());
+        GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
+        GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
         Collect q;
-        q.n = 2;
-        q.src[0] = c->orank_in.as<int>() + (n - 1); q.src[1] = c->oflag_in.as<int>() + (n - 1);
-        q.bytes[0] = q.bytes[1] = 4;
+        q.n = 3;
+        q.src[0] = c->orank_in.as<int>() + (n - 1); q.src[1] = c->oflag_in.as<int>() + (n - 1); q.src[2] = overflow_flag;
+        q.bytes[0] = q.bytes[1] = q.bytes[2] = 4;
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
         o_last = (int)w[0]; o_flag = (int)w[1];
+        if (!(fixed_tried && w[2] != 0ull) || attempt == 1) break;
+        // a bucket region overflowed (pairs far more clustered than 6x the mean): the sums are incomplete.  Exact partition, and
+        // this context stays with it
+        c->partition_overflowed = true;
+        c->stats_ex[2] = 1;
+        GSR_HIP(hipMemsetAsync(overflow_flag, 0, 4, st));
+        GSR_TRY(sums_exact());
+        if (sharded) return fail(GSR_E_INVALID, "gsr_hem_run_level: bucket overflow on a sharded level");     // (sharded levels use the exact partition)
     }
     const int64_t n_orph = (int64_t)o_last + o_flag;
     c->stats[2] = n_orph;
@@ -2612,7 +2860,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         MstepArgs ma;
         memset(&ma, 0, sizeof(ma));
         ma.geo = c->geo.as<float4>(); ma.shs = c->shs.as<float>(); ma.RSH = RSH;
-        ma.pair_child = c->pair_child.as<unsigned>(); ma.pair_wl = c->pair_wl.as<float>();
+        ma.pair_child = pc; ma.pair_wl = pw;
         ma.P = P; ma.F = F;
         // processing order: the selection's (heavy parents by candidates scanned first, then Z-order) -- parents with many
         // candidates are the ones with many pairs.  The per-parent headers are laid out in that order.
@@ -2620,7 +2868,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.xcd = mporder ? 1 : 0;
         ma.nheavy = mporder ? c->counters.as<int>() + 8 : nullptr;
         GSR_TRY(c->mhdr.reserve(Pm * sizeof(MstepHeader)));
-        hipLaunchKernelGGL(k_mstep_headers, dim3(stride_grid(P)), blk, 0, st, P, mporder, c->plist.as<unsigned>(), c->poff.as<int64_t>(),
+        hipLaunchKernelGGL(k_mstep_headers, dim3(stride_grid(P)), blk, 0, st, P, mporder, c->plist.as<unsigned>(), seg,
                            c->pcnt.as<unsigned>(), c->order.as<unsigned>(), c->prank_in.as<int>(), c->A.as<float4>(), own_lo, own_hi,
                            c->mhdr.as<MstepHeader>());
         ma.hdr = c->mhdr.as<MstepHeader>();
@@ -2642,8 +2890,12 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
                        O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>());
-    if (F > 0 && n_orph > 0)
-        hipLaunchKernelGGL(k_orphans_sh, grd, blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
+    if (F > 0 && n_orph > 0) {
+        if (n_orph * 64 > n)
+            hipLaunchKernelGGL(k_orphans_sh_wide, dim3(stride_grid(n * (RSH >> 2))), blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
+        else
+            hipLaunchKernelGGL(k_orphans_sh, grd, blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
+    }
     if (sharded && P > 0) {
         // exchange 2: the merged components.  Every rank packs the rows of ITS parents, ONE all-gather of equal chunks
         // (ceil(P / world) rows of 14 + F floats) moves them, and every rank scatters every chunk into the output rows
@@ -2770,6 +3022,34 @@ int32_t gsr_debug_kld(const float* cm, const float* cc, const float* pm, const f
     for (int i = 0; i < 5; ++i) b[i].release();
     if (r != GSR_OK) return r;
     if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_debug_kld: %s", hipGetErrorString(e));
+    return GSR_OK;
+}
+
+int32_t gsr_debug_stage1(const float* parent_mean, const float* parent_cov6, const float* child_mean, const float* child_cov6, int64_t n,
+                         float kld_thr, uint8_t* parent_regular, uint8_t* child_regular, uint8_t* white, uint8_t* reject, float* T1,
+                         uint8_t* clip_on, int32_t device) {
+    if (n < 0 || (n > 0 && (!parent_mean || !parent_cov6 || !child_mean || !child_cov6 || !parent_regular || !child_regular || !white || !reject || !T1 || !clip_on)))
+        return fail(GSR_E_INVALID, "gsr_debug_stage1: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(GSR_E_NO_DEVICE, "gsr_debug_stage1: no HIP device visible");
+    if (n == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    DevBuf b[10];
+    const size_t sz[10] = {(size_t)n * 12, (size_t)n * 24, (size_t)n * 12, (size_t)n * 24, (size_t)n, (size_t)n, (size_t)n, (size_t)n, (size_t)n * 4, (size_t)n};
+    const float* src[4] = {parent_mean, parent_cov6, child_mean, child_cov6};
+    void* dst[6] = {parent_regular, child_regular, white, reject, T1, clip_on};
+    int32_t r = GSR_OK;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 10 && r == GSR_OK; ++i) r = b[i].reserve(sz[i]);
+    for (int i = 0; i < 4 && r == GSR_OK && e == hipSuccess; ++i) e = hipMemcpy(b[i].p, src[i], sz[i], hipMemcpyHostToDevice);
+    if (r == GSR_OK && e == hipSuccess) {
+        hipLaunchKernelGGL(k_debug_stage1, dim3(stride_grid(n)), dim3(256), 0, nullptr, n, b[0].as<float>(), b[1].as<float>(), b[2].as<float>(), b[3].as<float>(),
+                           kld_thr, b[4].as<uint8_t>(), b[5].as<uint8_t>(), b[6].as<uint8_t>(), b[7].as<uint8_t>(), b[8].as<float>(), b[9].as<uint8_t>());
+        for (int i = 0; i < 6 && e == hipSuccess; ++i) e = hipMemcpy(dst[i], b[4 + i].p, sz[4 + i], hipMemcpyDeviceToHost);
+    }
+    for (int i = 0; i < 10; ++i) b[i].release();
+    if (r != GSR_OK) return r;
+    if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_debug_stage1: %s", hipGetErrorString(e));
     return GSR_OK;
 }
 

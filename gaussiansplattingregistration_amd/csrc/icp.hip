@@ -299,6 +299,8 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
 struct IcpState;
 __device__ __forceinline__ bool icp_state_done(const IcpState* st);
 __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]);
+template <int THREADS> __device__ void icp_fold_partials(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced, double (*s_x)[32]);
+__device__ void icp_step_solve(const double* acc32, const IcpState& s_st, IcpState* st);
 
 // nn_j[i] = sorted target position of the accepted nearest neighbour of source point i, or -1.  One thread per source
 // point: a search kernel with few registers (56 VGPRs, 8 waves per SIMD) in front of a streaming accumulate kernel.
@@ -1074,13 +1076,24 @@ __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]) {
     for (int i = 0; i < 12; ++i) T[i] = st->T[i];
 }
 
+// FUSE: what the LAST workgroup to finish does with the block partials (it learns that it is the last from a device-scope
+// ticket; release / acquire at agent scope around it as MI355X_MICROARCH.md prescribes for a cross-CU hand-off):
+//   0  nothing (k_icp_reduce / k_icp_step follow as their own launches)
+//   1  the whole step -- fold the partials in k_icp_finalize's order, test convergence, solve, update T: ONE launch per ICP
+//      iteration instead of two (a coarse level's iteration was 36 us + 8.5 us of k_icp_step and its launch gap)
+//   2  fold the partials into acc_out (the rank-local vector of a multi-GPU source split; the all-reduce and k_icp_step follow)
 template <int KIND, bool BLOCK>
-__global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, const IcpState* __restrict__ st,
+__global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, IcpState* st,
                                                             IcpGrid g, const int* __restrict__ cellStart, const int* __restrict__ nn_j,
                                                             const float4* __restrict__ Tq, const double* __restrict__ Tn,
                                                             const double* __restrict__ Sc, ColorArgs ca, double max_corr2,
-                                                            int loss, double kparam, double* __restrict__ partials) {
-    if (st->done) return;
+                                                            int loss, double kparam, double* partials, int fuse, unsigned* ticket,
+                                                            double* acc_out) {
+    if (st->done) {
+        // converged: nothing to search.  The ranks of a multi-GPU run still meet in the collective: zeros
+        if (fuse == 2 && blockIdx.x == 0 && threadIdx.x < GSR_ICP_ACC_LEN) acc_out[threadIdx.x] = 0.0;
+        return;
+    }
     constexpr int NACC = KIND == 0 ? 17 : 30;
     double T[12];
 #pragma unroll
@@ -1136,6 +1149,32 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
         }
     }
     block_reduce_store<NACC>(acc, partials);
+    if (fuse == 0) return;
+    // hand-off: this workgroup's partials out to memory (agent-scope release by the storing lanes' wave), then the ticket
+    __shared__ int s_last;
+    __shared__ double s_x[8][GSR_ICP_ACC_LEN];
+    __shared__ IcpState s_st;
+    if (threadIdx.x < 64) {                               // the wave that stored the partials (threads < NACC <= 32)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) {
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = t == gridDim.x - 1 ? 1 : 0;
+        }
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
+    icp_fold_partials<256>((int)gridDim.x, partials, nullptr, s_x);
+    if (fuse == 2) {
+        if (threadIdx.x < GSR_ICP_ACC_LEN) acc_out[threadIdx.x] = s_x[0][threadIdx.x];
+    } else if (threadIdx.x == 0) {
+        icp_step_solve(&s_x[0][0], s_st, st);
+    }
+    if (threadIdx.x == 0) *ticket = 0u;                   // for the next launch (a kernel boundary away)
 }
 
 // `reduced` == NULL: fold the block partials here (single GPU).  Multi-GPU source split: k_icp_reduce folds them into a
@@ -1148,48 +1187,53 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
 // read one 256-byte row per load; the old wave-per-accumulator loop read 8 bytes of 64 different rows), folds the two
 // butterfly steps it holds both operands of, and an LDS tree over g does the remaining four.
 #define ICP_STEP_THREADS 512
-__global__ __launch_bounds__(ICP_STEP_THREADS) void k_icp_step(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced,
-                                                   IcpState* __restrict__ st) {
-    __shared__ double s_x[16][GSR_ICP_ACC_LEN];
-    __shared__ IcpState s_st;
-    static_assert(GSR_ICP_ACC_LEN == 32 && sizeof(IcpState) % 4 == 0, "k_icp_step layout");
-    if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
+// The fold in k_icp_finalize's summation ORDER per accumulator k -- s_l = sum over the blocks b = l, l + 64, ... ascending, then the
+// butterfly s_l + s_(l ^ 32), + (l ^ 16), ... down to lane 0 -- with THREADS = 32 G threads: thread (g = t / 32, k = t % 32) forms
+// the lane sums s_g, s_(g + G), ... of accumulator k (32 threads read one 256-byte row per load, four rounds of loads in flight),
+// folds the butterfly steps it holds both operands of, and an LDS tree over g does the remaining log2 G.  Result: s_x[0][k].
+template <int THREADS>
+__device__ void icp_fold_partials(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced, double (*s_x)[32]) {
+    constexpr int G = THREADS / 32, NL = 64 / G;
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
     if (reduced) {
         if (g == 0) s_x[0][k] = reduced[k];
         __syncthreads();
-    } else {
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-        // four rounds of loads in flight (16 independent loads) before the adds that consume them, in block order
-        for (int b0 = g; b0 < nblocks; b0 += 256) {
-            double v[4][4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int b = b0 + 64 * u + 16 * j;
-                    v[u][j] = b < nblocks ? partials[(int64_t)b * GSR_ICP_ACC_LEN + k] : 0.0;
-                }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int b = b0 + 64 * u;
-                if (b < nblocks) s0 += v[u][0];
-                if (b + 16 < nblocks) s1 += v[u][1];
-                if (b + 32 < nblocks) s2 += v[u][2];
-                if (b + 48 < nblocks) s3 += v[u][3];
-            }
-        }
-        s_x[g][k] = (s0 + s2) + (s1 + s3);                 // lane g of the butterfly after its steps 32 and 16
-        __syncthreads();
-        for (int o = 8; o > 0; o >>= 1) {
-            if (g < o) s_x[g][k] = s_x[g][k] + s_x[g + o][k];
-            __syncthreads();
-        }
+        return;
     }
-    if (threadIdx.x != 0 || s_st.done) return;
+    double sl[NL];
+#pragma unroll
+    for (int j = 0; j < NL; ++j) sl[j] = 0.0;
+    for (int b0 = g; b0 < nblocks; b0 += 256) {
+        double v[4][NL];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NL; ++j) {
+                const int b = b0 + 64 * u + G * j;
+                v[u][j] = b < nblocks ? partials[(int64_t)b * GSR_ICP_ACC_LEN + k] : 0.0;
+            }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int j = 0; j < NL; ++j)
+                if (b0 + 64 * u + G * j < nblocks) sl[j] += v[u][j];
+    }
+#pragma unroll
+    for (int h = NL / 2; h >= 1; h >>= 1)                   // butterfly steps 32, 16, ... between the lanes this thread holds
+#pragma unroll
+        for (int j = 0; j < h; ++j) sl[j] = sl[j] + sl[j + h];
+    s_x[g][k] = sl[0];
+    __syncthreads();
+    for (int o = G / 2; o > 0; o >>= 1) {
+        if (g < o) s_x[g][k] = s_x[g][k] + s_x[g + o][k];
+        __syncthreads();
+    }
+}
+// one thread: fitness / RMSE, the relative-change test, the estimator's solve and T <- update * T (registration_icp's loop body)
+__device__ void icp_step_solve(const double* acc32, const IcpState& s_st, IcpState* st) {
     double acc[GSR_ICP_ACC_LEN];
 #pragma unroll
-    for (int i = 0; i < GSR_ICP_ACC_LEN; ++i) acc[i] = s_x[0][i];
+    for (int i = 0; i < GSR_ICP_ACC_LEN; ++i) acc[i] = acc32[i];
     const double fit = acc[0] > 0 ? acc[0] / s_st.nsg : 0.0, rmse = acc[0] > 0 ? sqrt(acc[1] / acc[0]) : 0.0;
     const bool first = s_st.evals == 0;
     const bool stop = !first && fabs(s_st.fit - fit) < s_st.rel_fit && fabs(s_st.rmse - rmse) < s_st.rel_rmse;
@@ -1204,6 +1248,18 @@ __global__ __launch_bounds__(ICP_STEP_THREADS) void k_icp_step(int nblocks, cons
 #pragma unroll
     for (int i = 0; i < 16; ++i) st->T[i] = T[i];
     st->iters = s_st.iters + 1;
+}
+// 512 threads: the single-thread solve behind the reduction needs ~120 registers (a 1024-thread launch bound allows 128: it
+// spilled to scratch)
+__global__ __launch_bounds__(ICP_STEP_THREADS) void k_icp_step(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced,
+                                                   IcpState* __restrict__ st) {
+    __shared__ double s_x[16][GSR_ICP_ACC_LEN];
+    __shared__ IcpState s_st;
+    static_assert(GSR_ICP_ACC_LEN == 32 && sizeof(IcpState) % 4 == 0, "k_icp_step layout");
+    if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
+    icp_fold_partials<ICP_STEP_THREADS>(nblocks, partials, reduced, s_x);
+    if (threadIdx.x != 0 || s_st.done) return;
+    icp_step_solve(&s_x[0][0], s_st, st);
 }
 
 // rank-local accumulator vector of one iteration (same fixed summation order as k_icp_finalize); zeros once converged, so

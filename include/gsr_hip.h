@@ -52,6 +52,49 @@ const char* gsr_version(void);
 /* Number of visible HIP devices (0 when none; never fails). */
 int32_t gsr_device_count(void);
 
+/* ------------------------------------------------------------------------------------ communicator */
+
+/* Multi-GPU runs (BASELINE configs 4 and 5; the reference has no distributed code): one process per GPU,
+ * RCCL over xGMI called FROM THE LIBRARY on the context's own stream -- nothing crosses into the host language per ICP
+ * iteration or per HEM level.  Rank 0 calls gsr_comm_get_unique_id and hands the GSR_COMM_ID_BYTES bytes to every rank by any
+ * means (the Python side broadcasts them with torch.distributed); every rank then calls gsr_comm_create (ncclCommInitRank:
+ * collective, blocks until all ranks have called it).  librccl.so.1 is opened lazily: a single-GPU user never loads it.
+ * gsr_comm_create_callbacks builds the same object over host-language collectives on DEVICE buffers (test boxes where two
+ * ranks share one GPU, which RCCL refuses): a callback is called after the library has synchronised the stream and must have
+ * completed when it returns 0. */
+typedef struct gsr_comm gsr_comm;
+#define GSR_COMM_ID_BYTES 128
+#define GSR_DT_F64 0
+#define GSR_DT_F32 1
+#define GSR_DT_I32 2
+#define GSR_DT_U32 3
+#define GSR_DT_U64 4
+#define GSR_OP_SUM 0
+#define GSR_OP_MAX 1
+typedef struct gsr_comm_callbacks {
+    /* replace dev_buf[count] (elements of GSR_DT_*) by its element-wise GSR_OP_* over the ranks */
+    int32_t (*allreduce)(void* dev_buf, int64_t count, int32_t dtype, int32_t op, void* user);
+    /* dev_recv[r * bytes_per_rank ...] = rank r's dev_send[0 .. bytes_per_rank) */
+    int32_t (*allgather)(const void* dev_send, void* dev_recv, int64_t bytes_per_rank, void* user);
+    /* personalised exchange: send_bytes[r] bytes at dev_send + send_off[r] go to rank r, which receives them at its
+     * dev_recv + recv_off[this rank]; the arrays have one entry per rank (the entry of the calling rank is handled by the library) */
+    int32_t (*exchange)(const void* dev_send, const int64_t* send_off, const int64_t* send_bytes, void* dev_recv,
+                        const int64_t* recv_off, const int64_t* recv_bytes, void* user);
+    void* user;
+} gsr_comm_callbacks;
+int32_t gsr_comm_get_unique_id(void* id128);
+int32_t gsr_comm_create(gsr_comm** out, const void* id128, int32_t rank, int32_t world, int32_t device);
+int32_t gsr_comm_create_callbacks(gsr_comm** out, int32_t rank, int32_t world, int32_t device, const gsr_comm_callbacks* cb);
+int32_t gsr_comm_destroy(gsr_comm* comm);
+int32_t gsr_comm_rank(const gsr_comm* comm);
+int32_t gsr_comm_world(const gsr_comm* comm);
+/* The operations themselves (device buffers, enqueued on `stream` with the RCCL transport); exposed for tests and for host code
+ * that shares the communicator. */
+int32_t gsr_comm_allreduce(gsr_comm* comm, void* dev_buf, int64_t count, int32_t dtype, int32_t op, void* stream);
+int32_t gsr_comm_allgather(gsr_comm* comm, const void* dev_send, void* dev_recv, int64_t bytes_per_rank, void* stream);
+int32_t gsr_comm_exchange(gsr_comm* comm, const void* dev_send, const int64_t* send_off, const int64_t* send_bytes, void* dev_recv,
+                          const int64_t* recv_off, const int64_t* recv_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------- HEM */
 
 typedef struct gsr_hem_ctx gsr_hem_ctx;
@@ -117,7 +160,8 @@ int32_t gsr_hem_get_level(gsr_hem_ctx* ctx, float* xyz, float* color, float* cov
 int32_t gsr_hem_get_stats(gsr_hem_ctx* ctx, int64_t* out8);
 /* More counters of the most recent level:  [0] components outside the stage-1 filter's precondition ("irregular": not
  * verified symmetric positive definite with an accurate float32 determinant -- they take the exact gates only)
- * [1] 1 = the one-pass selection ran, 0 = the COUNT + FILL fallback  [2..7] reserved (0). */
+ * [1] 1 = the one-pass selection ran, 0 = the COUNT + FILL fallback  [2] 1 = a bucket region of the pair partition overflowed (in this level or an
+ * earlier one of the context) and the level's sums took the exact partition  [3..7] reserved (0). */
 int32_t gsr_hem_get_stats_ex(gsr_hem_ctx* ctx, int64_t* out8);
 /* Device time of the phases of the most recent level, in milliseconds (hipEvent pairs on the
  * context's stream):  [0] prep+grid  [1] selection (count+scan+fill)  [2] per-child sums
@@ -180,6 +224,10 @@ int32_t gsr_icp_set_allreduce(gsr_icp_ctx* ctx, gsr_allreduce_fn fn, void* user,
  * shard (gsr_icp_set_source with n = 0).  Installing one kind of callback removes the other; NULL restores single-GPU. */
 typedef int32_t (*gsr_allreduce_dev64_fn)(void* dev_f64, int64_t count, void* user);
 int32_t gsr_icp_set_allreduce_dev(gsr_icp_ctx* ctx, gsr_allreduce_dev64_fn fn, void* user, int64_t n_source_global);
+/* The same through a communicator: per iteration the accumulate kernel (its last workgroup folds the block partials), ONE
+ * all-reduce of 32 float64 enqueued on the context's stream (ncclAllReduce with the RCCL transport: no host involvement), and
+ * the solve kernel.  comm = NULL restores single-GPU.  The communicator must outlive the context's use of it. */
+int32_t gsr_icp_set_comm(gsr_icp_ctx* ctx, gsr_comm* comm, int64_t n_source_global);
 
 /* One correspondence evaluation + accumulator reduction at transform T (row-major 4x4 float64):
  * acc[0]=count, acc[1]=sum d^2, then for point-to-point acc[2..4]=sum p, [5..7]=sum q, [8..16]=sum p q^T

@@ -365,6 +365,61 @@ def test_fast_log_margin(hip_lib, oracle):
     # special values: log(0) = -inf -> k = +inf -> reject; q < 0 or NaN -> NaN -> passes; s2 = inf -> reject; s2 NaN -> passes
     assert list(rej[n:]) == [1, 0, 0, 0, 1, 1, 1, 0] and ex[n:].all()
 
+def test_stage1_filter_never_rejects_an_accepted_pair(hip_lib, oracle):
+    """The device's own stage-1 filter (gsr_debug_stage1: is_regular + make_filter + the nine fused multiply-adds of
+    white_smd, the functions k_select runs) on 600 000 adversarial (parent, child) pairs just beyond each parent's bound:
+    whatever it drops, the reference arithmetic rejects.  Its records agree with the NumPy restatement the CPU suite
+    attacks (tests/stage1_model.py), and flat discs are inside the filter's reach (the round-2 predicate stopped at a
+    condition number of 80)."""
+    import stage1_model as S1
+    from test_oracle_math import _adversarial_pairs
+    thr = 4.5
+    n = 600000
+    pm, pc, cm, cc, F = _adversarial_pairs(n, 23, thr)
+    preg = np.empty(n, np.uint8); creg = np.empty(n, np.uint8); white = np.empty(n, np.uint8); rej = np.empty(n, np.uint8)
+    T1 = np.empty(n, np.float32); clip = np.empty(n, np.uint8)
+    pm, pc, cm, cc = (np.ascontiguousarray(a, np.float32) for a in (pm, pc, cm, cc))
+    assert hip_lib.gsr_debug_stage1(pm.ctypes.data, pc.ctypes.data, cm.ctypes.data, cc.ctypes.data, n, float(thr), preg.ctypes.data,
+                                    creg.ctypes.data, white.ctypes.data, rej.ctypes.data, T1.ctypes.data, clip.ctypes.data, 0) == 0
+    with np.errstate(all="ignore"):
+        k = oracle.kld(cm, cc, pm, pc)
+    bad = (rej == 1) & ~(k > thr)
+    assert rej.sum() > 0.2 * n and not bad.any(), (int(rej.sum()), int(bad.sum()), np.flatnonzero(bad)[:5])
+    # the device's records against the model: the predicates equal but for borderline float64 roundings, T1 to 1e-5
+    mreg, _ = S1.is_regular(pc, pm)
+    assert (preg.astype(bool) != mreg).mean() < 1e-4 and (white.astype(bool) != F["white"]).mean() < 1e-3
+    both = white.astype(bool) & F["white"]
+    assert np.abs(T1[both].astype(np.float64) / F["T1"][both] - 1).max() < 1e-5
+    # reach: discs with condition numbers of 1e3 .. 1e4 are (mostly) certified and their rows clipped
+    ev = np.linalg.eigvalsh(np.stack([pc[:, [0, 1, 2]], pc[:, [1, 3, 4]], pc[:, [2, 4, 5]]], 1).astype(np.float64))
+    kap = ev[:, 2] / np.maximum(ev[:, 0], 1e-300)
+    band = (kap > 1e3) & (kap < 1e4)
+    assert white[band].mean() > 0.8 and clip[band].mean() > 0.8, (white[band].mean(), clip[band].mean())
+    # not regular: never white, never rejected in stage 1
+    assert not (white.astype(bool) & ~preg.astype(bool)).any() and not (rej.astype(bool) & ~creg.astype(bool)).any()
+
+
+def test_anisotropic_cloud_equals_oracle(oracle):
+    """The surfel workload (synth.make_cloud(shape="aniso"): 60 % flat discs, 15 % needles, condition numbers 1e2 .. 1e5 on a
+    smooth orientation field): every discrete outcome of level 1 equals the oracle's -- parents, accepted pairs, orphans,
+    dropped -- and the components to 1e-4; most components are inside the filter's precondition."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(150000, seed=4, shape="aniso")
+    want, wst = oracle.hem(c, 2)
+    with hem.HemMixture() as m:
+        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+        for k in range(2):
+            m.run_level()
+            st = m.stats()
+            got = m.get_level()
+            if k == 0:
+                assert (st["parents"], st["pairs"], st["orphans"], st["dropped"]) == (wst[0]["parents"], wst[0]["pairs"], wst[0]["orphans"], wst[0]["dropped"])
+                assert st["irregular"] < 0.25 * 150000, st["irregular"]
+                _check_level(got, want[k], ("aniso", k))
+            else:
+                _check_level_mostly(got, want[k], ("aniso", k))
+
+
 def test_sh_wider_than_a_wavefront(oracle):
     """F = 72 feature floats (> 64 lanes) exercises the multi-coefficient-per-lane M-step instantiation."""
     from gaussiansplattingregistration_amd import hem, synth
@@ -489,7 +544,7 @@ def test_ellipsoid_row_clipping_changes_nothing(monkeypatch):
     for ell in ("1", "0"):
         monkeypatch.setenv("GSR_HEM_ELL", ell)
         out = []
-        for c in (synth.make_cloud(300000, seed=8), _needle_cloud(100000, seed=9, frac=0.2)):
+        for c in (synth.make_cloud(300000, seed=8), _needle_cloud(100000, seed=9, frac=0.2), synth.make_cloud(200000, seed=10, shape="aniso")):
             with hem.HemMixture() as m:
                 m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
                 m.run_level()      # one level: later levels inherit summation-order noise (the pair order differs)
@@ -596,6 +651,39 @@ def test_bucketed_sums_equal_sorted_sums(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_pair_partition_variants_change_nothing(monkeypatch):
+    """The pairs go from the selection's per-parent segments straight into per-bucket regions of fixed capacity (k_partition);
+    GSR_HEM_PARTITION=exact takes the histogram + scan + scatter of a compacted copy instead, and a region that overflows
+    (GSR_HEM_PARTITION_FACTOR=0.3: capacity below the mean) makes the level redo its sums that way.  The per-child sums are order
+    independent (LDS fixed point) and the M-step reads the same runs of pairs: three levels bit for bit identical, also on the
+    two-pass fallback (compact CSR segments) and with many orphans (the anisotropic cloud)."""
+    from gaussiansplattingregistration_amd import hem, synth
+    clouds = [synth.make_cloud(250000, seed=21), synth.make_cloud(120000, seed=22, shape="aniso", sh_degree=1)]
+    res = {}
+    for tag, env in (("fixed", {}), ("exact", {"GSR_HEM_PARTITION": "exact"}), ("overflow", {"GSR_HEM_PARTITION_FACTOR": "0.3"}),
+                     ("two-pass", {"GSR_HEM_SPARSE_GB": "0"})):
+        for k in ("GSR_HEM_PARTITION", "GSR_HEM_PARTITION_FACTOR", "GSR_HEM_SPARSE_GB"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        out = []
+        for c in clouds:
+            with hem.HemMixture() as m:
+                m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+                for _ in range(3):
+                    m.run_level()
+                    st = m.stats()
+                    out.append((st["pairs"], st["orphans"], st["partition_overflow"], st["one_pass"], m.get_level(with_state=True)))
+        res[tag] = out
+    assert all(o[2] == 1 for o in res["overflow"][:3]) and not any(o[2] for o in res["fixed"])
+    assert all(o[3] == 0 for o in res["two-pass"]) and all(o[3] == 1 for o in res["fixed"])
+    for tag in ("exact", "overflow", "two-pass"):
+        for a, b in zip(res["fixed"], res[tag]):
+            assert a[:2] == b[:2], (tag, a[:2], b[:2])
+            for f in ("xyz", "color", "cov6", "opacity", "sh", "weight", "is_parent"):
+                assert np.array_equal(a[4][f], b[4][f]), (tag, f)
+
+
 def test_survey_known_answers_on_the_gpu():
     """The reference's own numbers from SURVEY.md 8c, on the GPU: 100 k -> 33 142 components, 33 120 parents, 3 889 315
     pairs; 20 k (box +-5) -> 16 177 / 13 719; 200 k -> 66 405 / 22 070 / 7 435 (levels 2 and 3 may move by a pair or two:

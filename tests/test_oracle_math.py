@@ -78,3 +78,64 @@ def test_smd_prereject_never_rejects_an_accepted_pair(oracle):
     bad = sel & ~(k > thr)                                 # would have been ACCEPTED by the reference (or NaN)
     assert not bad.any(), (int(bad.sum()), float(k[sel].min()))
     assert float(k[sel].min()) > thr + 0.05
+
+
+def _adversarial_pairs(n, seed, thr):
+    """(parent, child) pairs that sit just beyond the stage-1 bound: parents from spheres to discs and needles with condition
+    numbers up to 1e6 at every scale, children whose covariance equals or nearly equals the parent's (tr - 3 - log ~ 0, the
+    worst case for the bound), is a multiple of it, or is unrelated; offsets along random whitened directions -- a third of
+    them along the parent's thinnest axis -- with a Mahalanobis distance a hair to 30 % beyond the parent's own T1."""
+    import stage1_model as S1
+    from gaussiansplattingregistration_amd.synth import _quat_to_rot
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(0, 3, n)                               # 0 generic, 1 disc, 2 needle
+    logk = rng.uniform(0, 6, n)                                # condition number 1 .. 1e6
+    ev = np.ones((n, 3))
+    ev[:, 1] = np.where(kind == 1, 1.0, np.where(kind == 2, 10.0 ** -logk, 10.0 ** (-logk * rng.uniform(0, 1, n))))
+    ev[:, 2] = 10.0 ** -logk
+    ev *= 10.0 ** rng.uniform(-5, 2, (n, 1))                   # variances 1e-5 .. 1e2 for the largest axis
+    q = rng.normal(size=(n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    R = _quat_to_rot(q)
+    Sp = np.einsum("nij,nj,nkj->nik", R, ev, R)
+    mode = rng.integers(0, 4, n)
+    pert = 1.0 + rng.choice([0.0, 1e-6, 1e-4, 1e-2], size=(n, 1, 1)) * rng.normal(size=(n, 3, 3))
+    Sc = Sp * 0.5 * (pert + pert.transpose(0, 2, 1))
+    scale = np.where(mode == 2, np.exp(rng.uniform(-0.7, 0.7, n)), 1.0)
+    Sc = Sc * scale[:, None, None]
+    other = np.roll(Sp, 1, axis=0)
+    Sc = np.where((mode == 3)[:, None, None], other, Sc)
+    pack = lambda S: S[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]].astype(np.float32)
+    pc, cc = pack(Sp), pack(Sc)
+    pm = (rng.normal(size=(n, 3)) * np.sqrt(ev.max(1, keepdims=True)) * 3).astype(np.float32)
+    F = S1.make_filter(pc, pm, thr)
+    T1 = np.where(np.isfinite(F["T1"]), F["T1"].astype(np.float64), 2 * thr + 0.3)
+    uvec = rng.normal(size=(n, 3))
+    thin = rng.random(n) < 0.34
+    uvec[thin] = np.array([0.0, 0.0, 1.0]) + 0.05 * rng.normal(size=(int(thin.sum()), 3))      # ev[:, 2] is the thinnest axis
+    uvec /= np.linalg.norm(uvec, axis=1, keepdims=True)
+    smd_t = T1 * rng.choice([1.00001, 1.0001, 1.001, 1.01, 1.3], n) * rng.uniform(1.0, 1.00005, n)
+    d = np.einsum("nij,nj->ni", R, np.sqrt(ev) * uvec) * np.sqrt(smd_t)[:, None]
+    cm = (pm.astype(np.float64) + d).astype(np.float32)
+    return pm, pc, cm, cc, F
+
+
+def test_stage1_bound_model_never_rejects_an_accepted_pair(oracle):
+    """The stage-1 filter of k_select (make_filter in csrc/hem.hip; restated in tests/stage1_model.py) drops a pair
+    without the exact gates when the parent's filter is certified (white), the child is regular and |U d|^2 > T1.  For
+    every such pair the REFERENCE arithmetic (the oracle's float32 KLD) must reject as well."""
+    import stage1_model as S1
+    thr = 4.5
+    n = 600000
+    pm, pc, cm, cc, F = _adversarial_pairs(n, 11, thr)
+    creg, _ = S1.is_regular(cc, cm)
+    sw = S1.white_smd(F["U"], pm, cm)
+    rej = F["white"] & creg & (sw > F["T1"])
+    with np.errstate(all="ignore"):
+        k = oracle.kld(cm, cc, pm, pc)
+    assert F["white"].mean() > 0.5 and rej.sum() > 0.2 * n, (F["white"].mean(), rej.mean())     # not vacuous
+    bad = rej & ~(k > thr)                                    # accepted by the reference (or NaN): must not have been dropped
+    assert not bad.any(), (int(bad.sum()), np.flatnonzero(bad)[:5])
+    # and the filter is not uselessly loose where it applies: certified parents with condition number < 1e3 keep T1 within 3 %
+    ev = np.linalg.eigvalsh(np.stack([pc[:, [0, 1, 2]], pc[:, [1, 3, 4]], pc[:, [2, 4, 5]]], 1).astype(np.float64))
+    tame = F["white"] & (ev[:, 2] < 1e3 * ev[:, 0])
+    assert tame.sum() > 0.1 * n and float(F["T1"][tame].max()) < (2 * thr) * 1.03, float(F["T1"][tame].max())
