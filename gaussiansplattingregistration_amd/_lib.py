@@ -23,6 +23,8 @@ GSR_RNG_HASH = 1
 
 GSR_ICP_ACC_LEN = 32
 
+GSR_COMM_ID_BYTES = 128
+
 GSR_DECOMP_REFERENCE = 0
 GSR_DECOMP_EXACT = 1
 
@@ -30,12 +32,31 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.POINTER(C.c_double), C.c_int32, C.c_void
 ALLREDUCE_DEV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_void_p)
 ALLGATHER_DEV_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
 
+COMM_ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p)
+COMM_ALLGATHER_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p)
+COMM_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.POINTER(C.c_int64),
+                               C.POINTER(C.c_int64), C.c_void_p)
+
+
+class CommCallbacks(C.Structure):          # struct gsr_comm_callbacks
+    _fields_ = [("allreduce", COMM_ALLREDUCE_FN), ("allgather", COMM_ALLGATHER_FN), ("exchange", COMM_EXCHANGE_FN), ("user", C.c_void_p)]
+
+
 # name -> (restype, argtypes); mirrors include/gsr_hip.h one to one (tests/test_abi.py checks it)
 _vp, _i32, _i64, _u32, _u64, _f32, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double
 SIGNATURES = {
     "gsr_last_error": (C.c_char_p, []),
     "gsr_version": (C.c_char_p, []),
     "gsr_device_count": (_i32, []),
+    "gsr_comm_get_unique_id": (_i32, [_vp]),
+    "gsr_comm_create": (_i32, [C.POINTER(_vp), _vp, _i32, _i32, _i32]),
+    "gsr_comm_create_callbacks": (_i32, [C.POINTER(_vp), _i32, _i32, _i32, C.POINTER(CommCallbacks)]),
+    "gsr_comm_destroy": (_i32, [_vp]),
+    "gsr_comm_rank": (_i32, [_vp]),
+    "gsr_comm_world": (_i32, [_vp]),
+    "gsr_comm_allreduce": (_i32, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "gsr_comm_allgather": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "gsr_comm_exchange": (_i32, [_vp, _vp, C.POINTER(_i64), C.POINTER(_i64), _vp, C.POINTER(_i64), C.POINTER(_i64), _vp]),
     "gsr_hem_create": (_i32, [C.POINTER(_vp), _i32, _vp]),
     "gsr_hem_destroy": (_i32, [_vp]),
     "gsr_hem_set_params": (_i32, [_vp, _f32, _f32, _f32, _f32]),
@@ -65,6 +86,7 @@ SIGNATURES = {
     "gsr_icp_get_color_gradient": (_i32, [_vp, _vp]),
     "gsr_icp_set_allreduce": (_i32, [_vp, ALLREDUCE_FN, _vp, _i64]),
     "gsr_icp_set_allreduce_dev": (_i32, [_vp, ALLREDUCE_DEV_FN, _vp, _i64]),
+    "gsr_icp_set_comm": (_i32, [_vp, _vp, _i64]),
     "gsr_icp_accumulate": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp]),
     "gsr_icp_register": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _i32, _vp, C.POINTER(_f64), C.POINTER(_f64),
                                 C.POINTER(_i32)]),
@@ -72,6 +94,7 @@ SIGNATURES = {
     "gsr_icp_get_timing": (_i32, [_vp, C.POINTER(_f32)]),
     "gsr_normals_from_cov": (_i32, [_vp, _i64, _vp, _i32, _i32, _vp]),
     "gsr_normals_knn": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp]),
+    "gsr_cov_from_normals": (_i32, [_vp, _i64, _f64, _vp, _i32, _i32, _vp]),
     "gsr_decompose_cov": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
     "gsr_plane_score": (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _f32, _vp, _vp, C.POINTER(_i32), _i32, _i32, _vp]),
     "gsr_icp_solve": (_i32, [_vp, _i32, _vp, _vp]),

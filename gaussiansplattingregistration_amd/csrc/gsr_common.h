@@ -1,6 +1,7 @@
 // gsr_common.h -- host-side plumbing shared by the HEM and ICP halves of libgsr_hip.so.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
@@ -45,6 +46,17 @@ struct DevBuf {
     template <typename T> T* as() const { return reinterpret_cast<T*>(p); }
     void swap(DevBuf& o) { void* tp = p; p = o.p; o.p = tp; size_t tc = cap; cap = o.cap; o.cap = tc; }
 };
+
+// one step of a host spin loop on device-written pinned memory: a pause instruction on x86, a yield elsewhere; after ~20 us of
+// spinning (the read-backs normally arrive in ~5 us) the core is handed back between looks
+inline void cpu_relax(unsigned spins) {
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#else
+    asm volatile("" ::: "memory");
+#endif
+    if (spins > 4096u && (spins & 63u) == 0u) sched_yield();
+}
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // grid for a grid-stride elementwise kernel: enough blocks to fill 256 CUs x 8, no more

@@ -1128,7 +1128,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
 __global__ __launch_bounds__(1024) void k_heavy_items(const int* __restrict__ nheavy_p, const unsigned* __restrict__ porder,
                                                       const unsigned* __restrict__ pcap, unsigned part, int own_lo, int own_hi, int first_pull, int max_items,
                                                       uint2* __restrict__ hitem, int* __restrict__ hfirst, unsigned* __restrict__ pcnt,
-                                                      int* __restrict__ hq) {
+                                                      int* __restrict__ hq, int* __restrict__ error_flag) {
     __shared__ int s_wsum[16];
     __shared__ int s_base;
     const int nheavy = *nheavy_p;
@@ -1150,7 +1150,8 @@ __global__ __launch_bounds__(1024) void k_heavy_items(const int* __restrict__ nh
         for (int w = 0; w < wv; ++w) off += s_wsum[w];
         off += incl - np;
         if (p >= 0) {
-            const bool fits = off + np <= max_items;                 // cannot fail: max_items bounds sum(ceil(cap / SEL_PART))
+            const bool fits = off + np <= max_items;                 // max_items bounds sum(ceil(cap / part)) -- unless a capacity saturated
+            if (np > 0 && !fits) *error_flag = 1;                    // (the light launch skips this slot: its pairs would vanish; the host checks)
             hfirst[p] = np > 0 && fits ? off : -1;
             pcnt[p] = 0u;
             if (fits) for (int k = 0; k < np; ++k) hitem[off + k] = make_uint2((unsigned)h, (unsigned)k);
@@ -2038,7 +2039,7 @@ struct gsr_hem_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t aux2 = nullptr;     // third stream: the SH rows are gathered into cell order (an HBM stream only the M-step needs)
     hipEvent_t ev_sh_fork = nullptr, ev_sh_join = nullptr;      // beside the selection (VALU / latency bound)
-    bool sh_overlap = true;         // GSR_HEM_SH_OVERLAP=0: k_gather_sh in line on the main stream
+    int sh_overlap = 0;             // GSR_HEM_SH_OVERLAP: where k_gather_sh runs (0 in line, 1 forked in the grid phase, 2 forked beside k_select)
     float rho = 3.0f, delta = 3.0f, kappa = 2.5f, tau = 1.0f;
     int rng_mode = GSR_RNG_GLIBC;
     uint32_t rng_seed = 1;
@@ -2191,7 +2192,7 @@ int32_t read_back(gsr_hem_ctx* c, const Collect& q, unsigned long long* out) {
         const auto t0 = std::chrono::steady_clock::now();
         for (unsigned spins = 1; !(seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq); ++spins) {
             if ((spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;   // a fault upstream: let the
-            __builtin_ia32_pause();                                                                                       // synchronisation report it
+            gsr::cpu_relax(spins);                                                                                        // synchronisation report it
         }
     }
     if (!seen) GSR_HIP(hipStreamSynchronize(c->stream));
@@ -2279,7 +2280,8 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "second stream: %s", hipGetErrorString(e)); }
     }
     {
-        hipError_t e = hipHostMalloc((void**)&c->host_rb, 128, hipHostMallocDefault);
+        // pinned, device-mapped, COHERENT: the read-back kernel's system-scope stores must reach the host while the stream is running
+        hipError_t e = hipHostMalloc((void**)&c->host_rb, 128, hipHostMallocMapped | hipHostMallocCoherent);
         if (e != hipSuccess) { c->host_rb = nullptr; delete c; return fail(GSR_E_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
         memset(c->host_rb, 0, 128);
     }
@@ -2288,7 +2290,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
-    if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
     if (const char* s = getenv("GSR_HEM_PARTITION")) c->partition_fixed = strcmp(s, "exact") != 0;
     if (const char* s = getenv("GSR_HEM_PARTITION_FACTOR")) c->partition_factor = atof(s);
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
@@ -2524,18 +2526,22 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), c->rec.as<float4>(), c->delta, c->A.as<float4>(), c->geo.as<float4>(),
                        c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
     bool sh_pending = false;
-    if (F > 0) {
-        // only the M-step reads the sorted SH rows: the gather (1.9 GB of HBM traffic at 5 M) runs on its own stream beside the
-        // selection, which is bound by VALU issue and load latency, and is joined in front of the M-step
+    // only the M-step reads the sorted SH rows: the gather (1.9 GB of HBM traffic at 5 M) can run on its own stream beside the
+    // selection, which is bound by VALU issue and load latency, and is joined in front of the M-step.  sh_overlap: 0 = in line
+    // here, 1 = forked here (beside the rest of the grid phase), 2 = forked just in front of k_select
+    auto launch_gather_sh = [&](bool fork) -> int32_t {
+        if (F <= 0) return GSR_OK;
         hipStream_t sst = st;
-        if (c->sh_overlap) {
+        if (fork) {
             GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
             sst = c->aux2;
-            sh_pending = true;
         }
         hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * (RSH >> 2))), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
-        if (sh_pending) GSR_HIP(hipEventRecord(c->ev_sh_join, c->aux2));
-    }
+        if (fork) { GSR_HIP(hipEventRecord(c->ev_sh_join, c->aux2)); sh_pending = true; }
+        return GSR_OK;
+    };
+    bool sh_launched = false;
+    if (c->sh_overlap != 2) { GSR_TRY(launch_gather_sh(c->sh_overlap == 1)); sh_launched = true; }
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
     // the irregular components (never pre-rejected): their sorted positions, and their rank at every position
@@ -2669,7 +2675,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                 sa.hitem = c->hitem.as<uint2>(); sa.hfirst = c->hfirst.as<int>(); sa.part_cnt = c->part_cnt.as<unsigned>();
                 sa.hq = c->counters.as<int>() + 10;
                 hipLaunchKernelGGL(k_heavy_items, dim3(1), dim3(1024), 0, st, sa.nheavy, sa.porder, c->pcap.as<unsigned>(), sa.part, own_lo, own_hi,
-                                   SEL_HEAVY_BLOCKS * WPB, max_items, c->hitem.as<uint2>(), c->hfirst.as<int>(), c->pcnt.as<unsigned>(), sa.hq);
+                                   SEL_HEAVY_BLOCKS * WPB, max_items, c->hitem.as<uint2>(), c->hfirst.as<int>(), c->pcnt.as<unsigned>(), sa.hq,
+                                   c->counters.as<int>() + 13);
             }
         }
         size_t free_b = 0, total_b = 0;
@@ -2677,6 +2684,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 20 * 9;      // 45 % of what is free (a 40 M-splat level needs 79 GB)
         if (const char* e = getenv("GSR_HEM_SPARSE_GB")) budget = (size_t)(atof(e) * 1073741824.0);
         const bool sparse = (double)cand * 8.0 <= (double)budget && cand < (1ull << 40);
+        if (!sh_launched) { GSR_TRY(launch_gather_sh(true)); sh_launched = true; }
         if (sparse) {
             const size_t Cm = (size_t)(cand > 0 ? cand : 1);
             GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
@@ -2833,12 +2841,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
         GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
         Collect q;
-        q.n = 3;
+        q.n = 4;
         q.src[0] = c->orank_in.as<int>() + (n - 1); q.src[1] = c->oflag_in.as<int>() + (n - 1); q.src[2] = overflow_flag;
-        q.bytes[0] = q.bytes[1] = q.bytes[2] = 4;
+        q.src[3] = c->counters.as<int>() + 13;
+        q.bytes[0] = q.bytes[1] = q.bytes[2] = q.bytes[3] = 4;
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
         o_last = (int)w[0]; o_flag = (int)w[1];
+        if (w[3] != 0ull) return fail(GSR_E_INVALID, "gsr_hem_run_level: the work-item table of the heavy parents overflowed (rerun with GSR_HEM_SPLIT=0)");
         if (!(fixed_tried && w[2] != 0ull) || attempt == 1) break;
         // a bucket region overflowed (pairs far more clustered than 6x the mean): the sums are incomplete.  Exact partition, and
         // this context stays with it
@@ -2855,6 +2865,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     Level& O = c->nxt;
     GSR_TRY(O.reserve(n_pre, F));
     O.n = n_pre; O.F = F;
+    if (!sh_launched) { GSR_TRY(launch_gather_sh(false)); sh_launched = true; }                       // (a level without parents)
     if (sh_pending) { GSR_HIP(hipStreamWaitEvent(st, c->ev_sh_join, 0)); sh_pending = false; }      // the sorted SH rows are needed from here on
     if (P > 0) {
         MstepArgs ma;

@@ -299,8 +299,8 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
 struct IcpState;
 __device__ __forceinline__ bool icp_state_done(const IcpState* st);
 __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]);
-template <int THREADS> __device__ void icp_fold_partials(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced, double (*s_x)[32]);
-__device__ void icp_step_solve(const double* acc32, const IcpState& s_st, IcpState* st);
+template <int THREADS, bool SC1 = false> __device__ __forceinline__ void icp_fold_partials(int nblocks, const double* partials, const double* __restrict__ reduced, double (*s_x)[32]);
+__device__ __forceinline__ void icp_step_solve(const double* acc32, const IcpState& s_st, IcpState* st);
 
 // nn_j[i] = sorted target position of the accepted nearest neighbour of source point i, or -1.  One thread per source
 // point: a search kernel with few registers (56 VGPRs, 8 waves per SIMD) in front of a streaming accumulate kernel.
@@ -588,7 +588,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
-template <int NACC>
+// WT: the partials leave with write-through (sc1) stores -- what a workgroup that hands them to another workgroup of the SAME
+// launch must use (k_icp_accumulate_dev's fused step); plain stores otherwise (the reader is a later kernel)
+template <int NACC, bool WT = false>
 __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ partials) {
     __shared__ double s_red[4][NACC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -600,7 +602,9 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
     __syncthreads();
     if (threadIdx.x < NACC) {
         const int k = threadIdx.x;
-        partials[(int64_t)blockIdx.x * GSR_ICP_ACC_LEN + k] = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+        const double v = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
+        if (WT) __hip_atomic_store(partials + (int64_t)blockIdx.x * GSR_ICP_ACC_LEN + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else partials[(int64_t)blockIdx.x * GSR_ICP_ACC_LEN + k] = v;
     }
 }
 
@@ -799,6 +803,38 @@ __global__ __launch_bounds__(256) void k_normals_from_cov(int64_t n, const float
         double v[3];
         normal_of_cov_d(cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5], v);
         out[3 * i] = v[0]; out[3 * i + 1] = v[1]; out[3 * i + 2] = v[2];
+    }
+}
+
+// Covariances of a cloud that has none, for generalized ICP (Open3D GeneralizedICP.cpp, InitializePointCloudForGeneralizedICP):
+// C_i = Rx diag(epsilon, 1, 1) Rx^T with Rx = GetRotationFromE1ToX(n_i) = I + [v]x + [v]x^2 / (1 + c), v = e1 x n_i, c = e1 . n_i
+// (the identity when c < -0.99, as Open3D has it).  The reference reaches this with its SPARSE input clouds, which carry KNN-30
+// normals but no covariances (point_cloud_converter.py:9-28, qt_multiscale_registrator.py:82-85).  cov6 out: xx xy xz yy yz zz.
+__global__ __launch_bounds__(256) void k_cov_from_normals(int64_t n, const double* __restrict__ nrm, double eps, double* __restrict__ cov6) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const double x = nrm[3 * i], y = nrm[3 * i + 1], z = nrm[3 * i + 2];
+        double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+        const double c = x;                                   // e1 . n
+        if (!(c < -0.99)) {
+            const double v[3] = {0.0, -z, y};                 // e1 x n
+            const double sv[3][3] = {{0, -v[2], v[1]}, {v[2], 0, -v[0]}, {-v[1], v[0], 0}};
+            const double f = 1.0 / (1.0 + c);
+            for (int a = 0; a < 3; ++a)
+                for (int b = 0; b < 3; ++b) {
+                    double sq = 0;
+                    for (int k = 0; k < 3; ++k) sq += sv[a][k] * sv[k][b];
+                    R[a][b] = (a == b ? 1.0 : 0.0) + sv[a][b] + sq * f;
+                }
+        }
+        const double d[3] = {eps, 1.0, 1.0};
+        int t = 0;
+        for (int a = 0; a < 3; ++a)
+            for (int b = a; b < 3; ++b) {
+                // (Rx * C) * Rx^T in Eigen's evaluation order: the product with the diagonal first
+                double sum = 0;
+                for (int k = 0; k < 3; ++k) sum += (R[a][k] * d[k]) * R[b][k];
+                cov6[6 * i + t++] = sum;
+            }
     }
 }
 
@@ -1082,13 +1118,17 @@ __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]) {
 //   1  the whole step -- fold the partials in k_icp_finalize's order, test convergence, solve, update T: ONE launch per ICP
 //      iteration instead of two (a coarse level's iteration was 36 us + 8.5 us of k_icp_step and its launch gap)
 //   2  fold the partials into acc_out (the rank-local vector of a multi-GPU source split; the all-reduce and k_icp_step follow)
-template <int KIND, bool BLOCK>
-__global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, IcpState* st,
+// (FUSE is a template parameter: the step's code costs the kernel ~24 VGPRs, and with them a wave per SIMD on the levels whose
+// blocks just fill the chip once; the bound of 3 waves per SIMD keeps the fused forms at <= 168 registers -- whatever does not
+// fit spills in the step's code, which one workgroup runs once)
+template <int KIND, bool BLOCK, int FUSE>
+__global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, IcpState* st,
                                                             IcpGrid g, const int* __restrict__ cellStart, const int* __restrict__ nn_j,
                                                             const float4* __restrict__ Tq, const double* __restrict__ Tn,
                                                             const double* __restrict__ Sc, ColorArgs ca, double max_corr2,
-                                                            int loss, double kparam, double* partials, int fuse, unsigned* ticket,
+                                                            int loss, double kparam, double* partials, unsigned* ticket,
                                                             double* acc_out) {
+    constexpr int fuse = FUSE;
     if (st->done) {
         // converged: nothing to search.  The ranks of a multi-GPU run still meet in the collective: zeros
         if (fuse == 2 && blockIdx.x == 0 && threadIdx.x < GSR_ICP_ACC_LEN) acc_out[threadIdx.x] = 0.0;
@@ -1148,14 +1188,17 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
             acc[29] += r * r;
         }
     }
-    block_reduce_store<NACC>(acc, partials);
-    if (fuse == 0) return;
-    // hand-off: this workgroup's partials out to memory (agent-scope release by the storing lanes' wave), then the ticket
+    block_reduce_store<NACC, FUSE != 0>(acc, partials);
+    if constexpr (FUSE == 0) return;
+    // Hand-off inside one launch (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): the
+    // partials left with write-through (sc1) stores by the lanes of wave 0; that wave waits for them (vmcnt(0)), then its lane 0
+    // takes a device-scope ticket.  The workgroup whose ticket is the last one reads every block's partials with sc1 loads -- no
+    // L2 write-back / invalidate fences: with a release fence per workgroup (buffer_wbl2) the fused form was 4 us SLOWER per
+    // iteration than two launches.
     __shared__ int s_last;
     __shared__ double s_x[8][GSR_ICP_ACC_LEN];
     __shared__ IcpState s_st;
-    if (threadIdx.x < 64) {                               // the wave that stored the partials (threads < NACC <= 32)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (threadIdx.x < 64) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
             const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1164,11 +1207,8 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
     }
     __syncthreads();
     if (!s_last) return;
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
     if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
-    icp_fold_partials<256>((int)gridDim.x, partials, nullptr, s_x);
+    icp_fold_partials<256, true>((int)gridDim.x, partials, nullptr, s_x);
     if (fuse == 2) {
         if (threadIdx.x < GSR_ICP_ACC_LEN) acc_out[threadIdx.x] = s_x[0][threadIdx.x];
     } else if (threadIdx.x == 0) {
@@ -1191,8 +1231,9 @@ __global__ __launch_bounds__(256) void k_icp_accumulate_dev(int64_t ns, const fl
 // butterfly s_l + s_(l ^ 32), + (l ^ 16), ... down to lane 0 -- with THREADS = 32 G threads: thread (g = t / 32, k = t % 32) forms
 // the lane sums s_g, s_(g + G), ... of accumulator k (32 threads read one 256-byte row per load, four rounds of loads in flight),
 // folds the butterfly steps it holds both operands of, and an LDS tree over g does the remaining log2 G.  Result: s_x[0][k].
-template <int THREADS>
-__device__ void icp_fold_partials(int nblocks, const double* __restrict__ partials, const double* __restrict__ reduced, double (*s_x)[32]) {
+// SC1: the partials were stored write-through by other workgroups of the SAME launch: read them with sc1 loads (past the L1)
+template <int THREADS, bool SC1>
+__device__ __forceinline__ void icp_fold_partials(int nblocks, const double* partials, const double* __restrict__ reduced, double (*s_x)[32]) {
     constexpr int G = THREADS / 32, NL = 64 / G;
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
     if (reduced) {
@@ -1210,7 +1251,8 @@ __device__ void icp_fold_partials(int nblocks, const double* __restrict__ partia
 #pragma unroll
             for (int j = 0; j < NL; ++j) {
                 const int b = b0 + 64 * u + G * j;
-                v[u][j] = b < nblocks ? partials[(int64_t)b * GSR_ICP_ACC_LEN + k] : 0.0;
+                if (SC1) v[u][j] = b < nblocks ? __hip_atomic_load(partials + (int64_t)b * GSR_ICP_ACC_LEN + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                else v[u][j] = b < nblocks ? partials[(int64_t)b * GSR_ICP_ACC_LEN + k] : 0.0;
             }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
@@ -1230,7 +1272,7 @@ __device__ void icp_fold_partials(int nblocks, const double* __restrict__ partia
     }
 }
 // one thread: fitness / RMSE, the relative-change test, the estimator's solve and T <- update * T (registration_icp's loop body)
-__device__ void icp_step_solve(const double* acc32, const IcpState& s_st, IcpState* st) {
+__device__ __forceinline__ void icp_step_solve(const double* acc32, const IcpState& s_st, IcpState* st) {
     double acc[GSR_ICP_ACC_LEN];
 #pragma unroll
     for (int i = 0; i < GSR_ICP_ACC_LEN; ++i) acc[i] = acc32[i];
@@ -1288,12 +1330,15 @@ struct gsr_icp_ctx {
     bool have_target = false, have_normals = false, have_source = false;
     int64_t nt = 0, ns = 0, ns_global = 0;
     double max_corr = 0;
-    DevBuf src_raw, src_order, state, nn_j, Tc, Sc, stage_cov, Ti, Tg, Si;
+    DevBuf src_raw, src_order, state, nn_j, Tc, Sc, stage_cov, Ti, Tg, Si, ticket;
     bool have_tcov = false, have_scov = false, have_tcol = false, have_scol = false;
     double lambda_geometric = 0.968;            // Open3D TransformationEstimationForColoredICP default
     bool src_sorted = false;
     bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
     bool block_search = true;       // GSR_ICP_BLOCK_SEARCH=0: always the ring loop from ring 0
+    bool fused_step = false;        // GSR_ICP_FUSED_STEP=1: the accumulate kernel's last workgroup does k_icp_step's (or k_icp_reduce's) work instead of a launch of its own: measured equal (44.8 vs 44.0 us at 185 k), so off
+                                    // accumulate kernel's last workgroup
+    gsr_comm* comm = nullptr;       // multi-GPU source split through a communicator (gsr_icp_set_comm)
     unsigned* host_rb = nullptr;    // pinned host memory for small read-backs: 256 words + the sequence flag
     unsigned long long rb_seq = 0;
     // Search / accumulate split (GSR_ICP_NN_KERNEL): 0 = one fused kernel (120 VGPRs with the 30 float64 accumulators:
@@ -1414,7 +1459,7 @@ static int32_t icp_fetch(gsr_icp_ctx* c, const void* dev, void* out, size_t byte
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 1; !(seen = __atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq); ++spins) {
         if ((spins & 0x3ffu) == 0u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(200)) break;
-        __builtin_ia32_pause();
+        gsr::cpu_relax(spins);
     }
     if (!seen) GSR_HIP(hipStreamSynchronize(st));
     memcpy(out, (const void*)c->host_rb, bytes);
@@ -1436,7 +1481,12 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     // Environment knobs (all of them): none changes a result, tests/test_icp_gpu.py::test_icp_knobs_change_nothing
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
-    if (hipHostMalloc((void**)&c->host_rb, 1024 + 64, hipHostMallocDefault) == hipSuccess) memset(c->host_rb, 0, 1024 + 64);
+    if (const char* e = getenv("GSR_ICP_FUSED_STEP")) c->fused_step = atoi(e) != 0;
+    // pinned, device-mapped, COHERENT host memory: the device's system-scope stores must reach the host while the stream is still
+    // running (a non-coherent mapping would only show them at the end of the kernel).  GSR_ICP_RB_POLL=0: no polling at all
+    bool poll = true;
+    if (const char* e = getenv("GSR_ICP_RB_POLL")) poll = atoi(e) != 0;
+    if (poll && hipHostMalloc((void**)&c->host_rb, 1024 + 64, hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) memset(c->host_rb, 0, 1024 + 64);
     else { c->host_rb = nullptr; (void)hipGetLastError(); }
     if (const char* e = getenv("GSR_ICP_NN_KERNEL")) c->nn_kernel = atoi(e);
     if (const char* e = getenv("GSR_ICP_CELL_TARGET")) { double v = atof(e); if (v > 0.01 && v < 1000) c->cell_target = v; }
@@ -1448,7 +1498,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
 int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
-    DevBuf* all[] = {&c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->Tc, &c->Sc, &c->stage_cov, &c->Ti, &c->Tg, &c->Si, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
+    DevBuf* all[] = {&c->ticket, &c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->Tc, &c->Sc, &c->stage_cov, &c->Ti, &c->Tg, &c->Si, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
                      &c->src, &c->partials, &c->acc_dev, &c->rocprim_tmp, &c->corr_idx, &c->corr_d2};
     for (DevBuf* b : all) b->release();
     if (c->e0) (void)hipEventDestroy(c->e0);
@@ -1572,11 +1622,12 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t 
     }
     GSR_HIP(hipStreamSynchronize(st));
     c->ns = n; c->have_source = true; c->have_scov = false; c->have_scol = false;
-    if (!c->allreduce && !c->allreduce_dev) c->ns_global = n;
+    if (!c->allreduce && !c->allreduce_dev && !c->comm) c->ns_global = n;
     return GSR_OK;
 }
 
 static int32_t set_cov(gsr_icp_ctx* c, const double* cov6, int64_t n, const unsigned* order, DevBuf& dst, int32_t on_device) {
+    if (n == 0) return dst.reserve(48);               // an empty shard of a multi-GPU source split: nothing to gather
     GSR_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const double* in = cov6;
@@ -1598,7 +1649,7 @@ int32_t gsr_icp_set_target_cov(gsr_icp_ctx* c, const double* cov6, int32_t on_de
     return GSR_OK;
 }
 int32_t gsr_icp_set_source_cov(gsr_icp_ctx* c, const double* cov6, int32_t on_device) {
-    if (!c || !cov6) return fail(GSR_E_INVALID, "gsr_icp_set_source_cov: NULL argument");
+    if (!c || (!cov6 && !(c->have_source && c->ns == 0))) return fail(GSR_E_INVALID, "gsr_icp_set_source_cov: NULL argument");
     if (!c->have_source) return fail(GSR_E_PRECONDITION, "gsr_icp_set_source_cov: set the source first");
     GSR_TRY(set_cov(c, cov6, c->ns, c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->Sc, on_device));
     c->have_scov = true;
@@ -1628,11 +1679,12 @@ int32_t gsr_icp_set_target_color(gsr_icp_ctx* c, const double* rgb, int32_t on_d
     return GSR_OK;
 }
 int32_t gsr_icp_set_source_color(gsr_icp_ctx* c, const double* rgb, int32_t on_device) {
-    if (!c || !rgb) return fail(GSR_E_INVALID, "gsr_icp_set_source_color: NULL argument");
+    if (!c || (!rgb && !(c->have_source && c->ns == 0))) return fail(GSR_E_INVALID, "gsr_icp_set_source_color: NULL argument");
     if (!c->have_source) return fail(GSR_E_PRECONDITION, "gsr_icp_set_source_color: set the source first");
     GSR_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     const int64_t n = c->ns;
+    if (n == 0) { GSR_TRY(c->Si.reserve(8)); c->have_scol = true; return GSR_OK; }      // an empty shard of a multi-GPU source split
     const double* in = rgb;
     if (!on_device) {
         GSR_TRY(c->stage_cov.reserve((size_t)n * 24));
@@ -1669,14 +1721,21 @@ int32_t gsr_icp_get_color_gradient(gsr_icp_ctx* c, double* out) {
 int32_t gsr_icp_set_allreduce_dev(gsr_icp_ctx* c, gsr_allreduce_dev64_fn fn, void* user, int64_t n_source_global) {
     if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_allreduce_dev: NULL context");
     c->allreduce_dev = fn; c->allreduce_dev_user = user;
-    if (fn) { c->allreduce = nullptr; c->allreduce_user = nullptr; }
+    if (fn) { c->allreduce = nullptr; c->allreduce_user = nullptr; c->comm = nullptr; }
     c->ns_global = fn ? n_source_global : c->ns;
+    return GSR_OK;
+}
+int32_t gsr_icp_set_comm(gsr_icp_ctx* c, gsr_comm* comm, int64_t n_source_global) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_comm: NULL context");
+    c->comm = comm;
+    if (comm) { c->allreduce = nullptr; c->allreduce_user = nullptr; c->allreduce_dev = nullptr; c->allreduce_dev_user = nullptr; }
+    c->ns_global = comm ? n_source_global : c->ns;
     return GSR_OK;
 }
 int32_t gsr_icp_set_allreduce(gsr_icp_ctx* c, gsr_allreduce_fn fn, void* user, int64_t n_source_global) {
     if (!c) return fail(GSR_E_INVALID, "gsr_icp_set_allreduce: NULL context");
     c->allreduce = fn; c->allreduce_user = user;
-    if (fn) { c->allreduce_dev = nullptr; c->allreduce_dev_user = nullptr; }
+    if (fn) { c->allreduce_dev = nullptr; c->allreduce_dev_user = nullptr; c->comm = nullptr; }
     c->ns_global = fn ? n_source_global : c->ns;
     return GSR_OK;
 }
@@ -1692,9 +1751,10 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
     if (!c || !init_T || !out_T) return fail(GSR_E_INVALID, "gsr_icp_register: NULL argument");
     GSR_HIP(hipSetDevice(c->device));
     c->ms_iter = 0; c->n_iter_kernels = 0;
-    if (!c->allreduce && !c->allreduce_dev && c->have_source && c->ns == 0)
+    const bool multi = c->allreduce_dev != nullptr || c->comm != nullptr;      // a device-side all-reduce per iteration
+    if (!c->allreduce && !multi && c->have_source && c->ns == 0)
         return fail(GSR_E_PRECONDITION, "gsr_icp_register: empty source cloud");
-    if (!c->allreduce && (c->device_loop || c->allreduce_dev)) {
+    if (!c->allreduce && (c->device_loop || multi)) {
         // device-resident loop: no per-iteration host round trip.  With a device all-reduce (multi-GPU source split) the
         // only addition per iteration is one stream-ordered collective on 32 doubles between the reduction and the solve.
         if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
@@ -1710,7 +1770,7 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         memset(&hs, 0, sizeof(hs));
         memcpy(hs.T, init_T, sizeof(hs.T));
         hs.ctr[0] = c->grid.cx; hs.ctr[1] = c->grid.cy; hs.ctr[2] = c->grid.cz;
-        hs.nsg = (double)(c->allreduce_dev ? c->ns_global : c->ns); hs.rel_fit = rel_fitness; hs.rel_rmse = rel_rmse;
+        hs.nsg = (double)(multi ? c->ns_global : c->ns); hs.rel_fit = rel_fitness; hs.rel_rmse = rel_rmse;
         hs.max_iter = max_iter < 0 ? 0 : max_iter; hs.kind = kind;
         GSR_TRY(c->state.reserve(sizeof(IcpState)));
         GSR_HIP(hipMemcpyAsync(c->state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
@@ -1720,7 +1780,11 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         GSR_TRY(c->partials.reserve((size_t)nb * GSR_ICP_ACC_LEN * 8));
         GSR_TRY(c->nn_j.reserve((size_t)(c->ns > 0 ? c->ns : 1) * 4));
         GSR_TRY(c->acc_dev.reserve(GSR_ICP_ACC_LEN * 8));
+        GSR_TRY(c->ticket.reserve(64));
         GSR_HIP(hipMemsetAsync(c->partials.p, 0, (size_t)nb * GSR_ICP_ACC_LEN * 8, st));
+        GSR_HIP(hipMemsetAsync(c->ticket.p, 0, 64, st));
+        // what the accumulate kernel's last workgroup does: the whole step (single GPU), the rank-local fold (multi-GPU), nothing
+        const int fuse = !c->fused_step ? 0 : (multi ? 2 : 1);
         const double mc2 = c->max_corr * c->max_corr;
         const ColorArgs cargs = {c->Ti.as<double>(), c->Tg.as<double>(), c->Si.as<double>(), sqrt(c->lambda_geometric), sqrt(1.0 - c->lambda_geometric)};
         const int total_evals = hs.max_iter + 1;
@@ -1732,14 +1796,14 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
             const int chunk = total_evals - issued < 8 ? total_evals - issued : 8;
             const int* nnj = c->nn_mode() ? c->nn_j.as<int>() : (const int*)nullptr;
             for (int i = 0; i < chunk; ++i) {
+#define GSR_ICP_ACC1(KIND, BLK, FUSE, TN, SC)                                                                                        \
+    hipLaunchKernelGGL((k_icp_accumulate_dev<KIND, BLK, FUSE>), dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), \
+                       c->grid, c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), TN, SC, cargs, mc2, loss, k, c->partials.as<double>(),     \
+                       c->ticket.as<unsigned>(), c->acc_dev.as<double>())
 #define GSR_ICP_ACC(KIND, TN, SC)                                                                                                    \
     do {                                                                                                                             \
-        if (blockf)                                                                                                                  \
-            hipLaunchKernelGGL((k_icp_accumulate_dev<KIND, true>), dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), \
-                               c->grid, c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), TN, SC, cargs, mc2, loss, k, c->partials.as<double>()); \
-        else                                                                                                                         \
-            hipLaunchKernelGGL((k_icp_accumulate_dev<KIND, false>), dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), \
-                               c->grid, c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), TN, SC, cargs, mc2, loss, k, c->partials.as<double>()); \
+        if (blockf) { if (fuse == 0) GSR_ICP_ACC1(KIND, true, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, true, 1, TN, SC); else GSR_ICP_ACC1(KIND, true, 2, TN, SC); } \
+        else { if (fuse == 0) GSR_ICP_ACC1(KIND, false, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, false, 1, TN, SC); else GSR_ICP_ACC1(KIND, false, 2, TN, SC); } \
     } while (0)
                 if (c->nn_mode()) {
                     if (blockf)
@@ -1754,12 +1818,18 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
                 else if (kind == GSR_ICP_POINT_TO_PLANE) GSR_ICP_ACC(1, c->Tn.as<double>(), (const double*)nullptr);
                 else GSR_ICP_ACC(2, c->Tc.as<double>(), c->Sc.as<double>());
 #undef GSR_ICP_ACC
-                if (c->allreduce_dev) {
-                    hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>(), c->acc_dev.as<double>());
-                    const int32_t rc = c->allreduce_dev(c->acc_dev.p, GSR_ICP_ACC_LEN, c->allreduce_dev_user);
-                    if (rc != 0) return fail(GSR_E_INVALID, "icp: device all-reduce callback returned %d", rc);
+#undef GSR_ICP_ACC1
+                if (multi) {
+                    if (fuse == 0)
+                        hipLaunchKernelGGL(k_icp_reduce, dim3(1), dim3(1024), 0, st, nb, c->partials.as<double>(), c->state.as<IcpState>(), c->acc_dev.as<double>());
+                    if (c->comm) {                            // RCCL enqueued on this stream: no host involvement
+                        GSR_TRY(gsr_comm_allreduce(c->comm, c->acc_dev.p, GSR_ICP_ACC_LEN, GSR_DT_F64, GSR_OP_SUM, (void*)st));
+                    } else {
+                        const int32_t rc = c->allreduce_dev(c->acc_dev.p, GSR_ICP_ACC_LEN, c->allreduce_dev_user);
+                        if (rc != 0) return fail(GSR_E_INVALID, "icp: device all-reduce callback returned %d", rc);
+                    }
                     hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ICP_STEP_THREADS), 0, st, nb, c->partials.as<double>(), c->acc_dev.as<double>(), c->state.as<IcpState>());
-                } else {
+                } else if (fuse == 0) {
                     hipLaunchKernelGGL(k_icp_step, dim3(1), dim3(ICP_STEP_THREADS), 0, st, nb, c->partials.as<double>(), (const double*)nullptr, c->state.as<IcpState>());
                 }
             }
@@ -1864,6 +1934,34 @@ int32_t gsr_normals_from_cov(const float* cov6, int64_t n, double* normals, int3
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     in.release(); out.release();
     if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_normals_from_cov: %s", hipGetErrorString(e));
+    return GSR_OK;
+}
+
+int32_t gsr_cov_from_normals(const double* normals, int64_t n, double epsilon, double* cov6, int32_t on_device, int32_t device, void* stream) {
+    if (n < 0 || (n > 0 && (!normals || !cov6))) return fail(GSR_E_INVALID, "gsr_cov_from_normals: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GSR_E_NO_DEVICE, "gsr_cov_from_normals: no HIP device visible (this backend has no CPU fallback)");
+    if (n == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    hipStream_t st = (hipStream_t)stream;
+    if (on_device) {
+        hipLaunchKernelGGL(k_cov_from_normals, dim3(stride_grid(n)), dim3(256), 0, st, n, normals, epsilon, cov6);
+        GSR_HIP(hipStreamSynchronize(st));
+        return GSR_OK;
+    }
+    DevBuf in, out;
+    int32_t r = in.reserve((size_t)n * 24);
+    if (r == GSR_OK) r = out.reserve((size_t)n * 48);
+    if (r != GSR_OK) { in.release(); out.release(); return r; }
+    hipError_t e = hipMemcpyAsync(in.p, normals, (size_t)n * 24, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_cov_from_normals, dim3(stride_grid(n)), dim3(256), 0, st, n, in.as<double>(), epsilon, out.as<double>());
+        e = hipMemcpyAsync(cov6, out.p, (size_t)n * 48, hipMemcpyDeviceToHost, st);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    in.release(); out.release();
+    if (e != hipSuccess) return fail(GSR_E_HIP, "gsr_cov_from_normals: %s", hipGetErrorString(e));
     return GSR_OK;
 }
 

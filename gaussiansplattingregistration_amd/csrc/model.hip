@@ -143,13 +143,17 @@ __global__ __launch_bounds__(256) void k_decompose_cov(int64_t n, const float* _
 // ballot + popcount (one LDS atomic per wave and candidate).
 //   distance  = (x n'_0 + y n'_1 + z n'_2 + d) / |n'|      n' = the plane normal re-normalised in float32 (:91-96)
 //   inlier   <=> |distance| < distance_threshold  and  |<point normal, plane normal>| > normal_threshold   (:54-61)
-// float32 throughout, dot products as fused multiply-add chains in index order (what the host BLAS does for K = 3).
+// float32 throughout.  The reference's dot products come out of torch.mm / torch.matmul on the CPU, i.e. MKL's sgemv, whose
+// K = 3 rows round as  fl(z n2) + fma(y, n1, fl(x n0))  -- measured in the build container: that expression reproduces
+// torch.mm bit for bit on 10^6 random rows, EXCEPT the few rows in the tail of each OpenMP thread's share (266 of 2.3 M rows
+// with 8 threads; which rows depends on the thread count of the machine), which take another path.  So the host result
+// cannot be reproduced exactly in general; the kernel uses the dominant rounding (tests/test_planes_gpu.py).
 struct PlaneCand { float n0, n1, n2, d, m0, m1, m2, nn; };      // n' (re-normalised), d, plane normal as sampled, |n'|
 
 __device__ __forceinline__ bool plane_inlier(const PlaneCand& c, float x, float y, float z, float nx, float ny, float nz, float dist_thr, float nrm_thr) {
-    const float dot = __builtin_fmaf(z, c.n2, __builtin_fmaf(y, c.n1, x * c.n0));
+    const float dot = z * c.n2 + __builtin_fmaf(y, c.n1, x * c.n0);
     const float dist = (dot + c.d) / c.nn;
-    const float al = __builtin_fmaf(nz, c.m2, __builtin_fmaf(ny, c.m1, nx * c.m0));
+    const float al = nz * c.m2 + __builtin_fmaf(ny, c.m1, nx * c.m0);
     return fabsf(dist) < dist_thr && fabsf(al) > nrm_thr;
 }
 

@@ -15,7 +15,7 @@ try:
 except Exception:  # pragma: no cover
     torch = None
 
-__all__ = ["IcpContext", "registration_icp_arrays", "normals_from_cov", "RegistrationResult"]
+__all__ = ["IcpContext", "registration_icp_arrays", "normals_from_cov", "normals_knn", "cov_from_normals", "RegistrationResult"]
 
 KIND_POINT_TO_POINT = 0
 KIND_POINT_TO_PLANE = 1
@@ -68,6 +68,8 @@ class IcpContext:
         _lib.check(self._L.gsr_icp_create(C.byref(h), self.device, C.c_void_p(stream or 0)), "gsr_icp_create")
         self._h = h
         self._cb = None
+        self._stream = int(stream or 0)
+        self._comm = None
         self.n_source = 0
 
     def close(self):
@@ -199,9 +201,15 @@ class IcpContext:
             def __init__(self, ptr, count):
                 self.__cuda_array_interface__ = {"shape": (count,), "typestr": "<f8", "data": (ptr, False), "version": 3}
 
+        ext = torch.cuda.ExternalStream(self._stream, device=torch.device("cuda", dev)) if self._stream else None
+
         def _tramp(ptr, count, _user):
             try:
-                fn(torch.as_tensor(_Ptr(int(ptr), int(count)), device=torch.device("cuda", dev)))
+                t = torch.as_tensor(_Ptr(int(ptr), int(count)), device=torch.device("cuda", dev))
+                # the collective must be ordered on the CONTEXT's stream (the library enqueues the reduction in front of it and
+                # the solve behind it there), whatever torch's current stream is when the library calls back
+                with torch.cuda.stream(ext if ext is not None else torch.cuda.default_stream(dev)):
+                    fn(t)
                 return 0
             except Exception:  # pragma: no cover
                 import traceback
@@ -210,6 +218,12 @@ class IcpContext:
 
         self._cb_dev = _lib.ALLREDUCE_DEV_FN(_tramp)
         _lib.check(self._L.gsr_icp_set_allreduce_dev(self._h, self._cb_dev, None, int(n_source_global)), "gsr_icp_set_allreduce_dev")
+
+    def set_comm(self, comm, n_source_global=0):
+        """Multi-GPU source split through a library communicator (``comm.Comm``): per iteration ONE all-reduce of 32 float64,
+        enqueued by the library itself on this context's stream (RCCL transport).  ``comm = None`` restores single-GPU."""
+        self._comm = comm                      # keep it alive while the context may use it
+        _lib.check(self._L.gsr_icp_set_comm(self._h, comm.handle if comm is not None else None, int(n_source_global)), "gsr_icp_set_comm")
 
     def accumulate(self, T, kind=0, loss=0, k=0.0):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
@@ -297,4 +311,22 @@ def normals_knn(xyz, knn=30, device=0):
     a = np.ascontiguousarray(xyz.detach().cpu().numpy() if _is_tensor(xyz) else xyz, dtype=np.float32).reshape(n, 3)
     out = np.empty((n, 3), np.float64)
     _lib.check(L.gsr_normals_knn(a.ctypes.data, n, int(knn), out.ctypes.data, 0, int(device), None), "gsr_normals_knn")
+    return out
+
+
+def cov_from_normals(normals, epsilon=1e-3, device=0):
+    """float64 covariances (n,6) [xx,xy,xz,yy,yz,zz] of Open3D's ``InitializePointCloudForGeneralizedICP``: a disc of
+    thickness ``epsilon`` perpendicular to each normal -- what generalized ICP uses for a cloud without covariances."""
+    L = _lib.load(require_device=True)
+    n = int(normals.shape[0])
+    if _is_tensor(normals) and normals.is_cuda:
+        t = normals.detach().to(torch.float64).reshape(n, 3).contiguous()
+        out = torch.empty((n, 6), dtype=torch.float64, device=t.device)
+        torch.cuda.current_stream(t.device.index).synchronize()
+        _lib.check(L.gsr_cov_from_normals(t.data_ptr(), n, float(epsilon), out.data_ptr(), 1, t.device.index,
+                                          C.c_void_p(torch.cuda.current_stream(t.device.index).cuda_stream)), "gsr_cov_from_normals")
+        return out
+    a = np.ascontiguousarray(normals.detach().cpu().numpy() if _is_tensor(normals) else normals, dtype=np.float64).reshape(n, 3)
+    out = np.empty((n, 6), np.float64)
+    _lib.check(L.gsr_cov_from_normals(a.ctypes.data, n, float(epsilon), out.ctypes.data, 0, int(device), None), "gsr_cov_from_normals")
     return out

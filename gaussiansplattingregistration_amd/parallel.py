@@ -112,8 +112,11 @@ def assign_clouds(n_clouds: int, rank: int, world: int):
 
 
 def registration_icp_sharded(source, target, max_correspondence_distance, init, estimation_method, criteria,
-                             rank: int, world: int, device=None, group=None, ctx=None):
+                             rank: int, world: int, device=None, group=None, ctx=None, comm=None):
     """``registration_icp`` with the source split over the ranks of ``group`` and the target replicated.
+
+    ``comm`` (a ``comm.Comm``): the collective is the library's own -- ncclAllReduce enqueued on the ICP context's stream,
+    no Python per iteration; without it a ``torch.distributed`` trampoline is installed (kept for callers without a ``Comm``).
 
     ``source`` / ``target`` are the FULL clouds on every rank (``PointCloud`` records); each rank keeps its
     ``shard_range`` of the source points (and of their covariances / colours).  The only exchange is one all-reduce of
@@ -126,6 +129,9 @@ def registration_icp_sharded(source, target, max_correspondence_distance, init, 
     lo, hi = shard_range(n, rank, world)
     cut = lambda a: None if a is None else a[lo:hi]
     local = PointCloud(xyz32=source.xyz32[lo:hi], colors=cut(source.colors), cov6=cut(source.cov6))
+    if comm is not None:          # the library's own communicator (RCCL enqueued on the context's stream)
+        return registration_icp(local, target, max_correspondence_distance, init, estimation_method, criteria,
+                                device=device, comm=comm, n_source_global=n, ctx=ctx)
     ar = make_allreduce_device(group)
     return registration_icp(local, target, max_correspondence_distance, init, estimation_method, criteria,
                             device=device, allreduce_device=ar, n_source_global=n, ctx=ctx)

@@ -122,7 +122,7 @@ def get_rejection_loss(rejection_type, k_value, registration_type):
 
 
 def registration_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, device=None,
-                     allreduce=None, n_source_global=None, ctx=None, allreduce_device=None):
+                     allreduce=None, n_source_global=None, ctx=None, allreduce_device=None, comm=None):
     """``o3d.pipelines.registration.registration_icp`` on ``PointCloud`` records (see ``point_cloud.py``)."""
     if not (max_correspondence_distance > 0.0):
         raise RuntimeError("[Open3D Error] Invalid max_correspondence_distance.")
@@ -133,9 +133,18 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
         raise NotImplementedError(f"{estimation_method.name} is not part of this backend yet (SURVEY.md 8f, N2)")
     if estimation_method.kind == _icp.KIND_COLORED and (source.colors is None or target.colors is None):
         raise RuntimeError("[Open3D Error] ColoredICP requires color for both source and target PointCloud.")
-    if estimation_method.kind == _icp.KIND_GENERALIZED and not (source.has_covariances() and target.has_covariances()):
-        raise RuntimeError("registration_generalized_icp: this backend uses the clouds' own covariances "
-                           "(point_cloud_converter.py:38 always sets them); a cloud without covariances is not supported")
+    gicp_cov = {}
+    if estimation_method.kind == _icp.KIND_GENERALIZED:
+        # Open3D's InitializePointCloudForGeneralizedICP: pre-computed covariances are used as they are (every splat cloud,
+        # point_cloud_converter.py:38); a cloud without them -- the reference's sparse input clouds, which reach this through
+        # qt_multiscale_registrator.py:82-85 -- gets discs of thickness epsilon = 1e-3 perpendicular to its normals, and a cloud
+        # without normals the 20-nearest-neighbour normals first
+        for tag, pc in (("source", source), ("target", target)):
+            if pc.has_covariances():
+                gicp_cov[tag] = pc.cov6
+            else:
+                nrm = pc.normals if pc.has_normals() else _icp.normals_knn(pc.xyz32, knn=20, device=getattr(pc, "device_index", 0))
+                gicp_cov[tag] = _icp.cov_from_normals(nrm, 1e-3, device=getattr(pc, "device_index", 0))
     dev = device if device is not None else getattr(target, "device_index", 0)
     loss = estimation_method.loss or RobustLoss(_icp.LOSS_L2)
     own = ctx is None            # a caller-provided context keeps its workspace across calls (no allocation in steady state)
@@ -146,15 +155,19 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
                        max_correspondence_distance)
         ctx.set_source(source.xyz32)
         if estimation_method.kind == _icp.KIND_GENERALIZED:
-            ctx.set_target_cov(target.cov6)
-            ctx.set_source_cov(source.cov6)
+            ctx.set_target_cov(gicp_cov["target"])
+            ctx.set_source_cov(gicp_cov["source"])
         if estimation_method.kind == _icp.KIND_COLORED:
             ctx.set_target_color(target.colors)
             ctx.set_source_color(source.colors)
         # always (re)install the callbacks: a reused context must not keep a stale one from an earlier sharded call
-        if allreduce_device is not None:
+        if comm is not None:
+            ctx.set_comm(comm, n_source_global)
+        elif allreduce_device is not None:
+            ctx.set_comm(None, 0)
             ctx.set_allreduce_device(allreduce_device, n_source_global)
         else:
+            ctx.set_comm(None, 0)
             ctx.set_allreduce_device(None, 0)
             ctx.set_allreduce(allreduce, n_source_global if allreduce is not None else 0)
         r = ctx.register(np.asarray(init, dtype=np.float64), estimation_method.kind, loss.code, loss.k,

@@ -8,9 +8,11 @@ generator (``torch.randint`` in the reference's order, so a seeded run draws the
 rejection between them, the candidate's normal and offset (float32 torch ops, bit for bit the reference's).  The samples
 of all iterations are drawn first -- sampling never looks at the scores -- then scored together.
 
-One deliberate deviation: after a plane's inliers are removed the reference filters ``points_tensor`` but keeps indexing
-the UNFILTERED normals with the filtered indices (``:15,23-27,57``), so from the second plane on it tests the normals of
-the wrong points.  Here the normals are filtered with the points (the intended behaviour); the first plane is identical.
+After a plane's inliers are removed the reference filters ``points_tensor`` but keeps indexing the UNFILTERED normals with the
+filtered indices (``:15,23-27,57``), so from the second plane on it tests the normals of the wrong points.
+``fit_planes(..., reference_compat=True)`` reproduces exactly that (point k of the filtered set is tested against normal k of the
+ORIGINAL cloud; golden vectors from the reference's own function: ``tests/golden/planes2.npz``); the default filters the
+normals with the points -- the intended behaviour.  The first plane is identical either way.
 """
 from __future__ import annotations
 
@@ -89,10 +91,11 @@ def _fit_single_plane(points_tensor, normal_tensors, iterations, distance_thresh
     return planes[best.value], mask_t.nonzero(as_tuple=True)[0].cpu().numpy()
 
 
-def fit_planes(point_cloud, plane_count, iterations, threshold, normal_threshold, min_sample_distance, device=None):
+def fit_planes(point_cloud, plane_count, iterations, threshold, normal_threshold, min_sample_distance, device=None, reference_compat=False):
     """``fit_planes`` (``:6-35``): up to ``plane_count`` planes, each the RANSAC winner over the points the earlier planes
     left; returns (list of plane coefficient arrays [a, b, c, d], list of ORIGINAL index tensors of their inliers).
-    ``point_cloud`` needs ``points`` and ``normals`` (the ``PointCloud`` record or an Open3D cloud)."""
+    ``point_cloud`` needs ``points`` and ``normals`` (the ``PointCloud`` record or an Open3D cloud).
+    ``reference_compat``: index the unfiltered normals with the filtered indices from the second plane on, as the reference does."""
     points_tensor = torch.from_numpy(np.array(point_cloud.points, dtype=np.float32))
     nrm = point_cloud.normals
     nrm = nrm.detach().cpu().numpy() if isinstance(nrm, torch.Tensor) else np.asarray(nrm)
@@ -101,8 +104,10 @@ def fit_planes(point_cloud, plane_count, iterations, threshold, normal_threshold
     original_indices = torch.arange(points_tensor.shape[0])
     plane_coefficients, inlier_indices_list = [], []
     pd = nd = None
+    normal_all = normal_tensor                          # reference_compat: the normals are never filtered
     if torch.cuda.is_available():                       # keep the (shrinking) point set resident between planes
         pd, nd = points_tensor.to(f"cuda:{dev}").contiguous(), normal_tensor.to(f"cuda:{dev}").contiguous()
+    nd_all = nd
     for _ in range(plane_count):
         best_plane, best_inliers = _fit_single_plane(points_tensor, normal_tensor, iterations, threshold, normal_threshold,
                                                      min_sample_distance, dev, pd, nd)
@@ -112,11 +117,14 @@ def fit_planes(point_cloud, plane_count, iterations, threshold, normal_threshold
             mask = torch.ones(points_tensor.shape[0], dtype=torch.bool)
             mask[best_inliers] = False
             points_tensor = points_tensor[mask]
-            normal_tensor = normal_tensor[mask]          # the reference forgets this one (see the module docstring)
+            # the reference forgets to filter the normals (see the module docstring): point k of the filtered set then meets
+            # normal k of the original cloud
+            normal_tensor = normal_all[: points_tensor.shape[0]] if reference_compat else normal_tensor[mask]
             original_indices = original_indices[mask]
             if pd is not None:
                 md = mask.to(pd.device)
-                pd, nd = pd[md].contiguous(), nd[md].contiguous()
+                pd = pd[md].contiguous()
+                nd = nd_all[: pd.shape[0]].contiguous() if reference_compat else nd[md].contiguous()
         else:
             break
         if points_tensor.shape[0] == 0:

@@ -273,6 +273,15 @@ int32_t gsr_icp_get_centre(gsr_icp_ctx* ctx, double* centre3);
  * xyz[n*3] float32, normals[n*3] float64 (host or device as on_device says), knn in [1, 30]. */
 int32_t gsr_normals_knn(const float* xyz, int64_t n, int32_t knn, double* normals, int32_t on_device, int32_t device, void* stream);
 
+/* Covariances for generalized ICP on a cloud that carries none: Open3D's InitializePointCloudForGeneralizedICP
+ * (GeneralizedICP.cpp) -- C_i = Rx diag(epsilon, 1, 1) Rx^T, Rx = the rotation taking e1 to the point's normal.  The reference
+ * reaches it through registration_generalized_icp on its SPARSE input clouds (local_registration_util.py:96-98 called from
+ * qt_multiscale_registrator.py:82-85), which have KNN-30 normals (point_cloud_converter.py:26) and no covariances; a cloud
+ * without normals gets gsr_normals_knn(knn = 20) first, as Open3D does.  epsilon = 1e-3 is Open3D's default.
+ * normals[n*3] float64 in, cov6[n*6] float64 (xx, xy, xz, yy, yz, zz) out; host or device as on_device says. */
+int32_t gsr_cov_from_normals(const double* normals, int64_t n, double epsilon, double* cov6, int32_t on_device,
+                             int32_t device, void* stream);
+
 /* ------------------------------------------------------------------------------------ level export */
 
 /* Scaling / rotation of every component from its covariance, on the device: replaces

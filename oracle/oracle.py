@@ -358,3 +358,22 @@ def quaternions_reference(M):
         w = np.sqrt(np.float32(1) + (M[:, 0, 0] + M[:, 1, 1] + M[:, 2, 2])) / np.float32(2)
         d = np.float32(4) * w
         return np.stack([w, (M[:, 2, 1] - M[:, 1, 2]) / d, (M[:, 0, 2] - M[:, 2, 0]) / d, (M[:, 1, 0] - M[:, 0, 1]) / d], -1).astype(np.float32)
+
+
+def cov_from_normals(normals, epsilon=1e-3):
+    """Open3D GeneralizedICP.cpp, InitializePointCloudForGeneralizedICP + GetRotationFromE1ToX (numpy restatement;
+    parity unpinned like the rest of the ICP half): C_i = Rx diag(eps, 1, 1) Rx^T, (n,3,3) float64."""
+    nrm = np.asarray(normals, np.float64)
+    n = nrm.shape[0]
+    e1 = np.array([1.0, 0.0, 0.0])
+    v = np.cross(np.broadcast_to(e1, nrm.shape), nrm)
+    c = nrm @ e1
+    sv = np.zeros((n, 3, 3))
+    sv[:, 0, 1], sv[:, 0, 2] = -v[:, 2], v[:, 1]
+    sv[:, 1, 0], sv[:, 1, 2] = v[:, 2], -v[:, 0]
+    sv[:, 2, 0], sv[:, 2, 1] = -v[:, 1], v[:, 0]
+    with np.errstate(all="ignore"):
+        R = np.eye(3)[None] + sv + (sv @ sv) / (1.0 + c)[:, None, None]
+    R[c < -0.99] = np.eye(3)
+    C = np.diag([epsilon, 1.0, 1.0])
+    return R @ C @ R.transpose(0, 2, 1)

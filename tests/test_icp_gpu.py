@@ -2,6 +2,7 @@
 Tolerance (BASELINE.json north_star): final transform within 1e-5 Frobenius."""
 import numpy as np
 import pytest
+import torch
 
 from conftest import load_golden
 
@@ -176,6 +177,7 @@ def test_generalized_icp_through_do_icp_registration(oracle):
     from gaussiansplattingregistration_amd.utils.local_registration_util import (KernelLossFunctionType, LocalRegistrationType,
                                                                                  do_icp_registration)
     from gaussiansplattingregistration_amd.utils.point_cloud_converter import convert_gs_to_open3d_pc
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
     src, tgt, T_gt = synth.make_pair(8000, seed=14, sh_degree=0)
     pcs = []
     for c in (src, tgt):
@@ -188,10 +190,23 @@ def test_generalized_icp_through_do_icp_registration(oracle):
     w = oracle.gicp(src["xyz"], _cov33(src["cov6"]), tgt["xyz"], _cov33(tgt["cov6"]), init, loss=2, k=0.4, max_corr=0.3, max_iter=20)
     assert np.linalg.norm(res.transformation - w["transformation"]) < TOL_T
     assert abs(res.fitness - w["fitness"]) < 1e-9
-    # covariances are mandatory for this estimator here
-    pcs[0].cov6 = None
-    with pytest.raises(RuntimeError, match="covariances"):
-        do_icp_registration(pcs[0], pcs[1], init, p)
+    # a cloud WITHOUT covariances (the reference's sparse input clouds reach this estimator through
+    # qt_multiscale_registrator.py:82-85): Open3D's InitializePointCloudForGeneralizedICP gives it discs of thickness 1e-3
+    # perpendicular to its normals -- the normals it carries, or 20-nearest-neighbour normals when it has none
+    from gaussiansplattingregistration_amd import icp
+    nrm = oracle.normals_knn(src["xyz"].astype(np.float64), 30)
+    got = icp.cov_from_normals(nrm, 1e-3)
+    want = oracle.cov_from_normals(nrm, 1e-3)
+    assert np.abs(got - want[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]).max() < 1e-15
+    flip = np.array([[-1.0, 0.0, 0.0], [-0.995, 0.0998, 0.0], [1.0, 0.0, 0.0]])          # c < -0.99: the identity, as Open3D has it
+    assert np.abs(icp.cov_from_normals(flip) - oracle.cov_from_normals(flip)[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]).max() < 1e-15
+    for variant in ("normals", "bare"):
+        a = PointCloud(xyz32=src["xyz"], normals=nrm if variant == "normals" else None)       # no covariances
+        res = do_icp_registration(a, pcs[1], init, p)
+        n_used = nrm if variant == "normals" else oracle.normals_knn(src["xyz"].astype(np.float64), 20)
+        w = oracle.gicp(src["xyz"], oracle.cov_from_normals(n_used, 1e-3), tgt["xyz"], _cov33(tgt["cov6"]), init, loss=2, k=0.4, max_corr=0.3, max_iter=20)
+        assert np.linalg.norm(res.transformation - w["transformation"]) < TOL_T, variant
+        assert abs(res.fitness - w["fitness"]) < 1e-9 and res.iterations == w["iterations"]
 
 
 def _colored_pair(n, seed, oracle):
@@ -266,7 +281,8 @@ def test_icp_knobs_change_nothing(monkeypatch):
     against the split one (GSR_ICP_NN_KERNEL), the host-driven loop against the device-resident one (GSR_ICP_DEVICE_LOOP),
     other grid resolutions (GSR_ICP_CELL_TARGET, GSR_ICP_MAX_CELLS), the ring loop from ring 0 against the 27-cell block of
     batched loads the coarse levels start with (GSR_ICP_BLOCK_SEARCH; max_corr = 0.3 spans several cells here, and the
-    split-kernel case runs it in k_icp_nn too)."""
+    split-kernel case runs it in k_icp_nn too), k_icp_step as its own launch against the accumulate kernel's last workgroup doing
+    its work (GSR_ICP_FUSED_STEP: one launch per iteration instead of two)."""
     from gaussiansplattingregistration_amd import icp, synth
     src, tgt, _ = synth.make_pair(50000, seed=13, sh_degree=0)
     C = tgt["cov6"]
@@ -286,7 +302,7 @@ def test_icp_knobs_change_nothing(monkeypatch):
     ref = run()
     for env in ({"GSR_ICP_NN_KERNEL": "0"}, {"GSR_ICP_NN_KERNEL": "2"}, {"GSR_ICP_DEVICE_LOOP": "0"}, {"GSR_ICP_CELL_TARGET": "0.5"},
                 {"GSR_ICP_CELL_TARGET": "16"}, {"GSR_ICP_MAX_CELLS": "4096"}, {"GSR_ICP_BLOCK_SEARCH": "0"},
-                {"GSR_ICP_BLOCK_SEARCH": "0", "GSR_ICP_NN_KERNEL": "2"}):
+                {"GSR_ICP_BLOCK_SEARCH": "0", "GSR_ICP_NN_KERNEL": "2"}, {"GSR_ICP_FUSED_STEP": "1"}, {"GSR_ICP_FUSED_STEP": "1", "GSR_ICP_NN_KERNEL": "2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()
@@ -295,3 +311,37 @@ def test_icp_knobs_change_nothing(monkeypatch):
         for a, b in zip(ref[:2], got[:2]):
             assert np.abs(a[0] - b[0]).max() < 1e-12 and a[3] == b[3] and abs(a[1] - b[1]) < 1e-15 and abs(a[2] - b[2]) < 1e-12, env
         assert np.array_equal(ref[2][0], got[2][0]) and np.array_equal(ref[2][1], got[2][1]), env
+
+
+def test_library_communicator_world1_rccl_and_side_stream():
+    """The communicator of csrc/comm.hip on the box's one GPU: ncclCommInitRank with one rank (librccl opened lazily by the
+    library), an all-reduce and an all-gather through it, and a registration whose per-iteration all-reduce the library
+    enqueues itself (gsr_icp_set_comm): bit-identical to the plain registration.  The registration runs under a NON-default
+    torch stream: the context's stream is that stream, and every launch and the collective are ordered on it."""
+    from gaussiansplattingregistration_amd import icp, synth
+    from gaussiansplattingregistration_amd.comm import Comm
+    src, tgt, _ = synth.make_pair(40000, seed=17, sh_degree=0)
+    nrm = icp.normals_from_cov(tgt["cov6"])
+    with Comm.rccl(Comm.unique_id(), 0, 1, 0) as cm:
+        assert cm.world == 1 and cm.transport == "rccl"
+        t = torch.arange(32, dtype=torch.float64, device="cuda")
+        cm.all_reduce(t)
+        torch.cuda.synchronize()
+        assert torch.equal(t.cpu(), torch.arange(32, dtype=torch.float64))
+        send = torch.arange(100, dtype=torch.uint8, device="cuda"); recv = torch.zeros(100, dtype=torch.uint8, device="cuda")
+        cm.all_gather_bytes(send, recv)
+        torch.cuda.synchronize()
+        assert torch.equal(send, recv)
+        side = torch.cuda.Stream()
+        out = {}
+        for tag in ("plain", "comm"):
+            with torch.cuda.stream(side):
+                with icp.IcpContext() as c:
+                    c.set_target(tgt["xyz"], nrm, 0.3)
+                    c.set_source(src["xyz"])
+                    if tag == "comm":
+                        c.set_comm(cm, src["xyz"].shape[0])
+                    out[tag] = c.register(np.eye(4), kind=1, max_iter=25)
+        a, b = out["plain"], out["comm"]
+        assert np.array_equal(a["transformation"], b["transformation"]) and a["iterations"] == b["iterations"] > 3
+        assert a["fitness"] == b["fitness"] and a["inlier_rmse"] == b["inlier_rmse"]

@@ -2,8 +2,12 @@
 
 fit_planes against golden vectors produced by the REFERENCE's own fit_planes (tests/golden/planes.npz,
 make_golden_planes.py) under the same torch seed: the candidates are drawn on the host with the reference's torch calls, so
-the winning plane must be the same plane; its inlier set may differ by points whose float32 distance sits within rounding
-of the threshold (the reference's distances come out of a host BLAS gemm), bounded here at 0.1 % of the set."""
+the winning plane must be the same plane, and so must its inlier set.  The reference's distances come out of torch.mm on the
+CPU (MKL sgemv); the scoring kernel rounds its three-term dot products the way MKL's main loop does --
+fl(z n2) + fma(y, n1, fl(x n0)), measured in the build container to reproduce torch.mm bit for bit except on the rows in the tail
+of each OpenMP thread's share (about 1e-4 of the rows with 8 threads; which rows depends on the machine's thread count, so no
+device code can follow it).  A tail row flips only if its distance also sits within an ulp of the threshold: the fixtures'
+inlier sets come out identical."""
 import os
 
 import numpy as np
@@ -28,9 +32,28 @@ def test_fit_planes_against_reference_vectors(case):
     torch.manual_seed(int(seed))
     planes, inliers = fit_planes(_PC(g[f"points_{case}"], g[f"normals_{case}"]), 1, int(iters), float(thr), float(nthr), float(msd))
     assert len(planes) == 1 and np.array_equal(planes[0], g[f"plane_{case}"])          # the same candidate wins, bit for bit
-    got, want = set(inliers[0].tolist()), set(g[f"inliers_{case}"].tolist())
-    assert len(got ^ want) <= max(1, len(want) // 1000), (len(got), len(want), len(got ^ want))
+    assert np.array_equal(inliers[0].numpy(), g[f"inliers_{case}"]), (len(inliers[0]), len(g[f"inliers_{case}"]))
     assert inliers[0].dtype == torch.int64 and bool((inliers[0][1:] > inliers[0][:-1]).all())
+
+
+def test_fit_planes_reference_compat_several_planes():
+    """plane_count = 3 as the REFERENCE computes it (tests/golden/planes2.npz, its own fit_planes): from the second plane on it
+    tests the filtered points against the UNFILTERED normals (plane_fitting_util.py:15,23-27,57), which leaves planes two and
+    three with ~100 inliers each.  reference_compat=True reproduces it: same planes bit for bit, same inlier index sets.  The
+    default (normals filtered with the points) finds the planes the scene really has."""
+    from gaussiansplattingregistration_amd.utils.plane_fitting_util import fit_planes
+    g = np.load(os.path.join(GOLDEN, "planes2.npz"))
+    count, iters, thr, nthr, msd, seed = g["params"]
+    torch.manual_seed(int(seed))
+    planes, inliers = fit_planes(_PC(g["points"], g["normals"]), int(count), int(iters), float(thr), float(nthr), float(msd), reference_compat=True)
+    assert len(planes) == int(g["n_planes"]) == 3
+    for k in range(3):
+        assert np.array_equal(planes[k], g[f"plane_{k}"]), k
+        assert np.array_equal(inliers[k].numpy(), g[f"inliers_{k}"]), (k, len(inliers[k]), len(g[f"inliers_{k}"]))
+    torch.manual_seed(int(seed))
+    planes2, inliers2 = fit_planes(_PC(g["points"], g["normals"]), int(count), int(iters), float(thr), float(nthr), float(msd))
+    assert np.array_equal(planes2[0], planes[0]) and np.array_equal(inliers2[0].numpy(), inliers[0].numpy())     # the first plane: identical
+    assert len(inliers2[1]) > 10 * len(inliers[1])                                                                # then the intended behaviour
 
 
 def test_fit_planes_several_planes_and_exhaustion():

@@ -110,3 +110,37 @@ def test_transform_and_merge_models():
     # identity: no copy, plain concatenation
     m2 = GaussianModel.get_merged_gaussian_point_clouds(ga, gb, np.eye(4))
     assert torch.equal(m2.get_xyz[:300], ga.get_xyz)
+
+
+def test_gaussian_ply_bytes_follow_the_reference_writer(tmp_path):
+    """N3 without `plyfile` (absent in the image, so no reference-produced file can be generated here): the bytes
+    `save_gaussian_ply` writes against a HAND-WRITTEN expectation derived from the reference's writer --
+    `construct_list_of_attributes` (`gaussian_model.py:155-167`: x y z nx ny nz, f_dc_0..2, f_rest_0..3K-1, opacity, scale_0..2,
+    rot_0..3) in `save_ply`'s column order (`:169-185`: normals zero, `_features_rest` transposed to channel-major before it
+    is flattened), every attribute 'f4', and the header text plyfile's `PlyData([el]).write` emits for a binary little-endian
+    file.  Two splats, SH degree 1 (K = 3 rest coefficients per channel)."""
+    import struct
+    from gaussiansplattingregistration_amd.utils import ply_io
+    xyz = np.float32([[1, 2, 3], [4, 5, 6]])
+    dc = np.float32([[0.1, 0.2, 0.3], [0.4, 0.5, 0.6]])
+    # SH rest as the model holds it: (N, K, 3) coefficient-major, channel-minor  ->  flattened (N, 3K) for the C ABI
+    rest = np.arange(2 * 3 * 3, dtype=np.float32).reshape(2, 3, 3) + 10                        # rest[n, k, c]
+    op = np.float32([0.7, -0.8])
+    scale = np.float32([[-1, -2, -3], [-4, -5, -6]])
+    rot = np.float32([[1, 0, 0, 0], [0.5, 0.5, 0.5, 0.5]])
+    path = tmp_path / "two.ply"
+    ply_io.save_gaussian_ply(path, xyz, dc, rest.reshape(2, 9), op, scale, rot)
+    names = (["x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"] + [f"f_rest_{i}" for i in range(9)] + ["opacity", "scale_0", "scale_1", "scale_2",
+             "rot_0", "rot_1", "rot_2", "rot_3"])
+    header = "ply\nformat binary_little_endian 1.0\nelement vertex 2\n" + "".join(f"property float {n}\n" for n in names) + "end_header\n"
+    rows = b""
+    for n in range(2):
+        vals = list(xyz[n]) + [0.0, 0.0, 0.0] + list(dc[n])
+        vals += [rest[n, k, c] for c in range(3) for k in range(3)]                            # channel-major on disk (transpose(1, 2).flatten)
+        vals += [op[n]] + list(scale[n]) + list(rot[n])
+        rows += struct.pack("<%df" % len(vals), *[float(v) for v in vals])
+    assert open(path, "rb").read() == header.encode("ascii") + rows
+    # and the reader inverts it, f_rest back to coefficient-major (gaussian_model.py:112-120)
+    back = ply_io.load_gaussian_arrays(path)
+    assert back["sh_degree"] == 1 and np.array_equal(back["sh"], rest.reshape(2, 9)) and np.array_equal(back["color"], dc)
+    assert np.array_equal(back["xyz"], xyz) and np.array_equal(back["opacity"], op) and np.array_equal(back["rot"], rot)
