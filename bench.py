@@ -44,6 +44,7 @@ HEM_PARAMS = dict(hem_reduction=3.0, distance_delta=3.0, color_delta=2.5, decay_
 LEVELS = 3
 ITER_VALUES = [50, 30, 20, 10]
 MAX_CORR = [0.5, 0.3, 0.2, 0.1]
+PAIR_ANGLE_DEG, PAIR_SHIFT_H = 5.0, 0.05      # rotation 5 degrees about (1,1,1)/sqrt(3), translation 0.05 h (1, -1, 0.5)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
 # measured on MI355X (profiles/r02_valu_issue_microbench.txt): cycles a SIMD needs per wave64 VALU instruction with >= 2 waves resident
 VALU_CYCLES = {"full_rate (v_fma/mul/add/and/or with VGPR or constant operands)": 2.2,
@@ -312,6 +313,10 @@ def main():
     ap.add_argument("--target-splats", type=int, default=5_000_000, help="c5: splats of the target cloud")
     ap.add_argument("--mode", choices=["replicas", "c4", "c5"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["iso", "aniso"], default="iso",
+                    help="splat shapes of the pair: SURVEY 8(d)'s isotropic recipe, or the surfel recipe (synth.make_cloud(shape='aniso'): 60 %% discs, "
+                         "15 %% needles, covariance condition numbers 1e2 .. 1e5 on a smooth orientation field)")
+    ap.add_argument("--no-aniso", action="store_true", help="skip the anisotropic side measurement of the default run")
     a = ap.parse_args()
 
     import torch
@@ -348,7 +353,7 @@ def main():
     seed = 100 + (rank if a.mode == "replicas" else 0)     # c4 / c5: every rank holds the same data (replicated inputs)
     if a.mode == "c5":
         big = synth.make_cloud_torch(n, seed=seed, device=dev)
-        T_gt = synth.rigid_transform(1.0, (1, 1, 1), 0.004 * big["h"] * np.array([1.0, -1.0, 0.5]))
+        T_gt = synth.rigid_transform(PAIR_ANGLE_DEG, (1, 1, 1), PAIR_SHIFT_H * big["h"] * np.array([1.0, -1.0, 0.5]))
         # the target: the first --target-splats of the large cloud, moved (a sub-sample of the same scene)
         nt = min(a.target_splats, n)
         sub = {k: (v[:nt].contiguous() if isinstance(v, torch.Tensor) else v) for k, v in big.items()}
@@ -356,8 +361,8 @@ def main():
         tgt = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in tgt.items()}
         src = big
     else:
-        tgt = synth.make_cloud_torch(n, seed=seed, device=dev)
-        T_gt = synth.rigid_transform(1.0, (1, 1, 1), 0.004 * tgt["h"] * np.array([1.0, -1.0, 0.5]))
+        tgt = synth.make_cloud_torch(n, seed=seed, device=dev, shape=a.workload)
+        T_gt = synth.rigid_transform(PAIR_ANGLE_DEG, (1, 1, 1), PAIR_SHIFT_H * tgt["h"] * np.array([1.0, -1.0, 0.5]))
         src = synth.apply_rigid_torch(tgt, np.linalg.inv(T_gt))
         gen = torch.Generator(device=dev).manual_seed(7 + (rank if a.mode == "replicas" else 0))
         src["xyz"] = src["xyz"] + torch.randn(src["xyz"].shape, device=dev, generator=gen) * 0.002
@@ -415,33 +420,47 @@ def main():
         last = runs[-1]
         kern = [k for r in runs for k in r["kern"]]
         phases = {p: sum(k[p] for k in kern) / a.steps for p in ("ms_grid", "ms_select", "ms_sumlw", "ms_mstep", "ms_flags", "ms_level",
-                                                                  "ms_k_select_count", "ms_k_select_fill")}
-        # dominant kernel: k_select<SPARSE> (selection + likelihood), timed by hipEvent pairs on the library's stream around
-        # every launch (gsr_hem_get_phase_ms[7]).  Algorithmic bytes of a launch = SURVEY 8(d)'s bytes_level of ITS level.
-        sel_ms = np.array([k["ms_k_select_fill"] for k in kern])
+                                                                  "ms_k_select_count", "ms_k_select_fill", "ms_k_select", "ms_k_mstep", "ms_k_partition", "ms_k_bucket_sum")}
+        # the two big kernels, each timed by hipEvent pairs on the library's stream around every launch (gsr_hem_get_kernel_ms):
+        # k_select (child selection + likelihood) and k_mstep (moment matching).  The roofline object prices the one with the larger
+        # total time.  Algorithmic bytes of a launch = SURVEY 8(d)'s bytes_level of ITS level.
         lvl_b = np.array([bytes_level(k["n_in"], k["n_out"], F) for k in kern], dtype=np.float64)
         n_in = np.array([k["n_in"] for k in kern], dtype=np.float64)
+        per_kernel = {}
+        for kname, key in (("k_select", "ms_k_select"), ("k_mstep", "ms_k_mstep")):
+            ms = np.array([k[key] for k in kern])
+            per_kernel[kname] = {"total_ms_per_step": float(ms.sum() / a.steps), "avg_launch_ms": float(ms.mean()) if len(ms) else 0.0,
+                                 "achieved_GBps": float(lvl_b.mean() / (ms.mean() * 1e-3) / 1e9) if len(ms) and ms.mean() > 0 else 0.0}
+        dom = max(per_kernel, key=lambda k: per_kernel[k]["total_ms_per_step"])
+        dom_key = {"k_select": "ms_k_select", "k_mstep": "ms_k_mstep"}[dom]
+        sel_ms = np.array([k[dom_key] for k in kern])
         avg_ms = float(sel_ms.mean()) if len(sel_ms) else 0.0
         achieved = float(lvl_b.mean() / (avg_ms * 1e-3) / 1e9) if avg_ms > 0 else 0.0
         big_n = max(k["n_in"] for k in kern) if kern else n
         lvl1 = [k for k in kern if k["n_in"] == big_n]
         l1_bytes = float(np.mean([bytes_level(k["n_in"], k["n_out"], F) for k in lvl1])) if lvl1 else 0.0
         l1_ms = float(np.mean([k["ms_level"] for k in lvl1])) if lvl1 else 0.0
-        l1_sel = float(np.mean([k["ms_k_select_fill"] for k in lvl1])) if lvl1 else 0.0
-        pmc, pmc_note = pmc_summary("gsr::k_select<2, 2, false>")
-        roof = {"bound": "hbm", "kernel": "k_select<SPARSE> (child selection + likelihood, one wavefront per parent)",
+        l1_sel = float(np.mean([k["ms_k_select"] for k in lvl1])) if lvl1 else 0.0
+        l1_mst = float(np.mean([k["ms_k_mstep"] for k in lvl1])) if lvl1 else 0.0
+        desc = {"k_select": "k_select<SPARSE> (child selection + likelihood, one wavefront per parent)",
+                "k_mstep": "k_mstep (responsibilities + moment matching: one 64-byte record and one 192-byte SH row gathered per pair)"}
+        pmc, pmc_note = pmc_summary({"k_select": "gsr::k_select<2, 2, false>", "k_mstep": "gsr::k_mstep<4, 1>"}[dom])
+        roof = {"bound": "hbm", "kernel": desc[dom],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "bytes_model": "SURVEY 8(d) bytes_level = n_in (57 + 4F + 16) + n_out (57 + 4F) of the launch's level, / launch duration",
                 "avg_launch_ms": avg_ms, "launches": int(len(sel_ms)), "avg_units_per_launch": float(n_in.mean()) if len(n_in) else 0.0,
                 "avg_algorithmic_bytes_per_launch": float(lvl_b.mean()) if len(lvl_b) else 0.0,
                 "traffic": None, "measured_copy_GBps": copy_gbs, "frac_of_measured_copy": (achieved / copy_gbs) if copy_gbs else None,
-                "level1": {"n_in": int(big_n), "algorithmic_bytes": l1_bytes, "ms_level": l1_ms, "ms_k_select": l1_sel,
+                "kernels": per_kernel,
+                "level1": {"n_in": int(big_n), "algorithmic_bytes": l1_bytes, "ms_level": l1_ms, "ms_k_select": l1_sel, "ms_k_mstep": l1_mst,
                            "level_GBps": l1_bytes / (l1_ms * 1e-3) / 1e9 if l1_ms else None,
                            "level_frac": l1_bytes / (l1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS if l1_ms else None,
                            "k_select_GBps": l1_bytes / (l1_sel * 1e-3) / 1e9 if l1_sel else None,
-                           "k_select_frac": l1_bytes / (l1_sel * 1e-3) / 1e9 / HBM_PEAK_GBS if l1_sel else None},
-                "why_not_hbm_bound": "the level evaluates ~240 candidate tests and ~80 KL divergences per input splat (neighbour work the 8(d) "
-                                     "byte model does not count): k_select is bound by VALU issue and L2 request rate, see valu / DESIGN.md 4"}
+                           "k_select_frac": l1_bytes / (l1_sel * 1e-3) / 1e9 / HBM_PEAK_GBS if l1_sel else None,
+                           "k_mstep_frac": l1_bytes / (l1_mst * 1e-3) / 1e9 / HBM_PEAK_GBS if l1_mst else None},
+                "why_not_hbm_bound": "the level evaluates ~170 candidate tests and ~50 KL divergences per input splat and gathers 256 bytes per accepted pair "
+                                     "(22 pairs per splat) -- neighbour work the 8(d) byte model does not count: k_select is bound by VALU issue and L2 request rate, "
+                                     "k_mstep by the L2 -> CU gather rate (28 GB per 5 M level), see DESIGN.md 4"}
         if pmc:
             roof["traffic"] = pmc.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) + pmc.get("hbm_write_bytes_per_launch", 0.0)
             roof["traffic_source"] = pmc["source"] + " (level-1 launch at 5 M; FETCH_SIZE x2 per MI355X_MICROARCH.md)"
@@ -474,19 +493,19 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if a.mode == "replicas" else "strong", "vs_baseline": None,
             "dtype": "f32 (HEM) / f64 (ICP)", "data": "synthetic",
-            "config": {"workload": (f"2x{n} synthetic splats (SH deg 3) per GPU: 3 HEM levels per cloud + 4-level coarse-to-fine point-to-plane ICP "
-                                    "(BASELINE configs[2])") if a.mode == "replicas" else
+            "config": {"workload": (f"2x{n} synthetic splats (SH deg 3{', surfel shapes' if a.workload == 'aniso' else ''}) per GPU: 3 HEM levels per cloud + "
+                                    "4-level coarse-to-fine point-to-plane ICP (BASELINE configs[2])") if a.mode == "replicas" else
                                    (f"2x{n} splats, clouds one per GPU + ICP source split (BASELINE configs[3])" if a.mode == "c4" else
                                     f"one {n}-splat cloud vs a {min(a.target_splats, n)}-splat target, sharded HEM + split ICP (BASELINE configs[4])"),
-                       "mode": a.mode, "hem_params": HEM_PARAMS, "iter_values": ITER_VALUES, "max_corr": MAX_CORR, "level_sizes": last["level_sizes"],
+                       "mode": a.mode, "splat_shapes": a.workload, "pair": {"angle_deg": PAIR_ANGLE_DEG, "shift_h": PAIR_SHIFT_H}, "hem_params": HEM_PARAMS, "iter_values": ITER_VALUES, "max_corr": MAX_CORR, "level_sizes": last["level_sizes"],
                        "parallelism": par},
             "icp_iters_per_sec": icp_iters / icp_s,
             "icp_iterations_per_step": last["icp_iters"],
             "icp_per_level": [{"ns": l["ns"], "iterations": l["iterations"], "ms_per_iteration": l["ms_iters"] / max(1, l["evals"]),
                                "ms_target_index_build": l["ms_build"]} for l in last["levels"]],
-            "icp_note": "the blended icp_iters_per_sec is dominated by the coarse levels (launch floor ~70 us per iteration); the finest level's "
-                        "rate is roofline.icp_finest.  The synthetic pair is an easy case (1 degree / 0.4 % misalignment): the loops stop well "
-                        "inside their iteration budgets",
+            "icp_note": "the pair is SURVEY 8(d)'s: 5 degrees about (1,1,1)/sqrt(3) and 0.05 h (1,-1,0.5) apart; the coarsest level uses its whole "
+                        "budget of 50 iterations.  The blended icp_iters_per_sec is dominated by the coarse levels (~45 us per iteration at 185 k points: "
+                        "a latency-bound grid walk per source point); the finest level's rate is roofline.icp_finest",
             "hem_s_per_step": hem_s / a.steps, "icp_s_per_step": icp_s / a.steps,
             "icp_result": {"fitness": last["fitness"], "inlier_rmse": last["rmse"], "T_err_vs_ground_truth_F": float(np.linalg.norm(last["T"] - T_gt))},
             "hem_phase_ms_per_step": phases,
@@ -494,6 +513,32 @@ def main():
         }
         if "exchange_s" in last:
             line["exchange_s_per_step"] = sum(r["exchange_s"] for r in runs) / a.steps
+        if world == 1 and a.mode == "replicas" and a.workload == "iso" and not a.no_aniso:
+            # the same level on the surfel workload (real 3DGS splats are flat discs and needles, far outside the condition numbers of the
+            # isotropic recipe): one 5 M-splat cloud, level 1, beside the isotropic level above
+            try:
+                ca = synth.make_cloud_torch(n, seed=300, device=dev, shape="aniso")
+                m = ctxs["hem"]
+                rows = []
+                for _ in range(3):
+                    m.set_rng("glibc", 1, 0)
+                    m.set_level0(ca["xyz"], ca["color"], ca["opacity"], ca["cov6"], ca["sh"], borrow=True)
+                    m.run_level()
+                    rows.append(m.stats())
+                st = rows[-1]
+                ms = float(np.median([r["ms_level"] for r in rows]))
+                c6 = ca["cov6"][:200000].double().cpu().numpy()
+                ev = np.linalg.eigvalsh(np.stack([c6[:, [0, 1, 2]], c6[:, [1, 3, 4]], c6[:, [2, 4, 5]]], 1))
+                line["aniso_level"] = {"workload": f"one {n}-splat cloud, synth shape 'aniso' (60 % discs, 15 % needles on a smooth orientation field), level 1",
+                                       "condition_number_percentiles_50_90_99": [float(v) for v in np.percentile(ev[:, 2] / ev[:, 0], [50, 90, 99])],
+                                       "irregular_fraction": st["irregular"] / st["n_in"], "parents": st["parents"],
+                                       "candidates_per_parent": st["candidates"] / max(1, st["parents"]), "pairs": st["pairs"], "orphans": st["orphans"],
+                                       "n_out": st["n_out"], "ms_level": ms, "ms_k_select": st["ms_k_select"], "ms_k_mstep": st["ms_k_mstep"],
+                                       "gaussians_per_s": st["n_in"] / (ms * 1e-3),
+                                       "iso_level1_ms_same_n": l1_ms, "ratio_to_iso_level": ms / l1_ms if l1_ms else None}
+                del ca
+            except Exception as e:  # pragma: no cover
+                line["aniso_level"] = {"error": str(e)[:200]}
         if world == 1 and a.mode == "replicas" and not a.no_cpu_baseline:
             def gpu_level1_rate(nn):
                 c = synth.make_cloud(nn, seed=0)

@@ -2078,6 +2078,8 @@ struct gsr_hem_ctx {
     float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of k_select<COUNT> and k_select<FILL>
+    hipEvent_t evm[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // brackets of k_mstep, k_partition, k_bucket_sum
+    float kernel_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float cell_target = 16.0f;      // components per grid cell (GSR_HEM_CELL_TARGET; the result does not depend on it).  Swept at 5 M after the parents left
                                     // the candidate stream: 5 -> 13.15 ms per level, 8 -> 12.87, 12 -> 12.70, 16 -> 12.61, 24 -> 12.60, 32 -> 12.68 (fewer, longer rows)
     int max_cells = 1 << 24;
@@ -2270,6 +2272,10 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         hipError_t e = hipEventCreate(&c->evk[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
     }
+    for (int i = 0; i < 6; ++i) {
+        hipError_t e = hipEventCreate(&c->evm[i]);
+        if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate: %s", hipGetErrorString(e)); }
+    }
     {
         hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
@@ -2318,6 +2324,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
+    for (int i = 0; i < 6; ++i) if (c->evm[i]) (void)hipEventDestroy(c->evm[i]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_sh_fork) (void)hipEventDestroy(c->ev_sh_fork);
@@ -2447,6 +2454,11 @@ int32_t gsr_hem_get_stats(gsr_hem_ctx* c, int64_t* out8) {
 int32_t gsr_hem_get_stats_ex(gsr_hem_ctx* c, int64_t* out8) {
     if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_stats_ex: NULL argument");
     memcpy(out8, c->stats_ex, sizeof(c->stats_ex));
+    return GSR_OK;
+}
+int32_t gsr_hem_get_kernel_ms(gsr_hem_ctx* c, float* out8) {
+    if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_kernel_ms: NULL argument");
+    memcpy(out8, c->kernel_ms, sizeof(c->kernel_ms));
     return GSR_OK;
 }
 int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out8) {
@@ -2763,13 +2775,17 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
         GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
         (void)hipGetLastError();
+        GSR_HIP(hipEventRecord(c->evm[2], st));
         hipLaunchKernelGGL(k_partition, dim3(ceil_div(P, PART_PPW)), blk, (size_t)nbuckets * 4, st, P, seg, c->pcnt.as<unsigned>(), pc, pw,
                            nbuckets, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
         GSR_HIP(hipGetLastError());
+        GSR_HIP(hipEventRecord(c->evm[3], st));
         GSR_CHECKPOINT("pair partition (fixed capacity)");
+        GSR_HIP(hipEventRecord(c->evm[4], st));
         hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, (const unsigned long long*)nullptr, cap,
                            c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
                            c->geo.as<float>() + 15);
+        GSR_HIP(hipEventRecord(c->evm[5], st));
         GSR_HIP(hipGetLastError());
         fixed_tried = true;
         return GSR_OK;
@@ -2889,6 +2905,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         // were measured 1 / 10 / 24 % slower)
         const int nq = RSH >> 2;                                // float4 per SH row; a lane covers MSTEP_NV of them
 #define GSR_LAUNCH_MSTEP(G) hipLaunchKernelGGL((k_mstep<G, 1>), dim3(8 * ceil_div(ceil_div(P, MSTEP_K), 8)), dim3(64), 0, st, ma);
+        GSR_HIP(hipEventRecord(c->evm[0], st));
         if (nq == 0) { GSR_LAUNCH_MSTEP(0) }
         else if (nq <= 1 * MSTEP_NV) { GSR_LAUNCH_MSTEP(1) }
         else if (nq <= 2 * MSTEP_NV) { GSR_LAUNCH_MSTEP(2) }
@@ -2897,6 +2914,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         else if (nq <= 16 * MSTEP_NV) { GSR_LAUNCH_MSTEP(16) }
         else { GSR_LAUNCH_MSTEP(32) }      // F <= 384
 #undef GSR_LAUNCH_MSTEP
+        GSR_HIP(hipEventRecord(c->evm[1], st));
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
@@ -2984,6 +3002,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     c->phase_ms[6] = c->phase_ms[7] = 0.0f;
     if (P > 0 && !c->sparse_path) (void)hipEventElapsedTime(&c->phase_ms[6], c->evk[0], c->evk[1]);
     if (P > 0 && (M > 0 || c->sparse_path)) (void)hipEventElapsedTime(&c->phase_ms[7], c->evk[2], c->evk[3]);
+    memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
+    c->kernel_ms[0] = c->phase_ms[7];
+    if (P > 0) (void)hipEventElapsedTime(&c->kernel_ms[1], c->evm[0], c->evm[1]);
+    if (fixed_tried && !c->partition_overflowed) {
+        (void)hipEventElapsedTime(&c->kernel_ms[2], c->evm[2], c->evm[3]);
+        (void)hipEventElapsedTime(&c->kernel_ms[3], c->evm[4], c->evm[5]);
+    }
     if (n_out) *n_out = c->cur.n;
     if (n_dropped) *n_dropped = dropped;
     return GSR_OK;

@@ -169,6 +169,10 @@ int32_t gsr_hem_get_stats_ex(gsr_hem_ctx* ctx, int64_t* out8);
  * [6] the k_select<COUNT> launch alone (two-pass fallback only, else 0)
  * [7] the k_select<SPARSE> launch alone (or k_select<FILL> on the fallback) */
 int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* ctx, float* out8);
+/* Device time of single kernel launches of the most recent level (hipEvent pairs on the context's stream), milliseconds:
+ *  [0] k_select (the light parents' launch; the heavy work items run beside it)  [1] k_mstep  [2] k_partition  [3] k_bucket_sum
+ *  [4..7] reserved (0).  What bench.py prices against the roofline. */
+int32_t gsr_hem_get_kernel_ms(gsr_hem_ctx* ctx, float* out8);
 
 /* ------------------------------------------------------------------------------------------- ICP */
 
