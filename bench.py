@@ -101,9 +101,11 @@ def hem_levels(m, cloud, borrow=True):
     return lv, stats
 
 
-def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None):
+def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None, comm=None, src_global_sizes=None):
     """4-entry coarse-to-fine ICP over the level lists (qt_multiscale_registrator.py:197-236).  sharded = (rank, world)
-    splits every level's source over the ranks."""
+    splits every level's source over the ranks; src_global_sizes: the source levels ARE this rank's shards already (the pieces of
+    a spatially partitioned HEM) and these are their sizes over all ranks.  comm: the library's communicator (RCCL enqueued by
+    the library on the ICP context's stream); without it the torch.distributed trampoline of round 2."""
     from gaussiansplattingregistration_amd import parallel
     T = np.eye(4)
     est = lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Plane, lru.RobustLoss(0))
@@ -112,8 +114,10 @@ def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None):
         s, t = clouds_src[-(k + 1)], clouds_tgt[-(k + 1)]
         t.estimate_normals()
         crit = lru.get_convergence_criteria(1e-6, 1e-6, ITER_VALUES[k])
-        if sharded:
-            r = parallel.registration_icp_sharded(s, t, MAX_CORR[k], T, est, crit, sharded[0], sharded[1], device=device, ctx=ctx)
+        if src_global_sizes is not None:
+            r = lru.registration_icp(s, t, MAX_CORR[k], T, est, crit, device=device, ctx=ctx, comm=comm, n_source_global=src_global_sizes[-(k + 1)])
+        elif sharded:
+            r = parallel.registration_icp_sharded(s, t, MAX_CORR[k], T, est, crit, sharded[0], sharded[1], device=device, ctx=ctx, comm=comm)
         else:
             r = lru.registration_icp(s, t, MAX_CORR[k], T, est, crit, device=device, ctx=ctx)
         T = r.transformation
@@ -147,7 +151,7 @@ def step_replicas(ctxs, lru, src, tgt, device, sync):
     return out
 
 
-def step_c4(ctxs, lru, src, tgt, device, sync, rank, world):
+def step_c4(ctxs, lru, src, tgt, device, sync, rank, world, comm=None):
     """configs[3]: cloud A's HEM on rank 0, cloud B's on rank 1 (no collective), one exchange of the level lists, ICP with
     the source split over all ranks and the accumulator all-reduce."""
     import torch
@@ -196,33 +200,47 @@ def step_c4(ctxs, lru, src, tgt, device, sync, rank, world):
     t2 = time.perf_counter()
     out["exchange_s"] = t2 - t1
     out["level_sizes"] = [len(p) for p in lists[0]]
-    out.update(coarse_to_fine(lru, ctxs["icp"], lists[0], lists[1], device, sharded=(rank, world)))
+    out.update(coarse_to_fine(lru, ctxs["icp"], lists[0], lists[1], device, sharded=(rank, world), comm=comm))
     sync()
     out["icp_s"] = time.perf_counter() - t2
     return out
 
 
-def step_c5(lru, ctxs, big, tgt, device, sync, rank, world):
-    """configs[4]: one large source cloud against a smaller target: work-sharded HEM levels of both (every rank ends with the
-    complete level lists), ICP with the source split over all ranks."""
+def step_c5(lru, ctxs, big, tgt, device, sync, rank, world, comm=None, owned=None):
+    """configs[4]: one large source cloud against a smaller target.  The source's HEM levels are SPATIALLY PARTITIONED over the
+    ranks (every rank owns one slab, halo rows and integer partial sums through the library's communicator; the levels stay
+    distributed); the target's levels are computed by every rank (it is the replicated side of the ICP); the ICP takes every
+    rank's piece of a source level as its shard -- one all-reduce of 32 float64 per iteration."""
     from gaussiansplattingregistration_amd import hem, parallel
     from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
     out = {"hem_gaussians": 0, "kern": []}
     t0 = time.perf_counter()
-    lists = []
-    for c in (big, tgt):
-        if world > 1:
-            lv, st = parallel.hem_sharded(c, LEVELS, rank, world, device=device, as_torch=True, rng_mode="glibc", **HEM_PARAMS)
-        else:
-            lv, st = hem.create_mixture(c, LEVELS, device=device, as_torch=True, **HEM_PARAMS)
-        out["kern"] += st
-        out["hem_gaussians"] += sum(s["n_in"] for s in st)
-        lists.append([PointCloud(xyz32=c["xyz"], cov6=c["cov6"])] + [PointCloud(xyz32=l["xyz"], cov6=l["cov6"]) for l in lv])
+    if world > 1:
+        pieces, st = parallel.hem_partitioned(big, LEVELS, comm, device=device, as_torch=True, owned=owned, mixture=ctxs["hem"], rng_mode="glibc")
+        idx = owned if owned is not None else parallel.slab_of(big["xyz"], rank, world)
+        src_list = [PointCloud(xyz32=big["xyz"][idx].contiguous(), cov6=big["cov6"][idx].contiguous())] + [PointCloud(xyz32=p["xyz"], cov6=p["cov6"]) for p in pieces]
+        sizes = [int(big["xyz"].shape[0])] + [int(s["n_global"]) for s in st]
+        for s_ in st:
+            s_["n_in"] = s_["n_in"]                # (rank-local level input; the global sizes ride in n_global)
+        out["part"] = [{k: s_[k] for k in ("ghosts", "rows_sent", "halo_bytes_received", "sum_exchange_bytes_received", "n_global")} for s_ in st]
+    else:
+        lv, st = hem.create_mixture(big, LEVELS, device=device, as_torch=True, **HEM_PARAMS)
+        src_list = [PointCloud(xyz32=big["xyz"], cov6=big["cov6"])] + [PointCloud(xyz32=l["xyz"], cov6=l["cov6"]) for l in lv]
+        sizes = None
+    out["kern"] += st
+    out["hem_gaussians"] += sum(s["n_in"] for s in st)
+    ctxs["hem2"].set_rng("glibc", 1, 0)
+    tgt_list, stt = hem_levels(ctxs["hem2"], tgt)
+    out["kern"] += stt
+    # every rank computes the target's levels (the replicated side of the ICP): the job counts them once
+    out["hem_gaussians_target_replicated"] = sum(s["n_in"] for s in stt)
+    if rank == 0:
+        out["hem_gaussians"] += out["hem_gaussians_target_replicated"]
     sync()
     t1 = time.perf_counter()
     out["hem_s"] = t1 - t0
-    out["level_sizes"] = [len(p) for p in lists[0]]
-    out.update(coarse_to_fine(lru, ctxs["icp"], lists[0], lists[1], device, sharded=(rank, world) if world > 1 else None))
+    out["level_sizes"] = sizes if sizes is not None else [len(p) for p in src_list]
+    out.update(coarse_to_fine(lru, ctxs["icp"], src_list, tgt_list, device, comm=comm, src_global_sizes=sizes))
     sync()
     out["icp_s"] = time.perf_counter() - t1
     return out
@@ -370,12 +388,19 @@ def main():
     sync()
 
     ctxs = {"hem": hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS), "icp": icp_mod.IcpContext(device=device)}
+    # the data-path collectives of c4 / c5 go through the LIBRARY's communicator: RCCL (nccl backend) enqueued by the library on its
+    # own streams, or the callback transport (gloo: test boxes where the ranks share a GPU)
+    from gaussiansplattingregistration_amd.comm import Comm
+    comm = Comm.from_torch_group(device) if (world > 1 and a.mode in ("c4", "c5")) else None
+    if a.mode == "c5":
+        ctxs["hem2"] = hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS)       # the replicated target's levels
+    owned = parallel.slab_of(src["xyz"], rank, world) if (a.mode == "c5" and world > 1) else None
 
     def one_step():
         if a.mode == "c4":
-            return step_c4(ctxs, lru, src, tgt, device, sync, rank, world)
+            return step_c4(ctxs, lru, src, tgt, device, sync, rank, world, comm=comm)
         if a.mode == "c5":
-            return step_c5(lru, ctxs, src, tgt, device, sync, rank, world)
+            return step_c5(lru, ctxs, src, tgt, device, sync, rank, world, comm=comm, owned=owned)
         return step_replicas(ctxs, lru, src, tgt, device, sync)
 
     for _ in range(a.warmup):
@@ -394,8 +419,9 @@ def main():
         elapsed, hem_s, icp_s = (float(v) for v in t)
         tg = torch.tensor([float(hem_gauss)], dtype=torch.float64, device=rdev)
         torch.distributed.all_reduce(tg, op=torch.distributed.ReduceOp.SUM)
-        # replicas / c4: every rank's level inputs are different work; c5: the ranks share the SAME levels (count them once)
-        hem_gauss = float(tg) / (world if a.mode == "c5" else 1)
+        # every rank's level inputs are different work (c5: the slabs of the partitioned source; the replicated target levels are
+        # counted once, by rank 0)
+        hem_gauss = float(tg)
     icp_iters = sum(r["icp_iters"] for r in runs) * (world if a.mode == "replicas" else 1)
 
     # measured device-copy bandwidth of this very GPU (SURVEY 8d asks for the fraction of both the nominal and a measured
@@ -483,8 +509,9 @@ def main():
         gpu_icp_coarse = coarse["evals"] / (coarse["ms_iters"] * 1e-3) if coarse["ms_iters"] else None
         par = {"replicas": f"{world} independent pair(s), one per GPU, no data-path collective",
                "c4": f"cloud A HEM on rank 0, cloud B on rank 1, levels broadcast once, ICP source split over {world} ranks + all-reduce of 32 doubles per iteration",
-               "c5": f"work-sharded HEM levels over {world} rank(s) (all-reduce of per-child sums + one all-gather of merged components per level), "
-                     f"ICP source split over {world} rank(s)"}[a.mode]
+               "c5": f"source cloud spatially partitioned over {world} rank(s): halo rows + integer partial sums per HEM level through the library's "
+                     f"communicator ({comm.transport if comm else 'none'}), levels stay distributed; target levels replicated; ICP shard = the rank's piece, "
+                     "one all-reduce of 32 float64 per iteration"}[a.mode]
         line = {
             "metric": "Gaussians/sec through HEM level + ICP iters/sec, 2x5M-splat pair",
             "value": hem_gauss / hem_s,
@@ -513,6 +540,8 @@ def main():
         }
         if "exchange_s" in last:
             line["exchange_s_per_step"] = sum(r["exchange_s"] for r in runs) / a.steps
+        if "part" in last:
+            line["partition_rank0"] = last["part"]
         if world == 1 and a.mode == "replicas" and a.workload == "iso" and not a.no_aniso:
             # the same level on the surfel workload (real 3DGS splats are flat discs and needles, far outside the condition numbers of the
             # isotropic recipe): one 5 M-splat cloud, level 1, beside the isotropic level above

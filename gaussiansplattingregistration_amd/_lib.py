@@ -65,6 +65,10 @@ SIGNATURES = {
     "gsr_hem_set_shard": (_i32, [_vp, _i32, _i32, ALLREDUCE_DEV_FN, ALLGATHER_DEV_FN, _vp]),
     "gsr_hem_set_level0": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32]),
     "gsr_hem_set_state": (_i32, [_vp, _vp, _vp]),
+    "gsr_hem_set_comm": (_i32, [_vp, _vp]),
+    "gsr_hem_set_level0_part": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32]),
+    "gsr_hem_get_gids": (_i32, [_vp, _vp, _i32]),
+    "gsr_hem_get_part_stats": (_i32, [_vp, C.POINTER(_i64)]),
     "gsr_hem_run_level": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "gsr_hem_level_size": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32)]),
     "gsr_hem_get_level": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),

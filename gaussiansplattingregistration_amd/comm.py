@@ -104,11 +104,21 @@ class Comm:
                 name = _DT[int(dtype)]
                 size = 8 if name in ("float64", "uint64") else 4
                 raw = _view(ptr, int(count) * size, device)
-                # uint32 / uint64 sums and maxima are computed on the signed view of the same bits where torch lacks the
-                # unsigned type for gloo: sums wrap identically; the library only takes maxima of values below 2^31 / 2^63
+                # gloo has no unsigned types: sums are taken on the signed view of the same bits (they wrap identically); an unsigned
+                # 32-bit MAXIMUM is taken on zero-extended 64-bit values (the order-preserving codes of the bounding box have
+                # their top bit set); an unsigned 64-bit maximum is not needed by the library
                 tdt = {"float64": torch.float64, "float32": torch.float32, "int32": torch.int32, "uint32": torch.int32, "uint64": torch.int64}[name]
                 host = raw.view(tdt).cpu()
-                dist.all_reduce(host, op=dist.ReduceOp.SUM if int(op) == 0 else dist.ReduceOp.MAX, group=group)
+                if int(op) == 0:
+                    dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                elif name == "uint32":
+                    wide = host.to(torch.int64) & 0xFFFFFFFF
+                    dist.all_reduce(wide, op=dist.ReduceOp.MAX, group=group)
+                    host = wide.to(torch.int32)                                   # the low 32 bits back (the cast wraps)
+                elif name == "uint64":
+                    raise RuntimeError("unsigned 64-bit maximum is not supported by the callback transport")
+                else:
+                    dist.all_reduce(host, op=dist.ReduceOp.MAX, group=group)
                 raw.view(tdt).copy_(host)
                 torch.cuda.synchronize(device)
                 return 0

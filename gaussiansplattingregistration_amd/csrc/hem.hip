@@ -1934,6 +1934,286 @@ __global__ __launch_bounds__(256) void k_shard_rows(int lo, int cnt, int F, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Spatially partitioned levels (BASELINE config 5): ONE large cloud over several GPUs.
+//
+// Every rank OWNS a subset of the level's components (a spatial slab at level 0; the merged components of its parents and its
+// orphans afterwards) and carries their GLOBAL indices gid (= positions in the level's global order: parents by ascending index,
+// then orphans, mixture.cpp:169-253).  A level then runs on owned + GHOST components:
+//   grid      the ranks all-reduce the bounding box and the three axis histograms (integers: exact), so every rank derives the
+//             SAME grid as a single GPU would;
+//   ghosts    every rank marks, in a bit mask over the grid's cells, the cells the search spheres of its owned parents touch
+//             (k_mark_cells); the masks are all-gathered, and a rank sends each of its owned components to the ranks whose mask
+//             holds its cell (one personalised exchange of 64 + 4F + 8-byte rows).  A parent then finds, in every cell its
+//             rows scan, exactly the components a single GPU holds there, in the same order (cell sort stable over the gid
+//             order): same candidates, same survivors, same pairs in the same order -- long-range parents simply mark more cells;
+//   sums      a child's wL terms come from parents on several ranks.  The deterministic LDS fixed point of k_bucket_sum is split
+//             in three (k_part_max / k_part_acc / k_part_finish) with the ghosts' partial results sent to their owners in between:
+//             first the largest |wL| (it sets the child's scale: integer max), then the 64-bit fixed-point sums (integer adds),
+//             then the finished float32 sum back -- integers throughout, so the sum is BIT FOR BIT the single-GPU one;
+//   output    a parent's output row is its rank among ALL parents by global index: the ranks all-reduce a bit map of parent gids
+//             (and one of orphan gids; disjoint bits: an integer sum is an OR) and prefix-count it; the new flags are drawn from
+//             the libc stream at those global ranks.  No floating-point value is ever combined across ranks.
+// ------------------------------------------------------------------------------------------------
+#define PART_ROW_EXTRA 2      // a ghost row: 16 floats of the packed record, F SH floats, gid, index at its owner
+
+// bits of the cells the search sphere's box of every owned parent covers (the box of select_scan's rows: a superset of what the
+// parent scans).  16 lanes per parent; a word is tested before the atomic (neighbours mark the same cells).
+__global__ __launch_bounds__(256) void k_mark_cells(int64_t n_own, const float4* __restrict__ rec, const GridParams* __restrict__ gpp, float delta,
+                                                    unsigned* __restrict__ mask) {
+    const GridParams g = *gpp;
+    const int sub = threadIdx.x & 15;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_own; i += stride) {
+        const float4 a = rec[4 * i];
+        if (!(__float_as_uint(a.w) & 1u)) continue;
+        const float4 b = rec[4 * i + 1], cc = rec[4 * i + 2];
+        const s6 cov = {b.x, b.y, b.z, b.w, cc.x, cc.y};
+        const float R = delta * sqrtf(eig_max6(cov));
+        const bool finite = fabsf(a.x) <= FLT_MAX && fabsf(a.y) <= FLT_MAX && fabsf(a.z) <= FLT_MAX;
+        if (!(R * R > 0.0f) || !finite) continue;                       // no children at all (k_parent_prep: active = 0)
+        const float Ra = fabsf(R) * 1.00001f + g.slack;
+        const int x0 = cell_of(a.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(a.x + Ra, g.ox, g.inv_c, g.gx);
+        const int y0 = cell_of(a.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(a.y + Ra, g.oy, g.inv_c, g.gy);
+        const int z0 = cell_of(a.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(a.z + Ra, g.oz, g.inv_c, g.gz);
+        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+        for (int r = sub; r < nrows; r += 16) {
+            const int64_t c0 = ((int64_t)(z0 + r / ny) * g.gy + (y0 + r % ny)) * g.gx + x0, c1 = c0 + (x1 - x0);
+            for (int64_t w = c0 >> 5; w <= (c1 >> 5); ++w) {
+                const int lo = w == (c0 >> 5) ? (int)(c0 & 31) : 0, hi = w == (c1 >> 5) ? (int)(c1 & 31) : 31;
+                const unsigned bits = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                if ((mask[w] & bits) != bits) atomicOr(&mask[w], bits);
+            }
+        }
+    }
+}
+// dflag[q][i] = 1 when owned component i lies in a cell rank q marked (q != self)
+__global__ __launch_bounds__(256) void k_dest_flags(int64_t n_own, const float4* __restrict__ rec, const GridParams* __restrict__ gpp, int world, int self,
+                                                    int64_t mask_words, const unsigned* __restrict__ masks, int* __restrict__ dflag) {
+    const GridParams g = *gpp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += (int64_t)gridDim.x * blockDim.x) {
+        const float4 a = rec[4 * i];
+        const int64_t c = ((int64_t)cell_of(a.z, g.oz, g.inv_c, g.gz) * g.gy + cell_of(a.y, g.oy, g.inv_c, g.gy)) * g.gx + cell_of(a.x, g.ox, g.inv_c, g.gx);
+        for (int q = 0; q < world; ++q)
+            dflag[(int64_t)q * n_own + i] = q != self && ((masks[(int64_t)q * mask_words + (c >> 5)] >> (c & 31)) & 1u) ? 1 : 0;
+    }
+}
+// rows to send: for destination q the k-th flagged owned component (pos = exclusive scan of its flags)
+__global__ __launch_bounds__(256) void k_pack_rows(int64_t n_own, int F, const int* __restrict__ dflag, const int* __restrict__ dpos,
+                                                   const float4* __restrict__ rec, const float* __restrict__ sh, const unsigned* __restrict__ gid,
+                                                   float* __restrict__ rows, unsigned* __restrict__ sent_idx) {
+    const int RW = 16 + F + PART_ROW_EXTRA;
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_own; i += stride) {      // a wave per component
+        if (!dflag[i]) continue;
+        float* row = rows + (int64_t)dpos[i] * RW;
+        const float* r = reinterpret_cast<const float*>(rec + 4 * i);
+        for (int f = lane; f < 16 + F; f += 64) row[f] = f < 16 ? r[f] : sh[i * F + (f - 16)];
+        if (lane == 0) { row[16 + F] = __uint_as_float(gid[i]); row[16 + F + 1] = __uint_as_float((unsigned)i); sent_idx[dpos[i]] = (unsigned)i; }
+    }
+}
+// received rows -> the ghosts' records behind the owned ones, their SH rows, global indices and indices at their owners
+__global__ __launch_bounds__(256) void k_unpack_rows(int64_t n_ghost, int64_t n_own, int F, const float* __restrict__ rows, float4* __restrict__ rec_loc,
+                                                     float* __restrict__ ghost_sh, unsigned* __restrict__ gid_loc, unsigned* __restrict__ ghost_src) {
+    const int RW = 16 + F + PART_ROW_EXTRA;
+    const int lane = threadIdx.x & 63;
+    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < n_ghost; k += stride) {
+        const float* row = rows + k * RW;
+        float* r = reinterpret_cast<float*>(rec_loc + 4 * (n_own + k));
+        for (int f = lane; f < 16 + F; f += 64) { if (f < 16) r[f] = row[f]; else ghost_sh[k * F + (f - 16)] = row[f]; }
+        if (lane == 0) { gid_loc[n_own + k] = __float_as_uint(row[16 + F]); ghost_src[k] = __float_as_uint(row[16 + F + 1]); }
+    }
+}
+// cell keys of the local components in the order perm (ascending global index): the stable cell sort then keeps that order inside a cell
+__global__ __launch_bounds__(256) void k_keys_rec(int64_t n, const float4* __restrict__ rec, const unsigned* __restrict__ perm, const GridParams* __restrict__ gpp,
+                                                  unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
+    const GridParams g = *gpp;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned i = perm[k];
+        const float4 a = rec[4 * (int64_t)i];
+        keys[k] = (unsigned)((cell_of(a.z, g.oz, g.inv_c, g.gz) * g.gy + cell_of(a.y, g.oy, g.inv_c, g.gy)) * g.gx + cell_of(a.x, g.ox, g.inv_c, g.gx));
+        idx[k] = i;
+    }
+}
+__global__ __launch_bounds__(256) void k_iota(int64_t n, unsigned* __restrict__ p) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = (unsigned)i;
+}
+// pown[j] = the component at sorted position j is a parent this rank owns;  inv[local index] = sorted position
+__global__ __launch_bounds__(256) void k_own_flags(int64_t n, int64_t n_own, const unsigned* __restrict__ order, const int* __restrict__ pflag,
+                                                   int* __restrict__ pown, unsigned* __restrict__ inv) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned i = order[j];
+        pown[j] = pflag[j] && (int64_t)i < n_own ? 1 : 0;
+        inv[i] = (unsigned)j;
+    }
+}
+// shs rows from two sources: owned components from the level's SH array, ghosts from theirs
+__global__ __launch_bounds__(256) void k_gather_sh2(int64_t n, int64_t n_own, int F, int RSH, const unsigned* __restrict__ order,
+                                                    const float* __restrict__ sh_own, const float* __restrict__ sh_ghost, float* __restrict__ shs) {
+    const int Q = RSH >> 2;
+    const int64_t total = n * Q;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = t / Q;
+        const int q = (int)(t - j * Q);
+        const int64_t i = order[j];
+        const float* src = (i < n_own ? sh_own + i * F : sh_ghost + (i - n_own) * F) + 4 * q;
+        const int left = F - 4 * q;
+        float4 v;
+        v.x = left > 0 ? src[0] : 0.0f; v.y = left > 1 ? src[1] : 0.0f; v.z = left > 2 ? src[2] : 0.0f; v.w = left > 3 ? src[3] : 0.0f;
+        reinterpret_cast<float4*>(shs + j * RSH)[q] = v;
+    }
+}
+// k_bucket_sum in three steps with global per-child arrays (sorted positions): the largest |wL| ...
+__global__ __launch_bounds__(1024) void k_part_max(int64_t n, int shift, unsigned cap, const unsigned* __restrict__ cursor, const unsigned* __restrict__ child,
+                                                   const float* __restrict__ wl, unsigned* __restrict__ gmax) {
+    extern __shared__ unsigned s_m[];
+    const int bucket = 1 << shift;
+    const int b = blockIdx.x;
+    const int64_t c0 = (int64_t)b << shift;
+    const int nc = (int)(n - c0 < bucket ? n - c0 : bucket);
+    for (int i = threadIdx.x; i < bucket; i += blockDim.x) s_m[i] = 0u;
+    __syncthreads();
+    const unsigned cnt = cursor[b];
+    const unsigned long long k0 = (unsigned long long)b * cap, k1 = k0 + (cnt < cap ? cnt : cap);
+    for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) atomicMax(&s_m[child[k] - (unsigned)c0], __float_as_uint(wl[k]) & 0x7fffffffu);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) gmax[c0 + i] = s_m[i];
+}
+// ... the fixed-point sums on the scale of the (now global) maximum: 64-bit integers, or flag bits where a term is not finite ...
+__global__ __launch_bounds__(1024) void k_part_acc(int64_t n, int shift, unsigned cap, const unsigned* __restrict__ cursor, const unsigned* __restrict__ child,
+                                                   const float* __restrict__ wl, const unsigned* __restrict__ gmax, unsigned long long* __restrict__ gacc) {
+    extern __shared__ unsigned long long s_acc[];
+    const int bucket = 1 << shift;
+    unsigned* s_max = (unsigned*)(s_acc + bucket);
+    const int b = blockIdx.x;
+    const int64_t c0 = (int64_t)b << shift;
+    const int nc = (int)(n - c0 < bucket ? n - c0 : bucket);
+    for (int i = threadIdx.x; i < bucket; i += blockDim.x) { s_acc[i] = 0ull; s_max[i] = i < nc ? gmax[c0 + i] : 0u; }
+    __syncthreads();
+    const unsigned cnt = cursor[b];
+    const unsigned long long k0 = (unsigned long long)b * cap, k1 = k0 + (cnt < cap ? cnt : cap);
+    for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
+        const unsigned i = child[k] - (unsigned)c0;
+        const float w = wl[k];
+        const unsigned mb = s_max[i];
+        if (mb >= 0x7f800000u) {                   // a non-finite term somewhere: collect flags (1 +inf, 2 -inf, 4 NaN)
+            const unsigned wb = __float_as_uint(w);
+            const unsigned long long f = (wb & 0x7fffffffu) > 0x7f800000u ? 4ull : (wb == 0x7f800000u ? 1ull : (wb == 0xff800000u ? 2ull : 0ull));
+            if (f) atomicOr(&s_acc[i], f);
+            continue;
+        }
+        int e = (int)(mb >> 23);
+        e = e < 1 ? 1 : e;
+        const int k2 = 38 - (e - 127);
+        const double scale = __longlong_as_double((long long)(1023 + k2) << 52);
+        atomicAdd(&s_acc[i], (unsigned long long)__double2ll_rn((double)w * scale));
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nc; i += blockDim.x) gacc[c0 + i] = s_acc[i];
+}
+// ... and the float32 sum of the components this rank owns (the owners' totals go back to the ghosts afterwards)
+__global__ __launch_bounds__(256) void k_part_finish(int64_t n, const unsigned* __restrict__ gmax, const unsigned long long* __restrict__ gacc,
+                                                     float* __restrict__ sumLw) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned mb = gmax[j];
+        float sres;
+        if (mb >= 0x7f800000u) {
+            const unsigned long long f = gacc[j];
+            sres = (f & 4ull) || ((f & 1ull) && (f & 2ull)) ? __builtin_nanf("") : ((f & 1ull) ? __builtin_inff() : -__builtin_inff());
+        } else {
+            int e = (int)(mb >> 23);
+            e = e < 1 ? 1 : e;
+            const int k2 = 38 - (e - 127);
+            const double inv = __longlong_as_double((long long)(1023 - k2) << 52);
+            sres = (float)((double)(long long)gacc[j] * inv);
+        }
+        sumLw[j] = sres;
+    }
+}
+// sumLw into the geometry records; orphans are decided by a child's OWNER only
+__global__ __launch_bounds__(256) void k_part_orphans(int64_t n, int64_t n_own, const unsigned* __restrict__ order, const float* __restrict__ sumLw,
+                                                      int* __restrict__ orphan_flag, float* __restrict__ geo_sl) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const float s = sumLw[j];
+        geo_sl[16 * j] = s;
+        orphan_flag[j] = s == 0.0f && (int64_t)order[j] < n_own ? 1 : 0;
+    }
+}
+// values of the ghosts (local index n_own + k -> sorted position inv[..]) into a send buffer, and received values applied at
+// the owned components the rows went out for (sent_idx, the order they were sent in).  OP: 0 max (u32), 1 add (u64), 2 or (u64,
+// where the child's maximum is not finite: flag bits), 3 set
+template <typename T>
+__global__ __launch_bounds__(256) void k_ghost_gather(int64_t cnt, int64_t first_local, const unsigned* __restrict__ inv, const T* __restrict__ v, T* __restrict__ out) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) out[k] = v[inv[first_local + k]];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_sent_gather(int64_t cnt, const unsigned* __restrict__ sent_idx, const unsigned* __restrict__ inv, const T* __restrict__ v,
+                                                     T* __restrict__ out) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) out[k] = v[inv[sent_idx[k]]];
+}
+__global__ __launch_bounds__(256) void k_sent_apply_max(int64_t cnt, const unsigned* __restrict__ sent_idx, const unsigned* __restrict__ inv,
+                                                        const unsigned* __restrict__ in, unsigned* __restrict__ gmax) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) atomicMax(&gmax[inv[sent_idx[k]]], in[k]);
+}
+__global__ __launch_bounds__(256) void k_sent_apply_acc(int64_t cnt, const unsigned* __restrict__ sent_idx, const unsigned* __restrict__ inv,
+                                                        const unsigned long long* __restrict__ in, const unsigned* __restrict__ gmax,
+                                                        unsigned long long* __restrict__ gacc) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned j = inv[sent_idx[k]];
+        if (gmax[j] >= 0x7f800000u) atomicOr(&gacc[j], in[k]);        // flag bits
+        else atomicAdd(&gacc[j], in[k]);                               // two's complement fixed point: integer addition
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_ghost_set(int64_t cnt, int64_t first_local, const unsigned* __restrict__ inv, const T* __restrict__ in, T* __restrict__ v) {
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < cnt; k += (int64_t)gridDim.x * blockDim.x) v[inv[first_local + k]] = in[k];
+}
+// bit maps over the level's global indices, and ranks out of them
+__global__ __launch_bounds__(256) void k_bits_set(int64_t n_own, const unsigned* __restrict__ gid, const int* __restrict__ flag, unsigned* __restrict__ bits) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += (int64_t)gridDim.x * blockDim.x)
+        if (flag[i]) atomicOr(&bits[gid[i] >> 5], 1u << (gid[i] & 31));
+}
+__global__ __launch_bounds__(256) void k_bits_popc(int64_t words, const unsigned* __restrict__ bits, int* __restrict__ cnt) {
+    for (int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; w < words; w += (int64_t)gridDim.x * blockDim.x) cnt[w] = __popc(bits[w]);
+}
+// global rank of every flagged owned component: set bits below its gid (+ base); others keep what they have
+__global__ __launch_bounds__(256) void k_bits_rank(int64_t n_own, const unsigned* __restrict__ gid, const int* __restrict__ flag, const unsigned* __restrict__ bits,
+                                                   const int* __restrict__ wpre, unsigned base, unsigned* __restrict__ rank) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += (int64_t)gridDim.x * blockDim.x)
+        if (flag[i]) { const unsigned g = gid[i]; rank[i] = base + (unsigned)wpre[g >> 5] + (unsigned)__popc(bits[g >> 5] & ((1u << (g & 31)) - 1u)); }
+}
+// new gid of every output row: parents' rows by their local parent rank, orphans' rows behind them by their local orphan rank
+__global__ __launch_bounds__(256) void k_part_new_gid(int64_t n_own, int P_loc, const int* __restrict__ pflag_in, const int* __restrict__ prank_in,
+                                                      const int* __restrict__ oflag_in, const int* __restrict__ orank_in, const unsigned* __restrict__ grank,
+                                                      unsigned* __restrict__ new_gid) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += (int64_t)gridDim.x * blockDim.x) {
+        if (pflag_in[i]) new_gid[prank_in[i]] = grank[i];
+        else if (oflag_in[i]) new_gid[P_loc + orank_in[i]] = grank[i];
+    }
+}
+__global__ __launch_bounds__(256) void k_gather_bytes(int64_t n, const unsigned* __restrict__ idx, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
+}
+// the erased rows' global ranks leave the numbering: new gid -= erased rows below it
+__global__ __launch_bounds__(256) void k_gid_drop(int64_t n, const unsigned* __restrict__ bits, const int* __restrict__ wpre, unsigned* __restrict__ gid) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned g = gid[i];
+        gid[i] = g - ((unsigned)wpre[g >> 5] + (unsigned)__popc(bits[g >> 5] & ((1u << (g & 31)) - 1u)));
+    }
+}
+__global__ __launch_bounds__(256) void k_compact_u32(int64_t n, const int* __restrict__ keep, const int* __restrict__ pos, const unsigned* __restrict__ src,
+                                                     unsigned* __restrict__ dst) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        if (keep[i]) dst[pos[i]] = src[i];
+}
+__global__ __launch_bounds__(256) void k_not_flag(int64_t n, const int* __restrict__ in, int* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) out[i] = in[i] ? 0 : 1;
+}
+__global__ void k_last_total(const int* __restrict__ pos_last, const int* __restrict__ flag_last, long long* __restrict__ out) { *out = (long long)*pos_last + *flag_last; }
+__global__ void k_flip3(unsigned* __restrict__ w) { if (threadIdx.x < 3) w[threadIdx.x] = ~w[threadIdx.x]; }
+
 // validity (mixture.cpp:262-282): keep iff !(isnan(mean) || isnan(det) || det <= 0)
 __global__ __launch_bounds__(256) void k_valid(int64_t n, const float* __restrict__ xyz, const float* __restrict__ cov6,
                                                int* __restrict__ keep) {
@@ -2055,6 +2335,13 @@ struct gsr_hem_ctx {
     DevBuf hist, iflag, irank, ipos, rng_blocks, bhist, bstart, bcursor;
     bool split_heavy = true;        // heavy parents are cut into work items of SEL_PART candidates (GSR_HEM_SPLIT=0: one wave per parent)
     bool sum_bucket = true;         // per-child sums by bucket partition + LDS fixed point (GSR_HEM_SUMLW=sort for the radix sort)
+    // spatially partitioned levels (gsr_hem_set_comm + gsr_hem_set_level0_part): this rank owns cur.n components of a level of
+    // n_global; gid = their global indices (ascending)
+    gsr_comm* comm = nullptr;
+    int64_t n_global = 0;
+    DevBuf gid, gid_next, rec_loc, gid_loc, ghost_sh, ghost_src, perm, pown, ppos_own, inv, gmax, gacc, cmask, dflag, dpos, sent_idx, rows_send, rows_recv,
+        xsend, xrecv, gbits, wcnt, wpre, grank, allflags, pcounts, pmatrix;
+    int64_t part_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // ghosts, rows sent, bytes received in the halo exchange, bytes of the other exchanges, ...
     bool partition_fixed = true;    // bucket regions of fixed capacity filled straight from the segments (GSR_HEM_PARTITION=exact: histogram + scan)
     bool partition_overflowed = false;      // a region overflowed once: this context uses the exact partition from then on
     double partition_factor = 0.0;  // GSR_HEM_PARTITION_FACTOR: region capacity in multiples of the mean (test knob: < 1 forces the overflow path)
@@ -2107,14 +2394,13 @@ const unsigned* rng_xpow_table() {
     return t.tab;
 }
 
-// draw n parent flags for `lv` in order (consumes n hem::rand() values)
-int32_t draw_flags(gsr_hem_ctx* c, Level& lv) {
-    const int64_t n = lv.n;
+// draw n parent flags in order into dst (consumes n hem::rand() values)
+int32_t draw_flags_raw(gsr_hem_ctx* c, int64_t n, uint8_t* dst) {
     const float prob = 1.0f / c->rho;
     if (n == 0) return GSR_OK;
     if (c->rng_mode == GSR_RNG_HASH) {
         hipLaunchKernelGGL(k_flags_hash, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, c->rng_seed,
-                           (unsigned long long)c->rng_pos, prob, lv.is_parent.as<uint8_t>());
+                           (unsigned long long)c->rng_pos, prob, dst);
         c->rng_pos += (uint64_t)n;
         return GSR_OK;
     }
@@ -2157,10 +2443,11 @@ int32_t draw_flags(gsr_hem_ctx* c, Level& lv) {
     hipLaunchKernelGGL(k_rng_block_state, dim3((unsigned)nblocks), dim3(64), 0, c->stream, (unsigned long long)c->rng_pos,
                        c->draws.as<unsigned>(), c->rng_blocks.as<unsigned>());
     hipLaunchKernelGGL(k_flags_glibc, dim3((unsigned)nblocks), dim3(RNG_THREADS), 0, c->stream, n, prob, c->draws.as<unsigned>(),
-                       c->rng_blocks.as<unsigned>(), lv.is_parent.as<uint8_t>());
+                       c->rng_blocks.as<unsigned>(), dst);
     c->rng_pos += (uint64_t)n;
     return GSR_OK;
 }
+int32_t draw_flags(gsr_hem_ctx* c, Level& lv) { return draw_flags_raw(c, lv.n, lv.is_parent.as<uint8_t>()); }
 
 // Small device values the host needs (counts, totals, the grid geometry) are written by one tiny kernel straight
 // into pinned, device-visible host memory: one launch + one stream synchronisation per round trip.  (Separate
@@ -2304,6 +2591,8 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     (void)hipFuncSetAttribute((const void*)k_partition, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
+    (void)hipFuncSetAttribute((const void*)k_part_max, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << 13);
+    (void)hipFuncSetAttribute((const void*)k_part_acc, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     *out = c;
     return GSR_OK;
 }
@@ -2314,6 +2603,10 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     unborrow_level0(c);
     for (DevBuf& b : c->spare) b.release();
     c->cur.release(); c->nxt.release(); c->tmp.release();
+    DevBuf* part_bufs[] = {&c->gid, &c->gid_next, &c->rec_loc, &c->gid_loc, &c->ghost_sh, &c->ghost_src, &c->perm, &c->pown, &c->ppos_own, &c->inv, &c->gmax, &c->gacc,
+                           &c->cmask, &c->dflag, &c->dpos, &c->sent_idx, &c->rows_send, &c->rows_recv, &c->xsend, &c->xrecv, &c->gbits, &c->wcnt, &c->wpre,
+                           &c->grank, &c->allflags, &c->pcounts, &c->pmatrix};
+    for (DevBuf* b : part_bufs) b->release();
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->geo, &c->shs,
                      &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->Ac, &c->cellStartC, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
@@ -2408,6 +2701,51 @@ int32_t gsr_hem_set_level0(gsr_hem_ctx* c, const float* xyz, const float* color,
     return GSR_OK;
 }
 
+int32_t gsr_hem_set_comm(gsr_hem_ctx* c, gsr_comm* comm) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_comm: NULL context");
+    c->comm = comm;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_set_level0_part(gsr_hem_ctx* c, const float* xyz, const float* color, const float* cov6, const float* opacity, const float* sh,
+                                const uint32_t* gid, int64_t n_own, int64_t n_global, int32_t F, int32_t on_device) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_level0_part: NULL context");
+    if (!c->comm) return fail(GSR_E_INVALID, "gsr_hem_set_level0_part: no communicator (gsr_hem_set_comm first)");
+    if (n_own <= 0 || n_global < n_own || !gid) return fail(GSR_E_INVALID, "gsr_hem_set_level0_part: every rank must own at least one component (n_own=%lld of %lld)", (long long)n_own, (long long)n_global);
+    if (n_global >= ((int64_t)1 << 31) - 1) return fail(GSR_E_INVALID, "gsr_hem_set_level0_part: n_global=%lld exceeds 2^31-2", (long long)n_global);
+    // the owned arrays as an ordinary (copied) level 0; its flags are replaced below by the flags at the global indices
+    const uint64_t pos0 = c->rng_pos;
+    GSR_TRY(gsr_hem_set_level0(c, xyz, color, cov6, opacity, sh, n_own, F, on_device ? 1 : 0));
+    c->rng_pos = pos0;
+    hipStream_t st = c->stream;
+    GSR_TRY(c->gid.reserve((size_t)n_own * 4));
+    GSR_HIP(hipMemcpyAsync(c->gid.p, gid, (size_t)n_own * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    GSR_TRY(c->allflags.reserve((size_t)n_global));
+    GSR_TRY(draw_flags_raw(c, n_global, c->allflags.as<uint8_t>()));          // Mixture::initMixture draws one flag per component of the WHOLE cloud
+    hipLaunchKernelGGL(k_gather_bytes, dim3(stride_grid(n_own)), dim3(256), 0, st, n_own, c->gid.as<unsigned>(), c->allflags.as<uint8_t>(), c->cur.is_parent.as<uint8_t>());
+    GSR_HIP(hipStreamSynchronize(st));
+    c->n_global = n_global;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_get_gids(gsr_hem_ctx* c, uint32_t* gid, int32_t on_device) {
+    if (!c || !c->have_level || !gid) return fail(GSR_E_INVALID, "gsr_hem_get_gids: no level set");
+    if (!c->comm) return fail(GSR_E_INVALID, "gsr_hem_get_gids: not a partitioned level");
+    GSR_HIP(hipSetDevice(c->device));
+    if (c->cur.n > 0) {
+        GSR_HIP(hipMemcpyAsync(gid, c->gid.p, (size_t)c->cur.n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost, c->stream));
+        GSR_HIP(hipStreamSynchronize(c->stream));
+    }
+    return GSR_OK;
+}
+
+int32_t gsr_hem_get_part_stats(gsr_hem_ctx* c, int64_t* out8) {
+    if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_part_stats: NULL argument");
+    memcpy(out8, c->part_stats, sizeof(c->part_stats));
+    out8[7] = c->n_global;
+    return GSR_OK;
+}
+
 int32_t gsr_hem_set_state(gsr_hem_ctx* c, const uint8_t* parent_mask, const float* weight) {
     if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_set_state: no level set");
     GSR_HIP(hipSetDevice(c->device));
@@ -2484,19 +2822,40 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
     Level& L = c->cur;
-    const int64_t n = L.n;
+    // spatially partitioned level: the working set is this rank's owned components + the ghosts the halo exchange brings in;
+    // n becomes their number once the exchange is through (n_own = L.n stays the owned ones, the first n_own local indices)
+    const bool part = c->comm != nullptr;
+    const int64_t n_own = L.n;
+    int64_t n = n_own;
     const int F = L.F;
     memset(c->stats, 0, sizeof(c->stats));
     memset(c->stats_ex, 0, sizeof(c->stats_ex));
+    memset(c->part_stats, 0, sizeof(c->part_stats));
     c->stats[6] = n;
     if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld components (the candidate records carry the sorted position in 30 bits)", (long long)n);
+    if (part && n == 0) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank of a partitioned level owns no component (use fewer ranks)");
+    if (part && c->shard_world > 1) return fail(GSR_E_INVALID, "gsr_hem_run_level: spatial partition and work sharding are exclusive");
     if (n == 0) {
         if (n_out) *n_out = 0;
         if (n_dropped) *n_dropped = 0;
         return GSR_OK;
     }
     const dim3 blk(256);
-    const dim3 grd(stride_grid(n));
+    dim3 grd(stride_grid(n));
+    const int W = part ? gsr_comm_world(c->comm) : 1, me = part ? gsr_comm_rank(c->comm) : 0;
+    if (W > 8) return fail(GSR_E_INVALID, "gsr_hem_run_level: more than 8 ranks");
+    // halo bookkeeping (host): rows sent to / received from every rank, and their offsets in the concatenated buffers
+    int64_t send_cnt[8] = {0}, recv_cnt[8] = {0}, soff[8] = {0}, roff[8] = {0}, n_sent = 0, n_ghost = 0;
+    // one typed exchange along the halo's lists: to_owner = the ghosts' values go to their owners (roles of the lists reversed)
+    auto halo_exchange = [&](const void* sendbuf, void* recvbuf, size_t elem, bool to_owner) -> int32_t {
+        int64_t so[8], sb[8], ro[8], rb[8];
+        for (int q = 0; q < W; ++q) {
+            so[q] = (to_owner ? roff[q] : soff[q]) * (int64_t)elem; sb[q] = (to_owner ? recv_cnt[q] : send_cnt[q]) * (int64_t)elem;
+            ro[q] = (to_owner ? soff[q] : roff[q]) * (int64_t)elem; rb[q] = (to_owner ? send_cnt[q] : recv_cnt[q]) * (int64_t)elem;
+            if (q != me) c->part_stats[3] += rb[q];
+        }
+        return gsr_comm_exchange(c->comm, sendbuf, so, sb, recvbuf, ro, rb, (void*)st);
+    };
     GSR_HIP(hipEventRecord(c->ev[0], st));
 
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
@@ -2507,11 +2866,17 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
                        L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>());
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>());
+    if (part) {     // the box of ALL ranks' components: maximum of the (order-preserving) codes, the minima complemented
+        hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
+        GSR_TRY(gsr_comm_allreduce(c->comm, c->bbox.p, 6, GSR_DT_U32, GSR_OP_MAX, (void*)st));
+        hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
+    }
     GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
     GSR_HIP(hipMemsetAsync(c->hist.p, 0, 3 * HIST_BINS * 4, st));
     hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>());
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), n, c->cell_target, c->max_cells,
-                       c->gparams.as<GridParams>());
+    if (part) GSR_TRY(gsr_comm_allreduce(c->comm, c->hist.p, 3 * HIST_BINS, GSR_DT_U32, GSR_OP_SUM, (void*)st));      // integer counts: exact
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), part ? c->n_global : n, c->cell_target,
+                       c->max_cells, c->gparams.as<GridParams>());
     GridParams gp;
     {
         static_assert(sizeof(GridParams) == 40, "GridParams is read back as five 8-byte words");
@@ -2524,7 +2889,63 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     }
     c->stats[5] = gp.ncells;
 
+    const float4* rec_src = c->rec.as<float4>();            // the packed records of the working set, by local index
+    if (part) {
+        // ---- halo: which cells do my parents' search spheres touch -> masks of all ranks -> my components they need -> rows
+        const int64_t mwords = ((int64_t)gp.ncells + 31) / 32 + 1;
+        GSR_TRY(c->cmask.reserve((size_t)W * mwords * 4));
+        unsigned* my_mask = c->cmask.as<unsigned>() + (int64_t)me * mwords;
+        GSR_HIP(hipMemsetAsync(my_mask, 0, (size_t)mwords * 4, st));
+        hipLaunchKernelGGL(k_mark_cells, dim3(stride_grid(n_own * 16)), blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), c->delta, my_mask);
+        GSR_TRY(gsr_comm_allgather(c->comm, my_mask, c->cmask.p, mwords * 4, (void*)st));
+        GSR_TRY(c->dflag.reserve((size_t)W * n_own * 4)); GSR_TRY(c->dpos.reserve((size_t)W * n_own * 4));
+        hipLaunchKernelGGL(k_dest_flags, grd, blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), W, me, mwords, c->cmask.as<unsigned>(),
+                           c->dflag.as<int>());
+        GSR_TRY(c->pcounts.reserve(64)); GSR_TRY(c->pmatrix.reserve(64 * 8));
+        GSR_HIP(hipMemsetAsync(c->pcounts.p, 0, 64, st));
+        for (int q = 0; q < W; ++q) {
+            if (q == me) continue;
+            GSR_TRY(exclusive_scan<int>(c, c->dflag.as<int>() + (int64_t)q * n_own, c->dpos.as<int>() + (int64_t)q * n_own, n_own));
+            hipLaunchKernelGGL(k_last_total, dim3(1), dim3(1), 0, st, c->dpos.as<int>() + (int64_t)q * n_own + (n_own - 1),
+                               c->dflag.as<int>() + (int64_t)q * n_own + (n_own - 1), c->pcounts.as<long long>() + q);
+        }
+        GSR_TRY(gsr_comm_allgather(c->comm, c->pcounts.p, c->pmatrix.p, 64, (void*)st));
+        long long mat[64];
+        GSR_HIP(hipMemcpyAsync(mat, c->pmatrix.p, (size_t)W * 64, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        for (int q = 0; q < W; ++q) { send_cnt[q] = q == me ? 0 : mat[me * 8 + q]; recv_cnt[q] = q == me ? 0 : mat[q * 8 + me]; }
+        for (int q = 0; q < W; ++q) { soff[q] = n_sent; n_sent += send_cnt[q]; roff[q] = n_ghost; n_ghost += recv_cnt[q]; }
+        const int RW = 16 + F + PART_ROW_EXTRA;
+        GSR_TRY(c->rows_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * RW * 4)); GSR_TRY(c->rows_recv.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * RW * 4));
+        GSR_TRY(c->sent_idx.reserve((size_t)(n_sent > 0 ? n_sent : 1) * 4));
+        for (int q = 0; q < W; ++q)
+            if (send_cnt[q] > 0)
+                hipLaunchKernelGGL(k_pack_rows, dim3(stride_grid(n_own * 64)), blk, 0, st, n_own, F, c->dflag.as<int>() + (int64_t)q * n_own,
+                                   c->dpos.as<int>() + (int64_t)q * n_own, c->rec.as<float4>(), L.sh.as<float>(), c->gid.as<unsigned>(),
+                                   c->rows_send.as<float>() + soff[q] * RW, c->sent_idx.as<unsigned>() + soff[q]);
+        GSR_TRY(halo_exchange(c->rows_send.p, c->rows_recv.p, (size_t)RW * 4, false));
+        c->part_stats[0] = n_ghost; c->part_stats[1] = n_sent; c->part_stats[2] = c->part_stats[3]; c->part_stats[3] = 0;
+        n = n_own + n_ghost;
+        if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld local components", (long long)n);
+        grd = dim3(stride_grid(n));
+        GSR_TRY(c->rec_loc.reserve((size_t)n * 64)); GSR_TRY(c->gid_loc.reserve((size_t)n * 4));
+        GSR_TRY(c->ghost_sh.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * (F > 0 ? F : 1) * 4)); GSR_TRY(c->ghost_src.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * 4));
+        GSR_HIP(hipMemcpyAsync(c->rec_loc.p, c->rec.p, (size_t)n_own * 64, hipMemcpyDeviceToDevice, st));
+        GSR_HIP(hipMemcpyAsync(c->gid_loc.p, c->gid.p, (size_t)n_own * 4, hipMemcpyDeviceToDevice, st));
+        if (n_ghost > 0)
+            hipLaunchKernelGGL(k_unpack_rows, dim3(stride_grid(n_ghost * 64)), blk, 0, st, n_ghost, n_own, F, c->rows_recv.as<float>(), c->rec_loc.as<float4>(),
+                               c->ghost_sh.as<float>(), c->gid_loc.as<unsigned>(), c->ghost_src.as<unsigned>());
+        rec_src = c->rec_loc.as<float4>();
+        c->stats[6] = n_own;
+    }
     GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->order.reserve(n * 4));
+    if (part) {
+        // local components in ascending GLOBAL index (what a single GPU's input order is), then the stable sort by cell
+        GSR_TRY(c->perm.reserve(n * 4));
+        hipLaunchKernelGGL(k_iota, grd, blk, 0, st, n, c->idx.as<unsigned>());
+        GSR_TRY(sort_pairs<unsigned>(c, c->gid_loc.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(), c->perm.as<unsigned>(), n, bits_for(c->n_global + 1)));
+        hipLaunchKernelGGL(k_keys_rec, grd, blk, 0, st, n, rec_src, c->perm.as<unsigned>(), c->gparams.as<GridParams>(), c->keys.as<unsigned>(), c->idx.as<unsigned>());
+    } else
     hipLaunchKernelGGL(k_keys, grd, blk, 0, st, n, L.xyz.as<float>(), c->gparams.as<GridParams>(), c->keys.as<unsigned>(), c->idx.as<unsigned>());
     GSR_TRY(sort_pairs<unsigned>(c, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(), c->order.as<unsigned>(), n,
                                  bits_for(gp.ncells)));
@@ -2535,7 +2956,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->A.reserve((n + SEL_PAD) * 16)); GSR_TRY(c->geo.reserve((size_t)n * 64)); GSR_TRY(c->shs.reserve((size_t)n * (RSH > 0 ? RSH : 1) * 4));
     GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4));
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
-    hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), c->rec.as<float4>(), c->delta, c->A.as<float4>(), c->geo.as<float4>(),
+    hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), rec_src, c->delta, c->A.as<float4>(), c->geo.as<float4>(),
                        c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
     bool sh_pending = false;
     // only the M-step reads the sorted SH rows: the gather (1.9 GB of HBM traffic at 5 M) can run on its own stream beside the
@@ -2548,6 +2969,10 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
             sst = c->aux2;
         }
+        if (part)
+            hipLaunchKernelGGL(k_gather_sh2, dim3(stride_grid(n * (RSH >> 2))), blk, 0, sst, n, n_own, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(),
+                               c->ghost_sh.as<float>(), c->shs.as<float>());
+        else
         hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * (RSH >> 2))), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
         if (fork) { GSR_HIP(hipEventRecord(c->ev_sh_join, c->aux2)); sh_pending = true; }
         return GSR_OK;
@@ -2555,27 +2980,36 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     bool sh_launched = false;
     if (c->sh_overlap != 2) { GSR_TRY(launch_gather_sh(c->sh_overlap == 1)); sh_launched = true; }
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
+    if (part) {     // the parents this rank works on are the ones it owns; the ghosts' parent flags still keep them out of the children's stream
+        GSR_TRY(c->pown.reserve(n * 4)); GSR_TRY(c->ppos_own.reserve(n * 4)); GSR_TRY(c->inv.reserve(n * 4));
+        hipLaunchKernelGGL(k_own_flags, grd, blk, 0, st, n, n_own, c->order.as<unsigned>(), c->pflag.as<int>(), c->pown.as<int>(), c->inv.as<unsigned>());
+        GSR_TRY(exclusive_scan<int>(c, c->pown.as<int>(), c->ppos_own.as<int>(), n));
+        hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pown.as<int>(), c->ppos_own.as<int>(), c->plist.as<unsigned>());
+    } else
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
     // the irregular components (never pre-rejected): their sorted positions, and their rank at every position
     GSR_TRY(exclusive_scan<int>(c, c->iflag.as<int>(), c->irank.as<int>(), n + 1));
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->iflag.as<int>(), c->irank.as<int>(), c->ipos.as<unsigned>());
-    int last_pos = 0, last_flag = 0, n_irr = 0;
+    int last_pos = 0, last_flag = 0, n_irr = 0, own_pos = 0, own_flag = 0;
     {
         Collect q;
-        q.n = 3;
+        q.n = part ? 5 : 3;
         q.src[0] = c->irank.as<int>() + n; q.src[1] = c->ppos.as<int>() + (n - 1); q.src[2] = c->pflag.as<int>() + (n - 1);
-        q.bytes[0] = q.bytes[1] = q.bytes[2] = 4;
+        if (part) { q.src[3] = c->ppos_own.as<int>() + (n - 1); q.src[4] = c->pown.as<int>() + (n - 1); }
+        for (int i = 0; i < 5; ++i) q.bytes[i] = 4;
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
         n_irr = (int)w[0]; last_pos = (int)w[1]; last_flag = (int)w[2];
+        if (part) { own_pos = (int)w[3]; own_flag = (int)w[4]; }
     }
-    const int P = last_pos + last_flag;
+    const int P_all = last_pos + last_flag;                   // parents among the local components (they are no candidates)
+    const int P = part ? own_pos + own_flag : P_all;          // parents this rank evaluates
     c->stats[0] = P;
     c->stats_ex[0] = n_irr;
     // the candidate stream of pass A (non-parents only) and its prefix table
-    GSR_TRY(c->Ac.reserve(((size_t)(n - P) + SEL_PAD) * 16)); GSR_TRY(c->cellStartC.reserve(((size_t)gp.ncells + 1) * 4));
-    GSR_HIP(hipMemsetAsync((char*)c->Ac.p + (size_t)(n - P) * 16, 0, (size_t)SEL_PAD * 16, st));      // the pad k_select reads past the last row
-    hipLaunchKernelGGL(k_child_stream, grd, blk, 0, st, n, (int64_t)gp.ncells, P, c->A.as<float4>(), c->pflag.as<int>(), c->ppos.as<int>(),
+    GSR_TRY(c->Ac.reserve(((size_t)(n - P_all) + SEL_PAD) * 16)); GSR_TRY(c->cellStartC.reserve(((size_t)gp.ncells + 1) * 4));
+    GSR_HIP(hipMemsetAsync((char*)c->Ac.p + (size_t)(n - P_all) * 16, 0, (size_t)SEL_PAD * 16, st));      // the pad k_select reads past the last row
+    hipLaunchKernelGGL(k_child_stream, grd, blk, 0, st, n, (int64_t)gp.ncells, P_all, c->A.as<float4>(), c->pflag.as<int>(), c->ppos.as<int>(),
                        c->cellStart.as<int>(), c->Ac.as<float4>(), c->cellStartC.as<int>());
     GSR_CHECKPOINT("grid + gather");
     GSR_HIP(hipEventRecord(c->ev[1], st));
@@ -2815,7 +3249,61 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipGetLastError());
         return GSR_OK;
     };
-    if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
+    // spatially partitioned level: k_bucket_sum's three steps with the ghosts' partial results sent to their owners in between --
+    // integers only (maximum, 64-bit fixed-point sums), then the owners' finished float32 sums back to the ghosts
+    auto sums_part = [&]() -> int32_t {
+        if (nbuckets > SUM_MAX_BUCKETS) return fail(GSR_E_INVALID, "gsr_hem_run_level: level too large for the partitioned sums");
+        GSR_TRY(c->gmax.reserve((size_t)n * 4)); GSR_TRY(c->gacc.reserve((size_t)n * 8)); GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
+        unsigned cap = 0;
+        for (double factor = 8.0;; factor *= 2.0) {            // bucket regions of fixed capacity; doubled until nothing overflows
+            const double capd = (double)M / (double)nbuckets * factor + 4096.0;
+            if (capd > 4.0e9) return fail(GSR_E_INVALID, "gsr_hem_run_level: pair partition capacity");
+            cap = (unsigned)capd;
+            GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * 4)); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
+            GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
+            GSR_HIP(hipMemsetAsync(overflow_flag, 0, 4, st));
+            if (M > 0 && P > 0)
+                hipLaunchKernelGGL(k_partition, dim3(ceil_div(P, PART_PPW)), blk, (size_t)nbuckets * 4, st, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift,
+                                   cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
+            GSR_HIP(hipGetLastError());
+            Collect q;
+            q.n = 1; q.src[0] = overflow_flag; q.bytes[0] = 4;
+            unsigned long long w[8];
+            GSR_TRY(read_back(c, q, w));
+            if (w[0] == 0ull) break;
+        }
+        const dim3 bblk(bshift >= 10 ? 1024 : 256);
+        const dim3 gs(stride_grid(n_sent > 0 ? n_sent : 1)), gg(stride_grid(n_ghost > 0 ? n_ghost : 1));
+        GSR_TRY(c->xsend.reserve((size_t)(n_sent + n_ghost + 1) * 8)); GSR_TRY(c->xrecv.reserve((size_t)(n_sent + n_ghost + 1) * 8));
+        // 1. the largest |wL| of every child: local, then the ghosts' maxima to their owners, then the owners' result back
+        hipLaunchKernelGGL(k_part_max, dim3(nbuckets), bblk, (size_t)4 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(),
+                           c->spair_wl.as<float>(), c->gmax.as<unsigned>());
+        GSR_HIP(hipGetLastError());
+        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_gather<unsigned>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->gmax.as<unsigned>(), c->xsend.as<unsigned>());
+        GSR_TRY(halo_exchange(c->xsend.p, c->xrecv.p, 4, true));
+        if (n_sent > 0) hipLaunchKernelGGL(k_sent_apply_max, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->xrecv.as<unsigned>(), c->gmax.as<unsigned>());
+        if (n_sent > 0) hipLaunchKernelGGL(k_sent_gather<unsigned>, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->gmax.as<unsigned>(), c->xsend.as<unsigned>());
+        GSR_TRY(halo_exchange(c->xsend.p, c->xrecv.p, 4, false));
+        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_set<unsigned>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->xrecv.as<unsigned>(), c->gmax.as<unsigned>());
+        // 2. the fixed-point sums on that scale: local, then the ghosts' partial sums to their owners (integer addition)
+        hipLaunchKernelGGL(k_part_acc, dim3(nbuckets), bblk, (size_t)12 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(),
+                           c->spair_wl.as<float>(), c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>());
+        GSR_HIP(hipGetLastError());
+        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_gather<unsigned long long>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->gacc.as<unsigned long long>(), c->xsend.as<unsigned long long>());
+        GSR_TRY(halo_exchange(c->xsend.p, c->xrecv.p, 8, true));
+        if (n_sent > 0) hipLaunchKernelGGL(k_sent_apply_acc, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->xrecv.as<unsigned long long>(),
+                                           c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>());
+        // 3. the float32 sums (correct for the owned components), the owners' values back to the ghosts, orphans among the owned
+        hipLaunchKernelGGL(k_part_finish, grd, blk, 0, st, n, c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>(), c->sumLw.as<float>());
+        if (n_sent > 0) hipLaunchKernelGGL(k_sent_gather<float>, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->sumLw.as<float>(), c->xsend.as<float>());
+        GSR_TRY(halo_exchange(c->xsend.p, c->xrecv.p, 4, false));
+        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_set<float>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->xrecv.as<float>(), c->sumLw.as<float>());
+        hipLaunchKernelGGL(k_part_orphans, grd, blk, 0, st, n, n_own, c->order.as<unsigned>(), c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
+        return GSR_OK;
+    };
+    if (part) {
+        GSR_TRY(sums_part());
+    } else if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
         if (c->partition_fixed && !c->partition_overflowed) {
             const int32_t r = sums_fixed();
             if (r == GSR_E_INVALID && !fixed_tried) GSR_TRY(sums_exact()); else GSR_TRY(r);
@@ -2852,7 +3340,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->oslot.reserve(n * 8));
     int o_last = 0, o_flag = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        hipLaunchKernelGGL(k_flags_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), c->pflag.as<int>(), c->oflag.as<int>(),
+        hipLaunchKernelGGL(k_flags_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), part ? c->pown.as<int>() : c->pflag.as<int>(), c->oflag.as<int>(),
                            c->pflag_in.as<int>(), c->oflag_in.as<int>());
         GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
         GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
@@ -2950,10 +3438,50 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                                    O.color.as<float>(), O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>());
         }
     }
+    // spatially partitioned level: the rows' GLOBAL ranks (a parent's = parents below it in the level's global order, an orphan's =
+    // all parents + orphans below it): bit maps of the parents' and orphans' global indices, summed over the ranks (disjoint bits)
+    int64_t P_glob = P, O_glob = n_orph;
+    if (part) {
+        const int64_t words = (c->n_global + 31) / 32 + 1;
+        GSR_TRY(c->gbits.reserve((size_t)2 * words * 4)); GSR_TRY(c->wcnt.reserve((size_t)2 * words * 4)); GSR_TRY(c->wpre.reserve((size_t)2 * words * 4));
+        GSR_TRY(c->grank.reserve((size_t)n_own * 4)); GSR_TRY(c->gid_next.reserve((size_t)(n_pre > 0 ? n_pre : 1) * 4));
+        GSR_HIP(hipMemsetAsync(c->gbits.p, 0, (size_t)2 * words * 4, st));
+        const dim3 go(stride_grid(n_own));
+        hipLaunchKernelGGL(k_bits_set, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->pflag_in.as<int>(), c->gbits.as<unsigned>());
+        hipLaunchKernelGGL(k_bits_set, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->oflag_in.as<int>(), c->gbits.as<unsigned>() + words);
+        GSR_TRY(gsr_comm_allreduce(c->comm, c->gbits.p, 2 * words, GSR_DT_U32, GSR_OP_SUM, (void*)st));
+        hipLaunchKernelGGL(k_bits_popc, dim3(stride_grid(2 * words)), blk, 0, st, 2 * words, c->gbits.as<unsigned>(), c->wcnt.as<int>());
+        GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>(), c->wpre.as<int>(), words));
+        GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>() + words, c->wpre.as<int>() + words, words));
+        {
+            Collect q;
+            q.n = 4;
+            q.src[0] = c->wpre.as<int>() + (words - 1); q.src[1] = c->wcnt.as<int>() + (words - 1);
+            q.src[2] = c->wpre.as<int>() + (2 * words - 1); q.src[3] = c->wcnt.as<int>() + (2 * words - 1);
+            for (int i = 0; i < 4; ++i) q.bytes[i] = 4;
+            unsigned long long w[8];
+            GSR_TRY(read_back(c, q, w));
+            P_glob = (int64_t)w[0] + (int64_t)w[1]; O_glob = (int64_t)w[2] + (int64_t)w[3];
+        }
+        hipLaunchKernelGGL(k_bits_rank, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->pflag_in.as<int>(), c->gbits.as<unsigned>(), c->wpre.as<int>(), 0u,
+                           c->grank.as<unsigned>());
+        hipLaunchKernelGGL(k_bits_rank, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->oflag_in.as<int>(), c->gbits.as<unsigned>() + words, c->wpre.as<int>() + words,
+                           (unsigned)P_glob, c->grank.as<unsigned>());
+        hipLaunchKernelGGL(k_part_new_gid, go, blk, 0, st, n_own, P, c->pflag_in.as<int>(), c->prank_in.as<int>(), c->oflag_in.as<int>(), c->orank_in.as<int>(),
+                           c->grank.as<unsigned>(), c->gid_next.as<unsigned>());
+        c->part_stats[4] = P_glob; c->part_stats[5] = O_glob;
+    }
+    const int64_t n_pre_glob = P_glob + O_glob;
     GSR_CHECKPOINT("M-step + orphans");
     GSR_HIP(hipEventRecord(c->ev[4], st));
 
     // ---- 5. new parent flags (one draw per component, before the erase), validity erase ---------
+    if (part) {     // the libc stream is drawn for the GLOBAL level; a row takes the flag at its global rank
+        GSR_TRY(c->allflags.reserve((size_t)(n_pre_glob > 0 ? n_pre_glob : 1)));
+        GSR_TRY(draw_flags_raw(c, n_pre_glob, c->allflags.as<uint8_t>()));
+        if (n_pre > 0)
+            hipLaunchKernelGGL(k_gather_bytes, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->gid_next.as<unsigned>(), c->allflags.as<uint8_t>(), O.is_parent.as<uint8_t>());
+    } else
     GSR_TRY(draw_flags(c, O));
     int64_t dropped = 0;
     if (n_pre > 0) {
@@ -2990,11 +3518,45 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             O.swap(T);
         }
     }
+    int64_t n_glob_next = n_pre_glob;
+    if (part) {
+        // erased rows leave the GLOBAL numbering too: how many over all ranks, and (rarely more than none) which
+        GSR_TRY(c->pcounts.reserve(64));
+        const long long dl = dropped;
+        GSR_HIP(hipMemcpyAsync(c->pcounts.p, &dl, 8, hipMemcpyHostToDevice, st));
+        GSR_HIP(hipStreamSynchronize(st));                      // (dl lives on this stack frame)
+        GSR_TRY(gsr_comm_allreduce(c->comm, c->pcounts.p, 1, GSR_DT_U64, GSR_OP_SUM, (void*)st));
+        long long dg = 0;
+        GSR_HIP(hipMemcpyAsync(&dg, c->pcounts.p, 8, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        if (dg > 0) {
+            const int64_t words = (n_pre_glob + 31) / 32 + 1;
+            GSR_TRY(c->gbits.reserve((size_t)words * 4)); GSR_TRY(c->wcnt.reserve((size_t)words * 4)); GSR_TRY(c->wpre.reserve((size_t)words * 4));
+            GSR_HIP(hipMemsetAsync(c->gbits.p, 0, (size_t)words * 4, st));
+            if (n_pre > 0) {
+                GSR_TRY(c->scratch.reserve((size_t)n_pre * 4));
+                hipLaunchKernelGGL(k_not_flag, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->keep.as<int>(), c->scratch.as<int>());
+                hipLaunchKernelGGL(k_bits_set, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->gid_next.as<unsigned>(), c->scratch.as<int>(), c->gbits.as<unsigned>());
+            }
+            GSR_TRY(gsr_comm_allreduce(c->comm, c->gbits.p, words, GSR_DT_U32, GSR_OP_SUM, (void*)st));
+            hipLaunchKernelGGL(k_bits_popc, dim3(stride_grid(words)), blk, 0, st, words, c->gbits.as<unsigned>(), c->wcnt.as<int>());
+            GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>(), c->wpre.as<int>(), words));
+            if (dropped > 0) {                                  // my own erased rows out of my list first
+                GSR_TRY(c->grank.reserve((size_t)n_pre * 4));
+                hipLaunchKernelGGL(k_compact_u32, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->keep.as<int>(), c->kpos.as<int>(), c->gid_next.as<unsigned>(), c->grank.as<unsigned>());
+                c->gid_next.swap(c->grank);
+            }
+            if (O.n > 0) hipLaunchKernelGGL(k_gid_drop, dim3(stride_grid(O.n)), blk, 0, st, O.n, c->gbits.as<unsigned>(), c->wpre.as<int>(), c->gid_next.as<unsigned>());
+            n_glob_next = n_pre_glob - dg;
+        }
+        c->part_stats[6] = dg;
+    }
     GSR_CHECKPOINT("flags + validity");
     GSR_HIP(hipEventRecord(c->ev[5], st));
     GSR_HIP(hipStreamSynchronize(st));
     unborrow_level0(c);                 // a borrowed level 0 goes back to the caller; cur gets its own buffers again
     c->cur.swap(c->nxt);
+    if (part) { c->gid.swap(c->gid_next); c->n_global = n_glob_next; }
     c->stats[3] = dropped;
     c->stats[7] = c->cur.n;
     for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);

@@ -155,6 +155,46 @@ class HemMixture:
         self._borrowed = (kx, kc, kv, ko, ks) if mode == 2 else None
         del kx, kc, kv, ko, ks
 
+    # -- spatially partitioned levels (one large cloud over several GPUs) ------------------------------------------------
+    def set_comm(self, comm):
+        """The communicator (``comm.Comm``) the partitioned levels exchange through; ``None`` = single GPU."""
+        self._comm = comm
+        _lib.check(self._L.gsr_hem_set_comm(self._h, comm.handle if comm is not None else None), "gsr_hem_set_comm")
+
+    def set_level0_part(self, xyz, colors, opacities, covariance, features, gid, n_global):
+        """This rank's OWNED components of a cloud of ``n_global`` with their global indices ``gid`` (ascending, uint32)."""
+        n = int(xyz.shape[0])
+        f = features
+        F = int(f.shape[1]) if hasattr(f, "shape") and len(f.shape) == 2 else 0
+        self.F = F
+        px, kx, dx = _prep(xyz, (n, 3), self.device)
+        pc, kc, dc = _prep(colors, (n, 3), self.device)
+        pv, kv, dv = _prep(covariance, (n, 6), self.device)
+        po, ko, do = _prep(opacities, (n,), self.device)
+        ps, ks, ds = _prep(features, (n, F), self.device) if F > 0 else (0, None, dx)
+        if len({dx, dc, dv, do, ds}) != 1:
+            raise RuntimeError("all level-0 arrays must live in the same place (all host or all device)")
+        if dx:
+            g = gid.detach().to(torch.int32).contiguous() if _is_tensor(gid) else torch.as_tensor(np.asarray(gid, np.int64).astype(np.int32)).to(xyz.device)
+            pg, kg = g.data_ptr(), g
+            torch.cuda.current_stream(self.device).synchronize()
+        else:
+            kg = np.ascontiguousarray(gid.cpu().numpy() if _is_tensor(gid) else gid, dtype=np.uint32)
+            pg = kg.ctypes.data
+        _lib.check(self._L.gsr_hem_set_level0_part(self._h, px, pc, pv, po, ps, pg, n, int(n_global), F, 1 if dx else 0), "gsr_hem_set_level0_part")
+
+    def gids(self):
+        """Global indices (uint32 numpy) of the current partitioned level's owned rows."""
+        out = np.empty(self.size, np.uint32)
+        _lib.check(self._L.gsr_hem_get_gids(self._h, out.ctypes.data, 0), "gsr_hem_get_gids")
+        return out
+
+    def part_stats(self):
+        s = (C.c_int64 * 8)()
+        _lib.check(self._L.gsr_hem_get_part_stats(self._h, s), "gsr_hem_get_part_stats")
+        return {"ghosts": s[0], "rows_sent": s[1], "halo_bytes_received": s[2], "sum_exchange_bytes_received": s[3], "parents_global": s[4],
+                "orphans_global": s[5], "dropped_global": s[6], "n_global": s[7]}
+
     def set_state(self, parent_mask=None, weight=None):
         pm = None if parent_mask is None else np.ascontiguousarray(parent_mask, dtype=np.uint8)
         w = None if weight is None else np.ascontiguousarray(weight, dtype=np.float32)

@@ -30,7 +30,7 @@ except Exception:  # pragma: no cover
     dist = None
 
 __all__ = ["init_distributed", "shard_range", "make_allreduce", "make_allreduce_device", "make_allgather_device", "assign_clouds",
-           "registration_icp_sharded", "hem_sharded"]
+           "registration_icp_sharded", "hem_sharded", "slab_of", "hem_partitioned", "assemble_partitioned_level"]
 
 
 def init_distributed(backend: str | None = None):
@@ -158,3 +158,64 @@ def hem_sharded(cloud: dict, cluster_level: int, rank: int, world: int, device=N
             stats.append(m.stats())
             levels.append(m.get_level(as_torch=as_torch))
         return levels, stats
+
+
+def slab_of(xyz, rank: int, world: int):
+    """Global indices (ascending) of the components of slab ``rank`` of ``world``: the cloud cut along its longest axis into
+    ``world`` slabs of equal counts (a stable argsort of that coordinate, so every rank computes the same cut)."""
+    if torch is not None and isinstance(xyz, torch.Tensor):
+        ext = xyz.max(0).values - xyz.min(0).values
+        axis = int(torch.argmax(ext))
+        order = torch.argsort(xyz[:, axis], stable=True)
+        lo, hi = shard_range(xyz.shape[0], rank, world)
+        return torch.sort(order[lo:hi]).values
+    x = np.asarray(xyz)
+    axis = int(np.argmax(x.max(0) - x.min(0)))
+    order = np.argsort(x[:, axis], kind="stable")
+    lo, hi = shard_range(x.shape[0], rank, world)
+    return np.sort(order[lo:hi])
+
+
+def hem_partitioned(cloud: dict, cluster_level: int, comm, device=None, as_torch=False, owned=None, mixture=None, **hem_params):
+    """``MixtureCreator.CreateMixture`` of ONE large cloud SPATIALLY partitioned over the ranks of ``comm`` (BASELINE config 5):
+    this rank keeps the components of its slab (``owned`` = their global indices; default ``slab_of``) -- here cut out of the full
+    ``cloud`` every rank passes; a caller that holds only its slab passes that and ``owned`` -- and every level runs on owned +
+    halo components, bit for bit the single-GPU level (include/gsr_hip.h, gsr_hem_set_level0_part).  Returns (pieces, stats): per
+    level a dict of this rank's rows and ``gid``, their positions in the level's global order; ``assemble_partitioned_level``
+    puts the pieces of all ranks together."""
+    from . import hem as _hem
+    dev = device if device is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
+    n_global = int(cloud["xyz"].shape[0])
+    idx = owned if owned is not None else slab_of(cloud["xyz"], comm.rank, comm.world)
+    take = lambda a: a[idx]
+    import contextlib
+    # a caller-provided mixture context keeps its workspaces from call to call (no allocation in steady state)
+    with (contextlib.nullcontext(mixture) if mixture is not None else _hem.HemMixture(device=dev, **hem_params)) as m:
+        if mixture is not None:
+            m.set_rng(hem_params.get("rng_mode", "glibc"), hem_params.get("rng_seed", 1), hem_params.get("rng_skip", 0))
+        m.set_comm(comm)
+        m.set_level0_part(take(cloud["xyz"]), take(cloud["color"]), take(cloud["opacity"]), take(cloud["cov6"]), take(cloud["sh"]), idx, n_global)
+        pieces, stats = [], []
+        for _ in range(int(cluster_level)):
+            m.run_level()
+            st = m.stats()
+            st.update(m.part_stats())
+            stats.append(st)
+            piece = m.get_level(as_torch=as_torch)
+            piece["gid"] = m.gids()
+            pieces.append(piece)
+        m.set_comm(None)
+        return pieces, stats
+
+
+def assemble_partitioned_level(pieces_of_all_ranks):
+    """The global level out of every rank's piece (host arrays): row gid[k] of the result = row k of the piece."""
+    n = sum(len(p["gid"]) for p in pieces_of_all_ranks)
+    out = {}
+    for f in ("xyz", "color", "cov6", "opacity", "sh"):
+        first = np.asarray(pieces_of_all_ranks[0][f])
+        full = np.empty((n,) + first.shape[1:], first.dtype)
+        for p in pieces_of_all_ranks:
+            full[np.asarray(p["gid"], np.int64)] = np.asarray(p[f])
+        out[f] = full
+    return out

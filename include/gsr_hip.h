@@ -143,6 +143,27 @@ typedef int32_t (*gsr_allgather_dev_fn)(const void* dev_send, void* dev_recv, in
 int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_allreduce_dev_fn allreduce,
                           gsr_allgather_dev_fn allgather, void* user);
 
+/* SPATIALLY PARTITIONED levels for one large cloud on several GPUs (BASELINE config 5; the reference has no
+ * such thing).  Every rank owns a subset of the cloud -- a slab along the longest axis keeps the halo small, but any disjoint
+ * cover works -- and passes its components with their GLOBAL indices (ascending) to gsr_hem_set_level0_part; gsr_hem_run_level
+ * then runs the level on owned + ghost components and the result is BIT FOR BIT the single-GPU level, distributed: per level
+ *   - integer all-reduces of the bounding box (24 bytes), the axis histograms (12 KB) and two bit maps over the level's global
+ *     indices (n_global / 4 bytes): every rank derives the same grid and the same global output ranks;
+ *   - one all-gather of a bit mask over the grid's cells (which cells do my parents' search spheres touch) and ONE personalised
+ *     exchange of halo rows (64 + 4F + 8 bytes per component that another rank's parents may reach);
+ *   - five small exchanges along the same halo lists for the per-child sums: maxima (u32), the owners' maxima back, 64-bit
+ *     fixed-point partial sums, the owners' float32 sums back -- no floating-point value is ever combined across ranks.
+ * The new level stays distributed (gsr_hem_get_level returns the owned rows, gsr_hem_get_gids their global indices; ownership
+ * follows the parents).  All of it goes through the communicator: RCCL enqueued on the context's stream, or callbacks. */
+int32_t gsr_hem_set_comm(gsr_hem_ctx* ctx, gsr_comm* comm);
+int32_t gsr_hem_set_level0_part(gsr_hem_ctx* ctx, const float* xyz, const float* color, const float* cov6, const float* opacity,
+                                const float* sh, const uint32_t* gid, int64_t n_own, int64_t n_global, int32_t F, int32_t on_device);
+int32_t gsr_hem_get_gids(gsr_hem_ctx* ctx, uint32_t* gid, int32_t on_device);
+/* of the most recent partitioned level: [0] ghost components received  [1] halo rows sent  [2] bytes received in the halo exchange
+ * [3] bytes received in the five sum exchanges  [4] parents of the level over all ranks  [5] orphans over all ranks
+ * [6] components erased over all ranks  [7] components of the CURRENT level over all ranks */
+int32_t gsr_hem_get_part_stats(gsr_hem_ctx* ctx, int64_t* out8);
+
 /* One clustering level on the current level (Mixture::createClusterLevel, mixture.cpp:66-285).
  * n_out = components of the new level (after the validity erase); n_dropped = components erased by
  * it (the reference prints these to cerr, mixture.cpp:270-274).  The new level becomes current. */

@@ -56,11 +56,11 @@ def test_mixture_level_marshalling_and_errors():
 def test_do_icp_registration_argument_forms():
     with pytest.raises(TypeError):
         lru.do_icp_registration(None, None, np.eye(4), LocalRegistrationType.ICP_Point_To_Point, 1.0)
-    # every registration type has an estimator now; a cloud without normals / colours is refused like Open3D does
+    # every registration type has an estimator now; a cloud without normals / colours is refused like Open3D does (Generalized ICP
+    # derives missing covariances from normals on the device -- tests/test_icp_gpu.py)
     from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
     pc = PointCloud(xyz32=np.zeros((4, 3), np.float32))
-    for rt, msg in ((LocalRegistrationType.ICP_Color, "normal"), (LocalRegistrationType.ICP_General, "covariances"),
-                    (LocalRegistrationType.ICP_Point_To_Plane, "normal")):
+    for rt, msg in ((LocalRegistrationType.ICP_Color, "normal"), (LocalRegistrationType.ICP_Point_To_Plane, "normal")):
         p = LocalRegistrationParams(registration_type=rt)
         with pytest.raises(RuntimeError, match=msg):
             lru.do_icp_registration(pc, pc, np.eye(4), p)

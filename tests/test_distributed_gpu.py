@@ -61,6 +61,17 @@ def _worker(rank, world, port, q, what):
         r = parallel.registration_icp_sharded(tiny_g, t, 0.25, np.eye(4), lru.get_estimation(lru.LocalRegistrationType.ICP_General, lru.RobustLoss(0)),
                                               lru.get_convergence_criteria(1e-7, 1e-7, 3), rank, world, device=0, comm=cm)
         out["tiny_gicp"] = (r.transformation, r.fitness, r.inlier_rmse, r.iterations)
+    elif what == "part":
+        from gaussiansplattingregistration_amd.comm import Comm
+        cm = Comm.from_torch_group(0)
+        for tag, c in (("iso", synth.make_cloud(60000, seed=61, sh_degree=1)), ("aniso", synth.make_cloud(40000, seed=62, sh_degree=0, shape="aniso"))):
+            if tag == "iso":                                   # a far-away giant: a long-range parent whose sphere crosses every slab
+                c["xyz"][7] = [9.0, 0.5, -0.5]; c["cov6"][7] = [4.0, 0, 0, 3.0, 0, 2.0]
+                c["cov6"][11] = [1.0, 0, 0, 1.0, 0, -1.0]        # and a component the validity erase drops (det <= 0)
+            pieces, st = parallel.hem_partitioned(c, 3, cm, device=0)
+            out[tag] = [{k: v for k, v in p.items()} for p in pieces]
+            out[tag + "_stats"] = [{k: s[k] for k in ("parents", "pairs", "orphans", "dropped", "ghosts", "rows_sent", "halo_bytes_received", "sum_exchange_bytes_received",
+                                                      "parents_global", "orphans_global", "dropped_global", "n_global")} for s in st]
     else:
         c = synth.make_cloud(40000, seed=51, sh_degree=1)
         levels, st = parallel.hem_sharded(c, 2, rank, world, device=0)
@@ -75,7 +86,7 @@ def _worker(rank, world, port, q, what):
 def _run(what, world=2):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + (7 if what == "icp" else 13)
+    port = 29500 + (os.getpid() % 2000) + {"icp": 7, "part": 23}.get(what, 13)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, what)) for r in range(world)]
     for p in procs:
         p.start()
@@ -134,3 +145,35 @@ def test_two_process_sharded_hem_equals_single_context():
                 assert np.abs(a - b).max() / (np.abs(b).max() + 1e-30) < 1e-5, (r, k, f)
                 assert np.array_equal(res[r]["levels"][k][f], res[0]["levels"][k][f])        # identical on every rank
     assert res[0]["pairs"][0] + res[1]["pairs"][0] == wst[0]["pairs"]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_spatially_partitioned_hem_is_bit_identical_to_one_gpu(world):
+    """BASELINE config 5's partition with the real kernels: `world` processes, each owning one slab of the
+    cloud, exchange halo rows and integer partial sums through the library's communicator (callback transport: the ranks
+    share the test box's GPU); three levels.  Assembled by global index, every level equals the single-context level BIT FOR
+    BIT -- positions, colours, covariances, opacities, SH -- on an isotropic cloud with a long-range parent (its search sphere
+    crosses every slab) and an erased component, and on the anisotropic cloud (thousands of orphans).  A rank receives a
+    fraction of the cloud as ghosts, not all of it."""
+    from gaussiansplattingregistration_amd import hem, parallel, synth
+    res = _run("part", world)
+    for tag, c in (("iso", synth.make_cloud(60000, seed=61, sh_degree=1)), ("aniso", synth.make_cloud(40000, seed=62, sh_degree=0, shape="aniso"))):
+        if tag == "iso":
+            c["xyz"][7] = [9.0, 0.5, -0.5]; c["cov6"][7] = [4.0, 0, 0, 3.0, 0, 2.0]
+            c["cov6"][11] = [1.0, 0, 0, 1.0, 0, -1.0]
+        want, wst = hem.create_mixture(c, 3)
+        for k in range(3):
+            got = parallel.assemble_partitioned_level([res[r][tag][k] for r in range(world)])
+            gids = np.sort(np.concatenate([res[r][tag][k]["gid"] for r in range(world)]))
+            assert np.array_equal(gids, np.arange(want[k]["xyz"].shape[0])), (tag, k, len(gids), want[k]["xyz"].shape[0])
+            for f in ("xyz", "color", "cov6", "opacity", "sh"):
+                assert np.array_equal(got[f], want[k][f]), (tag, k, f)
+            st = [res[r][tag + "_stats"][k] for r in range(world)]
+            assert sum(s["parents"] for s in st) == wst[k]["parents"] == st[0]["parents_global"]
+            assert sum(s["pairs"] for s in st) == wst[k]["pairs"] and sum(s["orphans"] for s in st) == wst[k]["orphans"] == st[0]["orphans_global"]
+            assert sum(s["dropped"] for s in st) == wst[k]["dropped"] == st[0]["dropped_global"]
+            assert all(s["n_global"] == want[k]["xyz"].shape[0] for s in st)
+        if tag == "iso":
+            assert wst[0]["dropped"] >= 1
+            n0 = 60000
+            assert all(0 < res[r][tag + "_stats"][0]["ghosts"] < 0.8 * n0 for r in range(world))

@@ -700,3 +700,22 @@ def test_survey_known_answers_on_the_gpu():
     want = ka["counts_only"]["n200000_h1.5_seed0"]
     assert lv[0]["xyz"].shape[0] == want[0]
     assert abs(lv[1]["xyz"].shape[0] - want[1]) <= 3 and abs(lv[2]["xyz"].shape[0] - want[2]) <= 3
+
+
+def test_partitioned_level_with_one_rank_equals_the_plain_level():
+    """The code path of the spatially partitioned level (grid from all-reduced box / histograms, sort in global-index order, split
+    per-child sums, global ranks from bit maps, flags at global ranks) with a ONE-rank RCCL communicator -- every collective goes
+    through librccl on the box's GPU: bit for bit the plain level, three levels, also with erased components."""
+    from gaussiansplattingregistration_amd import hem, parallel, synth
+    from gaussiansplattingregistration_amd.comm import Comm
+    c = synth.make_cloud(80000, seed=71, sh_degree=2)
+    c["cov6"][5] = [1.0, 0, 0, 1.0, 0, -1.0]
+    want, wst = hem.create_mixture(c, 3)
+    with Comm.rccl(Comm.unique_id(), 0, 1, 0) as cm:
+        pieces, st = parallel.hem_partitioned(c, 3, cm, device=0)
+    for k in range(3):
+        assert np.array_equal(pieces[k]["gid"], np.arange(want[k]["xyz"].shape[0]))
+        for f in ("xyz", "color", "cov6", "opacity", "sh"):
+            assert np.array_equal(pieces[k][f], want[k][f]), (k, f)
+        assert (st[k]["parents"], st[k]["pairs"], st[k]["orphans"], st[k]["dropped"]) == (wst[k]["parents"], wst[k]["pairs"], wst[k]["orphans"], wst[k]["dropped"])
+        assert st[k]["ghosts"] == 0 and st[k]["n_global"] == want[k]["xyz"].shape[0]
