@@ -76,7 +76,59 @@ for k, v in pmc.items():
         e["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
     out[k] = e
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1, sort_keys=True)
-for name in ("bench.json", "bench_prof.json", "pytest_gpu.log", "smoke.log"):
+
+
+def pmc_set(dirs, prefix, command, fetch_dir):
+    """Per-kernel per-launch counter averages of one group of --pmc passes (the same layout as <dst>_pmc.json)."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    nl = collections.defaultdict(int)
+    for d in dirs:
+        for fn in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+            seen_ = set()
+            for r in csv.DictReader(open(fn)):
+                k = short(r["Kernel_Name"])
+                if not k.startswith("gsr::"):
+                    continue
+                acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
+                key = (k, r["Dispatch_Id"])
+                if d == fetch_dir and key not in seen_:
+                    seen_.add(key); nl[k] += 1
+    if not acc:
+        return None
+    o = {"kernel_build": bench.kernel_build_id(), "command": command,
+         "note": "FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a streaming read, x1.0 of random 64-byte "
+                 "records, x0.67 of random 192-byte rows (profiles/r03_fetch_calibration.txt): raw and x2 figures are both given"}
+    for k, v in acc.items():
+        n_ = max(1, nl.get(k, 1))
+        e_ = {"launches_in_pass": n_}
+        for c_, val in v.items():
+            e_[c_ + "_per_launch"] = val / n_
+        if "FETCH_SIZE" in v:
+            e_["hbm_read_bytes_per_launch_raw"] = v["FETCH_SIZE"] * 1024 / n_
+            e_["hbm_read_bytes_per_launch_x2_corrected"] = v["FETCH_SIZE"] * 1024 * 2 / n_
+        if "WRITE_SIZE" in v:
+            e_["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024 / n_
+        if "TCC_HIT_sum" in v:
+            e_["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+        o[k] = e_
+    json.dump(o, open(dst + prefix, "w"), indent=1, sort_keys=True)
+    return dst + prefix
+
+
+pmc_set(("pmc_icp_fetch", "pmc_icp_write", "pmc_icp_l2", "pmc_icp_sq", "pmc_icp_sq2"), "_pmc_icp.json",
+        "scripts/prof_icp.py 5000000 2  (the bench's 4-level point-to-plane schedule on the HEM levels of a 5 M pair; per-launch averages "
+        "over ALL launches of a kernel, i.e. over the four levels)", "pmc_icp_fetch")
+pmc_set(("pmc_aniso_fetch", "pmc_aniso_write"), "_pmc_aniso.json",
+        "scripts/prof_hem.py 5000000 1 2 aniso  (level 1 of a 5 M surfel-shaped cloud)", "pmc_aniso_fetch")
+f = glob.glob(os.path.join(src, "icp_stats", "*", "*kernel_stats.csv"))
+if f:
+    rows = list(csv.DictReader(open(f[0])))
+    with open(dst + "_icp_kernel_stats.csv", "w") as o:
+        o.write("kernel,calls,total_ms,avg_us,pct\n")
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        for r in sorted(rows, key=lambda r: -float(r["TotalDurationNs"])):
+            o.write(f"{short(r['Name'])},{r['Calls']},{float(r['TotalDurationNs'])/1e6:.3f},{float(r['TotalDurationNs'])/int(r['Calls'])/1e3:.2f},{100*float(r['TotalDurationNs'])/tot:.2f}\n")
+for name in ("bench.json", "bench_prof.json", "bench_c2.json", "prof_icp.log", "pytest_gpu.log", "smoke.log"):
     p = os.path.join(src, name)
     if os.path.exists(p):
         shutil.copy(p, dst + "_" + name)
