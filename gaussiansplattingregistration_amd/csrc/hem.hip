@@ -1320,37 +1320,133 @@ __global__ __launch_bounds__(256) void k_join_parts(const int* __restrict__ nhea
 // touches with ONE global atomic each, and places the pairs on a second walk (L2 resident).  A bucket that overflows raises
 // *overflow; the caller then takes the exact path (histogram + scan of a compacted copy).
 #define PART_PPW 128
-__global__ __launch_bounds__(256) void k_partition(int P, const int64_t* __restrict__ seg, const unsigned* __restrict__ pcnt,
+#define PART_STAGE_PPW 112                       // parents per workgroup of the staged form (~60 pairs each: ~6.7 k pairs of the 8 192 that fit)
+#define PART_STAGE 8192                          // pairs a workgroup of k_partition<true> stages in LDS (64 KiB)
+#define PART_STAGE_T 1024
+#define PART_STAGE_MAX_BUCKETS 1536              // 8 bytes of LDS per bucket beside the stage: two workgroups per CU up to here
+// STAGED: the workgroup (512 threads, PART_STAGE_PPW parents) reads every pair ONCE into registers, ranks it inside its bucket
+// with an LDS atomic, lays the pairs out by bucket in LDS and writes every bucket's run with consecutive lanes on consecutive
+// addresses (runs of ~70 pairs instead of the 3-pair fragments of a 256-lane walk; the second read of the pair list is gone:
+// 0.99 -> see DESIGN.md 3 at the 5 M level).  A chunk with more than PART_STAGE pairs (heavy parents) takes the two-walk form.
+// The order of the pairs inside a bucket is arbitrary in both forms: k_bucket_sum adds integers.
+template <bool STAGED>
+__global__ __launch_bounds__(STAGED ? PART_STAGE_T : 256, STAGED ? 8 : 1) void k_partition(int P, const int64_t* __restrict__ seg, const unsigned* __restrict__ pcnt,
                                                    const unsigned* __restrict__ sc, const float* __restrict__ sw, int nb, int shift, unsigned cap,
                                                    unsigned* __restrict__ cursor, unsigned* __restrict__ o_child, float* __restrict__ o_wl,
                                                    int* __restrict__ overflow) {
+    constexpr int PPW = STAGED ? PART_STAGE_PPW : PART_PPW;
     extern __shared__ unsigned s_h[];
-    __shared__ unsigned long long s_off[PART_PPW + 1];       // exclusive prefix of the parents' pair counts (a heavy level: > 2^32 in one chunk is impossible, 64 bits anyway)
-    __shared__ long long s_seg[PART_PPW];
+    __shared__ unsigned long long s_off[PPW + 1];            // exclusive prefix of the parents' pair counts (a heavy level: > 2^32 in one chunk is impossible, 64 bits anyway)
+    __shared__ long long s_seg[PPW];
     __shared__ unsigned long long s_w0;
+    __shared__ unsigned s_ws[PART_STAGE_T / 64];
     for (int b = threadIdx.x; b < nb; b += blockDim.x) s_h[b] = 0u;
-    const int p0 = (int)blockIdx.x * PART_PPW;
-    const int np = P - p0 < PART_PPW ? P - p0 : PART_PPW;
+    const int p0 = (int)blockIdx.x * PPW;
+    const int np = P - p0 < PPW ? P - p0 : PPW;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x < PART_PPW) {
+    if (threadIdx.x < 128) {
         const int t = (int)threadIdx.x;
         unsigned long long cnt = t < np ? (unsigned long long)pcnt[p0 + t] : 0ull;
         if (t < np) s_seg[t] = seg[p0 + t];
         unsigned long long incl = cnt;
         for (int o = 1; o < 64; o <<= 1) { const unsigned long long v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
         if (wv == 0 && lane == 63) s_w0 = incl;
-        s_off[t + 1] = incl;                                  // wave 1's entries still lack wave 0's total
+        if (t < PPW) s_off[t + 1] = incl;                     // wave 1's entries still lack wave 0's total
     }
     if (threadIdx.x == 0) s_off[0] = 0ull;
     __syncthreads();
-    if (threadIdx.x >= 64 && threadIdx.x < PART_PPW) s_off[threadIdx.x + 1] += s_w0;
+    if (threadIdx.x >= 64 && threadIdx.x < PPW) s_off[threadIdx.x + 1] += s_w0;
     __syncthreads();
-    const unsigned long long total = s_off[PART_PPW];
+    const unsigned long long total = s_off[PPW];
+    auto pair_at = [&](unsigned long long f) -> long long {
+        int a = 0, b = PPW;                                    // last parent with s_off[parent] <= f
+        while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= f) a = m; else b = m; }
+        return s_seg[a] + (long long)(f - s_off[a]);
+    };
+    if (STAGED && total <= (unsigned long long)PART_STAGE) {
+        constexpr int IT = PART_STAGE / PART_STAGE_T;
+        unsigned* s_g = s_h + nb;                              // global slot of the bucket's run minus its LDS position
+        unsigned* st_c = s_g + nb;
+        float* st_w = reinterpret_cast<float*>(st_c + PART_STAGE);
+        const unsigned tot = (unsigned)total;
+        // the parent of every flat pair index as a byte table (in the not yet used wl stage): one LDS read per pair instead of a
+        // seven-step binary search (16 dependent searches per thread were 3/4 of this kernel's time)
+        unsigned char* s_par = reinterpret_cast<unsigned char*>(st_w);
+        for (int pp = wv; pp < np; pp += PART_STAGE_T / 64) {
+            const unsigned o = (unsigned)s_off[pp], cnt = (unsigned)s_off[pp + 1] - o;
+            for (unsigned k = lane; k < cnt; k += 64) s_par[o + k] = (unsigned char)pp;
+        }
+        __syncthreads();
+        if (threadIdx.x < PPW) s_seg[threadIdx.x] -= (long long)s_off[threadIdx.x];       // pair address = s_seg[parent] + flat index
+        __syncthreads();
+        unsigned ch[IT], slot[IT];
+        float wl[IT];
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const unsigned f = threadIdx.x + (unsigned)i * PART_STAGE_T;
+            ch[i] = 0u; wl[i] = 0.0f;
+            if (f < tot) { const long long at = s_seg[s_par[f]] + (long long)f; ch[i] = sc[at]; wl[i] = sw[at]; }
+        }
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const unsigned f = threadIdx.x + (unsigned)i * PART_STAGE_T;
+            // consecutive pairs of a parent mostly share their bucket: one LDS atomic per RUN of equal buckets in the wave (64 lanes on
+            // one LDS address would take 64 turns), the run's lanes take consecutive slots behind its head
+            const unsigned bk = f < tot ? ch[i] >> shift : 0xffffffffu;
+            const unsigned prev = __shfl_up(bk, 1, 64);
+            const bool head = lane == 0 || bk != prev;
+            const unsigned long long hm = __ballot(head);
+            const unsigned long long upto = (2ull << lane) - 1ull;            // bits 0..lane (lane 63: all)
+            const int hl = 63 - __clzll((long long)(hm & upto));
+            const unsigned long long above = hm & ~upto;
+            const int nxt = above ? __ffsll((long long)above) - 1 : 64;
+            unsigned base = 0u;
+            if (head && f < tot) base = atomicAdd(&s_h[bk], (unsigned)(nxt - lane));
+            base = __shfl(base, hl, 64);
+            slot[i] = base + (unsigned)(lane - hl);
+        }
+        __syncthreads();
+        // exclusive prefix of the bucket counts (thread t owns K consecutive buckets), one global atomic per touched bucket
+        const int K = (nb + PART_STAGE_T - 1) / PART_STAGE_T;
+        const int b0 = (int)threadIdx.x * K;
+        unsigned mine = 0u;
+        for (int k = 0; k < K; ++k) if (b0 + k < nb) mine += s_h[b0 + k];
+        unsigned incl = mine;
+        for (int o = 1; o < 64; o <<= 1) { const unsigned v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+        if (lane == 63) s_ws[wv] = incl;
+        __syncthreads();
+        unsigned before = incl - mine;
+        for (int w = 0; w < wv; ++w) before += s_ws[w];
+        for (int k = 0; k < K; ++k) {
+            const int b = b0 + k;
+            if (b >= nb) break;
+            const unsigned cnt = s_h[b];
+            s_h[b] = before;
+            if (cnt) {
+                const unsigned base = atomicAdd(&cursor[b], cnt);
+                if (base + cnt > cap || base + cnt < base) *overflow = 1;
+                s_g[b] = base - before;
+            }
+            before += cnt;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < IT; ++i) {
+            const unsigned f = threadIdx.x + (unsigned)i * PART_STAGE_T;
+            if (f < tot) { const unsigned pos = s_h[ch[i] >> shift] + slot[i]; st_c[pos] = ch[i]; st_w[pos] = wl[i]; }
+        }
+        __syncthreads();
+        for (unsigned pos = threadIdx.x; pos < tot; pos += PART_STAGE_T) {
+            const unsigned c = st_c[pos];
+            const unsigned bk = c >> shift;
+            const unsigned sl = s_g[bk] + pos;
+            if (sl < cap) { const size_t gp = (size_t)bk * cap + sl; o_child[gp] = c; o_wl[gp] = st_w[pos]; }
+        }
+        return;
+    }
     for (int pass = 0; pass < 2; ++pass) {
         for (unsigned long long f = threadIdx.x; f < total; f += blockDim.x) {
-            int a = 0, b = PART_PPW;                           // last parent with s_off[parent] <= f
-            while (b - a > 1) { const int m = (a + b) >> 1; if (s_off[m] <= f) a = m; else b = m; }
-            const long long at = s_seg[a] + (long long)(f - s_off[a]);
+            const long long at = pair_at(f);
             const unsigned ch = sc[at];
             const int bk = (int)(ch >> shift);
             const unsigned slot = atomicAdd(&s_h[bk], 1u);
@@ -1369,6 +1465,16 @@ __global__ __launch_bounds__(256) void k_partition(int P, const int64_t* __restr
             __syncthreads();
         }
     }
+}
+// one launch of the pair partition: the staged form where its LDS fits twice on a CU
+static inline void launch_partition(hipStream_t st, bool staged_ok, int P, const int64_t* seg, const unsigned* pcnt, const unsigned* sc, const float* sw, int nb,
+                                    int shift, unsigned cap, unsigned* cursor, unsigned* o_child, float* o_wl, int* overflow) {
+    if (staged_ok && nb <= PART_STAGE_MAX_BUCKETS)
+        hipLaunchKernelGGL(k_partition<true>, dim3(ceil_div(P, PART_STAGE_PPW)), dim3(PART_STAGE_T), (size_t)nb * 8 + (size_t)PART_STAGE * 8, st, P, seg, pcnt, sc, sw,
+                           nb, shift, cap, cursor, o_child, o_wl, overflow);
+    else
+        hipLaunchKernelGGL(k_partition<false>, dim3(ceil_div(P, PART_PPW)), dim3(256), (size_t)nb * 4, st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child,
+                           o_wl, overflow);
 }
 
 // per-child sum of wL_si, sequential in the (stable) sorted pair order (mixture.cpp:162)
@@ -1510,16 +1616,20 @@ __global__ __launch_bounds__(256) void k_orphan_flags(int64_t n, const float* __
     }
 }
 
-// flags back to INPUT order, where the output ranks are defined (mixture.cpp:169,250-253)
-__global__ __launch_bounds__(256) void k_flags_to_input_order(int64_t n, const unsigned* __restrict__ order,
-                                                              const int* __restrict__ pflag_sorted,
-                                                              const int* __restrict__ oflag_sorted,
-                                                              int* __restrict__ pflag_in, int* __restrict__ oflag_in) {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t i = order[j];
-        pflag_in[i] = pflag_sorted[j];
-        oflag_in[i] = oflag_sorted[j];
+// flags in INPUT order, where the output ranks are defined (mixture.cpp:169,250-253).  The parent flags were drawn in input order
+// (Level::is_parent; ghosts of a partitioned level are nobody's output here); only the orphans -- few -- travel back from their
+// sorted positions (scattering both flag arrays of all n components cost 0.17 ms and 0.33 GB of partial-line writes at 5 M).
+__global__ __launch_bounds__(256) void k_flags_in(int64_t n, int64_t n_own, const uint8_t* __restrict__ is_parent, int* __restrict__ pflag_in,
+                                                  int* __restrict__ oflag_in) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        pflag_in[i] = i < n_own && is_parent[i] ? 1 : 0;
+        oflag_in[i] = 0;
     }
+}
+__global__ __launch_bounds__(256) void k_orphans_to_input_order(int64_t n, const unsigned* __restrict__ order, const int* __restrict__ oflag_sorted,
+                                                                int* __restrict__ oflag_in) {
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x)
+        if (oflag_sorted[j]) oflag_in[order[j]] = 1;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2319,6 +2429,7 @@ struct gsr_hem_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t aux2 = nullptr;     // third stream: the SH rows are gathered into cell order (an HBM stream only the M-step needs)
     hipEvent_t ev_sh_fork = nullptr, ev_sh_join = nullptr;      // beside the selection (VALU / latency bound)
+    int sh_grid = 0;                // GSR_HEM_SH_GRID: workgroups of a forked k_gather_sh (0 = as many as in line)
     int sh_overlap = 0;             // GSR_HEM_SH_OVERLAP: where k_gather_sh runs (0 in line, 1 forked in the grid phase, 2 forked beside k_select)
     float rho = 3.0f, delta = 3.0f, kappa = 2.5f, tau = 1.0f;
     int rng_mode = GSR_RNG_GLIBC;
@@ -2342,6 +2453,7 @@ struct gsr_hem_ctx {
     DevBuf gid, gid_next, rec_loc, gid_loc, ghost_sh, ghost_src, perm, pown, ppos_own, inv, gmax, gacc, cmask, dflag, dpos, sent_idx, rows_send, rows_recv,
         xsend, xrecv, gbits, wcnt, wpre, grank, allflags, pcounts, pmatrix;
     int64_t part_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // ghosts, rows sent, bytes received in the halo exchange, bytes of the other exchanges, ...
+    bool partition_staged = true;   // k_partition<true>: pairs staged by bucket in LDS, read once (GSR_HEM_PARTITION=walk: the two-walk form)
     bool partition_fixed = true;    // bucket regions of fixed capacity filled straight from the segments (GSR_HEM_PARTITION=exact: histogram + scan)
     bool partition_overflowed = false;      // a region overflowed once: this context uses the exact partition from then on
     double partition_factor = 0.0;  // GSR_HEM_PARTITION_FACTOR: region capacity in multiples of the mean (test knob: < 1 forces the overflow path)
@@ -2584,13 +2696,15 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
-    if (const char* s = getenv("GSR_HEM_PARTITION")) c->partition_fixed = strcmp(s, "exact") != 0;
+    if (const char* s = getenv("GSR_HEM_SH_GRID")) c->sh_grid = atoi(s);
+    if (const char* s = getenv("GSR_HEM_PARTITION")) { c->partition_fixed = strcmp(s, "exact") != 0; c->partition_staged = strcmp(s, "walk") != 0; }
     if (const char* s = getenv("GSR_HEM_PARTITION_FACTOR")) c->partition_factor = atof(s);
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
-    (void)hipFuncSetAttribute((const void*)k_partition, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
+    (void)hipFuncSetAttribute((const void*)k_partition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
+    (void)hipFuncSetAttribute((const void*)k_partition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_STAGE_MAX_BUCKETS * 8 + PART_STAGE * 8);
     (void)hipFuncSetAttribute((const void*)k_part_max, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << 13);
     (void)hipFuncSetAttribute((const void*)k_part_acc, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     *out = c;
@@ -2969,11 +3083,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
             sst = c->aux2;
         }
+        int shg = stride_grid(n * (RSH >> 2));
+        if (fork && c->sh_grid > 0 && shg > c->sh_grid) shg = c->sh_grid;
         if (part)
-            hipLaunchKernelGGL(k_gather_sh2, dim3(stride_grid(n * (RSH >> 2))), blk, 0, sst, n, n_own, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(),
+            hipLaunchKernelGGL(k_gather_sh2, dim3(shg), blk, 0, sst, n, n_own, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(),
                                c->ghost_sh.as<float>(), c->shs.as<float>());
         else
-        hipLaunchKernelGGL(k_gather_sh, dim3(stride_grid(n * (RSH >> 2))), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
+        hipLaunchKernelGGL(k_gather_sh, dim3(shg), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
         if (fork) { GSR_HIP(hipEventRecord(c->ev_sh_join, c->aux2)); sh_pending = true; }
         return GSR_OK;
     };
@@ -3210,8 +3326,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
         (void)hipGetLastError();
         GSR_HIP(hipEventRecord(c->evm[2], st));
-        hipLaunchKernelGGL(k_partition, dim3(ceil_div(P, PART_PPW)), blk, (size_t)nbuckets * 4, st, P, seg, c->pcnt.as<unsigned>(), pc, pw,
-                           nbuckets, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
+        launch_partition(st, c->partition_staged, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
+                         c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
         GSR_HIP(hipGetLastError());
         GSR_HIP(hipEventRecord(c->evm[3], st));
         GSR_CHECKPOINT("pair partition (fixed capacity)");
@@ -3263,8 +3379,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
             GSR_HIP(hipMemsetAsync(overflow_flag, 0, 4, st));
             if (M > 0 && P > 0)
-                hipLaunchKernelGGL(k_partition, dim3(ceil_div(P, PART_PPW)), blk, (size_t)nbuckets * 4, st, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift,
-                                   cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
+                launch_partition(st, c->partition_staged, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
+                                 c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
             GSR_HIP(hipGetLastError());
             Collect q;
             q.n = 1; q.src[0] = overflow_flag; q.bytes[0] = 4;
@@ -3340,8 +3456,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(c->oslot.reserve(n * 8));
     int o_last = 0, o_flag = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        hipLaunchKernelGGL(k_flags_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), part ? c->pown.as<int>() : c->pflag.as<int>(), c->oflag.as<int>(),
-                           c->pflag_in.as<int>(), c->oflag_in.as<int>());
+        hipLaunchKernelGGL(k_flags_in, grd, blk, 0, st, n, n_own, L.is_parent.as<uint8_t>(), c->pflag_in.as<int>(), c->oflag_in.as<int>());
+        hipLaunchKernelGGL(k_orphans_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), c->oflag.as<int>(), c->oflag_in.as<int>());
         GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
         GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
         Collect q;

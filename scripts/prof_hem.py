@@ -19,3 +19,4 @@ for rep in range(reps):
         torch.cuda.synchronize(); dt = time.perf_counter() - t
         st = m.stats()
         print(f"rep{rep} L{l+1}: wall {dt*1e3:.2f} ms", {k: (round(v, 3) if isinstance(v, float) else v) for k, v in st.items()}, flush=True)
+        print(f"rep{rep} L{l+1} kernels:", " ".join(f"{k[5:]} {st[k]:.3f}" for k in st if k.startswith("ms_k_")), f"level {st['ms_level']:.3f}", flush=True)
