@@ -199,18 +199,26 @@ __device__ __forceinline__ void icp_consider(const float4 q, int j, double px, d
 // minimum of (d^2, input index), and the ring loop continues at ring 2 when the bound of ring 1 does not close.
 // Coarse-to-fine pair of the bench: -11 % at 185 k points, -13 % at 1.67 M.  On a converged fine level (max_corr ~ one
 // cell) the neighbour sits in the own cell and the block costs 2.3x: BLOCK = false keeps the ring loop from ring 0.
-template <bool BLOCK>
+// Measured and rejected on the coarse levels (185 k - 556 k source points, where the chip is not full): four lanes per query
+// (each a z-plane of the block; 1024-thread workgroups), nine rows' loads in flight per lane, and the wave staging the joined
+// candidate runs of its 64 neighbouring queries in LDS -- all slower (what they add in registers / LDS costs a
+// round of workgroups on the chip, and the kernel's time is its slowest wave, not its average one).
+template <int BLOCK>
 __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restrict__ cellStart,
-                                           const float4* __restrict__ Tq, double px, double py, double pz, double& best_d2) {
+                                           const float4* __restrict__ Tq, double px, double py, double pz, double& best_d2,
+                                           double bound2 = 1.0 / 0.0) {
+    // bound2: only a neighbour with d^2 < bound2 is of use to the caller (max_corr^2): the search starts from that bound instead of
+    // +inf, so a query with nothing in reach prunes its rings like one that has found something (the outliers of a coarse level
+    // walked all (2 rings + 1)^3 cells, one lane holding up its wave)
     int best = -1;
     unsigned best_i = 0xffffffffu;
-    double bd = 1.0 / 0.0;
-    if (!(px == px) || !(py == py) || !(pz == pz)) { best_d2 = bd; return -1; }
+    double bd = bound2;
+    if (!(px == px) || !(py == py) || !(pz == pz)) { best_d2 = 1.0 / 0.0; return -1; }
     const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
     // absolute slack of every geometric bound: ~500 ulp of the largest coordinate involved
     const double eps = 1e-13 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.ox) + fabs(g.oy) + fabs(g.oz) + g.c * (double)(g.gx + g.gy + g.gz));
     int r0 = 0;
-    if (BLOCK && g.rings >= 1) {
+    if (BLOCK == 1 && g.rings >= 1) {
         int rs[9], re[9];
         const int xa = cx - 1 > 0 ? cx - 1 : 0, xb = cx + 1 < g.gx - 1 ? cx + 1 : g.gx - 1;
 #pragma unroll
@@ -221,6 +229,7 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
             rs[t] = ok ? cellStart[rowbase + xa] : 0;
             re[t] = ok ? cellStart[rowbase + xb + 1] : 0;
         }
+        {
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             for (int j = rs[t]; j < re[t]; j += 4) {
@@ -233,6 +242,9 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
                 icp_consider(q3, j3, px, py, pz, bd, best, best_i);
             }
         }
+        }
+    }
+    if (BLOCK && g.rings >= 1) {
         double reach = 1.0 / 0.0;
         if (cx - 1 > 0) reach = fmin(reach, px - (g.ox + (double)(cx - 1) * g.c));
         if (cx + 1 < g.gx - 1) reach = fmin(reach, (g.ox + (double)(cx + 2) * g.c) - px);
@@ -305,7 +317,7 @@ __device__ __forceinline__ void icp_step_solve(const double* acc32, const IcpSta
 // nn_j[i] = sorted target position of the accepted nearest neighbour of source point i, or -1.  One thread per source
 // point: a search kernel with few registers (56 VGPRs, 8 waves per SIMD) in front of a streaming accumulate kernel.
 // (Measured and rejected: eight lanes per point with shuffle-combined partial searches -- 1.5x slower.)
-template <bool FROM_STATE, bool BLOCK>
+template <bool FROM_STATE, int BLOCK>
 __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restrict__ src, Xform X, const IcpState* __restrict__ st,
                                                 IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
                                                 double max_corr2, int* __restrict__ nn_j) {
@@ -323,7 +335,7 @@ __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restr
         const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
         const double pz = T[8] * x + T[9] * y + T[10] * z + T[11];
         double d2;
-        const int j = icp_nearest<BLOCK>(g, cellStart, Tq, px, py, pz, d2);
+        const int j = icp_nearest<BLOCK>(g, cellStart, Tq, px, py, pz, d2, max_corr2);
         nn_j[i] = (j >= 0 && d2 < max_corr2) ? j : -1;
     }
 }
@@ -630,7 +642,7 @@ __global__ __launch_bounds__(256) void k_icp_accumulate(int64_t ns, const float*
             if (j < 0) continue;
         } else {
             double dd;
-            j = icp_nearest<false>(g, cellStart, Tq, px, py, pz, dd);
+            j = icp_nearest<0>(g, cellStart, Tq, px, py, pz, dd, max_corr2);
             if (j < 0 || !(dd < max_corr2)) continue;
         }
         const float4 q = Tq[j];
@@ -1121,7 +1133,7 @@ __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]) {
 // (FUSE is a template parameter: the step's code costs the kernel ~24 VGPRs, and with them a wave per SIMD on the levels whose
 // blocks just fill the chip once; the bound of 3 waves per SIMD keeps the fused forms at <= 168 registers -- whatever does not
 // fit spills in the step's code, which one workgroup runs once)
-template <int KIND, bool BLOCK, int FUSE>
+template <int KIND, int BLOCK, int FUSE>
 __global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_accumulate_dev(int64_t ns, const float* __restrict__ src, IcpState* st,
                                                             IcpGrid g, const int* __restrict__ cellStart, const int* __restrict__ nn_j,
                                                             const float4* __restrict__ Tq, const double* __restrict__ Tn,
@@ -1152,7 +1164,7 @@ __global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_a
             if (j < 0) continue;
         } else {
             double dd;
-            j = icp_nearest<BLOCK>(g, cellStart, Tq, px, py, pz, dd);
+            j = icp_nearest<BLOCK>(g, cellStart, Tq, px, py, pz, dd, max_corr2);
             if (j < 0 || !(dd < max_corr2)) continue;
         }
         const float4 q = Tq[j];
@@ -1359,7 +1371,9 @@ struct gsr_icp_ctx {
     float ms_build = 0, ms_iter = 0;
     int n_iter_kernels = 0;
     int max_cells = 1 << 25;
-    int nblocks = 1024;
+    // workgroups of the search + accumulate kernel: three fit a CU (141 VGPRs), 768 are ONE round on the chip.  With 1 024 the last
+    // 256 ran as a second, quarter-full round: 108 -> 95 us per iteration at 556 k source points (GSR_ICP_BLOCKS)
+    int nblocks = 768;
 };
 
 namespace {
@@ -1394,7 +1408,7 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     const int* nnj = nullptr;
     if (c->nn_mode()) {
         GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-        hipLaunchKernelGGL((k_icp_nn<false, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+        hipLaunchKernelGGL((k_icp_nn<false, 0>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
                            c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
         nnj = c->nn_j.as<int>();
     }
@@ -1482,6 +1496,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_FUSED_STEP")) c->fused_step = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->nblocks = v; }
     // pinned, device-mapped, COHERENT host memory: the device's system-scope stores must reach the host while the stream is still
     // running (a non-coherent mapping would only show them at the end of the kernel).  GSR_ICP_RB_POLL=0: no polling at all
     bool poll = true;
@@ -1802,15 +1817,15 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
                        c->ticket.as<unsigned>(), c->acc_dev.as<double>())
 #define GSR_ICP_ACC(KIND, TN, SC)                                                                                                    \
     do {                                                                                                                             \
-        if (blockf) { if (fuse == 0) GSR_ICP_ACC1(KIND, true, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, true, 1, TN, SC); else GSR_ICP_ACC1(KIND, true, 2, TN, SC); } \
-        else { if (fuse == 0) GSR_ICP_ACC1(KIND, false, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, false, 1, TN, SC); else GSR_ICP_ACC1(KIND, false, 2, TN, SC); } \
+        if (blockf) { if (fuse == 0) GSR_ICP_ACC1(KIND, 1, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, 1, 1, TN, SC); else GSR_ICP_ACC1(KIND, 1, 2, TN, SC); } \
+        else { if (fuse == 0) GSR_ICP_ACC1(KIND, 0, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, 0, 1, TN, SC); else GSR_ICP_ACC1(KIND, 0, 2, TN, SC); } \
     } while (0)
                 if (c->nn_mode()) {
                     if (blockf)
-                        hipLaunchKernelGGL((k_icp_nn<true, true>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
+                        hipLaunchKernelGGL((k_icp_nn<true, 1>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
                                            c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
                     else
-                        hipLaunchKernelGGL((k_icp_nn<true, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
+                        hipLaunchKernelGGL((k_icp_nn<true, 0>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
                                            c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
                 }
                 if (kind == GSR_ICP_COLORED) GSR_ICP_ACC(3, c->Tn.as<double>(), (const double*)nullptr);
@@ -1878,7 +1893,7 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
     GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-    hipLaunchKernelGGL((k_icp_nn<false, false>), dim3(nn_grid1(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+    hipLaunchKernelGGL((k_icp_nn<false, 0>), dim3(nn_grid1(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
                        c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
     hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->nn_j.as<int>(),
                        c->Tq.as<float4>(), c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->corr_idx.as<int64_t>(),

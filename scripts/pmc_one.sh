@@ -4,7 +4,7 @@
 set -uo pipefail
 OUT=${GRAFT_REPO_ROOT:?}/gpurun_out/$1; KSUB=$2; shift; shift; mkdir -p "$(dirname "$OUT")"
 SCRIPT=$(realpath "$1"); shift; cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --pmc ${PMC:-SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS} --output-format csv -d $OUT -- python3 "$SCRIPT" "$@" > $OUT.log 2>&1; tail -3 $OUT.log
+timeout 300 rocprofv3 --kernel-trace --pmc ${PMC:-SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS} --output-format csv -d $OUT -- python3 "$SCRIPT" "$@" > $OUT.log 2>&1; tail -3 $OUT.log
 cd "${GRAFT_REPO_ROOT:?}"
 python3 - "$OUT" "$KSUB" <<'PY'
 import csv, glob, sys, collections
