@@ -217,7 +217,7 @@ def step_c5(lru, ctxs, big, tgt, device, sync, rank, world, comm=None, owned=Non
     t0 = time.perf_counter()
     if world > 1:
         pieces, st = parallel.hem_partitioned(big, LEVELS, comm, device=device, as_torch=True, owned=owned, mixture=ctxs["hem"], rng_mode="glibc")
-        idx = owned if owned is not None else parallel.slab_of(big["xyz"], rank, world)
+        idx = owned if owned is not None else parallel.block_of(big["xyz"], rank, world)
         src_list = [PointCloud(xyz32=big["xyz"][idx].contiguous(), cov6=big["cov6"][idx].contiguous())] + [PointCloud(xyz32=p["xyz"], cov6=p["cov6"]) for p in pieces]
         sizes = [int(big["xyz"].shape[0])] + [int(s["n_global"]) for s in st]
         for s_ in st:
@@ -394,7 +394,7 @@ def main():
     comm = Comm.from_torch_group(device) if (world > 1 and a.mode in ("c4", "c5")) else None
     if a.mode == "c5":
         ctxs["hem2"] = hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS)       # the replicated target's levels
-    owned = parallel.slab_of(src["xyz"], rank, world) if (a.mode == "c5" and world > 1) else None
+    owned = parallel.block_of(src["xyz"], rank, world) if (a.mode == "c5" and world > 1) else None
 
     def one_step():
         if a.mode == "c4":

@@ -144,7 +144,7 @@ int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_all
                           gsr_allgather_dev_fn allgather, void* user);
 
 /* SPATIALLY PARTITIONED levels for one large cloud on several GPUs (BASELINE config 5; the reference has no
- * such thing).  Every rank owns a subset of the cloud -- a slab along the longest axis keeps the halo small, but any disjoint
+ * such thing).  Every rank owns a subset of the cloud -- compact blocks keep the halo small (parallel.block_of), but any disjoint
  * cover works -- and passes its components with their GLOBAL indices (ascending) to gsr_hem_set_level0_part; gsr_hem_run_level
  * then runs the level on owned + ghost components and the result is BIT FOR BIT the single-GPU level, distributed: per level
  *   - integer all-reduces of the bounding box (24 bytes), the axis histograms (12 KB) and two bit maps over the level's global

@@ -71,3 +71,25 @@ def test_two_rank_source_split_equals_single_process(hip_lib, oracle):
     src, tgt, T_gt = synth.make_pair(3000, seed=3, sh_degree=0)
     want = oracle.icp(src["xyz"], tgt["xyz"], None, np.eye(4), kind=0, max_corr=0.25, max_iter=6, rel_fitness=0, rel_rmse=0)
     assert np.linalg.norm(res[0][1] - want["transformation"]) < 1e-9
+
+
+def test_block_partition_covers_the_cloud_once():
+    """parallel.block_of / slab_of: every component belongs to exactly one rank, counts differ by at most one per cut, numpy and
+    torch inputs give the same cut, and the blocks are boxes (8 ranks: 2 x 2 x 2; the halo of a block is 40 % of its own components
+    at 40 M splats where a slab's is 99 %, scripts/halo_estimate.py)."""
+    import torch
+    from gaussiansplattingregistration_amd import parallel
+    assert [parallel.block_dims(w) for w in (1, 2, 3, 4, 6, 8, 16)] == [(1, 1, 1), (2, 1, 1), (3, 1, 1), (2, 2, 1), (3, 2, 1), (2, 2, 2), (4, 2, 2)]
+    rng = np.random.default_rng(3)
+    x = (rng.uniform(-1, 1, (5003, 3)) * [3.0, 2.0, 1.0]).astype(np.float32)
+    for fn in (parallel.block_of, parallel.slab_of):
+        for w in (1, 2, 3, 4, 8):
+            parts = [fn(x, r, w) for r in range(w)]
+            assert np.array_equal(np.sort(np.concatenate(parts)), np.arange(5003))
+            assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 3
+            assert all(np.array_equal(fn(torch.from_numpy(x), r, w).numpy(), parts[r]) for r in range(w))
+    parts = [parallel.block_of(x, r, 8) for r in range(8)]
+    boxes = [(x[p].min(0), x[p].max(0)) for p in parts]
+    for a in range(8):
+        for b in range(a + 1, 8):      # two blocks are separated along at least one axis
+            assert any(boxes[a][1][k] <= boxes[b][0][k] or boxes[b][1][k] <= boxes[a][0][k] for k in range(3)), (a, b)

@@ -147,10 +147,10 @@ def test_two_process_sharded_hem_equals_single_context():
     assert res[0]["pairs"][0] + res[1]["pairs"][0] == wst[0]["pairs"]
 
 
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_spatially_partitioned_hem_is_bit_identical_to_one_gpu(world):
-    """BASELINE config 5's partition with the real kernels: `world` processes, each owning one slab of the
-    cloud, exchange halo rows and integer partial sums through the library's communicator (callback transport: the ranks
+    """BASELINE config 5's partition with the real kernels: `world` processes, each owning one block of the
+    cloud (parallel.block_of: slabs for 2 and 3 ranks, 2 x 2 columns for 4), exchange halo rows and integer partial sums through the library's communicator (callback transport: the ranks
     share the test box's GPU); three levels.  Assembled by global index, every level equals the single-context level BIT FOR
     BIT -- positions, colours, covariances, opacities, SH -- on an isotropic cloud with a long-range parent (its search sphere
     crosses every slab) and an erased component, and on the anisotropic cloud (thousands of orphans).  A rank receives a
