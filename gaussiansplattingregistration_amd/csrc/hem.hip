@@ -271,8 +271,12 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
     }
 }
 // bbox[0..2] = min, bbox[3..5] = max over the per-block partial boxes (order-preserving uint encoding)
-__global__ __launch_bounds__(256) void k_bbox_reduce(int nblocks, const unsigned* __restrict__ part, unsigned* __restrict__ bbox) {
+// (also clears the level's counters and the axis histograms: two memset launches less per level)
+__global__ __launch_bounds__(256) void k_bbox_reduce(int nblocks, const unsigned* __restrict__ part, unsigned* __restrict__ bbox,
+                                                     unsigned* __restrict__ zero_a, int na, unsigned* __restrict__ zero_b, int nzb) {
     __shared__ unsigned s_v[4][6];
+    for (int i = threadIdx.x; i < na; i += blockDim.x) zero_a[i] = 0u;
+    for (int i = threadIdx.x; i < nzb; i += blockDim.x) zero_b[i] = 0u;
     unsigned v[6];
     for (int k = 0; k < 3; ++k) { v[k] = 0xffffffffu; v[3 + k] = 0u; }
     for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
@@ -498,8 +502,9 @@ __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __re
 // before it).  ppos = exclusive scan of pflag; P = its total.
 __global__ __launch_bounds__(256) void k_child_stream(int64_t n, int64_t cells, int P, const float4* __restrict__ A, const int* __restrict__ pflag,
                                                       const int* __restrict__ ppos, const int* __restrict__ cellStart,
-                                                      float4* __restrict__ Ac, int* __restrict__ cellStartC) {
+                                                      float4* __restrict__ Ac, int* __restrict__ cellStartC, int pad) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t t = t0; t < pad; t += stride) Ac[(n - P) + t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // the pad k_select reads past the last row
     for (int64_t j = t0; j < n; j += stride) {
         if (pflag[j]) continue;
         const float4 a = A[j];
@@ -2507,11 +2512,12 @@ const unsigned* rng_xpow_table() {
 }
 
 // draw n parent flags in order into dst (consumes n hem::rand() values)
-int32_t draw_flags_raw(gsr_hem_ctx* c, int64_t n, uint8_t* dst) {
+int32_t draw_flags_raw(gsr_hem_ctx* c, int64_t n, uint8_t* dst, hipStream_t on = nullptr) {
+    const hipStream_t fst = on ? on : c->stream;
     const float prob = 1.0f / c->rho;
     if (n == 0) return GSR_OK;
     if (c->rng_mode == GSR_RNG_HASH) {
-        hipLaunchKernelGGL(k_flags_hash, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, c->rng_seed,
+        hipLaunchKernelGGL(k_flags_hash, dim3(stride_grid(n)), dim3(256), 0, fst, n, c->rng_seed,
                            (unsigned long long)c->rng_pos, prob, dst);
         c->rng_pos += (uint64_t)n;
         return GSR_OK;
@@ -2552,9 +2558,9 @@ int32_t draw_flags_raw(gsr_hem_ctx* c, int64_t n, uint8_t* dst) {
     }
     const int64_t nblocks = (n + RNG_BLOCK_ELEMS - 1) / RNG_BLOCK_ELEMS;
     GSR_TRY(c->rng_blocks.reserve((size_t)nblocks * 64 * 4));
-    hipLaunchKernelGGL(k_rng_block_state, dim3((unsigned)nblocks), dim3(64), 0, c->stream, (unsigned long long)c->rng_pos,
+    hipLaunchKernelGGL(k_rng_block_state, dim3((unsigned)nblocks), dim3(64), 0, fst, (unsigned long long)c->rng_pos,
                        c->draws.as<unsigned>(), c->rng_blocks.as<unsigned>());
-    hipLaunchKernelGGL(k_flags_glibc, dim3((unsigned)nblocks), dim3(RNG_THREADS), 0, c->stream, n, prob, c->draws.as<unsigned>(),
+    hipLaunchKernelGGL(k_flags_glibc, dim3((unsigned)nblocks), dim3(RNG_THREADS), 0, fst, n, prob, c->draws.as<unsigned>(),
                        c->rng_blocks.as<unsigned>(), dst);
     c->rng_pos += (uint64_t)n;
     return GSR_OK;
@@ -2975,18 +2981,16 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
     GSR_TRY(c->rec.reserve(n * 64)); GSR_TRY(c->bbox.reserve(64));
     GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(64));
-    GSR_HIP(hipMemsetAsync(c->counters.p, 0, 64, st));
-    GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 6 * 4));
+    GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 6 * 4)); GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
     hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
                        L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>());
-    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>());
+    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>(),
+                       c->counters.as<unsigned>(), 16, c->hist.as<unsigned>(), 3 * HIST_BINS);
     if (part) {     // the box of ALL ranks' components: maximum of the (order-preserving) codes, the minima complemented
         hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
         GSR_TRY(gsr_comm_allreduce(c->comm, c->bbox.p, 6, GSR_DT_U32, GSR_OP_MAX, (void*)st));
         hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
     }
-    GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
-    GSR_HIP(hipMemsetAsync(c->hist.p, 0, 3 * HIST_BINS * 4, st));
     hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>());
     if (part) GSR_TRY(gsr_comm_allreduce(c->comm, c->hist.p, 3 * HIST_BINS, GSR_DT_U32, GSR_OP_SUM, (void*)st));      // integer counts: exact
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), part ? c->n_global : n, c->cell_target,
@@ -3124,9 +3128,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     c->stats_ex[0] = n_irr;
     // the candidate stream of pass A (non-parents only) and its prefix table
     GSR_TRY(c->Ac.reserve(((size_t)(n - P_all) + SEL_PAD) * 16)); GSR_TRY(c->cellStartC.reserve(((size_t)gp.ncells + 1) * 4));
-    GSR_HIP(hipMemsetAsync((char*)c->Ac.p + (size_t)(n - P_all) * 16, 0, (size_t)SEL_PAD * 16, st));      // the pad k_select reads past the last row
     hipLaunchKernelGGL(k_child_stream, grd, blk, 0, st, n, (int64_t)gp.ncells, P_all, c->A.as<float4>(), c->pflag.as<int>(), c->ppos.as<int>(),
-                       c->cellStart.as<int>(), c->Ac.as<float4>(), c->cellStartC.as<int>());
+                       c->cellStart.as<int>(), c->Ac.as<float4>(), c->cellStartC.as<int>(), (int)SEL_PAD);
     GSR_CHECKPOINT("grid + gather");
     GSR_HIP(hipEventRecord(c->ev[1], st));
 
@@ -3485,6 +3488,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     Level& O = c->nxt;
     GSR_TRY(O.reserve(n_pre, F));
     O.n = n_pre; O.F = F;
+    // the new level's parent flags depend on nothing but the stream position and n_pre: drawn on the second stream beside the
+    // M-step (the jump to the stream position is a fixed ~40 us chain, 5 % of a 200 k-splat level)
+    bool flags_forked = false;
+    if (!part && c->aux && n_pre > 0) {
+        GSR_HIP(hipEventRecord(c->ev_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        GSR_TRY(draw_flags_raw(c, n_pre, O.is_parent.as<uint8_t>(), c->aux));
+        GSR_HIP(hipEventRecord(c->ev_join, c->aux));
+        flags_forked = true;
+    }
     if (!sh_launched) { GSR_TRY(launch_gather_sh(false)); sh_launched = true; }                       // (a level without parents)
     if (sh_pending) { GSR_HIP(hipStreamWaitEvent(st, c->ev_sh_join, 0)); sh_pending = false; }      // the sorted SH rows are needed from here on
     if (P > 0) {
@@ -3597,8 +3609,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(draw_flags_raw(c, n_pre_glob, c->allflags.as<uint8_t>()));
         if (n_pre > 0)
             hipLaunchKernelGGL(k_gather_bytes, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->gid_next.as<unsigned>(), c->allflags.as<uint8_t>(), O.is_parent.as<uint8_t>());
-    } else
-    GSR_TRY(draw_flags(c, O));
+    } else if (flags_forked) {
+        GSR_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+    } else {
+        GSR_TRY(draw_flags(c, O));
+    }
     int64_t dropped = 0;
     if (n_pre > 0) {
         GSR_TRY(c->keep.reserve(n_pre * 4)); GSR_TRY(c->kpos.reserve(n_pre * 4));
