@@ -154,7 +154,11 @@ int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_all
  *   - five small exchanges along the same halo lists for the per-child sums: maxima (u32), the owners' maxima back, 64-bit
  *     fixed-point partial sums, the owners' float32 sums back -- no floating-point value is ever combined across ranks.
  * The new level stays distributed (gsr_hem_get_level returns the owned rows, gsr_hem_get_gids their global indices; ownership
- * follows the parents).  All of it goes through the communicator: RCCL enqueued on the context's stream, or callbacks. */
+ * follows the parents).  All of it goes through the communicator: RCCL enqueued on the context's stream, or callbacks.
+ * ERRORS ARE LOCAL: a rank whose call fails (an allocation, a callback returning non-zero) returns its error code while the
+ * other ranks are inside or in front of the next collective -- as with any RCCL program the caller must then abort the process
+ * group (ncclCommAbort / tear the job down); the library does not try to agree on a status across ranks.  The same holds for
+ * gsr_icp_register with a communicator or an all-reduce callback. */
 int32_t gsr_hem_set_comm(gsr_hem_ctx* ctx, gsr_comm* comm);
 int32_t gsr_hem_set_level0_part(gsr_hem_ctx* ctx, const float* xyz, const float* color, const float* cov6, const float* opacity,
                                 const float* sh, const uint32_t* gid, int64_t n_own, int64_t n_global, int32_t F, int32_t on_device);
