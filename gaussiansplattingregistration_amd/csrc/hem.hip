@@ -476,6 +476,7 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
         __builtin_amdgcn_wave_barrier();
     }
 }
+struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };      // a float4 at a 4-byte aligned address (gfx950 loads it with one dwordx4)
 // shs rows: the F SH-rest coefficients of the component, zero padded to RSH = whole float4.  One thread per float4.
 __global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, int RSH, const unsigned* __restrict__ order,
                                                    const float* __restrict__ sh, float* __restrict__ shs) {
@@ -487,7 +488,12 @@ __global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, int RSH, co
         const float* src = sh + (int64_t)order[j] * F + 4 * q;
         const int left = F - 4 * q;
         float4 v;
-        v.x = left > 0 ? src[0] : 0.0f; v.y = left > 1 ? src[1] : 0.0f; v.z = left > 2 ? src[2] : 0.0f; v.w = left > 3 ? src[3] : 0.0f;
+        if (left >= 4) {                 // rows of F floats are only 4-byte aligned: ONE unaligned 16-byte load instead of four dword loads
+            const f4u u = *reinterpret_cast<const f4u*>(src);
+            v = make_float4(u.x, u.y, u.z, u.w);
+        } else {
+            v.x = left > 0 ? src[0] : 0.0f; v.y = left > 1 ? src[1] : 0.0f; v.z = left > 2 ? src[2] : 0.0f; v.w = 0.0f;
+        }
         reinterpret_cast<float4*>(shs + j * RSH)[q] = v;
     }
 }
@@ -2176,7 +2182,12 @@ __global__ __launch_bounds__(256) void k_gather_sh2(int64_t n, int64_t n_own, in
         const float* src = (i < n_own ? sh_own + i * F : sh_ghost + (i - n_own) * F) + 4 * q;
         const int left = F - 4 * q;
         float4 v;
-        v.x = left > 0 ? src[0] : 0.0f; v.y = left > 1 ? src[1] : 0.0f; v.z = left > 2 ? src[2] : 0.0f; v.w = left > 3 ? src[3] : 0.0f;
+        if (left >= 4) {
+            const f4u u = *reinterpret_cast<const f4u*>(src);
+            v = make_float4(u.x, u.y, u.z, u.w);
+        } else {
+            v.x = left > 0 ? src[0] : 0.0f; v.y = left > 1 ? src[1] : 0.0f; v.z = left > 2 ? src[2] : 0.0f; v.w = 0.0f;
+        }
         reinterpret_cast<float4*>(shs + j * RSH)[q] = v;
     }
 }
@@ -2616,12 +2627,20 @@ int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n) {
     return GSR_OK;
 }
 
+// rocPRIM's Onesweep with its gfx950 kernel shapes but 10 bits per pass: the 19-bit cell keys of a 5 M level take two passes
+// instead of three (grid phase 1.21 -> 1.15 ms; 11 bits: no further gain).  Up to 2^20 keys rocPRIM's merge sort runs as before.
+#ifndef GSR_SORT_RADIX_BITS
+#define GSR_SORT_RADIX_BITS 10
+#endif
+using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                            rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, GSR_SORT_RADIX_BITS,
+                                                                                rocprim::block_radix_rank_algorithm::match>>;
 template <typename V>
 int32_t sort_pairs(gsr_hem_ctx* c, const unsigned* kin, unsigned* kout, const V* vin, V* vout, int64_t n, int end_bit) {
     size_t bytes = 0;
-    GSR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
+    GSR_HIP(rocprim::radix_sort_pairs<sort_cfg>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
     GSR_TRY(c->rocprim_tmp.reserve(bytes));
-    GSR_HIP(rocprim::radix_sort_pairs(c->rocprim_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
+    GSR_HIP(rocprim::radix_sort_pairs<sort_cfg>(c->rocprim_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
     return GSR_OK;
 }
 
