@@ -230,6 +230,8 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
     float4* st = s_t[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    unsigned n_par = 0u, n_irr = 0u;                // parents / irregular components seen by this thread (the level's P and the size of
+                                                    // pass B's list: read back with the grid, one host round trip less per level)
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t i = base + lane;
         if (i < n) {
@@ -237,6 +239,8 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
             const float dt = det6(c);
             float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
             const unsigned fl = (is_parent[i] ? 1u : 0u) | (is_regular(c, dt, x, y, z) ? 2u : 0u);   // bit 0 parent, bit 1 regular
+            n_par += fl & 1u;
+            n_irr += (fl & 2u) ? 0u : 1u;
             st[lane * 5] = make_float4(x, y, z, __uint_as_float(fl));
             st[lane * 5 + 1] = make_float4(c.e00, c.e01, c.e02, c.e11);
             st[lane * 5 + 2] = make_float4(c.e12, c.e22, color[3 * i], color[3 * i + 1]);
@@ -258,46 +262,58 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
     // per-block partial box, no atomics: 10^4 same-address atomics cost ~0.5 ms on this part (they serialise
     // across the XCDs); k_bbox_reduce folds the partials
     __shared__ float s_mn[4][3], s_mx[4][3];
+    __shared__ unsigned s_cnt[4][2];
     for (int k = 0; k < 3; ++k) { mn[k] = wave_min(mn[k]); mx[k] = wave_max(mx[k]); }
-    if ((threadIdx.x & 63) == 0)
+    for (int o = 32; o > 0; o >>= 1) { n_par += (unsigned)__shfl_xor((int)n_par, o); n_irr += (unsigned)__shfl_xor((int)n_irr, o); }
+    if ((threadIdx.x & 63) == 0) {
         for (int k = 0; k < 3; ++k) { s_mn[threadIdx.x >> 6][k] = mn[k]; s_mx[threadIdx.x >> 6][k] = mx[k]; }
+        s_cnt[threadIdx.x >> 6][0] = n_par; s_cnt[threadIdx.x >> 6][1] = n_irr;
+    }
     __syncthreads();
     if (threadIdx.x < 3) {
         const int k = threadIdx.x;
         float a = s_mn[0][k], b = s_mx[0][k];
         for (int w = 1; w < 4; ++w) { a = fminf(a, s_mn[w][k]); b = fmaxf(b, s_mx[w][k]); }
-        bbox_part[6 * blockIdx.x + k] = enc_f(a);
-        bbox_part[6 * blockIdx.x + 3 + k] = enc_f(b);
+        bbox_part[8 * blockIdx.x + k] = enc_f(a);
+        bbox_part[8 * blockIdx.x + 3 + k] = enc_f(b);
+    } else if (threadIdx.x < 5) {
+        const int k = threadIdx.x - 3;
+        bbox_part[8 * blockIdx.x + 6 + k] = s_cnt[0][k] + s_cnt[1][k] + s_cnt[2][k] + s_cnt[3][k];
     }
 }
 // bbox[0..2] = min, bbox[3..5] = max over the per-block partial boxes (order-preserving uint encoding)
 // (also clears the level's counters and the axis histograms: two memset launches less per level)
 __global__ __launch_bounds__(256) void k_bbox_reduce(int nblocks, const unsigned* __restrict__ part, unsigned* __restrict__ bbox,
                                                      unsigned* __restrict__ zero_a, int na, unsigned* __restrict__ zero_b, int nzb) {
-    __shared__ unsigned s_v[4][6];
+    __shared__ unsigned s_v[4][8];
     for (int i = threadIdx.x; i < na; i += blockDim.x) zero_a[i] = 0u;
     for (int i = threadIdx.x; i < nzb; i += blockDim.x) zero_b[i] = 0u;
-    unsigned v[6];
+    unsigned v[8];
     for (int k = 0; k < 3; ++k) { v[k] = 0xffffffffu; v[3 + k] = 0u; }
-    for (int b = threadIdx.x; b < nblocks; b += blockDim.x)
+    v[6] = v[7] = 0u;                                // bbox[6] = parents of the level, bbox[7] = irregular components (k_prep's counts)
+    for (int b = threadIdx.x; b < nblocks; b += blockDim.x) {
         for (int k = 0; k < 3; ++k) {
-            const unsigned lo = part[6 * b + k], hi = part[6 * b + 3 + k];
+            const unsigned lo = part[8 * b + k], hi = part[8 * b + 3 + k];
             v[k] = lo < v[k] ? lo : v[k];
             v[3 + k] = hi > v[3 + k] ? hi : v[3 + k];
         }
+        v[6] += part[8 * b + 6]; v[7] += part[8 * b + 7];
+    }
     for (int k = 0; k < 3; ++k)
         for (int o = 32; o > 0; o >>= 1) {
             const unsigned lo = (unsigned)__shfl_xor((int)v[k], o), hi = (unsigned)__shfl_xor((int)v[3 + k], o);
             v[k] = lo < v[k] ? lo : v[k];
             v[3 + k] = hi > v[3 + k] ? hi : v[3 + k];
         }
+    for (int k = 6; k < 8; ++k)
+        for (int o = 32; o > 0; o >>= 1) v[k] += (unsigned)__shfl_xor((int)v[k], o);
     if ((threadIdx.x & 63) == 0)
-        for (int k = 0; k < 6; ++k) s_v[threadIdx.x >> 6][k] = v[k];
+        for (int k = 0; k < 8; ++k) s_v[threadIdx.x >> 6][k] = v[k];
     __syncthreads();
-    if (threadIdx.x < 6) {
+    if (threadIdx.x < 8) {
         const int k = threadIdx.x;
         unsigned r = s_v[0][k];
-        for (int w = 1; w < 4; ++w) r = k < 3 ? (s_v[w][k] < r ? s_v[w][k] : r) : (s_v[w][k] > r ? s_v[w][k] : r);
+        for (int w = 1; w < 4; ++w) r = k < 3 ? (s_v[w][k] < r ? s_v[w][k] : r) : (k < 6 ? (s_v[w][k] > r ? s_v[w][k] : r) : r + s_v[w][k]);
         bbox[k] = r;
     }
 }
@@ -3029,7 +3045,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
     GSR_TRY(c->rec.reserve(n * 64)); GSR_TRY(c->bbox.reserve(64));
     GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(64));
-    GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 6 * 4)); GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
+    GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 8 * 4)); GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
     hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
                        L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>());
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>(),
@@ -3044,14 +3060,18 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), part ? c->n_global : n, c->cell_target,
                        c->max_cells, c->gparams.as<GridParams>());
     GridParams gp;
+    int early_P = 0, early_irr = 0;
     {
         static_assert(sizeof(GridParams) == 40, "GridParams is read back as five 8-byte words");
         Collect q;
-        q.n = 5;
+        q.n = 7;
         for (int i = 0; i < 5; ++i) { q.src[i] = (const char*)c->gparams.p + 8 * i; q.bytes[i] = 8; }
+        q.src[5] = c->bbox.as<unsigned>() + 6; q.src[6] = c->bbox.as<unsigned>() + 7;      // k_prep's counts: parents, irregular components
+        q.bytes[5] = q.bytes[6] = 4;
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
         memcpy(&gp, w, sizeof(gp));
+        early_P = (int)(unsigned)w[5]; early_irr = (int)(unsigned)w[6];
     }
     c->stats[5] = gp.ncells;
 
@@ -3159,7 +3179,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_TRY(exclusive_scan<int>(c, c->iflag.as<int>(), c->irank.as<int>(), n + 1));
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->iflag.as<int>(), c->irank.as<int>(), c->ipos.as<unsigned>());
     int last_pos = 0, last_flag = 0, n_irr = 0, own_pos = 0, own_flag = 0;
-    {
+    if (!part) {        // the two counts came with the grid (k_prep counted them): no read-back here
+        n_irr = early_irr; last_pos = early_P; last_flag = 0;
+    } else {
         Collect q;
         q.n = part ? 5 : 3;
         q.src[0] = c->irank.as<int>() + n; q.src[1] = c->ppos.as<int>() + (n - 1); q.src[2] = c->pflag.as<int>() + (n - 1);
