@@ -1263,7 +1263,13 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {      // 10 bits -> ev
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-// key = [work class : 2 bits][Morton code of the parent's cell : 30 bits].  Within a class the parents are
+// Morton bits per axis of the ordering key: the curve runs over blocks of (grid / 2^bits)^3 cells, the parents of a block stay in
+// cell order (stable sort).  6 bits: 20-bit keys = two 10-bit Onesweep passes where 10 bits per axis took four (-0.1 ms at 5 M;
+// k_select and k_mstep, which run in this order, measure the same with 6, 7 and 10 bits).
+#ifndef ORDER_AXIS_BITS
+#define ORDER_AXIS_BITS 6
+#endif
+// key = [work class : 2 bits][Morton code of the parent's block of cells : 3 ORDER_AXIS_BITS bits].  Within a class the parents are
 // processed along a Z-order curve: the parents in flight at any time then cover a compact 3-D block, so
 // the children / candidates they share stay in L2 (the x-fastest linear order of the arrays makes the
 // in-flight set a full-width slab of the scene, which does not fit).
@@ -1274,7 +1280,7 @@ __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __res
     int gm = g.gx > g.gy ? g.gx : g.gy;
     gm = gm > g.gz ? gm : g.gz;
     int sh = 0;
-    while ((gm >> sh) > 1024) ++sh;
+    while ((gm >> sh) > (1 << ORDER_AXIS_BITS)) ++sh;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const unsigned w = work[p];
         // classes: 0 = >= 64 thr, 1 = >= 8 thr, 2 = >= thr, 3 = light
@@ -1283,14 +1289,14 @@ __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __res
         const unsigned cx = (unsigned)cell_of(a.x, g.ox, g.inv_c, g.gx) >> sh;
         const unsigned cy = (unsigned)cell_of(a.y, g.oy, g.inv_c, g.gy) >> sh;
         const unsigned cz = (unsigned)cell_of(a.z, g.oz, g.inv_c, g.gz) >> sh;
-        keys[p] = (cls << 30) | spread10(cx) | (spread10(cy) << 1) | (spread10(cz) << 2);
+        keys[p] = (cls << (3 * ORDER_AXIS_BITS)) | spread10(cx) | (spread10(cy) << 1) | (spread10(cz) << 2);
         idx[p] = (unsigned)p;
     }
 }
 
 __global__ void k_count_heavy(int P, const unsigned* __restrict__ sorted_keys, int* __restrict__ out) {
-    int lo = 0, hi = P;                       // first key >= (3 << 30)
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << 30)) hi = mid; else lo = mid + 1; }
+    int lo = 0, hi = P;                       // first key of class 3
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << (3 * ORDER_AXIS_BITS))) hi = mid; else lo = mid + 1; }
     *out = lo;
 }
 
@@ -3290,7 +3296,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             const unsigned thr = (unsigned)(16.0 * (double)cand / (double)P) + 1u;     // "heavy" = 16x the mean (8x: +0.8 % at 5 M, 32x: +10 % at 200 k)
             hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), thr, c->plist.as<unsigned>(),
                                c->A.as<float4>(), c->gparams.as<GridParams>(), c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
-            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 32));
+            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 3 * ORDER_AXIS_BITS + 2));
             hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
             sa.porder = c->porder.as<unsigned>();
             sa.xcd = 1;
