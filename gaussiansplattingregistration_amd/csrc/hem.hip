@@ -3182,8 +3182,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     } else
     hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
     // the irregular components (never pre-rejected): their sorted positions, and their rank at every position
-    GSR_TRY(exclusive_scan<int>(c, c->iflag.as<int>(), c->irank.as<int>(), n + 1));
-    hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->iflag.as<int>(), c->irank.as<int>(), c->ipos.as<unsigned>());
+    // (a level without any -- k_prep counted them -- builds no list: pass B does not run then)
+    if (part || early_irr > 0) {
+        GSR_TRY(exclusive_scan<int>(c, c->iflag.as<int>(), c->irank.as<int>(), n + 1));
+        hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->iflag.as<int>(), c->irank.as<int>(), c->ipos.as<unsigned>());
+    }
     int last_pos = 0, last_flag = 0, n_irr = 0, own_pos = 0, own_flag = 0;
     if (!part) {        // the two counts came with the grid (k_prep counted them): no read-back here
         n_irr = early_irr; last_pos = early_P; last_flag = 0;
@@ -3320,11 +3323,16 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                                    c->counters.as<int>() + 13);
             }
         }
-        size_t free_b = 0, total_b = 0;
-        (void)hipMemGetInfo(&free_b, &total_b);
-        size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 20 * 9;      // 45 % of what is free (a 40 M-splat level needs 79 GB)
-        if (const char* e = getenv("GSR_HEM_SPARSE_GB")) budget = (size_t)(atof(e) * 1073741824.0);
-        const bool sparse = (double)cand * 8.0 <= (double)budget && cand < (1ull << 40);
+        // the budget question needs the driver (hipMemGetInfo: a system call per level) only when the buffers would have to grow
+        const char* sparse_env = getenv("GSR_HEM_SPARSE_GB");
+        bool sparse = cand < (1ull << 40);
+        if (sparse && (sparse_env || (size_t)cand * 4 > c->sp_child.cap || (size_t)cand * 4 > c->sp_wl.cap)) {
+            size_t free_b = 0, total_b = 0;
+            (void)hipMemGetInfo(&free_b, &total_b);
+            size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 20 * 9;      // 45 % of what is free (a 40 M-splat level needs 79 GB)
+            if (sparse_env) budget = (size_t)(atof(sparse_env) * 1073741824.0);
+            sparse = (double)cand * 8.0 <= (double)budget;
+        }
         if (!sh_launched) { GSR_TRY(launch_gather_sh(true)); sh_launched = true; }
         if (sparse) {
             const size_t Cm = (size_t)(cand > 0 ? cand : 1);
