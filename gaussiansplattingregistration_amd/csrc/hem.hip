@@ -1165,19 +1165,34 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     }
 }
 
+// Morton bits per axis of the ordering key: the curve runs over blocks of (grid / 2^bits)^3 cells, the parents of a block stay in
+// cell order (stable sort).  6 bits: 20-bit keys = two 10-bit Onesweep passes where 10 bits per axis took four (-0.1 ms at 5 M;
+// k_select and k_mstep, which run in this order, measure the same with 6, 7 and 10 bits).
+#ifndef ORDER_AXIS_BITS
+#define ORDER_AXIS_BITS 6
+#endif
 // The work items of the heavy parents (the first *nheavy slots of the processing order): parts of SEL_PART candidates.
 // ONE workgroup: the heavy parents are a few thousand.  hq[0] = number of items, hq[1] = the queue cursor, which starts
 // behind the items the waves of the serving workgroups take without asking (see k_select).
-__global__ __launch_bounds__(1024) void k_heavy_items(const int* __restrict__ nheavy_p, const unsigned* __restrict__ porder,
+// It also COUNTS the heavy parents (the sorted ordering keys below class 3: k_count_heavy's binary search, a launch less) and leaves
+// the count in *nheavy_p for the selection kernels.  hfirst[] is written for every heavy parent and read for no other.
+__global__ __launch_bounds__(1024) void k_heavy_items(int P, const unsigned* __restrict__ sorted_keys, int* __restrict__ nheavy_p,
+                                                      const unsigned* __restrict__ porder,
                                                       const unsigned* __restrict__ pcap, unsigned part, int own_lo, int own_hi, int first_pull, int max_items,
                                                       uint2* __restrict__ hitem, int* __restrict__ hfirst, unsigned* __restrict__ pcnt,
                                                       int* __restrict__ hq, int* __restrict__ error_flag) {
     __shared__ int s_wsum[16];
-    __shared__ int s_base;
-    const int nheavy = *nheavy_p;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_base = 0;
+    __shared__ int s_base, s_nheavy;
+    if (threadIdx.x == 0) {
+        int lo = 0, hi = P;                       // first key of class 3
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << (3 * ORDER_AXIS_BITS))) hi = mid; else lo = mid + 1; }
+        s_nheavy = lo;
+        *nheavy_p = lo;
+        s_base = 0;
+    }
     __syncthreads();
+    const int nheavy = s_nheavy;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     for (int h0 = 0; h0 < nheavy; h0 += 1024) {
         const int h = h0 + (int)threadIdx.x;
         int p = -1, np = 0;
@@ -1263,12 +1278,6 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {      // 10 bits -> ev
     v = (v | (v << 2)) & 0x09249249u;
     return v;
 }
-// Morton bits per axis of the ordering key: the curve runs over blocks of (grid / 2^bits)^3 cells, the parents of a block stay in
-// cell order (stable sort).  6 bits: 20-bit keys = two 10-bit Onesweep passes where 10 bits per axis took four (-0.1 ms at 5 M;
-// k_select and k_mstep, which run in this order, measure the same with 6, 7 and 10 bits).
-#ifndef ORDER_AXIS_BITS
-#define ORDER_AXIS_BITS 6
-#endif
 // key = [work class : 2 bits][Morton code of the parent's block of cells : 3 ORDER_AXIS_BITS bits].  Within a class the parents are
 // processed along a Z-order curve: the parents in flight at any time then cover a compact 3-D block, so
 // the children / candidates they share stay in L2 (the x-fastest linear order of the arrays makes the
@@ -3300,7 +3309,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), thr, c->plist.as<unsigned>(),
                                c->A.as<float4>(), c->gparams.as<GridParams>(), c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
             GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 3 * ORDER_AXIS_BITS + 2));
-            hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
+            if (!c->split_heavy)
+                hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
             sa.porder = c->porder.as<unsigned>();
             sa.xcd = 1;
             sa.nheavy = c->counters.as<int>() + 8;
@@ -3314,11 +3324,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                 const int max_items = (int)std::min<unsigned long long>(cand / part + (unsigned long long)P + 1ull, 0x7fffffffull);
                 GSR_TRY(c->hitem.reserve((size_t)max_items * sizeof(uint2))); GSR_TRY(c->hfirst.reserve(Pm * 4));
                 GSR_TRY(c->part_cnt.reserve((size_t)max_items * 4));
-                GSR_HIP(hipMemsetAsync(c->hfirst.p, 0xff, Pm * 4, st));
                 sa.heavy_blocks = SEL_HEAVY_BLOCKS;
                 sa.hitem = c->hitem.as<uint2>(); sa.hfirst = c->hfirst.as<int>(); sa.part_cnt = c->part_cnt.as<unsigned>();
                 sa.hq = c->counters.as<int>() + 10;
-                hipLaunchKernelGGL(k_heavy_items, dim3(1), dim3(1024), 0, st, sa.nheavy, sa.porder, c->pcap.as<unsigned>(), sa.part, own_lo, own_hi,
+                hipLaunchKernelGGL(k_heavy_items, dim3(1), dim3(1024), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8, sa.porder,
+                                   c->pcap.as<unsigned>(), sa.part, own_lo, own_hi,
                                    SEL_HEAVY_BLOCKS * WPB, max_items, c->hitem.as<uint2>(), c->hfirst.as<int>(), c->pcnt.as<unsigned>(), sa.hq,
                                    c->counters.as<int>() + 13);
             }
