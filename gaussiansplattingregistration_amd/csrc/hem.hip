@@ -2503,6 +2503,7 @@ struct gsr_hem_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;      // second stream: the queue of heavy work items runs beside the light parents
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_pre = nullptr;    // the parents' output ranks (flags in input order + their scan), computed beside the grid phase
     hipStream_t aux2 = nullptr;     // third stream: the SH rows are gathered into cell order (an HBM stream only the M-step needs)
     hipEvent_t ev_sh_fork = nullptr, ev_sh_join = nullptr;      // beside the selection (VALU / latency bound)
     int sh_grid = 0;                // GSR_HEM_SH_GRID: workgroups of a forked k_gather_sh (0 = as many as in line)
@@ -2547,7 +2548,7 @@ struct gsr_hem_ctx {
     bool sparse_path = false;
     DevBuf hitem, hfirst, part_cnt, Ac, cellStartC;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
-    DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp;
+    DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp, rocprim_tmp2;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t stats_ex[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2678,12 +2679,15 @@ int32_t read_back(gsr_hem_ctx* c, const Collect& q, unsigned long long* out) {
     return GSR_OK;
 }
 
+// (side = true: on the context's second stream, with its own temporary storage)
 template <typename T>
-int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n) {
+int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n, bool side = false) {
     size_t bytes = 0;
-    GSR_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (T)0, (size_t)n, rocprim::plus<T>(), c->stream));
-    GSR_TRY(c->rocprim_tmp.reserve(bytes));
-    GSR_HIP(rocprim::exclusive_scan(c->rocprim_tmp.p, bytes, in, out, (T)0, (size_t)n, rocprim::plus<T>(), c->stream));
+    const hipStream_t s = side ? c->aux : c->stream;
+    DevBuf& tmp = side ? c->rocprim_tmp2 : c->rocprim_tmp;
+    GSR_HIP(rocprim::exclusive_scan(nullptr, bytes, in, out, (T)0, (size_t)n, rocprim::plus<T>(), s));
+    GSR_TRY(tmp.reserve(bytes));
+    GSR_HIP(rocprim::exclusive_scan(tmp.p, bytes, in, out, (T)0, (size_t)n, rocprim::plus<T>(), s));
     return GSR_OK;
 }
 
@@ -2764,6 +2768,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         hipError_t e = hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_pre, hipEventDisableTiming);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sh_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sh_join, hipEventDisableTiming);
@@ -2811,13 +2816,14 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
                      &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
-                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp};
+                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
     for (int i = 0; i < 4; ++i) if (c->evk[i]) (void)hipEventDestroy(c->evk[i]);
     for (int i = 0; i < 6; ++i) if (c->evm[i]) (void)hipEventDestroy(c->evm[i]);
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_pre) (void)hipEventDestroy(c->ev_pre);
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_sh_fork) (void)hipEventDestroy(c->ev_sh_fork);
     if (c->ev_sh_join) (void)hipEventDestroy(c->ev_sh_join);
@@ -3065,6 +3071,17 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                        L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>());
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>(),
                        c->counters.as<unsigned>(), 16, c->hist.as<unsigned>(), 3 * HIST_BINS);
+    // The parents' output ranks depend on nothing but the level's flags (input order): flags as ints + their scan on the second
+    // stream, beside the grid phase, instead of between the sums and the M-step (three launches off the critical path).
+    GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
+    bool ranks_forked = false;
+    if (!part && c->aux && c->ev_pre) {
+        GSR_HIP(hipEventRecord(c->ev_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        hipLaunchKernelGGL(k_flags_in, grd, blk, 0, c->aux, n, n_own, L.is_parent.as<uint8_t>(), c->pflag_in.as<int>(), c->oflag_in.as<int>());
+        GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n, true));
+        GSR_HIP(hipEventRecord(c->ev_pre, c->aux));
+        ranks_forked = true;
+    }
     if (part) {     // the box of ALL ranks' components: maximum of the (order-preserving) codes, the minima complemented
         hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
         GSR_TRY(gsr_comm_allreduce(c->comm, c->bbox.p, 6, GSR_DT_U32, GSR_OP_MAX, (void*)st));
@@ -3550,12 +3567,16 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 
     // ---- 4. output ranks in input order; M-step; orphans -----------------------------------------
     GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
-    GSR_TRY(c->oslot.reserve(n * 8));
+    GSR_TRY(c->oslot.reserve(n * 8));               // (n includes the ghosts of a partitioned level here)
     int o_last = 0, o_flag = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
-        hipLaunchKernelGGL(k_flags_in, grd, blk, 0, st, n, n_own, L.is_parent.as<uint8_t>(), c->pflag_in.as<int>(), c->oflag_in.as<int>());
+        if (ranks_forked && attempt == 0) {
+            GSR_HIP(hipStreamWaitEvent(st, c->ev_pre, 0));
+        } else {
+            hipLaunchKernelGGL(k_flags_in, grd, blk, 0, st, n, n_own, L.is_parent.as<uint8_t>(), c->pflag_in.as<int>(), c->oflag_in.as<int>());
+            GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
+        }
         hipLaunchKernelGGL(k_orphans_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), c->oflag.as<int>(), c->oflag_in.as<int>());
-        GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n));
         GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
         Collect q;
         q.n = 4;
