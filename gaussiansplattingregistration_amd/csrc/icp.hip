@@ -308,6 +308,26 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
     return best;
 }
 
+// Which source points a workgroup takes.  The source is sorted by the target's cells, so a CONTIGUOUS run of it queries a compact
+// region of the target.  Workgroups go to the 8 XCDs round robin: logical block L = (bid % 8) * ceil(nb / 8) + bid / 8 gives every
+// XCD one contiguous eighth of the source, and with it an eighth of the target (+ halo) for its own L2 -- block b taking the
+// points b * 256 + k * stride made every XCD pull the WHOLE target through its 4 MB (L2 hit rate 46 % on the coarse levels).
+// Launch 8 * ceil(nb / 8) workgroups; padding workgroups get nothing.  The partial sums are stored by logical block.
+struct IcpRange { int row; int64_t lo, hi; };
+__device__ __forceinline__ IcpRange icp_block_range(int64_t ns, int nb, bool remap) {
+    int L = (int)blockIdx.x;
+    if (remap) {
+        const int chunk = (nb + 7) >> 3;
+        L = ((int)blockIdx.x & 7) * chunk + ((int)blockIdx.x >> 3);
+    }
+    const int64_t ppb = ((ns + nb - 1) / nb + 255) / 256 * 256;       // points per logical block, whole waves of a 256-thread block
+    IcpRange r;
+    r.row = L < nb ? L : -1;
+    r.lo = (int64_t)L * ppb;
+    r.hi = r.lo + ppb < ns ? r.lo + ppb : ns;
+    return r;
+}
+
 struct IcpState;
 __device__ __forceinline__ bool icp_state_done(const IcpState* st);
 __device__ __forceinline__ void icp_state_T(const IcpState* st, double T[12]);
@@ -320,7 +340,7 @@ __device__ __forceinline__ void icp_step_solve(const double* acc32, const IcpSta
 template <bool FROM_STATE, int BLOCK>
 __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restrict__ src, Xform X, const IcpState* __restrict__ st,
                                                 IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
-                                                double max_corr2, int* __restrict__ nn_j) {
+                                                double max_corr2, int* __restrict__ nn_j, int nb_logical) {
     double T[12];
     if (FROM_STATE) {
         if (icp_state_done(st)) return;
@@ -329,7 +349,9 @@ __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restr
 #pragma unroll
         for (int i = 0; i < 12; ++i) T[i] = X.m[i];
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
+    const IcpRange rg = icp_block_range(ns, nb_logical < 0 ? -nb_logical : nb_logical, nb_logical > 0);
+    if (rg.row < 0) return;
+    for (int64_t i = rg.lo + threadIdx.x; i < rg.hi; i += blockDim.x) {
         const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
         const double px = T[0] * x + T[1] * y + T[2] * z + T[3];
         const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
@@ -603,7 +625,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // WT: the partials leave with write-through (sc1) stores -- what a workgroup that hands them to another workgroup of the SAME
 // launch must use (k_icp_accumulate_dev's fused step); plain stores otherwise (the reader is a later kernel)
 template <int NACC, bool WT = false>
-__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ partials) {
+__device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* __restrict__ partials, int row = -1) {
+    if (row < 0) row = (int)blockIdx.x;
     __shared__ double s_red[4][NACC];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
@@ -615,8 +638,8 @@ __device__ __forceinline__ void block_reduce_store(double (&acc)[NACC], double* 
     if (threadIdx.x < NACC) {
         const int k = threadIdx.x;
         const double v = ((s_red[0][k] + s_red[1][k]) + s_red[2][k]) + s_red[3][k];
-        if (WT) __hip_atomic_store(partials + (int64_t)blockIdx.x * GSR_ICP_ACC_LEN + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else partials[(int64_t)blockIdx.x * GSR_ICP_ACC_LEN + k] = v;
+        if (WT) __hip_atomic_store(partials + (int64_t)row * GSR_ICP_ACC_LEN + k, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else partials[(int64_t)row * GSR_ICP_ACC_LEN + k] = v;
     }
 }
 
@@ -1139,7 +1162,7 @@ __global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_a
                                                             const float4* __restrict__ Tq, const double* __restrict__ Tn,
                                                             const double* __restrict__ Sc, ColorArgs ca, double max_corr2,
                                                             int loss, double kparam, double* partials, unsigned* ticket,
-                                                            double* acc_out) {
+                                                            double* acc_out, int nb_logical) {
     constexpr int fuse = FUSE;
     if (st->done) {
         // converged: nothing to search.  The ranks of a multi-GPU run still meet in the collective: zeros
@@ -1153,7 +1176,9 @@ __global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_a
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ns; i += (int64_t)gridDim.x * blockDim.x) {
+    const IcpRange rg = icp_block_range(ns, nb_logical < 0 ? -nb_logical : nb_logical, FUSE == 0 && nb_logical > 0);
+    if (rg.row < 0) return;                         // (a padding workgroup of the XCD mapping; FUSE != 0 launches none)
+    for (int64_t i = rg.lo + threadIdx.x; i < rg.hi; i += blockDim.x) {
         const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
         const double px = T[0] * x + T[1] * y + T[2] * z + T[3];
         const double py = T[4] * x + T[5] * y + T[6] * z + T[7];
@@ -1200,7 +1225,7 @@ __global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_a
             acc[29] += r * r;
         }
     }
-    block_reduce_store<NACC, FUSE != 0>(acc, partials);
+    block_reduce_store<NACC, FUSE != 0>(acc, partials, rg.row);
     if constexpr (FUSE == 0) return;
     // Hand-off inside one launch (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): the
     // partials left with write-through (sc1) stores by the lanes of wave 0; that wave waits for them (vmcnt(0)), then its lane 0
@@ -1348,6 +1373,7 @@ struct gsr_icp_ctx {
     bool src_sorted = false;
     bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
     bool block_search = true;       // GSR_ICP_BLOCK_SEARCH=0: always the ring loop from ring 0
+    bool xcd_ranges = true;         // GSR_ICP_XCD=0: logical block = physical block (every XCD walks the whole source)
     bool fused_step = false;        // GSR_ICP_FUSED_STEP=1: the accumulate kernel's last workgroup does k_icp_step's (or k_icp_reduce's) work instead of a launch of its own: measured equal (44.8 vs 44.0 us at 185 k), so off
                                     // accumulate kernel's last workgroup
     gsr_comm* comm = nullptr;       // multi-GPU source split through a communicator (gsr_icp_set_comm)
@@ -1378,12 +1404,15 @@ struct gsr_icp_ctx {
 
 namespace {
 
-inline int nn_grid1(int64_t ns) {      // grid of the search kernel: one thread per point, capped (grid-stride loop)
-    int64_t g = (ns + 255) / 256;
-    if (g < 1) g = 1;
-    if (g > 16384) g = 16384;
-    return (int)g;
+// Logical blocks for ns points when at most `cap` workgroups are wanted: every block takes a whole number of 256-point trips
+// (icp_block_range), and there are exactly as many blocks as have points -- the XCD mapping deals them out in eighths, so
+// blocks without work at the end would leave whole XCDs idle.
+inline int icp_blocks(int64_t ns, int cap) {
+    if (ns <= 0) return 1;
+    const int64_t ppb = ((ns + cap - 1) / cap + 255) / 256 * 256;
+    return (int)((ns + ppb - 1) / ppb);
 }
+inline int nn_grid1(int64_t ns) { return icp_blocks(ns, 16384); }      // grid of the search kernel: one thread per point, capped
 
 int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, double k, double* acc, bool timed) {
     if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
@@ -1397,9 +1426,7 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     hipStream_t st = c->stream;
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
-    int nb = c->nblocks;
-    if ((int64_t)nb * 256 > c->ns) nb = (int)((c->ns + 255) / 256);
-    if (nb < 1) nb = 1;
+    const int nb = icp_blocks(c->ns, c->nblocks);
     GSR_TRY(c->partials.reserve((size_t)nb * GSR_ICP_ACC_LEN * 8));
     GSR_TRY(c->acc_dev.reserve(GSR_ICP_ACC_LEN * 8));
     GSR_HIP(hipMemsetAsync(c->partials.p, 0, (size_t)nb * GSR_ICP_ACC_LEN * 8, st));
@@ -1408,8 +1435,8 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     const int* nnj = nullptr;
     if (c->nn_mode()) {
         GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-        hipLaunchKernelGGL((k_icp_nn<false, 0>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                           c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+        hipLaunchKernelGGL((k_icp_nn<false, 0>), dim3(8 * ((nn_grid1(c->ns) + 7) / 8)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                           c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>(), c->xcd_ranges ? nn_grid1(c->ns) : -nn_grid1(c->ns));
         nnj = c->nn_j.as<int>();
     }
     const ColorArgs cargs = {c->Ti.as<double>(), c->Tg.as<double>(), c->Si.as<double>(), sqrt(c->lambda_geometric), sqrt(1.0 - c->lambda_geometric)};
@@ -1495,6 +1522,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     // Environment knobs (all of them): none changes a result, tests/test_icp_gpu.py::test_icp_knobs_change_nothing
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_XCD")) c->xcd_ranges = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_FUSED_STEP")) c->fused_step = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->nblocks = v; }
     // pinned, device-mapped, COHERENT host memory: the device's system-scope stores must reach the host while the stream is still
@@ -1789,9 +1817,7 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         hs.max_iter = max_iter < 0 ? 0 : max_iter; hs.kind = kind;
         GSR_TRY(c->state.reserve(sizeof(IcpState)));
         GSR_HIP(hipMemcpyAsync(c->state.p, &hs, sizeof(hs), hipMemcpyHostToDevice, st));
-        int nb = c->nblocks;
-        if ((int64_t)nb * 256 > c->ns) nb = (int)((c->ns + 255) / 256);
-        if (nb < 1) nb = 1;
+        const int nb = icp_blocks(c->ns, c->nblocks);
         GSR_TRY(c->partials.reserve((size_t)nb * GSR_ICP_ACC_LEN * 8));
         GSR_TRY(c->nn_j.reserve((size_t)(c->ns > 0 ? c->ns : 1) * 4));
         GSR_TRY(c->acc_dev.reserve(GSR_ICP_ACC_LEN * 8));
@@ -1812,9 +1838,9 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
             const int* nnj = c->nn_mode() ? c->nn_j.as<int>() : (const int*)nullptr;
             for (int i = 0; i < chunk; ++i) {
 #define GSR_ICP_ACC1(KIND, BLK, FUSE, TN, SC)                                                                                        \
-    hipLaunchKernelGGL((k_icp_accumulate_dev<KIND, BLK, FUSE>), dim3(nb), dim3(256), 0, st, c->ns, c->src.as<float>(), c->state.as<IcpState>(), \
-                       c->grid, c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), TN, SC, cargs, mc2, loss, k, c->partials.as<double>(),     \
-                       c->ticket.as<unsigned>(), c->acc_dev.as<double>())
+    hipLaunchKernelGGL((k_icp_accumulate_dev<KIND, BLK, FUSE>), dim3(FUSE == 0 ? 8 * ((nb + 7) / 8) : nb), dim3(256), 0, st, c->ns, c->src.as<float>(), \
+                       c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), nnj, c->Tq.as<float4>(), TN, SC, cargs, mc2, loss, k,          \
+                       c->partials.as<double>(), c->ticket.as<unsigned>(), c->acc_dev.as<double>(), c->xcd_ranges ? nb : -nb)
 #define GSR_ICP_ACC(KIND, TN, SC)                                                                                                    \
     do {                                                                                                                             \
         if (blockf) { if (fuse == 0) GSR_ICP_ACC1(KIND, 1, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, 1, 1, TN, SC); else GSR_ICP_ACC1(KIND, 1, 2, TN, SC); } \
@@ -1822,11 +1848,11 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
     } while (0)
                 if (c->nn_mode()) {
                     if (blockf)
-                        hipLaunchKernelGGL((k_icp_nn<true, 1>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
-                                           c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+                        hipLaunchKernelGGL((k_icp_nn<true, 1>), dim3(8 * ((nn_grid1(c->ns) + 7) / 8)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
+                                           c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>(), c->xcd_ranges ? nn_grid1(c->ns) : -nn_grid1(c->ns));
                     else
-                        hipLaunchKernelGGL((k_icp_nn<true, 0>), dim3(nn_grid1(c->ns)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
-                                           c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>());
+                        hipLaunchKernelGGL((k_icp_nn<true, 0>), dim3(8 * ((nn_grid1(c->ns) + 7) / 8)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
+                                           c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>(), c->xcd_ranges ? nn_grid1(c->ns) : -nn_grid1(c->ns));
                 }
                 if (kind == GSR_ICP_COLORED) GSR_ICP_ACC(3, c->Tn.as<double>(), (const double*)nullptr);
                 else if (kind == GSR_ICP_POINT_TO_POINT) GSR_ICP_ACC(0, (const double*)nullptr, (const double*)nullptr);
@@ -1893,8 +1919,8 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
     GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-    hipLaunchKernelGGL((k_icp_nn<false, 0>), dim3(nn_grid1(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>());
+    hipLaunchKernelGGL((k_icp_nn<false, 0>), dim3(8 * ((nn_grid1(c->ns) + 7) / 8)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
+                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>(), c->xcd_ranges ? nn_grid1(c->ns) : -nn_grid1(c->ns));
     hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->nn_j.as<int>(),
                        c->Tq.as<float4>(), c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->corr_idx.as<int64_t>(),
                        c->corr_d2.as<double>());

@@ -282,7 +282,7 @@ def test_icp_knobs_change_nothing(monkeypatch):
     other grid resolutions (GSR_ICP_CELL_TARGET, GSR_ICP_MAX_CELLS), the ring loop from ring 0 against the 27-cell block of
     batched loads the coarse levels start with (GSR_ICP_BLOCK_SEARCH; max_corr = 0.3 spans several cells here, and the
     split-kernel case runs it in k_icp_nn too), another number of workgroups -- another association of the points with the partial
-    sums (GSR_ICP_BLOCKS) --, k_icp_step as its own launch against the accumulate kernel's last workgroup doing
+    sums (GSR_ICP_BLOCKS) --, workgroups without the XCD-contiguous mapping of the source ranges (GSR_ICP_XCD=0), k_icp_step as its own launch against the accumulate kernel's last workgroup doing
     its work (GSR_ICP_FUSED_STEP: one launch per iteration instead of two)."""
     from gaussiansplattingregistration_amd import icp, synth
     src, tgt, _ = synth.make_pair(50000, seed=13, sh_degree=0)
@@ -303,7 +303,7 @@ def test_icp_knobs_change_nothing(monkeypatch):
     ref = run()
     for env in ({"GSR_ICP_NN_KERNEL": "0"}, {"GSR_ICP_NN_KERNEL": "2"}, {"GSR_ICP_DEVICE_LOOP": "0"}, {"GSR_ICP_CELL_TARGET": "0.5"},
                 {"GSR_ICP_CELL_TARGET": "16"}, {"GSR_ICP_MAX_CELLS": "4096"}, {"GSR_ICP_BLOCK_SEARCH": "0"},
-                {"GSR_ICP_BLOCKS": "100"}, {"GSR_ICP_RB_POLL": "0"},
+                {"GSR_ICP_BLOCKS": "100"}, {"GSR_ICP_RB_POLL": "0"}, {"GSR_ICP_XCD": "0"},
                 {"GSR_ICP_BLOCK_SEARCH": "0", "GSR_ICP_NN_KERNEL": "2"}, {"GSR_ICP_FUSED_STEP": "1"}, {"GSR_ICP_FUSED_STEP": "1", "GSR_ICP_NN_KERNEL": "2"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
