@@ -1378,21 +1378,23 @@ __global__ __launch_bounds__(256) void k_join_parts(const int* __restrict__ nhea
 // touches with ONE global atomic each, and places the pairs on a second walk (L2 resident).  A bucket that overflows raises
 // *overflow; the caller then takes the exact path (histogram + scan of a compacted copy).
 #define PART_PPW 128
-#define PART_STAGE_PPW 112                       // parents per workgroup of the staged form (~60 pairs each: ~6.7 k pairs of the 8 192 that fit)
-#define PART_STAGE 8192                          // pairs a workgroup of k_partition<true> stages in LDS (64 KiB)
 #define PART_STAGE_T 1024
-#define PART_STAGE_MAX_BUCKETS 1536              // 8 bytes of LDS per bucket beside the stage: two workgroups per CU up to here
-// STAGED: the workgroup (512 threads, PART_STAGE_PPW parents) reads every pair ONCE into registers, ranks it inside its bucket
-// with an LDS atomic, lays the pairs out by bucket in LDS and writes every bucket's run with consecutive lanes on consecutive
-// addresses (runs of ~70 pairs instead of the 3-pair fragments of a 256-lane walk; the second read of the pair list is gone:
-// 0.99 -> see DESIGN.md 3 at the 5 M level).  A chunk with more than PART_STAGE pairs (heavy parents) takes the two-walk form.
+// STAGE > 0: the workgroup (1 024 threads, STAGE * 112 / 8192 parents of ~60 pairs each) reads every pair ONCE into registers,
+// ranks it inside its bucket with an LDS atomic, lays the pairs out by bucket in LDS (8 bytes each) and writes every bucket's run
+// with consecutive lanes on consecutive addresses (runs of ~70 pairs instead of the 3-pair fragments of a 256-lane walk; the
+// second read of the pair list is gone: 0.99 -> 0.65 ms at the 5 M level).  Beside the stage the kernel keeps 8 bytes
+// of LDS per bucket; the launcher picks the largest stage that still lets TWO workgroups share a CU: 8 192 pairs up to 1 536
+// buckets (n <= 6.3 M), 6 144 up to 3 584, 4 096 up to 5 632 (a 40 M-splat level), the two-walk form beyond.  A chunk with more
+// pairs than the stage holds (heavy parents) takes the two-walk form inside the same kernel.
 // The order of the pairs inside a bucket is arbitrary in both forms: k_bucket_sum adds integers.
-template <bool STAGED>
-__global__ __launch_bounds__(STAGED ? PART_STAGE_T : 256, STAGED ? 8 : 1) void k_partition(int P, const int64_t* __restrict__ seg, const unsigned* __restrict__ pcnt,
+template <int STAGE>
+__global__ __launch_bounds__(STAGE ? PART_STAGE_T : 256, STAGE ? 8 : 1) void k_partition(int P, const int64_t* __restrict__ seg, const unsigned* __restrict__ pcnt,
                                                    const unsigned* __restrict__ sc, const float* __restrict__ sw, int nb, int shift, unsigned cap,
                                                    unsigned* __restrict__ cursor, unsigned* __restrict__ o_child, float* __restrict__ o_wl,
                                                    int* __restrict__ overflow) {
-    constexpr int PPW = STAGED ? PART_STAGE_PPW : PART_PPW;
+    constexpr bool STAGED = STAGE > 0;
+    constexpr int PPW = STAGED ? STAGE * 112 / 8192 : PART_PPW;
+    constexpr int PART_STAGE = STAGED ? STAGE : 1;
     extern __shared__ unsigned s_h[];
     __shared__ unsigned long long s_off[PPW + 1];            // exclusive prefix of the parents' pair counts (a heavy level: > 2^32 in one chunk is impossible, 64 bits anyway)
     __shared__ long long s_seg[PPW];
@@ -1422,7 +1424,7 @@ __global__ __launch_bounds__(STAGED ? PART_STAGE_T : 256, STAGED ? 8 : 1) void k
         return s_seg[a] + (long long)(f - s_off[a]);
     };
     if (STAGED && total <= (unsigned long long)PART_STAGE) {
-        constexpr int IT = PART_STAGE / PART_STAGE_T;
+        constexpr int IT = STAGED ? PART_STAGE / PART_STAGE_T : 1;
         unsigned* s_g = s_h + nb;                              // global slot of the bucket's run minus its LDS position
         unsigned* st_c = s_g + nb;
         float* st_w = reinterpret_cast<float*>(st_c + PART_STAGE);
@@ -1524,14 +1526,20 @@ __global__ __launch_bounds__(STAGED ? PART_STAGE_T : 256, STAGED ? 8 : 1) void k
         }
     }
 }
-// one launch of the pair partition: the staged form where its LDS fits twice on a CU
-static inline void launch_partition(hipStream_t st, bool staged_ok, int P, const int64_t* seg, const unsigned* pcnt, const unsigned* sc, const float* sw, int nb,
+// one launch of the pair partition: the largest stage whose LDS fits twice on a CU
+template <int STAGE>
+static inline void launch_partition_staged(hipStream_t st, int P, const int64_t* seg, const unsigned* pcnt, const unsigned* sc, const float* sw, int nb, int shift,
+                                           unsigned cap, unsigned* cursor, unsigned* o_child, float* o_wl, int* overflow) {
+    hipLaunchKernelGGL(k_partition<STAGE>, dim3(ceil_div(P, STAGE * 112 / 8192)), dim3(PART_STAGE_T), (size_t)nb * 8 + (size_t)STAGE * 8, st, P, seg, pcnt, sc, sw,
+                       nb, shift, cap, cursor, o_child, o_wl, overflow);
+}
+static inline void launch_partition(hipStream_t st, int staged_ok /* 0 walk, 1 auto, else the stage size to force */, int P, const int64_t* seg, const unsigned* pcnt, const unsigned* sc, const float* sw, int nb,
                                     int shift, unsigned cap, unsigned* cursor, unsigned* o_child, float* o_wl, int* overflow) {
-    if (staged_ok && nb <= PART_STAGE_MAX_BUCKETS)
-        hipLaunchKernelGGL(k_partition<true>, dim3(ceil_div(P, PART_STAGE_PPW)), dim3(PART_STAGE_T), (size_t)nb * 8 + (size_t)PART_STAGE * 8, st, P, seg, pcnt, sc, sw,
-                           nb, shift, cap, cursor, o_child, o_wl, overflow);
+    if ((staged_ok == 1 || staged_ok == 8192) && nb <= 1536) launch_partition_staged<8192>(st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child, o_wl, overflow);
+    else if ((staged_ok == 1 || staged_ok == 6144) && nb <= 3584) launch_partition_staged<6144>(st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child, o_wl, overflow);
+    else if ((staged_ok == 1 || staged_ok == 4096) && nb <= 5632) launch_partition_staged<4096>(st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child, o_wl, overflow);
     else
-        hipLaunchKernelGGL(k_partition<false>, dim3(ceil_div(P, PART_PPW)), dim3(256), (size_t)nb * 4, st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child,
+        hipLaunchKernelGGL(k_partition<0>, dim3(ceil_div(P, PART_PPW)), dim3(256), (size_t)nb * 4, st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child,
                            o_wl, overflow);
 }
 
@@ -2530,7 +2538,8 @@ struct gsr_hem_ctx {
     DevBuf gid, gid_next, rec_loc, gid_loc, ghost_sh, ghost_src, perm, pown, ppos_own, inv, gmax, gacc, cmask, dflag, dpos, sent_idx, rows_send, rows_recv,
         xsend, xrecv, gbits, wcnt, wpre, grank, allflags, pcounts, pmatrix;
     int64_t part_stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};      // ghosts, rows sent, bytes received in the halo exchange, bytes of the other exchanges, ...
-    bool partition_staged = true;   // k_partition<true>: pairs staged by bucket in LDS, read once (GSR_HEM_PARTITION=walk: the two-walk form)
+    int partition_stage = 0;        // GSR_HEM_PARTITION_STAGE=6144 / 4096: force a smaller stage than the bucket count asks for (tests)
+    bool partition_staged = true;   // k_partition<STAGE > 0>: pairs staged by bucket in LDS, read once (GSR_HEM_PARTITION=walk: the two-walk form)
     bool partition_fixed = true;    // bucket regions of fixed capacity filled straight from the segments (GSR_HEM_PARTITION=exact: histogram + scan)
     bool partition_overflowed = false;      // a region overflowed once: this context uses the exact partition from then on
     double partition_factor = 0.0;  // GSR_HEM_PARTITION_FACTOR: region capacity in multiples of the mean (test knob: < 1 forces the overflow path)
@@ -2787,14 +2796,17 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
     if (const char* s = getenv("GSR_HEM_SH_GRID")) c->sh_grid = atoi(s);
+    if (const char* s = getenv("GSR_HEM_PARTITION_STAGE")) { const int v = atoi(s); if (v == 8192 || v == 6144 || v == 4096) c->partition_stage = v; }
     if (const char* s = getenv("GSR_HEM_PARTITION")) { c->partition_fixed = strcmp(s, "exact") != 0; c->partition_staged = strcmp(s, "walk") != 0; }
     if (const char* s = getenv("GSR_HEM_PARTITION_FACTOR")) c->partition_factor = atof(s);
     if (const char* s = getenv("GSR_HEM_CELL_TARGET")) { float v = (float)atof(s); if (v > 0.25f && v < 4096.0f) c->cell_target = v; }
     (void)hipFuncSetAttribute((const void*)k_bucket_sum, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     (void)hipFuncSetAttribute((const void*)k_bucket_hist, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
     (void)hipFuncSetAttribute((const void*)k_bucket_scatter, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
-    (void)hipFuncSetAttribute((const void*)k_partition<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
-    (void)hipFuncSetAttribute((const void*)k_partition<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PART_STAGE_MAX_BUCKETS * 8 + PART_STAGE * 8);
+    (void)hipFuncSetAttribute((const void*)k_partition<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SUM_MAX_BUCKETS * 4);
+    (void)hipFuncSetAttribute((const void*)k_partition<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, 1536 * 8 + 8192 * 8);
+    (void)hipFuncSetAttribute((const void*)k_partition<6144>, hipFuncAttributeMaxDynamicSharedMemorySize, 3584 * 8 + 6144 * 8);
+    (void)hipFuncSetAttribute((const void*)k_partition<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 5632 * 8 + 4096 * 8);
     (void)hipFuncSetAttribute((const void*)k_part_max, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << 13);
     (void)hipFuncSetAttribute((const void*)k_part_acc, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
     *out = c;
@@ -3440,7 +3452,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
         (void)hipGetLastError();
         GSR_HIP(hipEventRecord(c->evm[2], st));
-        launch_partition(st, c->partition_staged, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
+        launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
                          c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
         GSR_HIP(hipGetLastError());
         GSR_HIP(hipEventRecord(c->evm[3], st));
@@ -3493,7 +3505,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
             GSR_HIP(hipMemsetAsync(overflow_flag, 0, 4, st));
             if (M > 0 && P > 0)
-                launch_partition(st, c->partition_staged, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
+                launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
                                  c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
             GSR_HIP(hipGetLastError());
             Collect q;

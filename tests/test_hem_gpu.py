@@ -657,15 +657,17 @@ def test_pair_partition_variants_change_nothing(monkeypatch):
     (GSR_HEM_PARTITION_FACTOR=0.3: capacity below the mean) makes the level redo its sums that way.  The per-child sums are order
     independent (LDS fixed point) and the M-step reads the same runs of pairs: three levels bit for bit identical, also on the
     two-pass fallback (compact CSR segments) and with many orphans (the anisotropic cloud).  GSR_HEM_PARTITION=walk: the
-    partition kernel without its LDS staging (what levels with more than 1 536 buckets and chunks of heavy parents use);
+    partition kernel without its LDS staging (what chunks of heavy parents and levels beyond 23 M components use), GSR_HEM_PARTITION_STAGE:
+    the smaller stages of the levels with more than 1 536 / 3 584 buckets;
     GSR_HEM_SH_OVERLAP / GSR_HEM_SH_GRID: the SH gather forked onto the context's third stream."""
     from gaussiansplattingregistration_amd import hem, synth
     clouds = [synth.make_cloud(250000, seed=21), synth.make_cloud(120000, seed=22, shape="aniso", sh_degree=1)]
     res = {}
     for tag, env in (("fixed", {}), ("exact", {"GSR_HEM_PARTITION": "exact"}), ("overflow", {"GSR_HEM_PARTITION_FACTOR": "0.3"}),
-                     ("two-pass", {"GSR_HEM_SPARSE_GB": "0"}), ("walk", {"GSR_HEM_PARTITION": "walk"}), ("sh-fork", {"GSR_HEM_SH_OVERLAP": "1"}),
+                     ("two-pass", {"GSR_HEM_SPARSE_GB": "0"}), ("walk", {"GSR_HEM_PARTITION": "walk"}), ("stage-6144", {"GSR_HEM_PARTITION_STAGE": "6144"}),
+                     ("stage-4096", {"GSR_HEM_PARTITION_STAGE": "4096"}), ("sh-fork", {"GSR_HEM_SH_OVERLAP": "1"}),
                      ("sh-fork-2", {"GSR_HEM_SH_OVERLAP": "2", "GSR_HEM_SH_GRID": "256"})):
-        for k in ("GSR_HEM_PARTITION", "GSR_HEM_PARTITION_FACTOR", "GSR_HEM_SPARSE_GB", "GSR_HEM_SH_OVERLAP", "GSR_HEM_SH_GRID"):
+        for k in ("GSR_HEM_PARTITION", "GSR_HEM_PARTITION_FACTOR", "GSR_HEM_PARTITION_STAGE", "GSR_HEM_SPARSE_GB", "GSR_HEM_SH_OVERLAP", "GSR_HEM_SH_GRID"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -680,7 +682,7 @@ def test_pair_partition_variants_change_nothing(monkeypatch):
         res[tag] = out
     assert all(o[2] == 1 for o in res["overflow"][:3]) and not any(o[2] for o in res["fixed"])
     assert all(o[3] == 0 for o in res["two-pass"]) and all(o[3] == 1 for o in res["fixed"])
-    for tag in ("exact", "overflow", "two-pass", "walk", "sh-fork", "sh-fork-2"):
+    for tag in ("exact", "overflow", "two-pass", "walk", "stage-6144", "stage-4096", "sh-fork", "sh-fork-2"):
         for a, b in zip(res["fixed"], res[tag]):
             assert a[:2] == b[:2], (tag, a[:2], b[:2])
             for f in ("xyz", "color", "cov6", "opacity", "sh", "weight", "is_parent"):
