@@ -488,8 +488,20 @@ def main():
                                      "(22 pairs per splat) -- neighbour work the 8(d) byte model does not count: k_select is bound by VALU issue and L2 request rate, "
                                      "k_mstep by the L2 -> CU gather rate (28 GB per 5 M level), see DESIGN.md 4"}
         if pmc:
-            roof["traffic"] = pmc.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) + pmc.get("hbm_write_bytes_per_launch", 0.0)
+            rd_raw, wr = pmc.get("hbm_read_bytes_per_launch_raw", 0.0), pmc.get("hbm_write_bytes_per_launch", 0.0)
+            roof["traffic"] = pmc.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) + wr
             roof["traffic_source"] = pmc["source"] + " (level-1 launch at 5 M; FETCH_SIZE x2 per MI355X_MICROARCH.md)"
+            # MI355X_MICROARCH.md: "other access widths are uncalibrated: calibrate on a known byte count in your own access pattern".
+            # profiles/r03_fetch_calibration.txt: FETCH_SIZE counts streams at x0.5 but random 64-byte records in full -- the x2 doubles
+            # the gathers of these two kernels.  Calibrated: raw + the half of the kernel's STREAMED bytes the counter leaves out
+            # (k_mstep: the pair list, 8 B per pair, and the 32-byte headers; k_select: nothing of size is streamed from HBM).
+            lv1 = [k for k in kern if k["n_in"] == big_n]
+            streamed = float(np.mean([8.0 * k["pairs"] + 32.0 * k["parents"] for k in lv1])) if (dom == "k_mstep" and lv1) else 0.0
+            roof["traffic_raw"] = rd_raw + wr
+            roof["traffic_calibrated"] = rd_raw + 0.5 * streamed + wr
+            roof["traffic_note"] = ("traffic = FETCH_SIZE x 2 + WRITE_SIZE (the guide's streaming-read correction, kept for comparison with "
+                                    "earlier rounds); traffic_calibrated = FETCH_SIZE + half of the kernel's streamed bytes + WRITE_SIZE "
+                                    "(profiles/r03_fetch_calibration.txt: gathers of 64-byte records are counted in full)")
             vi, va = pmc.get("SQ_INSTS_VALU_per_launch"), pmc.get("SQ_ACTIVE_INST_VALU_per_launch")
             busy = pmc.get("SQ_BUSY_CYCLES_per_launch")
             roof["valu"] = {"insts_per_launch": vi, "active_quad_cycles_per_launch": va,
