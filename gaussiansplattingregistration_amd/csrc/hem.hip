@@ -3023,8 +3023,13 @@ int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out8) {
 }
 
 // GSR_HEM_DEBUG_SYNC=1: synchronise and report after every stage of a level (localises a device fault)
+// Always: a failed LAUNCH of the stage just enqueued (bad configuration, too much LDS) is reported with the stage's name.
 #define GSR_CHECKPOINT(label)                                                                       \
     do {                                                                                            \
+        {                                                                                           \
+            const hipError_t _l = hipGetLastError();                                                \
+            if (_l != hipSuccess) return fail(GSR_E_HIP, "%s: launch failed: %s", label, hipGetErrorString(_l)); \
+        }                                                                                           \
         if (dbg_sync) {                                                                             \
             hipError_t _e = hipStreamSynchronize(st);                                               \
             fprintf(stderr, "[gsr_hem] %s: %s\n", label, hipGetErrorString(_e));                    \

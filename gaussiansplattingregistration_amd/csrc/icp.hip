@@ -1622,6 +1622,7 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     GSR_HIP(hipEventRecord(c->e1, st));
     GSR_HIP(hipStreamSynchronize(st));
     (void)hipEventElapsedTime(&c->ms_build, c->e0, c->e1);
+    GSR_HIP(hipGetLastError());                      // the launches of the index build
     c->nt = n; c->max_corr = max_corr; c->have_target = true; c->have_normals = normals != nullptr;
     c->have_tcov = false; c->have_scov = false; c->have_tcol = false; c->have_scol = false;
     c->have_source = false;              // the source is sorted by the target grid: set it again after a new target
@@ -1875,6 +1876,7 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
                 }
             }
             issued += chunk;
+            GSR_HIP(hipGetLastError());              // a failed launch of the chunk (configuration, LDS) is reported here, not as a hang
             GSR_TRY(icp_fetch(c, c->state.p, &hs, sizeof(hs)));
             if (hs.done) break;
         }
