@@ -38,6 +38,11 @@
 #include <rocprim/rocprim.hpp>
 
 namespace gsr {
+// rocPRIM's Onesweep with its gfx950 kernel shapes but 11 bits per pass: the 22-bit cell keys of a 5 M-point grid take two passes
+// instead of three (up to 2^20 keys rocPRIM's merge sort runs as before)
+using icp_sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                                rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 11,
+                                                                                    rocprim::block_radix_rank_algorithm::match>>;
 
 struct IcpGrid {
     double ox, oy, oz, inv_c, c;
@@ -1608,10 +1613,10 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     int bits = 1;
     while (bits < 32 && ((int64_t)1 << bits) < g.ncells) ++bits;
     size_t bytes = 0;
-    GSR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+    GSR_HIP(rocprim::radix_sort_pairs<icp_sort_cfg>(nullptr, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
                                       c->order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
     GSR_TRY(c->rocprim_tmp.reserve(bytes));
-    GSR_HIP(rocprim::radix_sort_pairs(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+    GSR_HIP(rocprim::radix_sort_pairs<icp_sort_cfg>(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
                                       c->order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
     GSR_TRY(c->cellStart.reserve(((size_t)g.ncells + 1) * 4));
     hipLaunchKernelGGL(k_icp_cell_starts, dim3(stride_grid(n)), dim3(256), 0, st, n, c->skeys.as<unsigned>(), (int64_t)g.ncells, c->cellStart.as<int>());
@@ -1654,10 +1659,10 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t 
         int bits = 1;
         while (bits < 32 && ((int64_t)1 << bits) < c->grid.ncells) ++bits;
         size_t bytes = 0;
-        GSR_HIP(rocprim::radix_sort_pairs(nullptr, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+        GSR_HIP(rocprim::radix_sort_pairs<icp_sort_cfg>(nullptr, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
                                           c->src_order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
         GSR_TRY(c->rocprim_tmp.reserve(bytes));
-        GSR_HIP(rocprim::radix_sort_pairs(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+        GSR_HIP(rocprim::radix_sort_pairs<icp_sort_cfg>(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
                                           c->src_order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
         hipLaunchKernelGGL(k_icp_gather_source, dim3(stride_grid(n)), dim3(256), 0, st, n, c->src_order.as<unsigned>(), raw, c->src.as<float>());
         c->src_sorted = true;
