@@ -64,7 +64,7 @@ def _worker(rank, world, port, q, what):
     elif what == "part":
         from gaussiansplattingregistration_amd.comm import Comm
         cm = Comm.from_torch_group(0)
-        for tag, c in (("iso", synth.make_cloud(60000, seed=61, sh_degree=1)), ("aniso", synth.make_cloud(40000, seed=62, sh_degree=0, shape="aniso"))):
+        for tag, c in _part_clouds(synth):
             if tag == "iso":                                   # a far-away giant: a long-range parent whose sphere crosses every slab
                 c["xyz"][7] = [9.0, 0.5, -0.5]; c["cov6"][7] = [4.0, 0, 0, 3.0, 0, 2.0]
                 c["cov6"][11] = [1.0, 0, 0, 1.0, 0, -1.0]        # and a component the validity erase drops (det <= 0)
@@ -81,6 +81,12 @@ def _worker(rank, world, port, q, what):
     q.put((rank, out))
     dist.barrier()
     dist.destroy_process_group()
+
+
+def _part_clouds(synth):
+    """The clouds of the partition test: SH degree 1 (F = 9), no SH at all, and SH degree 3 (F = 45: 252-byte halo rows, the bench's shape)."""
+    return (("iso", synth.make_cloud(60000, seed=61, sh_degree=1)), ("aniso", synth.make_cloud(40000, seed=62, sh_degree=0, shape="aniso")),
+            ("sh3", synth.make_cloud(30000, seed=63, sh_degree=3)))
 
 
 def _run(what, world=2):
@@ -157,7 +163,7 @@ def test_spatially_partitioned_hem_is_bit_identical_to_one_gpu(world):
     fraction of the cloud as ghosts, not all of it."""
     from gaussiansplattingregistration_amd import hem, parallel, synth
     res = _run("part", world)
-    for tag, c in (("iso", synth.make_cloud(60000, seed=61, sh_degree=1)), ("aniso", synth.make_cloud(40000, seed=62, sh_degree=0, shape="aniso"))):
+    for tag, c in _part_clouds(synth):
         if tag == "iso":
             c["xyz"][7] = [9.0, 0.5, -0.5]; c["cov6"][7] = [4.0, 0, 0, 3.0, 0, 2.0]
             c["cov6"][11] = [1.0, 0, 0, 1.0, 0, -1.0]
