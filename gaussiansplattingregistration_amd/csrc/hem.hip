@@ -2150,17 +2150,33 @@ __global__ __launch_bounds__(256) void k_shard_rows(int lo, int cnt, int F, cons
 // ------------------------------------------------------------------------------------------------
 #define PART_ROW_EXTRA 2      // a ghost row: 16 floats of the packed record, F SH floats, gid, index at its owner
 
-// bits of the cells the search sphere's box of every owned parent covers (the box of select_scan's rows: a superset of what the
-// parent scans).  16 lanes per parent; a word is tested before the atomic (neighbours mark the same cells).
-__global__ __launch_bounds__(256) void k_mark_cells(int64_t n_own, const float4* __restrict__ rec, const GridParams* __restrict__ gpp, float delta,
-                                                    unsigned* __restrict__ mask) {
+// Bits of the cells an owned parent can take candidates from -- two masks per rank:
+//   mask_all  the box of its search sphere (the rows of select_scan's pass B): where IRREGULAR components are wanted;
+//   mask_reg  that box cut down, along y and z, to the box of the parent's pre-reject ellipsoid (make_filter's ey / ez, exactly
+//             the rows pass A enumerates): where REGULAR components are wanted -- a regular child outside the ellipsoid is a
+//             certain rejection, pass A never looks at its cell, so it need not travel.  (40 M splats on 8 ranks: the halo of a
+//             block falls from 40 % to about a quarter of the rank's own components.)
+// 16 lanes per parent; a word is tested before the atomic (neighbours mark the same cells).
+__device__ __forceinline__ void mark_box(const GridParams& g, int sub, int x0, int x1, int y0, int y1, int z0, int z1, unsigned* __restrict__ mask) {
+    const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
+    for (int r = sub; r < nrows; r += 16) {
+        const int64_t c0 = ((int64_t)(z0 + r / ny) * g.gy + (y0 + r % ny)) * g.gx + x0, c1 = c0 + (x1 - x0);
+        for (int64_t w = c0 >> 5; w <= (c1 >> 5); ++w) {
+            const int lo = w == (c0 >> 5) ? (int)(c0 & 31) : 0, hi = w == (c1 >> 5) ? (int)(c1 & 31) : 31;
+            const unsigned bits = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+            if ((mask[w] & bits) != bits) atomicOr(&mask[w], bits);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_mark_cells(int64_t n_own, const float4* __restrict__ rec, const GridParams* __restrict__ gpp, float delta, float kldThr,
+                                                    int ell, unsigned* __restrict__ mask_reg, unsigned* __restrict__ mask_all) {
     const GridParams g = *gpp;
     const int sub = threadIdx.x & 15;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 4;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < n_own; i += stride) {
         const float4 a = rec[4 * i];
         if (!(__float_as_uint(a.w) & 1u)) continue;
-        const float4 b = rec[4 * i + 1], cc = rec[4 * i + 2];
+        const float4 b = rec[4 * i + 1], cc = rec[4 * i + 2], d = rec[4 * i + 3];
         const s6 cov = {b.x, b.y, b.z, b.w, cc.x, cc.y};
         const float R = delta * sqrtf(eig_max6(cov));
         const bool finite = fabsf(a.x) <= FLT_MAX && fabsf(a.y) <= FLT_MAX && fabsf(a.z) <= FLT_MAX;
@@ -2169,26 +2185,32 @@ __global__ __launch_bounds__(256) void k_mark_cells(int64_t n_own, const float4*
         const int x0 = cell_of(a.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(a.x + Ra, g.ox, g.inv_c, g.gx);
         const int y0 = cell_of(a.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(a.y + Ra, g.oy, g.inv_c, g.gy);
         const int z0 = cell_of(a.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(a.z + Ra, g.oz, g.inv_c, g.gz);
-        const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-        for (int r = sub; r < nrows; r += 16) {
-            const int64_t c0 = ((int64_t)(z0 + r / ny) * g.gy + (y0 + r % ny)) * g.gx + x0, c1 = c0 + (x1 - x0);
-            for (int64_t w = c0 >> 5; w <= (c1 >> 5); ++w) {
-                const int lo = w == (c0 >> 5) ? (int)(c0 & 31) : 0, hi = w == (c1 >> 5) ? (int)(c1 & 31) : 31;
-                const unsigned bits = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
-                if ((mask[w] & bits) != bits) atomicOr(&mask[w], bits);
-            }
+        mark_box(g, sub, x0, x1, y0, y1, z0, z1, mask_all);
+        // the same record k_parent_prep builds for this parent (same float32 inverse, same filter): pass A's rows
+        ParentRec pr;
+        const float det_p = d.w;
+        make_filter(inverse6(cov, det_p), det_p, kldThr, ell, (__float_as_uint(a.w) & 2u) != 0u, pr);
+        if (pr.ec.on != 0.0f) {
+            const float Ry = fminf(Ra, pr.ey + g.slack), Rz = fminf(Ra, pr.ez + g.slack);
+            const int yy0 = cell_of(a.y - Ry, g.oy, g.inv_c, g.gy), yy1 = cell_of(a.y + Ry, g.oy, g.inv_c, g.gy);
+            const int zz0 = cell_of(a.z - Rz, g.oz, g.inv_c, g.gz), zz1 = cell_of(a.z + Rz, g.oz, g.inv_c, g.gz);
+            mark_box(g, sub, x0, x1, yy0, yy1, zz0, zz1, mask_reg);
+        } else {
+            mark_box(g, sub, x0, x1, y0, y1, z0, z1, mask_reg);
         }
     }
 }
-// dflag[q][i] = 1 when owned component i lies in a cell rank q marked (q != self)
+// dflag[q][i] = 1 when owned component i lies in a cell rank q marked (q != self): in its mask for regular components or, an
+// irregular one, in its sphere mask.  masks: per rank [mask_reg | mask_all], mask_words words each.
 __global__ __launch_bounds__(256) void k_dest_flags(int64_t n_own, const float4* __restrict__ rec, const GridParams* __restrict__ gpp, int world, int self,
                                                     int64_t mask_words, const unsigned* __restrict__ masks, int* __restrict__ dflag) {
     const GridParams g = *gpp;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += (int64_t)gridDim.x * blockDim.x) {
         const float4 a = rec[4 * i];
         const int64_t c = ((int64_t)cell_of(a.z, g.oz, g.inv_c, g.gz) * g.gy + cell_of(a.y, g.oy, g.inv_c, g.gy)) * g.gx + cell_of(a.x, g.ox, g.inv_c, g.gx);
+        const int64_t which = (__float_as_uint(a.w) & 2u) ? 0 : mask_words;          // regular: mask_reg, irregular: mask_all
         for (int q = 0; q < world; ++q)
-            dflag[(int64_t)q * n_own + i] = q != self && ((masks[(int64_t)q * mask_words + (c >> 5)] >> (c & 31)) & 1u) ? 1 : 0;
+            dflag[(int64_t)q * n_own + i] = q != self && ((masks[(int64_t)q * 2 * mask_words + which + (c >> 5)] >> (c & 31)) & 1u) ? 1 : 0;
     }
 }
 // rows to send: for destination q the k-th flagged owned component (pos = exclusive scan of its flags)
@@ -3150,11 +3172,12 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (part) {
         // ---- halo: which cells do my parents' search spheres touch -> masks of all ranks -> my components they need -> rows
         const int64_t mwords = ((int64_t)gp.ncells + 31) / 32 + 1;
-        GSR_TRY(c->cmask.reserve((size_t)W * mwords * 4));
-        unsigned* my_mask = c->cmask.as<unsigned>() + (int64_t)me * mwords;
-        GSR_HIP(hipMemsetAsync(my_mask, 0, (size_t)mwords * 4, st));
-        hipLaunchKernelGGL(k_mark_cells, dim3(stride_grid(n_own * 16)), blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), c->delta, my_mask);
-        GSR_TRY(gsr_comm_allgather(c->comm, my_mask, c->cmask.p, mwords * 4, (void*)st));
+        GSR_TRY(c->cmask.reserve((size_t)W * 2 * mwords * 4));
+        unsigned* my_mask = c->cmask.as<unsigned>() + (int64_t)me * 2 * mwords;      // [cells wanted of regular components | of irregular ones]
+        GSR_HIP(hipMemsetAsync(my_mask, 0, (size_t)2 * mwords * 4, st));
+        hipLaunchKernelGGL(k_mark_cells, dim3(stride_grid(n_own * 16)), blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), c->delta,
+                           c->delta * c->delta * 0.5f, c->use_ell ? 1 : 0, my_mask, my_mask + mwords);
+        GSR_TRY(gsr_comm_allgather(c->comm, my_mask, c->cmask.p, 2 * mwords * 4, (void*)st));
         GSR_TRY(c->dflag.reserve((size_t)W * n_own * 4)); GSR_TRY(c->dpos.reserve((size_t)W * n_own * 4));
         hipLaunchKernelGGL(k_dest_flags, grd, blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), W, me, mwords, c->cmask.as<unsigned>(),
                            c->dflag.as<int>());

@@ -149,8 +149,9 @@ int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_all
  * then runs the level on owned + ghost components and the result is BIT FOR BIT the single-GPU level, distributed: per level
  *   - integer all-reduces of the bounding box (24 bytes), the axis histograms (12 KB) and two bit maps over the level's global
  *     indices (n_global / 4 bytes): every rank derives the same grid and the same global output ranks;
- *   - one all-gather of a bit mask over the grid's cells (which cells do my parents' search spheres touch) and ONE personalised
- *     exchange of halo rows (64 + 4F + 8 bytes per component that another rank's parents may reach);
+ *   - one all-gather of two bit masks over the grid's cells (which cells can my parents take regular / irregular candidates from:
+ *     the box of the pre-reject ellipsoid / of the search sphere) and ONE personalised exchange of halo rows (64 + 4F + 8 bytes
+ *     per component that another rank's parents may reach);
  *   - five small exchanges along the same halo lists for the per-child sums: maxima (u32), the owners' maxima back, 64-bit
  *     fixed-point partial sums, the owners' float32 sums back -- no floating-point value is ever combined across ranks.
  * The new level stays distributed (gsr_hem_get_level returns the owned rows, gsr_hem_get_gids their global indices; ownership

@@ -3,7 +3,8 @@ synth.make_cloud (uniform in a cube, radius R = 3 max(s), s = exp(N(-2.5, 0.5)))
 ghosts are the components of OTHER slabs in the grid cells its parents' search boxes touch (k_mark_cells).  Monte Carlo over the
 parents of one interior rank; 3-D difference array over the neighbouring slabs' cells."""
 import numpy as np
-n, world, rho, F = 40_000_000, 8, 3.0, 45
+import sys
+n, world, rho, F = (int(sys.argv[1]) if len(sys.argv) > 1 else 40_000_000), 8, 3.0, 45
 dens = 50000 / 27.0                      # synth.half_extent: 50 k splats in a cube of side 3
 side = (n / dens) ** (1 / 3)
 slab = side / world
