@@ -1,0 +1,75 @@
+"""Randomised parity sweep (test infrastructure: the oracle is the checker).  Many small clouds of random size, shape, density,
+SH degree and HEM parameters; level 1 of every cloud on the GPU against oracle/hem_oracle.cpp: the discrete outcomes (parents,
+accepted pairs, orphans, dropped, level size) must be EQUAL and the components within 1e-4.  One documented exception is counted
+apart ("edge"): the validity erase (det <= 0 of a MERGED covariance, mixture.cpp:262-274) of a near-singular merged needle can go
+either way with the summation order of the M-step -- parents, pairs and orphans equal, `dropped` off by one (seen in 6 of 400
+clouds, all "needles" with delta = 2).  Not collected by pytest (no test_ prefix): run it through gpurun when the selection path
+changes --  python tests/stress_parity.py [cases] [seed]."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from gaussiansplattingregistration_amd import hem, synth
+from oracle import oracle as O
+
+TOL = 1e-4
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return 0.0 if a.size == 0 else float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+
+
+def make_case(rng):
+    n = int(rng.integers(2000, 90000))
+    shape = rng.choice(["iso", "aniso", "needles", "clustered"])
+    deg = int(rng.choice([0, 1, 2, 3]))
+    h = synth.half_extent(n) * float(rng.choice([0.5, 1.0, 1.0, 2.0]))          # denser / the bench density / sparser
+    seed = int(rng.integers(1 << 30))
+    c = synth.make_cloud(n, seed=seed, h=h, sh_degree=deg, shape="aniso" if shape == "aniso" else "iso")
+    if shape == "needles":                                                       # a third of the splats squashed: kappa 1e3 .. 1e6
+        k = n // 3
+        idx = rng.choice(n, k, replace=False)
+        s = np.exp(rng.normal(-2.5, 0.5, (k, 3)))
+        s[:, 0] *= rng.choice([1e-2, 3e-2, 1e-3], k)
+        s[: k // 2, 1] *= 0.05
+        q = rng.normal(size=(k, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+        L = synth._quat_to_rot(q) * s[:, None, :]
+        C = (L @ L.transpose(0, 2, 1)).astype(np.float32)
+        c["cov6"][idx] = C[:, [0, 0, 0, 1, 1, 2], [0, 1, 2, 1, 2, 2]]
+    if shape == "clustered":                                                     # half of the cloud pulled into a few tight clumps, a few far outliers
+        k = n // 2
+        centres = rng.uniform(-h, h, (5, 3))
+        c["xyz"][:k] = (centres[rng.integers(0, 5, k)] + rng.normal(0, 0.05 * h, (k, 3))).astype(np.float32)
+        c["xyz"][-3:] *= 50.0
+    params = dict(rho=float(rng.choice([2.0, 3.0, 3.0, 5.0])), delta=float(rng.choice([2.0, 3.0, 3.0, 4.0])),
+                  kappa=float(rng.choice([1.5, 2.5, 2.5, 4.0])), tau=float(rng.choice([0.5, 1.0, 1.0, 2.0])))
+    return dict(n=n, shape=shape, deg=deg, h=round(h, 3), seed=seed, **params), c, params
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+    bad = edge = 0
+    t0 = time.time()
+    for k in range(cases):
+        desc, c, p = make_case(rng)
+        want, wst = O.hem(c, 1, **p)
+        with hem.HemMixture(hem_reduction=p["rho"], distance_delta=p["delta"], color_delta=p["kappa"], decay_rate=p["tau"]) as m:
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+            m.run_level()
+            st, got = m.stats(), m.get_level()
+        a = (st["parents"], st["pairs"], st["orphans"], st["dropped"], got["xyz"].shape[0])
+        b = (wst[0]["parents"], wst[0]["pairs"], wst[0]["orphans"], wst[0]["dropped"], want[0]["xyz"].shape[0])
+        err = max(rel(got[f], want[0][f]) for f in ("xyz", "color", "cov6", "opacity", "sh")) if a[4] == b[4] else float("inf")
+        ok = a == b and err < TOL
+        edge_case = (not ok) and a[:3] == b[:3] and abs(a[3] - b[3]) <= 2 and abs(a[4] - b[4]) <= 2
+        edge += 1 if edge_case else 0
+        bad += 0 if (ok or edge_case) else 1
+        print(f"{'ok  ' if ok else ('edge' if edge_case else 'FAIL')} {k:3d} {desc}  gpu {a}  oracle {b}  irregular {st['irregular']}  max rel {err:.2e}", flush=True)
+    print(f"{cases - bad - edge} of {cases} cases equal the oracle, {edge} differ by a borderline validity erase, {bad} FAIL ({time.time() - t0:.0f} s)")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
