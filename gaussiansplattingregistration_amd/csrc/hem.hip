@@ -2405,12 +2405,14 @@ __global__ __launch_bounds__(256) void k_bits_rank(int64_t n_own, const unsigned
         if (flag[i]) { const unsigned g = gid[i]; rank[i] = base + (unsigned)wpre[g >> 5] + (unsigned)__popc(bits[g >> 5] & ((1u << (g & 31)) - 1u)); }
 }
 // new gid of every output row: parents' rows by their local parent rank, orphans' rows behind them by their local orphan rank
+// (a component can be BOTH: a parent nobody selects -- not even itself: a degenerate needle whose self pair fails the gates -- has
+// sumLw == 0 and is copied as an orphan beside its merged row, mixture.cpp:250-253: two rows, two ranks)
 __global__ __launch_bounds__(256) void k_part_new_gid(int64_t n_own, int P_loc, const int* __restrict__ pflag_in, const int* __restrict__ prank_in,
-                                                      const int* __restrict__ oflag_in, const int* __restrict__ orank_in, const unsigned* __restrict__ grank,
-                                                      unsigned* __restrict__ new_gid) {
+                                                      const int* __restrict__ oflag_in, const int* __restrict__ orank_in, const unsigned* __restrict__ grank_p,
+                                                      const unsigned* __restrict__ grank_o, unsigned* __restrict__ new_gid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_own; i += (int64_t)gridDim.x * blockDim.x) {
-        if (pflag_in[i]) new_gid[prank_in[i]] = grank[i];
-        else if (oflag_in[i]) new_gid[P_loc + orank_in[i]] = grank[i];
+        if (pflag_in[i]) new_gid[prank_in[i]] = grank_p[i];
+        if (oflag_in[i]) new_gid[P_loc + orank_in[i]] = grank_o[i];
     }
 }
 __global__ __launch_bounds__(256) void k_gather_bytes(int64_t n, const unsigned* __restrict__ idx, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst) {
@@ -3749,7 +3751,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (part) {
         const int64_t words = (c->n_global + 31) / 32 + 1;
         GSR_TRY(c->gbits.reserve((size_t)2 * words * 4)); GSR_TRY(c->wcnt.reserve((size_t)2 * words * 4)); GSR_TRY(c->wpre.reserve((size_t)2 * words * 4));
-        GSR_TRY(c->grank.reserve((size_t)n_own * 4)); GSR_TRY(c->gid_next.reserve((size_t)(n_pre > 0 ? n_pre : 1) * 4));
+        GSR_TRY(c->grank.reserve((size_t)2 * n_own * 4)); GSR_TRY(c->gid_next.reserve((size_t)(n_pre > 0 ? n_pre : 1) * 4));     // [ranks as parents | as orphans]
         GSR_HIP(hipMemsetAsync(c->gbits.p, 0, (size_t)2 * words * 4, st));
         const dim3 go(stride_grid(n_own));
         hipLaunchKernelGGL(k_bits_set, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->pflag_in.as<int>(), c->gbits.as<unsigned>());
@@ -3771,9 +3773,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL(k_bits_rank, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->pflag_in.as<int>(), c->gbits.as<unsigned>(), c->wpre.as<int>(), 0u,
                            c->grank.as<unsigned>());
         hipLaunchKernelGGL(k_bits_rank, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->oflag_in.as<int>(), c->gbits.as<unsigned>() + words, c->wpre.as<int>() + words,
-                           (unsigned)P_glob, c->grank.as<unsigned>());
+                           (unsigned)P_glob, c->grank.as<unsigned>() + n_own);
         hipLaunchKernelGGL(k_part_new_gid, go, blk, 0, st, n_own, P, c->pflag_in.as<int>(), c->prank_in.as<int>(), c->oflag_in.as<int>(), c->orank_in.as<int>(),
-                           c->grank.as<unsigned>(), c->gid_next.as<unsigned>());
+                           c->grank.as<unsigned>(), c->grank.as<unsigned>() + n_own, c->gid_next.as<unsigned>());
         c->part_stats[4] = P_glob; c->part_stats[5] = O_glob;
     }
     const int64_t n_pre_glob = P_glob + O_glob;

@@ -84,9 +84,15 @@ def _worker(rank, world, port, q, what):
 
 
 def _part_clouds(synth):
-    """The clouds of the partition test: SH degree 1 (F = 9), no SH at all, and SH degree 3 (F = 45: 252-byte halo rows, the bench's shape)."""
+    """The clouds of the partition test: SH degree 1 (F = 9), no SH at all, SH degree 3 (F = 45: 252-byte halo rows, the bench's shape),
+    and a cloud with needles in which a component is parent AND orphan."""
+    import stress_parity                      # tests/stress_parity.py: the random clouds of the parity sweep
+    rng = np.random.default_rng(99)
+    needles = [stress_parity.make_case(rng) for _ in range(11)][10][1]      # 86 k splats, a third needles: one PARENT of it is selected by
+    # nobody, not even itself -- sumLw == 0 --, so it is copied as an orphan beside its merged row (mixture.cpp:250-253): the
+    # component has two output rows and two global ranks (found by tests/stress_partition.py: the ranks were one array)
     return (("iso", synth.make_cloud(60000, seed=61, sh_degree=1)), ("aniso", synth.make_cloud(40000, seed=62, sh_degree=0, shape="aniso")),
-            ("sh3", synth.make_cloud(30000, seed=63, sh_degree=3)))
+            ("sh3", synth.make_cloud(30000, seed=63, sh_degree=3)), ("needles", needles))
 
 
 def _run(what, world=2):
