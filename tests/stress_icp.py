@@ -1,0 +1,57 @@
+"""Randomised ICP sweep (test infrastructure, not collected by pytest): random pairs -- size, density, misalignment, outliers,
+max_corr from a fraction of a cell to many cells, estimator (point-to-point / point-to-plane), robust loss -- on the GPU against
+oracle/icp_oracle.cpp: the exact correspondences of the initial transform (indices EQUAL), then the registration (same iteration
+count, transform within 1e-5 Frobenius, fitness within 1e-9).  usage: python tests/stress_icp.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from gaussiansplattingregistration_amd import icp, synth
+from oracle import oracle as O
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+    bad = 0
+    t0 = time.time()
+    for k in range(cases):
+        n = int(rng.integers(1500, 60000))
+        seed = int(rng.integers(1 << 30))
+        angle = float(rng.choice([0.5, 2.0, 5.0]))
+        src, tgt, T_gt = synth.make_pair(n, seed=seed, sh_degree=0, angle_deg=angle)
+        sx, tx = src["xyz"].copy(), tgt["xyz"].copy()
+        if rng.random() < 0.4:                           # a tenth of the source thrown far out; a tenth of the target duplicated
+            m = rng.choice(n, n // 10, replace=False)
+            sx[m] += rng.normal(0, 3.0, (len(m), 3)).astype(np.float32)
+            tx[rng.choice(n, n // 10, replace=False)] = tx[rng.choice(n, n // 10, replace=False)]
+        if rng.random() < 0.3:                           # large coordinates: float32 spacing 1e-4
+            off = np.float32(rng.choice([300.0, 2000.0]))
+            sx += off; tx += off
+        kind = int(rng.choice([0, 1]))
+        loss = int(rng.choice([0, 0, 1, 2, 3, 4])) if kind == 1 else 0
+        kk = float(rng.choice([0.01, 0.05, 0.2]))
+        mc = float(rng.choice([0.02, 0.08, 0.2, 0.6]))
+        iters = int(rng.choice([3, 10, 25]))
+        nrm = icp.normals_from_cov(tgt["cov6"]) if kind == 1 else None
+        init = np.eye(4); init[:3, 3] = rng.normal(0, 0.01, 3)
+        with icp.IcpContext() as c:
+            c.set_target(tx, None, mc); c.set_source(sx)
+            idx, d2 = c.correspondences(init)
+        widx, wd2 = O.icp_correspond(sx, tx, init, mc)
+        ok_c = np.array_equal(idx, widx)
+        w = O.icp(sx, tx, nrm, init, kind=kind, loss=loss, k=kk, max_corr=mc, max_iter=iters)
+        r = icp.registration_icp_arrays(sx, tx, nrm, init, kind=kind, loss=loss, k=kk, max_corr=mc, max_iter=iters)
+        dT = float(np.linalg.norm(r["transformation"] - w["transformation"]))
+        ok_r = r["iterations"] == w["iterations"] and dT < 1e-5 and abs(r["fitness"] - w["fitness"]) < 1e-9
+        ok = ok_c and ok_r
+        bad += 0 if ok else 1
+        print(f"{'ok  ' if ok else 'FAIL'} {k:3d} n={n} angle={angle} kind={kind} loss={loss} k={kk} max_corr={mc} iters={iters}: correspondences "
+              f"{'equal' if ok_c else 'DIFFER'} ({int((idx >= 0).sum())} matched), iterations {r['iterations']}/{w['iterations']}, |dT| {dT:.1e}, "
+              f"fitness {r['fitness']:.6f}/{w['fitness']:.6f}", flush=True)
+    print(f"{cases - bad} of {cases} ICP cases equal the oracle ({time.time() - t0:.0f} s)")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
