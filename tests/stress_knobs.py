@@ -1,0 +1,68 @@
+"""Randomised "changes nothing" sweep (test infrastructure, not collected by pytest): on random clouds (the shapes of
+tests/stress_parity.py, plus a few giant splats that make heavy parents) every implementation knob of the HEM level must leave two
+levels BIT FOR BIT what the default gives.  usage: python tests/stress_knobs.py [cases] [seed]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from gaussiansplattingregistration_amd import hem
+from stress_parity import make_case
+
+KNOBS = [{"GSR_HEM_ELL": "0"}, {"GSR_HEM_SPLIT": "0"}, {"GSR_HEM_PARTITION": "walk"}, {"GSR_HEM_PARTITION": "exact"},
+         {"GSR_HEM_PARTITION_STAGE": "4096"}, {"GSR_HEM_PARTITION_FACTOR": "0.3"}, {"GSR_HEM_SPARSE_GB": "0"}, {"GSR_HEM_CELL_TARGET": "4"},
+         {"GSR_HEM_CELL_TARGET": "40"}, {"GSR_HEM_SH_OVERLAP": "2"}, {"GSR_HEM_RB_POLL": "0"}, {"GSR_HEM_SUMLW": "sort"}]
+ALL = sorted({k for d in KNOBS for k in d})
+
+
+def run(c):
+    out = []
+    with hem.HemMixture() as m:
+        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+        for _ in range(2):
+            m.run_level()
+            st = m.stats()
+            out.append(((st["parents"], st["pairs"], st["orphans"], st["dropped"]), m.get_level(with_state=True)))
+    return out
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
+    bad = 0
+    t0 = time.time()
+    for i in range(cases):
+        desc, c, _ = make_case(rng)
+        if rng.random() < 0.5:                              # a few giants: parents with 10^4 .. 10^5 candidates (work items, k_join_parts)
+            g = rng.choice(len(c["xyz"]), 4, replace=False)
+            c["cov6"][g] = np.array([0.6, 0, 0, 0.5, 0, 0.4], np.float32)
+        for k in ALL:
+            os.environ.pop(k, None)
+        ref = run(c)
+        fails = []
+        for kn in KNOBS:
+            for k in ALL:
+                os.environ.pop(k, None)
+            os.environ.update(kn)
+            got = run(c)
+            # another grid changes the ORDER of a parent's candidates, the sort path sums floats sequentially: level 1 with equal
+            # counts and values to 1e-4 (level 2 may then flip a borderline pair); every other knob bit for bit on both levels
+            exact = "GSR_HEM_SUMLW" not in kn and "GSR_HEM_CELL_TARGET" not in kn
+            for lvl, (a, b) in enumerate(zip(ref, got)):
+                if not exact and lvl > 0:
+                    break
+                same = a[0] == b[0] and all((np.array_equal(a[1][f], b[1][f]) if exact else
+                                             (a[1][f].shape == b[1][f].shape and np.allclose(a[1][f], b[1][f], rtol=1e-4, atol=1e-6)))
+                                            for f in ("xyz", "color", "cov6", "opacity", "sh", "weight", "is_parent"))
+                if not same:
+                    fails.append((kn, lvl + 1, a[0], b[0]))
+                    break
+        for k in ALL:
+            os.environ.pop(k, None)
+        bad += 1 if fails else 0
+        print("ok  " if not fails else "FAIL", i, desc, [r[0] for r in ref], fails[:3], flush=True)
+    print(f"{cases - bad} of {cases} clouds: every knob leaves two levels unchanged ({time.time() - t0:.0f} s)")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
