@@ -4,7 +4,8 @@ accepted pairs, orphans, dropped, level size) must be EQUAL and the components w
 apart ("edge"): the validity erase (det <= 0 of a MERGED covariance, mixture.cpp:262-274) of a near-singular merged needle can go
 either way with the summation order of the M-step -- parents, pairs and orphans equal, `dropped` off by one (seen in 6 of 400
 clouds, all "needles" with delta = 2).  Not collected by pytest (no test_ prefix): run it through gpurun when the selection path
-changes --  python tests/stress_parity.py [cases] [seed]."""
+changes --  python tests/stress_parity.py [cases] [seed]   (STRESS_PATHOLOGIES=1: a handful of NaN / inf / degenerate components in
+every cloud)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -16,8 +17,16 @@ TOL = 1e-4
 
 
 def rel(a, b):
+    """max |a - b| over max |b| on the finite entries; inf when NaN / inf sit in different places"""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return 0.0 if a.size == 0 else float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-30))
+    if a.size == 0:
+        return 0.0
+    fa, fb = np.isfinite(a), np.isfinite(b)
+    if not np.array_equal(fa, fb) or not np.array_equal(np.isnan(a), np.isnan(b)):
+        return float("inf")
+    if not fa.any():
+        return 0.0
+    return float(np.max(np.abs(a[fa] - b[fb])) / (np.max(np.abs(b[fb])) + 1e-30))
 
 
 def make_case(rng):
@@ -42,6 +51,18 @@ def make_case(rng):
         centres = rng.uniform(-h, h, (5, 3))
         c["xyz"][:k] = (centres[rng.integers(0, 5, k)] + rng.normal(0, 0.05 * h, (k, 3))).astype(np.float32)
         c["xyz"][-3:] *= 50.0
+    if os.environ.get("STRESS_PATHOLOGIES"):              # a handful of broken components in a cloud of ordinary size
+        def pick(m):
+            return rng.choice(n, m, replace=False)
+        if rng.random() < 0.5: c["cov6"][pick(20)] = 0.0
+        if rng.random() < 0.5: c["cov6"][pick(20)] = np.array([1, 0, 0, 1, 0, -1], np.float32) * 0.01
+        if rng.random() < 0.4: c["cov6"][pick(10), int(rng.integers(6))] = np.nan
+        if rng.random() < 0.4: c["xyz"][pick(10), int(rng.integers(3))] = np.nan
+        if rng.random() < 0.3: c["xyz"][pick(5), int(rng.integers(3))] = np.inf
+        if rng.random() < 0.4: c["cov6"][pick(30)] *= np.float32(1e8)
+        if rng.random() < 0.4: c["cov6"][pick(30)] *= np.float32(1e-12)
+        if rng.random() < 0.3: c["opacity"][pick(20)] = np.nan
+        if rng.random() < 0.3: i = pick(200); c["xyz"][i] = c["xyz"][rng.choice(n, 200)]
     params = dict(rho=float(rng.choice([2.0, 3.0, 3.0, 5.0])), delta=float(rng.choice([2.0, 3.0, 3.0, 4.0])),
                   kappa=float(rng.choice([1.5, 2.5, 2.5, 4.0])), tau=float(rng.choice([0.5, 1.0, 1.0, 2.0])))
     return dict(n=n, shape=shape, deg=deg, h=round(h, 3), seed=seed, **params), c, params
@@ -63,7 +84,8 @@ def main():
         b = (wst[0]["parents"], wst[0]["pairs"], wst[0]["orphans"], wst[0]["dropped"], want[0]["xyz"].shape[0])
         err = max(rel(got[f], want[0][f]) for f in ("xyz", "color", "cov6", "opacity", "sh")) if a[4] == b[4] else float("inf")
         ok = a == b and err < TOL
-        edge_case = (not ok) and a[:3] == b[:3] and abs(a[3] - b[3]) <= 2 and abs(a[4] - b[4]) <= 2
+        lim = 8 if os.environ.get("STRESS_PATHOLOGIES") else 2     # (merges with a 1e8-scaled needle: the determinant is cancellation noise)
+        edge_case = (not ok) and a[:3] == b[:3] and abs(a[3] - b[3]) <= lim and abs(a[4] - b[4]) <= lim
         edge += 1 if edge_case else 0
         bad += 0 if (ok or edge_case) else 1
         print(f"{'ok  ' if ok else ('edge' if edge_case else 'FAIL')} {k:3d} {desc}  gpu {a}  oracle {b}  irregular {st['irregular']}  max rel {err:.2e}", flush=True)
