@@ -49,12 +49,13 @@ def main():
         ok = True
         for k in range(2):
             got = parallel.assemble_partitioned_level([res[r][i][k] for r in range(world)])
-            same = got["xyz"].shape == want[k]["xyz"].shape and all(np.array_equal(got[f], want[k][f]) for f in ("xyz", "color", "cov6", "opacity", "sh"))
+            bits = lambda a: np.ascontiguousarray(a, np.float32).view(np.uint32)        # bit patterns: NaN rows must be the same NaNs
+            same = got["xyz"].shape == want[k]["xyz"].shape and all(np.array_equal(bits(got[f]), bits(want[k][f])) for f in ("xyz", "color", "cov6", "opacity", "sh"))
             if not same and os.environ.get("STRESS_VERBOSE"):
                 print("   level", k + 1, "shapes", got["xyz"].shape, want[k]["xyz"].shape)
                 if got["xyz"].shape == want[k]["xyz"].shape:
                     for f in ("xyz", "color", "cov6", "opacity", "sh"):
-                        d = np.any(np.asarray(got[f]).reshape(len(got[f]), -1) != np.asarray(want[k][f]).reshape(len(got[f]), -1), axis=1)
+                        d = np.any(bits(got[f]).reshape(len(got[f]), -1) != bits(want[k][f]).reshape(len(got[f]), -1), axis=1)
                         if d.any():
                             w = np.flatnonzero(d)
                             print("     ", f, "rows differing", len(w), "first", w[:5], "max abs", float(np.abs(np.asarray(got[f], np.float64) - want[k][f]).max()))
