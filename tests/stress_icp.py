@@ -1,5 +1,5 @@
 """Randomised ICP sweep (test infrastructure, not collected by pytest): random pairs -- size, density, misalignment, outliers,
-max_corr from a fraction of a cell to many cells, estimator (point-to-point / point-to-plane), robust loss -- on the GPU against
+max_corr from a fraction of a cell to many cells, estimator (point-to-point / point-to-plane / generalized / colored), robust loss -- on the GPU against
 oracle/icp_oracle.cpp: the exact correspondences of the initial transform (indices EQUAL), then the registration (same iteration
 count, transform within 1e-5 Frobenius, fitness within 1e-9).  usage: python tests/stress_icp.py [cases] [seed]"""
 import os, sys, time
@@ -28,22 +28,34 @@ def main():
         if rng.random() < 0.3:                           # large coordinates: float32 spacing 1e-4
             off = np.float32(rng.choice([300.0, 2000.0]))
             sx += off; tx += off
-        kind = int(rng.choice([0, 1]))
-        loss = int(rng.choice([0, 0, 1, 2, 3, 4])) if kind == 1 else 0
+        kind = int(rng.choice([0, 1, 1, 2, 3]))           # point-to-point, point-to-plane, generalized, colored
+        loss = int(rng.choice([0, 0, 1, 2, 3, 4])) if kind != 0 else 0
         kk = float(rng.choice([0.01, 0.05, 0.2]))
         mc = float(rng.choice([0.02, 0.08, 0.2, 0.6]))
         iters = int(rng.choice([3, 10, 25]))
-        nrm = icp.normals_from_cov(tgt["cov6"]) if kind == 1 else None
+        nrm = icp.normals_from_cov(tgt["cov6"]) if kind in (1, 3) else None
+        c33 = lambda c6: np.stack([np.asarray(c6, np.float64)[:, [0, 1, 2]], np.asarray(c6, np.float64)[:, [1, 3, 4]], np.asarray(c6, np.float64)[:, [2, 4, 5]]], 1)
+        scol = np.clip(0.5 + 0.3 * np.sin(3.0 * sx.astype(np.float64)), 0, 1)          # a smooth colour field of the coordinates (+ noise on the source)
+        tcol = np.clip(0.5 + 0.3 * np.sin(3.0 * tx.astype(np.float64)), 0, 1)
+        scol = np.clip(scol + rng.normal(0, 0.01, scol.shape), 0, 1)
         init = np.eye(4); init[:3, 3] = rng.normal(0, 0.01, 3)
         with icp.IcpContext() as c:
             c.set_target(tx, None, mc); c.set_source(sx)
             idx, d2 = c.correspondences(init)
         widx, wd2 = O.icp_correspond(sx, tx, init, mc)
         ok_c = np.array_equal(idx, widx)
-        w = O.icp(sx, tx, nrm, init, kind=kind, loss=loss, k=kk, max_corr=mc, max_iter=iters)
-        r = icp.registration_icp_arrays(sx, tx, nrm, init, kind=kind, loss=loss, k=kk, max_corr=mc, max_iter=iters)
+        if kind == 2:
+            w = O.gicp(sx, c33(src["cov6"]), tx, c33(tgt["cov6"]), init, loss=loss, k=kk, max_corr=mc, max_iter=iters)
+            r = icp.registration_icp_arrays(sx, tx, None, init, kind=2, loss=loss, k=kk, max_corr=mc, max_iter=iters, src_cov=src["cov6"], tgt_cov=tgt["cov6"])
+        elif kind == 3:
+            w = O.colored_icp(sx.astype(np.float64), scol, tx.astype(np.float64), nrm, tcol, init, loss=loss, k=kk, max_corr=mc, max_iter=iters)
+            r = icp.registration_icp_arrays(sx, tx, nrm, init, kind=3, loss=loss, k=kk, max_corr=mc, max_iter=iters, src_color=scol, tgt_color=tcol)
+        else:
+            w = O.icp(sx, tx, nrm, init, kind=kind, loss=loss, k=kk, max_corr=mc, max_iter=iters)
+            r = icp.registration_icp_arrays(sx, tx, nrm, init, kind=kind, loss=loss, k=kk, max_corr=mc, max_iter=iters)
         dT = float(np.linalg.norm(r["transformation"] - w["transformation"]))
-        ok_r = r["iterations"] == w["iterations"] and dT < 1e-5 and abs(r["fitness"] - w["fitness"]) < 1e-9
+        lost = r["fitness"] == 0.0 and w["fitness"] == 0.0            # both lost every correspondence: the last update came from an ill-conditioned system
+        ok_r = r["iterations"] == w["iterations"] and (dT < 1e-5 or lost) and abs(r["fitness"] - w["fitness"]) < 1e-9
         ok = ok_c and ok_r
         bad += 0 if ok else 1
         print(f"{'ok  ' if ok else 'FAIL'} {k:3d} n={n} angle={angle} kind={kind} loss={loss} k={kk} max_corr={mc} iters={iters}: correspondences "
