@@ -1390,7 +1390,10 @@ struct gsr_icp_ctx {
     // 8 % slower at 0.2 M (one more launch).  -1 = choose by size (the default).  Same results either way
     // (tests/test_icp_gpu.py::test_icp_knobs_change_nothing).
     int nn_kernel = -1;
-    int nn_mode() const { return nn_kernel >= 0 ? (nn_kernel ? 2 : 0) : (ns >= 1000000 ? 2 : 0); }
+    // the search in its own kernel (k_icp_nn, few registers, full occupancy) + a streaming accumulate from 400 k source points on:
+    // measured on the bench's levels with the XCD-contiguous ranges, fused / split: 185 k 51.7 / 59.2 us, 556 k 90.1 / 81.6, 1.67 M 233 / 190,
+    // 5 M 563 / 397 per iteration
+    int nn_mode() const { return nn_kernel >= 0 ? (nn_kernel ? 2 : 0) : (ns >= 400000 ? 2 : 0); }
     double cell_target = 2.0;       // target points per grid cell (GSR_ICP_CELL_TARGET).  Measured at 5M x 5M: 0.5 makes a
                                     // converged iteration 1.7x faster but a cold start (offsets ~ max_corr) 1.6x slower: keep 2
     DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
