@@ -16,8 +16,14 @@ Modes (one process per GPU, launched by torch.distributed.run for N > 1):
             (broadcast), then ICP with the source split over ALL ranks and one RCCL all-reduce of the 32-double
             accumulator per iteration (strong scaling: the work is fixed).
   c5        BASELINE configs[4]: ONE large source cloud (--splats, 40 M on 8 GPUs) against a target of --target-splats
-            (5 M): work-sharded HEM levels (all-reduce of the per-child sums + one all-gather of the merged components per
-            level), ICP source split over all ranks (strong scaling).
+            (5 M): SPATIALLY PARTITIONED HEM levels -- every rank draws and keeps only its own block of the cloud
+            (synth.make_block_cloud_torch), halo rows + integer partial sums per level through the library's communicator,
+            the levels stay distributed --, ICP on every rank's piece with one all-reduce of 32 float64 per iteration.
+
+With --gpus N > 1 in the default (replica) mode the line also carries a "strong" object: after the replica timing every rank
+starts a CHILD process (same RANK / WORLD_SIZE, its own rendezvous port) that runs --mode c5 with 5 M x N splats (and --mode c4
+when N = 2), under a host-side deadline; a hang, a crash or an RCCL error there ends up as {"error": ...} inside "strong" and can
+never lose the replica line.  (A child process, not an exec: this process has initialised the GPU.)
 
 Prints ONE JSON line on rank 0.  `value` = level-input Gaussians per second through the HEM levels (whole job);
 `icp_iters_per_sec` rides along; `roofline` is for the dominant kernel of the step (algorithmic bytes of SURVEY.md 8(d));
@@ -206,29 +212,28 @@ def step_c4(ctxs, lru, src, tgt, device, sync, rank, world, comm=None):
     return out
 
 
-def step_c5(lru, ctxs, big, tgt, device, sync, rank, world, comm=None, owned=None):
+def step_c5(lru, ctxs, blk, tgt, device, sync, rank, world, comm=None, owned=None, n_global=None):
     """configs[4]: one large source cloud against a smaller target.  The source's HEM levels are SPATIALLY PARTITIONED over the
-    ranks (every rank owns one slab, halo rows and integer partial sums through the library's communicator; the levels stay
-    distributed); the target's levels are computed by every rank (it is the replicated side of the ICP); the ICP takes every
-    rank's piece of a source level as its shard -- one all-reduce of 32 float64 per iteration."""
+    ranks (`blk` is this rank's block, `owned` its global indices; halo rows and integer partial sums through the library's
+    communicator; the levels stay distributed); the target's levels are computed by every rank (it is the replicated side of the
+    ICP); the ICP takes every rank's piece of a source level as its shard -- one all-reduce of 32 float64 per iteration."""
     from gaussiansplattingregistration_amd import hem, parallel
     from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
     out = {"hem_gaussians": 0, "kern": []}
     t0 = time.perf_counter()
     if world > 1:
-        pieces, st = parallel.hem_partitioned(big, LEVELS, comm, device=device, as_torch=True, owned=owned, mixture=ctxs["hem"], rng_mode="glibc")
-        idx = owned if owned is not None else parallel.block_of(big["xyz"], rank, world)
-        src_list = [PointCloud(xyz32=big["xyz"][idx].contiguous(), cov6=big["cov6"][idx].contiguous())] + [PointCloud(xyz32=p["xyz"], cov6=p["cov6"]) for p in pieces]
-        sizes = [int(big["xyz"].shape[0])] + [int(s["n_global"]) for s in st]
-        for s_ in st:
-            s_["n_in"] = s_["n_in"]                # (rank-local level input; the global sizes ride in n_global)
-        out["part"] = [{k: s_[k] for k in ("ghosts", "rows_sent", "halo_bytes_received", "sum_exchange_bytes_received", "n_global")} for s_ in st]
+        pieces, st = parallel.hem_partitioned(blk, LEVELS, comm, device=device, as_torch=True, owned=owned, n_global=n_global, mixture=ctxs["hem"],
+                                              rng_mode="glibc")
+        src_list = [PointCloud(xyz32=blk["xyz"], cov6=blk["cov6"])] + [PointCloud(xyz32=p["xyz"], cov6=p["cov6"]) for p in pieces]
+        sizes = [int(n_global)] + [int(s["n_global"]) for s in st]
+        out["part"] = [{k: s_[k] for k in ("ghosts", "rows_sent", "halo_bytes_received", "sum_exchange_bytes_received", "n_global", "ms_halo_rows",
+                                           "ms_halo_sh_overlapped", "ms_level")} for s_ in st]
     else:
-        lv, st = hem.create_mixture(big, LEVELS, device=device, as_torch=True, **HEM_PARAMS)
-        src_list = [PointCloud(xyz32=big["xyz"], cov6=big["cov6"])] + [PointCloud(xyz32=l["xyz"], cov6=l["cov6"]) for l in lv]
+        lv, st = hem.create_mixture(blk, LEVELS, device=device, as_torch=True, **HEM_PARAMS)
+        src_list = [PointCloud(xyz32=blk["xyz"], cov6=blk["cov6"])] + [PointCloud(xyz32=l["xyz"], cov6=l["cov6"]) for l in lv]
         sizes = None
     out["kern"] += st
-    out["hem_gaussians"] += sum(s["n_in"] for s in st)
+    out["hem_gaussians"] += sum(s["n_in"] for s in st)          # (rank-local level inputs; the global sizes ride in n_global)
     ctxs["hem2"].set_rng("glibc", 1, 0)
     tgt_list, stt = hem_levels(ctxs["hem2"], tgt)
     out["kern"] += stt
@@ -244,6 +249,62 @@ def step_c5(lru, ctxs, big, tgt, device, sync, rank, world, comm=None, owned=Non
     sync()
     out["icp_s"] = time.perf_counter() - t1
     return out
+
+
+def run_strong_children(a, rank, world, barrier):
+    """The strong-scaling block of a multi-GPU replica run: BASELINE configs[3] (--mode c4, N = 2 only) and
+    configs[4] (--mode c5 with --strong-splats x N splats) as CHILD processes of every rank, each with a host-side deadline.
+    Returns (on rank 0) {"c5": {...}, "c4": {...}} -- the child's line condensed, or {"error": ...}.  Never raises."""
+    base_port = int(os.environ.get("MASTER_PORT", "29500"))
+    jobs = [("c5", ["--mode", "c5", "--splats", str(a.strong_splats * world), "--target-splats", str(a.strong_splats)])]
+    if world == 2:
+        jobs.append(("c4", ["--mode", "c4", "--splats", str(a.strong_splats)]))
+    res = {}
+    for k, (name, extra) in enumerate(jobs):
+        port = base_port + 211 + 17 * k
+        if port > 65000:
+            port = base_port - 211 - 17 * k
+        # the child's own rendezvous: RANK / WORLD_SIZE / LOCAL_RANK as here, a port of its own, and NOT the launcher's agent store
+        env = {kk: v for kk, v in os.environ.items() if not kk.startswith("TORCHELASTIC_")}
+        env.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", str(a.strong_steps), "--warmup", "1", "--no-cpu-baseline",
+               "--no-strong"] + extra
+        t0 = time.perf_counter()
+        r = {}
+        try:
+            with tempfile.TemporaryFile("w+") as err:
+                p = subprocess.Popen(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE if rank == 0 else subprocess.DEVNULL, stderr=err, text=True)
+                try:
+                    out, _ = p.communicate(timeout=a.strong_timeout)
+                except subprocess.TimeoutExpired:
+                    p.kill()                                   # exactly the process started above
+                    out, _ = p.communicate()
+                    r["error"] = f"deadline of {a.strong_timeout:.0f} s passed (rank {rank}): the child was killed"
+                if "error" not in r and p.returncode != 0:
+                    err.seek(0)
+                    r["error"] = f"child exited with {p.returncode}: " + err.read()[-400:].replace("\n", " | ")
+            if "error" not in r and rank == 0:
+                rows = [l for l in (out or "").splitlines() if l.startswith("{")]
+                if not rows:
+                    r["error"] = "the child printed no line"
+                else:
+                    d = json.loads(rows[-1])
+                    r = {"workload": d["config"]["workload"], "parallelism": d["config"]["parallelism"], "level_sizes": d["config"]["level_sizes"],
+                         "ms_per_step": d["ms_per_step"], "gaussians_per_s": d["value"], "hem_s_per_step": d["hem_s_per_step"],
+                         "icp_s_per_step": d["icp_s_per_step"], "icp_iters_per_sec": d["icp_iters_per_sec"], "icp_iterations_per_step": d["icp_iterations_per_step"],
+                         "T_err_vs_ground_truth_F": d["icp_result"]["T_err_vs_ground_truth_F"], "steps": d["steps"], "scaling": d["scaling"]}
+                    for opt in ("partition_rank0", "exchange_s_per_step", "transport"):
+                        if opt in d:
+                            r[opt] = d[opt]
+        except Exception as e:  # pragma: no cover
+            r = {"error": f"{type(e).__name__}: {str(e)[:300]}"}
+        r["wall_s"] = time.perf_counter() - t0
+        res[name] = r
+        try:
+            barrier()                                          # the parents meet again before the next job
+        except Exception:  # pragma: no cover
+            pass
+    return res
 
 
 def cpu_baseline(gpu_level1_rate, gpu_icp_coarse):
@@ -335,6 +396,10 @@ def main():
                     help="splat shapes of the pair: SURVEY 8(d)'s isotropic recipe, or the surfel recipe (synth.make_cloud(shape='aniso'): 60 %% discs, "
                          "15 %% needles, covariance condition numbers 1e2 .. 1e5 on a smooth orientation field)")
     ap.add_argument("--no-aniso", action="store_true", help="skip the anisotropic side measurement of the default run")
+    ap.add_argument("--no-strong", action="store_true", help="--gpus N > 1, replica mode: skip the strong-scaling children (c5, and c4 at N = 2)")
+    ap.add_argument("--strong-splats", type=int, default=5_000_000, help="strong block: splats per GPU of the c5 source (x N) and per cloud of c4")
+    ap.add_argument("--strong-steps", type=int, default=2)
+    ap.add_argument("--strong-timeout", type=float, default=300.0, help="host-side deadline of one strong child, seconds")
     a = ap.parse_args()
 
     import torch
@@ -369,15 +434,36 @@ def main():
     # synthetic pair, resident in HBM before the timed region: target = cloud, source = inv(T_gt) * cloud + jitter
     n = a.n if a.n is not None else (40_000_000 if a.mode == "c5" else 5_000_000)
     seed = 100 + (rank if a.mode == "replicas" else 0)     # c4 / c5: every rank holds the same data (replicated inputs)
+    owned = None
     if a.mode == "c5":
-        big = synth.make_cloud_torch(n, seed=seed, device=dev)
-        T_gt = synth.rigid_transform(PAIR_ANGLE_DEG, (1, 1, 1), PAIR_SHIFT_H * big["h"] * np.array([1.0, -1.0, 0.5]))
-        # the target: the first --target-splats of the large cloud, moved (a sub-sample of the same scene)
+        # every rank draws ITS block of the large cloud and nothing else (the cloud is defined block by block: no rank ever holds or
+        # sorts the 40 M splats); the target is a sub-sample of the same scene -- the first rows of every block, gathered ONCE onto
+        # every rank (set-up, outside the timed region) -- moved by T_gt
+        src, owned = synth.make_block_cloud_torch(n, rank, world, seed=seed, device=dev)
+        T_gt = synth.rigid_transform(PAIR_ANGLE_DEG, (1, 1, 1), PAIR_SHIFT_H * src["h"] * np.array([1.0, -1.0, 0.5]))
         nt = min(a.target_splats, n)
-        sub = {k: (v[:nt].contiguous() if isinstance(v, torch.Tensor) else v) for k, v in big.items()}
+        fields = ("xyz", "color", "opacity", "cov6", "sh")
+        parts = {f: [] for f in fields}
+        for r in range(world):
+            lo_r, hi_r = parallel.shard_range(nt, r, world)
+            for f in fields:
+                if r == rank:
+                    t = src[f][:hi_r - lo_r].contiguous()
+                else:
+                    t = torch.empty((hi_r - lo_r,) + tuple(src[f].shape[1:]), dtype=torch.float32, device=dev)
+                if world > 1:
+                    if torch.distributed.get_backend() == "nccl":
+                        torch.distributed.broadcast(t, r)
+                    else:
+                        hbuf = t.cpu()
+                        torch.distributed.broadcast(hbuf, r)
+                        t.copy_(hbuf)
+                parts[f].append(t)
+        sub = {f: torch.cat(parts[f]).contiguous() for f in fields}
+        sub.update(sh_degree=src["sh_degree"], h=src["h"], shape=src["shape"])
+        del parts
         tgt = synth.apply_rigid_torch(sub, T_gt)
         tgt = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in tgt.items()}
-        src = big
     else:
         tgt = synth.make_cloud_torch(n, seed=seed, device=dev, shape=a.workload)
         T_gt = synth.rigid_transform(PAIR_ANGLE_DEG, (1, 1, 1), PAIR_SHIFT_H * tgt["h"] * np.array([1.0, -1.0, 0.5]))
@@ -394,13 +480,12 @@ def main():
     comm = Comm.from_torch_group(device) if (world > 1 and a.mode in ("c4", "c5")) else None
     if a.mode == "c5":
         ctxs["hem2"] = hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS)       # the replicated target's levels
-    owned = parallel.block_of(src["xyz"], rank, world) if (a.mode == "c5" and world > 1) else None
 
     def one_step():
         if a.mode == "c4":
             return step_c4(ctxs, lru, src, tgt, device, sync, rank, world, comm=comm)
         if a.mode == "c5":
-            return step_c5(lru, ctxs, src, tgt, device, sync, rank, world, comm=comm, owned=owned)
+            return step_c5(lru, ctxs, src, tgt, device, sync, rank, world, comm=comm, owned=owned, n_global=n)
         return step_replicas(ctxs, lru, src, tgt, device, sync)
 
     for _ in range(a.warmup):
@@ -440,6 +525,14 @@ def main():
             del src_t, dst_t
         except Exception:
             copy_gbs = None
+
+    strong = None
+    if world > 1 and a.mode == "replicas" and not a.no_strong:
+        # the replica measurement is complete: free its clouds, then the strong-scaling children (guarded: nothing that happens in
+        # them can lose the line below)
+        del src, tgt
+        torch.cuda.empty_cache()
+        strong = run_strong_children(a, rank, world, barrier)
 
     if rank == 0:
         F = 45
@@ -550,6 +643,10 @@ def main():
             "hem_phase_ms_per_step": phases,
             "roofline": roof,
         }
+        if strong is not None:
+            line["strong"] = strong
+        if comm is not None:
+            line["transport"] = comm.transport
         if "exchange_s" in last:
             line["exchange_s_per_step"] = sum(r["exchange_s"] for r in runs) / a.steps
         if "part" in last:

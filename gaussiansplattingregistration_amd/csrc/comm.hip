@@ -39,15 +39,21 @@ struct RcclApi {
     std::string error;
 };
 
-static RcclApi* rccl_api() {
+// why == the reason when NULL is returned (dlopen's own message, or the missing symbol)
+static RcclApi* rccl_api(const char** why = nullptr) {
     static RcclApi api;                               // function-local static: initialised once, thread-safely
     static const bool ok = [] {
-        const char* names[] = {getenv("GSR_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        // an explicit GSR_RCCL_LIB is the ONLY candidate: a wrong path is an error, not a silent switch to another copy
+        const char* env = getenv("GSR_RCCL_LIB");
+        const bool explicit_lib = env && *env;
+        const char* names[] = {env, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             if (!n || !*n) continue;
+            if (explicit_lib && n != env) break;
             api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
             if (api.handle) break;
-            api.error = dlerror() ? dlerror() : "dlopen failed";
+            const char* e = dlerror();                // ONE call: dlerror() clears the message it returns
+            api.error = e ? e : "dlopen failed";
         }
         if (!api.handle) return false;
 #define GSR_SYM(field, name)                                                              \
@@ -59,8 +65,10 @@ static RcclApi* rccl_api() {
 #undef GSR_SYM
         return true;
     }();
+    if (!ok && why) *why = api.error.empty() ? "no candidate library" : api.error.c_str();
     return ok ? &api : nullptr;
 }
+
 
 }  // namespace gsr
 
@@ -94,8 +102,9 @@ extern "C" {
 
 int32_t gsr_comm_get_unique_id(void* id128) {
     if (!id128) return fail(GSR_E_INVALID, "gsr_comm_get_unique_id: NULL argument");
-    RcclApi* api = rccl_api();
-    if (!api) return fail(GSR_E_HIP, "gsr_comm_get_unique_id: RCCL is not available (librccl.so.1 could not be opened)");
+    const char* why = "";
+    RcclApi* api = rccl_api(&why);
+    if (!api) return fail(GSR_E_HIP, "gsr_comm_get_unique_id: RCCL is not available (%s)", why);
     static_assert(sizeof(ncclUniqueId) == GSR_COMM_ID_BYTES, "ncclUniqueId is 128 bytes");
     ncclUniqueId id;
     GSR_NCCL(api, api->GetUniqueId(&id));
@@ -107,8 +116,9 @@ int32_t gsr_comm_create(gsr_comm** out, const void* id128, int32_t rank, int32_t
     if (!out || !id128) return fail(GSR_E_INVALID, "gsr_comm_create: NULL argument");
     *out = nullptr;
     if (world < 1 || rank < 0 || rank >= world) return fail(GSR_E_INVALID, "gsr_comm_create: rank %d of %d", rank, world);
-    RcclApi* api = rccl_api();
-    if (!api) return fail(GSR_E_HIP, "gsr_comm_create: RCCL is not available (librccl.so.1 could not be opened)");
+    const char* why = "";
+    RcclApi* api = rccl_api(&why);
+    if (!api) return fail(GSR_E_HIP, "gsr_comm_create: RCCL is not available (%s)", why);
     GSR_HIP(hipSetDevice(device));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
@@ -192,12 +202,24 @@ int32_t gsr_comm_exchange(gsr_comm* c, const void* dev_send, const int64_t* send
     }
     RcclApi* api = rccl_api();
     GSR_NCCL(api, api->GroupStart());
-    for (int r = 0; r < c->world; ++r) {
+    // the first error is remembered and the group is CLOSED whatever happened: a return between GroupStart and GroupEnd would
+    // leave the communicator with an open group, unusable for every later call
+    ncclResult_t first = ncclSuccess;
+    const char* what = "";
+    for (int r = 0; r < c->world && first == ncclSuccess; ++r) {
         if (r == c->rank) continue;
-        if (send_bytes[r] > 0) GSR_NCCL(api, api->Send((const char*)dev_send + send_off[r], (size_t)send_bytes[r], ncclUint8, r, c->nccl, st));
-        if (recv_bytes[r] > 0) GSR_NCCL(api, api->Recv((char*)dev_recv + recv_off[r], (size_t)recv_bytes[r], ncclUint8, r, c->nccl, st));
+        if (send_bytes[r] > 0) {
+            first = api->Send((const char*)dev_send + send_off[r], (size_t)send_bytes[r], ncclUint8, r, c->nccl, st);
+            if (first != ncclSuccess) { what = "ncclSend"; break; }
+        }
+        if (recv_bytes[r] > 0) {
+            first = api->Recv((char*)dev_recv + recv_off[r], (size_t)recv_bytes[r], ncclUint8, r, c->nccl, st);
+            if (first != ncclSuccess) { what = "ncclRecv"; break; }
+        }
     }
-    GSR_NCCL(api, api->GroupEnd());
+    ncclResult_t end = api->GroupEnd();
+    if (first != ncclSuccess) return fail(GSR_E_HIP, "gsr_comm_exchange: %s failed: %s", what, api->GetErrorString(first));
+    if (end != ncclSuccess) return fail(GSR_E_HIP, "gsr_comm_exchange: ncclGroupEnd failed: %s", api->GetErrorString(end));
     return GSR_OK;
 }
 

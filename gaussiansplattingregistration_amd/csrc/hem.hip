@@ -2148,7 +2148,7 @@ __global__ __launch_bounds__(256) void k_shard_rows(int lo, int cnt, int F, cons
 //             (and one of orphan gids; disjoint bits: an integer sum is an OR) and prefix-count it; the new flags are drawn from
 //             the libc stream at those global ranks.  No floating-point value is ever combined across ranks.
 // ------------------------------------------------------------------------------------------------
-#define PART_ROW_EXTRA 2      // a ghost row: 16 floats of the packed record, F SH floats, gid, index at its owner
+#define PART_ROW_EXTRA 2      // a ghost row: 16 floats of the packed record, gid, index at its owner (72 bytes); its F SH floats travel apart
 
 // Bits of the cells an owned parent can take candidates from -- two masks per rank:
 //   mask_all  the box of its search sphere (the rows of select_scan's pass B): where IRREGULAR components are wanted;
@@ -2216,29 +2216,31 @@ __global__ __launch_bounds__(256) void k_dest_flags(int64_t n_own, const float4*
 // rows to send: for destination q the k-th flagged owned component (pos = exclusive scan of its flags)
 __global__ __launch_bounds__(256) void k_pack_rows(int64_t n_own, int F, const int* __restrict__ dflag, const int* __restrict__ dpos,
                                                    const float4* __restrict__ rec, const float* __restrict__ sh, const unsigned* __restrict__ gid,
-                                                   float* __restrict__ rows, unsigned* __restrict__ sent_idx) {
-    const int RW = 16 + F + PART_ROW_EXTRA;
+                                                   float* __restrict__ rows, float* __restrict__ sh_rows, unsigned* __restrict__ sent_idx) {
+    constexpr int RW = 16 + PART_ROW_EXTRA;
     const int lane = threadIdx.x & 63;
     const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
     for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; i < n_own; i += stride) {      // a wave per component
         if (!dflag[i]) continue;
-        float* row = rows + (int64_t)dpos[i] * RW;
+        const int64_t k = dpos[i];
+        float* row = rows + k * RW;
         const float* r = reinterpret_cast<const float*>(rec + 4 * i);
-        for (int f = lane; f < 16 + F; f += 64) row[f] = f < 16 ? r[f] : sh[i * F + (f - 16)];
-        if (lane == 0) { row[16 + F] = __uint_as_float(gid[i]); row[16 + F + 1] = __uint_as_float((unsigned)i); sent_idx[dpos[i]] = (unsigned)i; }
+        if (lane < 16) row[lane] = r[lane];
+        for (int f = lane; f < F; f += 64) sh_rows[k * F + f] = sh[i * F + f];
+        if (lane == 0) { row[16] = __uint_as_float(gid[i]); row[17] = __uint_as_float((unsigned)i); sent_idx[k] = (unsigned)i; }
     }
 }
-// received rows -> the ghosts' records behind the owned ones, their SH rows, global indices and indices at their owners
-__global__ __launch_bounds__(256) void k_unpack_rows(int64_t n_ghost, int64_t n_own, int F, const float* __restrict__ rows, float4* __restrict__ rec_loc,
-                                                     float* __restrict__ ghost_sh, unsigned* __restrict__ gid_loc, unsigned* __restrict__ ghost_src) {
-    const int RW = 16 + F + PART_ROW_EXTRA;
-    const int lane = threadIdx.x & 63;
-    const int64_t stride = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t k = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6; k < n_ghost; k += stride) {
+// received rows -> the ghosts' records behind the owned ones, their global indices and indices at their owners (their SH rows arrive
+// by a second exchange straight into ghost_sh, in the same order)
+__global__ __launch_bounds__(256) void k_unpack_rows(int64_t n_ghost, int64_t n_own, const float* __restrict__ rows, float4* __restrict__ rec_loc,
+                                                     unsigned* __restrict__ gid_loc, unsigned* __restrict__ ghost_src) {
+    constexpr int RW = 16 + PART_ROW_EXTRA;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n_ghost * 16; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = t >> 4;
+        const int f = (int)(t & 15);
         const float* row = rows + k * RW;
-        float* r = reinterpret_cast<float*>(rec_loc + 4 * (n_own + k));
-        for (int f = lane; f < 16 + F; f += 64) { if (f < 16) r[f] = row[f]; else ghost_sh[k * F + (f - 16)] = row[f]; }
-        if (lane == 0) { gid_loc[n_own + k] = __float_as_uint(row[16 + F]); ghost_src[k] = __float_as_uint(row[16 + F + 1]); }
+        reinterpret_cast<float*>(rec_loc + 4 * (n_own + k))[f] = row[f];
+        if (f == 0) { gid_loc[n_own + k] = __float_as_uint(row[16]); ghost_src[k] = __float_as_uint(row[17]); }
     }
 }
 // cell keys of the local components in the order perm (ascending global index): the stable cell sort then keeps that order inside a cell
@@ -2418,6 +2420,13 @@ __global__ __launch_bounds__(256) void k_part_new_gid(int64_t n_own, int P_loc, 
 __global__ __launch_bounds__(256) void k_gather_bytes(int64_t n, const unsigned* __restrict__ idx, const uint8_t* __restrict__ src, uint8_t* __restrict__ dst) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) dst[i] = src[idx[i]];
 }
+// gsr_hem_set_level0_part trusts nothing about the caller's global indices: every later kernel indexes n_global-sized tables with them
+__global__ __launch_bounds__(256) void k_check_gids(int64_t n, int64_t n_global, const unsigned* __restrict__ gid, unsigned* __restrict__ bad) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned g = gid[i];
+        if ((int64_t)g >= n_global || (i > 0 && gid[i - 1] >= g)) atomicAdd(bad, 1u);
+    }
+}
 // the erased rows' global ranks leave the numbering: new gid -= erased rows below it
 __global__ __launch_bounds__(256) void k_gid_drop(int64_t n, const unsigned* __restrict__ bits, const int* __restrict__ wpre, unsigned* __restrict__ gid) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -2560,6 +2569,10 @@ struct gsr_hem_ctx {
     hipEvent_t ev_pre = nullptr;    // the parents' output ranks (flags in input order + their scan), computed beside the grid phase
     hipStream_t aux2 = nullptr;     // third stream: the SH rows are gathered into cell order (an HBM stream only the M-step needs)
     hipEvent_t ev_sh_fork = nullptr, ev_sh_join = nullptr;      // beside the selection (VALU / latency bound)
+    hipEvent_t ev_halo = nullptr;   // partitioned level: the ghosts' SH rows have arrived (their exchange runs on aux2 beside the grid phase and the selection)
+    hipEvent_t evp[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of the two halo exchanges (records on the main stream, SH rows on aux2)
+    float part_ms[4] = {0, 0, 0, 0};                            // their durations (gsr_hem_get_part_ms)
+    DevBuf sh_send;
     int sh_grid = 0;                // GSR_HEM_SH_GRID: workgroups of a forked k_gather_sh (0 = as many as in line)
     int sh_overlap = 0;             // GSR_HEM_SH_OVERLAP: where k_gather_sh runs (0 in line, 1 forked in the grid phase, 2 forked beside k_select)
     float rho = 3.0f, delta = 3.0f, kappa = 2.5f, tau = 1.0f;
@@ -2827,6 +2840,8 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->aux2, hipStreamNonBlocking);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sh_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sh_join, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming);
+        for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->evp[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "second stream: %s", hipGetErrorString(e)); }
     }
     {
@@ -2866,7 +2881,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     for (DevBuf& b : c->spare) b.release();
     c->cur.release(); c->nxt.release(); c->tmp.release();
     DevBuf* part_bufs[] = {&c->gid, &c->gid_next, &c->rec_loc, &c->gid_loc, &c->ghost_sh, &c->ghost_src, &c->perm, &c->pown, &c->ppos_own, &c->inv, &c->gmax, &c->gacc,
-                           &c->cmask, &c->dflag, &c->dpos, &c->sent_idx, &c->rows_send, &c->rows_recv, &c->xsend, &c->xrecv, &c->gbits, &c->wcnt, &c->wpre,
+                           &c->cmask, &c->dflag, &c->dpos, &c->sent_idx, &c->rows_send, &c->rows_recv, &c->sh_send, &c->xsend, &c->xrecv, &c->gbits, &c->wcnt, &c->wpre,
                            &c->grank, &c->allflags, &c->pcounts, &c->pmatrix};
     for (DevBuf* b : part_bufs) b->release();
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->geo, &c->shs,
@@ -2885,6 +2900,8 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     if (c->ev_join) (void)hipEventDestroy(c->ev_join);
     if (c->ev_sh_fork) (void)hipEventDestroy(c->ev_sh_fork);
     if (c->ev_sh_join) (void)hipEventDestroy(c->ev_sh_join);
+    if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+    for (int i = 0; i < 4; ++i) if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->aux2) (void)hipStreamDestroy(c->aux2);
     delete c;
@@ -2983,6 +3000,19 @@ int32_t gsr_hem_set_level0_part(gsr_hem_ctx* c, const float* xyz, const float* c
     hipStream_t st = c->stream;
     GSR_TRY(c->gid.reserve((size_t)n_own * 4));
     GSR_HIP(hipMemcpyAsync(c->gid.p, gid, (size_t)n_own * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
+    {   // strictly ascending and < n_global, checked on the device BEFORE anything is indexed with them
+        GSR_TRY(c->scratch.reserve(64));
+        GSR_HIP(hipMemsetAsync(c->scratch.p, 0, 4, st));
+        hipLaunchKernelGGL(k_check_gids, dim3(stride_grid(n_own)), dim3(256), 0, st, n_own, n_global, c->gid.as<unsigned>(), c->scratch.as<unsigned>());
+        unsigned bad = 0;
+        GSR_HIP(hipMemcpyAsync(&bad, c->scratch.p, 4, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        if (bad) {
+            c->have_level = false;
+            return fail(GSR_E_INVALID, "gsr_hem_set_level0_part: %u of %lld global indices are not strictly ascending or not below n_global=%lld", bad,
+                        (long long)n_own, (long long)n_global);
+        }
+    }
     GSR_TRY(c->allflags.reserve((size_t)n_global));
     GSR_TRY(draw_flags_raw(c, n_global, c->allflags.as<uint8_t>()));          // Mixture::initMixture draws one flag per component of the WHOLE cloud
     hipLaunchKernelGGL(k_gather_bytes, dim3(stride_grid(n_own)), dim3(256), 0, st, n_own, c->gid.as<unsigned>(), c->allflags.as<uint8_t>(), c->cur.is_parent.as<uint8_t>());
@@ -3047,6 +3077,12 @@ int32_t gsr_hem_get_level(gsr_hem_ctx* c, float* xyz, float* color, float* cov6,
     return GSR_OK;
 }
 
+int32_t gsr_hem_get_part_ms(gsr_hem_ctx* c, float* out4) {
+    if (!c || !out4) return fail(GSR_E_INVALID, "gsr_hem_get_part_ms: NULL argument");
+    memcpy(out4, c->part_ms, sizeof(c->part_ms));
+    return GSR_OK;
+}
+
 int32_t gsr_hem_get_stats(gsr_hem_ctx* c, int64_t* out8) {
     if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_stats: NULL argument");
     memcpy(out8, c->stats, sizeof(c->stats));
@@ -3101,8 +3137,21 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     memset(c->part_stats, 0, sizeof(c->part_stats));
     c->stats[6] = n;
     if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld components (the candidate records carry the sorted position in 30 bits)", (long long)n);
-    if (part && n == 0) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank of a partitioned level owns no component (use fewer ranks)");
     if (part && c->shard_world > 1) return fail(GSR_E_INVALID, "gsr_hem_run_level: spatial partition and work sharding are exclusive");
+    if (part) {
+        // Ownership follows the parents, so a rank CAN run out of components on a later level: that is data, not a local error.  The
+        // ranks agree on the level's preconditions before its first data collective (one all-reduce of a status word), so that
+        // every rank returns the error instead of one returning and its peers waiting in the next collective for ever.
+        GSR_TRY(c->pcounts.reserve(64));
+        const unsigned status = n == 0 ? 1u : 0u;
+        GSR_HIP(hipMemcpyAsync(c->pcounts.p, &status, 4, hipMemcpyHostToDevice, c->stream));
+        GSR_HIP(hipStreamSynchronize(c->stream));               // (status lives on this stack frame)
+        GSR_TRY(gsr_comm_allreduce(c->comm, c->pcounts.p, 1, GSR_DT_U32, GSR_OP_MAX, (void*)c->stream));
+        unsigned agreed = 0;
+        GSR_HIP(hipMemcpyAsync(&agreed, c->pcounts.p, 4, hipMemcpyDeviceToHost, c->stream));
+        GSR_HIP(hipStreamSynchronize(c->stream));
+        if (agreed) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank of the partitioned level owns no component (reported on every rank; use fewer ranks)");
+    }
     if (n == 0) {
         if (n_out) *n_out = 0;
         if (n_dropped) *n_dropped = 0;
@@ -3115,15 +3164,16 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // halo bookkeeping (host): rows sent to / received from every rank, and their offsets in the concatenated buffers
     int64_t send_cnt[8] = {0}, recv_cnt[8] = {0}, soff[8] = {0}, roff[8] = {0}, n_sent = 0, n_ghost = 0;
     // one typed exchange along the halo's lists: to_owner = the ghosts' values go to their owners (roles of the lists reversed)
-    auto halo_exchange = [&](const void* sendbuf, void* recvbuf, size_t elem, bool to_owner) -> int32_t {
+    auto halo_exchange = [&](const void* sendbuf, void* recvbuf, size_t elem, bool to_owner, hipStream_t xs = nullptr) -> int32_t {
         int64_t so[8], sb[8], ro[8], rb[8];
         for (int q = 0; q < W; ++q) {
             so[q] = (to_owner ? roff[q] : soff[q]) * (int64_t)elem; sb[q] = (to_owner ? recv_cnt[q] : send_cnt[q]) * (int64_t)elem;
             ro[q] = (to_owner ? soff[q] : roff[q]) * (int64_t)elem; rb[q] = (to_owner ? send_cnt[q] : recv_cnt[q]) * (int64_t)elem;
             if (q != me) c->part_stats[3] += rb[q];
         }
-        return gsr_comm_exchange(c->comm, sendbuf, so, sb, recvbuf, ro, rb, (void*)st);
+        return gsr_comm_exchange(c->comm, sendbuf, so, sb, recvbuf, ro, rb, (void*)(xs ? xs : st));
     };
+    bool halo_sh_pending = false;
     GSR_HIP(hipEventRecord(c->ev[0], st));
 
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
@@ -3197,26 +3247,41 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipStreamSynchronize(st));
         for (int q = 0; q < W; ++q) { send_cnt[q] = q == me ? 0 : mat[me * 8 + q]; recv_cnt[q] = q == me ? 0 : mat[q * 8 + me]; }
         for (int q = 0; q < W; ++q) { soff[q] = n_sent; n_sent += send_cnt[q]; roff[q] = n_ghost; n_ghost += recv_cnt[q]; }
-        const int RW = 16 + F + PART_ROW_EXTRA;
+        // TWO exchanges along the same lists: the 72-byte rows {record, global index, index at the owner} -- what the grid, the sort
+        // and the selection need -- on the level's stream, and the SH rows (4 F bytes: 71 % of a ghost at SH degree 3), which only the
+        // M-step reads, on the third stream beside the rest of the grid phase and the selection, received straight into ghost_sh
+        constexpr int RW = 16 + PART_ROW_EXTRA;
+        const size_t Fm = (size_t)(F > 0 ? F : 1);
         GSR_TRY(c->rows_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * RW * 4)); GSR_TRY(c->rows_recv.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * RW * 4));
+        GSR_TRY(c->sh_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * Fm * 4));
         GSR_TRY(c->sent_idx.reserve((size_t)(n_sent > 0 ? n_sent : 1) * 4));
+        GSR_TRY(c->ghost_sh.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * Fm * 4)); GSR_TRY(c->ghost_src.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * 4));
         for (int q = 0; q < W; ++q)
             if (send_cnt[q] > 0)
                 hipLaunchKernelGGL(k_pack_rows, dim3(stride_grid(n_own * 64)), blk, 0, st, n_own, F, c->dflag.as<int>() + (int64_t)q * n_own,
                                    c->dpos.as<int>() + (int64_t)q * n_own, c->rec.as<float4>(), L.sh.as<float>(), c->gid.as<unsigned>(),
-                                   c->rows_send.as<float>() + soff[q] * RW, c->sent_idx.as<unsigned>() + soff[q]);
+                                   c->rows_send.as<float>() + soff[q] * RW, c->sh_send.as<float>() + soff[q] * F, c->sent_idx.as<unsigned>() + soff[q]);
+        GSR_HIP(hipEventRecord(c->evp[0], st));
         GSR_TRY(halo_exchange(c->rows_send.p, c->rows_recv.p, (size_t)RW * 4, false));
+        GSR_HIP(hipEventRecord(c->evp[1], st));
+        if (F > 0) {        // every rank issues it (the same order of communicator calls everywhere), whatever its own counts
+            GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
+            GSR_HIP(hipEventRecord(c->evp[2], c->aux2));
+            GSR_TRY(halo_exchange(c->sh_send.p, c->ghost_sh.p, (size_t)F * 4, false, c->aux2));
+            GSR_HIP(hipEventRecord(c->evp[3], c->aux2));
+            GSR_HIP(hipEventRecord(c->ev_halo, c->aux2));
+            halo_sh_pending = true;
+        }
         c->part_stats[0] = n_ghost; c->part_stats[1] = n_sent; c->part_stats[2] = c->part_stats[3]; c->part_stats[3] = 0;
         n = n_own + n_ghost;
         if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld local components", (long long)n);
         grd = dim3(stride_grid(n));
         GSR_TRY(c->rec_loc.reserve((size_t)n * 64)); GSR_TRY(c->gid_loc.reserve((size_t)n * 4));
-        GSR_TRY(c->ghost_sh.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * (F > 0 ? F : 1) * 4)); GSR_TRY(c->ghost_src.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * 4));
         GSR_HIP(hipMemcpyAsync(c->rec_loc.p, c->rec.p, (size_t)n_own * 64, hipMemcpyDeviceToDevice, st));
         GSR_HIP(hipMemcpyAsync(c->gid_loc.p, c->gid.p, (size_t)n_own * 4, hipMemcpyDeviceToDevice, st));
         if (n_ghost > 0)
-            hipLaunchKernelGGL(k_unpack_rows, dim3(stride_grid(n_ghost * 64)), blk, 0, st, n_ghost, n_own, F, c->rows_recv.as<float>(), c->rec_loc.as<float4>(),
-                               c->ghost_sh.as<float>(), c->gid_loc.as<unsigned>(), c->ghost_src.as<unsigned>());
+            hipLaunchKernelGGL(k_unpack_rows, dim3(stride_grid(n_ghost * 16)), blk, 0, st, n_ghost, n_own, c->rows_recv.as<float>(), c->rec_loc.as<float4>(),
+                               c->gid_loc.as<unsigned>(), c->ghost_src.as<unsigned>());
         rec_src = c->rec_loc.as<float4>();
         c->stats[6] = n_own;
     }
@@ -3262,7 +3327,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         return GSR_OK;
     };
     bool sh_launched = false;
-    if (c->sh_overlap != 2) { GSR_TRY(launch_gather_sh(c->sh_overlap == 1)); sh_launched = true; }
+    // (a partitioned level: always forked -- the third stream carries the ghosts' SH rows, the gather queues up behind them)
+    if (part && F > 0) { GSR_TRY(launch_gather_sh(true)); sh_launched = true; }
+    else if (c->sh_overlap != 2) { GSR_TRY(launch_gather_sh(c->sh_overlap == 1)); sh_launched = true; }
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
     if (part) {     // the parents this rank works on are the ones it owns; the ghosts' parent flags still keep them out of the children's stream
         GSR_TRY(c->pown.reserve(n * 4)); GSR_TRY(c->ppos_own.reserve(n * 4)); GSR_TRY(c->inv.reserve(n * 4));
@@ -3546,6 +3613,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     // spatially partitioned level: k_bucket_sum's three steps with the ghosts' partial results sent to their owners in between --
     // integers only (maximum, 64-bit fixed-point sums), then the owners' finished float32 sums back to the ghosts
     auto sums_part = [&]() -> int32_t {
+        // the communicator's calls in ONE order on the device too: the exchanges below (this stream) behind the SH rows' (third stream)
+        if (halo_sh_pending) { GSR_HIP(hipStreamWaitEvent(st, c->ev_halo, 0)); halo_sh_pending = false; }
         if (nbuckets > SUM_MAX_BUCKETS) return fail(GSR_E_INVALID, "gsr_hem_run_level: level too large for the partitioned sums");
         GSR_TRY(c->gmax.reserve((size_t)n * 4)); GSR_TRY(c->gacc.reserve((size_t)n * 8)); GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
         unsigned cap = 0;
@@ -3874,6 +3943,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     c->phase_ms[6] = c->phase_ms[7] = 0.0f;
     if (P > 0 && !c->sparse_path) (void)hipEventElapsedTime(&c->phase_ms[6], c->evk[0], c->evk[1]);
     if (P > 0 && (M > 0 || c->sparse_path)) (void)hipEventElapsedTime(&c->phase_ms[7], c->evk[2], c->evk[3]);
+    memset(c->part_ms, 0, sizeof(c->part_ms));
+    if (part) {
+        (void)hipEventElapsedTime(&c->part_ms[0], c->evp[0], c->evp[1]);
+        if (F > 0) { GSR_HIP(hipStreamSynchronize(c->aux2)); (void)hipEventElapsedTime(&c->part_ms[1], c->evp[2], c->evp[3]); }
+    }
     memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
     c->kernel_ms[0] = c->phase_ms[7];
     if (P > 0) (void)hipEventElapsedTime(&c->kernel_ms[1], c->evm[0], c->evm[1]);

@@ -174,8 +174,10 @@ class HemMixture:
         ps, ks, ds = _prep(features, (n, F), self.device) if F > 0 else (0, None, dx)
         if len({dx, dc, dv, do, ds}) != 1:
             raise RuntimeError("all level-0 arrays must live in the same place (all host or all device)")
+        if int(np.prod(gid.shape)) != n:
+            raise RuntimeError(f"gid has {int(np.prod(gid.shape))} entries for {n} components")
         if dx:
-            g = gid.detach().to(torch.int32).contiguous() if _is_tensor(gid) else torch.as_tensor(np.asarray(gid, np.int64).astype(np.int32)).to(xyz.device)
+            g = (gid.detach() if _is_tensor(gid) else torch.as_tensor(np.asarray(gid, np.int64))).to(xyz.device, torch.int32).contiguous()
             pg, kg = g.data_ptr(), g
             torch.cuda.current_stream(self.device).synchronize()
         else:
@@ -192,8 +194,10 @@ class HemMixture:
     def part_stats(self):
         s = (C.c_int64 * 8)()
         _lib.check(self._L.gsr_hem_get_part_stats(self._h, s), "gsr_hem_get_part_stats")
+        ms = (C.c_float * 4)()
+        _lib.check(self._L.gsr_hem_get_part_ms(self._h, ms), "gsr_hem_get_part_ms")
         return {"ghosts": s[0], "rows_sent": s[1], "halo_bytes_received": s[2], "sum_exchange_bytes_received": s[3], "parents_global": s[4],
-                "orphans_global": s[5], "dropped_global": s[6], "n_global": s[7]}
+                "orphans_global": s[5], "dropped_global": s[6], "n_global": s[7], "ms_halo_rows": float(ms[0]), "ms_halo_sh_overlapped": float(ms[1])}
 
     def set_state(self, parent_mask=None, weight=None):
         pm = None if parent_mask is None else np.ascontiguousarray(parent_mask, dtype=np.uint8)

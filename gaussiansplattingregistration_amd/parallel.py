@@ -10,11 +10,12 @@ ROCm, ``gloo`` on CPU test boxes).  The reference has no distributed code at all
   (``make_allreduce_device``: RCCL on the tensor where it lies, stream ordered, no host bounce).  It is latency-bound
   (256 bytes), so xGMI link bandwidth is irrelevant; every rank then solves the same 3x3 SVD / 6x6 system ON THE DEVICE
   and stops on the same reduced fitness/RMSE -- the iteration loop stays device resident.
-* **One large cloud, HEM** -- work-sharded levels (``hem_sharded``): the level data is replicated, the
-  cell-sorted parents are split into ``world`` contiguous runs (spatial slabs), and a level makes two
-  exchanges: an all-reduce of the per-child sums of wL (float32[n]) and ONE all-gather of the merged components
-  (packed rows of 14 + F floats, scattered into the owners' slots on arrival: no arithmetic in the exchange).  Flags,
-  orphans and the validity erase are computed identically on every rank.
+* **One large cloud, HEM** -- spatially partitioned levels (``hem_partitioned``): every rank OWNS one block
+  of the cloud (``block_of`` cuts a full cloud; ``synth.make_block_cloud_torch`` draws a rank's block without the rest) and keeps
+  only that; per level the library exchanges halo rows with its neighbours (72-byte records on the level's stream, the SH rows on
+  a second stream beside the grid phase and the selection) and integer partial sums of the per-child weights -- no float is
+  combined across ranks, the levels are bit for bit the one-GPU levels and stay distributed.  (``hem_sharded``, round 2's
+  replicated-data work sharding, is kept for comparison only.)
 """
 from __future__ import annotations
 
@@ -214,18 +215,32 @@ def block_of(xyz, rank: int, world: int):
     return torch.sort(idx).values if tt else np.sort(idx)
 
 
-def hem_partitioned(cloud: dict, cluster_level: int, comm, device=None, as_torch=False, owned=None, mixture=None, **hem_params):
+def hem_partitioned(cloud: dict, cluster_level: int, comm, device=None, as_torch=False, owned=None, mixture=None, n_global=None,
+                    **hem_params):
     """``MixtureCreator.CreateMixture`` of ONE large cloud SPATIALLY partitioned over the ranks of ``comm`` (BASELINE config 5):
     this rank keeps the components of its block (``owned`` = their global indices; default ``block_of``) -- here cut out of the full
     ``cloud`` every rank passes; a caller that holds only its slab passes that and ``owned`` -- and every level runs on owned +
     halo components, bit for bit the single-GPU level (include/gsr_hip.h, gsr_hem_set_level0_part).  Returns (pieces, stats): per
     level a dict of this rank's rows and ``gid``, their positions in the level's global order; ``assemble_partitioned_level``
-    puts the pieces of all ranks together."""
+    puts the pieces of all ranks together.
+
+    ``n_global`` given: ``cloud`` IS this rank's block already (``owned`` = its ascending global indices, required) and nothing is
+    cut out -- the caller never held the whole cloud (``synth.make_block_cloud_torch``, bench.py --mode c5).
+
+    A rank whose call raises leaves its peers inside the next collective (include/gsr_hip.h, "errors are local"): the caller must
+    tear the process group down -- under ``torch.distributed.run`` the uncaught exception does."""
     from . import hem as _hem
     dev = device if device is not None else (torch.cuda.current_device() if torch.cuda.is_available() else 0)
-    n_global = int(cloud["xyz"].shape[0])
-    idx = owned if owned is not None else block_of(cloud["xyz"], comm.rank, comm.world)
-    take = lambda a: a[idx]
+    if n_global is not None:
+        if owned is None:
+            raise RuntimeError("hem_partitioned: a local block (n_global given) needs its global indices in `owned`")
+        idx = owned
+        take = lambda a: a
+    else:
+        n_global = int(cloud["xyz"].shape[0])
+        idx = owned if owned is not None else block_of(cloud["xyz"], comm.rank, comm.world)
+        take = lambda a: a[idx]
+    n_global = int(n_global)
     import contextlib
     # a caller-provided mixture context keeps its workspaces from call to call (no allocation in steady state)
     with (contextlib.nullcontext(mixture) if mixture is not None else _hem.HemMixture(device=dev, **hem_params)) as m:

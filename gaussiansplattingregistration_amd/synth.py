@@ -221,6 +221,39 @@ def make_cloud_torch(n: int, seed: int = 0, device="cuda:0", sh_degree: int = 3,
     return {"xyz": xyz, "color": col, "opacity": op, "cov6": cov6, "sh": sh, "sh_degree": sh_degree, "h": float(h), "shape": shape}
 
 
+def block_box(rank: int, world: int, h: float):
+    """(lo, hi) corners of block ``rank`` of ``world``: the cube [-h, h]^3 cut into ``parallel.block_dims(world)`` equal boxes
+    (px along x, py along y, pz along z; rank = (ix * py + iy) * pz + iz, the numbering of ``parallel.block_of``)."""
+    from .parallel import block_dims
+    px, py, pz = block_dims(world)
+    ix, iy, iz = rank // (py * pz), (rank // pz) % py, rank % pz
+    lo = np.array([-h + 2 * h * ix / px, -h + 2 * h * iy / py, -h + 2 * h * iz / pz])
+    hi = np.array([-h + 2 * h * (ix + 1) / px, -h + 2 * h * (iy + 1) / py, -h + 2 * h * (iz + 1) / pz])
+    return lo, hi
+
+
+def make_block_cloud_torch(n_global: int, rank: int, world: int, seed: int = 0, device="cuda:0", sh_degree: int = 3, shape: str = "iso"):
+    """ONE rank's block of a cloud of ``n_global`` splats that is never materialised as a whole (BASELINE config 5 at 40 M: every
+    rank used to draw and argsort the full cloud before cutting its block out).  The cloud is DEFINED block by block: block r holds
+    the global indices ``parallel.shard_range(n_global, r, world)`` (ascending, contiguous), drawn with ``make_cloud_torch``'s recipe
+    from the seed ``seed * 1000003 + r`` uniformly inside ``block_box(r, world, half_extent(n_global))`` -- the same density and the
+    same equal-count, equal-volume cut as ``parallel.block_of`` gives on a uniform cloud.  Returns (cloud dict, gid int32 tensor)."""
+    import torch
+    from .parallel import shard_range
+    h = half_extent(n_global)
+    lo_i, hi_i = shard_range(n_global, rank, world)
+    c = make_cloud_torch(hi_i - lo_i, seed=seed * 1000003 + rank, device=device, sh_degree=sh_degree, h=1.0, shape="iso")
+    lo, hi = block_box(rank, world, h)
+    ctr = torch.as_tensor((lo + hi) * 0.5, dtype=torch.float32, device=c["xyz"].device)
+    half = torch.as_tensor((hi - lo) * 0.5, dtype=torch.float32, device=c["xyz"].device)
+    c["xyz"] = (c["xyz"] * half + ctr).contiguous()
+    if shape != "iso":
+        raise ValueError("make_block_cloud_torch draws the isotropic recipe only")
+    c["h"] = float(h)
+    gid = torch.arange(lo_i, hi_i, dtype=torch.int32, device=c["xyz"].device)
+    return c, gid
+
+
 def apply_rigid_torch(cloud: dict, T):
     """Rigid motion of a device cloud (float64 maths, float32 storage)."""
     import torch

@@ -145,6 +145,9 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
             else:
                 nrm = pc.normals if pc.has_normals() else _icp.normals_knn(pc.xyz32, knn=20, device=getattr(pc, "device_index", 0))
                 gicp_cov[tag] = _icp.cov_from_normals(nrm, 1e-3, device=getattr(pc, "device_index", 0))
+    if (comm is not None or allreduce_device is not None or allreduce is not None) and n_source_global is None:
+        # fitness = correspondences / ALL source points: a shard cannot know the other shards' sizes
+        raise RuntimeError("registration_icp: a sharded call (comm / allreduce) needs n_source_global, the source size over all ranks")
     dev = device if device is not None else getattr(target, "device_index", 0)
     loss = estimation_method.loss or RobustLoss(_icp.LOSS_L2)
     own = ctx is None            # a caller-provided context keeps its workspace across calls (no allocation in steady state)

@@ -150,8 +150,9 @@ int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_all
  *   - integer all-reduces of the bounding box (24 bytes), the axis histograms (12 KB) and two bit maps over the level's global
  *     indices (n_global / 4 bytes): every rank derives the same grid and the same global output ranks;
  *   - one all-gather of two bit masks over the grid's cells (which cells can my parents take regular / irregular candidates from:
- *     the box of the pre-reject ellipsoid / of the search sphere) and ONE personalised exchange of halo rows (64 + 4F + 8 bytes
- *     per component that another rank's parents may reach);
+ *     the box of the pre-reject ellipsoid / of the search sphere) and the personalised exchange of the halo, in two messages per
+ *     neighbour along the same lists: 72-byte rows {packed record, global index, index at the owner} on the context's stream, and
+ *     the 4F-byte SH rows -- which only the M-step reads -- on a second stream, overlapped with the grid phase and the selection;
  *   - five small exchanges along the same halo lists for the per-child sums: maxima (u32), the owners' maxima back, 64-bit
  *     fixed-point partial sums, the owners' float32 sums back -- no floating-point value is ever combined across ranks.
  * The new level stays distributed (gsr_hem_get_level returns the owned rows, gsr_hem_get_gids their global indices; ownership
@@ -168,6 +169,9 @@ int32_t gsr_hem_get_gids(gsr_hem_ctx* ctx, uint32_t* gid, int32_t on_device);
  * [3] bytes received in the five sum exchanges  [4] parents of the level over all ranks  [5] orphans over all ranks
  * [6] components erased over all ranks  [7] components of the CURRENT level over all ranks */
 int32_t gsr_hem_get_part_stats(gsr_hem_ctx* ctx, int64_t* out8);
+/* durations (ms, device events) of the most recent partitioned level's halo exchanges: [0] the 72-byte rows (on the critical path)
+ * [1] the SH rows (second stream, overlapped)  [2], [3] reserved */
+int32_t gsr_hem_get_part_ms(gsr_hem_ctx* ctx, float* out4);
 
 /* One clustering level on the current level (Mixture::createClusterLevel, mixture.cpp:66-285).
  * n_out = components of the new level (after the validity erase); n_dropped = components erased by

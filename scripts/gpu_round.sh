@@ -26,6 +26,9 @@ rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_A
 PA="python3 $ABS/scripts/prof_hem.py 5000000 1 2 aniso"
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $ABS/$OUT/pmc_aniso_fetch -- $PA > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $ABS/$OUT/pmc_aniso_write -- $PA > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCP_TCC_READ_REQ_sum --output-format csv -d $ABS/$OUT/pmc_aniso_l2 -- $PA > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_LDS --output-format csv -d $ABS/$OUT/pmc_aniso_sq -- $PA > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES SQ_INSTS_VMEM_WR --output-format csv -d $ABS/$OUT/pmc_aniso_sq2 -- $PA > /dev/null 2>&1
 # ICP: the coarse-to-fine schedule of the bench on the levels of a 5 M pair (scripts/prof_icp.py), counters in separate passes
 PI="python3 $ABS/scripts/prof_icp.py 5000000 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $ABS/$OUT/icp_stats -- $PI > $ABS/$OUT/prof_icp.log 2>&1

@@ -78,17 +78,29 @@ for k, v in pmc.items():
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1, sort_keys=True)
 
 
-def pmc_set(dirs, prefix, command, fetch_dir):
-    """Per-kernel per-launch counter averages of one group of --pmc passes (the same layout as <dst>_pmc.json)."""
+def pmc_set(dirs, prefix, command, fetch_dir, marker=None, levels=4):
+    """Per-kernel per-launch counter averages of one group of --pmc passes (the same layout as <dst>_pmc.json).  marker: a kernel
+    the profiled script launches in front of every level of its schedule -- the rows are then keyed "L<k> <kernel>" with k = the
+    number of markers seen so far modulo `levels` (dispatch order), one entry per level instead of an average over all of them."""
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     nl = collections.defaultdict(int)
     for d in dirs:
         for fn in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
             seen_ = set()
-            for r in csv.DictReader(open(fn)):
+            rows_ = sorted(csv.DictReader(open(fn)), key=lambda r: int(r["Dispatch_Id"]))
+            marks, last_mark = 0, None
+            for r in rows_:
                 k = short(r["Kernel_Name"])
                 if not k.startswith("gsr::"):
                     continue
+                if marker:
+                    if k.startswith(marker):
+                        if r["Dispatch_Id"] != last_mark:
+                            marks += 1; last_mark = r["Dispatch_Id"]
+                        continue
+                    if marks == 0:
+                        continue                       # (the HEM levels in front of the schedule)
+                    k = "L%d %s" % ((marks - 1) % levels, k)
                 acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
                 key = (k, r["Dispatch_Id"])
                 if d == fetch_dir and key not in seen_:
@@ -116,9 +128,10 @@ def pmc_set(dirs, prefix, command, fetch_dir):
 
 
 pmc_set(("pmc_icp_fetch", "pmc_icp_write", "pmc_icp_l2", "pmc_icp_sq", "pmc_icp_sq2"), "_pmc_icp.json",
-        "scripts/prof_icp.py 5000000 2  (the bench's 4-level point-to-plane schedule on the HEM levels of a 5 M pair; per-launch averages "
-        "over ALL launches of a kernel, i.e. over the four levels)", "pmc_icp_fetch")
-pmc_set(("pmc_aniso_fetch", "pmc_aniso_write"), "_pmc_aniso.json",
+        "scripts/prof_icp.py 5000000 2  (the bench's 4-level point-to-plane schedule on the HEM levels of bench.py's own 5 M pair: 5 degrees / "
+        "0.05 h; one entry per LEVEL and kernel -- L0 = 185 k points ... L3 = 5 M --, per-launch averages within the level)", "pmc_icp_fetch",
+        marker="gsr::k_debug_logf")
+pmc_set(("pmc_aniso_fetch", "pmc_aniso_write", "pmc_aniso_l2", "pmc_aniso_sq", "pmc_aniso_sq2"), "_pmc_aniso.json",
         "scripts/prof_hem.py 5000000 1 2 aniso  (level 1 of a 5 M surfel-shaped cloud)", "pmc_aniso_fetch")
 f = glob.glob(os.path.join(src, "icp_stats", "*", "*kernel_stats.csv"))
 if f:

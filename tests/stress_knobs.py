@@ -25,9 +25,9 @@ def run(c):
     return out
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 31)
+def sweep(cases=12, seed=31, log=print):
+    """-> number of clouds on which some knob changed a level"""
+    rng = np.random.default_rng(seed)
     bad = 0
     t0 = time.time()
     for i in range(cases):
@@ -59,9 +59,15 @@ def main():
         for k in ALL:
             os.environ.pop(k, None)
         bad += 1 if fails else 0
-        print("ok  " if not fails else "FAIL", i, desc, [r[0] for r in ref], fails[:3], flush=True)
-    print(f"{cases - bad} of {cases} clouds: every knob leaves two levels unchanged ({time.time() - t0:.0f} s)")
-    sys.exit(1 if bad else 0)
+        log(f"{'ok  ' if not fails else 'FAIL'} {i} {desc} {[r[0] for r in ref]} {fails[:3]}")
+    log(f"{cases - bad} of {cases} clouds: every knob leaves two levels unchanged ({time.time() - t0:.0f} s)")
+    return bad
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 31
+    sys.exit(1 if sweep(cases, seed, log=lambda s: print(s, flush=True)) else 0)
 
 
 if __name__ == "__main__":

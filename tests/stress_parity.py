@@ -29,7 +29,9 @@ def rel(a, b):
     return float(np.max(np.abs(a[fa] - b[fb])) / (np.max(np.abs(b[fb])) + 1e-30))
 
 
-def make_case(rng):
+def make_case(rng, pathologies=None):
+    if pathologies is None:
+        pathologies = bool(os.environ.get("STRESS_PATHOLOGIES"))
     n = int(rng.integers(2000, 90000))
     shape = rng.choice(["iso", "aniso", "needles", "clustered"])
     deg = int(rng.choice([0, 1, 2, 3]))
@@ -51,7 +53,7 @@ def make_case(rng):
         centres = rng.uniform(-h, h, (5, 3))
         c["xyz"][:k] = (centres[rng.integers(0, 5, k)] + rng.normal(0, 0.05 * h, (k, 3))).astype(np.float32)
         c["xyz"][-3:] *= 50.0
-    if os.environ.get("STRESS_PATHOLOGIES"):              # a handful of broken components in a cloud of ordinary size
+    if pathologies:              # a handful of broken components in a cloud of ordinary size
         def pick(m):
             return rng.choice(n, m, replace=False)
         if rng.random() < 0.5: c["cov6"][pick(20)] = 0.0
@@ -68,13 +70,16 @@ def make_case(rng):
     return dict(n=n, shape=shape, deg=deg, h=round(h, 3), seed=seed, **params), c, params
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 2026)
+def sweep(cases=40, seed=2026, log=print, pathologies=None):
+    """-> (equal, edge, bad): `edge` = exactly the documented class (parents, pairs and orphans EQUAL, `dropped` and the level
+    size off by <= 2 -- 8 with STRESS_PATHOLOGIES), anything else is `bad`.  tests/test_stress_gpu.py runs a fixed-seed slice."""
+    if pathologies is None:
+        pathologies = bool(os.environ.get("STRESS_PATHOLOGIES"))
+    rng = np.random.default_rng(seed)
     bad = edge = 0
     t0 = time.time()
     for k in range(cases):
-        desc, c, p = make_case(rng)
+        desc, c, p = make_case(rng, pathologies)
         want, wst = O.hem(c, 1, **p)
         with hem.HemMixture(hem_reduction=p["rho"], distance_delta=p["delta"], color_delta=p["kappa"], decay_rate=p["tau"]) as m:
             m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
@@ -84,12 +89,19 @@ def main():
         b = (wst[0]["parents"], wst[0]["pairs"], wst[0]["orphans"], wst[0]["dropped"], want[0]["xyz"].shape[0])
         err = max(rel(got[f], want[0][f]) for f in ("xyz", "color", "cov6", "opacity", "sh")) if a[4] == b[4] else float("inf")
         ok = a == b and err < TOL
-        lim = 8 if os.environ.get("STRESS_PATHOLOGIES") else 2     # (merges with a 1e8-scaled needle: the determinant is cancellation noise)
+        lim = 8 if pathologies else 2     # (merges with a 1e8-scaled needle: the determinant is cancellation noise)
         edge_case = (not ok) and a[:3] == b[:3] and abs(a[3] - b[3]) <= lim and abs(a[4] - b[4]) <= lim
         edge += 1 if edge_case else 0
         bad += 0 if (ok or edge_case) else 1
-        print(f"{'ok  ' if ok else ('edge' if edge_case else 'FAIL')} {k:3d} {desc}  gpu {a}  oracle {b}  irregular {st['irregular']}  max rel {err:.2e}", flush=True)
-    print(f"{cases - bad - edge} of {cases} cases equal the oracle, {edge} differ by a borderline validity erase, {bad} FAIL ({time.time() - t0:.0f} s)")
+        log(f"{'ok  ' if ok else ('edge' if edge_case else 'FAIL')} {k:3d} {desc}  gpu {a}  oracle {b}  irregular {st['irregular']}  max rel {err:.2e}")
+    log(f"{cases - bad - edge} of {cases} cases equal the oracle, {edge} differ by a borderline validity erase, {bad} FAIL ({time.time() - t0:.0f} s)")
+    return cases - bad - edge, edge, bad
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 2026
+    _, _, bad = sweep(cases, seed, log=lambda s: print(s, flush=True))
     sys.exit(1 if bad else 0)
 
 

@@ -33,10 +33,8 @@ def worker(rank, world, port, cases, seed, q):
     dist.barrier(); dist.destroy_process_group()
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
-    world = int(sys.argv[2]) if len(sys.argv) > 2 else 3
-    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 99
+def sweep(cases=12, world=3, seed=99, log=print):
+    """-> number of clouds whose assembled pieces differ from the one-GPU levels"""
     ctx = mp.get_context("spawn"); q = ctx.Queue()
     ps = [ctx.Process(target=worker, args=(r, world, 29900 + os.getpid() % 90, cases, seed, q)) for r in range(world)]
     [p.start() for p in ps]
@@ -61,9 +59,16 @@ def main():
                             print("     ", f, "rows differing", len(w), "first", w[:5], "max abs", float(np.abs(np.asarray(got[f], np.float64) - want[k][f]).max()))
             ok = ok and same
         bad += 0 if ok else 1
-        print("ok  " if ok else "FAIL", i, desc, [w["xyz"].shape[0] for w in want], flush=True)
-    print(f"{cases - bad} of {cases} partitioned clouds are bit-identical to one GPU (world {world})")
-    sys.exit(1 if bad else 0)
+        log(f"{'ok  ' if ok else 'FAIL'} {i} {desc} {[w['xyz'].shape[0] for w in want]}")
+    log(f"{cases - bad} of {cases} partitioned clouds are bit-identical to one GPU (world {world})")
+    return bad
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    world = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 99
+    sys.exit(1 if sweep(cases, world, seed, log=lambda s: print(s, flush=True)) else 0)
 
 
 if __name__ == "__main__":

@@ -25,9 +25,9 @@ def same(a, b):
     return bool(np.abs(a[fa] - b[fb]).max() / scale < 1e-4)
 
 
-def main():
-    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 5)
+def sweep(cases=200, seed=5, log=print):
+    """-> number of failing clouds"""
+    rng = np.random.default_rng(seed)
     bad = 0
     t0 = time.time()
     for k in range(cases):
@@ -72,9 +72,15 @@ def main():
             ok, why = False, f"exception {type(e).__name__}: {str(e)[:120]}"
         bad += 0 if ok else 1
         if not ok:
-            print(f"FAIL {k} n={n} deg={deg} {what} {p}: {why}", flush=True)
-    print(f"{cases - bad} of {cases} tiny / pathological clouds equal the oracle ({time.time() - t0:.0f} s)")
-    sys.exit(1 if bad else 0)
+            log(f"FAIL {k} n={n} deg={deg} {what} {p}: {why}")
+    log(f"{cases - bad} of {cases} tiny / pathological clouds equal the oracle ({time.time() - t0:.0f} s)")
+    return bad
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    sys.exit(1 if sweep(cases, seed, log=lambda s: print(s, flush=True)) else 0)
 
 
 if __name__ == "__main__":

@@ -91,3 +91,27 @@ def test_host_solve_matches_oracle_umeyama(hip_lib, oracle):
     x = np.linalg.solve(JTJ, -JTr)
     assert np.allclose(upd[:3, 3], x[3:], atol=1e-12)
     assert abs(np.linalg.det(upd[:3, :3]) - 1) < 1e-12
+
+
+def test_wrong_rccl_library_is_an_error_not_a_crash(hip_lib):
+    """a dlopen candidate that fails must yield GSR_E_HIP with dlopen's message (it used to assign a
+    std::string from the NULL a second dlerror() returns).  Fresh process: the library handle is cached per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes as C, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "from gaussiansplattingregistration_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "buf = (C.c_char * 128)()\n"
+        "rc = lib.gsr_comm_get_unique_id(buf)\n"
+        "msg = lib.gsr_last_error()\n"
+        "assert rc == -2, rc\n"                                   # GSR_E_HIP
+        "assert b'not available' in msg and b'no_such_rccl' in msg, msg\n"
+        "h = C.c_void_p()\n"
+        "rc = lib.gsr_comm_create(C.byref(h), buf, 0, 1, 0)\n"
+        "assert rc == -2 and not h.value, rc\n"
+        "print('ok')\n" % ROOT)
+    env = dict(os.environ, GSR_RCCL_LIB="/tmp/no_such_rccl.so")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)

@@ -53,4 +53,30 @@ def test_mode_c5_two_ranks():
     assert d["n_gpus"] == 2 and d["config"]["mode"] == "c5" and d["config"]["level_sizes"][0] == 300000
     # the two ranks share the levels: counted once (3 levels of the 300 k cloud + 3 of the 100 k target)
     assert 1.3 * 400000 < d["value"] * d["hem_s_per_step"] < 1.6 * 400000
-    assert np.isfinite(d["icp_result"]["T_err_vs_ground_truth_F"])
+    assert d["icp_result"]["T_err_vs_ground_truth_F"] < 1e-3, d["icp_result"]
+    # every rank drew only its own block: the partition statistics of rank 0 ride along (ghosts a fraction of the block, the SH
+    # rows' exchange timed apart from the 72-byte rows')
+    p0 = d["partition_rank0"][0]
+    assert 0 < p0["ghosts"] < 150000 and p0["halo_bytes_received"] == p0["ghosts"] * (72 + 4 * 45) and p0["n_global"] < 300000
+    assert d["transport"] == "callbacks"
+
+
+def test_replica_line_carries_the_strong_block():
+    """`bench.py --gpus 2` (what the driver's SCALE tier launches): the replica line, and inside it the strong-scaling children --
+    configs[4] (c5, partitioned HEM of one cloud over both ranks) and configs[3] (c4, N = 2) -- each with its own accuracy."""
+    d = _torchrun(["--splats", "120000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--strong-splats", "100000", "--strong-steps", "1",
+                   "--strong-timeout", "400"], port=29717)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["mode"] == "replicas"
+    st = d["strong"]
+    for name in ("c5", "c4"):
+        assert "error" not in st[name], st[name]
+        assert st[name]["scaling"] == "strong" and st[name]["T_err_vs_ground_truth_F"] < 1e-3 and st[name]["gaussians_per_s"] > 1e5
+    assert st["c5"]["level_sizes"][0] == 200000 and st["c5"]["partition_rank0"][0]["ghosts"] > 0
+    assert st["c4"]["level_sizes"][0] == 100000 and st["c4"]["exchange_s_per_step"] > 0
+
+
+def test_a_failing_strong_child_cannot_lose_the_replica_line():
+    """The guard: a deadline far too short for the children -- the replica line still comes out, with the error recorded."""
+    d = _torchrun(["--splats", "120000", "--steps", "1", "--warmup", "0", "--no-cpu-baseline", "--strong-splats", "100000", "--strong-steps", "1",
+                   "--strong-timeout", "0.5"], port=29719)
+    assert d["value"] > 1e5 and "deadline" in d["strong"]["c5"]["error"] and "deadline" in d["strong"]["c4"]["error"]
