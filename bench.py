@@ -392,10 +392,11 @@ def main():
     ap.add_argument("--target-splats", type=int, default=5_000_000, help="c5: splats of the target cloud")
     ap.add_argument("--mode", choices=["replicas", "c4", "c5"], default="replicas")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["iso", "aniso"], default="iso",
+    ap.add_argument("--workload", choices=["iso", "aniso", "clustered"], default="iso",
                     help="splat shapes of the pair: SURVEY 8(d)'s isotropic recipe, or the surfel recipe (synth.make_cloud(shape='aniso'): 60 %% discs, "
-                         "15 %% needles, covariance condition numbers 1e2 .. 1e5 on a smooth orientation field)")
-    ap.add_argument("--no-aniso", action="store_true", help="skip the anisotropic side measurement of the default run")
+                         "15 %% needles, covariance condition numbers 1e2 .. 1e5 on a smooth orientation field), or the large-scene recipe "
+                         "(shape='clustered': 60 %% of the splats in 40 clumps of 30 .. 100 x the background density, giants, far outliers)")
+    ap.add_argument("--no-aniso", action="store_true", help="skip the anisotropic and clustered side measurements of the default run")
     ap.add_argument("--no-strong", action="store_true", help="--gpus N > 1, replica mode: skip the strong-scaling children (c5, and c4 at N = 2)")
     ap.add_argument("--strong-splats", type=int, default=5_000_000, help="strong block: splats per GPU of the c5 source (x N) and per cloud of c4")
     ap.add_argument("--strong-steps", type=int, default=2)
@@ -625,7 +626,7 @@ def main():
             "ms_per_step": elapsed / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak" if a.mode == "replicas" else "strong", "vs_baseline": None,
             "dtype": "f32 (HEM) / f64 (ICP)", "data": "synthetic",
-            "config": {"workload": (f"2x{n} synthetic splats (SH deg 3{', surfel shapes' if a.workload == 'aniso' else ''}) per GPU: 3 HEM levels per cloud + "
+            "config": {"workload": (f"2x{n} synthetic splats (SH deg 3{', surfel shapes' if a.workload == 'aniso' else (', clustered scene' if a.workload == 'clustered' else '')}) per GPU: 3 HEM levels per cloud + "
                                     "4-level coarse-to-fine point-to-plane ICP (BASELINE configs[2])") if a.mode == "replicas" else
                                    (f"2x{n} splats, clouds one per GPU + ICP source split (BASELINE configs[3])" if a.mode == "c4" else
                                     f"one {n}-splat cloud vs a {min(a.target_splats, n)}-splat target, sharded HEM + split ICP (BASELINE configs[4])"),
@@ -677,6 +678,34 @@ def main():
                 del ca
             except Exception as e:  # pragma: no cover
                 line["aniso_level"] = {"error": str(e)[:200]}
+            # and on the large-scene shape the reference's README complains about (README.md:113): dense clumps on a sparse background,
+            # a handful of giant splats, far outliers -- heavy parents, long grid rows, crowded sum buckets.  No silent fallback: the
+            # overflow / two-pass flags of the level ride along.
+            try:
+                cc = synth.make_cloud_torch(n, seed=400, device=dev, shape="clustered")
+                m = ctxs["hem"]
+                rows = []
+                for _ in range(3):
+                    m.set_rng("glibc", 1, 0)
+                    m.set_level0(cc["xyz"], cc["color"], cc["opacity"], cc["cov6"], cc["sh"], borrow=True)
+                    m.run_level()
+                    rows.append(m.stats())
+                st = rows[-1]
+                ms = float(np.median([r["ms_level"] for r in rows]))
+                line["clustered_level"] = {"workload": f"one {n}-splat cloud, synth shape 'clustered' (60 % in 40 Gaussian clumps of 30-100 x the background density with "
+                                                       "splats shrunk by the cube root of that, 6 giants of 40 x sigma, 12 outliers at 20-60 h), level 1",
+                                           "parents": st["parents"], "candidates_per_parent": st["candidates"] / max(1, st["parents"]), "pairs": st["pairs"],
+                                           "orphans": st["orphans"], "n_out": st["n_out"], "cells": st["cells"], "irregular_fraction": st["irregular"] / st["n_in"],
+                                           "heavy_parents": st["heavy_parents"], "heavy_work_items": st["heavy_work_items"],
+                                           "one_pass_selection": bool(st["one_pass"]), "bucket_region_overflow_fallback": bool(st["partition_overflow"]),
+                                           "ms_level": ms, "ms_phases": {k: st[k] for k in ("ms_grid", "ms_select", "ms_sumlw", "ms_mstep", "ms_flags")},
+                                           "ms_k_select": st["ms_k_select"], "ms_k_mstep": st["ms_k_mstep"], "gaussians_per_s": st["n_in"] / (ms * 1e-3),
+                                           "iso_level1_ms_same_n": l1_ms, "ratio_to_iso_level": ms / l1_ms if l1_ms else None}
+                del cc
+                ctxs["hem"].close()                                     # (a context that overflowed stays with the exact partition: a fresh one for what follows)
+                ctxs["hem"] = hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS)
+            except Exception as e:  # pragma: no cover
+                line["clustered_level"] = {"error": str(e)[:200]}
         if world == 1 and a.mode == "replicas" and not a.no_cpu_baseline:
             def gpu_level1_rate(nn):
                 c = synth.make_cloud(nn, seed=0)

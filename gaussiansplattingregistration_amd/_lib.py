@@ -102,6 +102,7 @@ SIGNATURES = {
     "gsr_normals_knn": (_i32, [_vp, _i64, _i32, _vp, _i32, _i32, _vp]),
     "gsr_cov_from_normals": (_i32, [_vp, _i64, _f64, _vp, _i32, _i32, _vp]),
     "gsr_decompose_cov": (_i32, [_vp, _i64, _i32, _vp, _vp, _vp, _i32, _i32, _vp]),
+    "gsr_ply_unpack": (_i32, [_vp, _i64, _i32, C.POINTER(_i32), _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "gsr_plane_score": (_i32, [_vp, _vp, _i64, _vp, _i32, _f32, _f32, _vp, _vp, C.POINTER(_i32), _i32, _i32, _vp]),
     "gsr_icp_solve": (_i32, [_vp, _i32, _vp, _vp]),
     "gsr_icp_get_centre": (_i32, [_vp, _vp]),

@@ -171,6 +171,23 @@ __device__ __forceinline__ float swap32_sum(float v) {          // v[l] + v[l ^ 
     const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
 }
+// the row-local part of class_sum<1>: every lane ends with the total of its row of 16 lanes (the same rotations in the same order)
+__device__ __forceinline__ float row_sum16(float v) {
+    v += dpp_f<0x128>(v);
+    v += dpp_f<0x124>(v);
+    v += dpp_f<0x122>(v);
+    v += dpp_f<0x121>(v);
+    return v;
+}
+// the row-local part of class_sum<G>: the total of the lanes l' == l (mod G) of the lane's own row
+template <int G>
+__device__ __forceinline__ float row_class_sum(float v) {
+    if (G <= 8) v += dpp_f<0x128>(v);
+    if (G <= 4) v += dpp_f<0x124>(v);
+    if (G <= 2) v += dpp_f<0x122>(v);
+    if (G <= 1) v += dpp_f<0x121>(v);
+    return v;
+}
 // sum over the lanes l' == l (mod G), G a power of two: every lane ends with the total of its residue class
 template <int G>
 __device__ __forceinline__ float class_sum(float v) {
@@ -1746,6 +1763,7 @@ struct MstepArgs {
     const unsigned* pair_child;
     const float* pair_wl;
     int P, F;
+    int small;                 // serve parents of <= MSTEP_SMALL pairs four at a time (GSR_HEM_MSTEP_SMALL=0: the general path for all)
     float *o_xyz, *o_color, *o_cov6, *o_opacity, *o_weight, *o_sh;
 };
 __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __restrict__ porder, const unsigned* __restrict__ plist,
@@ -1765,6 +1783,7 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
 }
 
 #define MSTEP_CHUNK 256
+#define MSTEP_SMALL 16        // parents with at most this many pairs are served four at a time, one per DPP row
 #define MSTEP_NV 3            // float4 per lane and SH row
 #define MSTEP_K 4             // parents per wavefront
 #define MSTEP_U 3             // rounds of SH row loads in flight (each: MSTEP_NV float4 per lane, 64/G children)
@@ -1800,7 +1819,163 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
 #pragma unroll
     for (int v = 0; v < MSTEP_NV; ++v) qi[v] = gl + GG * v < nq ? gl + GG * v : 0;
 
+    // ---- small parents (at most MSTEP_SMALL = 16 pairs: most parents of a surfel-shaped cloud, 6.5 pairs on average) ----------------
+    // The wave's small parents are served TOGETHER, parent q in DPP row q (lanes 16 q .. 16 q + 15), instead of one after the other
+    // with 6 of 64 lanes alive: one pair-list load, one record gather, one set of row loads and one output sequence for up to four
+    // parents.  Bit for bit the sums of the general path below: there lane l < 16 holds pair l, the lanes above hold +0.0, and
+    // class_sum<1> is the row-local rotations followed by two additions of +0.0 (swap16, swap32); the SH sum of a parent with
+    // <= 16 pairs is one product per lane group (16 / G groups per row), reduced by class_sum<G>'s row-local rotations inside each
+    // of the wave's four rows and then (S0 + S1) + (S2 + S3) over the rows -- here the four rows of the general path are four
+    // ROUNDS of this parent's own row, combined in the same order.  (G <= 4: a round then holds 16 / G >= 4 children per row and
+    // <= 16 children never chain two products through one fmaf; larger rows -- SH degree 4 and up -- take the general path.)
+    unsigned small_mask = 0u;
+    if constexpr (G <= 4) {
+#pragma unroll
+        for (int it = 0; it < MSTEP_K; ++it)
+            if (it < ns) {
+                const MstepHeader h = a.hdr[s0 + it];
+                if (h.oslot >= 0 && h.cnt <= MSTEP_SMALL) small_mask |= 1u << it;
+            }
+    }
+    if (G <= 4 && a.small && small_mask != 0u) {
+        const int q = lane >> 4, i = lane & 15;
+        // this lane's parent (row q): the four headers are uniform (scalar loads), the per-lane copy is a chain of selects
+        long long off_q = 0; unsigned cnt_q = 0u; int slot_q = -1; float ppx = 0.0f, ppy = 0.0f, ppz = 0.0f;
+        unsigned maxcnt = 0u;
+#pragma unroll
+        for (int it = 0; it < MSTEP_K; ++it)
+            if ((small_mask >> it) & 1u) {
+                const MstepHeader h = a.hdr[s0 + it];
+                maxcnt = h.cnt > maxcnt ? h.cnt : maxcnt;
+                if (q == it) { off_q = h.off; cnt_q = h.cnt; slot_q = h.oslot; ppx = h.px; ppy = h.py; ppz = h.pz; }
+            }
+        const bool live = (unsigned)i < cnt_q;
+        unsigned j = 0xffffffffu;
+        float wl = 0.0f;
+        if (live) { j = a.pair_child[off_q + i]; wl = a.pair_wl[off_q + i]; }
+        s_j[lane] = j;
+        __builtin_amdgcn_wave_barrier();
+        // records: gather round u serves row u (its 16 slots, four lanes per 64-byte record); rows without a small parent and
+        // slots beyond a parent's pairs load nothing
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!((small_mask >> u) & 1u)) continue;
+            const int r = (lane >> 2) + 16 * u;
+            const unsigned jr = s_j[r];
+            if (jr != 0xffffffffu) s_rec[r * 5 + (lane & 3)] = a.geo[4 * (int64_t)jr + (lane & 3)];
+        }
+        __builtin_amdgcn_wave_barrier();
+        float w = 0.0f;
+        float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
+        float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
+        if (live) {
+            const float4 ca = s_rec[lane * 5], cb = s_rec[lane * 5 + 1], cc = s_rec[lane * 5 + 2], cd = s_rec[lane * 5 + 3];
+            const float sl = cd.w;
+            if (sl != 0.0f) {
+                const float r_is = wl / sl;            // mixture.cpp:196
+                w = r_is * cd.z;                       // * child.weight (:197)
+                const f3 cm = {ca.x, ca.y, ca.z};
+                const f3 pmq = {ppx, ppy, ppz};
+                const f3 d = sub3(cm, pmq);
+                w_s += w;
+                smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
+                scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
+                v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
+                v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
+                so += w * cd.y;
+            }
+        }
+        s_w[lane] = w;
+        w_s = row_sum16(w_s);
+        smx = row_sum16(smx); smy = row_sum16(smy); smz = row_sum16(smz);
+        scx = row_sum16(scx); scy = row_sum16(scy); scz = row_sum16(scz);
+        v00 = row_sum16(v00); v01 = row_sum16(v01); v02 = row_sum16(v02);
+        v11 = row_sum16(v11); v12 = row_sum16(v12); v22 = row_sum16(v22);
+        so = row_sum16(so);
+        float* s_mom4 = reinterpret_cast<float*>(s_acc) + 256;          // 4 x 16 floats behind the four SH rows on their way out
+        if (i == 0) {
+            float* m = s_mom4 + 16 * q;
+            m[0] = w_s; m[1] = smx; m[2] = smy; m[3] = smz; m[4] = scx; m[5] = scy; m[6] = scz;
+            m[7] = v00; m[8] = v01; m[9] = v02; m[10] = v11; m[11] = v12; m[12] = v22; m[13] = so;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* mq = s_mom4 + 16 * q;
+        const float w_sq = mq[0];
+        const float inv_w = 1.0f / w_sq;                       // mixture.cpp:209
+        if (slot_q >= 0) {
+            const float mx = mq[1] * inv_w, my = mq[2] * inv_w, mz = mq[3] * inv_w;
+            const float dx = mx - ppx, dy = my - ppy, dz = mz - ppz;
+            const int64_t slot = slot_q;
+            float val = w_sq;                                                        // lane 13 of the row: weight
+            float* dst = a.o_weight + slot;
+            if (i < 3) { val = i == 0 ? mx : (i == 1 ? my : mz); dst = a.o_xyz + 3 * slot + i; }
+            else if (i < 6) { val = mq[4 + (i - 3)] * inv_w; dst = a.o_color + 3 * slot + (i - 3); }
+            else if (i < 12) {
+                const int t = i - 6;                                                 // xx xy xz yy yz zz
+                const float da = t < 3 ? dx : (t < 5 ? dy : dz);
+                const float db = t == 0 ? dx : (t == 1 || t == 3 ? dy : dz);
+                val = mq[7 + t] * inv_w - da * db;                                   // mixture.cpp:211-212,236-238
+                dst = a.o_cov6 + 6 * slot + t;
+            } else if (i == 12) { val = inv_w * mq[13]; dst = a.o_opacity + slot; }
+            if (i < 14) *dst = val;
+        }
+        if constexpr (G > 0) {
+            constexpr int CR = 16 / GG;                        // children per round and row
+            const int gi = i / GG;                             // this lane's group inside the row
+            float4 rowv[GG][MSTEP_NV];
+            float wr[GG];
+#pragma unroll
+            for (int r = 0; r < GG; ++r) {
+                const unsigned k = (unsigned)(CR * r + gi);
+                const bool lv = k < cnt_q && (unsigned)(CR * r) < maxcnt;
+                wr[r] = 0.0f;
+#pragma unroll
+                for (int v = 0; v < MSTEP_NV; ++v) rowv[r][v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (lv) {
+                    const unsigned jc = s_j[16 * q + k];
+                    wr[r] = s_w[16 * q + k];
+                    const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)jc * a.RSH);
+#pragma unroll
+                    for (int v = 0; v < MSTEP_NV; ++v) rowv[r][v] = row[qi[v]];
+                }
+            }
+            float4 tot[MSTEP_NV];
+#pragma unroll
+            for (int v = 0; v < MSTEP_NV; ++v) {
+                float4 sr[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float4 pr = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                    if (r < GG) {       // the general path's first accumulation into a zero: fmaf(row, w, +0.0); an absent child: +0.0
+                        pr.x = __builtin_fmaf(rowv[r][v].x, wr[r], 0.0f); pr.y = __builtin_fmaf(rowv[r][v].y, wr[r], 0.0f);
+                        pr.z = __builtin_fmaf(rowv[r][v].z, wr[r], 0.0f); pr.w = __builtin_fmaf(rowv[r][v].w, wr[r], 0.0f);
+                        pr.x = row_class_sum<GG>(pr.x); pr.y = row_class_sum<GG>(pr.y); pr.z = row_class_sum<GG>(pr.z); pr.w = row_class_sum<GG>(pr.w);
+                    }
+                    sr[r] = pr;
+                }
+                tot[v].x = (sr[0].x + sr[1].x) + (sr[2].x + sr[3].x); tot[v].y = (sr[0].y + sr[1].y) + (sr[2].y + sr[3].y);
+                tot[v].z = (sr[0].z + sr[1].z) + (sr[2].z + sr[3].z); tot[v].w = (sr[0].w + sr[1].w) + (sr[2].w + sr[3].w);
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (gi == 0) {
+#pragma unroll
+                for (int v = 0; v < MSTEP_NV; ++v) {
+                    const int f0 = 64 * q + 4 * (gl + GG * v);
+                    s_out[f0] = tot[v].x * inv_w; s_out[f0 + 1] = tot[v].y * inv_w;
+                    s_out[f0 + 2] = tot[v].z * inv_w; s_out[f0 + 3] = tot[v].w * inv_w;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            // four rows of F floats leave with coalesced stores: lane l of row q takes floats l, l + 16, ... of parent q's row
+            if (slot_q >= 0)
+                for (int f = i; f < a.F; f += 16) a.o_sh[(int64_t)slot_q * a.F + f] = s_out[64 * q + f];
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (!(G <= 4 && a.small)) small_mask = 0u;
+
     for (int it = 0; it < ns; ++it) {
+        if ((small_mask >> it) & 1u) continue;                  // served above
         const MstepHeader h = a.hdr[s0 + it];                   // uniform address: scalar loads
         if (h.oslot < 0) continue;
         const f3 pm = {h.px, h.py, h.pz};
@@ -2607,6 +2782,7 @@ struct gsr_hem_ctx {
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec;
+    bool mstep_small = true;        // GSR_HEM_MSTEP_SMALL=0: no four-at-a-time path for the parents of <= 16 pairs (test knob: nothing may change)
     bool use_ell = true;            // GSR_HEM_ELL=0: no ellipsoid row clipping (test knob: the pair set must not change)
     int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
     gsr_allreduce_dev_fn shard_allreduce = nullptr;
@@ -2854,6 +3030,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_MSTEP_SMALL")) c->mstep_small = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
     if (const char* s = getenv("GSR_HEM_SH_GRID")) c->sh_grid = atoi(s);
@@ -3712,13 +3889,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL(k_orphans_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), c->oflag.as<int>(), c->oflag_in.as<int>());
         GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
         Collect q;
-        q.n = 4;
+        q.n = 6;
         q.src[0] = c->orank_in.as<int>() + (n - 1); q.src[1] = c->oflag_in.as<int>() + (n - 1); q.src[2] = overflow_flag;
         q.src[3] = c->counters.as<int>() + 13;
-        q.bytes[0] = q.bytes[1] = q.bytes[2] = q.bytes[3] = 4;
+        q.src[4] = c->counters.as<int>() + 8; q.src[5] = c->counters.as<int>() + 10;      // heavy parents, their work items (statistics)
+        for (int i = 0; i < 6; ++i) q.bytes[i] = 4;
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
         o_last = (int)w[0]; o_flag = (int)w[1];
+        if (P > 0 && M >= 0 && c->stats[4] > 0) { c->stats_ex[3] = (int64_t)(unsigned)w[4]; c->stats_ex[4] = c->split_heavy ? (int64_t)(unsigned)w[5] : 0; }
         if (w[3] != 0ull) return fail(GSR_E_INVALID, "gsr_hem_run_level: the work-item table of the heavy parents overflowed (rerun with GSR_HEM_SPLIT=0)");
         if (!(fixed_tried && w[2] != 0ull) || attempt == 1) break;
         // a bucket region overflowed (pairs far more clustered than 6x the mean): the sums are incomplete.  Exact partition, and
@@ -3753,6 +3932,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.geo = c->geo.as<float4>(); ma.shs = c->shs.as<float>(); ma.RSH = RSH;
         ma.pair_child = pc; ma.pair_wl = pw;
         ma.P = P; ma.F = F;
+        ma.small = c->mstep_small ? 1 : 0;
         // processing order: the selection's (heavy parents by candidates scanned first, then Z-order) -- parents with many
         // candidates are the ones with many pairs.  The per-parent headers are laid out in that order.
         const unsigned* mporder = M > 0 ? c->porder.as<unsigned>() : nullptr;

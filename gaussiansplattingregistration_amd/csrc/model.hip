@@ -253,6 +253,90 @@ extern "C" int32_t gsr_plane_score(const float* xyz, const float* normals, int64
     return GSR_OK;
 }
 
+// ---- 3DGS .ply rows -> device SoA ------------------------------------------------------------------------
+// The reference loads a .ply straight onto cuda:0 (src/models/gaussian_model.py:98-139: plyfile -> numpy -> torch.tensor(device=
+// "cuda"), the f_rest block transposed from the file's channel-major (P, 3, K) to coefficient-major (P, K, 3), the covariance
+// built there from scale and rotation, :34-38,139).  Here the file's vertex rows (little-endian float32 properties, any order:
+// `off` holds each wanted property's byte offset inside a row) arrive in HBM as they are on disk -- chunked through pinned
+// memory by the host -- and ONE kernel scatters a chunk into the level-0 arrays the HEM boundary takes.
+struct PlyLayout {
+    int row_bytes;
+    int K;                      // SH-rest coefficients per channel (15 at degree 3)
+    int xyz[3], dc[3], opacity, scale[3], rot[4];
+    int rest0;                  // byte offset of f_rest_0 ... f_rest_(3K-1), consecutive float32
+};
+
+__device__ __forceinline__ float ply_f32(const unsigned char* row, int off) {
+    float v;
+    if ((reinterpret_cast<uintptr_t>(row + off) & 3u) == 0u) v = *reinterpret_cast<const float*>(row + off);
+    else memcpy(&v, row + off, 4);              // rows of files with uchar / double properties in front need not be 4-byte aligned
+    return v;
+}
+
+__global__ __launch_bounds__(256) void k_ply_unpack(int64_t n, const unsigned char* __restrict__ rows, PlyLayout L, float* __restrict__ xyz,
+                                                    float* __restrict__ color, float* __restrict__ sh, float* __restrict__ opacity,
+                                                    float* __restrict__ scale, float* __restrict__ rot, float* __restrict__ cov6) {
+    const int F = 3 * L.K;
+    // geometry: a thread per splat
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned char* r = rows + i * L.row_bytes;
+        xyz[3 * i] = ply_f32(r, L.xyz[0]); xyz[3 * i + 1] = ply_f32(r, L.xyz[1]); xyz[3 * i + 2] = ply_f32(r, L.xyz[2]);
+        color[3 * i] = ply_f32(r, L.dc[0]); color[3 * i + 1] = ply_f32(r, L.dc[1]); color[3 * i + 2] = ply_f32(r, L.dc[2]);
+        opacity[i] = ply_f32(r, L.opacity);
+        const float s0 = ply_f32(r, L.scale[0]), s1 = ply_f32(r, L.scale[1]), s2 = ply_f32(r, L.scale[2]);
+        const float qw = ply_f32(r, L.rot[0]), qx = ply_f32(r, L.rot[1]), qy = ply_f32(r, L.rot[2]), qz = ply_f32(r, L.rot[3]);
+        scale[3 * i] = s0; scale[3 * i + 1] = s1; scale[3 * i + 2] = s2;
+        rot[4 * i] = qw; rot[4 * i + 1] = qx; rot[4 * i + 2] = qy; rot[4 * i + 3] = qz;
+        // build_rotation (general_utils.py:43-66) on the normalised quaternion, L = R diag(exp(scale)), covariance = L L^T (:69-80), float32
+        const float nrm = sqrtf(qw * qw + qx * qx + qy * qy + qz * qz);
+        const float w = qw / nrm, x = qx / nrm, y = qy / nrm, z = qz / nrm;
+        const float e0 = expf(s0), e1 = expf(s1), e2 = expf(s2);
+        const float R00 = 1.0f - 2.0f * (y * y + z * z), R01 = 2.0f * (x * y - w * z), R02 = 2.0f * (x * z + w * y);
+        const float R10 = 2.0f * (x * y + w * z), R11 = 1.0f - 2.0f * (x * x + z * z), R12 = 2.0f * (y * z - w * x);
+        const float R20 = 2.0f * (x * z - w * y), R21 = 2.0f * (y * z + w * x), R22 = 1.0f - 2.0f * (x * x + y * y);
+        const float l00 = R00 * e0, l01 = R01 * e1, l02 = R02 * e2, l10 = R10 * e0, l11 = R11 * e1, l12 = R12 * e2, l20 = R20 * e0, l21 = R21 * e1, l22 = R22 * e2;
+        cov6[6 * i] = (l00 * l00 + l01 * l01) + l02 * l02; cov6[6 * i + 1] = (l00 * l10 + l01 * l11) + l02 * l12;
+        cov6[6 * i + 2] = (l00 * l20 + l01 * l21) + l02 * l22; cov6[6 * i + 3] = (l10 * l10 + l11 * l11) + l12 * l12;
+        cov6[6 * i + 4] = (l10 * l20 + l11 * l21) + l12 * l22; cov6[6 * i + 5] = (l20 * l20 + l21 * l21) + l22 * l22;
+    }
+    // SH rest: a thread per output float, consecutive threads on consecutive output addresses; sh[i][k][c] = file f_rest[c * K + k]
+    if (F > 0) {
+        const int64_t total = n * F;
+        for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t i = t / F;
+            const int f = (int)(t - i * F);
+            const int k = f / 3, c = f - 3 * k;
+            sh[t] = ply_f32(rows + i * L.row_bytes, L.rest0 + 4 * (c * L.K + k));
+        }
+    }
+}
+
+extern "C" int32_t gsr_ply_unpack(const void* rows_dev, int64_t n, int32_t row_bytes, const int32_t* offsets, int32_t K, float* xyz, float* color,
+                                  float* sh, float* opacity, float* scale, float* rot, float* cov6, int32_t device, void* stream) {
+    if (n < 0 || K < 0 || row_bytes <= 0 || !offsets || (n > 0 && (!rows_dev || !xyz || !color || !opacity || !scale || !rot || !cov6 || (K > 0 && !sh))))
+        return fail(GSR_E_INVALID, "gsr_ply_unpack: bad argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(GSR_E_NO_DEVICE, "gsr_ply_unpack: no HIP device visible (this backend has no CPU fallback)");
+    PlyLayout L;
+    L.row_bytes = row_bytes; L.K = K;
+    for (int i = 0; i < 3; ++i) { L.xyz[i] = offsets[i]; L.dc[i] = offsets[3 + i]; L.scale[i] = offsets[7 + i]; }
+    L.opacity = offsets[6];
+    for (int i = 0; i < 4; ++i) L.rot[i] = offsets[10 + i];
+    L.rest0 = offsets[14];
+    for (int i = 0; i < 15; ++i)
+        if (offsets[i] < 0 || offsets[i] + (i == 14 ? 12 * K : 4) > row_bytes) {
+            if (i == 14 && K == 0) continue;
+            return fail(GSR_E_INVALID, "gsr_ply_unpack: property offset %d outside the %d-byte row", offsets[i], row_bytes);
+        }
+    if (n == 0) return GSR_OK;
+    GSR_HIP(hipSetDevice(device));
+    hipLaunchKernelGGL(k_ply_unpack, dim3(stride_grid(n * (K > 0 ? 3 * K : 1))), dim3(256), 0, (hipStream_t)stream, n, (const unsigned char*)rows_dev, L, xyz, color, sh,
+                       opacity, scale, rot, cov6);
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
 extern "C" int32_t gsr_decompose_cov(const float* cov6, int64_t n, int32_t mode, float* scaling, float* rotation, float* matrix,
                                      int32_t on_device, int32_t device, void* stream) {
     if (n < 0 || (n > 0 && (!cov6 || !scaling || !rotation))) return fail(GSR_E_INVALID, "gsr_decompose_cov: bad argument");

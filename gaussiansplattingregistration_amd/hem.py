@@ -258,7 +258,7 @@ class HemMixture:
         _lib.check(self._L.gsr_hem_get_stats_ex(self._h, x), "gsr_hem_get_stats_ex")
         km = (C.c_float * 8)()
         _lib.check(self._L.gsr_hem_get_kernel_ms(self._h, km), "gsr_hem_get_kernel_ms")
-        return {"irregular": x[0], "one_pass": x[1], "partition_overflow": x[2],
+        return {"irregular": x[0], "one_pass": x[1], "partition_overflow": x[2], "heavy_parents": x[3], "heavy_work_items": x[4],
                 "ms_k_select": km[0], "ms_k_mstep": km[1], "ms_k_partition": km[2], "ms_k_bucket_sum": km[3],
                 "parents": s[0], "pairs": s[1], "orphans": s[2], "dropped": s[3], "candidates": s[4], "cells": s[5],
                 "n_in": s[6], "n_out": s[7], "ms_grid": t[0], "ms_select": t[1], "ms_sumlw": t[2], "ms_mstep": t[3],
@@ -267,8 +267,9 @@ class HemMixture:
 
 
 def create_mixture(cloud: dict, cluster_level: int, hem_reduction=3.0, distance_delta=3.0, color_delta=2.5,
-                   decay_rate=1.0, device=0, as_torch=False, rng_mode="glibc", rng_seed=1, rng_skip=0):
-    """``MixtureCreator.CreateMixture`` on a dict cloud: returns (levels, stats), level 0 dropped."""
+                   decay_rate=1.0, device=0, as_torch=False, rng_mode="glibc", rng_seed=1, rng_skip=0, with_state=False):
+    """``MixtureCreator.CreateMixture`` on a dict cloud: returns (levels, stats), level 0 dropped.  ``with_state``: the levels also
+    carry ``weight`` and ``is_parent`` (internal state the reference never exports)."""
     with HemMixture(hem_reduction, distance_delta, color_delta, decay_rate, device=device, rng_mode=rng_mode,
                     rng_seed=rng_seed, rng_skip=rng_skip) as m:
         m.set_level0(cloud["xyz"], cloud["color"], cloud["opacity"], cloud["cov6"], cloud["sh"])
@@ -276,5 +277,5 @@ def create_mixture(cloud: dict, cluster_level: int, hem_reduction=3.0, distance_
         for _ in range(int(cluster_level)):
             m.run_level()
             stats.append(m.stats())
-            levels.append(m.get_level(as_torch=as_torch))
+            levels.append(m.get_level(as_torch=as_torch, with_state=with_state))
         return levels, stats

@@ -110,11 +110,20 @@ class GaussianModel:
         self._covariance = _t(covariance, self.device_name, (n, 6))
         return self
 
-    def from_ply(self, path_or_arrays):
+    def from_ply(self, path_or_arrays, device=None, timing=None):
         """``GaussianModel.from_ply`` (reference ``gaussian_model.py:98-139``) from a file path (own reader,
-        ``utils/ply_io.py``) or from the dict ``ply_io.load_gaussian_arrays`` returns."""
+        ``utils/ply_io.py``) or from the dict ``ply_io.load_gaussian_arrays`` returns.  ``device`` (a CUDA index; default: this
+        model's ``device_name`` when that is a CUDA device): the file goes through pinned chunks straight into device SoA
+        (``ply_io.load_gaussian_device``) -- the reference, too, loads onto ``cuda:0`` (``file_loader.py:53-66``)."""
         from ..utils import ply_io
-        d = ply_io.load_gaussian_arrays(path_or_arrays) if isinstance(path_or_arrays, (str, bytes)) or hasattr(path_or_arrays, "__fspath__") else path_or_arrays
+        is_path = isinstance(path_or_arrays, (str, bytes)) or hasattr(path_or_arrays, "__fspath__")
+        if device is None and is_path and str(self.device_name).startswith("cuda"):
+            device = torch.device(self.device_name).index or 0
+        if is_path and device is not None:
+            self.device_name = f"cuda:{int(device)}"
+            d = ply_io.load_gaussian_device(path_or_arrays, int(device), timing=timing)
+        else:
+            d = ply_io.load_gaussian_arrays(path_or_arrays) if is_path else path_or_arrays
         self.from_arrays(d["xyz"], d["color"], d["opacity"], d["cov6"], d["sh"], d["sh_degree"])
         self._scaling = _t(d["scale"], self.device_name)
         self._rotation = _t(d["rot"], self.device_name)

@@ -79,10 +79,41 @@ def _aniso_frames(xyz: np.ndarray, jitter: np.ndarray, psi: np.ndarray, needle: 
     return np.stack([x, y, nrm], 2)
 
 
+# --- the clustered ("large scene") workload ------------------------------------------------------------------------
+# What the reference's README complains about (README.md:113, "for larger scenes the HEM downsampler becomes extremely slow"):
+# strongly non-uniform density and a few huge splats.  shape="clustered" draws
+#   60 % of the splats in CLUSTER_CLUMPS Gaussian clumps whose peak density is 30 ... 100 x the background's; their splats are
+#        smaller by the cube root of that factor (as trained scenes have it: small splats where there are many), so a parent of a
+#        clump merges about as many children as one of the background -- but the uniform grid's cells, sized for the average
+#        density, hold 30 ... 100 x more components there: long rows, heavy parents, crowded sum buckets;
+#   40 % a sparse uniform background (the isotropic recipe);
+#   CLUSTER_GIANTS background splats with 40 x the standard deviations (search radii of the size of the scene: the reference's grid
+#        cell is the largest parent radius, mixture.cpp:92-99, which is the pathology), and CLUSTER_OUTLIERS far outliers at 20 ... 60 h.
+CLUSTER_CLUMPS, CLUSTER_GIANTS, CLUSTER_OUTLIERS = 40, 6, 12
+
+
+def _clustered_layout(n: int, h: float, rng):
+    """Host-side plan shared by the numpy and the torch generator: clump sizes / centres / sigmas / scale factors, giants, outliers."""
+    n_cl = int(0.6 * n)
+    wts = rng.uniform(0.5, 1.5, CLUSTER_CLUMPS)
+    sizes = np.floor(wts / wts.sum() * n_cl).astype(np.int64)
+    sizes[0] += n_cl - sizes.sum()
+    centres = rng.uniform(-0.8 * h, 0.8 * h, (CLUSTER_CLUMPS, 3))
+    f = rng.uniform(30.0, 100.0, CLUSTER_CLUMPS)                          # peak density over the background's
+    rho_bg = 0.4 * n / (2.0 * h) ** 3
+    sigma = (sizes / ((2.0 * np.pi) ** 1.5 * f * rho_bg)) ** (1.0 / 3.0)
+    shrink = f ** (-1.0 / 3.0)
+    n_bg = n - n_cl
+    giants = n_cl + rng.choice(n_bg, min(CLUSTER_GIANTS, n_bg), replace=False)        # indices into the background part
+    outl = n_cl + rng.choice(n_bg, min(CLUSTER_OUTLIERS, n_bg), replace=False)
+    far = rng.uniform(20.0, 60.0, (len(outl), 1)) * h * rng.choice([-1.0, 1.0], (len(outl), 3))
+    return dict(sizes=sizes, centres=centres, sigma=sigma, shrink=shrink, giants=giants, outliers=outl, far=far, n_cl=n_cl)
+
+
 def make_cloud(n: int, seed: int = 0, h: float | None = None, sh_degree: int = 3,
                chunk: int = 1 << 20, shape: str = "iso") -> dict:
-    """Return the five level-0 arrays the HEM boundary takes, as float32 numpy arrays.  shape: "iso"  or
-    "aniso" (discs and needles on a smooth orientation field, see above)."""
+    """Return the five level-0 arrays the HEM boundary takes, as float32 numpy arrays.  shape: "iso" (SURVEY 8(d)), "aniso" (discs
+    and needles on a smooth orientation field) or "clustered" (dense clumps, a sparse background, giants and far outliers), see above."""
     if h is None:
         h = half_extent(n)
     F = 3 * ((sh_degree + 1) ** 2 - 1)
@@ -103,6 +134,16 @@ def make_cloud(n: int, seed: int = 0, h: float | None = None, sh_degree: int = 3
         s[:, 2] *= np.where(needle, f, 1.0)
         s = s.astype(np.float32)
         frames = (arng.normal(0, 0.05, (n, 3)), arng.uniform(0, 2 * np.pi, n), needle)
+    elif shape == "clustered":
+        crng = np.random.default_rng(seed + 15485863)       # its own stream
+        lay = _clustered_layout(n, h, crng)
+        which = np.repeat(np.arange(CLUSTER_CLUMPS), lay["sizes"])
+        xyz[:lay["n_cl"]] = (lay["centres"][which] + crng.normal(0, 1, (lay["n_cl"], 3)) * lay["sigma"][which, None]).astype(np.float32)
+        s[:lay["n_cl"]] *= lay["shrink"][which, None].astype(np.float32)
+        s[lay["giants"]] *= np.float32(40.0)
+        xyz[lay["outliers"]] = lay["far"].astype(np.float32)
+        perm = crng.permutation(n)                           # clumps, background, giants and outliers mixed in the input order
+        xyz, s, q = xyz[perm], s[perm], q[perm]
     elif shape != "iso":
         raise ValueError(f"unknown cloud shape {shape!r}")
     cov6 = np.empty((n, 6), dtype=np.float32)
@@ -202,9 +243,22 @@ def make_cloud_torch(n: int, seed: int = 0, device="cuda:0", sh_degree: int = 3,
         sn = torch.where(needle, torch.zeros_like(psi), torch.sin(psi))[:, None]
         R = torch.stack([c * t1 + sn * t2, -sn * t1 + c * t2, nrm], 2).float()       # columns = local x, y, z
         del jit, psi, ph, nrm, e, t1, t2, c, sn
-    elif shape != "iso":
+    elif shape not in ("iso", "clustered"):
         raise ValueError(f"unknown cloud shape {shape!r}")
     else:
+        if shape == "clustered":                # the recipe of make_cloud(shape="clustered"): the plan on the host, the draws on the device
+            lay = _clustered_layout(n, h, np.random.default_rng(seed + 15485863))
+            cg = torch.Generator(device=device).manual_seed(seed + 15485863)
+            t = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt, device=device)
+            which = torch.repeat_interleave(torch.arange(CLUSTER_CLUMPS, device=device), t(lay["sizes"], torch.int64))
+            n_cl = lay["n_cl"]
+            xyz[:n_cl] = t(lay["centres"])[which] + torch.randn((n_cl, 3), device=device, generator=cg) * t(lay["sigma"])[which, None]
+            s[:n_cl] *= t(lay["shrink"])[which, None]
+            s[t(lay["giants"], torch.int64)] *= 40.0
+            xyz[t(lay["outliers"], torch.int64)] = t(lay["far"])
+            perm = torch.randperm(n, device=device, generator=cg)
+            xyz, s, q = xyz[perm].contiguous(), s[perm].contiguous(), q[perm].contiguous()
+            del which, perm
         w, x, y, z = q.unbind(1)
         R = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
                          2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),

@@ -17,7 +17,8 @@ class PointCloudType(IntEnum):
 
 
 def check_point_cloud_type(vertices):
-    props = vertices.dtype.names or ()
+    """``vertices``: the structured vertex array, or just the tuple of its property names (the header is enough)."""
+    props = vertices if isinstance(vertices, (tuple, list)) else (vertices.dtype.names or ())
     if "red" in props:
         return PointCloudType.INPUT
     if "f_dc_0" in props:
@@ -40,7 +41,7 @@ def load_gaussian_pc(pc_path, device_name="cuda:0"):
     from ..models.gaussian_model import GaussianModel
     if not pc_path or not os.path.isfile(pc_path):
         return None, None
-    if check_point_cloud_type(ply_io.read_ply_vertices(pc_path)) is not PointCloudType.GAUSSIAN:
+    if check_point_cloud_type(ply_io.read_ply_property_names(pc_path)) is not PointCloudType.GAUSSIAN:       # the header decides
         return None, None
-    g = GaussianModel(device_name).from_ply(pc_path)
+    g = GaussianModel(device_name).from_ply(pc_path)          # a CUDA device: pinned chunks straight into device SoA (ply_io.load_gaussian_device)
     return convert_gs_to_open3d_pc(g), g

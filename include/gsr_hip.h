@@ -191,7 +191,8 @@ int32_t gsr_hem_get_stats(gsr_hem_ctx* ctx, int64_t* out8);
 /* More counters of the most recent level:  [0] components outside the stage-1 filter's precondition ("irregular": not
  * verified symmetric positive definite with an accurate float32 determinant -- they take the exact gates only)
  * [1] 1 = the one-pass selection ran, 0 = the COUNT + FILL fallback  [2] 1 = a bucket region of the pair partition overflowed (in this level or an
- * earlier one of the context) and the level's sums took the exact partition  [3..7] reserved (0). */
+ * earlier one of the context) and the level's sums took the exact partition  [3] heavy parents (candidates scanned > 16 x the mean: cut
+ * into work items)  [4] their work items  [5..7] reserved (0). */
 int32_t gsr_hem_get_stats_ex(gsr_hem_ctx* ctx, int64_t* out8);
 /* Device time of the phases of the most recent level, in milliseconds (hipEvent pairs on the
  * context's stream):  [0] prep+grid  [1] selection (count+scan+fill)  [2] per-child sums
@@ -333,6 +334,17 @@ int32_t gsr_cov_from_normals(const double* normals, int64_t n, double epsilon, d
 #define GSR_DECOMP_EXACT     1
 int32_t gsr_decompose_cov(const float* cov6, int64_t n, int32_t mode, float* scaling, float* rotation, float* matrix,
                           int32_t on_device, int32_t device, void* stream);
+
+/* 3DGS .ply vertex rows -> the level-0 arrays, on the device (replaces the plyfile -> numpy -> torch.tensor(device=
+ * "cuda") chain of GaussianModel.from_ply, src/models/gaussian_model.py:98-139, and the covariance it builds, :34-38 +
+ * src/utils/general_utils.py:43-80).  rows_dev: n rows of row_bytes bytes as they are in the file (binary little endian), already in
+ * HBM -- the host reads the file in chunks into pinned memory and copies them asynchronously; offsets[15] = byte offsets inside a
+ * row of  x y z  f_dc_0..2  opacity  scale_0..2  rot_0..3  f_rest_0  (float32 properties; f_rest_0 .. f_rest_(3K-1) consecutive);
+ * K = SH-rest coefficients per channel.  Outputs (device, float32): xyz[n*3], color[n*3] (SH DC), sh[n*3K] coefficient-major
+ * (the file is channel-major), opacity[n] (raw), scale[n*3] (log), rot[n*4] (w,x,y,z as stored), cov6[n*6] = R diag(exp(scale))^2 R^T.
+ * Enqueued on `stream`; does not synchronise. */
+int32_t gsr_ply_unpack(const void* rows_dev, int64_t n, int32_t row_bytes, const int32_t* offsets, int32_t K, float* xyz, float* color,
+                       float* sh, float* opacity, float* scale, float* rot, float* cov6, int32_t device, void* stream);
 
 /* RANSAC plane search, the data-parallel part: scores ALL candidate planes of one
  * _fit_single_plane call of the reference (src/utils/plane_fitting_util.py:38-69) in one pass over the points.

@@ -49,10 +49,12 @@ def main():
     t0 = time.perf_counter()
     for path, gl, ol in ((a.first, repo.pc_gaussian_list_first, repo.pc_open3d_list_first),
                          (a.second, repo.pc_gaussian_list_second, repo.pc_open3d_list_second)):
-        gm = GaussianModel("cuda:0").from_ply(path)
+        tm = {}
+        gm = GaussianModel("cuda:0").from_ply(path, timing=tm)        # pinned chunks -> HBM -> device SoA (utils/ply_io.load_gaussian_device)
         gl.append(gm)
         ol.append(convert_gs_to_open3d_pc(gm))
-        print(f"{path}: {len(gm)} splats, SH degree {gm.sh_degree}")
+        print(f"{path}: {len(gm)} splats, SH degree {gm.sh_degree}; file -> device arrays {tm['seconds'] * 1e3:.1f} ms "
+              f"({tm['bytes'] / tm['seconds'] / 1e9:.2f} GB/s of file bytes)")
     t1 = time.perf_counter()
     if not a.voxel:
         if len(a.max_corr) != a.levels + 1 or len(a.iters) != a.levels + 1:

@@ -290,6 +290,29 @@ def test_heavy_parent_work_items_change_nothing(monkeypatch):
                 assert np.array_equal(got[k][f], ref[k][f]), (budget, k, f)
 
 
+@pytest.mark.parametrize("deg", [3, 2, 1, 0])
+def test_small_parent_path_changes_nothing(monkeypatch, deg):
+    """Parents with at most 16 pairs are served four at a time, one per DPP row of the M-step's wavefront (most parents of a
+    surfel-shaped cloud; GSR_HEM_MSTEP_SMALL=0: every parent takes the general path).  The sums are formed in the same order, so two
+    levels are the same BIT FOR BIT -- on the surfel cloud (6 pairs per parent, thousands of orphans), on a sparse isotropic cloud
+    whose parents have 0 .. 16 pairs, and on the dense one (hardly a small parent: the mixed case inside a wave), for every
+    lanes-per-SH-row variant (SH degree 3, 2, 1 and no SH at all)."""
+    from gaussiansplattingregistration_amd import hem, synth
+    clouds = (synth.make_cloud(150000, seed=71, sh_degree=deg, shape="aniso"), synth.make_cloud(60000, seed=72, sh_degree=deg, h=2.6 * synth.half_extent(60000)),
+              synth.make_cloud(80000, seed=73, sh_degree=deg))
+    for ci, c in enumerate(clouds):
+        monkeypatch.setenv("GSR_HEM_MSTEP_SMALL", "0")
+        ref, rst = hem.create_mixture(c, 2, with_state=True)
+        monkeypatch.setenv("GSR_HEM_MSTEP_SMALL", "1")
+        got, st = hem.create_mixture(c, 2, with_state=True)
+        for k in range(2):
+            assert (st[k]["parents"], st[k]["pairs"], st[k]["orphans"], st[k]["dropped"]) == (rst[k]["parents"], rst[k]["pairs"], rst[k]["orphans"], rst[k]["dropped"])
+            for f in ("xyz", "color", "cov6", "sh", "opacity", "weight"):
+                assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (ci, k, f)
+        if ci < 2:
+            assert rst[0]["pairs"] < 17 * rst[0]["parents"]            # these clouds do have small parents
+
+
 def test_read_back_poll_changes_nothing(monkeypatch):
     """The host reads counts back by polling a sequence word the device writes into pinned memory; GSR_HEM_RB_POLL=0 waits with
     hipStreamSynchronize instead.  Same values either way."""

@@ -144,3 +144,54 @@ def test_gaussian_ply_bytes_follow_the_reference_writer(tmp_path):
     back = ply_io.load_gaussian_arrays(path)
     assert back["sh_degree"] == 1 and np.array_equal(back["sh"], rest.reshape(2, 9)) and np.array_equal(back["color"], dc)
     assert np.array_equal(back["xyz"], xyz) and np.array_equal(back["opacity"], op) and np.array_equal(back["rot"], rot)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("deg,n", [(3, 70001), (1, 5000), (0, 333)])
+def test_device_loader_equals_host_reader(tmp_path, deg, n):
+    """N3 on the device: a .ply goes through pinned chunks and ONE scatter kernel per chunk straight into device SoA
+    (ply_io.load_gaussian_device, gsr_ply_unpack) -- the arrays equal the host reader's: the copied properties bit for bit
+    (incl. the channel-major -> coefficient-major transpose of f_rest), the covariance R diag(exp(s))^2 R^T to float32 rounding.
+    Several chunks (chunk_rows far below n) and a ragged last one; the model built from it feeds the HEM boundary in place."""
+    import torch
+    from gaussiansplattingregistration_amd import hem, synth
+    from gaussiansplattingregistration_amd.models.gaussian_model import GaussianModel
+    from gaussiansplattingregistration_amd.utils import ply_io
+    c = synth.make_cloud(n, seed=17, sh_degree=deg)
+    rng = np.random.default_rng(3)
+    scale = rng.normal(-2.5, 0.5, (n, 3)).astype(np.float32)
+    rot = rng.normal(size=(n, 4)).astype(np.float32)                      # NOT normalised on disk, as 3DGS leaves it
+    path = tmp_path / "cloud.ply"
+    ply_io.save_gaussian_ply(path, c["xyz"], c["color"], c["sh"], c["opacity"], scale, rot)
+    host = ply_io.load_gaussian_arrays(path)
+    tm = {}
+    dev = ply_io.load_gaussian_device(path, 0, chunk_rows=4096, timing=tm)
+    assert dev["sh_degree"] == host["sh_degree"] == deg and tm["splats"] == n and tm["bytes"] == n * 4 * (17 + c["sh"].shape[1])
+    for f in ("xyz", "color", "sh", "opacity", "scale", "rot"):
+        assert dev[f].is_cuda and np.array_equal(dev[f].cpu().numpy(), host[f]), f
+    d = np.abs(dev["cov6"].cpu().numpy().astype(np.float64) - host["cov6"])
+    tr = host["cov6"][:, 0] + host["cov6"][:, 3] + host["cov6"][:, 5]
+    assert (d.max(1) <= 2e-6 * tr).all(), float((d.max(1) / tr).max())
+    # the model takes the device path by itself on a CUDA device, and its arrays go into the HEM boundary where they lie
+    g = GaussianModel("cuda:0").from_ply(path)
+    assert g.get_xyz.is_cuda and len(g) == n and g.sh_degree == deg
+    if deg == 3:
+        with hem.HemMixture() as m:
+            m.set_level0(g.get_xyz, g.get_colors, g.get_raw_opacity.flatten(), g.get_covariance(1), g.get_spherical_harmonics, borrow=True)
+            m.run_level()
+            a = m.get_level()
+        with hem.HemMixture() as m:
+            m.set_level0(host["xyz"], host["color"], host["opacity"], dev["cov6"].cpu().numpy(), host["sh"])
+            m.run_level()
+            b = m.get_level()
+        for f in ("xyz", "cov6", "sh"):
+            assert np.array_equal(a[f], b[f]), f
+
+
+def test_device_loader_refuses_what_it_cannot_read(tmp_path):
+    """ASCII files and non-float properties belong to the host reader: the device loader says so instead of guessing."""
+    from gaussiansplattingregistration_amd.utils import ply_io
+    p = tmp_path / "a.ply"
+    p.write_text("ply\nformat ascii 1.0\nelement vertex 1\nproperty float x\nproperty float y\nproperty float z\nend_header\n0 0 0\n")
+    with pytest.raises((ValueError, RuntimeError)):
+        ply_io.load_gaussian_device(p, 0)
