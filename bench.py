@@ -107,23 +107,27 @@ def hem_levels(m, cloud, borrow=True):
     return lv, stats
 
 
-def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None, comm=None, src_global_sizes=None):
+def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None, comm=None, src_global_sizes=None, prepared=None):
     """4-entry coarse-to-fine ICP over the level lists (qt_multiscale_registrator.py:197-236).  sharded = (rank, world)
     splits every level's source over the ranks; src_global_sizes: the source levels ARE this rank's shards already (the pieces of
     a spatially partitioned HEM) and these are their sizes over all ranks.  comm: the library's communicator (RCCL enqueued by
-    the library on the ICP context's stream); without it the torch.distributed trampoline of round 2."""
+    the library on the ICP context's stream); without it the torch.distributed trampoline of round 2.  prepared = one ICP context
+    per entry (coarsest first) whose target index and normals were built already, beside the HEM levels (step_replicas)."""
     from gaussiansplattingregistration_amd import parallel
     T = np.eye(4)
     est = lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Plane, lru.RobustLoss(0))
     out = {"icp_iters": 0, "levels": []}
     for k in range(LEVELS + 1):
         s, t = clouds_src[-(k + 1)], clouds_tgt[-(k + 1)]
-        t.estimate_normals()
+        if prepared is None:
+            t.estimate_normals()
         crit = lru.get_convergence_criteria(1e-6, 1e-6, ITER_VALUES[k])
         if src_global_sizes is not None:
             r = lru.registration_icp(s, t, MAX_CORR[k], T, est, crit, device=device, ctx=ctx, comm=comm, n_source_global=src_global_sizes[-(k + 1)])
         elif sharded:
             r = parallel.registration_icp_sharded(s, t, MAX_CORR[k], T, est, crit, sharded[0], sharded[1], device=device, ctx=ctx, comm=comm)
+        elif prepared is not None:
+            r = lru.registration_icp(s, t, MAX_CORR[k], T, est, crit, device=device, ctx=prepared[k], target_prepared=True)
         else:
             r = lru.registration_icp(s, t, MAX_CORR[k], T, est, crit, device=device, ctx=ctx)
         T = r.transformation
@@ -136,22 +140,87 @@ def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None, comm=
 
 def step_replicas(ctxs, lru, src, tgt, device, sync):
     """One pass over one pair on this rank.  `ctxs` holds the long-lived library contexts (their workspaces are reused
-    from step to step: no allocation in steady state)."""
+    from step to step: no allocation in steady state).
+
+    Default: the two clouds are independent, so their HEM levels run CONCURRENTLY -- two contexts on two
+    streams driven by two host threads (the C ABI releases the GIL) -- and the thread of the target cloud also builds every
+    level's normals and ICP target index as soon as that level exists (the ICP set-up hides behind the
+    latency-bound small levels of the other cloud).  Each cloud's parent flags are those of a fresh reference process (context-
+    local rand() stream at position 0).  `serial` in ctxs: the round-3 order -- cloud 1 then cloud 2 on ONE context and one shared
+    rand() stream (what a single reference process does, qt_gaussian_mixture.py:55,79), the ICP set-up inside the ICP phase."""
+    import threading
+    import torch
+    from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
     out = {"hem_gaussians": 0, "kern": []}
-    clouds = []
     t0 = time.perf_counter()
-    m = ctxs["hem"]
-    m.set_rng("glibc", 1, 0)                       # a fresh reference process: cloud 1 then cloud 2 on one stream
-    for c in (src, tgt):
-        lv, st = hem_levels(m, c)
-        out["hem_gaussians"] += sum(s["n_in"] for s in st)
-        out["kern"] += st
-        clouds.append(lv)
+    if ctxs.get("serial"):
+        clouds = []
+        m = ctxs["hem"]
+        m.set_rng("glibc", 1, 0)                       # a fresh reference process: cloud 1 then cloud 2 on one stream
+        for c in (src, tgt):
+            lv, st = hem_levels(m, c)
+            out["hem_gaussians"] += sum(s["n_in"] for s in st)
+            out["kern"] += st
+            clouds.append(lv)
+        sync()
+        t1 = time.perf_counter()
+        out["hem_s"] = t1 - t0
+        out["level_sizes"] = [len(p) for p in clouds[0]]
+        out.update(coarse_to_fine(lru, ctxs["icp"], clouds[0], clouds[1], device))
+        sync()
+        out["icp_s"] = time.perf_counter() - t1
+        return out
+    res, err = {}, []
+
+    def run_src():
+        try:
+            with torch.cuda.stream(ctxs["stream_a"]):
+                ctxs["hem"].set_rng("glibc", 1, 0)
+                res["src"] = hem_levels(ctxs["hem"], src)
+                ctxs["stream_a"].synchronize()
+        except BaseException as e:  # pragma: no cover
+            err.append(e)
+
+    def run_tgt():
+        try:
+            with torch.cuda.stream(ctxs["stream_b"]):
+                m = ctxs["hem_b"]
+                m.set_rng("glibc", 1, 0)
+
+                def prepare(pc, j):                        # level j of the list is entry LEVELS - j of the coarse-to-fine schedule
+                    pc.estimate_normals()
+                    ctxs["icp_levels"][LEVELS - j].set_target(pc.xyz32, pc.normals, MAX_CORR[LEVELS - j])
+
+                lv = [PointCloud(xyz32=tgt["xyz"], cov6=tgt["cov6"])]
+                m.set_level0(tgt["xyz"], tgt["color"], tgt["opacity"], tgt["cov6"], tgt["sh"], borrow=True)
+                stats = []
+                for j in range(1, LEVELS + 1):
+                    m.run_level()
+                    stats.append(m.stats())
+                    d = m.get_level(as_torch=True)
+                    lv.append(PointCloud(xyz32=d["xyz"], cov6=d["cov6"]))
+                    prepare(lv[j], j)
+                prepare(lv[0], 0)                          # the finest entry last: it is needed last
+                ctxs["stream_b"].synchronize()
+                res["tgt"] = (lv, stats)
+        except BaseException as e:  # pragma: no cover
+            err.append(e)
+
+    th = [threading.Thread(target=run_src), threading.Thread(target=run_tgt)]
+    for x in th:
+        x.start()
+    for x in th:
+        x.join()
+    if err:
+        raise err[0]
     sync()
     t1 = time.perf_counter()
     out["hem_s"] = t1 - t0
-    out["level_sizes"] = [len(p) for p in clouds[0]]
-    out.update(coarse_to_fine(lru, ctxs["icp"], clouds[0], clouds[1], device))
+    for key in ("src", "tgt"):
+        out["hem_gaussians"] += sum(s["n_in"] for s in res[key][1])
+        out["kern"] += res[key][1]
+    out["level_sizes"] = [len(p) for p in res["src"][0]]
+    out.update(coarse_to_fine(lru, None, res["src"][0], res["tgt"][0], device, prepared=ctxs["icp_levels"]))
     sync()
     out["icp_s"] = time.perf_counter() - t1
     return out
@@ -397,6 +466,8 @@ def main():
                          "15 %% needles, covariance condition numbers 1e2 .. 1e5 on a smooth orientation field), or the large-scene recipe "
                          "(shape='clustered': 60 %% of the splats in 40 clumps of 30 .. 100 x the background density, giants, far outliers)")
     ap.add_argument("--no-aniso", action="store_true", help="skip the anisotropic and clustered side measurements of the default run")
+    ap.add_argument("--serial-clouds", action="store_true", help="replica mode: cloud 1 then cloud 2 on ONE context and one shared rand() stream, ICP set-up "
+                    "inside the ICP phase (the round-3 step) instead of the two clouds' levels side by side on two streams")
     ap.add_argument("--no-strong", action="store_true", help="--gpus N > 1, replica mode: skip the strong-scaling children (c5, and c4 at N = 2)")
     ap.add_argument("--strong-splats", type=int, default=5_000_000, help="strong block: splats per GPU of the c5 source (x N) and per cloud of c4")
     ap.add_argument("--strong-steps", type=int, default=2)
@@ -474,7 +545,16 @@ def main():
         src = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in src.items()}
     sync()
 
-    ctxs = {"hem": hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS), "icp": icp_mod.IcpContext(device=device)}
+    if a.mode == "replicas" and not a.serial_clouds:
+        # two HEM contexts on two streams (the two clouds side by side), one ICP context per entry of the coarse-to-fine schedule on
+        # a third (their target indices are built by the target cloud's thread while the other cloud's levels still run)
+        sa_, sb_, si_ = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ctxs = {"stream_a": sa_, "stream_b": sb_, "stream_i": si_,
+                "hem": hem.HemMixture(device=device, rng_mode="glibc", stream=sa_.cuda_stream, **HEM_PARAMS),
+                "hem_b": hem.HemMixture(device=device, rng_mode="glibc", stream=sb_.cuda_stream, **HEM_PARAMS),
+                "icp_levels": [icp_mod.IcpContext(device=device, stream=si_.cuda_stream) for _ in range(LEVELS + 1)]}
+    else:
+        ctxs = {"hem": hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS), "icp": icp_mod.IcpContext(device=device), "serial": True}
     # the data-path collectives of c4 / c5 go through the LIBRARY's communicator: RCCL (nccl backend) enqueued by the library on its
     # own streams, or the callback transport (gloo: test boxes where the ranks share a GPU)
     from gaussiansplattingregistration_amd.comm import Comm
@@ -631,6 +711,11 @@ def main():
                                    (f"2x{n} splats, clouds one per GPU + ICP source split (BASELINE configs[3])" if a.mode == "c4" else
                                     f"one {n}-splat cloud vs a {min(a.target_splats, n)}-splat target, sharded HEM + split ICP (BASELINE configs[4])"),
                        "mode": a.mode, "splat_shapes": a.workload, "pair": {"angle_deg": PAIR_ANGLE_DEG, "shift_h": PAIR_SHIFT_H}, "hem_params": HEM_PARAMS, "iter_values": ITER_VALUES, "max_corr": MAX_CORR, "level_sizes": last["level_sizes"],
+                       "clouds": (("serial: cloud 1 then cloud 2 on one context and ONE shared rand() stream (a single reference process), ICP set-up inside the ICP phase"
+                                   if ctxs.get("serial") else
+                                   "concurrent: the two clouds' HEM levels side by side on two contexts / streams (each cloud = a fresh reference process: rand() "
+                                   "stream at position 0), every target level's normals + ICP index built by the target cloud's thread inside the HEM phase")
+                                  if a.mode == "replicas" else "n/a"),
                        "parallelism": par},
             "icp_iters_per_sec": icp_iters / icp_s,
             "icp_iterations_per_step": last["icp_iters"],

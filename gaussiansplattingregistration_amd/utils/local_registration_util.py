@@ -122,8 +122,12 @@ def get_rejection_loss(rejection_type, k_value, registration_type):
 
 
 def registration_icp(source, target, max_correspondence_distance, init, estimation_method, criteria, device=None,
-                     allreduce=None, n_source_global=None, ctx=None, allreduce_device=None, comm=None):
-    """``o3d.pipelines.registration.registration_icp`` on ``PointCloud`` records (see ``point_cloud.py``)."""
+                     allreduce=None, n_source_global=None, ctx=None, allreduce_device=None, comm=None, target_prepared=False):
+    """``o3d.pipelines.registration.registration_icp`` on ``PointCloud`` records (see ``point_cloud.py``).
+
+    ``target_prepared``: the caller has already given THIS target (points, normals, ``max_correspondence_distance``) to ``ctx`` with
+    ``ctx.set_target`` -- e.g. on a second stream while other work was running (bench.py builds every level's target index beside
+    the HEM levels of the other cloud) -- so the index is not built again."""
     if not (max_correspondence_distance > 0.0):
         raise RuntimeError("[Open3D Error] Invalid max_correspondence_distance.")
     if estimation_method.kind in (_icp.KIND_POINT_TO_PLANE, _icp.KIND_COLORED) and not target.has_normals():
@@ -154,8 +158,12 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
     if own:
         ctx = _icp.IcpContext(device=dev)
     try:
-        ctx.set_target(target.xyz32, target.normals if estimation_method.kind in (_icp.KIND_POINT_TO_PLANE, _icp.KIND_COLORED) else None,
-                       max_correspondence_distance)
+        if target_prepared:
+            if ctx is None or own or getattr(ctx, "n_target", -1) != len(target):
+                raise RuntimeError("registration_icp: target_prepared needs the caller's context with this target set")
+        else:
+            ctx.set_target(target.xyz32, target.normals if estimation_method.kind in (_icp.KIND_POINT_TO_PLANE, _icp.KIND_COLORED) else None,
+                           max_correspondence_distance)
         ctx.set_source(source.xyz32)
         if estimation_method.kind == _icp.KIND_GENERALIZED:
             ctx.set_target_cov(gicp_cov["target"])

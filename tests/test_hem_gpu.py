@@ -313,6 +313,46 @@ def test_small_parent_path_changes_nothing(monkeypatch, deg):
             assert rst[0]["pairs"] < 17 * rst[0]["parents"]            # these clouds do have small parents
 
 
+def test_two_contexts_on_two_threads_equal_each_alone():
+    """bench.py runs the HEM levels of the pair's two clouds side by side: two contexts on two streams, driven by two host threads
+    (the C ABI releases the GIL; a context owns every buffer it touches, the error message is thread-local).  Each cloud's levels
+    are bit for bit what its context computes alone."""
+    import threading
+    import torch
+    from gaussiansplattingregistration_amd import hem, synth
+    clouds = [synth.make_cloud(120000, seed=81, sh_degree=3), synth.make_cloud(90000, seed=82, sh_degree=1, shape="aniso")]
+    alone = [hem.create_mixture(c, 3, with_state=True) for c in clouds]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    ctx = [hem.HemMixture(stream=s.cuda_stream) for s in streams]
+    for rep in range(3):
+        got, err = [None, None], []
+
+        def work(k):
+            try:
+                with torch.cuda.stream(streams[k]):
+                    m, c = ctx[k], clouds[k]
+                    m.set_rng("glibc", 1, 0)
+                    m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+                    lv = []
+                    for _ in range(3):
+                        m.run_level()
+                        lv.append(m.get_level(with_state=True))
+                    got[k] = lv
+            except BaseException as e:      # noqa
+                err.append(e)
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        assert not err, err
+        for k in range(2):
+            for lvl in range(3):
+                for f in ("xyz", "color", "cov6", "opacity", "sh", "weight", "is_parent"):
+                    assert np.array_equal(got[k][lvl][f], alone[k][0][lvl][f]), (rep, k, lvl, f)
+    for m in ctx:
+        m.close()
+
+
 def test_read_back_poll_changes_nothing(monkeypatch):
     """The host reads counts back by polling a sequence word the device writes into pinned memory; GSR_HEM_RB_POLL=0 waits with
     hipStreamSynchronize instead.  Same values either way."""
