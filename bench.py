@@ -119,7 +119,7 @@ def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None, comm=
     out = {"icp_iters": 0, "levels": []}
     for k in range(LEVELS + 1):
         s, t = clouds_src[-(k + 1)], clouds_tgt[-(k + 1)]
-        if prepared is None:
+        if not t.has_normals():
             t.estimate_normals()
         crit = lru.get_convergence_criteria(1e-6, 1e-6, ITER_VALUES[k])
         if src_global_sizes is not None:
@@ -142,12 +142,13 @@ def step_replicas(ctxs, lru, src, tgt, device, sync):
     """One pass over one pair on this rank.  `ctxs` holds the long-lived library contexts (their workspaces are reused
     from step to step: no allocation in steady state).
 
-    Default: the two clouds are independent, so their HEM levels run CONCURRENTLY -- two contexts on two
-    streams driven by two host threads (the C ABI releases the GIL) -- and the thread of the target cloud also builds every
-    level's normals and ICP target index as soon as that level exists (the ICP set-up hides behind the
-    latency-bound small levels of the other cloud).  Each cloud's parent flags are those of a fresh reference process (context-
-    local rand() stream at position 0).  `serial` in ctxs: the round-3 order -- cloud 1 then cloud 2 on ONE context and one shared
-    rand() stream (what a single reference process does, qt_gaussian_mixture.py:55,79), the ICP set-up inside the ICP phase."""
+    Default (`serial` in ctxs): cloud 1 then cloud 2 on ONE context and one shared rand() stream (what a single reference process does,
+    qt_gaussian_mixture.py:55,79), then the ICP.  --concurrent-clouds: the two clouds are independent, so their HEM
+    levels run CONCURRENTLY -- two contexts on two
+    streams driven by two host threads (the C ABI releases the GIL) -- and the thread of the target cloud also computes every
+    level's normals as soon as that level exists (the ICP set-up hides behind the
+    latency-bound small levels of the other cloud; the index BUILDS stay in the ICP phase, see main()).  Each cloud's parent flags are those of a fresh reference process (context-
+    local rand() stream at position 0).  Measured and not made the default (see --concurrent-clouds in main())."""
     import threading
     import torch
     from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
@@ -187,9 +188,8 @@ def step_replicas(ctxs, lru, src, tgt, device, sync):
                 m = ctxs["hem_b"]
                 m.set_rng("glibc", 1, 0)
 
-                def prepare(pc, j):                        # level j of the list is entry LEVELS - j of the coarse-to-fine schedule
+                def prepare(pc, j):                        # the level's normals (what the ICP phase would compute first), on this thread's stream
                     pc.estimate_normals()
-                    ctxs["icp_levels"][LEVELS - j].set_target(pc.xyz32, pc.normals, MAX_CORR[LEVELS - j])
 
                 lv = [PointCloud(xyz32=tgt["xyz"], cov6=tgt["cov6"])]
                 m.set_level0(tgt["xyz"], tgt["color"], tgt["opacity"], tgt["cov6"], tgt["sh"], borrow=True)
@@ -220,7 +220,7 @@ def step_replicas(ctxs, lru, src, tgt, device, sync):
         out["hem_gaussians"] += sum(s["n_in"] for s in res[key][1])
         out["kern"] += res[key][1]
     out["level_sizes"] = [len(p) for p in res["src"][0]]
-    out.update(coarse_to_fine(lru, None, res["src"][0], res["tgt"][0], device, prepared=ctxs["icp_levels"]))
+    out.update(coarse_to_fine(lru, ctxs["icp"], res["src"][0], res["tgt"][0], device))
     sync()
     out["icp_s"] = time.perf_counter() - t1
     return out
@@ -466,8 +466,11 @@ def main():
                          "15 %% needles, covariance condition numbers 1e2 .. 1e5 on a smooth orientation field), or the large-scene recipe "
                          "(shape='clustered': 60 %% of the splats in 40 clumps of 30 .. 100 x the background density, giants, far outliers)")
     ap.add_argument("--no-aniso", action="store_true", help="skip the anisotropic and clustered side measurements of the default run")
-    ap.add_argument("--serial-clouds", action="store_true", help="replica mode: cloud 1 then cloud 2 on ONE context and one shared rand() stream, ICP set-up "
-                    "inside the ICP phase (the round-3 step) instead of the two clouds' levels side by side on two streams")
+    ap.add_argument("--concurrent-clouds", action="store_true", help="replica mode: the two clouds' HEM levels side by side on two contexts / streams / host "
+                    "threads (each cloud's rand() stream at position 0) and the target levels' normals computed in that phase, instead of cloud 1 then "
+                    "cloud 2 on ONE context and one shared rand() stream (the default: what a single reference process does).  Measured (profiles/r04c_*, "
+                    "r04d_*): the HEM levels alone overlap to 27.0 instead of 28.9 ms in a bare harness, but the full step does not gain (37.7 - 43 ms "
+                    "against 39.0): the two clouds' big kernels each fill the chip, and two Python threads add jitter")
     ap.add_argument("--no-strong", action="store_true", help="--gpus N > 1, replica mode: skip the strong-scaling children (c5, and c4 at N = 2)")
     ap.add_argument("--strong-splats", type=int, default=5_000_000, help="strong block: splats per GPU of the c5 source (x N) and per cloud of c4")
     ap.add_argument("--strong-steps", type=int, default=2)
@@ -545,14 +548,16 @@ def main():
         src = {k: (v.contiguous() if isinstance(v, torch.Tensor) else v) for k, v in src.items()}
     sync()
 
-    if a.mode == "replicas" and not a.serial_clouds:
-        # two HEM contexts on two streams (the two clouds side by side), one ICP context per entry of the coarse-to-fine schedule on
-        # a third (their target indices are built by the target cloud's thread while the other cloud's levels still run)
-        sa_, sb_, si_ = torch.cuda.Stream(dev), torch.cuda.Stream(dev), torch.cuda.Stream(dev)
-        ctxs = {"stream_a": sa_, "stream_b": sb_, "stream_i": si_,
+    if a.mode == "replicas" and a.concurrent_clouds:
+        # two HEM contexts on two streams (the two clouds side by side); the target cloud's thread also computes every level's normals.
+        # (Measured and not kept, profiles/r04c_*: one ICP context per schedule entry with its target index built in that thread too --
+        # the step fell from 38.97 to 37.7 ms, but the ICP iterations on the early-built indices ran 6-20 % slower and the HEM phase, with
+        # the index builds inside it, rose from 29.4 to 32.5 ms: the headline rate fell by 9 %.)
+        sa_, sb_ = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        ctxs = {"stream_a": sa_, "stream_b": sb_,
                 "hem": hem.HemMixture(device=device, rng_mode="glibc", stream=sa_.cuda_stream, **HEM_PARAMS),
                 "hem_b": hem.HemMixture(device=device, rng_mode="glibc", stream=sb_.cuda_stream, **HEM_PARAMS),
-                "icp_levels": [icp_mod.IcpContext(device=device, stream=si_.cuda_stream) for _ in range(LEVELS + 1)]}
+                "icp": icp_mod.IcpContext(device=device)}
     else:
         ctxs = {"hem": hem.HemMixture(device=device, rng_mode="glibc", **HEM_PARAMS), "icp": icp_mod.IcpContext(device=device), "serial": True}
     # the data-path collectives of c4 / c5 go through the LIBRARY's communicator: RCCL (nccl backend) enqueued by the library on its
@@ -714,7 +719,7 @@ def main():
                        "clouds": (("serial: cloud 1 then cloud 2 on one context and ONE shared rand() stream (a single reference process), ICP set-up inside the ICP phase"
                                    if ctxs.get("serial") else
                                    "concurrent: the two clouds' HEM levels side by side on two contexts / streams (each cloud = a fresh reference process: rand() "
-                                   "stream at position 0), every target level's normals + ICP index built by the target cloud's thread inside the HEM phase")
+                                   "stream at position 0), every target level's normals computed by the target cloud's thread inside the HEM phase")
                                   if a.mode == "replicas" else "n/a"),
                        "parallelism": par},
             "icp_iters_per_sec": icp_iters / icp_s,

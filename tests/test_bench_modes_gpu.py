@@ -39,16 +39,16 @@ def test_default_line_small():
     assert ro["bound"] == "hbm" and 0 < ro["frac"] < 1 and abs(ro["frac"] - ro["achieved"] / ro["peak"]) < 1e-12
     assert ro["level1"]["n_in"] == 200000 and ro["icp_finest"]["ns"] == 200000
     assert d["icp_result"]["T_err_vs_ground_truth_F"] < 1e-3
-    assert d["config"]["clouds"].startswith("concurrent")
+    assert d["config"]["clouds"].startswith("serial")
 
 
-def test_serial_clouds_line_small():
-    """--serial-clouds: the round-3 step (one context, one shared rand() stream, the ICP set-up inside the ICP phase)."""
+def test_concurrent_clouds_line_small():
+    """--concurrent-clouds: the two clouds' HEM levels on two contexts / streams / host threads, normals of the target levels beside them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--splats", "150000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-aniso",
-                        "--serial-clouds"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+                        "--concurrent-clouds"], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _line(r.stdout)
-    assert d["config"]["clouds"].startswith("serial") and d["icp_result"]["T_err_vs_ground_truth_F"] < 1e-3
+    assert d["config"]["clouds"].startswith("concurrent") and d["icp_result"]["T_err_vs_ground_truth_F"] < 1e-3
 
 
 def test_mode_c4_two_ranks():
