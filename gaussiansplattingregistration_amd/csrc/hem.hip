@@ -692,6 +692,19 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
     return v;
 }
 
+// GSR_SELECT_PROFILE (variant builds only, scripts/select_profile.py): where a selection wave spends its clock -- s_memtime deltas
+// of the phases, summed over all waves with one atomic per phase and parent
+#ifdef GSR_SELECT_PROFILE
+__device__ unsigned long long g_sel_prof[16];
+#define SEL_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
+#define SEL_PROF_ADD(slot, t0, lane) do { if ((lane) == 0) atomicAdd(&g_sel_prof[slot], __builtin_amdgcn_s_memtime() - (t0)); } while (0)
+#define SEL_PROF_CNT(slot, v, lane) do { if ((lane) == 0) atomicAdd(&g_sel_prof[slot], (unsigned long long)(v)); } while (0)
+#else
+#define SEL_PROF_T(var)
+#define SEL_PROF_ADD(slot, t0, lane)
+#define SEL_PROF_CNT(slot, v, lane)
+#endif
+
 // Third-stage queue (per wave, in LDS): the accepted pairs wait here until 64 of them fill a wavefront, so that
 // the likelihood (two expf, two sqrtf, two IEEE divisions) runs on full waves instead of the ~26 % of the lanes
 // that pass the KL gate.
@@ -749,6 +762,8 @@ __device__ __forceinline__ bool kl_gate_rejects(float s2, float det_c, float det
 template <int MODE>
 __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, const unsigned* q, int qh,
                                               unsigned& count, int64_t& base, Q3& q3) {
+    SEL_PROF_T(tp2);
+    SEL_PROF_CNT(8, 1, lane); SEL_PROF_CNT(9, cnt, lane);
     bool acc = false;
     int j = 0;
     float d2 = 0.0f, cdiff = 0.0f, op = 0.0f, det_c = 0.0f;
@@ -778,7 +793,7 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     const unsigned long long m = __ballot(acc);
     const int na = __popcll(m);
     count += (unsigned)na;
-    if (MODE == SEL_COUNT || na == 0) return;
+    if (MODE == SEL_COUNT || na == 0) { SEL_PROF_ADD(2, tp2, lane); return; }
     if (acc) {
         const int k = mbcnt64(m, q3.h + q3.n) & (SEL_Q3CAP - 1);
         q3.j[k] = (unsigned)j; q3.d2[k] = d2; q3.cd[k] = cdiff; q3.op[k] = op; q3.det[k] = det_c;
@@ -787,6 +802,7 @@ __device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentR
     __builtin_amdgcn_wave_barrier();
     if (q3.n >= 64) select_stage3(a, pr, lane, 64, q3, base);
     __builtin_amdgcn_wave_barrier();
+    SEL_PROF_ADD(2, tp2, lane);
 }
 
 // Row clipping by the parent's filter ellipsoid E = { d : d^T M d <= T_clip } (struct EllClip, filled by make_filter, which
@@ -995,7 +1011,10 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
     const int nrows = __builtin_amdgcn_readfirstlane(ny * nz);
     const float Ra2 = Ra * Ra;
     const bool white = !IRR && pr.white != 0.0f;                // wave-uniform
+    SEL_PROF_CNT(10, nrows, lane);
     for (int rb = 0; rb < nrows; rb += 64) {
+        SEL_PROF_T(tpr);
+        SEL_PROF_CNT(11, 1, lane);
         const int r = rb + lane;
         int s = 0, len = 0;
         if (r < nrows) select_row_span<IRR>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
@@ -1018,6 +1037,8 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
         const int below = mbcnt64(nz_m, 0);
         const int dst = len > 0 ? below : nrb + (lane - below);
         const int delta = __builtin_amdgcn_ds_permute(dst << 2, s - pre);
+        SEL_PROF_ADD(1, tpr, lane);
+        SEL_PROF_CNT(12, nrb, lane); SEL_PROF_CNT(13, total, lane);
         for (int seg0 = b_lo; seg0 < b_hi; seg0 += SEL_MCAP) {
             const int rel = pre - seg0;
             const bool mine = len > 0 && rel >= 0 && rel < SEL_MCAP;
@@ -1026,6 +1047,7 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
             __builtin_amdgcn_wave_barrier();
             const int seg_end = b_hi < seg0 + SEL_MCAP ? b_hi : seg0 + SEL_MCAP;
             for (int t0 = seg0; t0 < seg_end; t0 += 64 * SEL_U) {
+                SEL_PROF_CNT(14, 1, lane);
                 float4 ca[SEL_U];
                 int jj[SEL_U];
                 int left[SEL_U];                                              // active lanes of each chunk (uniform)
@@ -1090,6 +1112,7 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
 template <int MODE>
 __device__ __forceinline__ unsigned select_item(const SelectArgs& a, const GridParams& g, int p, unsigned lo, unsigned hi, int64_t base, int lane,
                                                 unsigned* q, unsigned long long* bits, Q3 q3) {
+    SEL_PROF_T(tp0);
     const ParentRec pr = a.prec[p];     // uniform address: scalar loads, the record lives in SGPRs
     // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs once per parent)
     float vc[11];
@@ -1112,8 +1135,12 @@ __device__ __forceinline__ unsigned select_item(const SelectArgs& a, const GridP
         select_scan<MODE, false>(a, g, pr, vc, lane, bits, q, qh, qn, count, base, q3, cum, lo, hi);
         if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, vc, lane, bits, q, qh, qn, count, base, q3, cum, lo, hi);
         if (qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base, q3);
+        SEL_PROF_T(tp3);
         if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, pr, lane, q3.n, q3, base);
+        SEL_PROF_ADD(3, tp3, lane);
     }
+    SEL_PROF_ADD(0, tp0, lane);
+    SEL_PROF_CNT(7, 1, lane); SEL_PROF_CNT(15, count, lane);
     return count;
 }
 
@@ -1764,12 +1791,20 @@ struct MstepArgs {
     const float* pair_wl;
     int P, F;
     int small;                 // serve parents of <= MSTEP_SMALL pairs four at a time (GSR_HEM_MSTEP_SMALL=0: the general path for all)
+    int split;                 // 1: parents of more than MSTEP_SEG pairs are left to k_mstep<.., HEAVY = true> (one wave per segment)
+    const unsigned* hcount;    // device: [0] heavy parents, [1] their segments (work items)
+    const uint4* hlist;        // heavy parent -> {slot, first item, segments}
+    const uint2* hitems;       // item -> {slot, segment}
+    float* hscratch;           // item -> 16 + RSH floats: the segment's 14 moment sums, its SH sums
     float *o_xyz, *o_color, *o_cov6, *o_opacity, *o_weight, *o_sh;
 };
 __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __restrict__ porder, const unsigned* __restrict__ plist,
                                                        const int64_t* __restrict__ poff, const unsigned* __restrict__ pcnt,
                                                        const unsigned* __restrict__ order, const int* __restrict__ prank_in,
-                                                       const float4* __restrict__ A, int own_lo, int own_hi, MstepHeader* __restrict__ hdr) {
+                                                       const float4* __restrict__ A, int own_lo, int own_hi, MstepHeader* __restrict__ hdr,
+                                                       unsigned* __restrict__ max_cnt, unsigned seg, unsigned* __restrict__ hcount,
+                                                       uint4* __restrict__ hlist, uint2* __restrict__ hitems) {
+    unsigned mx = 0u;
     for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < P; s += gridDim.x * blockDim.x) {
         const int p = porder ? (int)porder[s] : s;
         const int js = (int)plist[p];
@@ -1779,17 +1814,154 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
         h.oslot = (p >= own_lo && p < own_hi) ? prank_in[order[js]] : -1;
         h.px = a.x; h.py = a.y; h.pz = a.z;
         hdr[s] = h;
+        if (h.oslot >= 0) mx = h.cnt > mx ? h.cnt : mx;
+        // a HEAVY parent (more than one segment of `seg` pairs): its segments become work items of k_mstep<.., HEAVY> (hlist / hitems
+        // cannot overflow: a heavy parent holds more than seg of the level's pairs and ceil(cnt / seg) <= 2 cnt / seg)
+        if (hcount && h.oslot >= 0 && h.cnt > seg) {
+            const unsigned nseg = (h.cnt + seg - 1u) / seg;
+            const unsigned hi = atomicAdd(&hcount[0], 1u);
+            const unsigned base = atomicAdd(&hcount[1], nseg);
+            hlist[hi] = make_uint4((unsigned)s, base, nseg, 0u);
+            for (unsigned k = 0; k < nseg; ++k) hitems[base + k] = make_uint2((unsigned)s, k);
+        }
     }
+    // the largest pair count of a parent of this level (a statistic: gsr_hem_get_stats_ex [5])
+    for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mx, o); mx = t > mx ? t : mx; }
+    if ((threadIdx.x & 63) == 0 && mx > 0u) atomicMax(max_cnt, mx);
 }
 
 #define MSTEP_CHUNK 256
 #define MSTEP_SMALL 16        // parents with at most this many pairs are served four at a time, one per DPP row
+#define MSTEP_SEG 2048        // pairs per SEGMENT of a parent's sums (a multiple of MSTEP_CHUNK); see mstep_segment
 #define MSTEP_NV 3            // float4 per lane and SH row
 #define MSTEP_K 4             // parents per wavefront
 #define MSTEP_U 3             // rounds of SH row loads in flight (each: MSTEP_NV float4 per lane, 64/G children)
 
-// G = lanes per SH row (power of two, G * MSTEP_NV float4 >= RSH / 4); G == 0: no SH at all
-template <int G, int WPB>
+// One SEGMENT of a parent's sums: the pairs [off, off + cnt) (cnt <= MSTEP_SEG), from zero.  Leaves the 14 moment sums in s_mom and
+// the SH sums, folded over the lane classes, in acc (every lane of a class holds the class's total).
+// How a parent's sums are DEFINED (all paths agree bit for bit, test_mstep_heavy_parent_split_changes_nothing): its pairs are cut
+// into segments of MSTEP_SEG; inside a segment the sums run as they always did -- chunks of MSTEP_CHUNK pairs, lane l of a chunk
+// taking pairs l, l + 64, ..., the chunk's lane sums folded by class_sum<1> and added to the segment's running sums in chunk order,
+// the SH products accumulated per lane group along the segment by fused multiply-adds and folded once at its end -- and the
+// segments' totals are added in segment order.  A parent of at most MSTEP_SEG pairs (all but the giants) is one segment: nothing
+// changed for it.  The giants' segments are independent, which is the point: a parent with 5 * 10^4 pairs (found on the surfel
+// cloud) kept ONE wave busy for 2.5 ms, the whole M-step of that level.
+template <int G>
+__device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int gl, int grp, const int (&qi)[MSTEP_NV], float* s_w, unsigned* s_j,
+                                              float4* s_acc, float* s_mom, float4* s_rec, long long off, unsigned cnt, const f3 pm,
+                                              float4 (&acc)[MSTEP_NV]) {
+    constexpr int GG = G > 0 ? G : 1;
+    constexpr int CPR = 64 / GG;                                // children per round
+    if (lane < 16) s_mom[lane] = 0.0f;
+    // SH sums: local to a chunk of pairs (they occupy no registers during part 1); a segment with more than MSTEP_CHUNK
+    // pairs (rare) carries its per-lane partial sums from chunk to chunk in LDS
+#pragma unroll
+    for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const bool multi = cnt > MSTEP_CHUNK;
+    for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
+        const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
+        // part 1
+        {
+            float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
+            float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
+#pragma nounroll
+            for (unsigned k0 = 0; k0 < cn; k0 += 64) {
+                const unsigned k = k0 + lane;
+                const bool live = k < cn;
+                const unsigned j = a.pair_child[off + c0 + (live ? k : cn - 1)];
+                const float wl = a.pair_wl[off + c0 + (live ? k : cn - 1)];
+                // the 64-byte records of the batch's 64 children, fetched by FOUR lanes per record (a wave instruction then
+                // touches 16 cache lines instead of 64: one piece of 64 different records per instruction kept the CU's
+                // address pipeline busy four times as long) and handed to the pair's lane through LDS
+                s_j[k0 + lane] = j;
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = (lane >> 2) + 16 * u;
+                    const unsigned jr = s_j[k0 + r];
+                    s_rec[r * 5 + (lane & 3)] = a.geo[4 * (int64_t)jr + (lane & 3)];
+                }
+                __builtin_amdgcn_wave_barrier();
+                const float4 ca = s_rec[lane * 5], cb = s_rec[lane * 5 + 1], cc = s_rec[lane * 5 + 2], cd = s_rec[lane * 5 + 3];
+                __builtin_amdgcn_wave_barrier();
+                const float sl = cd.w;                     // sumLw_i: k_bucket_sum stored it in the record (in place of det)
+                float w = 0.0f;
+                if (live && sl != 0.0f) {                  // sumLw == 0: skipped (mixture.cpp:190)
+                    const float r_is = wl / sl;            // mixture.cpp:196
+                    w = r_is * cd.z;                       // * child.weight (:197)
+                    const f3 cm = {ca.x, ca.y, ca.z};
+                    const f3 d = sub3(cm, pm);
+                    w_s += w;
+                    smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
+                    scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
+                    v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
+                    v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
+                    so += w * cd.y;
+                }
+                if (live) s_w[k] = w;
+            }
+            // the chunk's 14 sums over the lanes, then out of the registers (part 2 needs them for its row loads)
+            w_s = class_sum<1>(w_s);
+            smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
+            scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
+            v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
+            v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
+            so = class_sum<1>(so);
+            if (lane == 0) {
+                s_mom[0] += w_s; s_mom[1] += smx; s_mom[2] += smy; s_mom[3] += smz; s_mom[4] += scx; s_mom[5] += scy; s_mom[6] += scz;
+                s_mom[7] += v00; s_mom[8] += v01; s_mom[9] += v02; s_mom[10] += v11; s_mom[11] += v12; s_mom[12] += v22; s_mom[13] += so;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // part 2: children in pair order, MSTEP_U rounds of row loads in flight; a skipped child has w = 0 (its row is
+        // loaded all the same: no branch per load)
+        if (G > 0) {
+            if (multi && c0 > 0) {
+#pragma unroll
+                for (int v = 0; v < MSTEP_NV; ++v) acc[v] = s_acc[v * 64 + lane];
+            }
+            for (unsigned k0 = 0; k0 < cn; k0 += CPR * MSTEP_U) {
+                float4 rowv[MSTEP_U][MSTEP_NV];
+                float wv_[MSTEP_U];
+#pragma unroll
+                for (int u = 0; u < MSTEP_U; ++u) {
+                    const unsigned k = k0 + CPR * u + grp;
+                    const unsigned kc = k < cn ? k : cn - 1;    // unconditional LDS reads and loads
+                    const unsigned j = s_j[kc];
+                    wv_[u] = k < cn ? s_w[kc] : 0.0f;
+                    const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
+#pragma unroll
+                    for (int v = 0; v < MSTEP_NV; ++v) rowv[u][v] = row[qi[v]];
+                }
+#pragma unroll
+                for (int u = 0; u < MSTEP_U; ++u) {
+#pragma unroll
+                    for (int v = 0; v < MSTEP_NV; ++v) {
+                        acc[v].x = __builtin_fmaf(rowv[u][v].x, wv_[u], acc[v].x); acc[v].y = __builtin_fmaf(rowv[u][v].y, wv_[u], acc[v].y);
+                        acc[v].z = __builtin_fmaf(rowv[u][v].z, wv_[u], acc[v].z); acc[v].w = __builtin_fmaf(rowv[u][v].w, wv_[u], acc[v].w);
+                    }
+                }
+            }
+            if (multi && c0 + MSTEP_CHUNK < cnt) {
+#pragma unroll
+                for (int v = 0; v < MSTEP_NV; ++v) s_acc[v * 64 + lane] = acc[v];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (G > 0) {
+#pragma unroll
+        for (int v = 0; v < MSTEP_NV; ++v) {
+            acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
+            acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
+        }
+    }
+}
+
+// G = lanes per SH row (power of two, G * MSTEP_NV float4 >= RSH / 4); G == 0: no SH at all.  HEAVY: the work items of the heavy
+// parents (k_mstep_headers) instead of the parents themselves -- one wave per segment, the segment's sums out to hscratch;
+// k_mstep_heavy_finish adds a parent's segments in order and writes its row
+template <int G, int WPB, bool HEAVY = false>
 __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ float s_w_[WPB][MSTEP_CHUNK];
     __shared__ unsigned s_j_[WPB][MSTEP_CHUNK];
@@ -1797,7 +1969,6 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ float s_mom_[WPB][16];                           // the 14 moment sums of the parent
     __shared__ float4 s_rec_[WPB][64 * 5];                      // part 1: the batch's geometry records on their way to the pairs' lanes (80-byte stride)
     constexpr int GG = G > 0 ? G : 1;
-    constexpr int CPR = 64 / GG;                                // children per round
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* s_w = s_w_[wv];
     unsigned* s_j = s_j_[wv];
@@ -1806,6 +1977,32 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     float4* s_rec = s_rec_[wv];
     float* s_out = reinterpret_cast<float*>(s_acc);             // at the end of a parent: its SH row on the way out
     const int gl = lane & (GG - 1), grp = lane / GG;
+    const int nq = a.RSH >> 2;                                  // float4 per SH row
+    int qi[MSTEP_NV];                                           // float4 slots of this lane (slots beyond the row: re-read slot 0, discarded)
+#pragma unroll
+    for (int v = 0; v < MSTEP_NV; ++v) qi[v] = gl + GG * v < nq ? gl + GG * v : 0;
+    if constexpr (HEAVY) {
+        const unsigned nitems = a.hcount[1];
+        const int RS = 16 + a.RSH;
+        for (unsigned item = blockIdx.x * WPB + wv; item < nitems; item += gridDim.x * WPB) {
+            const uint2 it = a.hitems[item];
+            const MstepHeader h = a.hdr[it.x];
+            const f3 pm = {h.px, h.py, h.pz};
+            const unsigned first = it.y * MSTEP_SEG;
+            const unsigned cn = h.cnt - first < MSTEP_SEG ? h.cnt - first : MSTEP_SEG;
+            float4 acc[MSTEP_NV];
+            mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off + first, cn, pm, acc);
+            float* rec = a.hscratch + (int64_t)item * RS;
+            if (lane < 14) rec[lane] = s_mom[lane];
+            if (G > 0 && grp == 0) {
+#pragma unroll
+                for (int v = 0; v < MSTEP_NV; ++v)
+                    if (gl + GG * v < nq) reinterpret_cast<float4*>(rec + 16)[gl + GG * v] = acc[v];
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        return;
+    }
     constexpr int KB = MSTEP_K * WPB;                           // parents per workgroup: consecutive slots, neighbours in space
     const int nblk = (a.P + KB - 1) / KB;
     const int hbk = a.nheavy ? (((*a.nheavy + KB - 1) / KB + 7) & ~7) : 0;
@@ -1814,10 +2011,6 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     const int s0 = bid * KB + wv * MSTEP_K;
     if (s0 >= a.P) return;
     const int ns = a.P - s0 < MSTEP_K ? a.P - s0 : MSTEP_K;     // parents of this wave
-    const int nq = a.RSH >> 2;                                  // float4 per SH row
-    int qi[MSTEP_NV];                                           // float4 slots of this lane (slots beyond the row: re-read slot 0, discarded)
-#pragma unroll
-    for (int v = 0; v < MSTEP_NV; ++v) qi[v] = gl + GG * v < nq ? gl + GG * v : 0;
 
     // ---- small parents (at most MSTEP_SMALL = 16 pairs: most parents of a surfel-shaped cloud, 6.5 pairs on average) ----------------
     // The wave's small parents are served TOGETHER, parent q in DPP row q (lanes 16 q .. 16 q + 15), instead of one after the other
@@ -1980,103 +2173,29 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         if (h.oslot < 0) continue;
         const f3 pm = {h.px, h.py, h.pz};
         const unsigned cnt = h.cnt;
-        if (lane < 16) s_mom[lane] = 0.0f;
-        // SH sums: local to a chunk of pairs (they occupy no registers during part 1); a parent with more than MSTEP_CHUNK
-        // pairs (rare) carries its per-lane partial sums from chunk to chunk in LDS
+        if (a.split && cnt > MSTEP_SEG) continue;               // a heavy parent: its segments are work items of k_mstep<.., HEAVY>
         float4 acc[MSTEP_NV];
+        mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off, cnt < MSTEP_SEG ? cnt : MSTEP_SEG, pm, acc);
+        if (cnt > MSTEP_SEG) {
+            // (GSR_HEM_MSTEP_SPLIT=0) the further segments in this wave, their totals added in segment order -- what
+            // k_mstep_heavy_finish does with the segments other waves computed
+            float4 tsh[MSTEP_NV];
 #pragma unroll
-        for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        const bool multi = cnt > MSTEP_CHUNK;
-
-        for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
-            const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
-            // part 1
-            {
-                float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
-                float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
-#pragma nounroll
-                for (unsigned k0 = 0; k0 < cn; k0 += 64) {
-                    const unsigned k = k0 + lane;
-                    const bool live = k < cn;
-                    const unsigned j = a.pair_child[h.off + c0 + (live ? k : cn - 1)];
-                    const float wl = a.pair_wl[h.off + c0 + (live ? k : cn - 1)];
-                    // the 64-byte records of the batch's 64 children, fetched by FOUR lanes per record (a wave instruction then
-                    // touches 16 cache lines instead of 64: one piece of 64 different records per instruction kept the CU's
-                    // address pipeline busy four times as long) and handed to the pair's lane through LDS
-                    s_j[k0 + lane] = j;
-                    __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const int r = (lane >> 2) + 16 * u;
-                        const unsigned jr = s_j[k0 + r];
-                        s_rec[r * 5 + (lane & 3)] = a.geo[4 * (int64_t)jr + (lane & 3)];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    const float4 ca = s_rec[lane * 5], cb = s_rec[lane * 5 + 1], cc = s_rec[lane * 5 + 2], cd = s_rec[lane * 5 + 3];
-                    __builtin_amdgcn_wave_barrier();
-                    const float sl = cd.w;                     // sumLw_i: k_bucket_sum stored it in the record (in place of det)
-                    float w = 0.0f;
-                    if (live && sl != 0.0f) {                  // sumLw == 0: skipped (mixture.cpp:190)
-                        const float r_is = wl / sl;            // mixture.cpp:196
-                        w = r_is * cd.z;                       // * child.weight (:197)
-                        const f3 cm = {ca.x, ca.y, ca.z};
-                        const f3 d = sub3(cm, pm);
-                        w_s += w;
-                        smx += cm.x * w; smy += cm.y * w; smz += cm.z * w;
-                        scx += cc.z * w; scy += cc.w * w; scz += cd.x * w;
-                        v00 += (cb.x + d.x * d.x) * w; v01 += (cb.y + d.x * d.y) * w; v02 += (cb.z + d.x * d.z) * w;
-                        v11 += (cb.w + d.y * d.y) * w; v12 += (cc.x + d.y * d.z) * w; v22 += (cc.y + d.z * d.z) * w;
-                        so += w * cd.y;
-                    }
-                    if (live) s_w[k] = w;
-                }
-                // the chunk's 14 sums over the lanes, then out of the registers (part 2 needs them for its row loads)
-                w_s = class_sum<1>(w_s);
-                smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
-                scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
-                v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
-                v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
-                so = class_sum<1>(so);
-                if (lane == 0) {
-                    s_mom[0] += w_s; s_mom[1] += smx; s_mom[2] += smy; s_mom[3] += smz; s_mom[4] += scx; s_mom[5] += scy; s_mom[6] += scz;
-                    s_mom[7] += v00; s_mom[8] += v01; s_mom[9] += v02; s_mom[10] += v11; s_mom[11] += v12; s_mom[12] += v22; s_mom[13] += so;
-                }
-            }
+            for (int v = 0; v < MSTEP_NV; ++v) tsh[v] = acc[v];
+            float tm = lane < 14 ? s_mom[lane] : 0.0f;          // lane t carries moment t across the segments
             __builtin_amdgcn_wave_barrier();
-            // part 2: children in pair order, MSTEP_U rounds of row loads in flight; a skipped child has w = 0 (its row is
-            // loaded all the same: no branch per load)
-            if (G > 0) {
-                if (multi && c0 > 0) {
+            for (unsigned first = MSTEP_SEG; first < cnt; first += MSTEP_SEG) {
+                mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off + first, cnt - first < MSTEP_SEG ? cnt - first : MSTEP_SEG, pm, acc);
+                if (lane < 14) tm = tm + s_mom[lane];
 #pragma unroll
-                    for (int v = 0; v < MSTEP_NV; ++v) acc[v] = s_acc[v * 64 + lane];
+                for (int v = 0; v < MSTEP_NV; ++v) {
+                    tsh[v].x = tsh[v].x + acc[v].x; tsh[v].y = tsh[v].y + acc[v].y; tsh[v].z = tsh[v].z + acc[v].z; tsh[v].w = tsh[v].w + acc[v].w;
                 }
-                for (unsigned k0 = 0; k0 < cn; k0 += CPR * MSTEP_U) {
-                    float4 rowv[MSTEP_U][MSTEP_NV];
-                    float wv_[MSTEP_U];
-#pragma unroll
-                    for (int u = 0; u < MSTEP_U; ++u) {
-                        const unsigned k = k0 + CPR * u + grp;
-                        const unsigned kc = k < cn ? k : cn - 1;    // unconditional LDS reads and loads
-                        const unsigned j = s_j[kc];
-                        wv_[u] = k < cn ? s_w[kc] : 0.0f;
-                        const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
-#pragma unroll
-                        for (int v = 0; v < MSTEP_NV; ++v) rowv[u][v] = row[qi[v]];
-                    }
-#pragma unroll
-                    for (int u = 0; u < MSTEP_U; ++u) {
-#pragma unroll
-                        for (int v = 0; v < MSTEP_NV; ++v) {
-                            acc[v].x = __builtin_fmaf(rowv[u][v].x, wv_[u], acc[v].x); acc[v].y = __builtin_fmaf(rowv[u][v].y, wv_[u], acc[v].y);
-                            acc[v].z = __builtin_fmaf(rowv[u][v].z, wv_[u], acc[v].z); acc[v].w = __builtin_fmaf(rowv[u][v].w, wv_[u], acc[v].w);
-                        }
-                    }
-                }
-                if (multi && c0 + MSTEP_CHUNK < cnt) {
-#pragma unroll
-                    for (int v = 0; v < MSTEP_NV; ++v) s_acc[v * 64 + lane] = acc[v];
-                }
+                __builtin_amdgcn_wave_barrier();
             }
+            if (lane < 14) s_mom[lane] = tm;
+#pragma unroll
+            for (int v = 0; v < MSTEP_NV; ++v) acc[v] = tsh[v];
             __builtin_amdgcn_wave_barrier();
         }
         const float w_s = s_mom[0];
@@ -2102,11 +2221,6 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
             if (lane < 14) *dst = val;
         }
         if (G > 0) {
-#pragma unroll
-            for (int v = 0; v < MSTEP_NV; ++v) {
-                acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
-                acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
-            }
             // the row leaves through LDS: F consecutive floats, one coalesced store per 64
             __builtin_amdgcn_wave_barrier();
             if (grp == 0) {
@@ -2120,6 +2234,49 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
             __builtin_amdgcn_wave_barrier();
             for (int f = lane; f < a.F; f += 64) a.o_sh[slot * a.F + f] = s_out[f];
         }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// A heavy parent's row: its segments' sums (k_mstep<.., HEAVY>) added in segment order, then the output expressions of k_mstep.
+// One wave per heavy parent; element e of a segment record: 0..13 the moment sums, 16 + f the SH sums.
+__global__ __launch_bounds__(64) void k_mstep_heavy_finish(MstepArgs a) {
+    __shared__ float s_t[16 + 4 * MSTEP_NV * 32 + 16];         // RSH <= 4 * MSTEP_NV * 32 floats
+    const int lane = threadIdx.x;
+    const unsigned nheavy = a.hcount[0];
+    const int RS = 16 + a.RSH;
+    for (unsigned hi = blockIdx.x; hi < nheavy; hi += gridDim.x) {
+        const uint4 e = a.hlist[hi];
+        const MstepHeader h = a.hdr[e.x];
+        const float* rec = a.hscratch + (int64_t)e.y * RS;
+        for (int t = lane; t < RS; t += 64) {
+            float tot = rec[t];
+            for (unsigned k = 1; k < e.z; ++k) tot = tot + rec[(int64_t)k * RS + t];
+            s_t[t] = tot;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const float* s_mom = s_t;
+        const f3 pm = {h.px, h.py, h.pz};
+        const float w_s = s_mom[0];
+        const float inv_w = 1.0f / w_s;                        // mixture.cpp:209
+        const int64_t slot = h.oslot;
+        {
+            const float mx = s_mom[1] * inv_w, my = s_mom[2] * inv_w, mz = s_mom[3] * inv_w;
+            const float dx = mx - pm.x, dy = my - pm.y, dz = mz - pm.z;
+            float val = w_s;
+            float* dst = a.o_weight + slot;
+            if (lane < 3) { val = lane == 0 ? mx : (lane == 1 ? my : mz); dst = a.o_xyz + 3 * slot + lane; }
+            else if (lane < 6) { val = s_mom[4 + (lane - 3)] * inv_w; dst = a.o_color + 3 * slot + (lane - 3); }
+            else if (lane < 12) {
+                const int t = lane - 6;
+                const float da = t < 3 ? dx : (t < 5 ? dy : dz);
+                const float db = t == 0 ? dx : (t == 1 || t == 3 ? dy : dz);
+                val = s_mom[7 + t] * inv_w - da * db;
+                dst = a.o_cov6 + 6 * slot + t;
+            } else if (lane == 12) { val = inv_w * s_mom[13]; dst = a.o_opacity + slot; }
+            if (lane < 14) *dst = val;
+        }
+        for (int f = lane; f < a.F; f += 64) a.o_sh[slot * a.F + f] = s_t[16 + f] * inv_w;
         __builtin_amdgcn_wave_barrier();
     }
 }
@@ -2782,6 +2939,9 @@ struct gsr_hem_ctx {
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec;
+    bool mstep_split = true;        // GSR_HEM_MSTEP_SPLIT=0: a parent of more than MSTEP_SEG pairs keeps its one wave (test knob: nothing may change)
+    DevBuf mh_list, mh_items, mh_scratch;
+    hipEvent_t ev_mfork = nullptr, ev_mjoin = nullptr;          // the heavy parents' segments run on the second stream beside k_mstep
     bool mstep_small = true;        // GSR_HEM_MSTEP_SMALL=0: no four-at-a-time path for the parents of <= 16 pairs (test knob: nothing may change)
     bool use_ell = true;            // GSR_HEM_ELL=0: no ellipsoid row clipping (test knob: the pair set must not change)
     int shard_rank = 0, shard_world = 1;      // work-sharded level: parents split over ranks, data replicated
@@ -3017,6 +3177,8 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sh_fork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_sh_join, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_mfork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_mjoin, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->evp[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "second stream: %s", hipGetErrorString(e)); }
     }
@@ -3031,6 +3193,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SUMLW")) c->sum_bucket = strcmp(s, "sort") != 0;
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SMALL")) c->mstep_small = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_MSTEP_SPLIT")) c->mstep_split = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
     if (const char* s = getenv("GSR_HEM_SH_GRID")) c->sh_grid = atoi(s);
@@ -3066,7 +3229,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
                      &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
-                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2};
+                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -3078,6 +3241,8 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     if (c->ev_sh_fork) (void)hipEventDestroy(c->ev_sh_fork);
     if (c->ev_sh_join) (void)hipEventDestroy(c->ev_sh_join);
     if (c->ev_halo) (void)hipEventDestroy(c->ev_halo);
+    if (c->ev_mfork) (void)hipEventDestroy(c->ev_mfork);
+    if (c->ev_mjoin) (void)hipEventDestroy(c->ev_mjoin);
     for (int i = 0; i < 4; ++i) if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->aux2) (void)hipStreamDestroy(c->aux2);
@@ -3939,16 +4104,46 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.xcd = mporder ? 1 : 0;
         ma.nheavy = mporder ? c->counters.as<int>() + 8 : nullptr;
         GSR_TRY(c->mhdr.reserve(Pm * sizeof(MstepHeader)));
+        // heavy parents (more than MSTEP_SEG pairs): their segments are work items of a second launch (mstep_segment)
+        const bool msplit = c->mstep_split && M > MSTEP_SEG;
+        if (msplit) {
+            const size_t cap_heavy = (size_t)(M / MSTEP_SEG) + 2, cap_items = 2 * (size_t)(M / MSTEP_SEG) + 4;
+            GSR_TRY(c->mh_list.reserve(cap_heavy * sizeof(uint4))); GSR_TRY(c->mh_items.reserve(cap_items * sizeof(uint2)));
+            GSR_TRY(c->mh_scratch.reserve(cap_items * (size_t)(16 + RSH) * 4));
+        }
+        unsigned* hcount = c->counters.as<unsigned>();           // [0] heavy parents, [1] their segments (cleared with the level's counters)
         hipLaunchKernelGGL(k_mstep_headers, dim3(stride_grid(P)), blk, 0, st, P, mporder, c->plist.as<unsigned>(), seg,
                            c->pcnt.as<unsigned>(), c->order.as<unsigned>(), c->prank_in.as<int>(), c->A.as<float4>(), own_lo, own_hi,
-                           c->mhdr.as<MstepHeader>());
+                           c->mhdr.as<MstepHeader>(), c->counters.as<unsigned>() + 15, (unsigned)MSTEP_SEG, msplit ? hcount : (unsigned*)nullptr,
+                           c->mh_list.as<uint4>(), c->mh_items.as<uint2>());
         ma.hdr = c->mhdr.as<MstepHeader>();
+        ma.split = msplit ? 1 : 0;
+        ma.hcount = hcount; ma.hlist = c->mh_list.as<uint4>(); ma.hitems = c->mh_items.as<uint2>(); ma.hscratch = c->mh_scratch.as<float>();
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
         // one wavefront per workgroup: consecutive parents on one CU share no cache lines in time (2 / 4 / 8 waves per workgroup
         // were measured 1 / 10 / 24 % slower)
         const int nq = RSH >> 2;                                // float4 per SH row; a lane covers MSTEP_NV of them
-#define GSR_LAUNCH_MSTEP(G) hipLaunchKernelGGL((k_mstep<G, 1>), dim3(8 * ceil_div(ceil_div(P, MSTEP_K), 8)), dim3(64), 0, st, ma);
+        // the heavy parents' segments: 2 048 waves pull them from the item table, on the second stream beside k_mstep when there is
+        // one (the finish kernel adds a parent's segments in order); joined behind k_mstep
+        hipStream_t hst = st;
+        if (msplit && c->aux) {
+            GSR_HIP(hipEventRecord(c->ev_mfork, st)); GSR_HIP(hipStreamWaitEvent(c->aux, c->ev_mfork, 0));
+            hst = c->aux;
+        }
+#define GSR_LAUNCH_MSTEP(G)                                                                                              \
+    {                                                                                                                    \
+        if (msplit && hst != st) {                                                                                       \
+            hipLaunchKernelGGL((k_mstep<G, 1, true>), dim3(2048), dim3(64), 0, hst, ma);                                 \
+            hipLaunchKernelGGL(k_mstep_heavy_finish, dim3(256), dim3(64), 0, hst, ma);                                   \
+            GSR_HIP(hipEventRecord(c->ev_mjoin, hst));                                                                   \
+        }                                                                                                                \
+        hipLaunchKernelGGL((k_mstep<G, 1>), dim3(8 * ceil_div(ceil_div(P, MSTEP_K), 8)), dim3(64), 0, st, ma);           \
+        if (msplit && hst == st) {                                                                                       \
+            hipLaunchKernelGGL((k_mstep<G, 1, true>), dim3(2048), dim3(64), 0, st, ma);                                  \
+            hipLaunchKernelGGL(k_mstep_heavy_finish, dim3(256), dim3(64), 0, st, ma);                                    \
+        }                                                                                                                \
+    }
         GSR_HIP(hipEventRecord(c->evm[0], st));
         if (nq == 0) { GSR_LAUNCH_MSTEP(0) }
         else if (nq <= 1 * MSTEP_NV) { GSR_LAUNCH_MSTEP(1) }
@@ -3958,6 +4153,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         else if (nq <= 16 * MSTEP_NV) { GSR_LAUNCH_MSTEP(16) }
         else { GSR_LAUNCH_MSTEP(32) }      // F <= 384
 #undef GSR_LAUNCH_MSTEP
+        if (msplit && hst != st) GSR_HIP(hipStreamWaitEvent(st, c->ev_mjoin, 0));
         GSR_HIP(hipEventRecord(c->evm[1], st));
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
@@ -4051,12 +4247,13 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         int k_last = 0, k_flag = 0;
         {
             Collect q;
-            q.n = 2;
-            q.src[0] = c->kpos.as<int>() + (n_pre - 1); q.src[1] = c->keep.as<int>() + (n_pre - 1);
-            q.bytes[0] = q.bytes[1] = 4;
+            q.n = 3;
+            q.src[0] = c->kpos.as<int>() + (n_pre - 1); q.src[1] = c->keep.as<int>() + (n_pre - 1); q.src[2] = c->counters.as<int>() + 15;
+            q.bytes[0] = q.bytes[1] = q.bytes[2] = 4;
             unsigned long long w[8];
             GSR_TRY(read_back(c, q, w));
             k_last = (int)w[0]; k_flag = (int)w[1];
+            if (P > 0) c->stats_ex[5] = (int64_t)(unsigned)w[2];
         }
         const int64_t n_keep = (int64_t)k_last + k_flag;
         dropped = n_pre - n_keep;
@@ -4139,6 +4336,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (n_dropped) *n_dropped = dropped;
     return GSR_OK;
 }
+
+#ifdef GSR_SELECT_PROFILE
+int32_t gsr_debug_select_profile(unsigned long long* out16, int32_t reset) {
+    if (out16) { if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sel_prof), sizeof(g_sel_prof)) != hipSuccess) return GSR_E_HIP; }
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), z, sizeof(z)) != hipSuccess) return GSR_E_HIP; }
+    return GSR_OK;
+}
+#endif
 
 int32_t gsr_debug_logf(const float* x, int64_t n, float* out, int32_t device) {
     if (n < 0 || (n > 0 && (!x || !out))) return fail(GSR_E_INVALID, "gsr_debug_logf: bad argument");

@@ -192,7 +192,7 @@ int32_t gsr_hem_get_stats(gsr_hem_ctx* ctx, int64_t* out8);
  * verified symmetric positive definite with an accurate float32 determinant -- they take the exact gates only)
  * [1] 1 = the one-pass selection ran, 0 = the COUNT + FILL fallback  [2] 1 = a bucket region of the pair partition overflowed (in this level or an
  * earlier one of the context) and the level's sums took the exact partition  [3] heavy parents (candidates scanned > 16 x the mean: cut
- * into work items)  [4] their work items  [5..7] reserved (0). */
+ * into work items)  [4] their work items  [5] the largest number of accepted pairs of one parent  [6..7] reserved (0). */
 int32_t gsr_hem_get_stats_ex(gsr_hem_ctx* ctx, int64_t* out8);
 /* Device time of the phases of the most recent level, in milliseconds (hipEvent pairs on the
  * context's stream):  [0] prep+grid  [1] selection (count+scan+fill)  [2] per-child sums
