@@ -3462,6 +3462,244 @@ int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out8) {
         }                                                                                           \
     } while (0)
 
+namespace {
+
+// Host-side state of ONE spatially partitioned level (gsr_hem_set_comm + gsr_hem_set_level0_part): everything
+// the plain level does not have -- who sends which rows to whom, the exchanges along those lists, the global output ranks.  The
+// level itself (gsr_hem_run_level) reads as the single-GPU level with five calls into this for `part`.
+struct PartLevel {
+    gsr_hem_ctx* c;
+    hipStream_t st;
+    int W = 1, me = 0;
+    int64_t n_own = 0;                          // owned components = the first n_own local indices; the ghosts follow
+    // halo bookkeeping: rows sent to / received from every rank, and their offsets in the concatenated buffers
+    int64_t send_cnt[8] = {0}, recv_cnt[8] = {0}, soff[8] = {0}, roff[8] = {0}, n_sent = 0, n_ghost = 0;
+    bool halo_sh_pending = false;               // the ghosts' SH rows are still on their way (third stream)
+
+    // Ownership follows the parents, so a rank CAN run out of components on a later level: that is data, not a local error.  The
+    // ranks agree on the level's preconditions before its first data collective (one all-reduce of a status word), so that
+    // every rank returns the error instead of one returning and its peers waiting in the next collective for ever.
+    int32_t agree_on_preconditions(int64_t n) {
+        GSR_TRY(c->pcounts.reserve(64));
+        const unsigned status = n == 0 ? 1u : 0u;
+        GSR_HIP(hipMemcpyAsync(c->pcounts.p, &status, 4, hipMemcpyHostToDevice, st));
+        GSR_HIP(hipStreamSynchronize(st));               // (status lives on this stack frame)
+        GSR_TRY(gsr_comm_allreduce(c->comm, c->pcounts.p, 1, GSR_DT_U32, GSR_OP_MAX, (void*)st));
+        unsigned agreed = 0;
+        GSR_HIP(hipMemcpyAsync(&agreed, c->pcounts.p, 4, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        if (agreed) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank of the partitioned level owns no component (reported on every rank; use fewer ranks)");
+        return GSR_OK;
+    }
+
+    // one typed exchange along the halo's lists: to_owner = the ghosts' values go to their owners (roles of the lists reversed)
+    int32_t exchange(const void* sendbuf, void* recvbuf, size_t elem, bool to_owner, hipStream_t xs = nullptr) {
+        int64_t so[8], sb[8], ro[8], rb[8];
+        for (int q = 0; q < W; ++q) {
+            so[q] = (to_owner ? roff[q] : soff[q]) * (int64_t)elem; sb[q] = (to_owner ? recv_cnt[q] : send_cnt[q]) * (int64_t)elem;
+            ro[q] = (to_owner ? soff[q] : roff[q]) * (int64_t)elem; rb[q] = (to_owner ? send_cnt[q] : recv_cnt[q]) * (int64_t)elem;
+            if (q != me) c->part_stats[3] += rb[q];
+        }
+        return gsr_comm_exchange(c->comm, sendbuf, so, sb, recvbuf, ro, rb, (void*)(xs ? xs : st));
+    }
+
+    // The halo: which cells do my parents' search regions touch -> the masks of all ranks -> my components they need -> rows.
+    // On return n = owned + ghosts, and c->rec_loc / c->gid_loc hold the working set's records and global indices.
+    int32_t halo(const GridParams& gp, Level& L, int F, int64_t& n) {
+        const dim3 blk(256), grd(stride_grid(n_own));
+        // ---- halo: which cells do my parents' search spheres touch -> masks of all ranks -> my components they need -> rows
+        const int64_t mwords = ((int64_t)gp.ncells + 31) / 32 + 1;
+        GSR_TRY(c->cmask.reserve((size_t)W * 2 * mwords * 4));
+        unsigned* my_mask = c->cmask.as<unsigned>() + (int64_t)me * 2 * mwords;      // [cells wanted of regular components | of irregular ones]
+        GSR_HIP(hipMemsetAsync(my_mask, 0, (size_t)2 * mwords * 4, st));
+        hipLaunchKernelGGL(k_mark_cells, dim3(stride_grid(n_own * 16)), blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), c->delta,
+                           c->delta * c->delta * 0.5f, c->use_ell ? 1 : 0, my_mask, my_mask + mwords);
+        GSR_TRY(gsr_comm_allgather(c->comm, my_mask, c->cmask.p, 2 * mwords * 4, (void*)st));
+        GSR_TRY(c->dflag.reserve((size_t)W * n_own * 4)); GSR_TRY(c->dpos.reserve((size_t)W * n_own * 4));
+        hipLaunchKernelGGL(k_dest_flags, grd, blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), W, me, mwords, c->cmask.as<unsigned>(),
+                           c->dflag.as<int>());
+        GSR_TRY(c->pcounts.reserve(64)); GSR_TRY(c->pmatrix.reserve(64 * 8));
+        GSR_HIP(hipMemsetAsync(c->pcounts.p, 0, 64, st));
+        for (int q = 0; q < W; ++q) {
+            if (q == me) continue;
+            GSR_TRY(exclusive_scan<int>(c, c->dflag.as<int>() + (int64_t)q * n_own, c->dpos.as<int>() + (int64_t)q * n_own, n_own));
+            hipLaunchKernelGGL(k_last_total, dim3(1), dim3(1), 0, st, c->dpos.as<int>() + (int64_t)q * n_own + (n_own - 1),
+                               c->dflag.as<int>() + (int64_t)q * n_own + (n_own - 1), c->pcounts.as<long long>() + q);
+        }
+        GSR_TRY(gsr_comm_allgather(c->comm, c->pcounts.p, c->pmatrix.p, 64, (void*)st));
+        long long mat[64];
+        GSR_HIP(hipMemcpyAsync(mat, c->pmatrix.p, (size_t)W * 64, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        for (int q = 0; q < W; ++q) { send_cnt[q] = q == me ? 0 : mat[me * 8 + q]; recv_cnt[q] = q == me ? 0 : mat[q * 8 + me]; }
+        for (int q = 0; q < W; ++q) { soff[q] = n_sent; n_sent += send_cnt[q]; roff[q] = n_ghost; n_ghost += recv_cnt[q]; }
+        // TWO exchanges along the same lists: the 72-byte rows {record, global index, index at the owner} -- what the grid, the sort
+        // and the selection need -- on the level's stream, and the SH rows (4 F bytes: 71 % of a ghost at SH degree 3), which only the
+        // M-step reads, on the third stream beside the rest of the grid phase and the selection, received straight into ghost_sh
+        constexpr int RW = 16 + PART_ROW_EXTRA;
+        const size_t Fm = (size_t)(F > 0 ? F : 1);
+        GSR_TRY(c->rows_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * RW * 4)); GSR_TRY(c->rows_recv.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * RW * 4));
+        GSR_TRY(c->sh_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * Fm * 4));
+        GSR_TRY(c->sent_idx.reserve((size_t)(n_sent > 0 ? n_sent : 1) * 4));
+        GSR_TRY(c->ghost_sh.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * Fm * 4)); GSR_TRY(c->ghost_src.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * 4));
+        for (int q = 0; q < W; ++q)
+            if (send_cnt[q] > 0)
+                hipLaunchKernelGGL(k_pack_rows, dim3(stride_grid(n_own * 64)), blk, 0, st, n_own, F, c->dflag.as<int>() + (int64_t)q * n_own,
+                                   c->dpos.as<int>() + (int64_t)q * n_own, c->rec.as<float4>(), L.sh.as<float>(), c->gid.as<unsigned>(),
+                                   c->rows_send.as<float>() + soff[q] * RW, c->sh_send.as<float>() + soff[q] * F, c->sent_idx.as<unsigned>() + soff[q]);
+        GSR_HIP(hipEventRecord(c->evp[0], st));
+        GSR_TRY(exchange(c->rows_send.p, c->rows_recv.p, (size_t)RW * 4, false));
+        GSR_HIP(hipEventRecord(c->evp[1], st));
+        if (F > 0) {        // every rank issues it (the same order of communicator calls everywhere), whatever its own counts
+            GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
+            GSR_HIP(hipEventRecord(c->evp[2], c->aux2));
+            GSR_TRY(exchange(c->sh_send.p, c->ghost_sh.p, (size_t)F * 4, false, c->aux2));
+            GSR_HIP(hipEventRecord(c->evp[3], c->aux2));
+            GSR_HIP(hipEventRecord(c->ev_halo, c->aux2));
+            halo_sh_pending = true;
+        }
+        c->part_stats[0] = n_ghost; c->part_stats[1] = n_sent; c->part_stats[2] = c->part_stats[3]; c->part_stats[3] = 0;
+        n = n_own + n_ghost;
+        if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld local components", (long long)n);
+        GSR_TRY(c->rec_loc.reserve((size_t)n * 64)); GSR_TRY(c->gid_loc.reserve((size_t)n * 4));
+        GSR_HIP(hipMemcpyAsync(c->rec_loc.p, c->rec.p, (size_t)n_own * 64, hipMemcpyDeviceToDevice, st));
+        GSR_HIP(hipMemcpyAsync(c->gid_loc.p, c->gid.p, (size_t)n_own * 4, hipMemcpyDeviceToDevice, st));
+        if (n_ghost > 0)
+            hipLaunchKernelGGL(k_unpack_rows, dim3(stride_grid(n_ghost * 16)), blk, 0, st, n_ghost, n_own, c->rows_recv.as<float>(), c->rec_loc.as<float4>(),
+                               c->gid_loc.as<unsigned>(), c->ghost_src.as<unsigned>());
+        c->stats[6] = n_own;
+        return GSR_OK;
+    }
+
+    // k_bucket_sum's three steps with the ghosts' partial results sent to their owners in between -- integers only (maximum,
+    // 64-bit fixed-point sums), then the owners' finished float32 sums back to the ghosts
+    int32_t sums(int64_t n, int P, int64_t M, const int64_t* seg, const unsigned* pc, const float* pw, int nbuckets, int bshift, int* overflow_flag) {
+        const dim3 blk(256), grd(stride_grid(n));
+        // the communicator's calls in ONE order on the device too: the exchanges below (this stream) behind the SH rows' (third stream)
+        if (halo_sh_pending) { GSR_HIP(hipStreamWaitEvent(st, c->ev_halo, 0)); halo_sh_pending = false; }
+        if (nbuckets > SUM_MAX_BUCKETS) return fail(GSR_E_INVALID, "gsr_hem_run_level: level too large for the partitioned sums");
+        GSR_TRY(c->gmax.reserve((size_t)n * 4)); GSR_TRY(c->gacc.reserve((size_t)n * 8)); GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
+        unsigned cap = 0;
+        for (double factor = 8.0;; factor *= 2.0) {            // bucket regions of fixed capacity; doubled until nothing overflows
+            const double capd = (double)M / (double)nbuckets * factor + 4096.0;
+            if (capd > 4.0e9) return fail(GSR_E_INVALID, "gsr_hem_run_level: pair partition capacity");
+            cap = (unsigned)capd;
+            GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * 4)); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
+            GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
+            GSR_HIP(hipMemsetAsync(overflow_flag, 0, 4, st));
+            if (M > 0 && P > 0)
+                launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
+                                 c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
+            GSR_HIP(hipGetLastError());
+            Collect q;
+            q.n = 1; q.src[0] = overflow_flag; q.bytes[0] = 4;
+            unsigned long long w[8];
+            GSR_TRY(read_back(c, q, w));
+            if (w[0] == 0ull) break;
+        }
+        const dim3 bblk(bshift >= 10 ? 1024 : 256);
+        const dim3 gs(stride_grid(n_sent > 0 ? n_sent : 1)), gg(stride_grid(n_ghost > 0 ? n_ghost : 1));
+        GSR_TRY(c->xsend.reserve((size_t)(n_sent + n_ghost + 1) * 8)); GSR_TRY(c->xrecv.reserve((size_t)(n_sent + n_ghost + 1) * 8));
+        // 1. the largest |wL| of every child: local, then the ghosts' maxima to their owners, then the owners' result back
+        hipLaunchKernelGGL(k_part_max, dim3(nbuckets), bblk, (size_t)4 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(),
+                           c->spair_wl.as<float>(), c->gmax.as<unsigned>());
+        GSR_HIP(hipGetLastError());
+        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_gather<unsigned>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->gmax.as<unsigned>(), c->xsend.as<unsigned>());
+        GSR_TRY(exchange(c->xsend.p, c->xrecv.p, 4, true));
+        if (n_sent > 0) hipLaunchKernelGGL(k_sent_apply_max, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->xrecv.as<unsigned>(), c->gmax.as<unsigned>());
+        if (n_sent > 0) hipLaunchKernelGGL(k_sent_gather<unsigned>, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->gmax.as<unsigned>(), c->xsend.as<unsigned>());
+        GSR_TRY(exchange(c->xsend.p, c->xrecv.p, 4, false));
+        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_set<unsigned>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->xrecv.as<unsigned>(), c->gmax.as<unsigned>());
+        // 2. the fixed-point sums on that scale: local, then the ghosts' partial sums to their owners (integer addition)
+        hipLaunchKernelGGL(k_part_acc, dim3(nbuckets), bblk, (size_t)12 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(),
+                           c->spair_wl.as<float>(), c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>());
+        GSR_HIP(hipGetLastError());
+        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_gather<unsigned long long>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->gacc.as<unsigned long long>(), c->xsend.as<unsigned long long>());
+        GSR_TRY(exchange(c->xsend.p, c->xrecv.p, 8, true));
+        if (n_sent > 0) hipLaunchKernelGGL(k_sent_apply_acc, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->xrecv.as<unsigned long long>(),
+                                           c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>());
+        // 3. the float32 sums (correct for the owned components), the owners' values back to the ghosts, orphans among the owned
+        hipLaunchKernelGGL(k_part_finish, grd, blk, 0, st, n, c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>(), c->sumLw.as<float>());
+        if (n_sent > 0) hipLaunchKernelGGL(k_sent_gather<float>, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->sumLw.as<float>(), c->xsend.as<float>());
+        GSR_TRY(exchange(c->xsend.p, c->xrecv.p, 4, false));
+        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_set<float>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->xrecv.as<float>(), c->sumLw.as<float>());
+        hipLaunchKernelGGL(k_part_orphans, grd, blk, 0, st, n, n_own, c->order.as<unsigned>(), c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
+        return GSR_OK;
+    }
+
+    // The rows' GLOBAL ranks (a parent's = parents below it in the level's global order, an orphan's = all parents + orphans below
+    // it): bit maps of the parents' and orphans' global indices, summed over the ranks (disjoint bits)
+    int32_t global_ranks(int P, int64_t n_pre, int64_t& P_glob, int64_t& O_glob) {
+        const dim3 blk(256);
+        const int64_t words = (c->n_global + 31) / 32 + 1;
+        GSR_TRY(c->gbits.reserve((size_t)2 * words * 4)); GSR_TRY(c->wcnt.reserve((size_t)2 * words * 4)); GSR_TRY(c->wpre.reserve((size_t)2 * words * 4));
+        GSR_TRY(c->grank.reserve((size_t)2 * n_own * 4)); GSR_TRY(c->gid_next.reserve((size_t)(n_pre > 0 ? n_pre : 1) * 4));     // [ranks as parents | as orphans]
+        GSR_HIP(hipMemsetAsync(c->gbits.p, 0, (size_t)2 * words * 4, st));
+        const dim3 go(stride_grid(n_own));
+        hipLaunchKernelGGL(k_bits_set, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->pflag_in.as<int>(), c->gbits.as<unsigned>());
+        hipLaunchKernelGGL(k_bits_set, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->oflag_in.as<int>(), c->gbits.as<unsigned>() + words);
+        GSR_TRY(gsr_comm_allreduce(c->comm, c->gbits.p, 2 * words, GSR_DT_U32, GSR_OP_SUM, (void*)st));
+        hipLaunchKernelGGL(k_bits_popc, dim3(stride_grid(2 * words)), blk, 0, st, 2 * words, c->gbits.as<unsigned>(), c->wcnt.as<int>());
+        GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>(), c->wpre.as<int>(), words));
+        GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>() + words, c->wpre.as<int>() + words, words));
+        {
+            Collect q;
+            q.n = 4;
+            q.src[0] = c->wpre.as<int>() + (words - 1); q.src[1] = c->wcnt.as<int>() + (words - 1);
+            q.src[2] = c->wpre.as<int>() + (2 * words - 1); q.src[3] = c->wcnt.as<int>() + (2 * words - 1);
+            for (int i = 0; i < 4; ++i) q.bytes[i] = 4;
+            unsigned long long w[8];
+            GSR_TRY(read_back(c, q, w));
+            P_glob = (int64_t)w[0] + (int64_t)w[1]; O_glob = (int64_t)w[2] + (int64_t)w[3];
+        }
+        hipLaunchKernelGGL(k_bits_rank, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->pflag_in.as<int>(), c->gbits.as<unsigned>(), c->wpre.as<int>(), 0u,
+                           c->grank.as<unsigned>());
+        hipLaunchKernelGGL(k_bits_rank, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->oflag_in.as<int>(), c->gbits.as<unsigned>() + words, c->wpre.as<int>() + words,
+                           (unsigned)P_glob, c->grank.as<unsigned>() + n_own);
+        hipLaunchKernelGGL(k_part_new_gid, go, blk, 0, st, n_own, P, c->pflag_in.as<int>(), c->prank_in.as<int>(), c->oflag_in.as<int>(), c->orank_in.as<int>(),
+                           c->grank.as<unsigned>(), c->grank.as<unsigned>() + n_own, c->gid_next.as<unsigned>());
+        c->part_stats[4] = P_glob; c->part_stats[5] = O_glob;
+        return GSR_OK;
+    }
+
+    // Erased rows leave the GLOBAL numbering too: how many over all ranks, and (rarely more than none) which
+    int32_t drop_erased(Level& O, int64_t n_pre, int64_t n_pre_glob, int64_t dropped, int64_t& n_glob_next) {
+        const dim3 blk(256);
+        // erased rows leave the GLOBAL numbering too: how many over all ranks, and (rarely more than none) which
+        GSR_TRY(c->pcounts.reserve(64));
+        const long long dl = dropped;
+        GSR_HIP(hipMemcpyAsync(c->pcounts.p, &dl, 8, hipMemcpyHostToDevice, st));
+        GSR_HIP(hipStreamSynchronize(st));                      // (dl lives on this stack frame)
+        GSR_TRY(gsr_comm_allreduce(c->comm, c->pcounts.p, 1, GSR_DT_U64, GSR_OP_SUM, (void*)st));
+        long long dg = 0;
+        GSR_HIP(hipMemcpyAsync(&dg, c->pcounts.p, 8, hipMemcpyDeviceToHost, st));
+        GSR_HIP(hipStreamSynchronize(st));
+        if (dg > 0) {
+            const int64_t words = (n_pre_glob + 31) / 32 + 1;
+            GSR_TRY(c->gbits.reserve((size_t)words * 4)); GSR_TRY(c->wcnt.reserve((size_t)words * 4)); GSR_TRY(c->wpre.reserve((size_t)words * 4));
+            GSR_HIP(hipMemsetAsync(c->gbits.p, 0, (size_t)words * 4, st));
+            if (n_pre > 0) {
+                GSR_TRY(c->scratch.reserve((size_t)n_pre * 4));
+                hipLaunchKernelGGL(k_not_flag, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->keep.as<int>(), c->scratch.as<int>());
+                hipLaunchKernelGGL(k_bits_set, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->gid_next.as<unsigned>(), c->scratch.as<int>(), c->gbits.as<unsigned>());
+            }
+            GSR_TRY(gsr_comm_allreduce(c->comm, c->gbits.p, words, GSR_DT_U32, GSR_OP_SUM, (void*)st));
+            hipLaunchKernelGGL(k_bits_popc, dim3(stride_grid(words)), blk, 0, st, words, c->gbits.as<unsigned>(), c->wcnt.as<int>());
+            GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>(), c->wpre.as<int>(), words));
+            if (dropped > 0) {                                  // my own erased rows out of my list first
+                GSR_TRY(c->grank.reserve((size_t)n_pre * 4));
+                hipLaunchKernelGGL(k_compact_u32, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->keep.as<int>(), c->kpos.as<int>(), c->gid_next.as<unsigned>(), c->grank.as<unsigned>());
+                c->gid_next.swap(c->grank);
+            }
+            if (O.n > 0) hipLaunchKernelGGL(k_gid_drop, dim3(stride_grid(O.n)), blk, 0, st, O.n, c->gbits.as<unsigned>(), c->wpre.as<int>(), c->gid_next.as<unsigned>());
+            n_glob_next = n_pre_glob - dg;
+        }
+        c->part_stats[6] = dg;
+        return GSR_OK;
+    }
+};
+
+}  // namespace
+
 int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     const bool dbg_sync = getenv("GSR_HEM_DEBUG_SYNC") != nullptr;
     if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_run_level: no level set");
@@ -3478,22 +3716,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     memset(c->stats_ex, 0, sizeof(c->stats_ex));
     memset(c->part_stats, 0, sizeof(c->part_stats));
     c->stats[6] = n;
+    PartLevel pl;                                // (only a partitioned level uses it)
+    pl.c = c; pl.st = st; pl.n_own = n_own;
+    if (part) {
+        pl.W = gsr_comm_world(c->comm); pl.me = gsr_comm_rank(c->comm);
+        if (pl.W > 8) return fail(GSR_E_INVALID, "gsr_hem_run_level: more than 8 ranks");
+    }
     if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld components (the candidate records carry the sorted position in 30 bits)", (long long)n);
     if (part && c->shard_world > 1) return fail(GSR_E_INVALID, "gsr_hem_run_level: spatial partition and work sharding are exclusive");
-    if (part) {
-        // Ownership follows the parents, so a rank CAN run out of components on a later level: that is data, not a local error.  The
-        // ranks agree on the level's preconditions before its first data collective (one all-reduce of a status word), so that
-        // every rank returns the error instead of one returning and its peers waiting in the next collective for ever.
-        GSR_TRY(c->pcounts.reserve(64));
-        const unsigned status = n == 0 ? 1u : 0u;
-        GSR_HIP(hipMemcpyAsync(c->pcounts.p, &status, 4, hipMemcpyHostToDevice, c->stream));
-        GSR_HIP(hipStreamSynchronize(c->stream));               // (status lives on this stack frame)
-        GSR_TRY(gsr_comm_allreduce(c->comm, c->pcounts.p, 1, GSR_DT_U32, GSR_OP_MAX, (void*)c->stream));
-        unsigned agreed = 0;
-        GSR_HIP(hipMemcpyAsync(&agreed, c->pcounts.p, 4, hipMemcpyDeviceToHost, c->stream));
-        GSR_HIP(hipStreamSynchronize(c->stream));
-        if (agreed) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank of the partitioned level owns no component (reported on every rank; use fewer ranks)");
-    }
+    if (part) GSR_TRY(pl.agree_on_preconditions(n));
     if (n == 0) {
         if (n_out) *n_out = 0;
         if (n_dropped) *n_dropped = 0;
@@ -3501,21 +3732,6 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     }
     const dim3 blk(256);
     dim3 grd(stride_grid(n));
-    const int W = part ? gsr_comm_world(c->comm) : 1, me = part ? gsr_comm_rank(c->comm) : 0;
-    if (W > 8) return fail(GSR_E_INVALID, "gsr_hem_run_level: more than 8 ranks");
-    // halo bookkeeping (host): rows sent to / received from every rank, and their offsets in the concatenated buffers
-    int64_t send_cnt[8] = {0}, recv_cnt[8] = {0}, soff[8] = {0}, roff[8] = {0}, n_sent = 0, n_ghost = 0;
-    // one typed exchange along the halo's lists: to_owner = the ghosts' values go to their owners (roles of the lists reversed)
-    auto halo_exchange = [&](const void* sendbuf, void* recvbuf, size_t elem, bool to_owner, hipStream_t xs = nullptr) -> int32_t {
-        int64_t so[8], sb[8], ro[8], rb[8];
-        for (int q = 0; q < W; ++q) {
-            so[q] = (to_owner ? roff[q] : soff[q]) * (int64_t)elem; sb[q] = (to_owner ? recv_cnt[q] : send_cnt[q]) * (int64_t)elem;
-            ro[q] = (to_owner ? soff[q] : roff[q]) * (int64_t)elem; rb[q] = (to_owner ? send_cnt[q] : recv_cnt[q]) * (int64_t)elem;
-            if (q != me) c->part_stats[3] += rb[q];
-        }
-        return gsr_comm_exchange(c->comm, sendbuf, so, sb, recvbuf, ro, rb, (void*)(xs ? xs : st));
-    };
-    bool halo_sh_pending = false;
     GSR_HIP(hipEventRecord(c->ev[0], st));
 
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
@@ -3564,68 +3780,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 
     const float4* rec_src = c->rec.as<float4>();            // the packed records of the working set, by local index
     if (part) {
-        // ---- halo: which cells do my parents' search spheres touch -> masks of all ranks -> my components they need -> rows
-        const int64_t mwords = ((int64_t)gp.ncells + 31) / 32 + 1;
-        GSR_TRY(c->cmask.reserve((size_t)W * 2 * mwords * 4));
-        unsigned* my_mask = c->cmask.as<unsigned>() + (int64_t)me * 2 * mwords;      // [cells wanted of regular components | of irregular ones]
-        GSR_HIP(hipMemsetAsync(my_mask, 0, (size_t)2 * mwords * 4, st));
-        hipLaunchKernelGGL(k_mark_cells, dim3(stride_grid(n_own * 16)), blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), c->delta,
-                           c->delta * c->delta * 0.5f, c->use_ell ? 1 : 0, my_mask, my_mask + mwords);
-        GSR_TRY(gsr_comm_allgather(c->comm, my_mask, c->cmask.p, 2 * mwords * 4, (void*)st));
-        GSR_TRY(c->dflag.reserve((size_t)W * n_own * 4)); GSR_TRY(c->dpos.reserve((size_t)W * n_own * 4));
-        hipLaunchKernelGGL(k_dest_flags, grd, blk, 0, st, n_own, c->rec.as<float4>(), c->gparams.as<GridParams>(), W, me, mwords, c->cmask.as<unsigned>(),
-                           c->dflag.as<int>());
-        GSR_TRY(c->pcounts.reserve(64)); GSR_TRY(c->pmatrix.reserve(64 * 8));
-        GSR_HIP(hipMemsetAsync(c->pcounts.p, 0, 64, st));
-        for (int q = 0; q < W; ++q) {
-            if (q == me) continue;
-            GSR_TRY(exclusive_scan<int>(c, c->dflag.as<int>() + (int64_t)q * n_own, c->dpos.as<int>() + (int64_t)q * n_own, n_own));
-            hipLaunchKernelGGL(k_last_total, dim3(1), dim3(1), 0, st, c->dpos.as<int>() + (int64_t)q * n_own + (n_own - 1),
-                               c->dflag.as<int>() + (int64_t)q * n_own + (n_own - 1), c->pcounts.as<long long>() + q);
-        }
-        GSR_TRY(gsr_comm_allgather(c->comm, c->pcounts.p, c->pmatrix.p, 64, (void*)st));
-        long long mat[64];
-        GSR_HIP(hipMemcpyAsync(mat, c->pmatrix.p, (size_t)W * 64, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipStreamSynchronize(st));
-        for (int q = 0; q < W; ++q) { send_cnt[q] = q == me ? 0 : mat[me * 8 + q]; recv_cnt[q] = q == me ? 0 : mat[q * 8 + me]; }
-        for (int q = 0; q < W; ++q) { soff[q] = n_sent; n_sent += send_cnt[q]; roff[q] = n_ghost; n_ghost += recv_cnt[q]; }
-        // TWO exchanges along the same lists: the 72-byte rows {record, global index, index at the owner} -- what the grid, the sort
-        // and the selection need -- on the level's stream, and the SH rows (4 F bytes: 71 % of a ghost at SH degree 3), which only the
-        // M-step reads, on the third stream beside the rest of the grid phase and the selection, received straight into ghost_sh
-        constexpr int RW = 16 + PART_ROW_EXTRA;
-        const size_t Fm = (size_t)(F > 0 ? F : 1);
-        GSR_TRY(c->rows_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * RW * 4)); GSR_TRY(c->rows_recv.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * RW * 4));
-        GSR_TRY(c->sh_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * Fm * 4));
-        GSR_TRY(c->sent_idx.reserve((size_t)(n_sent > 0 ? n_sent : 1) * 4));
-        GSR_TRY(c->ghost_sh.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * Fm * 4)); GSR_TRY(c->ghost_src.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * 4));
-        for (int q = 0; q < W; ++q)
-            if (send_cnt[q] > 0)
-                hipLaunchKernelGGL(k_pack_rows, dim3(stride_grid(n_own * 64)), blk, 0, st, n_own, F, c->dflag.as<int>() + (int64_t)q * n_own,
-                                   c->dpos.as<int>() + (int64_t)q * n_own, c->rec.as<float4>(), L.sh.as<float>(), c->gid.as<unsigned>(),
-                                   c->rows_send.as<float>() + soff[q] * RW, c->sh_send.as<float>() + soff[q] * F, c->sent_idx.as<unsigned>() + soff[q]);
-        GSR_HIP(hipEventRecord(c->evp[0], st));
-        GSR_TRY(halo_exchange(c->rows_send.p, c->rows_recv.p, (size_t)RW * 4, false));
-        GSR_HIP(hipEventRecord(c->evp[1], st));
-        if (F > 0) {        // every rank issues it (the same order of communicator calls everywhere), whatever its own counts
-            GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
-            GSR_HIP(hipEventRecord(c->evp[2], c->aux2));
-            GSR_TRY(halo_exchange(c->sh_send.p, c->ghost_sh.p, (size_t)F * 4, false, c->aux2));
-            GSR_HIP(hipEventRecord(c->evp[3], c->aux2));
-            GSR_HIP(hipEventRecord(c->ev_halo, c->aux2));
-            halo_sh_pending = true;
-        }
-        c->part_stats[0] = n_ghost; c->part_stats[1] = n_sent; c->part_stats[2] = c->part_stats[3]; c->part_stats[3] = 0;
-        n = n_own + n_ghost;
-        if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld local components", (long long)n);
+        GSR_TRY(pl.halo(gp, L, F, n));
         grd = dim3(stride_grid(n));
-        GSR_TRY(c->rec_loc.reserve((size_t)n * 64)); GSR_TRY(c->gid_loc.reserve((size_t)n * 4));
-        GSR_HIP(hipMemcpyAsync(c->rec_loc.p, c->rec.p, (size_t)n_own * 64, hipMemcpyDeviceToDevice, st));
-        GSR_HIP(hipMemcpyAsync(c->gid_loc.p, c->gid.p, (size_t)n_own * 4, hipMemcpyDeviceToDevice, st));
-        if (n_ghost > 0)
-            hipLaunchKernelGGL(k_unpack_rows, dim3(stride_grid(n_ghost * 16)), blk, 0, st, n_ghost, n_own, c->rows_recv.as<float>(), c->rec_loc.as<float4>(),
-                               c->gid_loc.as<unsigned>(), c->ghost_src.as<unsigned>());
         rec_src = c->rec_loc.as<float4>();
-        c->stats[6] = n_own;
     }
     GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->order.reserve(n * 4));
     if (part) {
@@ -3952,62 +4109,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_HIP(hipGetLastError());
         return GSR_OK;
     };
-    // spatially partitioned level: k_bucket_sum's three steps with the ghosts' partial results sent to their owners in between --
-    // integers only (maximum, 64-bit fixed-point sums), then the owners' finished float32 sums back to the ghosts
-    auto sums_part = [&]() -> int32_t {
-        // the communicator's calls in ONE order on the device too: the exchanges below (this stream) behind the SH rows' (third stream)
-        if (halo_sh_pending) { GSR_HIP(hipStreamWaitEvent(st, c->ev_halo, 0)); halo_sh_pending = false; }
-        if (nbuckets > SUM_MAX_BUCKETS) return fail(GSR_E_INVALID, "gsr_hem_run_level: level too large for the partitioned sums");
-        GSR_TRY(c->gmax.reserve((size_t)n * 4)); GSR_TRY(c->gacc.reserve((size_t)n * 8)); GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
-        unsigned cap = 0;
-        for (double factor = 8.0;; factor *= 2.0) {            // bucket regions of fixed capacity; doubled until nothing overflows
-            const double capd = (double)M / (double)nbuckets * factor + 4096.0;
-            if (capd > 4.0e9) return fail(GSR_E_INVALID, "gsr_hem_run_level: pair partition capacity");
-            cap = (unsigned)capd;
-            GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * 4)); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
-            GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
-            GSR_HIP(hipMemsetAsync(overflow_flag, 0, 4, st));
-            if (M > 0 && P > 0)
-                launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
-                                 c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
-            GSR_HIP(hipGetLastError());
-            Collect q;
-            q.n = 1; q.src[0] = overflow_flag; q.bytes[0] = 4;
-            unsigned long long w[8];
-            GSR_TRY(read_back(c, q, w));
-            if (w[0] == 0ull) break;
-        }
-        const dim3 bblk(bshift >= 10 ? 1024 : 256);
-        const dim3 gs(stride_grid(n_sent > 0 ? n_sent : 1)), gg(stride_grid(n_ghost > 0 ? n_ghost : 1));
-        GSR_TRY(c->xsend.reserve((size_t)(n_sent + n_ghost + 1) * 8)); GSR_TRY(c->xrecv.reserve((size_t)(n_sent + n_ghost + 1) * 8));
-        // 1. the largest |wL| of every child: local, then the ghosts' maxima to their owners, then the owners' result back
-        hipLaunchKernelGGL(k_part_max, dim3(nbuckets), bblk, (size_t)4 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(),
-                           c->spair_wl.as<float>(), c->gmax.as<unsigned>());
-        GSR_HIP(hipGetLastError());
-        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_gather<unsigned>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->gmax.as<unsigned>(), c->xsend.as<unsigned>());
-        GSR_TRY(halo_exchange(c->xsend.p, c->xrecv.p, 4, true));
-        if (n_sent > 0) hipLaunchKernelGGL(k_sent_apply_max, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->xrecv.as<unsigned>(), c->gmax.as<unsigned>());
-        if (n_sent > 0) hipLaunchKernelGGL(k_sent_gather<unsigned>, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->gmax.as<unsigned>(), c->xsend.as<unsigned>());
-        GSR_TRY(halo_exchange(c->xsend.p, c->xrecv.p, 4, false));
-        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_set<unsigned>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->xrecv.as<unsigned>(), c->gmax.as<unsigned>());
-        // 2. the fixed-point sums on that scale: local, then the ghosts' partial sums to their owners (integer addition)
-        hipLaunchKernelGGL(k_part_acc, dim3(nbuckets), bblk, (size_t)12 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(),
-                           c->spair_wl.as<float>(), c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>());
-        GSR_HIP(hipGetLastError());
-        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_gather<unsigned long long>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->gacc.as<unsigned long long>(), c->xsend.as<unsigned long long>());
-        GSR_TRY(halo_exchange(c->xsend.p, c->xrecv.p, 8, true));
-        if (n_sent > 0) hipLaunchKernelGGL(k_sent_apply_acc, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->xrecv.as<unsigned long long>(),
-                                           c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>());
-        // 3. the float32 sums (correct for the owned components), the owners' values back to the ghosts, orphans among the owned
-        hipLaunchKernelGGL(k_part_finish, grd, blk, 0, st, n, c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>(), c->sumLw.as<float>());
-        if (n_sent > 0) hipLaunchKernelGGL(k_sent_gather<float>, gs, blk, 0, st, n_sent, c->sent_idx.as<unsigned>(), c->inv.as<unsigned>(), c->sumLw.as<float>(), c->xsend.as<float>());
-        GSR_TRY(halo_exchange(c->xsend.p, c->xrecv.p, 4, false));
-        if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_set<float>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->xrecv.as<float>(), c->sumLw.as<float>());
-        hipLaunchKernelGGL(k_part_orphans, grd, blk, 0, st, n, n_own, c->order.as<unsigned>(), c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
-        return GSR_OK;
-    };
     if (part) {
-        GSR_TRY(sums_part());
+        GSR_TRY(pl.sums(n, P, M, seg, pc, pw, nbuckets, bshift, overflow_flag));
     } else if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
         if (c->partition_fixed && !c->partition_overflowed) {
             const int32_t r = sums_fixed();
@@ -4190,39 +4293,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                                    O.color.as<float>(), O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>());
         }
     }
-    // spatially partitioned level: the rows' GLOBAL ranks (a parent's = parents below it in the level's global order, an orphan's =
-    // all parents + orphans below it): bit maps of the parents' and orphans' global indices, summed over the ranks (disjoint bits)
     int64_t P_glob = P, O_glob = n_orph;
-    if (part) {
-        const int64_t words = (c->n_global + 31) / 32 + 1;
-        GSR_TRY(c->gbits.reserve((size_t)2 * words * 4)); GSR_TRY(c->wcnt.reserve((size_t)2 * words * 4)); GSR_TRY(c->wpre.reserve((size_t)2 * words * 4));
-        GSR_TRY(c->grank.reserve((size_t)2 * n_own * 4)); GSR_TRY(c->gid_next.reserve((size_t)(n_pre > 0 ? n_pre : 1) * 4));     // [ranks as parents | as orphans]
-        GSR_HIP(hipMemsetAsync(c->gbits.p, 0, (size_t)2 * words * 4, st));
-        const dim3 go(stride_grid(n_own));
-        hipLaunchKernelGGL(k_bits_set, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->pflag_in.as<int>(), c->gbits.as<unsigned>());
-        hipLaunchKernelGGL(k_bits_set, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->oflag_in.as<int>(), c->gbits.as<unsigned>() + words);
-        GSR_TRY(gsr_comm_allreduce(c->comm, c->gbits.p, 2 * words, GSR_DT_U32, GSR_OP_SUM, (void*)st));
-        hipLaunchKernelGGL(k_bits_popc, dim3(stride_grid(2 * words)), blk, 0, st, 2 * words, c->gbits.as<unsigned>(), c->wcnt.as<int>());
-        GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>(), c->wpre.as<int>(), words));
-        GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>() + words, c->wpre.as<int>() + words, words));
-        {
-            Collect q;
-            q.n = 4;
-            q.src[0] = c->wpre.as<int>() + (words - 1); q.src[1] = c->wcnt.as<int>() + (words - 1);
-            q.src[2] = c->wpre.as<int>() + (2 * words - 1); q.src[3] = c->wcnt.as<int>() + (2 * words - 1);
-            for (int i = 0; i < 4; ++i) q.bytes[i] = 4;
-            unsigned long long w[8];
-            GSR_TRY(read_back(c, q, w));
-            P_glob = (int64_t)w[0] + (int64_t)w[1]; O_glob = (int64_t)w[2] + (int64_t)w[3];
-        }
-        hipLaunchKernelGGL(k_bits_rank, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->pflag_in.as<int>(), c->gbits.as<unsigned>(), c->wpre.as<int>(), 0u,
-                           c->grank.as<unsigned>());
-        hipLaunchKernelGGL(k_bits_rank, go, blk, 0, st, n_own, c->gid.as<unsigned>(), c->oflag_in.as<int>(), c->gbits.as<unsigned>() + words, c->wpre.as<int>() + words,
-                           (unsigned)P_glob, c->grank.as<unsigned>() + n_own);
-        hipLaunchKernelGGL(k_part_new_gid, go, blk, 0, st, n_own, P, c->pflag_in.as<int>(), c->prank_in.as<int>(), c->oflag_in.as<int>(), c->orank_in.as<int>(),
-                           c->grank.as<unsigned>(), c->grank.as<unsigned>() + n_own, c->gid_next.as<unsigned>());
-        c->part_stats[4] = P_glob; c->part_stats[5] = O_glob;
-    }
+    if (part) GSR_TRY(pl.global_ranks(P, n_pre, P_glob, O_glob));
     const int64_t n_pre_glob = P_glob + O_glob;
     GSR_CHECKPOINT("M-step + orphans");
     GSR_HIP(hipEventRecord(c->ev[4], st));
@@ -4275,38 +4347,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         }
     }
     int64_t n_glob_next = n_pre_glob;
-    if (part) {
-        // erased rows leave the GLOBAL numbering too: how many over all ranks, and (rarely more than none) which
-        GSR_TRY(c->pcounts.reserve(64));
-        const long long dl = dropped;
-        GSR_HIP(hipMemcpyAsync(c->pcounts.p, &dl, 8, hipMemcpyHostToDevice, st));
-        GSR_HIP(hipStreamSynchronize(st));                      // (dl lives on this stack frame)
-        GSR_TRY(gsr_comm_allreduce(c->comm, c->pcounts.p, 1, GSR_DT_U64, GSR_OP_SUM, (void*)st));
-        long long dg = 0;
-        GSR_HIP(hipMemcpyAsync(&dg, c->pcounts.p, 8, hipMemcpyDeviceToHost, st));
-        GSR_HIP(hipStreamSynchronize(st));
-        if (dg > 0) {
-            const int64_t words = (n_pre_glob + 31) / 32 + 1;
-            GSR_TRY(c->gbits.reserve((size_t)words * 4)); GSR_TRY(c->wcnt.reserve((size_t)words * 4)); GSR_TRY(c->wpre.reserve((size_t)words * 4));
-            GSR_HIP(hipMemsetAsync(c->gbits.p, 0, (size_t)words * 4, st));
-            if (n_pre > 0) {
-                GSR_TRY(c->scratch.reserve((size_t)n_pre * 4));
-                hipLaunchKernelGGL(k_not_flag, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->keep.as<int>(), c->scratch.as<int>());
-                hipLaunchKernelGGL(k_bits_set, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->gid_next.as<unsigned>(), c->scratch.as<int>(), c->gbits.as<unsigned>());
-            }
-            GSR_TRY(gsr_comm_allreduce(c->comm, c->gbits.p, words, GSR_DT_U32, GSR_OP_SUM, (void*)st));
-            hipLaunchKernelGGL(k_bits_popc, dim3(stride_grid(words)), blk, 0, st, words, c->gbits.as<unsigned>(), c->wcnt.as<int>());
-            GSR_TRY(exclusive_scan<int>(c, c->wcnt.as<int>(), c->wpre.as<int>(), words));
-            if (dropped > 0) {                                  // my own erased rows out of my list first
-                GSR_TRY(c->grank.reserve((size_t)n_pre * 4));
-                hipLaunchKernelGGL(k_compact_u32, dim3(stride_grid(n_pre)), blk, 0, st, n_pre, c->keep.as<int>(), c->kpos.as<int>(), c->gid_next.as<unsigned>(), c->grank.as<unsigned>());
-                c->gid_next.swap(c->grank);
-            }
-            if (O.n > 0) hipLaunchKernelGGL(k_gid_drop, dim3(stride_grid(O.n)), blk, 0, st, O.n, c->gbits.as<unsigned>(), c->wpre.as<int>(), c->gid_next.as<unsigned>());
-            n_glob_next = n_pre_glob - dg;
-        }
-        c->part_stats[6] = dg;
-    }
+    if (part) GSR_TRY(pl.drop_erased(O, n_pre, n_pre_glob, dropped, n_glob_next));
     GSR_CHECKPOINT("flags + validity");
     GSR_HIP(hipEventRecord(c->ev[5], st));
     GSR_HIP(hipStreamSynchronize(st));

@@ -1233,18 +1233,20 @@ __global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_a
     block_reduce_store<NACC, FUSE != 0>(acc, partials, rg.row);
     if constexpr (FUSE == 0) return;
     // Hand-off inside one launch (MI355X_MICROARCH.md, "Workgroup dispatch, XCD placement & inter-workgroup visibility"): the
-    // partials left with write-through (sc1) stores by the lanes of wave 0; that wave waits for them (vmcnt(0)), then its lane 0
-    // takes a device-scope ticket.  The workgroup whose ticket is the last one reads every block's partials with sc1 loads -- no
-    // L2 write-back / invalidate fences: with a release fence per workgroup (buffer_wbl2) the fused form was 4 us SLOWER per
-    // iteration than two launches.
+    // partials were stored by the lanes of wave 0; lane 0 RELEASES them at agent scope and takes a device-scope ticket
+    // (acquire-release); the workgroup whose ticket is the last one ACQUIRES and reads every block's partials.  (Round 3 shipped
+    // this with relaxed atomics and a bare vmcnt(0) -- no release / acquire pair ordered the partials before the ticket across
+    // XCDs; the fences cost ~4 us per iteration, which is one more reason the knob stays off: two launches are faster.)
     __shared__ int s_last;
     __shared__ double s_x[8][GSR_ICP_ACC_LEN];
     __shared__ IcpState s_st;
     if (threadIdx.x < 64) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
-            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             s_last = t == gridDim.x - 1 ? 1 : 0;
+            if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
     }
     __syncthreads();
