@@ -1791,7 +1791,7 @@ struct MstepArgs {
     const float* pair_wl;
     int P, F;
     int small;                 // serve parents of <= MSTEP_SMALL pairs four at a time (GSR_HEM_MSTEP_SMALL=0: the general path for all)
-    int split;                 // 1: parents of more than MSTEP_SEG pairs are left to k_mstep<.., HEAVY = true> (one wave per segment)
+    int split;                 // k_mstep<.., HEAVY>: 1 = one wave per segment of a heavy parent, 0 = one wave per heavy parent
     const unsigned* hcount;    // device: [0] heavy parents, [1] their segments (work items)
     const uint4* hlist;        // heavy parent -> {slot, first item, segments}
     const uint2* hitems;       // item -> {slot, segment}
@@ -1982,24 +1982,30 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
 #pragma unroll
     for (int v = 0; v < MSTEP_NV; ++v) qi[v] = gl + GG * v < nq ? gl + GG * v : 0;
     if constexpr (HEAVY) {
-        const unsigned nitems = a.hcount[1];
+        // a.split: one wave per work item (segment); GSR_HEM_MSTEP_SPLIT=0: one wave per heavy PARENT, its segments one after the
+        // other (the schedule of rounds 1-3) -- the same segment records either way, added in order by k_mstep_heavy_finish
+        const unsigned nitems = a.hcount[1], nheavy = a.hcount[0];
         const int RS = 16 + a.RSH;
-        for (unsigned item = blockIdx.x * WPB + wv; item < nitems; item += gridDim.x * WPB) {
-            const uint2 it = a.hitems[item];
-            const MstepHeader h = a.hdr[it.x];
-            const f3 pm = {h.px, h.py, h.pz};
-            const unsigned first = it.y * MSTEP_SEG;
-            const unsigned cn = h.cnt - first < MSTEP_SEG ? h.cnt - first : MSTEP_SEG;
-            float4 acc[MSTEP_NV];
-            mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off + first, cn, pm, acc);
-            float* rec = a.hscratch + (int64_t)item * RS;
-            if (lane < 14) rec[lane] = s_mom[lane];
-            if (G > 0 && grp == 0) {
+        const unsigned nwork = a.split ? nitems : nheavy;
+        for (unsigned wk = blockIdx.x * WPB + wv; wk < nwork; wk += gridDim.x * WPB) {
+            const uint4 hp = a.split ? make_uint4(0u, wk, 1u, 0u) : a.hlist[wk];        // {-, first item, items}
+            for (unsigned item = hp.y; item < hp.y + hp.z; ++item) {
+                const uint2 it = a.hitems[item];
+                const MstepHeader h = a.hdr[it.x];
+                const f3 pm = {h.px, h.py, h.pz};
+                const unsigned first = it.y * MSTEP_SEG;
+                const unsigned cn = h.cnt - first < MSTEP_SEG ? h.cnt - first : MSTEP_SEG;
+                float4 acc[MSTEP_NV];
+                mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off + first, cn, pm, acc);
+                float* rec = a.hscratch + (int64_t)item * RS;
+                if (lane < 14) rec[lane] = s_mom[lane];
+                if (G > 0 && grp == 0) {
 #pragma unroll
-                for (int v = 0; v < MSTEP_NV; ++v)
-                    if (gl + GG * v < nq) reinterpret_cast<float4*>(rec + 16)[gl + GG * v] = acc[v];
+                    for (int v = 0; v < MSTEP_NV; ++v)
+                        if (gl + GG * v < nq) reinterpret_cast<float4*>(rec + 16)[gl + GG * v] = acc[v];
+                }
+                __builtin_amdgcn_wave_barrier();
             }
-            __builtin_amdgcn_wave_barrier();
         }
         return;
     }
@@ -2173,31 +2179,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         if (h.oslot < 0) continue;
         const f3 pm = {h.px, h.py, h.pz};
         const unsigned cnt = h.cnt;
-        if (a.split && cnt > MSTEP_SEG) continue;               // a heavy parent: its segments are work items of k_mstep<.., HEAVY>
+        if (cnt > MSTEP_SEG) continue;                          // a heavy parent: its segments belong to k_mstep<.., HEAVY> + k_mstep_heavy_finish
         float4 acc[MSTEP_NV];
-        mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off, cnt < MSTEP_SEG ? cnt : MSTEP_SEG, pm, acc);
-        if (cnt > MSTEP_SEG) {
-            // (GSR_HEM_MSTEP_SPLIT=0) the further segments in this wave, their totals added in segment order -- what
-            // k_mstep_heavy_finish does with the segments other waves computed
-            float4 tsh[MSTEP_NV];
-#pragma unroll
-            for (int v = 0; v < MSTEP_NV; ++v) tsh[v] = acc[v];
-            float tm = lane < 14 ? s_mom[lane] : 0.0f;          // lane t carries moment t across the segments
-            __builtin_amdgcn_wave_barrier();
-            for (unsigned first = MSTEP_SEG; first < cnt; first += MSTEP_SEG) {
-                mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off + first, cnt - first < MSTEP_SEG ? cnt - first : MSTEP_SEG, pm, acc);
-                if (lane < 14) tm = tm + s_mom[lane];
-#pragma unroll
-                for (int v = 0; v < MSTEP_NV; ++v) {
-                    tsh[v].x = tsh[v].x + acc[v].x; tsh[v].y = tsh[v].y + acc[v].y; tsh[v].z = tsh[v].z + acc[v].z; tsh[v].w = tsh[v].w + acc[v].w;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (lane < 14) s_mom[lane] = tm;
-#pragma unroll
-            for (int v = 0; v < MSTEP_NV; ++v) acc[v] = tsh[v];
-            __builtin_amdgcn_wave_barrier();
-        }
+        mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off, cnt, pm, acc);
         const float w_s = s_mom[0];
         const float inv_w = 1.0f / w_s;                        // mixture.cpp:209
         const int64_t slot = h.oslot;
@@ -2939,7 +2923,7 @@ struct gsr_hem_ctx {
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec;
-    bool mstep_split = true;        // GSR_HEM_MSTEP_SPLIT=0: a parent of more than MSTEP_SEG pairs keeps its one wave (test knob: nothing may change)
+    bool mstep_split = true;        // GSR_HEM_MSTEP_SPLIT=0: a parent of more than MSTEP_SEG pairs keeps ONE wave for all its segments (the schedule of rounds 1-3)
     DevBuf mh_list, mh_items, mh_scratch;
     hipEvent_t ev_mfork = nullptr, ev_mjoin = nullptr;          // the heavy parents' segments run on the second stream beside k_mstep
     bool mstep_small = true;        // GSR_HEM_MSTEP_SMALL=0: no four-at-a-time path for the parents of <= 16 pairs (test knob: nothing may change)
@@ -4208,7 +4192,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.nheavy = mporder ? c->counters.as<int>() + 8 : nullptr;
         GSR_TRY(c->mhdr.reserve(Pm * sizeof(MstepHeader)));
         // heavy parents (more than MSTEP_SEG pairs): their segments are work items of a second launch (mstep_segment)
-        const bool msplit = c->mstep_split && M > MSTEP_SEG;
+        const bool msplit = M > MSTEP_SEG;                        // (a parent of more than MSTEP_SEG pairs can exist)
         if (msplit) {
             const size_t cap_heavy = (size_t)(M / MSTEP_SEG) + 2, cap_items = 2 * (size_t)(M / MSTEP_SEG) + 4;
             GSR_TRY(c->mh_list.reserve(cap_heavy * sizeof(uint4))); GSR_TRY(c->mh_items.reserve(cap_items * sizeof(uint2)));
@@ -4220,7 +4204,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                            c->mhdr.as<MstepHeader>(), c->counters.as<unsigned>() + 15, (unsigned)MSTEP_SEG, msplit ? hcount : (unsigned*)nullptr,
                            c->mh_list.as<uint4>(), c->mh_items.as<uint2>());
         ma.hdr = c->mhdr.as<MstepHeader>();
-        ma.split = msplit ? 1 : 0;
+        ma.split = c->mstep_split ? 1 : 0;
         ma.hcount = hcount; ma.hlist = c->mh_list.as<uint4>(); ma.hitems = c->mh_items.as<uint2>(); ma.hscratch = c->mh_scratch.as<float>();
         ma.o_xyz = O.xyz.as<float>(); ma.o_color = O.color.as<float>(); ma.o_cov6 = O.cov6.as<float>();
         ma.o_opacity = O.opacity.as<float>(); ma.o_weight = O.weight.as<float>(); ma.o_sh = O.sh.as<float>();
