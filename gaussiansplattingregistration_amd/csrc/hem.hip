@@ -695,10 +695,10 @@ __device__ __forceinline__ int wave_incl_scan(int v) {
 // GSR_SELECT_PROFILE (variant builds only, scripts/select_profile.py): where a selection wave spends its clock -- s_memtime deltas
 // of the phases, summed over all waves with one atomic per phase and parent
 #ifdef GSR_SELECT_PROFILE
-__device__ unsigned long long g_sel_prof[16];
+__device__ unsigned long long g_sel_prof[1024 * 16];       // 1024 copies (by workgroup): atomics on ONE address from 10^6 waves serialise
 #define SEL_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define SEL_PROF_ADD(slot, t0, lane) do { if ((lane) == 0) atomicAdd(&g_sel_prof[slot], __builtin_amdgcn_s_memtime() - (t0)); } while (0)
-#define SEL_PROF_CNT(slot, v, lane) do { if ((lane) == 0) atomicAdd(&g_sel_prof[slot], (unsigned long long)(v)); } while (0)
+#define SEL_PROF_ADD(slot, t0, lane) do { if ((lane) == 0) atomicAdd(&g_sel_prof[(blockIdx.x & 1023u) * 16 + (slot)], __builtin_amdgcn_s_memtime() - (t0)); } while (0)
+#define SEL_PROF_CNT(slot, v, lane) do { if ((lane) == 0) atomicAdd(&g_sel_prof[(blockIdx.x & 1023u) * 16 + (slot)], (unsigned long long)(v)); } while (0)
 #else
 #define SEL_PROF_T(var)
 #define SEL_PROF_ADD(slot, t0, lane)
@@ -1048,6 +1048,7 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
             const int seg_end = b_hi < seg0 + SEL_MCAP ? b_hi : seg0 + SEL_MCAP;
             for (int t0 = seg0; t0 < seg_end; t0 += 64 * SEL_U) {
                 SEL_PROF_CNT(14, 1, lane);
+                SEL_PROF_T(tps);
                 float4 ca[SEL_U];
                 int jj[SEL_U];
                 int left[SEL_U];                                              // active lanes of each chunk (uniform)
@@ -1094,6 +1095,7 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
                 }
                 // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
                 __builtin_amdgcn_wave_barrier();
+                SEL_PROF_ADD(4, tps, lane);
                 while (qn >= 64) {
                     select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base, q3);
                     qh = (qh + 64) & (SEL_QCAP - 1);
@@ -3084,9 +3086,14 @@ int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n, bool side
 #ifndef GSR_SORT_RADIX_BITS
 #define GSR_SORT_RADIX_BITS 10
 #endif
+// GSR_SORT_MERGE_LIMIT: up to this many keys rocPRIM sorts by block sort + merge passes (~20 launches at 5 * 10^5 keys), beyond it by Onesweep
+#ifndef GSR_SORT_MERGE_LIMIT
+#define GSR_SORT_MERGE_LIMIT (256 * 1024)      // measured on the bench levels (profiles/r04i): 1 M -> 256 k takes 0.05 ms off the 1.67 M level (its 556 k parents) and 0.04 off the 556 k level; 128 k, 32 k: the same
+#endif
 using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, GSR_SORT_RADIX_BITS,
-                                                                                rocprim::block_radix_rank_algorithm::match>>;
+                                                                                rocprim::block_radix_rank_algorithm::match>,
+                                            GSR_SORT_MERGE_LIMIT>;
 template <typename V>
 int32_t sort_pairs(gsr_hem_ctx* c, const unsigned* kin, unsigned* kout, const V* vin, V* vout, int64_t n, int end_bit) {
     size_t bytes = 0;
@@ -4364,8 +4371,12 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 
 #ifdef GSR_SELECT_PROFILE
 int32_t gsr_debug_select_profile(unsigned long long* out16, int32_t reset) {
-    if (out16) { if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sel_prof), sizeof(g_sel_prof)) != hipSuccess) return GSR_E_HIP; }
-    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), z, sizeof(z)) != hipSuccess) return GSR_E_HIP; }
+    static unsigned long long h[1024 * 16];
+    if (out16) {
+        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sel_prof), sizeof(h)) != hipSuccess) return GSR_E_HIP;
+        for (int k = 0; k < 16; ++k) { out16[k] = 0; for (int b = 0; b < 1024; ++b) out16[k] += h[b * 16 + k]; }
+    }
+    if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), h, sizeof(h)) != hipSuccess) return GSR_E_HIP; }
     return GSR_OK;
 }
 #endif
