@@ -68,6 +68,7 @@ SIGNATURES = {
     "gsr_hem_set_comm": (_i32, [_vp, _vp]),
     "gsr_hem_set_level0_part": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i64, _i32, _i32]),
     "gsr_hem_get_gids": (_i32, [_vp, _vp, _i32]),
+    "gsr_hem_set_output": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64]),
     "gsr_hem_get_part_stats": (_i32, [_vp, C.POINTER(_i64)]),
     "gsr_hem_get_part_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "gsr_hem_run_level": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),

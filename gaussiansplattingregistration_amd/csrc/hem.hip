@@ -2903,6 +2903,11 @@ struct gsr_hem_ctx {
     // level 0 borrowed from the caller (gsr_hem_set_level0, on_device = 2): `spare` keeps cur's own five big buffers meanwhile
     bool cur_borrowed = false;
     DevBuf spare[5];
+    // gsr_hem_set_output: the next level is written straight into caller-owned arrays, which then ARE the current level (borrowed)
+    void* out_ptr[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int64_t out_rows = 0;
+    bool out_pending = false;
+    DevBuf spare_out[5];            // nxt's own big arrays, parked while the caller's stand in for them
     bool have_level = false;
     // workspace
     DevBuf hist, iflag, irank, ipos, rng_blocks, bhist, bstart, bcursor;
@@ -3210,6 +3215,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     (void)hipSetDevice(c->device);
     unborrow_level0(c);
     for (DevBuf& b : c->spare) b.release();
+    for (DevBuf& b : c->spare_out) b.release();
     c->cur.release(); c->nxt.release(); c->tmp.release();
     DevBuf* part_bufs[] = {&c->gid, &c->gid_next, &c->rec_loc, &c->gid_loc, &c->ghost_sh, &c->ghost_src, &c->perm, &c->pown, &c->ppos_own, &c->inv, &c->gmax, &c->gacc,
                            &c->cmask, &c->dflag, &c->dpos, &c->sent_idx, &c->rows_send, &c->rows_recv, &c->sh_send, &c->xsend, &c->xrecv, &c->gbits, &c->wcnt, &c->wpre,
@@ -3351,6 +3357,16 @@ int32_t gsr_hem_set_level0_part(gsr_hem_ctx* c, const float* xyz, const float* c
     hipLaunchKernelGGL(k_gather_bytes, dim3(stride_grid(n_own)), dim3(256), 0, st, n_own, c->gid.as<unsigned>(), c->allflags.as<uint8_t>(), c->cur.is_parent.as<uint8_t>());
     GSR_HIP(hipStreamSynchronize(st));
     c->n_global = n_global;
+    return GSR_OK;
+}
+
+int32_t gsr_hem_set_output(gsr_hem_ctx* c, float* xyz, float* color, float* cov6, float* opacity, float* sh, int64_t capacity_rows) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_hem_set_output: NULL context");
+    if (capacity_rows <= 0 || !xyz) { c->out_pending = false; return GSR_OK; }          // (clears a pending request)
+    if (!color || !cov6 || !opacity) return fail(GSR_E_INVALID, "gsr_hem_set_output: NULL array");
+    c->out_ptr[0] = xyz; c->out_ptr[1] = color; c->out_ptr[2] = cov6; c->out_ptr[3] = opacity; c->out_ptr[4] = sh;
+    c->out_rows = capacity_rows;
+    c->out_pending = true;
     return GSR_OK;
 }
 
@@ -4172,6 +4188,24 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     const int64_t n_pre = (int64_t)P + n_orph;
 
     Level& O = c->nxt;
+    // gsr_hem_set_output: the new level goes straight into the caller's arrays (no copy out afterwards, none into the next level)
+    struct OutGuard {               // an error return below hands nxt its own buffers back
+        gsr_hem_ctx* c; bool active;
+        ~OutGuard() { if (active) for (int i = 0; i < 5; ++i) { DevBuf* b = level_big(c->nxt, i); b->p = nullptr; b->cap = 0; b->swap(c->spare_out[i]); } }
+    } out_guard{c, false};
+    if (c->out_pending) {
+        c->out_pending = false;                                 // one request, one level
+        if (n_pre > c->out_rows) return fail(GSR_E_INVALID, "gsr_hem_run_level: the output arrays hold %lld rows, the level has %lld", (long long)c->out_rows, (long long)n_pre);
+        if (F > 0 && !c->out_ptr[4]) return fail(GSR_E_INVALID, "gsr_hem_run_level: the output has no SH array but the level has F = %d", F);
+        if (n_pre > 0) {
+            for (int i = 0; i < 5; ++i) {
+                DevBuf* b = level_big(O, i);
+                b->swap(c->spare_out[i]);
+                b->p = c->out_ptr[i] ? c->out_ptr[i] : c->out_ptr[0]; b->cap = (size_t)-1;       // reserve() on them is a no-op
+            }
+            out_guard.active = true;
+        }
+    }
     GSR_TRY(O.reserve(n_pre, F));
     O.n = n_pre; O.F = F;
     // the new level's parent flags depend on nothing but the stream position and n_pre: drawn on the second stream beside the
@@ -4334,6 +4368,14 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             if (F > 0)
                 hipLaunchKernelGGL(k_compact_rows4, dim3(stride_grid(n_pre * ((F + 3) / 4))), blk, 0, st, n_pre, F, keep, pos, O.sh.as<float>(), T.sh.as<float>());
             hipLaunchKernelGGL(k_compact_bytes, g2, blk, 0, st, n_pre, keep, pos, O.is_parent.as<uint8_t>(), T.is_parent.as<uint8_t>());
+            if (out_guard.active) {     // the caller's arrays stay the level's home: the compacted rows are copied back into them
+                const size_t row_bytes[5] = {12, 12, 24, 4, (size_t)F * 4};
+                for (int i = 0; i < 5; ++i)
+                    if (row_bytes[i] > 0 && n_keep > 0)
+                        GSR_HIP(hipMemcpyAsync(level_big(O, i)->p, level_big(T, i)->p, (size_t)n_keep * row_bytes[i], hipMemcpyDeviceToDevice, st));
+                O.weight.swap(T.weight); O.is_parent.swap(T.is_parent);
+                O.n = n_keep;
+            } else
             O.swap(T);
         }
     }
@@ -4344,6 +4386,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     GSR_HIP(hipStreamSynchronize(st));
     unborrow_level0(c);                 // a borrowed level 0 goes back to the caller; cur gets its own buffers again
     c->cur.swap(c->nxt);
+    if (out_guard.active) {             // the new current level lives in the caller's arrays: borrowed, its own buffers parked in spare
+        out_guard.active = false;
+        for (int i = 0; i < 5; ++i) c->spare[i].swap(c->spare_out[i]);
+        c->cur_borrowed = true;
+    }
     if (part) { c->gid.swap(c->gid_next); c->n_global = n_glob_next; }
     c->stats[3] = dropped;
     c->stats[7] = c->cur.n;

@@ -101,6 +101,65 @@ __global__ __launch_bounds__(256) void k_icp_bbox_reduce(int nblocks, const floa
     }
 }
 
+// A robust box for the grid.  The reference's scenes come with floaters: a dozen points at 50 scene radii make the box of ALL points
+// 10^5 times the scene's volume, the cells -- sized for two points each over that box -- swallow the scene whole, and every query
+// scans millions of points (found with bench.py --workload clustered: 116 s per registration).  So: per-axis histograms over the raw
+// box (ICP_HIST_BINS bins), the range that holds all but the outermost 0.1 % of the points per side; when that range is less than
+// half the raw extent on some axis the grid is laid over it (after ONE refinement pass at the finer resolution), and the points
+// beyond are clamped into the boundary cells, which every search treats as half-infinite (icp_slab_dist; the ring logic skips the
+// boundary faces anyway).  A cloud without outliers keeps the raw box: nothing changes for it.
+#define ICP_HIST_BINS 1024
+__global__ __launch_bounds__(256) void k_icp_hist(int64_t n, const float* __restrict__ xyz, const float* __restrict__ box, unsigned* __restrict__ hist) {
+    __shared__ unsigned s_h[3 * ICP_HIST_BINS];
+    for (int k = threadIdx.x; k < 3 * ICP_HIST_BINS; k += blockDim.x) s_h[k] = 0u;
+    __syncthreads();
+    float mn[3], sc[3];
+    for (int k = 0; k < 3; ++k) {
+        mn[k] = box[k];
+        const float ext = box[3 + k] - mn[k];
+        sc[k] = ext > 0.0f ? (float)ICP_HIST_BINS / ext : 0.0f;
+    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v[3] = {xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]};
+        if (fabsf(v[0]) <= FLT_MAX && fabsf(v[1]) <= FLT_MAX && fabsf(v[2]) <= FLT_MAX) {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float t = (v[k] - mn[k]) * sc[k];
+                t = fminf(fmaxf(t, 0.0f), (float)(ICP_HIST_BINS - 1));
+                atomicAdd(&s_h[k * ICP_HIST_BINS + (int)t], 1u);
+            }
+        }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < 3 * ICP_HIST_BINS; k += blockDim.x)
+        if (s_h[k]) atomicAdd(&hist[k], s_h[k]);
+}
+// box_out = per axis the bins [lo, hi] of box_in that hold all but the outermost 0.1 % of the points per side, widened by one bin on
+// either side; *flag = 1 when on some axis that is less than half of box_in's extent.  One thread per axis.
+__global__ void k_icp_trim(const unsigned* __restrict__ hist, const float* __restrict__ box_in, float* __restrict__ box_out, float* __restrict__ flag) {
+    __shared__ int s_narrow[3];
+    if (threadIdx.x < 3) {
+        const int k = threadIdx.x;
+        const unsigned* h = hist + k * ICP_HIST_BINS;
+        unsigned long long total = 0;
+        for (int b = 0; b < ICP_HIST_BINS; ++b) total += h[b];
+        const unsigned long long trim = total / 1000ull;
+        int lo = 0, hi = ICP_HIST_BINS - 1;
+        unsigned long long acc = 0;
+        while (lo < ICP_HIST_BINS - 1 && acc + h[lo] <= trim) { acc += h[lo]; ++lo; }
+        acc = 0;
+        while (hi > lo && acc + h[hi] <= trim) { acc += h[hi]; --hi; }
+        const float mn = box_in[k], ext = box_in[3 + k] - mn, w = ext / (float)ICP_HIST_BINS;
+        lo = lo > 0 ? lo - 1 : 0;
+        hi = hi < ICP_HIST_BINS - 1 ? hi + 1 : ICP_HIST_BINS - 1;
+        box_out[k] = mn + (float)lo * w;
+        box_out[3 + k] = mn + (float)(hi + 1) * w;
+        s_narrow[k] = (float)(hi + 1 - lo) * w < 0.5f * ext ? 1 : 0;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) *flag = (s_narrow[0] | s_narrow[1] | s_narrow[2]) ? 1.0f : 0.0f;
+}
+
 __global__ __launch_bounds__(256) void k_icp_keys(int64_t n, const float* __restrict__ xyz, IcpGrid g,
                                                   unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
@@ -183,9 +242,11 @@ __device__ __forceinline__ void icp_scan_span(const int* __restrict__ cellStart,
 
 // Distance from coordinate v to the slab of cell k along one axis (0 inside), shrunk by a relative 1e-9 so that the
 // float64 rounding of the cell classification can never make a bound too large.
-__device__ __forceinline__ double icp_slab_dist(double v, double o, double c, int k, double eps) {
+// The first and the last cell of an axis also hold every point CLAMPED in from beyond the grid's box (the box is a robust one when
+// the cloud has far outliers, gsr_icp_set_target): they are half-infinite slabs.
+__device__ __forceinline__ double icp_slab_dist(double v, double o, double c, int k, double eps, int g) {
     const double lo = o + (double)k * c, hi = o + (double)(k + 1) * c;
-    const double d = (v < lo ? lo - v : (v > hi ? v - hi : 0.0)) * 0.999999999 - eps;
+    const double d = ((v < lo && k > 0) ? lo - v : ((v > hi && k < g - 1) ? v - hi : 0.0)) * 0.999999999 - eps;
     return d > 0.0 ? d : 0.0;
 }
 
@@ -267,7 +328,7 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
             const int z = cz + dz;
             if (z < 0 || z >= g.gz) continue;
             const int adz = dz < 0 ? -dz : dz;
-            const double dzb = icp_slab_dist(pz, g.oz, g.c, z, eps);
+            const double dzb = icp_slab_dist(pz, g.oz, g.c, z, eps, g.gz);
             for (int dy = -r; dy <= r; ++dy) {
                 const int y = cy + dy;
                 if (y < 0 || y >= g.gy) continue;
@@ -275,7 +336,7 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
                 // prune by the best so far: every point of this row is at least (dyb, dzb) away in y / z, and a cell
                 // at x-distance dxb adds that.  STRICT comparisons: a candidate at exactly the best distance can still
                 // win the tie on its index, so only cells that are strictly farther are skipped.
-                const double dyb = icp_slab_dist(py, g.oy, g.c, y, eps);
+                const double dyb = icp_slab_dist(py, g.oy, g.c, y, eps, g.gy);
                 const double rem = bd - dyb * dyb - dzb * dzb;
                 if (rem < 0.0) continue;
                 int xlo = 0, xhi = g.gx - 1;
@@ -1398,6 +1459,9 @@ struct gsr_icp_ctx {
     int nn_mode() const { return nn_kernel >= 0 ? (nn_kernel ? 2 : 0) : (ns >= 400000 ? 2 : 0); }
     double cell_target = 2.0;       // target points per grid cell (GSR_ICP_CELL_TARGET).  Measured at 5M x 5M: 0.5 makes a
                                     // converged iteration 1.7x faster but a cold start (offsets ~ max_corr) 1.6x slower: keep 2
+    DevBuf hist;
+    bool robust_box = false;        // the current target's grid lies over the trimmed box (far outliers clamped into the boundary cells)
+    bool robust_allowed = true;     // GSR_ICP_ROBUST_BOX=0: always the box of all points (test knob: results must not change)
     DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
     gsr_allreduce_fn allreduce = nullptr;
     void* allreduce_user = nullptr;
@@ -1533,6 +1597,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_XCD")) c->xcd_ranges = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_ROBUST_BOX")) c->robust_allowed = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_FUSED_STEP")) c->fused_step = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->nblocks = v; }
     // pinned, device-mapped, COHERENT host memory: the device's system-scope stores must reach the host while the stream is still
@@ -1551,7 +1616,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
 int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
     if (!c) return GSR_OK;
     (void)hipSetDevice(c->device);
-    DevBuf* all[] = {&c->ticket, &c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->Tc, &c->Sc, &c->stage_cov, &c->Ti, &c->Tg, &c->Si, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
+    DevBuf* all[] = {&c->hist, &c->ticket, &c->src_raw, &c->src_order, &c->state, &c->nn_j, &c->Tc, &c->Sc, &c->stage_cov, &c->Ti, &c->Tg, &c->Si, &c->bbox, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->Tq, &c->Tn, &c->stage_xyz, &c->stage_nrm,
                      &c->src, &c->partials, &c->acc_dev, &c->rocprim_tmp, &c->corr_idx, &c->corr_d2};
     for (DevBuf* b : all) b->release();
     if (c->e0) (void)hipEventDestroy(c->e0);
@@ -1586,8 +1651,20 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     GSR_TRY(c->bbox.reserve(64 + (size_t)nbb * 24));
     hipLaunchKernelGGL(k_icp_bbox, dim3(nbb), dim3(256), 0, st, n, dxyz, c->bbox.as<float>() + 16);
     hipLaunchKernelGGL(k_icp_bbox_reduce, dim3(1), dim3(256), 0, st, nbb, c->bbox.as<float>() + 16, c->bbox.as<float>());
-    float hb[6];
-    GSR_TRY(icp_fetch(c, c->bbox.p, hb, sizeof(hb)));
+    // the robust candidate of the raw box: header floats [0..5] raw, [6..11] trimmed, [12] "the raw box is far too large"
+    GSR_TRY(c->hist.reserve(3 * ICP_HIST_BINS * 4));
+    GSR_HIP(hipMemsetAsync(c->hist.p, 0, 3 * ICP_HIST_BINS * 4, st));
+    hipLaunchKernelGGL(k_icp_hist, dim3(nbb > 512 ? 512 : nbb), dim3(256), 0, st, n, dxyz, c->bbox.as<float>(), c->hist.as<unsigned>());
+    hipLaunchKernelGGL(k_icp_trim, dim3(1), dim3(64), 0, st, c->hist.as<unsigned>(), c->bbox.as<float>(), c->bbox.as<float>() + 6, c->bbox.as<float>() + 12);
+    float hb[13];
+    GSR_TRY(icp_fetch(c, c->bbox.p, hb, 13 * 4));
+    c->robust_box = hb[12] != 0.0f && c->robust_allowed;
+    if (c->robust_box) {        // far outliers: one refinement at the resolution of the trimmed range, then the grid goes over THAT
+        GSR_HIP(hipMemsetAsync(c->hist.p, 0, 3 * ICP_HIST_BINS * 4, st));
+        hipLaunchKernelGGL(k_icp_hist, dim3(nbb > 512 ? 512 : nbb), dim3(256), 0, st, n, dxyz, c->bbox.as<float>() + 6, c->hist.as<unsigned>());
+        hipLaunchKernelGGL(k_icp_trim, dim3(1), dim3(64), 0, st, c->hist.as<unsigned>(), c->bbox.as<float>() + 6, c->bbox.as<float>(), c->bbox.as<float>() + 12);
+        GSR_TRY(icp_fetch(c, c->bbox.p, hb, 6 * 4));
+    }
     double mn[3], mx[3];
     for (int k = 0; k < 3; ++k) { mn[k] = hb[k]; mx[k] = hb[3 + k]; }
     IcpGrid g;

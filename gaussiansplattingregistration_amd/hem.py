@@ -57,6 +57,7 @@ class HemMixture:
         _lib.check(self._L.gsr_hem_create(C.byref(h), self.device, C.c_void_p(stream or 0)), "gsr_hem_create")
         self._h = h
         self._borrowed = None
+        self._out_cur = self._out_prev = None           # run_level(out=...): the caller's tensors the current / the previous level lives in
         _lib.check(self._L.gsr_hem_set_params(h, hem_reduction, distance_delta, color_delta, decay_rate), "gsr_hem_set_params")
         mode = {"glibc": _lib.GSR_RNG_GLIBC, "hash": _lib.GSR_RNG_HASH}[rng_mode]
         _lib.check(self._L.gsr_hem_set_rng(h, mode, rng_seed, rng_skip), "gsr_hem_set_rng")
@@ -153,6 +154,7 @@ class HemMixture:
         mode = (2 if borrow else 1) if dx else 0
         _lib.check(self._L.gsr_hem_set_level0(self._h, px, pc, pv, po, ps, n, F, mode), "gsr_hem_set_level0")
         self._borrowed = (kx, kc, kv, ko, ks) if mode == 2 else None
+        self._out_cur = self._out_prev = None
         del kx, kc, kv, ko, ks
 
     # -- spatially partitioned levels (one large cloud over several GPUs) ------------------------------------------------
@@ -184,6 +186,7 @@ class HemMixture:
             kg = np.ascontiguousarray(gid.cpu().numpy() if _is_tensor(gid) else gid, dtype=np.uint32)
             pg = kg.ctypes.data
         _lib.check(self._L.gsr_hem_set_level0_part(self._h, px, pc, pv, po, ps, pg, n, int(n_global), F, 1 if dx else 0), "gsr_hem_set_level0_part")
+        self._out_cur = self._out_prev = None
 
     def gids(self):
         """Global indices (uint32 numpy) of the current partitioned level's owned rows."""
@@ -206,12 +209,38 @@ class HemMixture:
                                              None if w is None else w.ctypes.data), "gsr_hem_set_state")
 
     # -- levels ------------------------------------------------------------------------------------
-    def run_level(self):
-        """One ``createClusterLevel``.  Returns ``(n_out, n_dropped)``."""
+    def run_level(self, out=None):
+        """One ``createClusterLevel``.  Returns ``(n_out, n_dropped)``.
+
+        ``out``: a dict of CUDA float32 tensors ``xyz (R,3) color (R,3) cov6 (R,6) opacity (R,) sh (R,F)`` with R >= the size of the level
+        being reduced -- the new level is written straight into them (``gsr_hem_set_output``) and they then ARE the current level: no
+        copy on the way out, none on the way into the next level; ``get_level(as_torch=True)`` afterwards returns views of their first
+        ``n_out`` rows.  They must stay untouched until the ``run_level`` after this one has returned (this object keeps them alive)."""
         n_out, n_drop = C.c_int64(0), C.c_int64(0)
+        if out is not None:
+            rows = int(out["xyz"].shape[0])
+            for k, w in (("xyz", 3), ("color", 3), ("cov6", 6), ("opacity", 1), ("sh", self.F)):
+                t = out.get(k)
+                if w == 0 and k == "sh":
+                    continue
+                if t is None or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != rows * w or t.device.index != self.device:
+                    raise RuntimeError(f"run_level(out=...): '{k}' must be a contiguous float32 CUDA tensor of {rows} x {w} on cuda:{self.device}")
+            torch.cuda.current_stream(self.device).synchronize()
+            sh = out["sh"].data_ptr() if self.F > 0 else None
+            _lib.check(self._L.gsr_hem_set_output(self._h, out["xyz"].data_ptr(), out["color"].data_ptr(), out["cov6"].data_ptr(), out["opacity"].data_ptr(),
+                                                  sh, rows), "gsr_hem_set_output")
         _lib.check(self._L.gsr_hem_run_level(self._h, C.byref(n_out), C.byref(n_drop)), "gsr_hem_run_level")
         self._borrowed = None                       # a borrowed level 0 has been consumed
+        self._out_prev = getattr(self, "_out_cur", None)         # (the level just consumed: free to go once this call has returned)
+        self._out_cur = out
         return int(n_out.value), int(n_drop.value)
+
+    def new_output(self, rows=None):
+        """Uninitialised output arrays for ``run_level(out=...)``: ``rows`` defaults to the current level's size (always enough)."""
+        rows = self.size if rows is None else int(rows)
+        dev = torch.device("cuda", self.device)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        return {"xyz": e(rows, 3), "color": e(rows, 3), "cov6": e(rows, 6), "opacity": e(rows), "sh": e(rows, self.F)}
 
     @property
     def size(self):
@@ -222,6 +251,15 @@ class HemMixture:
     def get_level(self, as_torch=False, with_state=False):
         """Current level as a dict of arrays: xyz, color, cov6, opacity, sh (+ weight, is_parent)."""
         n, F = self.size, self.F
+        cur = getattr(self, "_out_cur", None)
+        if as_torch and cur is not None:            # the level already lives in the caller's tensors (run_level(out=...)): views, no copy
+            out = {k: cur[k][:n] for k in ("xyz", "color", "cov6", "opacity", "sh")}
+            if with_state:
+                dev = torch.device("cuda", self.device)
+                out["weight"] = torch.empty((n,), dtype=torch.float32, device=dev)
+                out["is_parent"] = torch.empty((n,), dtype=torch.uint8, device=dev)
+                _lib.check(self._L.gsr_hem_get_level(self._h, None, None, None, None, None, out["weight"].data_ptr(), out["is_parent"].data_ptr(), 1), "gsr_hem_get_level")
+            return out
         if as_torch:
             dev = torch.device("cuda", self.device)
             out = {"xyz": torch.empty((n, 3), dtype=torch.float32, device=dev),

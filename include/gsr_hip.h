@@ -173,6 +173,16 @@ int32_t gsr_hem_get_part_stats(gsr_hem_ctx* ctx, int64_t* out8);
  * [1] the SH rows (second stream, overlapped)  [2], [3] reserved */
 int32_t gsr_hem_get_part_ms(gsr_hem_ctx* ctx, float* out4);
 
+/* Zero-copy level output ("returning torch tensors, zero-copy on device"): the NEXT gsr_hem_run_level writes its level
+ * straight into these caller-owned DEVICE arrays -- xyz[rows*3], color[rows*3], cov6[rows*6], opacity[rows], sh[rows*F] (sh may be
+ * NULL when F = 0) -- instead of the context's own buffers, and that memory then IS the current level (borrowed exactly like an
+ * on_device = 2 level 0): nothing is copied on the way out, nothing on the way into the level after.  capacity_rows >= the size of
+ * the level being reduced is always enough (a level never grows); the call fails cleanly if the new level does not fit.  The
+ * arrays hold the level when run_level returns (n_out rows) and must stay valid and unchanged until the run_level AFTER that one
+ * (or gsr_hem_set_level0 / destroy) has returned.  One request covers one level; capacity_rows <= 0 withdraws it.
+ * (The reference copies every level by value, mixture.cpp:342, and then into Python lists, mixturelevel.cpp:30-70.) */
+int32_t gsr_hem_set_output(gsr_hem_ctx* ctx, float* xyz, float* color, float* cov6, float* opacity, float* sh, int64_t capacity_rows);
+
 /* One clustering level on the current level (Mixture::createClusterLevel, mixture.cpp:66-285).
  * n_out = components of the new level (after the validity erase); n_dropped = components erased by
  * it (the reference prints these to cerr, mixture.cpp:270-274).  The new level becomes current. */

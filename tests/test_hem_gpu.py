@@ -336,6 +336,43 @@ def test_mstep_heavy_parent_split_changes_nothing(monkeypatch):
             assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (k, f)
 
 
+@pytest.mark.parametrize("shape,deg", [("iso", 3), ("aniso", 1), ("iso", 0)])
+def test_zero_copy_level_output_equals_the_copied_levels(shape, deg):
+    """``run_level(out=...)`` / ``gsr_hem_set_output``: a level is written straight into the caller's tensors, which then ARE the current
+    level (borrowed) -- no copy out, none into the next level.  Three levels that way are bit for bit the levels of the copying path
+    (the surfel cloud drops components in the validity erase: the compacted rows must land in the caller's arrays too); the returned
+    tensors are views of the caller's, a too small output is refused cleanly, and the context carries on afterwards."""
+    import torch
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(90000, seed=91, sh_degree=deg, shape=shape)
+    if shape == "aniso":
+        c["cov6"][11] = [1.0, 0, 0, 1.0, 0, -1.0]            # a component the validity erase drops
+    want, wst = hem.create_mixture(c, 3, with_state=True)
+    dc = {k: torch.from_numpy(c[k]).cuda() for k in ("xyz", "color", "opacity", "cov6", "sh")}
+    with hem.HemMixture() as m:
+        m.set_level0(dc["xyz"], dc["color"], dc["opacity"], dc["cov6"], dc["sh"], borrow=True)
+        outs = []
+        for k in range(3):
+            out = m.new_output()
+            n_out, dropped = m.run_level(out=out)
+            got = m.get_level(as_torch=True, with_state=True)
+            assert got["xyz"].data_ptr() == out["xyz"].data_ptr() and got["sh"].data_ptr() == out["sh"].data_ptr()      # views, not copies
+            assert n_out == want[k]["xyz"].shape[0] and dropped == wst[k]["dropped"]
+            outs.append(got)
+        for k in range(3):          # every level is still intact in its own tensors after the later levels ran
+            for f in ("xyz", "color", "cov6", "opacity", "sh", "weight", "is_parent"):
+                assert np.array_equal(outs[k][f].cpu().numpy(), want[k][f]), (k, f)
+        if shape == "aniso":
+            assert sum(s_["dropped"] for s_ in wst) >= 1
+        # an output that cannot hold the level: an error, nothing written past its end, and the context still works
+        m.set_level0(dc["xyz"], dc["color"], dc["opacity"], dc["cov6"], dc["sh"])
+        with pytest.raises(RuntimeError, match="output arrays hold"):
+            m.run_level(out=m.new_output(rows=10))
+        m.set_level0(dc["xyz"], dc["color"], dc["opacity"], dc["cov6"], dc["sh"])
+        m.run_level()
+        assert np.array_equal(m.get_level()["xyz"], want[0]["xyz"])
+
+
 def test_two_contexts_on_two_threads_equal_each_alone():
     """bench.py runs the HEM levels of the pair's two clouds side by side: two contexts on two streams, driven by two host threads
     (the C ABI releases the GIL; a context owns every buffer it touches, the error message is thread-local).  Each cloud's levels

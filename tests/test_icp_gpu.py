@@ -347,3 +347,60 @@ def test_library_communicator_world1_rccl_and_side_stream():
         a, b = out["plain"], out["comm"]
         assert np.array_equal(a["transformation"], b["transformation"]) and a["iterations"] == b["iterations"] > 3
         assert a["fitness"] == b["fitness"] and a["inlier_rmse"] == b["inlier_rmse"]
+
+
+@pytest.mark.parametrize("max_corr", [0.08, 0.3, 1.5])
+def test_far_outliers_keep_the_grid_robust_and_the_search_exact(oracle, monkeypatch, max_corr):
+    """Scenes come with floaters: a dozen target points at 50 scene radii made the box of ALL points 10^5 times the scene's volume and
+    the grid's cells swallowed the scene (bench.py --workload clustered: 116 s per registration).  The grid now lies over the box
+    that holds all but 0.1 % of the points per side; the points beyond are clamped into the boundary cells, which the search treats
+    as half-infinite.  The correspondences stay EXACT -- equal to the oracle's KD-tree and to the search over the raw box
+    (GSR_ICP_ROBUST_BOX=0) -- also for queries far outside, for outliers that are each other's neighbours, and for targets sitting
+    just outside the trimmed box; the registration equals the oracle's."""
+    from gaussiansplattingregistration_amd import icp, synth
+    src, tgt, T_gt = synth.make_pair(60000, seed=11, sh_degree=0, angle_deg=1.0)
+    rng = np.random.default_rng(4)
+    h = tgt["h"]
+    tx, sx = tgt["xyz"].copy(), src["xyz"].copy()
+    far = (rng.uniform(20.0, 60.0, (12, 1)) * h * rng.choice([-1.0, 1.0], (12, 3))).astype(np.float32)
+    tx[:12] = far                                               # floaters in the target ...
+    sx[100:106] = far[:6] + rng.normal(0, 0.02, (6, 3)).astype(np.float32)      # ... some of them with a source point right beside them
+    sx[200:203] = far[6:9] * 1.5                                # ... and source points far from everything
+    tx[300:340] = (tx[300:340] * 1.08).astype(np.float32)       # targets just outside the trimmed box
+    T = np.eye(4); T[:3, 3] = 0.01
+    res = {}
+    for knob in ("1", "0"):
+        monkeypatch.setenv("GSR_ICP_ROBUST_BOX", knob)
+        with icp.IcpContext() as c:
+            c.set_target(tx, None, max_corr)
+            c.set_source(sx)
+            res[knob] = c.correspondences(T)
+    widx, wd2 = oracle.icp_correspond(sx, tx, T, max_corr)
+    for knob in ("1", "0"):
+        assert np.array_equal(res[knob][0], widx), (knob, int((res[knob][0] != widx).sum()))
+        assert np.allclose(res[knob][1], wd2, rtol=1e-12, atol=0)
+    assert (widx[100:106] >= 0).all() and (widx[100:106] < 12).all()            # the floaters' companions found them
+    monkeypatch.setenv("GSR_ICP_ROBUST_BOX", "1")
+    nrm = icp.normals_from_cov(tgt["cov6"])
+    r = icp.registration_icp_arrays(sx, tx, nrm, np.eye(4), kind=1, max_corr=max_corr, max_iter=15)
+    w = oracle.icp(sx, tx, nrm, np.eye(4), kind=1, max_corr=max_corr, max_iter=15)
+    assert r["iterations"] == w["iterations"] and np.linalg.norm(r["transformation"] - w["transformation"]) < 1e-5
+    assert abs(r["fitness"] - w["fitness"]) < 1e-9
+
+
+def test_registration_time_does_not_explode_with_floaters():
+    """The symptom itself: 400 k points + 12 floaters at 20-60 h register in milliseconds, not seconds."""
+    import time
+    from gaussiansplattingregistration_amd import icp, synth
+    src, tgt, _ = synth.make_pair(400000, seed=12, sh_degree=0, angle_deg=1.0)
+    rng = np.random.default_rng(5)
+    far = (rng.uniform(20.0, 60.0, (12, 1)) * tgt["h"] * rng.choice([-1.0, 1.0], (12, 3))).astype(np.float32)
+    tx, sx = tgt["xyz"].copy(), src["xyz"].copy()
+    tx[:12] = far
+    sx[50:62] = far * 0.9
+    nrm = icp.normals_from_cov(tgt["cov6"])
+    icp.registration_icp_arrays(sx, tx, nrm, np.eye(4), kind=1, max_corr=0.2, max_iter=5)      # warm-up (allocation)
+    t = time.perf_counter()
+    r = icp.registration_icp_arrays(sx, tx, nrm, np.eye(4), kind=1, max_corr=0.2, max_iter=10)
+    dt = time.perf_counter() - t
+    assert r["fitness"] > 0.9 and dt < 0.5, (r["fitness"], dt)
