@@ -183,6 +183,18 @@ __global__ __launch_bounds__(256) void k_icp_cell_starts(int64_t m, const unsign
     }
 }
 
+// sum over the cells of (points in the cell)^2 = n * (the occupancy of the cell an average POINT sits in): 3 for a uniform cloud at two
+// points per cell, hundreds when most points sit in clumps the box-volume rule does not see
+__global__ __launch_bounds__(256) void k_icp_occupancy(int64_t ncells, const int* __restrict__ cellStart, unsigned long long* __restrict__ out) {
+    unsigned long long acc = 0;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < ncells; k += (int64_t)gridDim.x * blockDim.x) {
+        const unsigned long long len = (unsigned long long)(cellStart[k + 1] - cellStart[k]);
+        acc += len * len;
+    }
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
 __global__ __launch_bounds__(256) void k_icp_gather_target(int64_t n, const unsigned* __restrict__ order,
                                                            const float* __restrict__ xyz, const double* __restrict__ nrm,
                                                            float4* __restrict__ Tq, double* __restrict__ Tn) {
@@ -1461,6 +1473,8 @@ struct gsr_icp_ctx {
                                     // converged iteration 1.7x faster but a cold start (offsets ~ max_corr) 1.6x slower: keep 2
     DevBuf hist;
     bool robust_box = false;        // the current target's grid lies over the trimmed box (far outliers clamped into the boundary cells)
+    bool adapt_cells = false;       // GSR_ICP_ADAPT=1: a finer grid when the points are clumped (experiment)
+    double occupancy = 0.0;         // of the cell an average point sits in (measured when adapt_cells)
     bool robust_allowed = true;     // GSR_ICP_ROBUST_BOX=0: always the box of all points (test knob: results must not change)
     DevBuf bbox, keys, idx, skeys, order, cellStart, Tq, Tn, stage_xyz, stage_nrm, src, partials, acc_dev, rocprim_tmp, corr_idx, corr_d2;
     gsr_allreduce_fn allreduce = nullptr;
@@ -1598,6 +1612,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_XCD")) c->xcd_ranges = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_ROBUST_BOX")) c->robust_allowed = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_ADAPT")) c->adapt_cells = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_FUSED_STEP")) c->fused_step = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->nblocks = v; }
     // pinned, device-mapped, COHERENT host memory: the device's system-scope stores must reach the host while the stream is still
@@ -1678,30 +1693,47 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
         if (!(cell > 0)) cell = max_corr;
         if (cell < max_corr / 8.0) cell = max_corr / 8.0;
     }
-    for (;;) {
-        double fx = floor((mx[0] - mn[0]) / cell) + 1, fy = floor((mx[1] - mn[1]) / cell) + 1, fz = floor((mx[2] - mn[2]) / cell) + 1;
-        if (fx * fy * fz <= (double)c->max_cells) { g.gx = (int)fx; g.gy = (int)fy; g.gz = (int)fz; break; }
-        cell *= 1.2599210498948732;
-    }
-    g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
-    g.c = cell; g.inv_c = 1.0 / cell;
-    g.cx = 0.5 * (mn[0] + mx[0]); g.cy = 0.5 * (mn[1] + mx[1]); g.cz = 0.5 * (mn[2] + mx[2]);
-    g.ncells = g.gx * g.gy * g.gz;
-    g.rings = (int)ceil(max_corr / cell);
-    if (g.rings < 1) g.rings = 1;
-    c->grid = g;
     GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->order.reserve(n * 4));
-    hipLaunchKernelGGL(k_icp_keys, dim3(stride_grid(n)), dim3(256), 0, st, n, dxyz, g, c->keys.as<unsigned>(), c->idx.as<unsigned>());
-    int bits = 1;
-    while (bits < 32 && ((int64_t)1 << bits) < g.ncells) ++bits;
-    size_t bytes = 0;
-    GSR_HIP(rocprim::radix_sort_pairs<icp_sort_cfg>(nullptr, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
-                                      c->order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
-    GSR_TRY(c->rocprim_tmp.reserve(bytes));
-    GSR_HIP(rocprim::radix_sort_pairs<icp_sort_cfg>(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
-                                      c->order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
-    GSR_TRY(c->cellStart.reserve(((size_t)g.ncells + 1) * 4));
-    hipLaunchKernelGGL(k_icp_cell_starts, dim3(stride_grid(n)), dim3(256), 0, st, n, c->skeys.as<unsigned>(), (int64_t)g.ncells, c->cellStart.as<int>());
+    c->occupancy = 0.0;
+    for (int attempt = 0;; ++attempt) {
+        for (;;) {
+            double fx = floor((mx[0] - mn[0]) / cell) + 1, fy = floor((mx[1] - mn[1]) / cell) + 1, fz = floor((mx[2] - mn[2]) / cell) + 1;
+            if (fx * fy * fz <= (double)c->max_cells) { g.gx = (int)fx; g.gy = (int)fy; g.gz = (int)fz; break; }
+            cell *= 1.2599210498948732;
+        }
+        g.ox = mn[0]; g.oy = mn[1]; g.oz = mn[2];
+        g.c = cell; g.inv_c = 1.0 / cell;
+        g.cx = 0.5 * (mn[0] + mx[0]); g.cy = 0.5 * (mn[1] + mx[1]); g.cz = 0.5 * (mn[2] + mx[2]);
+        g.ncells = g.gx * g.gy * g.gz;
+        g.rings = (int)ceil(max_corr / cell);
+        if (g.rings < 1) g.rings = 1;
+        hipLaunchKernelGGL(k_icp_keys, dim3(stride_grid(n)), dim3(256), 0, st, n, dxyz, g, c->keys.as<unsigned>(), c->idx.as<unsigned>());
+        int bits = 1;
+        while (bits < 32 && ((int64_t)1 << bits) < g.ncells) ++bits;
+        size_t bytes = 0;
+        GSR_HIP(rocprim::radix_sort_pairs<icp_sort_cfg>(nullptr, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+                                          c->order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
+        GSR_TRY(c->rocprim_tmp.reserve(bytes));
+        GSR_HIP(rocprim::radix_sort_pairs<icp_sort_cfg>(c->rocprim_tmp.p, bytes, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(),
+                                          c->order.as<unsigned>(), (size_t)n, 0u, (unsigned)bits, st));
+        GSR_TRY(c->cellStart.reserve(((size_t)g.ncells + 1) * 4));
+        hipLaunchKernelGGL(k_icp_cell_starts, dim3(stride_grid(n)), dim3(256), 0, st, n, c->skeys.as<unsigned>(), (int64_t)g.ncells, c->cellStart.as<int>());
+        if (!c->adapt_cells || attempt >= 2) break;
+        // Clustered clouds: the box-volume rule gives two points per cell ON AVERAGE OVER THE BOX, and a scene whose points sit in
+        // clumps has hundreds in the cells that matter.  When the average point shares its cell with more than ICP_OCC_MAX others the
+        // grid is rebuilt finer (GSR_ICP_ADAPT=1; measured).
+        GSR_HIP(hipMemsetAsync(c->hist.p, 0, 8, st));
+        hipLaunchKernelGGL(k_icp_occupancy, dim3(stride_grid(g.ncells)), dim3(256), 0, st, (int64_t)g.ncells, c->cellStart.as<int>(), c->hist.as<unsigned long long>());
+        unsigned long long sumsq = 0;
+        GSR_TRY(icp_fetch(c, c->hist.p, &sumsq, 8));
+        c->occupancy = (double)sumsq / (double)n;
+        const double floor_cell = max_corr / 8.0;
+        if (!(c->occupancy > 12.0) || cell <= floor_cell * 1.0001 || (double)g.ncells * 1.9 > (double)c->max_cells) break;
+        double f = cbrt(4.0 / c->occupancy);
+        f = f < 0.4 ? 0.4 : f;
+        cell = fmax(cell * f, floor_cell);
+    }
+    c->grid = g;
     GSR_TRY(c->Tq.reserve((size_t)n * 16));
     if (normals) GSR_TRY(c->Tn.reserve((size_t)n * 24));
     hipLaunchKernelGGL(k_icp_gather_target, dim3(stride_grid(n)), dim3(256), 0, st, n, c->order.as<unsigned>(), dxyz, dnrm,

@@ -29,18 +29,30 @@ def _worker(rank, world, port, q, what, backend="gloo"):
     from gaussiansplattingregistration_amd.utils import local_registration_util as lru
     # gloo: the ranks share GPU 0 and the library's communicator runs over callbacks; nccl: one GPU per rank, the library calls
     # RCCL itself (ncclAllReduce / ncclAllGather / grouped ncclSend + ncclRecv on its own stream)
+    # "mock": gloo for the rendezvous, and the library's RCCL TRANSPORT (csrc/comm.hip: ncclAllReduce / ncclAllGather / grouped ncclSend +
+    # ncclRecv) over tests/mock_rccl -- a test double of librccl for processes that share one GPU, stricter than RCCL about mismatched calls
     dev = rank if backend == "nccl" else 0
     torch.cuda.set_device(dev)
-    parallel.init_distributed(backend)
-    transport = "rccl" if backend == "nccl" else "callbacks"
+    if backend == "mock":
+        os.environ["GSR_RCCL_LIB"] = _mock_rccl_path()
+    parallel.init_distributed("gloo" if backend == "mock" else backend)
+    transport = "callbacks" if backend == "gloo" else "rccl"
+    from gaussiansplattingregistration_amd.comm import Comm as _Comm
+
+    def make_comm():
+        if backend != "mock":
+            return _Comm.from_torch_group(dev)
+        box = [_Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return _Comm.rccl(box[0], rank, world, dev)
+
     out = {}
     if what == "icp":
         src, tgt, _ = synth.make_pair(60000, seed=3, sh_degree=0)
         s = PointCloud(xyz32=torch.from_numpy(src["xyz"]).cuda(), cov6=torch.from_numpy(src["cov6"]).cuda())
         t = PointCloud(xyz32=torch.from_numpy(tgt["xyz"]).cuda(), cov6=torch.from_numpy(tgt["cov6"]).cuda()).estimate_normals()
         crit = lru.get_convergence_criteria(1e-7, 1e-7, 25)
-        from gaussiansplattingregistration_amd.comm import Comm
-        cm = Comm.from_torch_group(dev)
+        cm = make_comm()
         assert cm is not None and cm.transport == transport and cm.world == world
         side = torch.cuda.Stream()
         for name, kind in (("p2p", lru.LocalRegistrationType.ICP_Point_To_Point), ("plane", lru.LocalRegistrationType.ICP_Point_To_Plane),
@@ -67,8 +79,7 @@ def _worker(rank, world, port, q, what, backend="gloo"):
                                               lru.get_convergence_criteria(1e-7, 1e-7, 3), rank, world, device=dev, comm=cm)
         out["tiny_gicp"] = (r.transformation, r.fitness, r.inlier_rmse, r.iterations)
     elif what == "part":
-        from gaussiansplattingregistration_amd.comm import Comm
-        cm = Comm.from_torch_group(dev)
+        cm = make_comm()
         assert cm.transport == transport
         for tag, c in _part_clouds(synth):
             if tag == "iso":                                   # a far-away giant: a long-range parent whose sphere crosses every slab
@@ -89,6 +100,18 @@ def _worker(rank, world, port, q, what, backend="gloo"):
     dist.destroy_process_group()
 
 
+def _mock_rccl_path():
+    """tests/mock_rccl/libmock_rccl.so, built on first use (hipcc; host code only)."""
+    import subprocess
+    d = os.path.join(ROOT, "tests", "mock_rccl")
+    src, lib = os.path.join(d, "mock_rccl.cpp"), os.path.join(d, "libmock_rccl.so")
+    if not os.path.exists(lib) or os.path.getmtime(lib) < os.path.getmtime(src):
+        hipcc = "/opt/rocm/bin/hipcc"
+        subprocess.check_call([hipcc, "-shared", "-fPIC", "-O1", "-std=c++17", src, "-o", lib + ".tmp%d" % os.getpid(), "-lrt"])
+        os.replace(lib + ".tmp%d" % os.getpid(), lib)
+    return lib
+
+
 def _part_clouds(synth):
     """The clouds of the partition test: SH degree 1 (F = 9), no SH at all, SH degree 3 (F = 45: 252-byte halo rows, the bench's shape),
     and a cloud with needles in which a component is parent AND orphan."""
@@ -104,7 +127,7 @@ def _part_clouds(synth):
 def _run(what, world=2, backend="gloo"):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000) + {"icp": 7, "part": 23}.get(what, 13) + (31 if backend == "nccl" else 0)
+    port = 29500 + (os.getpid() % 2000) + {"icp": 7, "part": 23}.get(what, 13) + {"nccl": 31, "mock": 47}.get(backend, 0)
     procs = [ctx.Process(target=_worker, args=(r, world, port, q, what, backend)) for r in range(world)]
     for p in procs:
         p.start()
@@ -221,3 +244,17 @@ def test_rccl_transport_partitioned_hem_is_bit_identical_to_one_gpu(world):
     """The spatially partitioned levels over RCCL: u32 MAX / SUM all-reduces, the in-place all-gather of the cell masks, the grouped
     ncclSend / ncclRecv halo exchange and the bit-map all-reduces, one GPU per rank -- bit for bit the one-GPU levels."""
     _check_partitioned(_run("part", world, backend="nccl"), world)
+
+
+# ---- the RCCL transport of the library with world > 1 on ONE GPU: tests/mock_rccl stands in for librccl (see its header).  What runs is
+# comm.hip's own RCCL code path -- the calls, their order, counts, types, peers, the in-place all-gather, the grouped send / recv --
+# under the real kernels; what does NOT run is RCCL itself (the >= 2-GPU tests above are for that).
+def test_mock_rccl_transport_sharded_icp_equals_single_process():
+    _mock_rccl_path()
+    _check_sharded_icp(_run("icp", 2, backend="mock"))
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_mock_rccl_transport_partitioned_hem_is_bit_identical_to_one_gpu(world):
+    _mock_rccl_path()
+    _check_partitioned(_run("part", world, backend="mock"), world)
