@@ -655,7 +655,7 @@ def main():
         l1_mst = float(np.mean([k["ms_k_mstep"] for k in lvl1])) if lvl1 else 0.0
         desc = {"k_select": "k_select<SPARSE> (child selection + likelihood, one wavefront per parent)",
                 "k_mstep": "k_mstep (responsibilities + moment matching: one 64-byte record and one 192-byte SH row gathered per pair)"}
-        pmc, pmc_note = pmc_summary({"k_select": "gsr::k_select<2, 2, false>", "k_mstep": "gsr::k_mstep<4, 1>"}[dom])
+        pmc, pmc_note = pmc_summary({"k_select": "gsr::k_select<2, 2, false>", "k_mstep": "gsr::k_mstep<4, 1, false>"}[dom])
         roof = {"bound": "hbm", "kernel": desc[dom],
                 "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "bytes_model": "SURVEY 8(d) bytes_level = n_in (57 + 4F + 16) + n_out (57 + 4F) of the launch's level, / launch duration",
