@@ -93,3 +93,35 @@ def test_block_partition_covers_the_cloud_once():
     for a in range(8):
         for b in range(a + 1, 8):      # two blocks are separated along at least one axis
             assert any(boxes[a][1][k] <= boxes[b][0][k] or boxes[b][1][k] <= boxes[a][0][k] for k in range(3)), (a, b)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 6, 8])
+def test_block_clouds_tile_the_scene(world):
+    """bench.py --mode c5 never materialises the large cloud: it is DEFINED block by block (synth.make_block_cloud_torch).  The blocks'
+    boxes tile the cube without gaps or overlaps, their global indices are the contiguous shard ranges (ascending, disjoint, n in all),
+    every block's splats lie inside its own box, and a rank's block does not depend on who else draws theirs (CPU tensors here)."""
+    import torch
+    from gaussiansplattingregistration_amd import parallel, synth
+    n = 12_345
+    h = synth.half_extent(n)
+    vol, gids = 0.0, []
+    for r in range(world):
+        lo, hi = synth.block_box(r, world, h)
+        assert (hi > lo).all() and (lo >= -h - 1e-9).all() and (hi <= h + 1e-9).all()
+        vol += float(np.prod(hi - lo))
+        c, gid = synth.make_block_cloud_torch(n, r, world, seed=3, device="cpu", sh_degree=1)
+        a, b = parallel.shard_range(n, r, world)
+        assert gid.dtype == torch.int32 and gid.tolist() == list(range(a, b)) and c["xyz"].shape == (b - a, 3) and c["sh"].shape == (b - a, 9)
+        x = c["xyz"].double().numpy()
+        assert (x >= lo - 1e-5).all() and (x <= hi + 1e-5).all()
+        c2, _ = synth.make_block_cloud_torch(n, r, world, seed=3, device="cpu", sh_degree=1)
+        assert torch.equal(c["xyz"], c2["xyz"]) and torch.equal(c["cov6"], c2["cov6"])
+        gids.append(gid)
+    assert abs(vol - (2 * h) ** 3) < 1e-6 * (2 * h) ** 3
+    assert torch.equal(torch.cat(gids), torch.arange(n, dtype=torch.int32))
+    # boxes of different ranks do not overlap (interiors)
+    for r in range(world):
+        for q in range(r + 1, world):
+            lo1, hi1 = synth.block_box(r, world, h)
+            lo2, hi2 = synth.block_box(q, world, h)
+            assert ((np.minimum(hi1, hi2) - np.maximum(lo1, lo2)) <= 1e-9).any()
