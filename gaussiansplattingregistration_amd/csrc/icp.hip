@@ -281,6 +281,7 @@ __device__ __forceinline__ void icp_consider(const float4 q, int j, double px, d
 // (each a z-plane of the block; 1024-thread workgroups), nine rows' loads in flight per lane, and the wave staging the joined
 // candidate runs of its 64 neighbouring queries in LDS -- all slower (what they add in registers / LDS costs a
 // round of workgroups on the chip, and the kernel's time is its slowest wave, not its average one).
+#define ICP_BLOCK_CROWDED 24     // points in a row of the 27-cell block from which on the row is tested against the bound before it is scanned
 template <int BLOCK>
 __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restrict__ cellStart,
                                            const float4* __restrict__ Tq, double px, double py, double pz, double& best_d2,
@@ -308,8 +309,19 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
             re[t] = ok ? cellStart[rowbase + xb + 1] : 0;
         }
         {
+        // The query's own row first: its points give the bound a CROWDED neighbour row is tested against before it is scanned.  On
+        // a cloud at two points per cell no row is crowded and nothing is tested (the unconditional batched loads are what made the
+        // block fast); in a clump -- 45 points per cell on the coarse level of the clustered scene -- a query scanned 1 200 points
+        // of which its own row's 135 already held the neighbour.  A row is skipped only when it is STRICTLY farther than the best
+        // so far (a point at exactly the best distance could still win the tie on its index).
+        constexpr int order9[9] = {4, 1, 3, 5, 7, 0, 2, 6, 8};
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
+        for (int tt = 0; tt < 9; ++tt) {
+            const int t = order9[tt];
+            if (t != 4 && re[t] - rs[t] > ICP_BLOCK_CROWDED) {
+                const double dzb = icp_slab_dist(pz, g.oz, g.c, cz + t / 3 - 1, eps, g.gz), dyb = icp_slab_dist(py, g.oy, g.c, cy + t % 3 - 1, eps, g.gy);
+                if (dzb * dzb + dyb * dyb > bd) continue;
+            }
             for (int j = rs[t]; j < re[t]; j += 4) {
                 const int l = re[t] - 1;
                 const int j1 = j + 1 < l ? j + 1 : l, j2 = j + 2 < l ? j + 2 : l, j3 = j + 3 < l ? j + 3 : l;
