@@ -1254,19 +1254,38 @@ __global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_a
                                                             int loss, double kparam, double* partials, unsigned* ticket,
                                                             double* acc_out, int nb_logical) {
     constexpr int fuse = FUSE;
+    // FUSE == 3: the RESIDENT form (GSR_ICP_PERSISTENT=1, a cooperative launch: every workgroup is on the chip).  The workgroups stay
+    // for the whole registration: evaluate, arrive at a device-scope ticket, the last one folds + solves + publishes a generation
+    // word, the others spin on it (s_sleep, bounded), everybody reads the new transform and goes again.  ticket[0] = arrivals
+    // (monotonic), ticket[1] = generation, ticket[2] = "a spin ran out" (the host reports it).
+    constexpr bool PERSIST = FUSE == 3;
+    constexpr int NACC = KIND == 0 ? 17 : 30;
+    __shared__ int s_last;
+    __shared__ int s_stop;
+    __shared__ double s_x[8][GSR_ICP_ACC_LEN];
+    __shared__ IcpState s_st;
+    const IcpRange rg = icp_block_range(ns, nb_logical < 0 ? -nb_logical : nb_logical, FUSE == 0 && nb_logical > 0);
+    for (unsigned ev = 0;; ++ev) {
+    double T[12];
+    if constexpr (PERSIST) {
+        // the state another workgroup wrote: agent-scope loads (past the L1 and the scalar cache), behind the acquire of the spin
+        if (threadIdx.x == 0) s_stop = __hip_atomic_load(&st->done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) | (int)__hip_atomic_load(ticket + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (s_stop) return;
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = __hip_atomic_load(&st->T[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
     if (st->done) {
         // converged: nothing to search.  The ranks of a multi-GPU run still meet in the collective: zeros
         if (fuse == 2 && blockIdx.x == 0 && threadIdx.x < GSR_ICP_ACC_LEN) acc_out[threadIdx.x] = 0.0;
         return;
     }
-    constexpr int NACC = KIND == 0 ? 17 : 30;
-    double T[12];
 #pragma unroll
     for (int i = 0; i < 12; ++i) T[i] = st->T[i];
+    }
     double acc[NACC];
 #pragma unroll
     for (int k = 0; k < NACC; ++k) acc[k] = 0.0;
-    const IcpRange rg = icp_block_range(ns, nb_logical < 0 ? -nb_logical : nb_logical, FUSE == 0 && nb_logical > 0);
     if (rg.row < 0) return;                         // (a padding workgroup of the XCD mapping; FUSE != 0 launches none)
     for (int64_t i = rg.lo + threadIdx.x; i < rg.hi; i += blockDim.x) {
         const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
@@ -1322,28 +1341,54 @@ __global__ __launch_bounds__(256, (FUSE != 0 && KIND != 2) ? 3 : 1) void k_icp_a
     // (acquire-release); the workgroup whose ticket is the last one ACQUIRES and reads every block's partials.  (Round 3 shipped
     // this with relaxed atomics and a bare vmcnt(0) -- no release / acquire pair ordered the partials before the ticket across
     // XCDs; the fences cost ~4 us per iteration, which is one more reason the knob stays off: two launches are faster.)
-    __shared__ int s_last;
-    __shared__ double s_x[8][GSR_ICP_ACC_LEN];
-    __shared__ IcpState s_st;
     if (threadIdx.x < 64) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (threadIdx.x == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
             const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-            s_last = t == gridDim.x - 1 ? 1 : 0;
+            s_last = t == (PERSIST ? (ev + 1u) * gridDim.x - 1u : gridDim.x - 1u) ? 1 : 0;
             if (s_last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
     }
     __syncthreads();
-    if (!s_last) return;
-    if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
-    icp_fold_partials<256, true>((int)gridDim.x, partials, nullptr, s_x);
-    if (fuse == 2) {
-        if (threadIdx.x < GSR_ICP_ACC_LEN) acc_out[threadIdx.x] = s_x[0][threadIdx.x];
-    } else if (threadIdx.x == 0) {
-        icp_step_solve(&s_x[0][0], s_st, st);
+    if (s_last) {
+        if constexpr (PERSIST) {
+            if (threadIdx.x < sizeof(IcpState) / 4)
+                reinterpret_cast<int*>(&s_st)[threadIdx.x] = __hip_atomic_load(reinterpret_cast<const int*>(st) + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (threadIdx.x < sizeof(IcpState) / 4) reinterpret_cast<int*>(&s_st)[threadIdx.x] = reinterpret_cast<const int*>(st)[threadIdx.x];
+        }
+        icp_fold_partials<256, true>((int)gridDim.x, partials, nullptr, s_x);
+        if (fuse == 2) {
+            if (threadIdx.x < GSR_ICP_ACC_LEN) acc_out[threadIdx.x] = s_x[0][threadIdx.x];
+        } else if (threadIdx.x == 0) {
+            icp_step_solve(&s_x[0][0], s_st, st);
+        }
+        if constexpr (!PERSIST) {
+            if (threadIdx.x == 0) *ticket = 0u;               // for the next launch (a kernel boundary away)
+        }
     }
-    if (threadIdx.x == 0) *ticket = 0u;                   // for the next launch (a kernel boundary away)
+    if constexpr (!PERSIST) return;
+    if (s_last) {
+        __syncthreads();                                      // (uniform within the workgroup: s_last is shared)
+        if (threadIdx.x == 0) {                               // the new state is out: everybody may go on
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            __hip_atomic_store(ticket + 1, ev + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else if (threadIdx.x == 0) {
+        unsigned spins = 0;
+        // relaxed polls (a load past the L1, nothing invalidated), ONE acquire when the word has moved
+        while (__hip_atomic_load(ticket + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < ev + 1u) {
+            __builtin_amdgcn_s_sleep(8);
+            if (++spins > (1u << 21)) {                       // ~0.5 s: something is badly wrong
+                __hip_atomic_store(ticket + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    __syncthreads();
+    }
 }
 
 // `reduced` == NULL: fold the block partials here (single GPU).  Multi-GPU source split: k_icp_reduce folds them into a
@@ -1485,6 +1530,7 @@ struct gsr_icp_ctx {
                                     // converged iteration 1.7x faster but a cold start (offsets ~ max_corr) 1.6x slower: keep 2
     DevBuf hist;
     bool robust_box = false;        // the current target's grid lies over the trimmed box (far outliers clamped into the boundary cells)
+    bool persistent = false;        // GSR_ICP_PERSISTENT=1: one RESIDENT kernel per registration on the levels that take the fused search (experiment)
     bool adapt_cells = false;       // GSR_ICP_ADAPT=1: a finer grid when the points are clumped (experiment)
     double occupancy = 0.0;         // of the cell an average point sits in (measured when adapt_cells)
     bool robust_allowed = true;     // GSR_ICP_ROBUST_BOX=0: always the box of all points (test knob: results must not change)
@@ -1569,6 +1615,34 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     return GSR_OK;
 }
 
+// The resident form of one registration (k_icp_accumulate_dev<KIND, BLOCK, 3>): a cooperative launch -- every workgroup must be on the
+// chip, they wait for one another --, so it is taken only when the occupancy query says all nb workgroups fit.  Returns 1 when it
+// was launched, 0 when the caller should take the launch-per-iteration loop, < 0 on error.
+template <int KIND, int BLOCK>
+int32_t launch_persistent(gsr_icp_ctx* c, int nb, const double* TN, const double* SC, ColorArgs cargs, double mc2, int loss, double k) {
+    const void* fn = (const void*)k_icp_accumulate_dev<KIND, BLOCK, 3>;
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    if (!prop.cooperativeLaunch || (int64_t)per_cu * prop.multiProcessorCount < nb) return 0;
+    int64_t ns = c->ns;
+    const float* src = c->src.as<float>();
+    IcpState* st = c->state.as<IcpState>();
+    IcpGrid g = c->grid;
+    const int* cellStart = c->cellStart.as<int>();
+    const int* nnj = nullptr;
+    const float4* Tq = c->Tq.as<float4>();
+    double* partials = c->partials.as<double>();
+    unsigned* ticket = c->ticket.as<unsigned>();
+    double* acc_out = c->acc_dev.as<double>();
+    int nb_logical = -nb;                    // (logical block = physical block: the resident form launches exactly nb workgroups)
+    void* args[] = {&ns, &src, &st, &g, &cellStart, &nnj, &Tq, &TN, &SC, &cargs, &mc2, &loss, &k, &partials, &ticket, &acc_out, &nb_logical};
+    const hipError_t e = hipLaunchCooperativeKernel(fn, dim3(nb), dim3(256), args, 0, c->stream);
+    if (e != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return 1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1625,6 +1699,7 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     if (const char* e = getenv("GSR_ICP_XCD")) c->xcd_ranges = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_ROBUST_BOX")) c->robust_allowed = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_ADAPT")) c->adapt_cells = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_PERSISTENT")) c->persistent = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_FUSED_STEP")) c->fused_step = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCKS")) { int v = atoi(e); if (v >= 1 && v <= 65536) c->nblocks = v; }
     // pinned, device-mapped, COHERENT host memory: the device's system-scope stores must reach the host while the stream is still
@@ -1965,6 +2040,22 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         const bool blockf = c->block_search && c->grid.rings >= 2;
         int issued = 0;
         GSR_HIP(hipEventRecord(c->e0, st));
+        // GSR_ICP_PERSISTENT=1: single GPU, fused search (the levels below 4 * 10^5 source points): ONE resident kernel runs the whole loop
+        if (c->persistent && !multi && c->nn_mode() == 0 && c->ns > 0) {
+            int32_t pr = 0;
+            const double* tn = c->Tn.as<double>();
+            const double* nul = nullptr;
+            if (kind == GSR_ICP_POINT_TO_POINT) pr = blockf ? launch_persistent<0, 1>(c, nb, nul, nul, cargs, mc2, loss, k) : launch_persistent<0, 0>(c, nb, nul, nul, cargs, mc2, loss, k);
+            else if (kind == GSR_ICP_POINT_TO_PLANE) pr = blockf ? launch_persistent<1, 1>(c, nb, tn, nul, cargs, mc2, loss, k) : launch_persistent<1, 0>(c, nb, tn, nul, cargs, mc2, loss, k);
+            if (pr < 0) return pr;
+            if (pr == 1) {
+                GSR_TRY(icp_fetch(c, c->state.p, &hs, sizeof(hs)));
+                unsigned tk[4] = {0, 0, 0, 0};
+                GSR_TRY(icp_fetch(c, c->ticket.p, tk, sizeof(tk)));
+                if (tk[2]) return fail(GSR_E_HIP, "gsr_icp_register: the resident kernel's barrier ran out of patience (GSR_ICP_PERSISTENT=0 takes the launch-per-iteration loop)");
+                issued = total_evals;
+            }
+        }
         while (issued < total_evals) {
             const int chunk = total_evals - issued < 8 ? total_evals - issued : 8;
             const int* nnj = c->nn_mode() ? c->nn_j.as<int>() : (const int*)nullptr;

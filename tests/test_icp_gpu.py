@@ -305,7 +305,8 @@ def test_icp_knobs_change_nothing(monkeypatch):
                 {"GSR_ICP_CELL_TARGET": "16"}, {"GSR_ICP_MAX_CELLS": "4096"}, {"GSR_ICP_BLOCK_SEARCH": "0"},
                 {"GSR_ICP_BLOCKS": "100"}, {"GSR_ICP_RB_POLL": "0"}, {"GSR_ICP_XCD": "0"},
                 {"GSR_ICP_BLOCK_SEARCH": "0", "GSR_ICP_NN_KERNEL": "2"}, {"GSR_ICP_FUSED_STEP": "1"}, {"GSR_ICP_FUSED_STEP": "1", "GSR_ICP_NN_KERNEL": "2"},
-                {"GSR_ICP_ADAPT": "1"}, {"GSR_ICP_ADAPT": "1", "GSR_ICP_CELL_TARGET": "64"}, {"GSR_ICP_ROBUST_BOX": "0"}):
+                {"GSR_ICP_ADAPT": "1"}, {"GSR_ICP_ADAPT": "1", "GSR_ICP_CELL_TARGET": "64"}, {"GSR_ICP_ROBUST_BOX": "0"},
+                {"GSR_ICP_PERSISTENT": "1"}, {"GSR_ICP_PERSISTENT": "1", "GSR_ICP_BLOCK_SEARCH": "0"}, {"GSR_ICP_PERSISTENT": "1", "GSR_ICP_BLOCKS": "100"}):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         got = run()
