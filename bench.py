@@ -449,6 +449,16 @@ def cpu_baseline(gpu_level1_rate, gpu_icp_coarse):
                    icp_gpu_iters_per_sec_same_size=gpu_icp_coarse, icp_speedup_like_for_like=(gpu_icp_coarse / rate) if gpu_icp_coarse else None)
     except Exception as e:  # pragma: no cover
         res["icp_error"] = str(e)[:120]
+    # the bench's OWN size on the reference, measured once by hand (it takes 36 minutes on 256 cores: scripts/cpu_reference_5m.py) and
+    # kept under profiles/ -- quoted here as what it is, not re-measured in this run
+    try:
+        ref5 = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_reference_5m.json")))
+        res["reference_5m_measured_offline"] = {"source": "profiles/r04_cpu_reference_5m.json (scripts/cpu_reference_5m.py, not part of this run)",
+                                                "cores": ref5["cores"], "reference_wall_s_one_level": ref5["reference_wall_s"],
+                                                "gpu_level_s_same_cloud": ref5["gpu_level_s"], "speedup_like_for_like": ref5["speedup_like_for_like"],
+                                                "level_sizes_equal": ref5["level_sizes_equal"]}
+    except Exception:
+        pass
     return res
 
 
