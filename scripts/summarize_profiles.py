@@ -44,6 +44,23 @@ if f:
         for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
             o.write(f"{k},{a[0]},{a[1]/1e6:.3f},{a[1]/a[0]/1e6:.4f},{100*a[1]/tot:.2f},{a[2]/1e6:.4f},{a[3]/1e6:.4f}\n")
 
+
+
+def derived(e, v, n):
+    """Derived figures of one kernel's counters (per launch): lane utilisation, cycles per VALU instruction, wait fractions, VALU busy."""
+    g = lambda k: v.get(k, 0.0) / n
+    if g("SQ_ACTIVE_INST_VALU") > 0:
+        e["lane_utilisation"] = g("SQ_THREAD_CYCLES_VALU") / (64.0 * g("SQ_ACTIVE_INST_VALU"))
+        if g("SQ_INSTS_VALU") > 0:
+            e["cycles_per_valu_inst"] = 4.0 * g("SQ_ACTIVE_INST_VALU") / g("SQ_INSTS_VALU")
+        if g("SQ_BUSY_CYCLES") > 0:
+            e["valu_busy_frac"] = (4.0 * g("SQ_ACTIVE_INST_VALU") / 1024.0) / (g("SQ_BUSY_CYCLES") / 32.0)
+    if g("SQ_WAVE_CYCLES") > 0:
+        e["wait_any_frac_of_wave_cycles"] = g("SQ_WAIT_ANY") / g("SQ_WAVE_CYCLES")
+        e["wait_inst_any_frac_of_wave_cycles"] = g("SQ_WAIT_INST_ANY") / g("SQ_WAVE_CYCLES")
+    if g("SQ_WAVES") > 0 and g("SQ_INSTS_VALU") > 0:
+        e["valu_insts_per_wave"] = g("SQ_INSTS_VALU") / g("SQ_WAVES")
+
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(int)
 for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2", "pmc_tc"):
@@ -74,6 +91,7 @@ for k, v in pmc.items():
         e["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024 / n
     if "TCC_HIT_sum" in v:
         e["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    derived(e, v, n)
     out[k] = e
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1, sort_keys=True)
 
@@ -122,6 +140,7 @@ def pmc_set(dirs, prefix, command, fetch_dir, marker=None, levels=4):
             e_["hbm_write_bytes_per_launch"] = v["WRITE_SIZE"] * 1024 / n_
         if "TCC_HIT_sum" in v:
             e_["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+        derived(e_, v, n_)
         o[k] = e_
     json.dump(o, open(dst + prefix, "w"), indent=1, sort_keys=True)
     return dst + prefix
