@@ -637,6 +637,7 @@ struct SelectArgs {
     int* hq;                        // hq[0] = number of items, hq[1] = queue cursor
     int heavy_blocks;               // workgroups at the head of the launch that serve the queue (0 = no splitting)
     unsigned part;                  // candidates per work item (<= SEL_PART; smaller on small levels, where an item is the critical path)
+    int np;                         // light parents per wave (1 ... SEL_NP), see SEL_NP
 };
 
 enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
@@ -644,7 +645,7 @@ enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
 #define SEL_HEAVY_BLOCKS 2048  // workgroups at the head of k_select that serve the queue of heavy work items (a multiple of 8)
 #define SEL_QCAP 512          // survivor ring (power of two >= 64 + SEL_U*64)
 #define SEL_U 3               // chunks whose candidate loads are in flight together (2 or 3: equal, 4: +1 %, 6: +2 %, 8: +14 % -- registers)
-#define SEL_MCAP 2048         // flat positions covered by the row-start bit mask at a time
+#define SEL_MCAP 1024         // flat positions covered by the row-start bit mask at a time (2048 before the parent slots: LDS in 1 280-byte granules, 9 per workgroup = 14 workgroups per CU)
 #define SEL_PAD (64 * SEL_U)  // entries the sorted A array is padded by: the inactive lanes of a batch's last chunks read past the last row
 
 // Everything k_select / k_spans need to know about a parent, computed ONCE per parent by k_parent_prep (one thread each)
@@ -705,29 +706,53 @@ __device__ unsigned long long g_sel_prof[1024 * 16];       // 1024 copies (by wo
 #define SEL_PROF_CNT(slot, v, lane)
 #endif
 
+// Parents per wave.  A wave takes up to SEL_NP consecutive slots of the processing order (neighbours on the Z-order curve) ONE AFTER
+// THE OTHER and keeps the survivor ring and the third-stage queue ACROSS them: stage 2 and stage 3 run on full batches of 64
+// whatever parent the entries belong to (a surfel-like parent leaves 57 survivors and 7 pairs -- alone it runs stage 2 at 52 % and
+// stage 3 at 10 % of the lanes), and only the wave's last batches are partial.  A ring entry carries its parent's number k in the
+// bits above the sorted position (positions are < 2^30: the stream packs `position << 2 | flags` into 32 bits), and what stages
+// 2 / 3 need of parent k they read per lane from LDS (struct ParLds) instead of the scalar registers -- which also takes 17 dwords
+// of every parent out of the SGPR file.  The rings are FIFO and the parents are scanned in turn, so every parent's pairs come out in
+// exactly the order (and at exactly the places) the one-parent-per-wave form wrote them.
+#define SEL_NP 4
+#define SEL_TAG_SHIFT 30
+#define SEL_TAG_MASK 0x3fffffffu
+struct __attribute__((aligned(16))) ParLds {      // 20 dwords; the first 16 are the head of the parent's ParentRec as it lies in memory
+    float4 r0;                                    // pm.x, pm.y, pm.z, pcol.x
+    float4 r1;                                    // pcol.y, pcol.z, pinv.e00, pinv.e01
+    float4 r2;                                    // pinv.e02, pinv.e11, pinv.e12, pinv.e22
+    float4 r3;                                    // det_p, inv_det_p, pweight, R
+    float R2;
+    int js;
+    int64_t base;                                 // FILL / SPARSE: where the parent's (this work item's) pairs go
+};
+static_assert(sizeof(ParLds) == 80, "ParLds is read as four float4 and two 8-byte words");
+
 // Third-stage queue (per wave, in LDS): the accepted pairs wait here until 64 of them fill a wavefront, so that
 // the likelihood (two expf, two sqrtf, two IEEE divisions) runs on full waves instead of the ~26 % of the lanes
-// that pass the KL gate.
+// that pass the KL gate.  rel = the pair's rank among its parent's accepted pairs: it goes to ParLds::base + rel.
 #define SEL_Q3CAP 128
 struct Q3 {
-    unsigned* j;
+    unsigned *j, *rel;             // j keeps the parent tag
     float *d2, *cd, *op, *det;
     int h, n;                      // head, fill (wave-uniform)
 };
 
 // wL_si = w_s * clamp(hemLikelihoodOpacity, FLT_MIN, 1e8)   (mixture.cpp:54-64,155-158) for `cnt` queued pairs
-__device__ __forceinline__ void select_stage3(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, Q3& q3, int64_t& base) {
+__device__ __forceinline__ void select_stage3(const SelectArgs& a, const ParLds* par, int lane, int cnt, Q3& q3) {
     if (lane < cnt) {
         const int k = (q3.h + lane) & (SEL_Q3CAP - 1);
+        const unsigned e = q3.j[k];
+        const ParLds* pl = par + (e >> SEL_TAG_SHIFT);
         const float distanceDiff = sqrtf(q3.d2[k]);
         const float cdiff = sqrtf(q3.cd[k]);                  // ColorDelta (gaussian.hpp:111-114); the queue holds its square
         const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
         const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
         const float L = distWeight * q3.op[k] * colorInfluence * sqrtf(q3.det[k]);
-        a.pair_child[base + lane] = q3.j[k];
-        a.pair_wl[base + lane] = pr.pweight * ref_clamp(L, FLT_MIN, 1e8f);
+        const int64_t dst = pl->base + (int64_t)q3.rel[k];
+        a.pair_child[dst] = e & SEL_TAG_MASK;
+        a.pair_wl[dst] = pl->r3.z * ref_clamp(L, FLT_MIN, 1e8f);
     }
-    base += cnt;
     q3.h = (q3.h + cnt) & (SEL_Q3CAP - 1);
     q3.n -= cnt;
 }
@@ -759,48 +784,75 @@ __device__ __forceinline__ bool kl_gate_rejects(float s2, float det_c, float det
 
 // stage 2 on up to 64 queued survivors (lane < cnt holds one): radius test, colour gate, KL gate, parent rule -- the
 // reference's decisions, every expression in its operand order; accepted pairs go to the third-stage queue.
+// count_v: lane k holds the number of pairs parent k has had accepted so far (read and advanced here).
 template <int MODE>
-__device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParentRec& pr, int lane, int cnt, const unsigned* q, int qh,
-                                              unsigned& count, int64_t& base, Q3& q3) {
+__device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParLds* par, int lane, int cnt, const unsigned* q, int qh,
+                                              unsigned& count_v, Q3& q3) {
     SEL_PROF_T(tp2);
     SEL_PROF_CNT(8, 1, lane); SEL_PROF_CNT(9, cnt, lane);
     bool acc = false;
-    int j = 0;
+    unsigned e = 0u;
+    int k = 0;
     float d2 = 0.0f, cdiff = 0.0f, op = 0.0f, det_c = 0.0f;
     if (lane < cnt) {
-        j = (int)q[(qh + lane) & (SEL_QCAP - 1)];
+        e = q[(qh + lane) & (SEL_QCAP - 1)];
+        const int j = (int)(e & SEL_TAG_MASK);
+        k = (int)(e >> SEL_TAG_SHIFT);
+        const ParLds* pl = par + k;
+        const float4 p0 = pl->r0, p1 = pl->r1;
+        const float R2 = pl->R2;
         const float4* row = a.geo + 4 * (int64_t)j;
-        const float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];   // 64 contiguous bytes, all four up front: one round trip
+        float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];   // 64 contiguous bytes, all four up front: one round trip
+        // (an empty statement the compiler cannot see through: without it the loads of the covariance and the determinant sink into the
+        // branch behind the radius / colour gates -- a SECOND round trip per batch, +2 800 cycles, found in the phase profile)
+        asm volatile("" : "+v"(ca.x), "+v"(ca.y), "+v"(ca.z), "+v"(ca.w), "+v"(cb.x), "+v"(cb.y), "+v"(cb.z), "+v"(cb.w),
+                          "+v"(cc.x), "+v"(cc.y), "+v"(cc.z), "+v"(cc.w), "+v"(cd.x), "+v"(cd.y), "+v"(cd.z), "+v"(cd.w));
         const f3 cm = {ca.x, ca.y, ca.z};
         const f3 ccol = {cc.z, cc.w, cd.x};
-        const f3 d = sub3(cm, pr.pm);
+        const f3 pm = {p0.x, p0.y, p0.z}, pcol = {p0.w, p1.x, p1.y};
+        const f3 d = sub3(cm, pm);
         d2 = dot3(d, d);                                      // == dot(pm - cm, pm - cm) bit for bit (pointindex.cpp:137)
-        const f3 dc = sub3(ccol, pr.pcol);                    // ColorDelta(child, parent), gaussian.hpp:111-114
+        const f3 dc = sub3(ccol, pcol);                       // ColorDelta(child, parent), gaussian.hpp:111-114
         cdiff = dot3(dc, dc);                                 // its square; sqrtf(x) > colorThr  <=>  x > colorThr2 (a.colorThr2, host)
-        if (d2 < pr.R2 && !(cdiff > a.colorThr2)) {           // radiusSearch (strict), mixture.cpp:122-124
+        if (d2 < R2 && !(cdiff > a.colorThr2)) {              // radiusSearch (strict), mixture.cpp:122-124
+            const float4 p2 = pl->r2, p3 = pl->r3;
             const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
+            const s6 pinv = {p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
             det_c = cd.w;
             op = cd.y;
-            const float smd = dot3(d, mul6(pr.pinv, d));      // gaussian.hpp:82-85
-            const float tr = trace_prod6(pr.pinv, ccov);
+            const float smd = dot3(d, mul6(pinv, d));         // gaussian.hpp:82-85
+            const float tr = trace_prod6(pinv, ccov);
             const float s2 = smd + tr - 3.0f;                 // gaussian.hpp:106-109: 0.5f * (smd + tr - 3.0f - log(q))
-            if (!kl_gate_rejects(s2, det_c, pr.det_p, pr.inv_det_p, a.kldThr, a.logtab)) {      // mixture.cpp:126-129 (NaN passes)
+            if (!kl_gate_rejects(s2, det_c, p3.x, p3.y, a.kldThr, a.logtab)) {      // mixture.cpp:126-129 (NaN passes)
                 const bool child_is_parent = (__float_as_uint(ca.w) & 1u) != 0u;
-                acc = !(child_is_parent && j != pr.js);       // mixture.cpp:131-133
+                acc = !(child_is_parent && j != pl->js);      // mixture.cpp:131-133
             }
         }
     }
     const unsigned long long m = __ballot(acc);
     const int na = __popcll(m);
-    count += (unsigned)na;
-    if (MODE == SEL_COUNT || na == 0) { SEL_PROF_ADD(2, tp2, lane); return; }
+    SEL_PROF_CNT(15, na, lane);
+    if (na == 0) { SEL_PROF_ADD(2, tp2, lane); return; }
+    // the entries are in parent order (FIFO): the batch holds the parents k_lo .. k_hi, every one a contiguous run of lanes
+    const int k_lo = __builtin_amdgcn_readfirstlane(k);
+    const int k_hi = __builtin_amdgcn_readlane(k, __builtin_amdgcn_readfirstlane(cnt - 1));
+    unsigned rel = 0u;
+#pragma unroll
+    for (int kk = 0; kk < SEL_NP; ++kk) {
+        if (kk < k_lo || kk > k_hi) continue;                 // (uniform)
+        const unsigned long long mk = __ballot(acc && k == kk);
+        const unsigned ck = (unsigned)__builtin_amdgcn_readlane((int)count_v, kk);
+        if (acc && k == kk) rel = ck + (unsigned)mbcnt64(mk, 0);
+        if (lane == kk) count_v += (unsigned)__popcll(mk);
+    }
+    if (MODE == SEL_COUNT) { SEL_PROF_ADD(2, tp2, lane); return; }
     if (acc) {
-        const int k = mbcnt64(m, q3.h + q3.n) & (SEL_Q3CAP - 1);
-        q3.j[k] = (unsigned)j; q3.d2[k] = d2; q3.cd[k] = cdiff; q3.op[k] = op; q3.det[k] = det_c;
+        const int t = mbcnt64(m, q3.h + q3.n) & (SEL_Q3CAP - 1);
+        q3.j[t] = e; q3.rel[t] = rel; q3.d2[t] = d2; q3.cd[t] = cdiff; q3.op[t] = op; q3.det[t] = det_c;
     }
     q3.n += na;
     __builtin_amdgcn_wave_barrier();
-    if (q3.n >= 64) select_stage3(a, pr, lane, 64, q3, base);
+    if (q3.n >= 64) select_stage3(a, par, lane, 64, q3);
     __builtin_amdgcn_wave_barrier();
     SEL_PROF_ADD(2, tp2, lane);
 }
@@ -993,26 +1045,40 @@ __device__ __forceinline__ float white_smd(const float (&vc)[11], float cx, floa
 // One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
 // REGULAR ones; IRR = true scans the list of irregular components (ipos, addressed through irank at the cell
 // boundaries).  Survivors of the stage-1 filter go to the LDS ring.
-template <int MODE, bool IRR>
-__device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr,
-                                            const float (&vc)[11], int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count,
-                                            int64_t& base, Q3& q3, unsigned& cum, unsigned lo, unsigned hi) {
+// INDRAIN = true (the heavy work items): full batches of 64 survivors go through stage 2 from inside the scan.
+// INDRAIN = false (the light parents): the scan only FILLS the ring and the caller drains it -- behind the scan, where none of the
+// scan's vector state is alive (stage 2 inside the chunk loop made the kernel's register count the SUM of the two).  A ring without
+// room for another group of chunks SUSPENDS the scan: it returns false with the position (row batch rb0, the candidates `cum` in front
+// of that batch, the flat position `lo` to go on from -- the work items' own [lo, hi) mechanism), and the next call picks up there
+// at the price of that batch's row spans over again.  A light parent leaves ~110 survivors: it does not happen to it.
+template <int MODE, bool IRR, bool INDRAIN>
+__device__ __forceinline__ bool select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const ParLds* par, unsigned ktag,
+                                            const float (&vc)[11], int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count_v,
+                                            Q3& q3, int& rb0, unsigned& cum, unsigned& lo, unsigned hi) {
     const f3 pm = pr.pm;
     const EllClip& ec = pr.ec;
-    const float Ra = fabsf(pr.R) * 1.00001f + g.slack;             // conservative search extent
+    // (uniform values, but float arithmetic is VALU work and its results would sit in vector registers for the whole scan: the box
+    // goes back to the scalar file)
+    // (the compiler knows the values are uniform and folds a plain readfirstlane away -- leaving them where they are; a zero it cannot
+    // see through, added to the bit pattern, keeps the instruction)
+    int vz;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+    const auto uni = [vz](int v) { return __builtin_amdgcn_readfirstlane(v + vz); };
+    const auto unif = [vz](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v) + vz)); };
+    const float Ra = unif(fabsf(pr.R) * 1.00001f + g.slack);       // conservative search extent
     const bool clip = !IRR && ec.on != 0.0f;
     // rows: the sphere's box, cut down to the pre-reject ellipsoid's box when the rows are clipped to it (rows beyond its y / z
     // extent would come out empty one by one)
     const float Ry = clip ? fminf(Ra, pr.ey + g.slack) : Ra, Rz = clip ? fminf(Ra, pr.ez + g.slack) : Ra;
-    const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
-    const int y0 = cell_of(pm.y - Ry, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ry, g.oy, g.inv_c, g.gy);
-    const int z0 = cell_of(pm.z - Rz, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Rz, g.oz, g.inv_c, g.gz);
+    const int x0 = uni(cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx)), x1 = uni(cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx));
+    const int y0 = uni(cell_of(pm.y - Ry, g.oy, g.inv_c, g.gy)), y1 = uni(cell_of(pm.y + Ry, g.oy, g.inv_c, g.gy));
+    const int z0 = uni(cell_of(pm.z - Rz, g.oz, g.inv_c, g.gz)), z1 = uni(cell_of(pm.z + Rz, g.oz, g.inv_c, g.gz));
     const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-    const int nrows = __builtin_amdgcn_readfirstlane(ny * nz);
-    const float Ra2 = Ra * Ra;
+    const int nrows = ny * nz;
+    const float Ra2 = unif(Ra * Ra);
     const bool white = !IRR && pr.white != 0.0f;                // wave-uniform
     SEL_PROF_CNT(10, nrows, lane);
-    for (int rb = 0; rb < nrows; rb += 64) {
+    for (int rb = rb0; rb < nrows; rb += 64) {
         SEL_PROF_T(tpr);
         SEL_PROF_CNT(11, 1, lane);
         const int r = rb + lane;
@@ -1090,64 +1156,136 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
                     in = in && lane < left[u];
                     const unsigned long long m = __ballot(in);
                     if (m == 0ull) continue;
-                    if (in) q[mbcnt64(m, qh + qn) & (SEL_QCAP - 1)] = (unsigned)jj[u];
+                    if (in) q[mbcnt64(m, qh + qn) & (SEL_QCAP - 1)] = (unsigned)jj[u] | ktag;
                     qn += __popcll(m);
                 }
-                // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
                 __builtin_amdgcn_wave_barrier();
                 SEL_PROF_ADD(4, tps, lane);
-                while (qn >= 64) {
-                    select_stage2<MODE>(a, pr, lane, 64, q, qh, count, base, q3);
-                    qh = (qh + 64) & (SEL_QCAP - 1);
-                    qn -= 64;
+                if (INDRAIN) {
+                    // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
+                    while (qn >= 64) {
+                        select_stage2<MODE>(a, par, lane, 64, q, qh, count_v, q3);
+                        qh = (qh + 64) & (SEL_QCAP - 1);
+                        qn -= 64;
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                } else if (qn + 64 * SEL_U > SEL_QCAP) {                      // no room for the next group: suspend
+                    if (mine) bits[rel >> 6] = 0ull;
+                    __builtin_amdgcn_wave_barrier();
+                    // (the group's chunks end at the segment's end: what lies behind it has not been looked at)
+                    rb0 = rb; cum = cum0; lo = cum0 + (unsigned)(t0 + 64 * SEL_U < seg_end ? t0 + 64 * SEL_U : seg_end);
+                    return false;
                 }
-                __builtin_amdgcn_wave_barrier();
             }
             if (mine) bits[rel >> 6] = 0ull;                                  // leave the mask clean for the next segment / batch
             __builtin_amdgcn_wave_barrier();
         }
     }
+    rb0 = 0;
+    return true;
 }
 
-// One work item: parent p, part [lo, hi) of its flat candidate space (the whole parent: 0, 2^32 - 1).  Returns the number of
-// accepted pairs; writes them from `base` on (FILL / SPARSE).
-template <int MODE>
-__device__ __forceinline__ unsigned select_item(const SelectArgs& a, const GridParams& g, int p, unsigned lo, unsigned hi, int64_t base, int lane,
-                                                unsigned* q, unsigned long long* bits, Q3 q3) {
+// What stages 2 / 3 need of parent p, from its record in memory to the wave's LDS slot (ONE lane calls this per parent; the slot is
+// free: a wave's parents take different slots, a work item's rings are flushed before the next one starts).  (Lane 0 writing it from
+// the scalar copy of the record inside select_parent, measured: +5 % at four parents per wave -- 17 more live SGPRs and 20 v_mov.)
+__device__ __forceinline__ void select_fill_par(const SelectArgs& a, int p, int64_t base, ParLds* slot) {
+    const float4* r = reinterpret_cast<const float4*>(a.prec + p);
+    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
+    slot->r0 = r0; slot->r1 = r1; slot->r2 = r2; slot->r3 = r3;
+    slot->R2 = a.prec[p].R2; slot->js = a.prec[p].js; slot->base = base;
+}
+
+// One work item: parent p (the wave's k-th), part [lo, hi) of its flat candidate space (the whole parent: 0, 2^32 - 1); its pairs
+// go to par[k].base on (FILL / SPARSE; select_fill_par has filled par[k]).  Survivors and accepted pairs may stay behind in the
+// rings: select_flush ends a wave's (a work item's) run.  The number of accepted pairs accumulates in lane k of count_v.
+template <int MODE, bool INDRAIN>
+__device__ __forceinline__ void select_parent(const SelectArgs& a, const GridParams& g, int p, int k, unsigned lo, unsigned hi, int lane,
+                                              const ParLds* par, unsigned* q, int& qh, int& qn, unsigned long long* bits, unsigned& count_v, Q3& q3) {
     SEL_PROF_T(tp0);
-    const ParentRec pr = a.prec[p];     // uniform address: scalar loads, the record lives in SGPRs
-    // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs once per parent)
-    float vc[11];
+    // The record lives in SGPRs.  As inline assembly: this body runs in a loop behind the wave's own stores (pcnt, the pairs), the
+    // compiler cannot tell that they leave prec[] alone, and a load that "may be clobbered" is not made a scalar load however uniform
+    // its address -- it became ten global_load_dwordx4 with 64 lanes reading the same 160 bytes, and 40 v_readfirstlane behind them
+    // (SQ_INSTS_VMEM_RD +16 M per 5 M level, profiles/r04o_*).
+    ParentRec pr;
     {
-        const float src[11] = {pr.pm.x, pr.pm.y, pr.pm.z, pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
+        typedef unsigned u16v __attribute__((ext_vector_type(16)));
+        typedef unsigned u8v __attribute__((ext_vector_type(8)));
+        u16v w0, w1; u8v w2;
+        const ParentRec* rp = a.prec + p;
+        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx8 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
+                     : "=&s"(w0), "=&s"(w1), "=&s"(w2) : "s"(rp) : "memory");
+        unsigned raw[40];
+        static_assert(sizeof(raw) == sizeof(ParentRec), "the three scalar loads cover the record");
 #pragma unroll
-        for (int i = 0; i < 11; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vc[i]) : "s"(src[i]));
+        for (int i = 0; i < 16; ++i) { raw[i] = w0[i]; raw[16 + i] = w1[i]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) raw[32 + i] = w2[i];
+        __builtin_memcpy(&pr, raw, sizeof(pr));
     }
-    unsigned count = 0;                 // accepted pairs (uniform across the wave)
-    int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
+    const unsigned ktag = (unsigned)k << SEL_TAG_SHIFT;
     unsigned cum = 0;                   // flat candidates of the batches behind the scan
     if (pr.selfq) {                     // the parent itself: flat candidate 0, straight into the survivor ring (stage 2 decides)
         cum = 1u;
-        if (lo == 0u) { if (lane == 0) q[0] = (unsigned)pr.js; qn = 1; }
+        if (lo == 0u) {
+            if (lane == 0) q[(qh + qn) & (SEL_QCAP - 1)] = (unsigned)pr.js | ktag;
+            qn += 1;                    // (at most 64 now: the ring takes a whole group of chunks on top, SEL_QCAP)
+        }
         __builtin_amdgcn_wave_barrier();
     }
     if (pr.active) {
-        // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
-        // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
-        select_scan<MODE, false>(a, g, pr, vc, lane, bits, q, qh, qn, count, base, q3, cum, lo, hi);
-        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, vc, lane, bits, q, qh, qn, count, base, q3, cum, lo, hi);
-        if (qn > 0) select_stage2<MODE>(a, pr, lane, qn, q, qh, count, base, q3);
-        SEL_PROF_T(tp3);
-        if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, pr, lane, q3.n, q3, base);
-        SEL_PROF_ADD(3, tp3, lane);
+        int pass = 0, rb = 0;
+        for (;;) {
+            bool done = true;
+            {
+                // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs; again after every drain, so that they
+                // are not alive across stage 2)
+                float vc[11];
+                const float src[11] = {pr.pm.x, pr.pm.y, pr.pm.z, pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
+#pragma unroll
+                for (int i = 0; i < 11; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vc[i]) : "s"(src[i]));
+                // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
+                // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
+                if (pass == 0) {
+                    done = select_scan<MODE, false, INDRAIN>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, rb, cum, lo, hi);
+                    if (done) pass = 1;
+                }
+                if (done && a.n_irr > 0)
+                    done = select_scan<MODE, true, INDRAIN>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, rb, cum, lo, hi);
+            }
+            if (!INDRAIN) {
+                while (qn >= 64) {
+                    select_stage2<MODE>(a, par, lane, 64, q, qh, count_v, q3);
+                    qh = (qh + 64) & (SEL_QCAP - 1);
+                    qn -= 64;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (done) break;
+        }
     }
     SEL_PROF_ADD(0, tp0, lane);
-    SEL_PROF_CNT(7, 1, lane); SEL_PROF_CNT(15, count, lane);
-    return count;
+    SEL_PROF_CNT(7, 1, lane);
 }
 
-// WPB = wavefronts (= parents) per workgroup.  QUEUE = false: one light parent per wave in the processing order (the heavy
-// slots at its head are skipped when a.heavy_blocks > 0).  QUEUE = true, launched beside it on a second stream with
+// The partial batches at the end of a wave's run: the survivors left in the ring, then the accepted pairs left in the queue.
+template <int MODE>
+__device__ __forceinline__ void select_flush(const SelectArgs& a, const ParLds* par, int lane, const unsigned* q, int& qh, int& qn,
+                                             unsigned& count_v, Q3& q3) {
+    while (qn > 0) {                    // (the parent's own entry may have made it 64)
+        const int c = qn < 64 ? qn : 64;
+        select_stage2<MODE>(a, par, lane, c, q, qh, count_v, q3);
+        qh = (qh + c) & (SEL_QCAP - 1);
+        qn -= c;
+    }
+    SEL_PROF_T(tp3);
+    if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, par, lane, q3.n, q3);
+    SEL_PROF_ADD(3, tp3, lane);
+    __builtin_amdgcn_wave_barrier();
+}
+
+// WPB = wavefronts per workgroup.  QUEUE = false: a.np (1 ... SEL_NP) consecutive light parents of the processing order per wave,
+// one after the other with the rings kept across them (the heavy slots at the order's head are skipped when a.heavy_blocks > 0).
+// QUEUE = true, launched beside it on a second stream with
 // a.heavy_blocks workgroups: every wave serves the queue of heavy work items (item <its index> first, then it pulls).
 // Two kernels rather than one: the item loop's uniform state does not fit the scalar registers beside the parent record,
 // and the spills would cost the light parents, 99.7 % of the work, two waves per SIMD.
@@ -1155,17 +1293,20 @@ template <int MODE, int WPB, bool QUEUE>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     __shared__ unsigned s_q[WPB][SEL_QCAP];
     __shared__ double s_logtab[32];
-    __shared__ unsigned s_q3j[WPB][SEL_Q3CAP];
+    __shared__ unsigned s_q3u[WPB][2][SEL_Q3CAP];
     __shared__ float s_q3f[WPB][4][SEL_Q3CAP];
     __shared__ unsigned long long s_bits[WPB][SEL_MCAP / 64 + SEL_U];
+    __shared__ ParLds s_par[WPB][SEL_NP];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (lane < 32) s_logtab[lane] = k_logf_tab[lane];       // every wave writes the same 32 values: no barrier needed
     a.logtab = s_logtab;
     if (lane < SEL_MCAP / 64 + SEL_U) s_bits[wv][lane] = 0ull;
     unsigned* q = s_q[wv];
-    const Q3 q3 = {s_q3j[wv], s_q3f[wv][0], s_q3f[wv][1], s_q3f[wv][2], s_q3f[wv][3], 0, 0};
+    ParLds* par = s_par[wv];
+    Q3 q3 = {s_q3u[wv][0], s_q3u[wv][1], s_q3f[wv][0], s_q3f[wv][1], s_q3f[wv][2], s_q3f[wv][3], 0, 0};
     __builtin_amdgcn_wave_barrier();
     const GridParams g = *a.gp;
+    int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
 
     if constexpr (QUEUE) {
         const int n_items = a.hq[0];
@@ -1181,10 +1322,14 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
                 base = a.poff[p];
                 for (int k = a.hfirst[p]; k < item; ++k) base += a.part_cnt[k];
             }
-            const unsigned count = select_item<MODE>(a, g, p, lo, hi, base, lane, q, s_bits[wv], q3);
+            unsigned count_v = 0u;
+            if (lane == 0) select_fill_par(a, p, base, par);
+            __builtin_amdgcn_wave_barrier();
+            select_parent<MODE, true>(a, g, p, 0, lo, hi, lane, par, q, qh, qn, s_bits[wv], count_v, q3);
+            select_flush<MODE>(a, par, lane, q, qh, qn, count_v, q3);
             if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) {
-                a.part_cnt[item] = count;
-                atomicAdd(&a.pcnt[p], count);                       // integer sum: the order of the parts does not matter
+                a.part_cnt[item] = count_v;
+                atomicAdd(&a.pcnt[p], count_v);                     // integer sum: the order of the parts does not matter
             }
             int nxt = 0;
             if (lane == 0) nxt = atomicAdd(&a.hq[1], 1);
@@ -1192,22 +1337,44 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
             __builtin_amdgcn_wave_barrier();
         }
     } else {
+        SEL_PROF_T(tpk);
+        const int np = a.np;
+        const int ppb = WPB * np;                                   // parents per workgroup
         const int nheavy = a.nheavy ? *a.nheavy : 0;
-        const int nblk = (a.P + WPB - 1) / WPB;
-        const int hb = ((nheavy + WPB - 1) / WPB + 7) & ~7;
+        const int nblk = (a.P + ppb - 1) / ppb;
+        const int hb = ((nheavy + ppb - 1) / ppb + 7) & ~7;
         const int bid = block_slot((int)blockIdx.x, nblk, hb < nblk ? hb : nblk, a.xcd);
         if (bid < 0) return;
-        const int slot = bid * WPB + wv;
-        if (slot >= a.P) return;
-        if (a.heavy_blocks > 0 && slot < nheavy) return;          // a heavy parent: the queue has it
-        const int p = __builtin_amdgcn_readfirstlane(a.porder ? (int)a.porder[slot] : slot);
-        if (p < a.own_lo || p >= a.own_hi) {          // another rank's parent: no work, no pairs
-            if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p] = 0u;
-            return;
+        const int slot0 = (bid * WPB + wv) * np;
+        // lane k < np looks at the wave's k-th slot: whose parent it is, whether it is this launch's, and fills its LDS record --
+        // nothing of this stays in the scalar registers while the parents are scanned
+        int p_v = -1;                                               // lane k: the wave's k-th parent (-1: none, or not this launch's)
+        if (lane < np) {
+            const int slot = slot0 + lane;
+            if (slot < a.P && !(a.heavy_blocks > 0 && slot < nheavy)) {      // (a heavy parent: the queue has it)
+                const int p = a.porder ? (int)a.porder[slot] : slot;
+                if (p < a.own_lo || p >= a.own_hi) {                // another rank's parent: no work, no pairs
+                    if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[p] = 0u;
+                } else {
+                    p_v = p;
+                    select_fill_par(a, p, (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0, par + lane);
+                }
+            }
         }
-        const int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
-        const unsigned count = select_item<MODE>(a, g, p, 0u, 0xffffffffu, base, lane, q, s_bits[wv], q3);
-        if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p] = count;      // no global atomics: totals come from the scans
+        unsigned long long todo = __ballot(p_v >= 0);
+        unsigned count_v = 0u;
+        __builtin_amdgcn_wave_barrier();
+        SEL_PROF_ADD(5, tpk, lane);
+        while (todo != 0ull) {
+            const int k = __builtin_ctzll(todo);
+            todo &= todo - 1ull;
+            const int p = __builtin_amdgcn_readlane(p_v, k);
+            select_parent<MODE, false>(a, g, p, k, 0u, 0xffffffffu, lane, par, q, qh, qn, s_bits[wv], count_v, q3);
+        }
+        SEL_PROF_T(tpf);
+        select_flush<MODE>(a, par, lane, q, qh, qn, count_v, q3);
+        SEL_PROF_ADD(6, tpf, lane);
+        if (p_v >= 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p_v] = count_v;      // no global atomics: totals come from the scans
     }
 }
 
@@ -2930,6 +3097,7 @@ struct gsr_hem_ctx {
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec;
+    int select_np = 0;              // GSR_HEM_SELECT_NP=1|2|4: light parents per selection wave (the rings are kept across them, see SEL_NP); 0 = by level size
     bool mstep_split = true;        // GSR_HEM_MSTEP_SPLIT=0: a parent of more than MSTEP_SEG pairs keeps ONE wave for all its segments (the schedule of rounds 1-3)
     DevBuf mh_list, mh_items, mh_scratch;
     hipEvent_t ev_mfork = nullptr, ev_mjoin = nullptr;          // the heavy parents' segments run on the second stream beside k_mstep
@@ -3190,6 +3358,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SMALL")) c->mstep_small = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SPLIT")) c->mstep_split = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_SELECT_NP")) { const int v = atoi(s); c->select_np = v < 1 ? 1 : (v > SEL_NP ? SEL_NP : v); }
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
     if (const char* s = getenv("GSR_HEM_SH_GRID")) c->sh_grid = atoi(s);
@@ -3915,6 +4084,8 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.tau2 = c->tau * c->tau;                    // mixture.cpp:58,61
     sa.pcnt = c->pcnt.as<unsigned>();
     sa.pcap = c->pcap.as<unsigned>();
+    // parents per selection wave: SEL_NP, but no fewer waves than the chip holds at once (256 CUs x 28)
+    sa.np = c->select_np > 0 ? c->select_np : (P >= SEL_NP * 7168 ? SEL_NP : (P >= 2 * 7168 ? 2 : 1));
     int64_t M = 0;
     constexpr int WPB = 2;      // parents per workgroup (work per parent is heavy-tailed: small workgroups free their CU slot sooner)
     // the queue-serving kernel runs beside the light parents' on the context's second stream (fork / join by events)
@@ -3924,7 +4095,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             hipLaunchKernelGGL((k_select<MODE, WPB, true>), dim3(sa.heavy_blocks), dim3(64 * WPB), 0, c->aux, sa); \
             GSR_HIP(hipEventRecord(c->ev_join, c->aux)); \
         } \
-        hipLaunchKernelGGL((k_select<MODE, WPB, false>), dim3(8 * ceil_div(ceil_div(P, WPB), 8)), dim3(64 * WPB), 0, st, sa); \
+        hipLaunchKernelGGL((k_select<MODE, WPB, false>), dim3(8 * ceil_div(ceil_div(P, WPB * sa.np), 8)), dim3(64 * WPB), 0, st, sa); \
         if (sa.heavy_blocks) GSR_HIP(hipStreamWaitEvent(st, c->ev_join, 0)); \
     } while (0)
     auto widen_scan = [&](const unsigned* cnt, int64_t* off, int64_t count) -> int32_t {      // off = exclusive scan of cnt (int64)

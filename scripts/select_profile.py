@@ -28,6 +28,7 @@ for shape in shapes:
     print(f"   clock per parent (s_memtime ticks, 100 MHz): total {tot / P:.1f}  rows {out[1] / P:.1f} ({100 * out[1] / tot:.1f} %)  stage 2 (+ full stage-3 batches) {out[2] / P:.1f} ({100 * out[2] / tot:.1f} %)  "
           f"final stage 3 {out[3] / P:.1f} ({100 * out[3] / tot:.1f} %)  stage-1 stream (loads + filter + queue) {out[4] / P:.1f} ({100 * out[4] / tot:.1f} %)  "
           f"the rest (record load, set-up, masks, the final partial stage-2 batch is in stage 2) {(tot - out[1] - out[2] - out[3] - out[4]) / P:.1f} ({100 * (tot - out[1] - out[2] - out[3] - out[4]) / tot:.1f} %)")
+    print(f"   wave prologue {out[5] / P:.1f}, wave flush {out[6] / P:.1f} (per parent; not part of the total above)")
     print(f"   per parent: grid rows {out[10] / P:.1f}, row batches {out[11] / P:.2f}, non-empty rows {out[12] / P:.1f}, flat candidates {out[13] / P:.1f}, chunk groups (192 candidates) {out[14] / P:.2f}, "
           f"stage-2 batches {out[8] / P:.2f} with {out[9] / max(1, out[8]):.1f} survivors each ({out[9] / P:.1f} survivors per parent), accepted {out[15] / P:.2f}")
     del c, m

@@ -290,6 +290,32 @@ def test_heavy_parent_work_items_change_nothing(monkeypatch):
                 assert np.array_equal(got[k][f], ref[k][f]), (budget, k, f)
 
 
+@pytest.mark.parametrize("shape", ["iso", "aniso", "clustered"])
+def test_parents_per_selection_wave_change_nothing(monkeypatch, shape):
+    """A selection wave takes up to four consecutive parents of the processing order and keeps its survivor ring and its third-stage
+    queue across them (k_select, SEL_NP); the rings are FIFO, so every parent's pairs come out in the order -- and at the places -- one
+    parent per wave wrote them: GSR_HEM_SELECT_NP = 1, 2, 4 give the same levels bit for bit, on the one-pass path and on the COUNT +
+    FILL fallback.  The clouds hold irregular components (pass B), heavy parents (the queue kernel beside the light one) and parents
+    with more survivors than the ring takes in one go (the suspended scan: a few per cent of the parents of any cloud)."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(250000, seed=77, sh_degree=1, shape=shape)
+    c["cov6"][5::997] = np.array([1.0, 0, 0, 1.0, 0, -1.0], np.float32)       # irregular: not positive definite
+    monkeypatch.setenv("GSR_HEM_SELECT_NP", "1")
+    ref, rst = hem.create_mixture(c, 2)
+    assert rst[0]["irregular"] > 0 and rst[0]["heavy_parents"] > 0, rst[0]
+    for np_, budget in (("2", None), ("4", None), ("4", "0"), ("1", "0")):
+        monkeypatch.setenv("GSR_HEM_SELECT_NP", np_)
+        if budget is None:
+            monkeypatch.delenv("GSR_HEM_SPARSE_GB", raising=False)
+        else:
+            monkeypatch.setenv("GSR_HEM_SPARSE_GB", budget)
+        got, st = hem.create_mixture(c, 2)
+        for k in range(2):
+            assert (st[k]["parents"], st[k]["pairs"], st[k]["orphans"], st[k]["dropped"]) == (rst[k]["parents"], rst[k]["pairs"], rst[k]["orphans"], rst[k]["dropped"]), (np_, budget, k)
+            for f in ("xyz", "color", "cov6", "sh", "opacity"):
+                assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (np_, budget, k, f)
+
+
 @pytest.mark.parametrize("deg", [3, 2, 1, 0])
 def test_small_parent_path_changes_nothing(monkeypatch, deg):
     """Parents with at most 16 pairs are served four at a time, one per DPP row of the M-step's wavefront (most parents of a
