@@ -2196,13 +2196,27 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     // of the wave's four rows and then (S0 + S1) + (S2 + S3) over the rows -- here the four rows of the general path are four
     // ROUNDS of this parent's own row, combined in the same order.  (G <= 4: a round then holds 16 / G >= 4 children per row and
     // <= 16 children never chain two products through one fmaf; larger rows -- SH degree 4 and up -- take the general path.)
+    // The wave's (up to four) headers with ONE load: lane l takes dword l of the 128 contiguous bytes, a field is a v_readlane away.
+    // (`a.hdr[s0 + it]` per parent came out as vector loads of one header at a time, each waited for: eight dependent round trips at
+    // the head of every wave where one does.)
+    static_assert(sizeof(MstepHeader) == 32 && MSTEP_K * 8 <= 64, "a wave's headers are 8 dwords each, one per lane");
+    unsigned hv = 0u;
+    if (lane < ns * 8) hv = reinterpret_cast<const unsigned*>(a.hdr + s0)[lane];
+    const auto hfield = [hv](int it, int f) { return (unsigned)__builtin_amdgcn_readlane((int)hv, it * 8 + f); };
+    const auto header = [&hfield](int it) {
+        MstepHeader h;
+        h.off = (long long)(((unsigned long long)hfield(it, 1) << 32) | hfield(it, 0));
+        h.cnt = hfield(it, 2); h.oslot = (int)hfield(it, 3);
+        h.px = __uint_as_float(hfield(it, 4)); h.py = __uint_as_float(hfield(it, 5)); h.pz = __uint_as_float(hfield(it, 6));
+        h.js = (int)hfield(it, 7);
+        return h;
+    };
     unsigned small_mask = 0u;
     if constexpr (G <= 4) {
 #pragma unroll
         for (int it = 0; it < MSTEP_K; ++it)
             if (it < ns) {
-                const MstepHeader h = a.hdr[s0 + it];
-                if (h.oslot >= 0 && h.cnt <= MSTEP_SMALL) small_mask |= 1u << it;
+                if ((int)hfield(it, 3) >= 0 && hfield(it, 2) <= MSTEP_SMALL) small_mask |= 1u << it;
             }
     }
     if (G <= 4 && a.small && small_mask != 0u) {
@@ -2213,7 +2227,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
 #pragma unroll
         for (int it = 0; it < MSTEP_K; ++it)
             if ((small_mask >> it) & 1u) {
-                const MstepHeader h = a.hdr[s0 + it];
+                const MstepHeader h = header(it);
                 maxcnt = h.cnt > maxcnt ? h.cnt : maxcnt;
                 if (q == it) { off_q = h.off; cnt_q = h.cnt; slot_q = h.oslot; ppx = h.px; ppy = h.py; ppz = h.pz; }
             }
@@ -2225,12 +2239,22 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         __builtin_amdgcn_wave_barrier();
         // records: gather round u serves row u (its 16 slots, four lanes per 64-byte record); rows without a small parent and
         // slots beyond a parent's pairs load nothing
+        // (all four rounds' loads first, then the four LDS stores: a load under `if (jr valid)` followed by its store made every round
+        // a round trip of its own; a slot without a pair reads record 0 and stores nothing)
+        {
+            float4 rv[4];
+            unsigned jr[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (!((small_mask >> u) & 1u)) continue;
-            const int r = (lane >> 2) + 16 * u;
-            const unsigned jr = s_j[r];
-            if (jr != 0xffffffffu) s_rec[r * 5 + (lane & 3)] = a.geo[4 * (int64_t)jr + (lane & 3)];
+            for (int u = 0; u < 4; ++u) {
+                jr[u] = s_j[(lane >> 2) + 16 * u];
+                rv[u] = a.geo[4 * (int64_t)(jr[u] != 0xffffffffu ? jr[u] : 0u) + (lane & 3)];
+            }
+            // (pinned here: a load whose only use sits behind a branch is sunk into it by the compiler, and waited for there)
+            asm volatile("" : "+v"(rv[0].x), "+v"(rv[0].y), "+v"(rv[0].z), "+v"(rv[0].w), "+v"(rv[1].x), "+v"(rv[1].y), "+v"(rv[1].z), "+v"(rv[1].w),
+                              "+v"(rv[2].x), "+v"(rv[2].y), "+v"(rv[2].z), "+v"(rv[2].w), "+v"(rv[3].x), "+v"(rv[3].y), "+v"(rv[3].z), "+v"(rv[3].w));
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (jr[u] != 0xffffffffu) s_rec[((lane >> 2) + 16 * u) * 5 + (lane & 3)] = rv[u];
         }
         __builtin_amdgcn_wave_barrier();
         float w = 0.0f;
@@ -2344,7 +2368,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
 
     for (int it = 0; it < ns; ++it) {
         if ((small_mask >> it) & 1u) continue;                  // served above
-        const MstepHeader h = a.hdr[s0 + it];                   // uniform address: scalar loads
+        const MstepHeader h = header(it);
         if (h.oslot < 0) continue;
         const f3 pm = {h.px, h.py, h.pz};
         const unsigned cnt = h.cnt;
