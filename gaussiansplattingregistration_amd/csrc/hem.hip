@@ -482,14 +482,22 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t j = base + lane;
         const unsigned oi = j < n ? order[j] : 0u;
+        // (the four rounds' loads together, pinned in front of the stores: inside `if (base + r < n)` every round was a round trip of its
+        // own; the lanes behind the end read record order[0])
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const unsigned i = (unsigned)__shfl((int)oi, (lane >> 2) + 16 * u, 64);
+            v[u] = rec[4 * (int64_t)i + (lane & 3)];
+        }
+        asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z), "+v"(v[1].w),
+                          "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = (lane >> 2) + 16 * u;
-            const unsigned i = (unsigned)__shfl((int)oi, r, 64);
             if (base + r < n) {
-                const float4 v = rec[4 * (int64_t)i + (lane & 3)];
-                geo[4 * (base + r) + (lane & 3)] = v;
-                st[r * 5 + (lane & 3)] = v;
+                geo[4 * (base + r) + (lane & 3)] = v[u];
+                st[r * 5 + (lane & 3)] = v[u];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1442,11 +1450,22 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
     const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
     if (p >= a.P) return;
     unsigned long long scanned = 0;
+    int selfq = 0;
     if (p >= a.own_lo && p < a.own_hi) {
         const GridParams g = *a.gp;
-        const ParentRec* rp = a.prec + p;
-        const f3 pm = rp->pm;
-        const EllClip ec = rp->ec;
+        // the record's fields with six 16-byte loads issued together (field by field the compiler fetched `active` first, waited, then
+        // the rest one by one behind the branches that use them: four dependent round trips in a kernel that is nothing but latency)
+        const float4* rq = reinterpret_cast<const float4*>(a.prec + p);
+        float4 q0 = rq[0], q3 = rq[3], q6 = rq[6], q7 = rq[7], q8 = rq[8], q9 = rq[9];
+        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q3.w), "+v"(q6.y), "+v"(q6.z), "+v"(q6.w), "+v"(q7.x), "+v"(q7.y), "+v"(q7.z), "+v"(q7.w),
+                          "+v"(q8.x), "+v"(q8.y), "+v"(q8.w), "+v"(q9.x), "+v"(q9.y), "+v"(q9.z));
+        static_assert(offsetof(ParentRec, R) == 60 && offsetof(ParentRec, ec) == 100 && offsetof(ParentRec, active) == 140 && offsetof(ParentRec, ey) == 148,
+                      "k_spans reads the record by offsets");
+        const f3 pm = {q0.x, q0.y, q0.z};
+        const EllClip ec = {q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w, q8.x, q8.y};
+        struct { float R, ey, ez; int active; } rv = {q3.w, q9.y, q9.z, __float_as_int(q8.w)};
+        const auto* rp = &rv;
+        selfq = __float_as_int(q9.x);
         if (rp->active) {
             const float Ra = fabsf(rp->R) * 1.00001f + g.slack;
             const float Ra2 = Ra * Ra;
@@ -1476,7 +1495,7 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
         }
     }
     for (int o = 8; o > 0; o >>= 1) scanned += __shfl_xor(scanned, o);
-    if (p >= a.own_lo && p < a.own_hi && a.prec[p].selfq) scanned += 1ull;      // the parent itself is flat candidate 0
+    if (selfq) scanned += 1ull;                                 // the parent itself is flat candidate 0
     if (sub == 0) a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
 }
 
