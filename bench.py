@@ -611,6 +611,20 @@ def main():
         hem_gauss = float(tg)
     icp_iters = sum(r["icp_iters"] for r in runs) * (world if a.mode == "replicas" else 1)
 
+    # The phases of a level: the timed steps above record only the events a result needs (the level and the launches of k_select and
+    # k_mstep -- gsr_hem_set_timing 1, the library's default: every event between two kernels is a packet of its own, 22 per level).
+    # ONE more pass of the two clouds' levels, outside the timed region, with every phase event on, gives the breakdown.
+    phase_pass = None
+    if rank == 0 and a.mode == "replicas" and ctxs.get("serial"):
+        m = ctxs["hem"]
+        m.set_timing(2)
+        m.set_rng("glibc", 1, 0)
+        phase_pass = []
+        for c in (src, tgt):
+            phase_pass += hem_levels(m, c)[1]
+        sync()
+        m.set_timing(1)
+
     # measured device-copy bandwidth of this very GPU (SURVEY 8d asks for the fraction of both the nominal and a measured
     # figure): 1 GiB device-to-device, read + write traffic
     copy_gbs = None
@@ -640,8 +654,12 @@ def main():
         F = 45
         last = runs[-1]
         kern = [k for r in runs for k in r["kern"]]
-        phases = {p: sum(k[p] for k in kern) / a.steps for p in ("ms_grid", "ms_select", "ms_sumlw", "ms_mstep", "ms_flags", "ms_level",
-                                                                  "ms_k_select_count", "ms_k_select_fill", "ms_k_select", "ms_k_mstep", "ms_k_partition", "ms_k_bucket_sum")}
+        phases = {p: sum(k[p] for k in kern) / a.steps for p in ("ms_level", "ms_k_select_count", "ms_k_select_fill", "ms_k_select", "ms_k_mstep")}
+        if phase_pass:
+            phases.update({p: sum(k[p] for k in phase_pass) for p in ("ms_grid", "ms_select", "ms_sumlw", "ms_mstep", "ms_flags", "ms_k_partition", "ms_k_bucket_sum")})
+            phases["ms_level_with_every_phase_event"] = sum(k["ms_level"] for k in phase_pass)
+            phases["note"] = ("ms_level and ms_k_* of the first line: the timed steps (events around the level, k_select and k_mstep only); the phases: one "
+                              "extra untimed pass with all 22 events of a level on (ms_level_with_every_phase_event is that pass's total)")
         # the two big kernels, each timed by hipEvent pairs on the library's stream around every launch (gsr_hem_get_kernel_ms):
         # k_select (child selection + likelihood) and k_mstep (moment matching).  The roofline object prices the one with the larger
         # total time.  Algorithmic bytes of a launch = SURVEY 8(d)'s bytes_level of ITS level.
@@ -791,13 +809,15 @@ def main():
                 cc = synth.make_cloud_torch(n, seed=400, device=dev, shape="clustered")
                 m = ctxs["hem"]
                 rows = []
-                for _ in range(3):
+                for rep in range(4):
+                    m.set_timing(2 if rep == 3 else 1)                  # three timed like the isotropic level, a fourth with the phase events on
                     m.set_rng("glibc", 1, 0)
                     m.set_level0(cc["xyz"], cc["color"], cc["opacity"], cc["cov6"], cc["sh"], borrow=True)
                     m.run_level()
                     rows.append(m.stats())
+                m.set_timing(1)
                 st = rows[-1]
-                ms = float(np.median([r["ms_level"] for r in rows]))
+                ms = float(np.median([r["ms_level"] for r in rows[:3]]))
                 line["clustered_level"] = {"workload": f"one {n}-splat cloud, synth shape 'clustered' (60 % in 40 Gaussian clumps of 30-100 x the background density with "
                                                        "splats shrunk by the cube root of that, 6 giants of 40 x sigma, 12 outliers at 20-60 h), level 1",
                                            "parents": st["parents"], "candidates_per_parent": st["candidates"] / max(1, st["parents"]), "pairs": st["pairs"],

@@ -78,6 +78,7 @@ SIGNATURES = {
     "gsr_hem_get_stats_ex": (_i32, [_vp, C.POINTER(_i64)]),
     "gsr_hem_get_phase_ms": (_i32, [_vp, C.POINTER(_f32)]),
     "gsr_hem_get_kernel_ms": (_i32, [_vp, C.POINTER(_f32)]),
+    "gsr_hem_set_timing": (_i32, [_vp, _i32]),
     "gsr_icp_create": (_i32, [C.POINTER(_vp), _i32, _vp]),
     "gsr_icp_destroy": (_i32, [_vp]),
     "gsr_icp_set_target": (_i32, [_vp, _vp, _vp, _i64, _f64, _i32]),

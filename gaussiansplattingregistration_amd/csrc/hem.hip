@@ -3140,6 +3140,7 @@ struct gsr_hem_ctx {
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec;
+    int timing = 1;                 // gsr_hem_set_timing / GSR_HEM_TIMING: 0 no events, 1 level + k_select + k_mstep, 2 every phase (see GSR_TIME)
     int select_np = 0;              // GSR_HEM_SELECT_NP=1|2|4: light parents per selection wave (the rings are kept across them, see SEL_NP); 0 = by level size
     bool mstep_split = true;        // GSR_HEM_MSTEP_SPLIT=0: a parent of more than MSTEP_SEG pairs keeps ONE wave for all its segments (the schedule of rounds 1-3)
     DevBuf mh_list, mh_items, mh_scratch;
@@ -3401,6 +3402,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SMALL")) c->mstep_small = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SPLIT")) c->mstep_split = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_TIMING")) { const int v = atoi(s); c->timing = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* s = getenv("GSR_HEM_SELECT_NP")) { const int v = atoi(s); c->select_np = v < 1 ? 1 : (v > SEL_NP ? SEL_NP : v); }
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
@@ -3659,6 +3661,11 @@ int32_t gsr_hem_get_kernel_ms(gsr_hem_ctx* c, float* out8) {
     memcpy(out8, c->kernel_ms, sizeof(c->kernel_ms));
     return GSR_OK;
 }
+int32_t gsr_hem_set_timing(gsr_hem_ctx* c, int32_t level) {
+    if (!c || level < 0 || level > 2) return fail(GSR_E_INVALID, "gsr_hem_set_timing: NULL context or level outside 0..2");
+    c->timing = level;
+    return GSR_OK;
+}
 int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out8) {
     if (!c || !out8) return fail(GSR_E_INVALID, "gsr_hem_get_phase_ms: NULL argument");
     memcpy(out8, c->phase_ms, sizeof(c->phase_ms));
@@ -3667,6 +3674,11 @@ int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* c, float* out8) {
 
 // GSR_HEM_DEBUG_SYNC=1: synchronise and report after every stage of a level (localises a device fault)
 // Always: a failed LAUNCH of the stage just enqueued (bad configuration, too much LDS) is reported with the stage's name.
+// The events between the phases (gsr_hem_get_phase_ms / _kernel_ms).  An event record between two kernels is a barrier packet of its
+// own, 22 per level: 0.1 ms of a 5 M level, 6 % of a 556 k one.  gsr_hem_set_timing: 0 = none, 1 (default) = the level and the two
+// dominant kernels (GSR_TIME1), 2 = every phase.
+#define GSR_TIME(ev, stream) do { if (c->timing >= 2) GSR_HIP(hipEventRecord(ev, stream)); } while (0)
+#define GSR_TIME1(ev, stream) do { if (c->timing >= 1) GSR_HIP(hipEventRecord(ev, stream)); } while (0)
 #define GSR_CHECKPOINT(label)                                                                       \
     do {                                                                                            \
         {                                                                                           \
@@ -3765,14 +3777,14 @@ struct PartLevel {
                 hipLaunchKernelGGL(k_pack_rows, dim3(stride_grid(n_own * 64)), blk, 0, st, n_own, F, c->dflag.as<int>() + (int64_t)q * n_own,
                                    c->dpos.as<int>() + (int64_t)q * n_own, c->rec.as<float4>(), L.sh.as<float>(), c->gid.as<unsigned>(),
                                    c->rows_send.as<float>() + soff[q] * RW, c->sh_send.as<float>() + soff[q] * F, c->sent_idx.as<unsigned>() + soff[q]);
-        GSR_HIP(hipEventRecord(c->evp[0], st));
+        GSR_TIME(c->evp[0], st);
         GSR_TRY(exchange(c->rows_send.p, c->rows_recv.p, (size_t)RW * 4, false));
-        GSR_HIP(hipEventRecord(c->evp[1], st));
+        GSR_TIME(c->evp[1], st);
         if (F > 0) {        // every rank issues it (the same order of communicator calls everywhere), whatever its own counts
             GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
-            GSR_HIP(hipEventRecord(c->evp[2], c->aux2));
+            GSR_TIME(c->evp[2], c->aux2);
             GSR_TRY(exchange(c->sh_send.p, c->ghost_sh.p, (size_t)F * 4, false, c->aux2));
-            GSR_HIP(hipEventRecord(c->evp[3], c->aux2));
+            GSR_TIME(c->evp[3], c->aux2);
             GSR_HIP(hipEventRecord(c->ev_halo, c->aux2));
             halo_sh_pending = true;
         }
@@ -3951,7 +3963,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     }
     const dim3 blk(256);
     dim3 grd(stride_grid(n));
-    GSR_HIP(hipEventRecord(c->ev[0], st));
+    GSR_TIME1(c->ev[0], st);
 
     // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
     GSR_TRY(c->rec.reserve(n * 64)); GSR_TRY(c->bbox.reserve(64));
@@ -4085,7 +4097,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     hipLaunchKernelGGL(k_child_stream, grd, blk, 0, st, n, (int64_t)gp.ncells, P_all, c->A.as<float4>(), c->pflag.as<int>(), c->ppos.as<int>(),
                        c->cellStart.as<int>(), c->Ac.as<float4>(), c->cellStartC.as<int>(), (int)SEL_PAD);
     GSR_CHECKPOINT("grid + gather");
-    GSR_HIP(hipEventRecord(c->ev[1], st));
+    GSR_TIME(c->ev[1], st);
 
     // ---- 2. selection ------------------------------------------------------------------------------
     // Fast path (SPARSE): one evaluation pass.  k_spans sums the span lengths per parent (an upper bound of
@@ -4216,15 +4228,15 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             const size_t Cm = (size_t)(cand > 0 ? cand : 1);
             GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
             sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
-            GSR_HIP(hipEventRecord(c->evk[2], st));
+            GSR_TIME1(c->evk[2], st);
             GSR_CHECKPOINT("spans + ordering");
             GSR_LAUNCH_SELECT(SEL_SPARSE);
             GSR_CHECKPOINT("k_select<SPARSE>");
-            GSR_HIP(hipEventRecord(c->evk[3], st));
+            GSR_TIME1(c->evk[3], st);
         } else {
-            GSR_HIP(hipEventRecord(c->evk[0], st));
+            GSR_TIME1(c->evk[0], st);
             GSR_LAUNCH_SELECT(SEL_COUNT);
-            GSR_HIP(hipEventRecord(c->evk[1], st));
+            GSR_TIME1(c->evk[1], st);
         }
         GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), P));
         GSR_TRY(total_of(c->poff.as<int64_t>(), c->pcnt.as<unsigned>(), P, &M));
@@ -4241,9 +4253,9 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
                 if (sa.heavy_blocks)                         // the queue cursor back behind the statically assigned items
                     hipLaunchKernelGGL(k_fill_const<int>, dim3(1), dim3(1), 0, st, (int64_t)1, sa.hq + 1, (int)(SEL_HEAVY_BLOCKS * WPB));
-                GSR_HIP(hipEventRecord(c->evk[2], st));
+                GSR_TIME1(c->evk[2], st);
                 GSR_LAUNCH_SELECT(SEL_FILL);
-                GSR_HIP(hipEventRecord(c->evk[3], st));
+                GSR_TIME1(c->evk[3], st);
             }
         }
         c->sparse_path = sparse;
@@ -4252,7 +4264,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 #undef GSR_LAUNCH_SELECT
     c->stats[1] = M;
     GSR_CHECKPOINT("selection");
-    GSR_HIP(hipEventRecord(c->ev[2], st));
+    GSR_TIME(c->ev[2], st);
 
     // ---- 3. per-child sums of wL (deterministic whatever the order: LDS fixed point, k_bucket_sum) ----------
     // The pairs of parent p are the run [seg[p], seg[p] + pcnt[p]) of (pc, pw): the sparse segments of the one-pass selection or
@@ -4290,17 +4302,17 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
         GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
         (void)hipGetLastError();
-        GSR_HIP(hipEventRecord(c->evm[2], st));
+        GSR_TIME(c->evm[2], st);
         launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
                          c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
         GSR_HIP(hipGetLastError());
-        GSR_HIP(hipEventRecord(c->evm[3], st));
+        GSR_TIME(c->evm[3], st);
         GSR_CHECKPOINT("pair partition (fixed capacity)");
-        GSR_HIP(hipEventRecord(c->evm[4], st));
+        GSR_TIME(c->evm[4], st);
         hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, (const unsigned long long*)nullptr, cap,
                            c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
                            c->geo.as<float>() + 15);
-        GSR_HIP(hipEventRecord(c->evm[5], st));
+        GSR_TIME(c->evm[5], st);
         GSR_HIP(hipGetLastError());
         fixed_tried = true;
         return GSR_OK;
@@ -4362,7 +4374,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL(k_orphan_flags, grd, blk, 0, st, n, c->sumLw.as<float>(), c->oflag.as<int>(), c->geo.as<float>() + 15);
     }
     GSR_CHECKPOINT("per-child sums");
-    GSR_HIP(hipEventRecord(c->ev[3], st));
+    GSR_TIME(c->ev[3], st);
 
     // ---- 4. output ranks in input order; M-step; orphans -----------------------------------------
     GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
@@ -4486,7 +4498,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             hipLaunchKernelGGL(k_mstep_heavy_finish, dim3(256), dim3(64), 0, st, ma);                                    \
         }                                                                                                                \
     }
-        GSR_HIP(hipEventRecord(c->evm[0], st));
+        GSR_TIME1(c->evm[0], st);
         if (nq == 0) { GSR_LAUNCH_MSTEP(0) }
         else if (nq <= 1 * MSTEP_NV) { GSR_LAUNCH_MSTEP(1) }
         else if (nq <= 2 * MSTEP_NV) { GSR_LAUNCH_MSTEP(2) }
@@ -4496,7 +4508,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         else { GSR_LAUNCH_MSTEP(32) }      // F <= 384
 #undef GSR_LAUNCH_MSTEP
         if (msplit && hst != st) GSR_HIP(hipStreamWaitEvent(st, c->ev_mjoin, 0));
-        GSR_HIP(hipEventRecord(c->evm[1], st));
+        GSR_TIME1(c->evm[1], st);
     }
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
@@ -4536,7 +4548,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (part) GSR_TRY(pl.global_ranks(P, n_pre, P_glob, O_glob));
     const int64_t n_pre_glob = P_glob + O_glob;
     GSR_CHECKPOINT("M-step + orphans");
-    GSR_HIP(hipEventRecord(c->ev[4], st));
+    GSR_TIME(c->ev[4], st);
 
     // ---- 5. new parent flags (one draw per component, before the erase), validity erase ---------
     if (part) {     // the libc stream is drawn for the GLOBAL level; a row takes the flag at its global rank
@@ -4596,7 +4608,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     int64_t n_glob_next = n_pre_glob;
     if (part) GSR_TRY(pl.drop_erased(O, n_pre, n_pre_glob, dropped, n_glob_next));
     GSR_CHECKPOINT("flags + validity");
-    GSR_HIP(hipEventRecord(c->ev[5], st));
+    GSR_TIME1(c->ev[5], st);
     GSR_HIP(hipStreamSynchronize(st));
     unborrow_level0(c);                 // a borrowed level 0 goes back to the caller; cur gets its own buffers again
     c->cur.swap(c->nxt);
@@ -4608,22 +4620,25 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     if (part) { c->gid.swap(c->gid_next); c->n_global = n_glob_next; }
     c->stats[3] = dropped;
     c->stats[7] = c->cur.n;
-    for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
+    memset(c->phase_ms, 0, sizeof(c->phase_ms));
+    memset(c->part_ms, 0, sizeof(c->part_ms));
+    memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
+    if (c->timing >= 1) {
+    if (c->timing >= 2) for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
     (void)hipEventElapsedTime(&c->phase_ms[5], c->ev[0], c->ev[5]);
     c->phase_ms[6] = c->phase_ms[7] = 0.0f;
     if (P > 0 && !c->sparse_path) (void)hipEventElapsedTime(&c->phase_ms[6], c->evk[0], c->evk[1]);
     if (P > 0 && (M > 0 || c->sparse_path)) (void)hipEventElapsedTime(&c->phase_ms[7], c->evk[2], c->evk[3]);
-    memset(c->part_ms, 0, sizeof(c->part_ms));
-    if (part) {
+    if (part && c->timing >= 2) {
         (void)hipEventElapsedTime(&c->part_ms[0], c->evp[0], c->evp[1]);
         if (F > 0) { GSR_HIP(hipStreamSynchronize(c->aux2)); (void)hipEventElapsedTime(&c->part_ms[1], c->evp[2], c->evp[3]); }
     }
-    memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
     c->kernel_ms[0] = c->phase_ms[7];
     if (P > 0) (void)hipEventElapsedTime(&c->kernel_ms[1], c->evm[0], c->evm[1]);
-    if (fixed_tried && !c->partition_overflowed) {
+    if (c->timing >= 2 && fixed_tried && !c->partition_overflowed) {
         (void)hipEventElapsedTime(&c->kernel_ms[2], c->evm[2], c->evm[3]);
         (void)hipEventElapsedTime(&c->kernel_ms[3], c->evm[4], c->evm[5]);
+    }
     }
     if (n_out) *n_out = c->cur.n;
     if (n_dropped) *n_dropped = dropped;

@@ -285,6 +285,12 @@ class HemMixture:
                                              1 if as_torch else 0), "gsr_hem_get_level")
         return out
 
+    def set_timing(self, level: int):
+        """How much a level times: 0 nothing, 1 (the default) the level and the launches of k_select / k_mstep, 2 every phase and the
+        partition kernels too (``stats()``'s other ``ms_*`` entries read 0 below 2).  Events between kernels are not free: 22 per level
+        at 2, 0.1 ms of a 5 M-splat level (gsr_hem_set_timing)."""
+        _lib.check(self._L.gsr_hem_set_timing(self._h, int(level)), "gsr_hem_set_timing")
+
     def stats(self):
         s = (C.c_int64 * 8)()
         _lib.check(self._L.gsr_hem_get_stats(self._h, s), "gsr_hem_get_stats")

@@ -214,6 +214,13 @@ int32_t gsr_hem_get_phase_ms(gsr_hem_ctx* ctx, float* out8);
  *  [0] k_select (the light parents' launch; the heavy work items run beside it)  [1] k_mstep  [2] k_partition  [3] k_bucket_sum
  *  [4..7] reserved (0).  What bench.py prices against the roofline. */
 int32_t gsr_hem_get_kernel_ms(gsr_hem_ctx* ctx, float* out8);
+/* How much of the above a level records (the reference has no counterpart: its only trace is a `cout` per level, mixture.cpp:32).
+ * An event between two kernels is a packet of its own on the stream -- 22 per level, 0.1 ms of a 5 M-splat level, 6 % of a 556 k one:
+ *   0  nothing (every figure of gsr_hem_get_phase_ms / _kernel_ms reads 0)
+ *   1  the whole level and the launches of k_select and k_mstep: phase [5] [6] [7], kernel [0] [1]   (the default)
+ *   2  every phase and kernel listed above
+ * The environment variable GSR_HEM_TIMING sets the value a new context starts with. */
+int32_t gsr_hem_set_timing(gsr_hem_ctx* ctx, int32_t level);
 
 /* ------------------------------------------------------------------------------------------- ICP */
 

@@ -4,6 +4,7 @@ import torch
 from gaussiansplattingregistration_amd import hem, synth
 n = 5_000_000
 m = hem.HemMixture()
+m.set_timing(2)
 for seed, shape in ((100, "aniso"), (300, "aniso"), (100, "iso"), (400, "clustered")):
     c = synth.make_cloud_torch(n, seed=seed, shape=shape)
     for borrow in (True,):

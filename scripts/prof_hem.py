@@ -10,6 +10,7 @@ reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
 shape = sys.argv[4] if len(sys.argv) > 4 else "iso"
 c = synth.make_cloud_torch(n, seed=100, shape=shape)
 m = hem.HemMixture()
+m.set_timing(int(os.environ.get("GSR_HEM_TIMING", "2")))     # the phases are printed below
 for rep in range(reps):
     m.set_rng("glibc", 1, 0)
     m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])

@@ -440,6 +440,31 @@ def test_two_contexts_on_two_threads_equal_each_alone():
         m.close()
 
 
+def test_timing_levels_change_nothing_but_the_figures():
+    """``gsr_hem_set_timing``: 0 records no event at all, 1 (the default) the level and the launches of k_select / k_mstep, 2 every
+    phase.  Same level whatever the setting; the figures a setting does not record read 0; a value outside 0..2 is refused."""
+    from gaussiansplattingregistration_amd import hem, synth, _lib
+    c = synth.make_cloud(60000, seed=12, sh_degree=1)
+    ref = None
+    for level in (1, 0, 2):
+        with hem.HemMixture() as m:
+            if level != 1:
+                m.set_timing(level)
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+            m.run_level()
+            st = m.stats()
+            got = m.get_level()
+        if ref is None:
+            ref = got
+        for f in ("xyz", "color", "cov6", "sh", "opacity"):
+            assert np.array_equal(got[f], ref[f]), (level, f)
+        assert (st["ms_level"] > 0) == (level >= 1) and (st["ms_k_select"] > 0) == (level >= 1) and (st["ms_k_mstep"] > 0) == (level >= 1), (level, st)
+        assert (st["ms_grid"] > 0) == (level == 2) and (st["ms_sumlw"] > 0) == (level == 2) and (st["ms_k_partition"] > 0) == (level == 2), (level, st)
+    with hem.HemMixture() as m:
+        with pytest.raises(RuntimeError, match="outside 0..2"):
+            m.set_timing(3)
+
+
 def test_read_back_poll_changes_nothing(monkeypatch):
     """The host reads counts back by polling a sequence word the device writes into pinned memory; GSR_HEM_RB_POLL=0 waits with
     hipStreamSynchronize instead.  Same values either way."""
