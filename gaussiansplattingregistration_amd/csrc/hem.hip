@@ -1882,16 +1882,14 @@ __global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, int shift, const
         for (; k < k1; k += bd) atomicMax(&s_max[child[k] - (unsigned)c0], __float_as_uint(wl[k]) & 0x7fffffffu);
     }
     __syncthreads();
-#pragma unroll 4
-    for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-        const unsigned i = child[k] - (unsigned)c0;
-        const float w = wl[k];
+    const auto add_term = [&](unsigned ch, float w) {
+        const unsigned i = ch - (unsigned)c0;
         const unsigned mb = s_max[i];
         if (mb >= 0x7f800000u) {                   // a non-finite term somewhere: collect flags (1 +inf, 2 -inf, 4 NaN)
             const unsigned wb = __float_as_uint(w);
             const unsigned long long f = (wb & 0x7fffffffu) > 0x7f800000u ? 4ull : (wb == 0x7f800000u ? 1ull : (wb == 0xff800000u ? 2ull : 0ull));
             if (f) atomicOr(&s_acc[i], f);
-            continue;
+            return;
         }
         int e = (int)(mb >> 23);
         e = e < 1 ? 1 : e;                         // subnormal maximum: the scale of the smallest normal exponent
@@ -1899,6 +1897,19 @@ __global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, int shift, const
         const double scale = __longlong_as_double((long long)(1023 + k2) << 52);
         const long long q = __double2ll_rn((double)w * scale);
         atomicAdd(&s_acc[i], (unsigned long long)q);
+    };
+    // (the second walk like the first: four loads of a thread in flight -- an unrolled loop with the LDS work between its loads waited
+    // for every pair of loads: one round trip per 1 024 pairs, 88 of them for a bucket of a 5 M level)
+    {
+        unsigned long long k = k0 + threadIdx.x;
+        const unsigned long long bd = blockDim.x;
+        for (; k + 3 * bd < k1; k += 4 * bd) {
+            unsigned c_0 = child[k], c_1 = child[k + bd], c_2 = child[k + 2 * bd], c_3 = child[k + 3 * bd];
+            float w_0 = wl[k], w_1 = wl[k + bd], w_2 = wl[k + 2 * bd], w_3 = wl[k + 3 * bd];
+            asm volatile("" : "+v"(c_0), "+v"(c_1), "+v"(c_2), "+v"(c_3), "+v"(w_0), "+v"(w_1), "+v"(w_2), "+v"(w_3));
+            add_term(c_0, w_0); add_term(c_1, w_1); add_term(c_2, w_2); add_term(c_3, w_3);
+        }
+        for (; k < k1; k += bd) add_term(child[k], wl[k]);
     }
     __syncthreads();
     for (int i = threadIdx.x; i < nc; i += blockDim.x) {
