@@ -282,6 +282,9 @@ __device__ __forceinline__ void icp_consider(const float4 q, int j, double px, d
 // candidate runs of its 64 neighbouring queries in LDS -- all slower (what they add in registers / LDS costs a
 // round of workgroups on the chip, and the kernel's time is its slowest wave, not its average one).
 #define ICP_BLOCK_CROWDED 24     // points in a row of the 27-cell block from which on the row is tested against the bound before it is scanned
+#ifndef ICP_ROW_BATCH
+#define ICP_ROW_BATCH 4
+#endif
 template <int BLOCK>
 __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restrict__ cellStart,
                                            const float4* __restrict__ Tq, double px, double py, double pz, double& best_d2,
@@ -322,14 +325,18 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
                 const double dzb = icp_slab_dist(pz, g.oz, g.c, cz + t / 3 - 1, eps, g.gz), dyb = icp_slab_dist(py, g.oy, g.c, cy + t % 3 - 1, eps, g.gy);
                 if (dzb * dzb + dyb * dyb > bd) continue;
             }
-            for (int j = rs[t]; j < re[t]; j += 4) {
+            // ICP_ROW_BATCH points per round trip; the slots behind the row's end re-read its last point.  (A row of three cells holds
+            // ~6 points at two per cell, so four per batch are two dependent round trips per row -- and yet 2, 3 and 4 per batch measure
+            // the same, 6 per batch +3 % and 8 per batch +15-35 % on the coarse levels: the registers cost more waves than the shorter
+            // chain buys, profiles/r04q_icp_row_batch_ab.txt.)
+            for (int j = rs[t]; j < re[t]; j += ICP_ROW_BATCH) {
                 const int l = re[t] - 1;
-                const int j1 = j + 1 < l ? j + 1 : l, j2 = j + 2 < l ? j + 2 : l, j3 = j + 3 < l ? j + 3 : l;
-                const float4 q0 = Tq[j], q1 = Tq[j1], q2 = Tq[j2], q3 = Tq[j3];
-                icp_consider(q0, j, px, py, pz, bd, best, best_i);
-                icp_consider(q1, j1, px, py, pz, bd, best, best_i);
-                icp_consider(q2, j2, px, py, pz, bd, best, best_i);
-                icp_consider(q3, j3, px, py, pz, bd, best, best_i);
+                int jj[ICP_ROW_BATCH];
+                float4 qq[ICP_ROW_BATCH];
+#pragma unroll
+                for (int b = 0; b < ICP_ROW_BATCH; ++b) { jj[b] = j + b < l ? j + b : l; qq[b] = Tq[jj[b]]; }
+#pragma unroll
+                for (int b = 0; b < ICP_ROW_BATCH; ++b) icp_consider(qq[b], jj[b], px, py, pz, bd, best, best_i);
             }
         }
         }
