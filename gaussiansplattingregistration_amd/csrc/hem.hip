@@ -2045,9 +2045,16 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
 // segments' totals are added in segment order.  A parent of at most MSTEP_SEG pairs (all but the giants) is one segment: nothing
 // changed for it.  The giants' segments are independent, which is the point: a parent with 5 * 10^4 pairs (found on the surfel
 // cloud) kept ONE wave busy for 2.5 ms, the whole M-step of that level.
+// The 14 moment sums of the parent in flight live in the PADDING of the record stage (s_rec rows are 80 bytes apart for the sake of the
+// LDS banks; the fifth float4 of rows 60 .. 63 is nobody's): an array of their own made the workgroup 10 304 bytes of LDS -- nine
+// allocation granules of 1 280 bytes, 14 waves per CU -- where 10 240 are eight granules and 16 waves, what the kernel's registers allow.
+struct MomRef {
+    float4* rec;
+    __device__ __forceinline__ float& operator[](int i) const { return reinterpret_cast<float*>(rec + (60 + (i >> 2)) * 5 + 4)[i & 3]; }
+};
 template <int G>
 __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int gl, int grp, const int (&qi)[MSTEP_NV], float* s_w, unsigned* s_j,
-                                              float4* s_acc, float* s_mom, float4* s_rec, long long off, unsigned cnt, const f3 pm,
+                                              float4* s_acc, MomRef s_mom, float4* s_rec, long long off, unsigned cnt, const f3 pm,
                                               float4 (&acc)[MSTEP_NV]) {
     constexpr int GG = G > 0 ? G : 1;
     constexpr int CPR = 64 / GG;                                // children per round
@@ -2165,15 +2172,14 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ float s_w_[WPB][MSTEP_CHUNK];
     __shared__ unsigned s_j_[WPB][MSTEP_CHUNK];
     __shared__ float4 s_acc_[WPB][MSTEP_NV * 64];               // per-lane SH partial sums of a parent with more than MSTEP_CHUNK pairs
-    __shared__ float s_mom_[WPB][16];                           // the 14 moment sums of the parent
     __shared__ float4 s_rec_[WPB][64 * 5];                      // part 1: the batch's geometry records on their way to the pairs' lanes (80-byte stride)
     constexpr int GG = G > 0 ? G : 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     float* s_w = s_w_[wv];
     unsigned* s_j = s_j_[wv];
     float4* s_acc = s_acc_[wv];
-    float* s_mom = s_mom_[wv];
     float4* s_rec = s_rec_[wv];
+    const MomRef s_mom = {s_rec};                               // the 14 moment sums of the parent (see MomRef)
     float* s_out = reinterpret_cast<float*>(s_acc);             // at the end of a parent: its SH row on the way out
     const int gl = lane & (GG - 1), grp = lane / GG;
     const int nq = a.RSH >> 2;                                  // float4 per SH row
