@@ -651,7 +651,7 @@ struct SelectArgs {
 enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
 #define SEL_PART 8192         // candidates per work item of a heavy parent, at most (SelectArgs::part)
 #define SEL_HEAVY_BLOCKS 2048  // workgroups at the head of k_select that serve the queue of heavy work items (a multiple of 8)
-#define SEL_QCAP 512          // survivor ring (power of two >= 64 + SEL_U*64)
+#define SEL_QCAP 256          // survivor ring (power of two >= 64 + SEL_U*64: the rest of a batch -- or 63 entries and a parent's own -- plus a group of chunks)
 #define SEL_U 3               // chunks whose candidate loads are in flight together (2 or 3: equal, 4: +1 %, 6: +2 %, 8: +14 % -- registers)
 #define SEL_MCAP 1024         // flat positions covered by the row-start bit mask at a time (2048 before the parent slots: LDS in 1 280-byte granules, 9 per workgroup = 14 workgroups per CU)
 #define SEL_PAD (64 * SEL_U)  // entries the sorted A array is padded by: the inactive lanes of a batch's last chunks read past the last row
@@ -1053,16 +1053,15 @@ __device__ __forceinline__ float white_smd(const float (&vc)[11], float cx, floa
 // One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
 // REGULAR ones; IRR = true scans the list of irregular components (ipos, addressed through irank at the cell
 // boundaries).  Survivors of the stage-1 filter go to the LDS ring.
-// INDRAIN = true (the heavy work items): full batches of 64 survivors go through stage 2 from inside the scan.
-// INDRAIN = false (the light parents): the scan only FILLS the ring and the caller drains it -- behind the scan, where none of the
-// scan's vector state is alive (stage 2 inside the chunk loop made the kernel's register count the SUM of the two).  A ring without
-// room for another group of chunks SUSPENDS the scan: it returns false with the position (row batch rb0, the candidates `cum` in front
-// of that batch, the flat position `lo` to go on from -- the work items' own [lo, hi) mechanism), and the next call picks up there
-// at the price of that batch's row spans over again.  A light parent leaves ~110 survivors: it does not happen to it.
-template <int MODE, bool IRR, bool INDRAIN>
-__device__ __forceinline__ bool select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const ParLds* par, unsigned ktag,
+// Full batches of 64 survivors go through stage 2 from inside the scan (the ring holds the rest of a batch plus one group of chunks).
+// (Tried on the way to four parents per wave: the scan only FILLING a 512-entry ring, suspended when it is full and resumed through
+// the work items' [lo, hi) mechanism, the drain behind it -- it kept stage 2's registers out of the scan's when the kernel held 96
+// VGPRs.  With the parent record in scalar registers both forms need 65, and this one is 5 % faster: no suspended scans (6 % of the
+// parents recomputed a batch of row spans), half the ring.  profiles/r04o_*.)
+template <int MODE, bool IRR>
+__device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const ParLds* par, unsigned ktag,
                                             const float (&vc)[11], int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count_v,
-                                            Q3& q3, int& rb0, unsigned& cum, unsigned& lo, unsigned hi) {
+                                            Q3& q3, unsigned& cum, unsigned lo, unsigned hi) {
     const f3 pm = pr.pm;
     const EllClip& ec = pr.ec;
     // (uniform values, but float arithmetic is VALU work and its results would sit in vector registers for the whole scan: the box
@@ -1086,7 +1085,7 @@ __device__ __forceinline__ bool select_scan(const SelectArgs& a, const GridParam
     const float Ra2 = unif(Ra * Ra);
     const bool white = !IRR && pr.white != 0.0f;                // wave-uniform
     SEL_PROF_CNT(10, nrows, lane);
-    for (int rb = rb0; rb < nrows; rb += 64) {
+    for (int rb = 0; rb < nrows; rb += 64) {
         SEL_PROF_T(tpr);
         SEL_PROF_CNT(11, 1, lane);
         const int r = rb + lane;
@@ -1169,28 +1168,18 @@ __device__ __forceinline__ bool select_scan(const SelectArgs& a, const GridParam
                 }
                 __builtin_amdgcn_wave_barrier();
                 SEL_PROF_ADD(4, tps, lane);
-                if (INDRAIN) {
-                    // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
-                    while (qn >= 64) {
-                        select_stage2<MODE>(a, par, lane, 64, q, qh, count_v, q3);
-                        qh = (qh + 64) & (SEL_QCAP - 1);
-                        qn -= 64;
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                } else if (qn + 64 * SEL_U > SEL_QCAP) {                      // no room for the next group: suspend
-                    if (mine) bits[rel >> 6] = 0ull;
-                    __builtin_amdgcn_wave_barrier();
-                    // (the group's chunks end at the segment's end: what lies behind it has not been looked at)
-                    rb0 = rb; cum = cum0; lo = cum0 + (unsigned)(t0 + 64 * SEL_U < seg_end ? t0 + 64 * SEL_U : seg_end);
-                    return false;
+                // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
+                while (qn >= 64) {
+                    select_stage2<MODE>(a, par, lane, 64, q, qh, count_v, q3);
+                    qh = (qh + 64) & (SEL_QCAP - 1);
+                    qn -= 64;
                 }
+                __builtin_amdgcn_wave_barrier();
             }
             if (mine) bits[rel >> 6] = 0ull;                                  // leave the mask clean for the next segment / batch
             __builtin_amdgcn_wave_barrier();
         }
     }
-    rb0 = 0;
-    return true;
 }
 
 // What stages 2 / 3 need of parent p, from its record in memory to the wave's LDS slot (ONE lane calls this per parent; the slot is
@@ -1206,7 +1195,7 @@ __device__ __forceinline__ void select_fill_par(const SelectArgs& a, int p, int6
 // One work item: parent p (the wave's k-th), part [lo, hi) of its flat candidate space (the whole parent: 0, 2^32 - 1); its pairs
 // go to par[k].base on (FILL / SPARSE; select_fill_par has filled par[k]).  Survivors and accepted pairs may stay behind in the
 // rings: select_flush ends a wave's (a work item's) run.  The number of accepted pairs accumulates in lane k of count_v.
-template <int MODE, bool INDRAIN>
+template <int MODE>
 __device__ __forceinline__ void select_parent(const SelectArgs& a, const GridParams& g, int p, int k, unsigned lo, unsigned hi, int lane,
                                               const ParLds* par, unsigned* q, int& qh, int& qn, unsigned long long* bits, unsigned& count_v, Q3& q3) {
     SEL_PROF_T(tp0);
@@ -1230,6 +1219,13 @@ __device__ __forceinline__ void select_parent(const SelectArgs& a, const GridPar
         for (int i = 0; i < 8; ++i) raw[32 + i] = w2[i];
         __builtin_memcpy(&pr, raw, sizeof(pr));
     }
+    // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs once per parent)
+    float vc[11];
+    {
+        const float src[11] = {pr.pm.x, pr.pm.y, pr.pm.z, pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 11; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vc[i]) : "s"(src[i]));
+    }
     const unsigned ktag = (unsigned)k << SEL_TAG_SHIFT;
     unsigned cum = 0;                   // flat candidates of the batches behind the scan
     if (pr.selfq) {                     // the parent itself: flat candidate 0, straight into the survivor ring (stage 2 decides)
@@ -1241,35 +1237,10 @@ __device__ __forceinline__ void select_parent(const SelectArgs& a, const GridPar
         __builtin_amdgcn_wave_barrier();
     }
     if (pr.active) {
-        int pass = 0, rb = 0;
-        for (;;) {
-            bool done = true;
-            {
-                // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs; again after every drain, so that they
-                // are not alive across stage 2)
-                float vc[11];
-                const float src[11] = {pr.pm.x, pr.pm.y, pr.pm.z, pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
-#pragma unroll
-                for (int i = 0; i < 11; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vc[i]) : "s"(src[i]));
-                // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
-                // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
-                if (pass == 0) {
-                    done = select_scan<MODE, false, INDRAIN>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, rb, cum, lo, hi);
-                    if (done) pass = 1;
-                }
-                if (done && a.n_irr > 0)
-                    done = select_scan<MODE, true, INDRAIN>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, rb, cum, lo, hi);
-            }
-            if (!INDRAIN) {
-                while (qn >= 64) {
-                    select_stage2<MODE>(a, par, lane, 64, q, qh, count_v, q3);
-                    qh = (qh + 64) & (SEL_QCAP - 1);
-                    qn -= 64;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (done) break;
-        }
+        // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
+        // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
+        select_scan<MODE, false>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, cum, lo, hi);
+        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, cum, lo, hi);
     }
     SEL_PROF_ADD(0, tp0, lane);
     SEL_PROF_CNT(7, 1, lane);
@@ -1300,14 +1271,12 @@ __device__ __forceinline__ void select_flush(const SelectArgs& a, const ParLds* 
 template <int MODE, int WPB, bool QUEUE>
 __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
     __shared__ unsigned s_q[WPB][SEL_QCAP];
-    __shared__ double s_logtab[32];
     __shared__ unsigned s_q3u[WPB][2][SEL_Q3CAP];
     __shared__ float s_q3f[WPB][4][SEL_Q3CAP];
     __shared__ unsigned long long s_bits[WPB][SEL_MCAP / 64 + SEL_U];
     __shared__ ParLds s_par[WPB][SEL_NP];
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    if (lane < 32) s_logtab[lane] = k_logf_tab[lane];       // every wave writes the same 32 values: no barrier needed
-    a.logtab = s_logtab;
+    a.logtab = k_logf_tab;                                  // (the exact logf is a rare path: its table stays in constant memory, 256 bytes of LDS less)
     if (lane < SEL_MCAP / 64 + SEL_U) s_bits[wv][lane] = 0ull;
     unsigned* q = s_q[wv];
     ParLds* par = s_par[wv];
@@ -1333,7 +1302,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
             unsigned count_v = 0u;
             if (lane == 0) select_fill_par(a, p, base, par);
             __builtin_amdgcn_wave_barrier();
-            select_parent<MODE, true>(a, g, p, 0, lo, hi, lane, par, q, qh, qn, s_bits[wv], count_v, q3);
+            select_parent<MODE>(a, g, p, 0, lo, hi, lane, par, q, qh, qn, s_bits[wv], count_v, q3);
             select_flush<MODE>(a, par, lane, q, qh, qn, count_v, q3);
             if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) {
                 a.part_cnt[item] = count_v;
@@ -1377,7 +1346,7 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
             const int k = __builtin_ctzll(todo);
             todo &= todo - 1ull;
             const int p = __builtin_amdgcn_readlane(p_v, k);
-            select_parent<MODE, false>(a, g, p, k, 0u, 0xffffffffu, lane, par, q, qh, qn, s_bits[wv], count_v, q3);
+            select_parent<MODE>(a, g, p, k, 0u, 0xffffffffu, lane, par, q, qh, qn, s_bits[wv], count_v, q3);
         }
         SEL_PROF_T(tpf);
         select_flush<MODE>(a, par, lane, q, qh, qn, count_v, q3);
