@@ -296,7 +296,7 @@ def test_parents_per_selection_wave_change_nothing(monkeypatch, shape):
     queue across them (k_select, SEL_NP); the rings are FIFO, so every parent's pairs come out in the order -- and at the places -- one
     parent per wave wrote them: GSR_HEM_SELECT_NP = 1, 2, 4 give the same levels bit for bit, on the one-pass path and on the COUNT +
     FILL fallback.  The clouds hold irregular components (pass B), heavy parents (the queue kernel beside the light one) and parents
-    with more survivors than the ring takes in one go (the suspended scan: a few per cent of the parents of any cloud)."""
+    with several batches of survivors (batches that mix the entries of two or three parents)."""
     from gaussiansplattingregistration_amd import hem, synth
     c = synth.make_cloud(250000, seed=77, sh_degree=1, shape=shape)
     c["cov6"][5::997] = np.array([1.0, 0, 0, 1.0, 0, -1.0], np.float32)       # irregular: not positive definite
