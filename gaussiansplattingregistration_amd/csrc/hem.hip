@@ -27,7 +27,8 @@
 //   k_gather / k_gather_sh   the cell-sorted working set: A, geo, shs (+ parent radius: closed-form eigenvalue, f64 trig)
 //   k_child_stream    Ac and cellStartC from A, the parent flags and their scan
 //   k_spans           candidates every parent will scan (capacity of its output segment, LPT work estimate)
-//   k_select<SPARSE|COUNT|FILL, WPB, QUEUE>   one wavefront per parent: grid rows clipped to the pre-reject ellipsoid,
+//   k_select<SPARSE|COUNT|FILL, WPB, QUEUE>   a wavefront takes four consecutive parents one after the other (SEL_NP) and keeps its
+//                     two rings across them: grid rows clipped to the pre-reject ellipsoid,
 //                     flattened candidate stream -> stage 1 (radius test, Mahalanobis pre-reject) -> LDS ring -> stage 2
 //                     (colour gate, KL gate, parent rule; bit-exact float32 maths, gsr_math.h) -> LDS queue -> stage 3
 //                     (likelihood, pair records).  VALU issue + its chain of dependent loads.
@@ -653,7 +654,7 @@ enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
 #define SEL_HEAVY_BLOCKS 2048  // workgroups at the head of k_select that serve the queue of heavy work items (a multiple of 8)
 #define SEL_QCAP 256          // survivor ring (power of two >= 64 + SEL_U*64: the rest of a batch -- or 63 entries and a parent's own -- plus a group of chunks)
 #define SEL_U 3               // chunks whose candidate loads are in flight together (2 or 3: equal, 4: +1 %, 6: +2 %, 8: +14 % -- registers)
-#define SEL_MCAP 1024         // flat positions covered by the row-start bit mask at a time (2048 before the parent slots: LDS in 1 280-byte granules, 9 per workgroup = 14 workgroups per CU)
+#define SEL_MCAP 1024         // flat positions covered by the row-start bit mask at a time (a parent scans ~500 candidates; LDS is allocated in granules of 1 280 bytes and the workgroup sits just under eight)
 #define SEL_PAD (64 * SEL_U)  // entries the sorted A array is padded by: the inactive lanes of a batch's last chunks read past the last row
 
 // Everything k_select / k_spans need to know about a parent, computed ONCE per parent by k_parent_prep (one thread each)
