@@ -2043,12 +2043,20 @@ __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int 
         {
             float w_s = 0, smx = 0, smy = 0, smz = 0, scx = 0, scy = 0, scz = 0;
             float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
+            // (the next batch's pairs are requested before this batch's records: one dependent round trip less per further batch)
+            unsigned jn = a.pair_child[off + c0 + ((unsigned)lane < cn ? (unsigned)lane : cn - 1)];
+            float wn = a.pair_wl[off + c0 + ((unsigned)lane < cn ? (unsigned)lane : cn - 1)];
 #pragma nounroll
             for (unsigned k0 = 0; k0 < cn; k0 += 64) {
                 const unsigned k = k0 + lane;
                 const bool live = k < cn;
-                const unsigned j = a.pair_child[off + c0 + (live ? k : cn - 1)];
-                const float wl = a.pair_wl[off + c0 + (live ? k : cn - 1)];
+                const unsigned j = jn;
+                const float wl = wn;
+                if (k0 + 64 < cn) {
+                    const unsigned kn = k + 64 < cn ? k + 64 : cn - 1;
+                    jn = a.pair_child[off + c0 + kn];
+                    wn = a.pair_wl[off + c0 + kn];
+                }
                 // the 64-byte records of the batch's 64 children, fetched by FOUR lanes per record (a wave instruction then
                 // touches 16 cache lines instead of 64: one piece of 64 different records per instruction kept the CU's
                 // address pipeline busy four times as long) and handed to the pair's lane through LDS
