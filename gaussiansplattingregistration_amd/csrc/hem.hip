@@ -650,6 +650,7 @@ struct SelectArgs {
     int heavy_blocks;               // workgroups at the head of the launch that serve the queue (0 = no splitting)
     unsigned part;                  // candidates per work item (<= SEL_PART; smaller on small levels, where an item is the critical path)
     int np;                         // light parents per wave (1 ... SEL_NP), see SEL_NP
+    int2* rowlist;                  // [P][2][SEL_ROWS]: the non-empty row spans {first position, length} of pass A / pass B in scan order (k_spans), or NULL
 };
 
 enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
@@ -658,6 +659,7 @@ enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
 #define SEL_QCAP 256          // survivor ring (power of two >= 64 + SEL_U*64: the rest of a batch -- or 63 entries and a parent's own -- plus a group of chunks)
 #define SEL_U 3               // chunks whose candidate loads are in flight together (2 or 3: equal, 4: +1 %, 6: +2 %, 8: +14 % -- registers)
 #define SEL_MCAP 1024         // flat positions covered by the row-start bit mask at a time (a parent scans ~500 candidates; LDS is allocated in granules of 1 280 bytes and the workgroup sits just under eight)
+#define SEL_ROWS 16           // non-empty row spans per parent and pass that k_spans hands to k_select (a parent with more recomputes them)
 #define SEL_PAD (64 * SEL_U)  // entries the sorted A array is padded by: the inactive lanes of a batch's last chunks read past the last row
 
 // Everything k_select / k_spans need to know about a parent, computed ONCE per parent by k_parent_prep (one thread each)
@@ -679,7 +681,8 @@ struct ParentRec {            // 40 dwords
     int active;               // 0: zero / NaN radius or non-finite mean -> no children at all
     int selfq;                // 1: regular parent -- it is not in the stream of pass A and queues itself (flat candidate 0)
     float ey, ez;             // half extents of the pre-reject ellipsoid along y and z (+0.1 %): no row of pass A lies beyond them
-    int pad[1];
+    int rows;                 // written by k_spans: bit 31 = the row lists of this parent are valid; bits 0-7 / 8-15 = non-empty rows of pass A / B
+                              // (0xff = more than SEL_ROWS: that pass recomputes its spans)
 };
 static_assert(sizeof(ParentRec) == 160, "ParentRec is fetched as 40 dwords");
 
@@ -1033,7 +1036,7 @@ __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __re
         const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
         pr.active = (pr.R2 > 0.0f && pm_finite) ? 1 : 0;
         pr.selfq = (pr.active && (__float_as_uint(pa.w) & 2u)) ? 1 : 0;
-        pr.pad[0] = 0;
+        pr.rows = 0;
         s_pr[wv][lane] = pr;
         }
         __builtin_amdgcn_wave_barrier();
@@ -1065,28 +1068,38 @@ __device__ __forceinline__ float white_smd(const float (&vc)[11], float cx, floa
 template <int MODE, bool IRR>
 __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const ParLds* par, unsigned ktag,
                                             const float (&vc)[11], int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count_v,
-                                            Q3& q3, unsigned& cum, unsigned lo, unsigned hi) {
+                                            Q3& q3, unsigned& cum, unsigned lo, unsigned hi, const int2* rl, int lcnt) {
     const f3 pm = pr.pm;
     const EllClip& ec = pr.ec;
-    // (uniform values, but float arithmetic is VALU work and its results would sit in vector registers for the whole scan: the box
-    // goes back to the scalar file)
-    // (the compiler knows the values are uniform and folds a plain readfirstlane away -- leaving them where they are; a zero it cannot
-    // see through, added to the bit pattern, keeps the instruction)
-    int vz;
-    asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-    const auto uni = [vz](int v) { return __builtin_amdgcn_readfirstlane(v + vz); };
-    const auto unif = [vz](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v) + vz)); };
-    const float Ra = unif(fabsf(pr.R) * 1.00001f + g.slack);       // conservative search extent
-    const bool clip = !IRR && ec.on != 0.0f;
-    // rows: the sphere's box, cut down to the pre-reject ellipsoid's box when the rows are clipped to it (rows beyond its y / z
-    // extent would come out empty one by one)
-    const float Ry = clip ? fminf(Ra, pr.ey + g.slack) : Ra, Rz = clip ? fminf(Ra, pr.ez + g.slack) : Ra;
-    const int x0 = uni(cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx)), x1 = uni(cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx));
-    const int y0 = uni(cell_of(pm.y - Ry, g.oy, g.inv_c, g.gy)), y1 = uni(cell_of(pm.y + Ry, g.oy, g.inv_c, g.gy));
-    const int z0 = uni(cell_of(pm.z - Rz, g.oz, g.inv_c, g.gz)), z1 = uni(cell_of(pm.z + Rz, g.oz, g.inv_c, g.gz));
-    const int ny = y1 - y0 + 1, nz = z1 - z0 + 1;
-    const int nrows = ny * nz;
-    const float Ra2 = unif(Ra * Ra);
+    // rl != NULL: the spans of the parent's lcnt non-empty rows, in scan order, as k_spans left them (it computes every span anyway,
+    // for the capacities): one 8-byte load per row instead of the box, ~80 instructions per row and two dependent look-ups in the
+    // prefix table.  The candidates, their order and with it the pairs are the same either way (select_row_span made both).
+    const bool listed = rl != nullptr;
+    bool clip = false;
+    int x0 = 0, x1 = 0, y0 = 0, z0 = 0, ny = 1, nrows = lcnt;
+    float Ra2 = 0.0f;
+    if (!listed) {
+        // (uniform values, but float arithmetic is VALU work and its results would sit in vector registers for the whole scan: the box
+        // goes back to the scalar file.  The compiler knows the values are uniform and folds a plain readfirstlane away -- leaving them
+        // where they are; a zero it cannot see through, added to the bit pattern, keeps the instruction)
+        int vz;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
+        const auto uni = [vz](int v) { return __builtin_amdgcn_readfirstlane(v + vz); };
+        const auto unif = [vz](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v) + vz)); };
+        const float Ra = unif(fabsf(pr.R) * 1.00001f + g.slack);       // conservative search extent
+        clip = !IRR && ec.on != 0.0f;
+        // rows: the sphere's box, cut down to the pre-reject ellipsoid's box when the rows are clipped to it (rows beyond its y / z
+        // extent would come out empty one by one)
+        const float Ry = clip ? fminf(Ra, pr.ey + g.slack) : Ra, Rz = clip ? fminf(Ra, pr.ez + g.slack) : Ra;
+        x0 = uni(cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx)); x1 = uni(cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx));
+        y0 = uni(cell_of(pm.y - Ry, g.oy, g.inv_c, g.gy));
+        const int y1 = uni(cell_of(pm.y + Ry, g.oy, g.inv_c, g.gy));
+        z0 = uni(cell_of(pm.z - Rz, g.oz, g.inv_c, g.gz));
+        const int z1 = uni(cell_of(pm.z + Rz, g.oz, g.inv_c, g.gz));
+        ny = y1 - y0 + 1;
+        nrows = ny * (z1 - z0 + 1);
+        Ra2 = unif(Ra * Ra);
+    }
     const bool white = !IRR && pr.white != 0.0f;                // wave-uniform
     SEL_PROF_CNT(10, nrows, lane);
     for (int rb = 0; rb < nrows; rb += 64) {
@@ -1094,7 +1107,10 @@ __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParam
         SEL_PROF_CNT(11, 1, lane);
         const int r = rb + lane;
         int s = 0, len = 0;
-        if (r < nrows) select_row_span<IRR>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
+        if (r < nrows) {
+            if (listed) { const int2 e = rl[r]; s = e.x; len = e.y; }
+            else select_row_span<IRR>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
+        }
         len = len > 0 ? len : 0;
         const unsigned long long nz_m = __ballot(len > 0);
         if (nz_m == 0ull) continue;
@@ -1243,8 +1259,13 @@ __device__ __forceinline__ void select_parent(const SelectArgs& a, const GridPar
     if (pr.active) {
         // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
         // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
-        select_scan<MODE, false>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, cum, lo, hi);
-        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, cum, lo, hi);
+        // the row lists k_spans left for this parent (bit 31 of pr.rows), per pass: a count of at most SEL_ROWS is a complete list
+        const int cA = pr.rows & 0xff, cB = (pr.rows >> 8) & 0xff;
+        const int2* rlp = (a.rowlist != nullptr && pr.rows < 0) ? a.rowlist + (int64_t)p * (2 * SEL_ROWS) : nullptr;
+        select_scan<MODE, false>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, cum, lo, hi,
+                                 rlp != nullptr && cA <= SEL_ROWS ? rlp : nullptr, cA);
+        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, cum, lo, hi,
+                                                 rlp != nullptr && cB <= SEL_ROWS ? rlp + SEL_ROWS : nullptr, cB);
     }
     SEL_PROF_ADD(0, tp0, lane);
     SEL_PROF_CNT(7, 1, lane);
@@ -1424,6 +1445,7 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
     if (p >= a.P) return;
     unsigned long long scanned = 0;
     int selfq = 0;
+    int nA = 0, nB = 0;                                         // non-empty rows of the two passes
     if (p >= a.own_lo && p < a.own_hi) {
         const GridParams g = *a.gp;
         // the record's fields with six 16-byte loads issued together (field by field the compiler fetched `active` first, waited, then
@@ -1439,6 +1461,17 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
         struct { float R, ey, ez; int active; } rv = {q3.w, q9.y, q9.z, __float_as_int(q8.w)};
         const auto* rp = &rv;
         selfq = __float_as_int(q9.x);
+        // The non-empty spans go to k_select in scan order (ascending row): in one trip of the loops below the parent's 16 lanes hold 16
+        // consecutive rows, so a span's place is the count so far plus the non-empty rows on the lanes below it.
+        const unsigned gsh = (unsigned)(threadIdx.x & 48);          // this parent's 16 lanes inside the wave's ballot
+        const auto keep_span = [&](int pass, int s, int len, int& n) {
+            const unsigned gm = (unsigned)(__ballot(len > 0) >> gsh) & 0xffffu;
+            if (len > 0 && a.rowlist) {
+                const int pos = n + __popc(gm & ((1u << sub) - 1u));
+                if (pos < SEL_ROWS) a.rowlist[((int64_t)p * 2 + pass) * SEL_ROWS + pos] = make_int2(s, len);
+            }
+            n += __popc(gm);
+        };
         if (rp->active) {
             const float Ra = fabsf(rp->R) * 1.00001f + g.slack;
             const float Ra2 = Ra * Ra;
@@ -1453,6 +1486,7 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
                     int s = 0, len = 0;
                     select_row_span<false>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
                     scanned += (unsigned long long)(len > 0 ? len : 0);
+                    keep_span(0, s, len, nA);
                 }
             }
             if (a.n_irr > 0) {      // pass B: the irregular list over the sphere's rows
@@ -1463,13 +1497,18 @@ __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
                     int s = 0, len = 0;
                     select_row_span<true>(a, g, pm, ec, false, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
                     scanned += (unsigned long long)(len > 0 ? len : 0);
+                    keep_span(1, s, len, nB);
                 }
             }
         }
     }
     for (int o = 8; o > 0; o >>= 1) scanned += __shfl_xor(scanned, o);
     if (selfq) scanned += 1ull;                                 // the parent itself is flat candidate 0
-    if (sub == 0) a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
+    if (sub == 0) {
+        a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
+        // (the record is this kernel's input and k_select's; the count rides in it so that k_select gets it with the record's scalar loads)
+        if (a.rowlist) const_cast<ParentRec*>(a.prec)[p].rows = (int)(0x80000000u | (unsigned)(nA > SEL_ROWS ? 0xff : nA) | ((unsigned)(nB > SEL_ROWS ? 0xff : nB) << 8));
+    }
 }
 
 // Longest-processing-time-first: work per parent is heavy-tailed (a few parents scan 10^5 candidates), so the
@@ -3137,7 +3176,8 @@ struct gsr_hem_ctx {
     unsigned long long rb_seq = 0;
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
-    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec;
+    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec, rowlist;
+    bool use_rowlist = true;        // GSR_HEM_ROWLIST=0: k_select computes every row span itself instead of taking the non-empty ones from k_spans
     int timing = 1;                 // gsr_hem_set_timing / GSR_HEM_TIMING: 0 no events, 1 level + k_select + k_mstep, 2 every phase (see GSR_TIME)
     int select_np = 0;              // GSR_HEM_SELECT_NP=1|2|4: light parents per selection wave (the rings are kept across them, see SEL_NP); 0 = by level size
     bool mstep_split = true;        // GSR_HEM_MSTEP_SPLIT=0: a parent of more than MSTEP_SEG pairs keeps ONE wave for all its segments (the schedule of rounds 1-3)
@@ -3400,6 +3440,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SMALL")) c->mstep_small = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SPLIT")) c->mstep_split = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_ROWLIST")) c->use_rowlist = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_TIMING")) { const int v = atoi(s); c->timing = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* s = getenv("GSR_HEM_SELECT_NP")) { const int v = atoi(s); c->select_np = v < 1 ? 1 : (v > SEL_NP ? SEL_NP : v); }
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
@@ -3437,7 +3478,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->Ac, &c->cellStartC, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
-                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
+                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->rowlist, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
                      &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
@@ -4173,6 +4214,10 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL(k_parent_prep, dim3(stride_grid(P)), blk, 0, st, P, c->plist.as<unsigned>(), c->geo.as<float4>(), c->Rs.as<float>(),
                            sa.kldThr, sa.ell, c->prec.as<ParentRec>());
         sa.prec = c->prec.as<ParentRec>();
+        if (c->use_rowlist) {
+            GSR_TRY(c->rowlist.reserve(Pm * 2 * SEL_ROWS * sizeof(int2)));
+            sa.rowlist = c->rowlist.as<int2>();
+        }
         hipLaunchKernelGGL(k_spans, dim3(ceil_div(P, 16)), dim3(256), 0, st, sa);      // candidates scanned per parent
         GSR_TRY(c->coff.reserve((Pm + 1) * 8));
         GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>(), P));

@@ -316,6 +316,29 @@ def test_parents_per_selection_wave_change_nothing(monkeypatch, shape):
                 assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (np_, budget, k, f)
 
 
+@pytest.mark.parametrize("shape", ["iso", "aniso", "clustered"])
+def test_row_lists_from_the_capacity_pass_change_nothing(monkeypatch, shape):
+    """``k_spans`` computes every row span of every parent for the capacities; it now also leaves the non-empty ones (up to 16 per
+    pass) in scan order for ``k_select``, which reads them instead of computing them again.  GSR_HEM_ROWLIST=0 (every span computed
+    twice, as before): the same levels bit for bit -- with irregular components (pass B has its own list), heavy parents (more rows than
+    a list holds: they recompute) and on the COUNT + FILL fallback."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(200000, seed=78, sh_degree=1, shape=shape)
+    c["cov6"][7::499] = np.array([1.0, 0, 0, 1.0, 0, -1.0], np.float32)       # irregular: not positive definite
+    monkeypatch.setenv("GSR_HEM_ROWLIST", "0")
+    ref, rst = hem.create_mixture(c, 2)
+    assert rst[0]["irregular"] > 0 and rst[0]["heavy_parents"] > 0, rst[0]
+    for budget in (None, "0"):
+        monkeypatch.setenv("GSR_HEM_ROWLIST", "1")
+        if budget is not None:
+            monkeypatch.setenv("GSR_HEM_SPARSE_GB", budget)
+        got, st = hem.create_mixture(c, 2)
+        for k in range(2):
+            assert (st[k]["parents"], st[k]["pairs"], st[k]["orphans"], st[k]["dropped"], st[k]["candidates"]) == (rst[k]["parents"], rst[k]["pairs"], rst[k]["orphans"], rst[k]["dropped"], rst[k]["candidates"]), (budget, k)
+            for f in ("xyz", "color", "cov6", "sh", "opacity"):
+                assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (budget, k, f)
+
+
 @pytest.mark.parametrize("deg", [3, 2, 1, 0])
 def test_small_parent_path_changes_nothing(monkeypatch, deg):
     """Parents with at most 16 pairs are served four at a time, one per DPP row of the M-step's wavefront (most parents of a
