@@ -1438,7 +1438,9 @@ __global__ __launch_bounds__(1024) void k_heavy_items(int P, const unsigned* __r
 
 // Capacities (candidates every parent's passes will scan), with 16 lanes per parent instead of a wavefront: the pass has no
 // candidate work, so its cost is the per-parent set-up, which four parents per wavefront share.  Same row spans as k_select
-// by construction (select_row_span).
+// by construction (select_row_span).  (Measured in round 4: three rows per lane with their table look-ups issued together -- 0.30
+// against 0.25 ms on the isotropic 5 M level, 0.58 against 0.58 on the surfel one: the pass is bound by the rows' arithmetic, ~80
+// instructions each for 15 / 68 rows per parent, not by the look-ups.)
 __global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
     const int sub = threadIdx.x & 15;
     const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
