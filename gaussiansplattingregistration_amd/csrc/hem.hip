@@ -2521,11 +2521,13 @@ __global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigne
                                                  const int* __restrict__ oflag_sorted, const int* __restrict__ orank_in,
                                                  const float4* __restrict__ geo,
                                                  float* o_xyz, float* o_color, float* o_cov6, float* o_opacity,
-                                                 float* o_weight, int64_t* __restrict__ oslot_sorted) {
+                                                 float* o_weight, int64_t* __restrict__ oslot_sorted, unsigned* __restrict__ olist) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         int64_t slot = -1;
         if (oflag_sorted[j]) {
-            slot = (int64_t)P + orank_in[order[j]];
+            const int rank = orank_in[order[j]];
+            slot = (int64_t)P + rank;
+            if (olist) olist[rank] = (unsigned)j;          // orphan `rank` (output row P + rank) sits at sorted position j: k_orphans_sh_list
             const float4 a = geo[4 * j], b = geo[4 * j + 1], c = geo[4 * j + 2], d = geo[4 * j + 3];
             o_xyz[3 * slot] = a.x; o_xyz[3 * slot + 1] = a.y; o_xyz[3 * slot + 2] = a.z;
             o_color[3 * slot] = c.z; o_color[3 * slot + 1] = c.w; o_color[3 * slot + 2] = d.x;
@@ -2546,6 +2548,29 @@ __global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int RSH, c
         const int64_t slot = oslot_sorted[j];
         if (slot < 0) continue;
         for (int f = 0; f < F; ++f) o_sh[slot * F + f] = shs[j * RSH + f];
+    }
+}
+// Many orphans, one GPU: over the LIST of the orphans (k_orphans wrote it: orphan k of the output sits at sorted position olist[k]) instead
+// of over all components -- on a surfel level 29 % of the components are orphans and the other 71 % of k_orphans_sh_wide's threads
+// loaded a slot only to find -1 (0.28 -> ms at 5 M).
+__global__ __launch_bounds__(256) void k_orphans_sh_list(int64_t n_orph, int64_t P, int F, int RSH, const unsigned* __restrict__ olist,
+                                                         const float* __restrict__ shs, float* __restrict__ o_sh) {
+    const int Q = RSH >> 2;
+    const int64_t total = n_orph * Q;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = total < ((int64_t)1 << 31) ? (int64_t)((unsigned)t / (unsigned)Q) : t / Q;
+        const int q = (int)(t - k * Q);
+        const float4 v = reinterpret_cast<const float4*>(shs + (int64_t)olist[k] * RSH)[q];
+        float* dst = o_sh + (P + k) * F + 4 * q;
+        const int left = F - 4 * q;
+        if (left > 3) {                  // the output rows are only 4-byte aligned: one unaligned 16-byte store
+            f4u u; u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
+            *reinterpret_cast<f4u*>(dst) = u;
+        } else {
+            if (left > 0) dst[0] = v.x;
+            if (left > 1) dst[1] = v.y;
+            if (left > 2) dst[2] = v.z;
+        }
     }
 }
 __global__ __launch_bounds__(256) void k_orphans_sh_wide(int64_t n, int F, int RSH, const int64_t* __restrict__ oslot_sorted,
@@ -3178,7 +3203,8 @@ struct gsr_hem_ctx {
     unsigned long long rb_seq = 0;
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
-    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec, rowlist;
+    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec, rowlist, olist;
+    bool orphan_list = true;        // GSR_HEM_ORPHAN_LIST=0: the orphans' SH rows by k_orphans_sh_wide (a pass over all components) whatever their number
     bool use_rowlist = true;        // GSR_HEM_ROWLIST=0: k_select computes every row span itself instead of taking the non-empty ones from k_spans
     int timing = 1;                 // gsr_hem_set_timing / GSR_HEM_TIMING: 0 no events, 1 level + k_select + k_mstep, 2 every phase (see GSR_TIME)
     int select_np = 0;              // GSR_HEM_SELECT_NP=1|2|4: light parents per selection wave (the rings are kept across them, see SEL_NP); 0 = by level size
@@ -3442,6 +3468,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SMALL")) c->mstep_small = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SPLIT")) c->mstep_split = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_ORPHAN_LIST")) c->orphan_list = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_ROWLIST")) c->use_rowlist = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_TIMING")) { const int v = atoi(s); c->timing = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* s = getenv("GSR_HEM_SELECT_NP")) { const int v = atoi(s); c->select_np = v < 1 ? 1 : (v > SEL_NP ? SEL_NP : v); }
@@ -3480,7 +3507,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->Ac, &c->cellStartC, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
-                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->rowlist, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
+                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->rowlist, &c->olist, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
                      &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
@@ -4555,11 +4582,18 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         if (msplit && hst != st) GSR_HIP(hipStreamWaitEvent(st, c->ev_mjoin, 0));
         GSR_TIME1(c->evm[1], st);
     }
+    // many orphans on one GPU: their SH rows are copied over the list of the orphans (k_orphans_sh_list)
+    const bool orphan_list = F > 0 && n_orph * 64 > n && !part && !sharded && c->orphan_list;
+    if (orphan_list) GSR_TRY(c->olist.reserve((size_t)n_orph * 4));
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
-                       O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>());
+                       O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>(),
+                       orphan_list ? c->olist.as<unsigned>() : (unsigned*)nullptr);
     if (F > 0 && n_orph > 0) {
-        if (n_orph * 64 > n)
+        if (orphan_list)
+            hipLaunchKernelGGL(k_orphans_sh_list, dim3(stride_grid(n_orph * (RSH >> 2))), blk, 0, st, n_orph, (int64_t)P, F, RSH, c->olist.as<unsigned>(),
+                               c->shs.as<float>(), O.sh.as<float>());
+        else if (n_orph * 64 > n)
             hipLaunchKernelGGL(k_orphans_sh_wide, dim3(stride_grid(n * (RSH >> 2))), blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
         else
             hipLaunchKernelGGL(k_orphans_sh, grd, blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());

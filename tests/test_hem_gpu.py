@@ -339,6 +339,23 @@ def test_row_lists_from_the_capacity_pass_change_nothing(monkeypatch, shape):
                 assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (budget, k, f)
 
 
+@pytest.mark.parametrize("deg", [3, 1])
+def test_orphan_rows_over_the_orphan_list_change_nothing(monkeypatch, deg):
+    """A level with many orphans (a surfel cloud: a third of its components merge with nothing) copies their SH rows over the LIST of
+    the orphans instead of over all components (k_orphans_sh_list; GSR_HEM_ORPHAN_LIST=0: k_orphans_sh_wide): the same levels."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(150000, seed=81, sh_degree=deg, shape="aniso")
+    monkeypatch.setenv("GSR_HEM_ORPHAN_LIST", "0")
+    ref, rst = hem.create_mixture(c, 2)
+    assert rst[0]["orphans"] * 64 > rst[0]["n_in"], rst[0]          # (the list path is taken)
+    monkeypatch.setenv("GSR_HEM_ORPHAN_LIST", "1")
+    got, st = hem.create_mixture(c, 2)
+    for k in range(2):
+        assert (st[k]["parents"], st[k]["pairs"], st[k]["orphans"], st[k]["dropped"]) == (rst[k]["parents"], rst[k]["pairs"], rst[k]["orphans"], rst[k]["dropped"])
+        for f in ("xyz", "color", "cov6", "sh", "opacity"):
+            assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (k, f)
+
+
 @pytest.mark.parametrize("deg", [3, 2, 1, 0])
 def test_small_parent_path_changes_nothing(monkeypatch, deg):
     """Parents with at most 16 pairs are served four at a time, one per DPP row of the M-step's wavefront (most parents of a
