@@ -526,7 +526,11 @@ def main():
         # sorts the 40 M splats); the target is a sub-sample of the same scene -- the first rows of every block, gathered ONCE onto
         # every rank (set-up, outside the timed region) -- moved by T_gt
         src, owned = synth.make_block_cloud_torch(n, rank, world, seed=seed, device=dev)
-        T_gt = synth.rigid_transform(PAIR_ANGLE_DEG, (1, 1, 1), PAIR_SHIFT_H * src["h"] * np.array([1.0, -1.0, 0.5]))
+        # the pair's motion in ABSOLUTE terms is the 2 x 5 M pair's (5 degrees and 0.05 h there): at 40 M the scene is twice as wide, and 5
+        # degrees about its centre would move the corners by four correspondence distances -- nearest-neighbour ICP cannot start from there
+        # (measured at full size, profiles/r05a_bench_c5_40m_8ranks_one_gpu.json: fitness 0.59, T_err 0.76)
+        rel = min(1.0, synth.half_extent(5_000_000) / src["h"])
+        T_gt = synth.rigid_transform(PAIR_ANGLE_DEG * rel, (1, 1, 1), PAIR_SHIFT_H * rel * src["h"] * np.array([1.0, -1.0, 0.5]))
         nt = min(a.target_splats, n)
         fields = ("xyz", "color", "opacity", "cov6", "sh")
         parts = {f: [] for f in fields}

@@ -10,6 +10,7 @@ memory -- the library calls them synchronously.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 from . import _lib
 
@@ -88,7 +89,10 @@ class Comm:
         if dist is None or not dist.is_initialized() or dist.get_world_size(group) == 1:
             return None
         rank, world = dist.get_rank(group), dist.get_world_size(group)
-        if dist.get_backend(group) == "nccl" and not force_callbacks:
+        # RCCL transport: the nccl backend, or -- ranks that share ONE GPU under gloo (test boxes) -- an explicitly named library
+        # (GSR_RCCL_LIB: tests/mock_rccl, the test double of librccl for processes on one device) with GSR_COMM_TRANSPORT=rccl
+        explicit = os.environ.get("GSR_COMM_TRANSPORT") == "rccl" and os.environ.get("GSR_RCCL_LIB")
+        if (dist.get_backend(group) == "nccl" or explicit) and not force_callbacks:
             box = [cls.unique_id() if rank == 0 else None]
             dist.broadcast_object_list(box, src=0, group=group)
             return cls.rccl(box[0], rank, world, device)

@@ -1252,9 +1252,18 @@ __device__ __forceinline__ void select_parent(const SelectArgs& a, const GridPar
         cum = 1u;
         if (lo == 0u) {
             if (lane == 0) q[(qh + qn) & (SEL_QCAP - 1)] = (unsigned)pr.js | ktag;
-            qn += 1;                    // (at most 64 now: the ring takes a whole group of chunks on top, SEL_QCAP)
+            qn += 1;
         }
         __builtin_amdgcn_wave_barrier();
+        // The ring holds 64 + one group of chunks (SEL_QCAP): the scan's drain keeps qn < 64 behind every group, but a parent WITHOUT a
+        // non-empty candidate row never gets there -- several isolated parents in a row (SEL_NP per wave) each add their own entry, and
+        // a following parent's first group of SEL_U * 64 survivors would wrap onto the oldest entries (an accepted pair lost silently,
+        // ADVICE r04).  So a full batch goes through stage 2 right here: qn <= 63 again in front of every scan.
+        if (qn >= 64) {
+            select_stage2<MODE>(a, par, lane, 64, q, qh, count_v, q3);
+            qh = (qh + 64) & (SEL_QCAP - 1);
+            qn -= 64;
+        }
     }
     if (pr.active) {
         // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);

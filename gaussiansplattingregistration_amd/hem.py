@@ -176,14 +176,15 @@ class HemMixture:
         ps, ks, ds = _prep(features, (n, F), self.device) if F > 0 else (0, None, dx)
         if len({dx, dc, dv, do, ds}) != 1:
             raise RuntimeError("all level-0 arrays must live in the same place (all host or all device)")
-        if int(np.prod(gid.shape)) != n:
-            raise RuntimeError(f"gid has {int(np.prod(gid.shape))} entries for {n} components")
+        n_gid = int(gid.numel()) if _is_tensor(gid) else int(np.asarray(gid).size)      # (a plain list of indices is fine too)
+        if n_gid != n:
+            raise RuntimeError(f"gid has {n_gid} entries for {n} components")
         if dx:
             g = (gid.detach() if _is_tensor(gid) else torch.as_tensor(np.asarray(gid, np.int64))).to(xyz.device, torch.int32).contiguous()
             pg, kg = g.data_ptr(), g
             torch.cuda.current_stream(self.device).synchronize()
         else:
-            kg = np.ascontiguousarray(gid.cpu().numpy() if _is_tensor(gid) else gid, dtype=np.uint32)
+            kg = np.ascontiguousarray(gid.cpu().numpy() if _is_tensor(gid) else np.asarray(gid), dtype=np.uint32)
             pg = kg.ctypes.data
         _lib.check(self._L.gsr_hem_set_level0_part(self._h, px, pc, pv, po, ps, pg, n, int(n_global), F, 1 if dx else 0), "gsr_hem_set_level0_part")
         self._out_cur = self._out_prev = None
@@ -253,7 +254,9 @@ class HemMixture:
         n, F = self.size, self.F
         cur = getattr(self, "_out_cur", None)
         if as_torch and cur is not None:            # the level already lives in the caller's tensors (run_level(out=...)): views, no copy
-            out = {k: cur[k][:n] for k in ("xyz", "color", "cov6", "opacity", "sh")}
+            out = {k: cur[k][:n] for k in ("xyz", "color", "cov6", "opacity")}
+            # (F == 0: run_level(out=...) lets the caller leave 'sh' out)
+            out["sh"] = cur["sh"][:n] if (F > 0 or cur.get("sh") is not None) else torch.empty((n, 0), dtype=torch.float32, device=cur["xyz"].device)
             if with_state:
                 dev = torch.device("cuda", self.device)
                 out["weight"] = torch.empty((n,), dtype=torch.float32, device=dev)

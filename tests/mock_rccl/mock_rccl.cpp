@@ -30,7 +30,18 @@
 namespace {
 
 constexpr int MAX_RANKS = 8;
-constexpr size_t SLOT_BYTES = (size_t)96 << 20;        // per rank: what one rank publishes in one operation (the tests stay far below)
+// per rank: what one rank publishes in one operation.  96 MB by default (the tests stay far below); GSR_MOCK_RCCL_SLOT_MB raises it for
+// the full-size runs of BASELINE configs[4] (40 M splats over 8 ranks: a rank's SH halo rows are a few hundred MB).  Every rank reads the
+// same environment; the segment is sparse (POSIX shm: only touched pages exist).
+size_t slot_bytes() {
+    static const size_t v = [] {
+        const char* e = getenv("GSR_MOCK_RCCL_SLOT_MB");
+        const long mb = e ? atol(e) : 0;
+        return (size_t)(mb > 0 ? mb : 96) << 20;
+    }();
+    return v;
+}
+#define SLOT_BYTES (slot_bytes())
 constexpr int MAX_DIR = 64;
 
 struct DirEntry { int peer; unsigned long long off, bytes; };
