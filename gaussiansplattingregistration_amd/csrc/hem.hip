@@ -238,7 +238,9 @@ __device__ __forceinline__ bool is_regular(const s6& c, float det, float x, floa
 __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict__ xyz, const float* __restrict__ color,
                                               const float* __restrict__ cov6, const float* __restrict__ opacity,
                                               const float* __restrict__ weight, const uint8_t* __restrict__ is_parent,
-                                              float4* __restrict__ rec /* [n][4], input order */, unsigned* __restrict__ bbox_part) {
+                                              float4* __restrict__ rec /* [n][4], input order */, unsigned* __restrict__ bbox_part,
+                                              const long long* __restrict__ n_dev /* NULL, or the level's size where the host does not know it yet */) {
+    if (n_dev) n = *n_dev;
     // The four float4 of a component (the A/B/C/D layout of the working set) are packed here, in INPUT order and
     // with coalesced reads, so that the gather into cell order fetches one 64-byte record per component instead
     // of touching nine arrays at a random index (9 x 128-byte lines -> 0.9 ms at 5 M; one line -> 0.3 ms).
@@ -343,7 +345,8 @@ __global__ __launch_bounds__(256) void k_bbox_reduce(int nblocks, const unsigned
 // boundary rows are treated as half-infinite slabs when rows are culled).
 #define HIST_BINS 1024
 __global__ __launch_bounds__(256) void k_hist(int64_t n, const float* __restrict__ xyz, const unsigned* __restrict__ bbox,
-                                              unsigned* __restrict__ hist /* [3][HIST_BINS] */) {
+                                              unsigned* __restrict__ hist /* [3][HIST_BINS] */, const long long* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     __shared__ unsigned s_h[3 * HIST_BINS];
     for (int k = threadIdx.x; k < 3 * HIST_BINS; k += blockDim.x) s_h[k] = 0u;
     __syncthreads();
@@ -372,7 +375,8 @@ __global__ __launch_bounds__(256) void k_hist(int64_t n, const float* __restrict
 
 // Grid geometry: about `target` components per cell over the robust box, at most `max_cells` cells.
 __global__ void k_grid_params(const unsigned* __restrict__ bbox, const unsigned* __restrict__ hist, int64_t n, float target,
-                              int max_cells, GridParams* __restrict__ gp) {
+                              int max_cells, GridParams* __restrict__ gp, const long long* __restrict__ n_dev) {
+    if (n_dev) n = *n_dev;
     const int lane = threadIdx.x;                    // launched with ONE wavefront
     float mn[3], mx[3];
     for (int k = 0; k < 3; ++k) { mn[k] = dec_f(bbox[k]); mx[k] = dec_f(bbox[3 + k]); }
@@ -648,7 +652,13 @@ struct SelectArgs {
     unsigned* part_cnt;             // accepted pairs per item (COUNT / SPARSE out, FILL in)
     int* hq;                        // hq[0] = number of items, hq[1] = queue cursor
     int heavy_blocks;               // workgroups at the head of the launch that serve the queue (0 = no splitting)
-    unsigned part;                  // candidates per work item (<= SEL_PART; smaller on small levels, where an item is the critical path)
+    const unsigned* part_p;         // device: candidates per work item (<= SEL_PART; smaller on small levels, where an item is the critical path) -- k_heavy_items
+                                    // derives it from the level's candidate total, which the host of an asynchronous level never sees
+    // SPARSE: the pair buffers hold cap_pairs entries.  A segment that would end beyond them is SKIPPED (its parent gets no pairs) and
+    // *abort_p is raised: an asynchronous level sizes nothing from the candidate total -- it runs on the buffers the context has and
+    // reruns synchronously when they were too small -- so every write has to be clamped on the device.  0 = unchecked
+    unsigned long long cap_pairs;
+    int* abort_p;
     int np;                         // light parents per wave (1 ... SEL_NP), see SEL_NP
     int2* rowlist;                  // [P][2][SEL_ROWS]: the non-empty row spans {first position, length} of pass A / pass B in scan order (k_spans), or NULL
 };
@@ -1321,14 +1331,22 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
 
     if constexpr (QUEUE) {
         const int n_items = a.hq[0];
+        const unsigned part = *a.part_p;
         int item = (int)blockIdx.x * WPB + wv;
         while (item < n_items) {
             const uint2 it = a.hitem[item];
             const int p = __builtin_amdgcn_readfirstlane((int)a.porder[it.x]);
-            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.y * a.part));
-            const unsigned hi = lo + a.part > lo ? lo + a.part : 0xffffffffu;
+            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.y * part));
+            const unsigned hi = lo + part > lo ? lo + part : 0xffffffffu;
             int64_t base = 0;
             if (MODE == SEL_SPARSE) base = a.poff[p] + lo;          // accepted <= candidates of the part: the parts cannot collide
+            if (MODE == SEL_SPARSE && a.cap_pairs && (unsigned long long)base + part > a.cap_pairs) {      // beyond the buffers: no pairs, the level reruns
+                if (lane == 0) { a.part_cnt[item] = 0u; *a.abort_p = 1; }
+                int nxt0 = 0;
+                if (lane == 0) nxt0 = atomicAdd(&a.hq[1], 1);
+                item = __builtin_amdgcn_readfirstlane(nxt0);
+                continue;
+            }
             if (MODE == SEL_FILL) {
                 base = a.poff[p];
                 for (int k = a.hfirst[p]; k < item; ++k) base += a.part_cnt[k];
@@ -1367,8 +1385,13 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
                 if (p < a.own_lo || p >= a.own_hi) {                // another rank's parent: no work, no pairs
                     if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[p] = 0u;
                 } else {
-                    p_v = p;
-                    select_fill_par(a, p, (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0, par + lane);
+                    const int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
+                    if (MODE == SEL_SPARSE && a.cap_pairs && (unsigned long long)base + a.pcap[p] > a.cap_pairs) {
+                        a.pcnt[p] = 0u; *a.abort_p = 1;             // the segment would end beyond the buffers: no pairs, the level reruns
+                    } else {
+                        p_v = p;
+                        select_fill_par(a, p, base, par + lane);
+                    }
                 }
             }
         }
@@ -1402,12 +1425,21 @@ __global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
 // the count in *nheavy_p for the selection kernels.  hfirst[] is written for every heavy parent and read for no other.
 __global__ __launch_bounds__(1024) void k_heavy_items(int P, const unsigned* __restrict__ sorted_keys, int* __restrict__ nheavy_p,
                                                       const unsigned* __restrict__ porder,
-                                                      const unsigned* __restrict__ pcap, unsigned part, int own_lo, int own_hi, int first_pull, int max_items,
+                                                      const unsigned* __restrict__ pcap, const int64_t* __restrict__ coff, unsigned* __restrict__ part_out,
+                                                      int own_lo, int own_hi, int first_pull, int max_items,
                                                       uint2* __restrict__ hitem, int* __restrict__ hfirst, unsigned* __restrict__ pcnt,
                                                       int* __restrict__ hq, int* __restrict__ error_flag) {
     __shared__ int s_wsum[16];
     __shared__ int s_base, s_nheavy;
+    // part size: ~4 items per wave slot of the chip, between 2048 and SEL_PART candidates (on a small level one item of 8192
+    // candidates outlasts the whole light launch) -- from the level's candidate total, here on the device
+    unsigned part = SEL_PART;
+    {
+        const unsigned long long cand = (unsigned long long)coff[P - 1] + pcap[P - 1];
+        while (part > 2048u && (unsigned long long)part * 4ull * 7168ull > cand) part >>= 1;
+    }
     if (threadIdx.x == 0) {
+        *part_out = part;
         int lo = 0, hi = P;                       // first key of class 3
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << (3 * ORDER_AXIS_BITS))) hi = mid; else lo = mid + 1; }
         s_nheavy = lo;
@@ -1537,10 +1569,13 @@ __device__ __forceinline__ unsigned spread10(unsigned v) {      // 10 bits -> ev
 // processed along a Z-order curve: the parents in flight at any time then cover a compact 3-D block, so
 // the children / candidates they share stay in L2 (the x-fastest linear order of the arrays makes the
 // in-flight set a full-width slab of the scene, which does not fit).
-__global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __restrict__ work, unsigned thr,
+__global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __restrict__ work, const int64_t* __restrict__ coff,
                                                     const unsigned* __restrict__ plist, const float4* __restrict__ A,
                                                     const GridParams* __restrict__ gpp, unsigned* __restrict__ keys, unsigned* __restrict__ idx) {
     const GridParams g = *gpp;
+    // "heavy" = 16x the mean capacity (8x: +0.8 % at 5 M, 32x: +10 % at 200 k); the total from the capacities' scan, on the device
+    const unsigned long long cand = (unsigned long long)coff[P - 1] + work[P - 1];
+    const unsigned thr = (unsigned)(16.0 * (double)cand / (double)P) + 1u;
     int gm = g.gx > g.gy ? g.gx : g.gy;
     gm = gm > g.gz ? gm : g.gz;
     int sh = 0;
@@ -1568,9 +1603,10 @@ __global__ void k_count_heavy(int P, const unsigned* __restrict__ sorted_keys, i
 // of a split parent (hfirst[p] >= 0: segments SEL_PART apart, part_cnt pairs each) are concatenated in part order
 __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __restrict__ coff, const unsigned* __restrict__ pcnt,
                                                        const int64_t* __restrict__ poff, const int* __restrict__ hfirst,
-                                                       const unsigned* __restrict__ part_cnt, const unsigned* __restrict__ pcap, unsigned part,
+                                                       const unsigned* __restrict__ part_cnt, const unsigned* __restrict__ pcap, const unsigned* __restrict__ part_p,
                                                        const unsigned* __restrict__ sc, const float* __restrict__ sw,
                                                        unsigned* __restrict__ dc, float* __restrict__ dw) {
+    const unsigned part = part_p ? *part_p : SEL_PART;
     // 32 lanes per parent (a parent has ~65 pairs): two parents per wavefront (8 lanes: +9 % of the pass, 16: +3 %)
     const int sub = threadIdx.x & 31;
     const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 5);
@@ -1598,8 +1634,9 @@ __global__ __launch_bounds__(256) void k_compact_pairs(int P, const int64_t* __r
 // barrier: the destination never runs ahead of the source (dst <= src), so no pair is overwritten before it has been read.
 __global__ __launch_bounds__(256) void k_join_parts(const int* __restrict__ nheavy_p, const unsigned* __restrict__ porder, const int64_t* __restrict__ coff,
                                                     const int* __restrict__ hfirst, const unsigned* __restrict__ part_cnt,
-                                                    const unsigned* __restrict__ pcap, unsigned part, unsigned* __restrict__ sc, float* __restrict__ sw) {
+                                                    const unsigned* __restrict__ pcap, const unsigned* __restrict__ part_p, unsigned* __restrict__ sc, float* __restrict__ sw) {
     const int nheavy = *nheavy_p;
+    const unsigned part = *part_p;
     for (int h = blockIdx.x; h < nheavy; h += gridDim.x) {
         const int p = (int)porder[h];
         const int h0 = hfirst[p];
@@ -2530,12 +2567,15 @@ __global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigne
                                                  const int* __restrict__ oflag_sorted, const int* __restrict__ orank_in,
                                                  const float4* __restrict__ geo,
                                                  float* o_xyz, float* o_color, float* o_cov6, float* o_opacity,
-                                                 float* o_weight, int64_t* __restrict__ oslot_sorted, unsigned* __restrict__ olist) {
+                                                 float* o_weight, int64_t* __restrict__ oslot_sorted, unsigned* __restrict__ olist, int64_t out_cap) {
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         int64_t slot = -1;
         if (oflag_sorted[j]) {
             const int rank = orank_in[order[j]];
             slot = (int64_t)P + rank;
+            // (an asynchronous level writes into arrays sized before the number of orphans is known: a row beyond them is not written --
+            // k_level_tail has raised the abort flag, the level reruns synchronously)
+            if (slot >= out_cap) { oslot_sorted[j] = -1; continue; }
             if (olist) olist[rank] = (unsigned)j;          // orphan `rank` (output row P + rank) sits at sorted position j: k_orphans_sh_list
             const float4 a = geo[4 * j], b = geo[4 * j + 1], c = geo[4 * j + 2], d = geo[4 * j + 3];
             o_xyz[3 * slot] = a.x; o_xyz[3 * slot + 1] = a.y; o_xyz[3 * slot + 2] = a.z;
@@ -2563,7 +2603,9 @@ __global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int RSH, c
 // of over all components -- on a surfel level 29 % of the components are orphans and the other 71 % of k_orphans_sh_wide's threads
 // loaded a slot only to find -1 (0.28 -> ms at 5 M).
 __global__ __launch_bounds__(256) void k_orphans_sh_list(int64_t n_orph, int64_t P, int F, int RSH, const unsigned* __restrict__ olist,
-                                                         const float* __restrict__ shs, float* __restrict__ o_sh) {
+                                                         const float* __restrict__ shs, float* __restrict__ o_sh,
+                                                         const long long* __restrict__ n_orph_dev, int64_t out_cap) {
+    if (n_orph_dev) { n_orph = *n_orph_dev; if (P + n_orph > out_cap) n_orph = out_cap > P ? out_cap - P : 0; }
     const int Q = RSH >> 2;
     const int64_t total = n_orph * Q;
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
@@ -2634,7 +2676,8 @@ __global__ __launch_bounds__(256) void k_orphans_sh_wide(int64_t n, int F, int R
 #define RNG_TAB_WORDS (RNG_TAB_YBASE + 96)
 
 __global__ __launch_bounds__(64) void k_rng_block_state(unsigned long long first_draw, const unsigned* __restrict__ tab,
-                                                        unsigned* __restrict__ blockY /* [nblocks][64] */) {
+                                                        unsigned* __restrict__ blockY /* [nblocks][64] */, const long long* __restrict__ n_dev) {
+    if (n_dev && (long long)blockIdx.x * RNG_BLOCK_ELEMS >= *n_dev) return;       // launched for a bound: the blocks beyond the real count
     const int lane = threadIdx.x;
     const unsigned long long k = 310ull + 8ull * (first_draw + (unsigned long long)blockIdx.x * RNG_BLOCK_ELEMS);
     unsigned a = lane == 0 ? 1u : 0u;                       // x^0
@@ -2660,7 +2703,9 @@ __global__ __launch_bounds__(64) void k_rng_block_state(unsigned long long first
 }
 
 __global__ __launch_bounds__(RNG_THREADS) void k_flags_glibc(int64_t n, float prob, const unsigned* __restrict__ tab,
-                                                             const unsigned* __restrict__ blockY, uint8_t* __restrict__ is_parent) {
+                                                             const unsigned* __restrict__ blockY, uint8_t* __restrict__ is_parent,
+                                                             const long long* __restrict__ n_dev) {
+    if (n_dev && *n_dev < n) n = *n_dev;
     const int t = threadIdx.x;
     const int64_t i0 = ((int64_t)blockIdx.x * RNG_THREADS + t) * RNG_ELEMS;
     if (i0 >= n) return;
@@ -2701,7 +2746,8 @@ __device__ __forceinline__ unsigned hash32(unsigned long long x) {      // split
     return (unsigned)(x >> 32);
 }
 __global__ __launch_bounds__(256) void k_flags_hash(int64_t n, unsigned seed, unsigned long long first_draw, float prob,
-                                                    uint8_t* __restrict__ is_parent) {
+                                                    uint8_t* __restrict__ is_parent, const long long* __restrict__ n_dev) {
+    if (n_dev && *n_dev < n) n = *n_dev;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const unsigned r = hash32(((unsigned long long)seed << 40) ^ (first_draw + (unsigned long long)i));
         const float r01 = (float)r / 4294967296.0f;
@@ -3048,14 +3094,61 @@ __global__ void k_flip3(unsigned* __restrict__ w) { if (threadIdx.x < 3) w[threa
 
 // validity (mixture.cpp:262-282): keep iff !(isnan(mean) || isnan(det) || det <= 0)
 __global__ __launch_bounds__(256) void k_valid(int64_t n, const float* __restrict__ xyz, const float* __restrict__ cov6,
-                                               int* __restrict__ keep) {
+                                               int* __restrict__ keep, const long long* __restrict__ n_dev, int* __restrict__ dropped) {
+    if (n_dev) n = *n_dev;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
         s6 c = {cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5]};
         const float d = det6(c);
         const bool bad = (x != x) || (y != y) || (z != z) || (d != d) || (d <= 0.0f);
         keep[i] = bad ? 0 : 1;
+        if (bad && dropped) atomicAdd(dropped, 1);       // (erased rows are a handful per level: the counter tells the host whether anything has to move)
     }
+}
+
+// The counts of an asynchronous level stay on the device.  lvl[0] = rows of the new level before the validity erase (parents + orphans),
+// lvl[1] = orphans.  The arrays the rows go to were sized before that number existed: if they are too small the count is clamped (the
+// kernels behind this one only touch rows that exist), the abort flag goes up and the host reruns the level the synchronous way.
+__global__ void k_level_tail(int64_t n, int P, const int* __restrict__ orank_in, const int* __restrict__ oflag_in, long long out_cap,
+                             long long* __restrict__ lvl, int* __restrict__ abort_p) {
+    long long n_orph = (long long)orank_in[n - 1] + oflag_in[n - 1];
+    if ((long long)P + n_orph > out_cap) { *abort_p = 1; n_orph = out_cap > P ? out_cap - P : 0; }
+    lvl[0] = (long long)P + n_orph;
+    lvl[1] = n_orph;
+}
+
+// Everything the host wants to know about a level, in ONE round trip behind its last kernel (an asynchronous level; the synchronous one
+// uses it for the next level's prologue): the totals of the two scans, the counters, the next level's grid.  16 threads, word t of the
+// answer each; the values first, a system-scope fence, then the sequence number (see k_collect).
+struct LevelCollect {
+    const int64_t* coff; const unsigned* pcap;      // candidates = coff[P - 1] + pcap[P - 1]
+    const int64_t* poff; const unsigned* pcnt;      // pairs
+    int P;
+    const int* cnt;                                 // the level's counter block
+    const long long* lvl;                           // k_level_tail's counts (NULL: a synchronous level, the host has them)
+    const GridParams* gp; const unsigned* bbox;     // the NEXT level's prologue: grid, parents, irregular components
+};
+enum { LC_CAND = 0, LC_PAIRS, LC_ORPHANS, LC_NPRE, LC_FLAGS, LC_HEAVY, LC_ITEMS, LC_MAXPAIRS, LC_DROPPED, LC_NEXT_P, LC_NEXT_IRR, LC_NEXT_GP, LC_WORDS = 16 };
+__global__ void k_level_collect(LevelCollect q, unsigned long long* __restrict__ dst, unsigned long long seq) {
+    const int t = threadIdx.x;
+    unsigned long long v = 0ull;
+    const bool sel = q.P > 0 && q.coff != nullptr;
+    if (t == LC_CAND) v = sel ? (unsigned long long)q.coff[q.P - 1] + q.pcap[q.P - 1] : 0ull;
+    else if (t == LC_PAIRS) v = sel ? (unsigned long long)q.poff[q.P - 1] + q.pcnt[q.P - 1] : 0ull;
+    else if (t == LC_ORPHANS) v = q.lvl ? (unsigned long long)q.lvl[1] : 0ull;
+    else if (t == LC_NPRE) v = q.lvl ? (unsigned long long)q.lvl[0] : 0ull;
+    else if (t == LC_FLAGS) v = (q.cnt[2] ? 1ull : 0ull) | (q.cnt[12] ? 2ull : 0ull) | (q.cnt[13] ? 4ull : 0ull);
+    else if (t == LC_HEAVY) v = (unsigned)q.cnt[8];
+    else if (t == LC_ITEMS) v = (unsigned)q.cnt[10];
+    else if (t == LC_MAXPAIRS) v = (unsigned)q.cnt[15];
+    else if (t == LC_DROPPED) v = (unsigned)q.cnt[3];
+    else if (t == LC_NEXT_P) v = q.bbox[6];
+    else if (t == LC_NEXT_IRR) v = q.bbox[7];
+    else if (t < LC_WORDS) v = reinterpret_cast<const unsigned long long*>(q.gp)[t - LC_NEXT_GP];
+    if (t < LC_WORDS) __hip_atomic_store(dst + 16 + t, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (t == 0) __hip_atomic_store(dst + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 __global__ __launch_bounds__(256) void k_compact_rows(int64_t n, int width, const int* __restrict__ keep,
                                                       const int* __restrict__ pos, const float* __restrict__ src,
@@ -3238,6 +3331,17 @@ struct gsr_hem_ctx {
     hipEvent_t evk[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of k_select<COUNT> and k_select<FILL>
     hipEvent_t evm[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // brackets of k_mstep, k_partition, k_bucket_sum
     float kernel_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // The PROLOGUE of a level -- packed records, bounding box, axis histograms, grid geometry, the counts of parents and irregular
+    // components: everything the host needs before it can size and launch the level -- is computed when the level's INPUT comes into
+    // being (gsr_hem_set_level0, the end of the level before), and its answer rides in that moment's round trip.  pro.valid: `rec`,
+    // `gparams` and the counter block pro.cblock hold it for the current level of pro.n components.
+    struct Prologue { bool valid = false; GridParams gp; int P = 0, n_irr = 0, cblock = 0; int64_t n = 0; float ms = 0.0f; } pro;
+    hipEvent_t ev_pro[2] = {nullptr, nullptr};      // brackets of a prologue: its time counts for the level that consumes it (pro.ms)
+    int cblock = 0;                 // which of the two counter blocks the running level uses (the next level's prologue clears the other)
+    DevBuf lvl;                     // long long[8]: device-resident counts of an asynchronous level (k_level_tail); [2] = work-item size (k_heavy_items)
+    bool async_ok = true;           // GSR_HEM_ASYNC=0: every level sizes its buffers from counts read back on the way (five round trips, the rounds 1-4 schedule)
+    int round_trips = 0;            // host round trips of the last gsr_hem_run_level (statistic: gsr_hem_get_stats_ex [6])
+    int was_async = 0;              // the last level ran without a round trip between its first and its last kernel ([7])
     float cell_target = 16.0f;      // components per grid cell (GSR_HEM_CELL_TARGET; the result does not depend on it).  Swept at 5 M after the parents left
                                     // the candidate stream: 5 -> 13.15 ms per level, 8 -> 12.87, 12 -> 12.70, 16 -> 12.61, 24 -> 12.60, 32 -> 12.68 (fewer, longer rows)
     int max_cells = 1 << 24;
@@ -3266,13 +3370,15 @@ const unsigned* rng_xpow_table() {
 }
 
 // draw n parent flags in order into dst (consumes n hem::rand() values)
-int32_t draw_flags_raw(gsr_hem_ctx* c, int64_t n, uint8_t* dst, hipStream_t on = nullptr) {
+// (n_dev: n is only a bound -- the launch is sized for it -- and the real count lies on the device; the caller then sets the stream
+// position itself once it knows the count)
+int32_t draw_flags_raw(gsr_hem_ctx* c, int64_t n, uint8_t* dst, hipStream_t on = nullptr, const long long* n_dev = nullptr) {
     const hipStream_t fst = on ? on : c->stream;
     const float prob = 1.0f / c->rho;
     if (n == 0) return GSR_OK;
     if (c->rng_mode == GSR_RNG_HASH) {
         hipLaunchKernelGGL(k_flags_hash, dim3(stride_grid(n)), dim3(256), 0, fst, n, c->rng_seed,
-                           (unsigned long long)c->rng_pos, prob, dst);
+                           (unsigned long long)c->rng_pos, prob, dst, n_dev);
         c->rng_pos += (uint64_t)n;
         return GSR_OK;
     }
@@ -3313,9 +3419,9 @@ int32_t draw_flags_raw(gsr_hem_ctx* c, int64_t n, uint8_t* dst, hipStream_t on =
     const int64_t nblocks = (n + RNG_BLOCK_ELEMS - 1) / RNG_BLOCK_ELEMS;
     GSR_TRY(c->rng_blocks.reserve((size_t)nblocks * 64 * 4));
     hipLaunchKernelGGL(k_rng_block_state, dim3((unsigned)nblocks), dim3(64), 0, fst, (unsigned long long)c->rng_pos,
-                       c->draws.as<unsigned>(), c->rng_blocks.as<unsigned>());
+                       c->draws.as<unsigned>(), c->rng_blocks.as<unsigned>(), n_dev);
     hipLaunchKernelGGL(k_flags_glibc, dim3((unsigned)nblocks), dim3(RNG_THREADS), 0, fst, n, prob, c->draws.as<unsigned>(),
-                       c->rng_blocks.as<unsigned>(), dst);
+                       c->rng_blocks.as<unsigned>(), dst, n_dev);
     c->rng_pos += (uint64_t)n;
     return GSR_OK;
 }
@@ -3341,10 +3447,9 @@ __global__ void k_collect(Collect q, unsigned long long* __restrict__ dst, unsig
     __syncthreads();
     if (t == 0) __hip_atomic_store(dst + 15, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
-int32_t read_back(gsr_hem_ctx* c, const Collect& q, unsigned long long* out) {
-    const unsigned long long seq = ++c->rb_seq;
-    hipLaunchKernelGGL(k_collect, dim3(1), dim3(8), 0, c->stream, q, c->host_rb, seq);
-    GSR_HIP(hipGetLastError());
+// (the wait of a round trip: the kernel that carries sequence number `seq` has been enqueued on the context's stream)
+int32_t wait_round_trip(gsr_hem_ctx* c, unsigned long long seq) {
+    c->round_trips += 1;
     bool seen = false;
     if (c->rb_poll) {
         (void)hipStreamQuery(c->stream);                        // makes sure the queue is submitted
@@ -3357,7 +3462,23 @@ int32_t read_back(gsr_hem_ctx* c, const Collect& q, unsigned long long* out) {
         }
     }
     if (!seen) GSR_HIP(hipStreamSynchronize(c->stream));
+    return GSR_OK;
+}
+int32_t read_back(gsr_hem_ctx* c, const Collect& q, unsigned long long* out) {
+    const unsigned long long seq = ++c->rb_seq;
+    hipLaunchKernelGGL(k_collect, dim3(1), dim3(8), 0, c->stream, q, c->host_rb, seq);
+    GSR_HIP(hipGetLastError());
+    GSR_TRY(wait_round_trip(c, seq));
     for (int i = 0; i < q.n; ++i) out[i] = __atomic_load_n(c->host_rb + i, __ATOMIC_RELAXED);
+    return GSR_OK;
+}
+// the level-wide answer (k_level_collect): LC_WORDS words
+int32_t read_back_level(gsr_hem_ctx* c, const LevelCollect& q, unsigned long long* out) {
+    const unsigned long long seq = ++c->rb_seq;
+    hipLaunchKernelGGL(k_level_collect, dim3(1), dim3(64), 0, c->stream, q, c->host_rb, seq);
+    GSR_HIP(hipGetLastError());
+    GSR_TRY(wait_round_trip(c, seq));
+    for (int i = 0; i < LC_WORDS; ++i) out[i] = __atomic_load_n(c->host_rb + 16 + i, __ATOMIC_RELAXED);
     return GSR_OK;
 }
 
@@ -3416,6 +3537,52 @@ void unborrow_level0(gsr_hem_ctx* c) {
     }
     c->cur_borrowed = false;
 }
+
+// The prologue of the level whose input is L (gsr_hem_ctx::Prologue): k_prep (the packed records, box partials, the counts of parents
+// and irregular components), their fold (which also clears the level's counter block and the histograms), the axis histograms, the grid
+// geometry.  n_dev != NULL: the level's size lies on the device (the level before has not reported yet) and n is a bound for the grids.
+int32_t enqueue_prologue(gsr_hem_ctx* c, Level& L, int64_t n, const long long* n_dev, int cblock) {
+    hipStream_t st = c->stream;
+    const dim3 blk(256), grd(stride_grid(n));
+    GSR_TRY(c->rec.reserve((size_t)n * 64)); GSR_TRY(c->bbox.reserve(64));
+    GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(128));
+    GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 8 * 4)); GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
+    if (c->timing >= 1) GSR_HIP(hipEventRecord(c->ev_pro[0], st));
+    hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
+                       L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>(), n_dev);
+    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>(),
+                       c->counters.as<unsigned>() + 16 * cblock, 16, c->hist.as<unsigned>(), 3 * HIST_BINS);
+    hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>(), n_dev);
+    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), n, c->cell_target,
+                       c->max_cells, c->gparams.as<GridParams>(), n_dev);
+    if (c->timing >= 1) GSR_HIP(hipEventRecord(c->ev_pro[1], st));
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+// ... and its answer, out of the words of k_level_collect
+void take_prologue(gsr_hem_ctx* c, const unsigned long long* w, int64_t n, int cblock) {
+    static_assert(sizeof(GridParams) == 40 && LC_NEXT_GP + 5 == LC_WORDS, "GridParams travels as five 8-byte words");
+    memcpy(&c->pro.gp, w + LC_NEXT_GP, sizeof(GridParams));
+    c->pro.P = (int)(unsigned)w[LC_NEXT_P]; c->pro.n_irr = (int)(unsigned)w[LC_NEXT_IRR];
+    c->pro.n = n; c->pro.cblock = cblock; c->pro.valid = true;
+    c->pro.ms = 0.0f;
+    if (c->timing >= 1) (void)hipEventElapsedTime(&c->pro.ms, c->ev_pro[0], c->ev_pro[1]);      // (both have completed: the round trip came behind them)
+}
+// The current level's prologue, now, with its own round trip (gsr_hem_set_level0, gsr_hem_set_state, a level whose prologue is not there).
+// Partitioned / work-sharded levels compute theirs inside the level (their box and histograms are all-reduced over the ranks).
+int32_t prologue_now(gsr_hem_ctx* c) {
+    c->pro.valid = false;
+    if (c->cur.n <= 0 || c->comm != nullptr || c->shard_world > 1) return GSR_OK;
+    const int cb = c->cblock ^ 1;
+    GSR_TRY(enqueue_prologue(c, c->cur, c->cur.n, nullptr, cb));
+    LevelCollect q;
+    memset(&q, 0, sizeof(q));
+    q.cnt = c->counters.as<int>() + 16 * cb; q.gp = c->gparams.as<GridParams>(); q.bbox = c->bbox.as<unsigned>();
+    unsigned long long w[LC_WORDS];
+    GSR_TRY(read_back_level(c, q, w));
+    take_prologue(c, w, c->cur.n, cb);
+    return GSR_OK;
+}
 }  // namespace
 
 extern "C" {
@@ -3463,13 +3630,14 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_mfork, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_mjoin, hipEventDisableTiming);
         for (int i = 0; i < 4 && e == hipSuccess; ++i) e = hipEventCreate(&c->evp[i]);
+        for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreate(&c->ev_pro[i]);
         if (e != hipSuccess) { delete c; return fail(GSR_E_HIP, "second stream: %s", hipGetErrorString(e)); }
     }
     {
         // pinned, device-mapped, COHERENT: the read-back kernel's system-scope stores must reach the host while the stream is running
-        hipError_t e = hipHostMalloc((void**)&c->host_rb, 128, hipHostMallocMapped | hipHostMallocCoherent);
+        hipError_t e = hipHostMalloc((void**)&c->host_rb, 512, hipHostMallocMapped | hipHostMallocCoherent);      // [0..14] k_collect, [15] sequence, [16..31] k_level_collect
         if (e != hipSuccess) { c->host_rb = nullptr; delete c; return fail(GSR_E_HIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
-        memset(c->host_rb, 0, 128);
+        memset(c->host_rb, 0, 512);
     }
     // Environment knobs (all of them): none changes a result, each is exercised by a test.
     if (const char* s = getenv("GSR_HEM_ELL")) c->use_ell = atoi(s) != 0;
@@ -3482,6 +3650,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_TIMING")) { const int v = atoi(s); c->timing = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* s = getenv("GSR_HEM_SELECT_NP")) { const int v = atoi(s); c->select_np = v < 1 ? 1 : (v > SEL_NP ? SEL_NP : v); }
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_ASYNC")) c->async_ok = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
     if (const char* s = getenv("GSR_HEM_SH_GRID")) c->sh_grid = atoi(s);
     if (const char* s = getenv("GSR_HEM_PARTITION_STAGE")) { const int v = atoi(s); if (v == 8192 || v == 6144 || v == 4096) c->partition_stage = v; }
@@ -3517,7 +3686,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
                      &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->rowlist, &c->olist, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
-                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch};
+                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch, &c->lvl};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -3532,6 +3701,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     if (c->ev_mfork) (void)hipEventDestroy(c->ev_mfork);
     if (c->ev_mjoin) (void)hipEventDestroy(c->ev_mjoin);
     for (int i = 0; i < 4; ++i) if (c->evp[i]) (void)hipEventDestroy(c->evp[i]);
+    for (int i = 0; i < 2; ++i) if (c->ev_pro[i]) (void)hipEventDestroy(c->ev_pro[i]);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->aux2) (void)hipStreamDestroy(c->aux2);
     delete c;
@@ -3590,8 +3760,9 @@ int32_t gsr_hem_set_level0(gsr_hem_ctx* c, const float* xyz, const float* color,
         L.n = n; L.F = F;
         hipLaunchKernelGGL(k_fill_const<float>, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, L.weight.as<float>(), 1.0f);
         GSR_TRY(draw_flags(c, L));
-        GSR_HIP(hipStreamSynchronize(c->stream));
         c->have_level = true;
+        GSR_TRY(prologue_now(c));                               // (its round trip is this call's synchronisation)
+        if (!c->pro.valid) GSR_HIP(hipStreamSynchronize(c->stream));
         return GSR_OK;
     }
     GSR_TRY(L.reserve(n, F));
@@ -3606,8 +3777,9 @@ int32_t gsr_hem_set_level0(gsr_hem_ctx* c, const float* xyz, const float* color,
         hipLaunchKernelGGL(k_fill_const<float>, dim3(stride_grid(n)), dim3(256), 0, c->stream, n, L.weight.as<float>(), 1.0f);   // mixture.cpp:315
     }
     GSR_TRY(draw_flags(c, L));                                  // mixture.cpp:330
-    GSR_HIP(hipStreamSynchronize(c->stream));
     c->have_level = true;
+    GSR_TRY(prologue_now(c));                                   // (its round trip is this call's synchronisation: the caller's arrays are free again)
+    if (!c->pro.valid) GSR_HIP(hipStreamSynchronize(c->stream));
     return GSR_OK;
 }
 
@@ -3648,6 +3820,7 @@ int32_t gsr_hem_set_level0_part(gsr_hem_ctx* c, const float* xyz, const float* c
     hipLaunchKernelGGL(k_gather_bytes, dim3(stride_grid(n_own)), dim3(256), 0, st, n_own, c->gid.as<unsigned>(), c->allflags.as<uint8_t>(), c->cur.is_parent.as<uint8_t>());
     GSR_HIP(hipStreamSynchronize(st));
     c->n_global = n_global;
+    c->pro.valid = false;
     return GSR_OK;
 }
 
@@ -3685,6 +3858,7 @@ int32_t gsr_hem_set_state(gsr_hem_ctx* c, const uint8_t* parent_mask, const floa
     if (c->cur.n > 0) {
         if (parent_mask) GSR_HIP(hipMemcpyAsync(c->cur.is_parent.p, parent_mask, (size_t)c->cur.n, hipMemcpyHostToDevice, c->stream));
         if (weight) GSR_HIP(hipMemcpyAsync(c->cur.weight.p, weight, (size_t)c->cur.n * 4, hipMemcpyHostToDevice, c->stream));
+        GSR_TRY(prologue_now(c));                               // the records carry the flags and the weights: again
         GSR_HIP(hipStreamSynchronize(c->stream));
     }
     return GSR_OK;
@@ -4008,71 +4182,163 @@ struct PartLevel {
 
 }  // namespace
 
-int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
-    const bool dbg_sync = getenv("GSR_HEM_DEBUG_SYNC") != nullptr;
-    if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_run_level: no level set");
-    GSR_HIP(hipSetDevice(c->device));
-    hipStream_t st = c->stream;
-    Level& L = c->cur;
-    // spatially partitioned level: the working set is this rank's owned components + the ghosts the halo exchange brings in;
-    // n becomes their number once the exchange is through (n_own = L.n stays the owned ones, the first n_own local indices)
-    const bool part = c->comm != nullptr;
-    const int64_t n_own = L.n;
-    int64_t n = n_own;
-    const int F = L.F;
-    memset(c->stats, 0, sizeof(c->stats));
-    memset(c->stats_ex, 0, sizeof(c->stats_ex));
-    memset(c->part_stats, 0, sizeof(c->part_stats));
-    c->stats[6] = n;
-    PartLevel pl;                                // (only a partitioned level uses it)
-    pl.c = c; pl.st = st; pl.n_own = n_own;
-    if (part) {
-        pl.W = gsr_comm_world(c->comm); pl.me = gsr_comm_rank(c->comm);
-        if (pl.W > 8) return fail(GSR_E_INVALID, "gsr_hem_run_level: more than 8 ranks");
-    }
-    if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld components (the candidate records carry the sorted position in 30 bits)", (long long)n);
-    if (part && c->shard_world > 1) return fail(GSR_E_INVALID, "gsr_hem_run_level: spatial partition and work sharding are exclusive");
-    if (part) GSR_TRY(pl.agree_on_preconditions(n));
-    if (n == 0) {
-        if (n_out) *n_out = 0;
-        if (n_dropped) *n_dropped = 0;
-        return GSR_OK;
-    }
-    const dim3 blk(256);
-    dim3 grd(stride_grid(n));
-    GSR_TIME1(c->ev[0], st);
+namespace {
 
-    // ---- 1. det, radii, bounding box; grid; sort by cell -------------------------------------
-    GSR_TRY(c->rec.reserve(n * 64)); GSR_TRY(c->bbox.reserve(64));
-    GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(64));
-    GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 8 * 4)); GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
-    hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
-                       L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>());
-    hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>(),
-                       c->counters.as<unsigned>(), 16, c->hist.as<unsigned>(), 3 * HIST_BINS);
-    // The parents' output ranks depend on nothing but the level's flags (input order): flags as ints + their scan on the second
-    // stream, beside the grid phase, instead of between the sums and the M-step (three launches off the critical path).
-    GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
-    bool ranks_forked = false;
-    if (!part && c->aux && c->ev_pre) {
-        GSR_HIP(hipEventRecord(c->ev_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-        hipLaunchKernelGGL(k_flags_in, grd, blk, 0, c->aux, n, n_own, L.is_parent.as<uint8_t>(), c->pflag_in.as<int>(), c->oflag_in.as<int>());
-        GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n, true));
-        GSR_HIP(hipEventRecord(c->ev_pre, c->aux));
-        ranks_forked = true;
-    }
-    if (part) {     // the box of ALL ranks' components: maximum of the (order-preserving) codes, the minima complemented
-        hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
-        GSR_TRY(gsr_comm_allreduce(c->comm, c->bbox.p, 6, GSR_DT_U32, GSR_OP_MAX, (void*)st));
-        hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
-    }
-    hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>());
-    if (part) GSR_TRY(gsr_comm_allreduce(c->comm, c->hist.p, 3 * HIST_BINS, GSR_DT_U32, GSR_OP_SUM, (void*)st));      // integer counts: exact
-    hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), part ? c->n_global : n, c->cell_target,
-                       c->max_cells, c->gparams.as<GridParams>());
+// internal status of LevelRun::run: the buffers an asynchronous level ran on were too small (or one of its other assumptions did not hold);
+// nothing of the level's input has been touched -- gsr_hem_run_level runs it again the synchronous way, which sizes everything exactly
+constexpr int32_t GSR_RETRY_SYNC = -1000;
+
+// One level (gsr_hem_run_level), stage by stage.  Two schedules through the same stages:
+//  * SYNCHRONOUS (rounds 1-4; still what a partitioned / work-sharded level, a fresh context and every fallback path run): the host sizes each
+//    stage's buffers from counts it reads back on the way -- candidates, pairs, orphans, surviving rows: four round trips inside the level;
+//  * ASYNCHRONOUS (`spec`, the default once the context's buffers exist): NO round trip between the level's first and its last kernel.
+//    What the host knows when it starts is the level's prologue (grid, parents, irregular components: computed when the level's input came
+//    into being); everything else stays on the device -- the heavy threshold and the work-item size come from the capacities' scan
+//    (k_heavy_keys, k_heavy_items), the pair buffers are the ones the context has and every segment write is clamped to them (k_select),
+//    the bucket regions take their capacity from the buffers, the new level's size is k_level_tail's, launches are sized for bounds and
+//    their surplus blocks leave on the device count -- and ONE answer comes back behind the last kernel (k_level_collect) together with
+//    the NEXT level's prologue.  A raised abort / overflow flag there means the level is run again synchronously (GSR_RETRY_SYNC);
+//    its input was never written.
+// The reference's level is one function without such a boundary (src/cpp_ext/src/mixture.cpp:25-35, 66-285).
+struct LevelRun {
+    gsr_hem_ctx* c;
+    hipStream_t st;
+    Level& L;
+    Level& O;
+    const bool dbg_sync, part, sharded;
+    bool spec = false;
+    const int64_t n_own;
+    int64_t n;
+    const int F, RSH;
+    PartLevel pl;
+    const dim3 blk{256};
+    dim3 grd;
     GridParams gp;
-    int early_P = 0, early_irr = 0;
-    {
+    int P_all = 0, P = 0, n_irr = 0;
+    int* cnt = nullptr;                     // this level's counter block: [0] [1] heavy parents / segments of the M-step, [2] abort, [3] erased rows,
+                                            // [8] heavy parents of the selection, [10] [11] their queue, [12] bucket overflow, [13] item table overflow, [15] max pairs
+    long long* lvl = nullptr;               // device: [0] rows of the new level before the erase, [1] orphans, [2] (as unsigned) work-item size
+    const float4* rec_src = nullptr;
+    bool ranks_forked = false, sh_pending = false, sh_launched = false, flags_forked = false;
+    // selection
+    SelectArgs sa;
+    size_t Pm = 1;
+    int own_lo = 0, own_hi = 0;
+    int64_t M = 0;
+    unsigned long long cand = 0, cap_pairs = 0;
+    // per-child sums
+    const int64_t* seg = nullptr;
+    const unsigned* pc = nullptr;
+    const float* pw = nullptr;
+    int bshift = 0, nbuckets = 0;
+    int* overflow_flag = nullptr;
+    bool fixed_tried = false;
+    // output
+    int64_t n_orph = 0, n_pre = 0, out_cap = 0;
+    bool out_active = false;                // the new level is being written into the caller's arrays (gsr_hem_set_output)
+    uint64_t rng_pos0 = 0;
+    int64_t dropped = 0, P_glob = 0, O_glob = 0, n_pre_glob = 0, n_glob_next = 0;
+    float pro_ms = 0.0f;                    // the time of this level's prologue, which ran when its input came into being
+
+    LevelRun(gsr_hem_ctx* ctx, bool allow_async)
+        : c(ctx), st(ctx->stream), L(ctx->cur), O(ctx->nxt), dbg_sync(getenv("GSR_HEM_DEBUG_SYNC") != nullptr), part(ctx->comm != nullptr),
+          sharded(ctx->shard_world > 1 && ctx->shard_allreduce != nullptr), n_own(ctx->cur.n), n(ctx->cur.n), F(ctx->cur.F), RSH((ctx->cur.F + 3) & ~3) {
+        spec = allow_async;
+        pl.c = c; pl.st = st; pl.n_own = n_own;
+        memset(&sa, 0, sizeof(sa));
+    }
+    ~LevelRun() {       // an error return hands nxt its own buffers back
+        if (out_active) for (int i = 0; i < 5; ++i) { DevBuf* b = level_big(c->nxt, i); b->p = nullptr; b->cap = 0; b->swap(c->spare_out[i]); }
+    }
+
+    int32_t run(int64_t* n_out, int64_t* n_dropped);
+    int32_t grid_phase();
+    int32_t select_phase();
+    int32_t sums_phase();
+    int32_t sums_fixed();
+    int32_t sums_exact();
+    int32_t compact_pairs();
+    int32_t output_ranks();
+    int32_t open_output();
+    int32_t mstep_phase();
+    int32_t flags_and_validity();
+    int32_t compact_erased(int64_t n_keep);
+    int32_t launch_gather_sh(bool fork);
+    int32_t widen_scan(const unsigned* cnt_in, int64_t* off, int64_t count);
+    int32_t total_of(const int64_t* off, const unsigned* cnt_in, int64_t count, int64_t* out);
+};
+
+int32_t LevelRun::widen_scan(const unsigned* cnt_in, int64_t* off, int64_t count) {      // off = exclusive scan of cnt_in (int64)
+    GSR_TRY(c->scratch.reserve(((size_t)count + 128) * 8));
+    int64_t* cnt64 = c->scratch.as<int64_t>();
+    GSR_HIP(rocprim::transform(cnt_in, cnt64, (size_t)count, [] __device__(unsigned v) { return (int64_t)v; }, st));
+    return exclusive_scan<int64_t>(c, cnt64, off, count);
+}
+int32_t LevelRun::total_of(const int64_t* off, const unsigned* cnt_in, int64_t count, int64_t* out) {
+    Collect q;
+    q.n = 2;
+    q.src[0] = off + (count - 1); q.bytes[0] = 8;
+    q.src[1] = cnt_in + (count - 1); q.bytes[1] = 4;
+    unsigned long long w[8];
+    GSR_TRY(read_back(c, q, w));
+    *out = (int64_t)w[0] + (int64_t)(unsigned)w[1];
+    return GSR_OK;
+}
+
+// only the M-step reads the sorted SH rows: the gather (1.9 GB of HBM traffic at 5 M) can run on its own stream beside the
+// selection, which is bound by VALU issue and load latency, and is joined in front of the M-step.  sh_overlap: 0 = in line
+// here, 1 = forked here (beside the rest of the grid phase), 2 = forked just in front of k_select
+int32_t LevelRun::launch_gather_sh(bool fork) {
+    if (F <= 0) return GSR_OK;
+    hipStream_t sst = st;
+    if (fork) {
+        GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
+        sst = c->aux2;
+    }
+    int shg = stride_grid(n * (RSH >> 2));
+    if (fork && c->sh_grid > 0 && shg > c->sh_grid) shg = c->sh_grid;
+    if (part)
+        hipLaunchKernelGGL(k_gather_sh2, dim3(shg), blk, 0, sst, n, n_own, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(),
+                           c->ghost_sh.as<float>(), c->shs.as<float>());
+    else
+        hipLaunchKernelGGL(k_gather_sh, dim3(shg), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
+    if (fork) { GSR_HIP(hipEventRecord(c->ev_sh_join, c->aux2)); sh_pending = true; }
+    return GSR_OK;
+}
+
+// ---- 1. the level's prologue (det, packed records, bounding box, grid) if it is not there yet; sort by cell; the cell-sorted working set ----
+int32_t LevelRun::grid_phase() {
+    GSR_TRY(c->counters.reserve(128)); GSR_TRY(c->lvl.reserve(64));
+    lvl = c->lvl.as<long long>();
+    if (!part && !sharded) {
+        // the prologue came with the level's input (gsr_hem_set_level0, the level before); if not -- a caller changed the flags, an error
+        // path -- it is computed now, with a round trip of its own
+        if (!(c->pro.valid && c->pro.n == n)) GSR_TRY(prologue_now(c));
+        if (!c->pro.valid) return fail(GSR_E_INVALID, "gsr_hem_run_level: no prologue for the level");
+        gp = c->pro.gp; P_all = c->pro.P; n_irr = c->pro.n_irr; c->cblock = c->pro.cblock; pro_ms = c->pro.ms;
+        c->pro.valid = false;                   // consumed: `rec` and the counter block belong to this level now
+        cnt = c->counters.as<int>() + 16 * c->cblock;
+    } else {
+        c->pro.valid = false;
+        c->cblock ^= 1;
+        cnt = c->counters.as<int>() + 16 * c->cblock;
+        GSR_TRY(c->rec.reserve(n * 64)); GSR_TRY(c->bbox.reserve(64));
+        GSR_TRY(c->gparams.reserve(sizeof(GridParams)));
+        GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 8 * 4)); GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
+        hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
+                           L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>(), (const long long*)nullptr);
+        hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>(),
+                           (unsigned*)cnt, 16, c->hist.as<unsigned>(), 3 * HIST_BINS);
+        if (part) {     // the box of ALL ranks' components: maximum of the (order-preserving) codes, the minima complemented
+            hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
+            GSR_TRY(gsr_comm_allreduce(c->comm, c->bbox.p, 6, GSR_DT_U32, GSR_OP_MAX, (void*)st));
+            hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
+        }
+        hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>(),
+                           (const long long*)nullptr);
+        if (part) GSR_TRY(gsr_comm_allreduce(c->comm, c->hist.p, 3 * HIST_BINS, GSR_DT_U32, GSR_OP_SUM, (void*)st));      // integer counts: exact
+        hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), part ? c->n_global : n, c->cell_target,
+                           c->max_cells, c->gparams.as<GridParams>(), (const long long*)nullptr);
         static_assert(sizeof(GridParams) == 40, "GridParams is read back as five 8-byte words");
         Collect q;
         q.n = 7;
@@ -4082,11 +4348,22 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
         memcpy(&gp, w, sizeof(gp));
-        early_P = (int)(unsigned)w[5]; early_irr = (int)(unsigned)w[6];
+        P_all = (int)(unsigned)w[5]; n_irr = (int)(unsigned)w[6];
     }
+    overflow_flag = cnt + 12;
     c->stats[5] = gp.ncells;
+    // The parents' output ranks depend on nothing but the level's flags (input order): flags as ints + their scan on the second
+    // stream, beside the grid phase, instead of between the sums and the M-step (three launches off the critical path).
+    GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
+    if (!part && c->aux && c->ev_pre) {
+        GSR_HIP(hipEventRecord(c->ev_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
+        hipLaunchKernelGGL(k_flags_in, grd, blk, 0, c->aux, n, n_own, L.is_parent.as<uint8_t>(), c->pflag_in.as<int>(), c->oflag_in.as<int>());
+        GSR_TRY(exclusive_scan<int>(c, c->pflag_in.as<int>(), c->prank_in.as<int>(), n, true));
+        GSR_HIP(hipEventRecord(c->ev_pre, c->aux));
+        ranks_forked = true;
+    }
 
-    const float4* rec_src = c->rec.as<float4>();            // the packed records of the working set, by local index
+    rec_src = c->rec.as<float4>();              // the packed records of the working set, by local index
     if (part) {
         GSR_TRY(pl.halo(gp, L, F, n));
         grd = dim3(stride_grid(n));
@@ -4100,40 +4377,17 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(sort_pairs<unsigned>(c, c->gid_loc.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(), c->perm.as<unsigned>(), n, bits_for(c->n_global + 1)));
         hipLaunchKernelGGL(k_keys_rec, grd, blk, 0, st, n, rec_src, c->perm.as<unsigned>(), c->gparams.as<GridParams>(), c->keys.as<unsigned>(), c->idx.as<unsigned>());
     } else
-    hipLaunchKernelGGL(k_keys, grd, blk, 0, st, n, L.xyz.as<float>(), c->gparams.as<GridParams>(), c->keys.as<unsigned>(), c->idx.as<unsigned>());
+        hipLaunchKernelGGL(k_keys, grd, blk, 0, st, n, L.xyz.as<float>(), c->gparams.as<GridParams>(), c->keys.as<unsigned>(), c->idx.as<unsigned>());
     GSR_TRY(sort_pairs<unsigned>(c, c->keys.as<unsigned>(), c->skeys.as<unsigned>(), c->idx.as<unsigned>(), c->order.as<unsigned>(), n,
                                  bits_for(gp.ncells)));
     GSR_TRY(c->cellStart.reserve(((size_t)gp.ncells + 1) * 4));
     hipLaunchKernelGGL(k_run_starts<int>, grd, blk, 0, st, n, c->skeys.as<unsigned>(), (int64_t)gp.ncells, c->cellStart.as<int>());
 
-    const int RSH = (F + 3) & ~3;                               // SH rows padded to whole float4 (SH degree 3: 45 -> 48 floats)
     GSR_TRY(c->A.reserve((n + SEL_PAD) * 16)); GSR_TRY(c->geo.reserve((size_t)n * 64)); GSR_TRY(c->shs.reserve((size_t)n * (RSH > 0 ? RSH : 1) * 4));
     GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4));
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
     hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), rec_src, c->delta, c->A.as<float4>(), c->geo.as<float4>(),
                        c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
-    bool sh_pending = false;
-    // only the M-step reads the sorted SH rows: the gather (1.9 GB of HBM traffic at 5 M) can run on its own stream beside the
-    // selection, which is bound by VALU issue and load latency, and is joined in front of the M-step.  sh_overlap: 0 = in line
-    // here, 1 = forked here (beside the rest of the grid phase), 2 = forked just in front of k_select
-    auto launch_gather_sh = [&](bool fork) -> int32_t {
-        if (F <= 0) return GSR_OK;
-        hipStream_t sst = st;
-        if (fork) {
-            GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
-            sst = c->aux2;
-        }
-        int shg = stride_grid(n * (RSH >> 2));
-        if (fork && c->sh_grid > 0 && shg > c->sh_grid) shg = c->sh_grid;
-        if (part)
-            hipLaunchKernelGGL(k_gather_sh2, dim3(shg), blk, 0, sst, n, n_own, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(),
-                               c->ghost_sh.as<float>(), c->shs.as<float>());
-        else
-        hipLaunchKernelGGL(k_gather_sh, dim3(shg), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
-        if (fork) { GSR_HIP(hipEventRecord(c->ev_sh_join, c->aux2)); sh_pending = true; }
-        return GSR_OK;
-    };
-    bool sh_launched = false;
     // (a partitioned level: always forked -- the third stream carries the ghosts' SH rows, the gather queues up behind them)
     if (part && F > 0) { GSR_TRY(launch_gather_sh(true)); sh_launched = true; }
     else if (c->sh_overlap != 2) { GSR_TRY(launch_gather_sh(c->sh_overlap == 1)); sh_launched = true; }
@@ -4144,29 +4398,26 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(exclusive_scan<int>(c, c->pown.as<int>(), c->ppos_own.as<int>(), n));
         hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pown.as<int>(), c->ppos_own.as<int>(), c->plist.as<unsigned>());
     } else
-    hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
+        hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->pflag.as<int>(), c->ppos.as<int>(), c->plist.as<unsigned>());
     // the irregular components (never pre-rejected): their sorted positions, and their rank at every position
     // (a level without any -- k_prep counted them -- builds no list: pass B does not run then)
-    if (part || early_irr > 0) {
+    if (part || n_irr > 0) {
         GSR_TRY(exclusive_scan<int>(c, c->iflag.as<int>(), c->irank.as<int>(), n + 1));
         hipLaunchKernelGGL(k_scatter_list, grd, blk, 0, st, n, c->iflag.as<int>(), c->irank.as<int>(), c->ipos.as<unsigned>());
     }
-    int last_pos = 0, last_flag = 0, n_irr = 0, own_pos = 0, own_flag = 0;
-    if (!part) {        // the two counts came with the grid (k_prep counted them): no read-back here
-        n_irr = early_irr; last_pos = early_P; last_flag = 0;
-    } else {
+    P = P_all;                                  // (one GPU: the two counts came with the prologue, k_prep counted them)
+    if (part) {
         Collect q;
-        q.n = part ? 5 : 3;
+        q.n = 5;
         q.src[0] = c->irank.as<int>() + n; q.src[1] = c->ppos.as<int>() + (n - 1); q.src[2] = c->pflag.as<int>() + (n - 1);
-        if (part) { q.src[3] = c->ppos_own.as<int>() + (n - 1); q.src[4] = c->pown.as<int>() + (n - 1); }
+        q.src[3] = c->ppos_own.as<int>() + (n - 1); q.src[4] = c->pown.as<int>() + (n - 1);
         for (int i = 0; i < 5; ++i) q.bytes[i] = 4;
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
-        n_irr = (int)w[0]; last_pos = (int)w[1]; last_flag = (int)w[2];
-        if (part) { own_pos = (int)w[3]; own_flag = (int)w[4]; }
+        n_irr = (int)w[0];
+        P_all = (int)w[1] + (int)w[2];          // parents among the local components (they are no candidates)
+        P = (int)w[3] + (int)w[4];              // parents this rank evaluates
     }
-    const int P_all = last_pos + last_flag;                   // parents among the local components (they are no candidates)
-    const int P = part ? own_pos + own_flag : P_all;          // parents this rank evaluates
     c->stats[0] = P;
     c->stats_ex[0] = n_irr;
     // the candidate stream of pass A (non-parents only) and its prefix table
@@ -4175,27 +4426,26 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                        c->cellStart.as<int>(), c->Ac.as<float4>(), c->cellStartC.as<int>(), (int)SEL_PAD);
     GSR_CHECKPOINT("grid + gather");
     GSR_TIME(c->ev[1], st);
+    return GSR_OK;
+}
 
-    // ---- 2. selection ------------------------------------------------------------------------------
-    // Fast path (SPARSE): one evaluation pass.  k_spans sums the span lengths per parent (an upper bound of
-    // its child count); every parent writes its pairs at the head of a segment of that capacity;
-    // k_compact_pairs packs them.  The sparse buffers cost 8 bytes per candidate scanned; when that exceeds
-    // the budget (GSR_HEM_SPARSE_GB, default 45 % of free HBM) the two-pass COUNT + FILL fallback runs
-    // instead (same device code, evaluates every candidate twice).
-    const size_t Pm = (size_t)(P > 0 ? P : 1);
+// ---- 2. selection ------------------------------------------------------------------------------
+// Fast path (SPARSE): one evaluation pass.  k_spans sums the span lengths per parent (an upper bound of
+// its child count); every parent writes its pairs at the head of a segment of that capacity.  The sparse buffers cost 8 bytes per
+// candidate scanned; when that exceeds the budget (GSR_HEM_SPARSE_GB, default 45 % of free HBM) the two-pass COUNT + FILL fallback
+// runs instead (same device code, evaluates every candidate twice).  An asynchronous level takes the buffers as they are.
+int32_t LevelRun::select_phase() {
+    Pm = (size_t)(P > 0 ? P : 1);
     GSR_TRY(c->pcnt.reserve(Pm * 4)); GSR_TRY(c->pcap.reserve(Pm * 4)); GSR_TRY(c->poff.reserve((Pm + 1) * 8));
     GSR_TRY(c->scratch.reserve((Pm * 2 + 128) * 8));
-    SelectArgs sa;
-    memset(&sa, 0, sizeof(sa));
     sa.A = c->A.as<float4>(); sa.geo = c->geo.as<float4>();
     sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
     sa.gp = c->gparams.as<GridParams>(); sa.P = P;
     sa.Ac = c->Ac.as<float4>(); sa.cellStartC = c->cellStartC.as<int>();
     sa.irank = c->irank.as<int>(); sa.ipos = c->ipos.as<unsigned>(); sa.n_irr = n_irr; sa.ell = c->use_ell ? 1 : 0;
     // work sharding: rank r of W evaluates the contiguous run [P r / W, P (r+1) / W) of the cell-sorted parents
-    const bool sharded = c->shard_world > 1 && c->shard_allreduce != nullptr;
-    const int own_lo = sharded ? (int)((int64_t)P * c->shard_rank / c->shard_world) : 0;
-    const int own_hi = sharded ? (int)((int64_t)P * (c->shard_rank + 1) / c->shard_world) : P;
+    own_lo = sharded ? (int)((int64_t)P * c->shard_rank / c->shard_world) : 0;
+    own_hi = sharded ? (int)((int64_t)P * (c->shard_rank + 1) / c->shard_world) : P;
     sa.own_lo = own_lo; sa.own_hi = own_hi;
     {   // colour gate  sqrtf(x) > kappa^2/2  (mixture.cpp:123) as a test on x: sqrtf is correctly rounded and monotone, so the
         // gate is  x > x*,  x* = the largest float whose square root does not exceed the threshold
@@ -4216,9 +4466,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     sa.tau2 = c->tau * c->tau;                    // mixture.cpp:58,61
     sa.pcnt = c->pcnt.as<unsigned>();
     sa.pcap = c->pcap.as<unsigned>();
+    sa.part_p = reinterpret_cast<const unsigned*>(lvl + 2);
+    sa.abort_p = cnt + 2;
     // parents per selection wave: SEL_NP, but no fewer waves than the chip holds at once (256 CUs x 28)
     sa.np = c->select_np > 0 ? c->select_np : (P >= SEL_NP * 7168 ? SEL_NP : (P >= 2 * 7168 ? 2 : 1));
-    int64_t M = 0;
+    M = 0;
     constexpr int WPB = 2;      // parents per workgroup (work per parent is heavy-tailed: small workgroups free their CU slot sooner)
     // the queue-serving kernel runs beside the light parents' on the context's second stream (fork / join by events)
 #define GSR_LAUNCH_SELECT(MODE) do { \
@@ -4230,22 +4482,6 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL((k_select<MODE, WPB, false>), dim3(8 * ceil_div(ceil_div(P, WPB * sa.np), 8)), dim3(64 * WPB), 0, st, sa); \
         if (sa.heavy_blocks) GSR_HIP(hipStreamWaitEvent(st, c->ev_join, 0)); \
     } while (0)
-    auto widen_scan = [&](const unsigned* cnt, int64_t* off, int64_t count) -> int32_t {      // off = exclusive scan of cnt (int64)
-        GSR_TRY(c->scratch.reserve(((size_t)count + 128) * 8));
-        int64_t* cnt64 = c->scratch.as<int64_t>();
-        GSR_HIP(rocprim::transform(cnt, cnt64, (size_t)count, [] __device__(unsigned v) { return (int64_t)v; }, st));
-        return exclusive_scan<int64_t>(c, cnt64, off, count);
-    };
-    auto total_of = [&](const int64_t* off, const unsigned* cnt, int64_t count, int64_t* out) -> int32_t {
-        Collect q;
-        q.n = 2;
-        q.src[0] = off + (count - 1); q.bytes[0] = 8;
-        q.src[1] = cnt + (count - 1); q.bytes[1] = 4;
-        unsigned long long w[8];
-        GSR_TRY(read_back(c, q, w));
-        *out = (int64_t)w[0] + (int64_t)(unsigned)w[1];
-        return GSR_OK;
-    };
     c->sparse_path = false;
     if (P > 0) {
         GSR_TRY(c->prec.reserve(Pm * sizeof(ParentRec)));
@@ -4259,55 +4495,62 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         hipLaunchKernelGGL(k_spans, dim3(ceil_div(P, 16)), dim3(256), 0, st, sa);      // candidates scanned per parent
         GSR_TRY(c->coff.reserve((Pm + 1) * 8));
         GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>(), P));
-        int64_t cand_i = 0;
-        GSR_TRY(total_of(c->coff.as<int64_t>(), c->pcap.as<unsigned>(), P, &cand_i));
-        const unsigned long long cand = (unsigned long long)cand_i;
-        c->stats[4] = (int64_t)cand;
+        // what the pair buffers hold today: an asynchronous level runs on that (k_select clamps every segment to it)
+        cap_pairs = (unsigned long long)(std::min(c->sp_child.cap, c->sp_wl.cap) / 4);
+        if (!spec) {
+            int64_t cand_i = 0;
+            GSR_TRY(total_of(c->coff.as<int64_t>(), c->pcap.as<unsigned>(), P, &cand_i));
+            cand = (unsigned long long)cand_i;
+            c->stats[4] = (int64_t)cand;
+        }
         // processing order: heavy parents first (LPT), the light ones along a Z-order curve
         GSR_TRY(c->porder.reserve(Pm * 4)); GSR_TRY(c->pkeys.reserve(Pm * 4)); GSR_TRY(c->pkeys2.reserve(Pm * 4)); GSR_TRY(c->pidx.reserve(Pm * 4));
         {
-            const unsigned thr = (unsigned)(16.0 * (double)cand / (double)P) + 1u;     // "heavy" = 16x the mean (8x: +0.8 % at 5 M, 32x: +10 % at 200 k)
-            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), thr, c->plist.as<unsigned>(),
+            // "heavy" = 16x the mean capacity: k_heavy_keys takes the total from the scan itself
+            hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), c->coff.as<int64_t>(), c->plist.as<unsigned>(),
                                c->A.as<float4>(), c->gparams.as<GridParams>(), c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
             GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 3 * ORDER_AXIS_BITS + 2));
             if (!c->split_heavy)
-                hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8);
+                hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), cnt + 8);
             sa.porder = c->porder.as<unsigned>();
             sa.xcd = 1;
-            sa.nheavy = c->counters.as<int>() + 8;
-            // work items of the heavy parents: sum(ceil(cap / SEL_PART)) <= cand / SEL_PART + P
+            sa.nheavy = cnt + 8;
+            // work items of the heavy parents: sum(ceil(cap / part)) <= candidates / part + P, part >= 2048 (k_heavy_items chooses it)
             if (c->split_heavy) {
-                // part size: ~4 items per wave slot of the chip, between 2048 and SEL_PART candidates (on a small level one
-                // item of 8192 candidates outlasts the whole light launch)
-                unsigned part = SEL_PART;
-                while (part > 2048u && (unsigned long long)part * 4ull * 7168ull > cand) part >>= 1;
-                sa.part = part;
-                const int max_items = (int)std::min<unsigned long long>(cand / part + (unsigned long long)P + 1ull, 0x7fffffffull);
+                const unsigned long long cand_bound = spec ? cap_pairs : cand;
+                const int max_items = (int)std::min<unsigned long long>(cand_bound / 2048ull + (unsigned long long)P + 1ull, 0x7fffffffull);
                 GSR_TRY(c->hitem.reserve((size_t)max_items * sizeof(uint2))); GSR_TRY(c->hfirst.reserve(Pm * 4));
                 GSR_TRY(c->part_cnt.reserve((size_t)max_items * 4));
                 sa.heavy_blocks = SEL_HEAVY_BLOCKS;
                 sa.hitem = c->hitem.as<uint2>(); sa.hfirst = c->hfirst.as<int>(); sa.part_cnt = c->part_cnt.as<unsigned>();
-                sa.hq = c->counters.as<int>() + 10;
-                hipLaunchKernelGGL(k_heavy_items, dim3(1), dim3(1024), 0, st, P, c->pkeys2.as<unsigned>(), c->counters.as<int>() + 8, sa.porder,
-                                   c->pcap.as<unsigned>(), sa.part, own_lo, own_hi,
+                sa.hq = cnt + 10;
+                hipLaunchKernelGGL(k_heavy_items, dim3(1), dim3(1024), 0, st, P, c->pkeys2.as<unsigned>(), cnt + 8, sa.porder,
+                                   c->pcap.as<unsigned>(), c->coff.as<int64_t>(), reinterpret_cast<unsigned*>(lvl + 2), own_lo, own_hi,
                                    SEL_HEAVY_BLOCKS * WPB, max_items, c->hitem.as<uint2>(), c->hfirst.as<int>(), c->pcnt.as<unsigned>(), sa.hq,
-                                   c->counters.as<int>() + 13);
+                                   cnt + 13);
             }
         }
-        // the budget question needs the driver (hipMemGetInfo: a system call per level) only when the buffers would have to grow
-        const char* sparse_env = getenv("GSR_HEM_SPARSE_GB");
-        bool sparse = cand < (1ull << 40);
-        if (sparse && (sparse_env || (size_t)cand * 4 > c->sp_child.cap || (size_t)cand * 4 > c->sp_wl.cap)) {
-            size_t free_b = 0, total_b = 0;
-            (void)hipMemGetInfo(&free_b, &total_b);
-            size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 20 * 9;      // 45 % of what is free (a 40 M-splat level needs 79 GB)
-            if (sparse_env) budget = (size_t)(atof(sparse_env) * 1073741824.0);
-            sparse = (double)cand * 8.0 <= (double)budget;
+        bool sparse = true;
+        if (!spec) {
+            // the budget question needs the driver (hipMemGetInfo: a system call per level) only when the buffers would have to grow
+            const char* sparse_env = getenv("GSR_HEM_SPARSE_GB");
+            sparse = cand < (1ull << 40);
+            if (sparse && (sparse_env || (size_t)cand * 4 > c->sp_child.cap || (size_t)cand * 4 > c->sp_wl.cap)) {
+                size_t free_b = 0, total_b = 0;
+                (void)hipMemGetInfo(&free_b, &total_b);
+                size_t budget = (free_b + c->sp_child.cap + c->sp_wl.cap) / 20 * 9;      // 45 % of what is free (a 40 M-splat level needs 79 GB)
+                if (sparse_env) budget = (size_t)(atof(sparse_env) * 1073741824.0);
+                sparse = (double)cand * 8.0 <= (double)budget;
+            }
         }
         if (!sh_launched) { GSR_TRY(launch_gather_sh(true)); sh_launched = true; }
         if (sparse) {
-            const size_t Cm = (size_t)(cand > 0 ? cand : 1);
-            GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
+            if (!spec) {
+                const size_t Cm = (size_t)(cand > 0 ? cand : 1);
+                GSR_TRY(c->sp_child.reserve(Cm * 4)); GSR_TRY(c->sp_wl.reserve(Cm * 4));
+                cap_pairs = (unsigned long long)(std::min(c->sp_child.cap, c->sp_wl.cap) / 4);
+            }
+            sa.cap_pairs = cap_pairs;
             sa.poff = c->coff.as<int64_t>(); sa.pair_child = c->sp_child.as<unsigned>(); sa.pair_wl = c->sp_wl.as<float>();
             GSR_TIME1(c->evk[2], st);
             GSR_CHECKPOINT("spans + ordering");
@@ -4320,16 +4563,16 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
             GSR_TIME1(c->evk[1], st);
         }
         GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), P));
-        GSR_TRY(total_of(c->poff.as<int64_t>(), c->pcnt.as<unsigned>(), P, &M));
-        const size_t Mm = (size_t)(M > 0 ? M : 1);
-        if (M > 0) {
+        if (!spec) GSR_TRY(total_of(c->poff.as<int64_t>(), c->pcnt.as<unsigned>(), P, &M));
+        if (spec || M > 0) {
             if (sparse) {
                 // the pairs stay where the selection wrote them (segments of capacity pcap[p] at coff[p]): the partition pass and the
                 // M-step walk the segments.  Only the parts of the split parents are slid together (in place).
                 if (sa.heavy_blocks)
                     hipLaunchKernelGGL(k_join_parts, dim3(1024), blk, 0, st, sa.nheavy, sa.porder, c->coff.as<int64_t>(), sa.hfirst, sa.part_cnt,
-                                       c->pcap.as<unsigned>(), sa.part, c->sp_child.as<unsigned>(), c->sp_wl.as<float>());
+                                       c->pcap.as<unsigned>(), sa.part_p, c->sp_child.as<unsigned>(), c->sp_wl.as<float>());
             } else {
+                const size_t Mm = (size_t)(M > 0 ? M : 1);
                 GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
                 if (sa.heavy_blocks)                         // the queue cursor back behind the statically assigned items
@@ -4341,89 +4584,104 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         }
         c->sparse_path = sparse;
         c->stats_ex[1] = sparse ? 1 : 0;
+    } else if (spec) {
+        return GSR_RETRY_SYNC;                  // (a level without a parent: nothing to speculate about)
     }
 #undef GSR_LAUNCH_SELECT
     c->stats[1] = M;
     GSR_CHECKPOINT("selection");
     GSR_TIME(c->ev[2], st);
+    return GSR_OK;
+}
 
-    // ---- 3. per-child sums of wL (deterministic whatever the order: LDS fixed point, k_bucket_sum) ----------
-    // The pairs of parent p are the run [seg[p], seg[p] + pcnt[p]) of (pc, pw): the sparse segments of the one-pass selection or
-    // the compact CSR of the two-pass fallback.
-    const int64_t* seg = c->sparse_path ? c->coff.as<int64_t>() : c->poff.as<int64_t>();
-    const unsigned* pc = c->sparse_path ? c->sp_child.as<unsigned>() : c->pair_child.as<unsigned>();
-    const float* pw = c->sparse_path ? c->sp_wl.as<float>() : c->pair_wl.as<float>();
-    GSR_TRY(c->cstart.reserve(((size_t)n + 1) * 8)); GSR_TRY(c->sumLw.reserve(n * 4)); GSR_TRY(c->oflag.reserve(n * 4));
-    // children per bucket: SUM_BUCKET on large levels; on small ones fewer, so that the bucket kernel still has ~2 workgroups per CU
-    int bshift = SUM_BUCKET_SHIFT;
-    while (bshift > 6 && (n >> bshift) < 512) --bshift;
-    while (bshift < 13 && (n >> bshift) > 2500) ++bshift;       // very large levels: too many buckets scatter the partition's writes
-    const int nbuckets = (int)((n + (1 << bshift) - 1) >> bshift);
-    const int tile = SUM_TILE;      // (x4 on levels with > 2000 buckets: measured, no gain)
-    const int ntiles = (int)((M + tile - 1) / tile);
-    int* overflow_flag = c->counters.as<int>() + 12;
-    // a compact copy of the pair list: only the exact partition (histogram + scan) and the sort path read one
-    auto compact_pairs = [&]() -> int32_t {
-        if (!c->sparse_path) return GSR_OK;
-        const size_t Mm = (size_t)(M > 0 ? M : 1);
-        GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
-        hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 8)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(), c->poff.as<int64_t>(),
-                           (const int*)nullptr, (const unsigned*)nullptr, c->pcap.as<unsigned>(), SEL_PART, c->sp_child.as<unsigned>(), c->sp_wl.as<float>(),
-                           c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
-        return GSR_OK;
-    };
-    // fixed-capacity partition: bucket regions of `cap` pairs (6x the mean, 8x on small levels), straight from the segments
-    bool fixed_tried = false;
-    auto sums_fixed = [&]() -> int32_t {
+// a compact copy of the pair list: only the exact partition (histogram + scan) and the sort path read one
+int32_t LevelRun::compact_pairs() {
+    if (!c->sparse_path) return GSR_OK;
+    const size_t Mm = (size_t)(M > 0 ? M : 1);
+    GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
+    hipLaunchKernelGGL(k_compact_pairs, dim3(ceil_div(P, 8)), blk, 0, st, P, c->coff.as<int64_t>(), c->pcnt.as<unsigned>(), c->poff.as<int64_t>(),
+                       (const int*)nullptr, (const unsigned*)nullptr, c->pcap.as<unsigned>(), (const unsigned*)nullptr, c->sp_child.as<unsigned>(), c->sp_wl.as<float>(),
+                       c->pair_child.as<unsigned>(), c->pair_wl.as<float>());
+    return GSR_OK;
+}
+// fixed-capacity partition: bucket regions of `cap` pairs (6x the mean, 8x on small levels; an asynchronous level: what the buffers hold),
+// straight from the segments
+int32_t LevelRun::sums_fixed() {
+    unsigned cap;
+    if (spec) {
+        const size_t have = std::min(c->spair_child.cap, c->spair_wl.cap) / 4 / (size_t)nbuckets;
+        if (have < 4096) return GSR_RETRY_SYNC;
+        cap = (unsigned)std::min<size_t>(have, 0xfffff000u);
+    } else {
         const double mean = (double)M / (double)nbuckets;
         double capd = mean * (c->partition_factor > 0.0 ? c->partition_factor : (M < (1 << 24) ? 8.0 : 6.0)) + (c->partition_factor > 0.0 ? 64.0 : 4096.0);
         if (capd > 4.0e9) return GSR_E_INVALID;                  // (not an error: the caller takes the exact path)
-        const unsigned cap = (unsigned)capd;
+        cap = (unsigned)capd;
         GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * 4)); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
-        GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
-        GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
-        (void)hipGetLastError();
-        GSR_TIME(c->evm[2], st);
-        launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
-                         c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
-        GSR_HIP(hipGetLastError());
-        GSR_TIME(c->evm[3], st);
-        GSR_CHECKPOINT("pair partition (fixed capacity)");
-        GSR_TIME(c->evm[4], st);
-        hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, (const unsigned long long*)nullptr, cap,
-                           c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
-                           c->geo.as<float>() + 15);
-        GSR_TIME(c->evm[5], st);
-        GSR_HIP(hipGetLastError());
-        fixed_tried = true;
-        return GSR_OK;
-    };
-    auto sums_exact = [&]() -> int32_t {
-        // histogram + scan + scatter of a compact pair list, then one workgroup per bucket sums in LDS on a fixed-point scale.  The
-        // partition kernels keep per-bucket counters in dynamic LDS (raised above the 64 KiB default in gsr_hem_create)
-        GSR_TRY(compact_pairs());
-        const size_t Mm = (size_t)(M > 0 ? M : 1);
-        GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
-        GSR_TRY(c->bhist.reserve(((size_t)nbuckets + 1) * 4)); GSR_TRY(c->bstart.reserve(((size_t)nbuckets + 1) * 8));
-        GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
-        GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
-        (void)hipGetLastError();
-        hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, tile, c->pair_child.as<unsigned>(), nbuckets, bshift, c->bhist.as<unsigned>());
-        GSR_HIP(hipGetLastError());
-        GSR_TRY(widen_scan(c->bhist.as<unsigned>(), (int64_t*)c->bstart.p, nbuckets + 1));
-        GSR_HIP(hipMemcpyAsync(c->bcursor.p, c->bstart.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, tile, c->pair_child.as<unsigned>(),
-                           c->pair_wl.as<float>(), nbuckets, bshift, c->bstart.as<unsigned long long>(), c->bcursor.as<unsigned long long>(),
-                           c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
-        GSR_HIP(hipGetLastError());
-        GSR_CHECKPOINT("pair partition");
-        hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, c->bstart.as<unsigned long long>(), 0u,
-                           (const unsigned*)nullptr, c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
-                           c->geo.as<float>() + 15);
-        GSR_HIP(hipGetLastError());
-        return GSR_OK;
-    };
-    if (part) {
+    }
+    GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
+    GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
+    (void)hipGetLastError();
+    GSR_TIME(c->evm[2], st);
+    launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
+                     c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
+    GSR_HIP(hipGetLastError());
+    GSR_TIME(c->evm[3], st);
+    GSR_CHECKPOINT("pair partition (fixed capacity)");
+    GSR_TIME(c->evm[4], st);
+    hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, (const unsigned long long*)nullptr, cap,
+                       c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
+                       c->geo.as<float>() + 15);
+    GSR_TIME(c->evm[5], st);
+    GSR_HIP(hipGetLastError());
+    fixed_tried = true;
+    return GSR_OK;
+}
+int32_t LevelRun::sums_exact() {
+    // histogram + scan + scatter of a compact pair list, then one workgroup per bucket sums in LDS on a fixed-point scale.  The
+    // partition kernels keep per-bucket counters in dynamic LDS (raised above the 64 KiB default in gsr_hem_create)
+    const int tile = SUM_TILE;      // (x4 on levels with > 2000 buckets: measured, no gain)
+    const int ntiles = (int)((M + tile - 1) / tile);
+    GSR_TRY(compact_pairs());
+    const size_t Mm = (size_t)(M > 0 ? M : 1);
+    GSR_TRY(c->spair_child.reserve(Mm * 4)); GSR_TRY(c->spair_wl.reserve(Mm * 4));
+    GSR_TRY(c->bhist.reserve(((size_t)nbuckets + 1) * 4)); GSR_TRY(c->bstart.reserve(((size_t)nbuckets + 1) * 8));
+    GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
+    GSR_HIP(hipMemsetAsync(c->bhist.p, 0, ((size_t)nbuckets + 1) * 4, st));
+    (void)hipGetLastError();
+    hipLaunchKernelGGL(k_bucket_hist, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, tile, c->pair_child.as<unsigned>(), nbuckets, bshift, c->bhist.as<unsigned>());
+    GSR_HIP(hipGetLastError());
+    GSR_TRY(widen_scan(c->bhist.as<unsigned>(), (int64_t*)c->bstart.p, nbuckets + 1));
+    GSR_HIP(hipMemcpyAsync(c->bcursor.p, c->bstart.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, tile, c->pair_child.as<unsigned>(),
+                       c->pair_wl.as<float>(), nbuckets, bshift, c->bstart.as<unsigned long long>(), c->bcursor.as<unsigned long long>(),
+                       c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
+    GSR_HIP(hipGetLastError());
+    GSR_CHECKPOINT("pair partition");
+    hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, c->bstart.as<unsigned long long>(), 0u,
+                       (const unsigned*)nullptr, c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
+                       c->geo.as<float>() + 15);
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
+// ---- 3. per-child sums of wL (deterministic whatever the order: LDS fixed point, k_bucket_sum) ----------
+// The pairs of parent p are the run [seg[p], seg[p] + pcnt[p]) of (pc, pw): the sparse segments of the one-pass selection or
+// the compact CSR of the two-pass fallback.
+int32_t LevelRun::sums_phase() {
+    seg = c->sparse_path ? c->coff.as<int64_t>() : c->poff.as<int64_t>();
+    pc = c->sparse_path ? c->sp_child.as<unsigned>() : c->pair_child.as<unsigned>();
+    pw = c->sparse_path ? c->sp_wl.as<float>() : c->pair_wl.as<float>();
+    GSR_TRY(c->cstart.reserve(((size_t)n + 1) * 8)); GSR_TRY(c->sumLw.reserve(n * 4)); GSR_TRY(c->oflag.reserve(n * 4));
+    // children per bucket: SUM_BUCKET on large levels; on small ones fewer, so that the bucket kernel still has ~2 workgroups per CU
+    bshift = SUM_BUCKET_SHIFT;
+    while (bshift > 6 && (n >> bshift) < 512) --bshift;
+    while (bshift < 13 && (n >> bshift) > 2500) ++bshift;       // very large levels: too many buckets scatter the partition's writes
+    nbuckets = (int)((n + (1 << bshift) - 1) >> bshift);
+    if (spec) {
+        if (nbuckets > SUM_MAX_BUCKETS) return GSR_RETRY_SYNC;
+        GSR_TRY(sums_fixed());
+    } else if (part) {
         GSR_TRY(pl.sums(n, P, M, seg, pc, pw, nbuckets, bshift, overflow_flag));
     } else if (c->sum_bucket && M > 0 && nbuckets <= SUM_MAX_BUCKETS) {
         if (c->partition_fixed && !c->partition_overflowed) {
@@ -4456,8 +4714,11 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     }
     GSR_CHECKPOINT("per-child sums");
     GSR_TIME(c->ev[3], st);
+    return GSR_OK;
+}
 
-    // ---- 4. output ranks in input order; M-step; orphans -----------------------------------------
+// ---- 4a. output ranks in input order: the orphans' flags back to input order, their scan, the level's row count ----------
+int32_t LevelRun::output_ranks() {
     GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
     GSR_TRY(c->oslot.reserve(n * 8));               // (n includes the ghosts of a partitioned level here)
     int o_last = 0, o_flag = 0;
@@ -4470,11 +4731,12 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         }
         hipLaunchKernelGGL(k_orphans_to_input_order, grd, blk, 0, st, n, c->order.as<unsigned>(), c->oflag.as<int>(), c->oflag_in.as<int>());
         GSR_TRY(exclusive_scan<int>(c, c->oflag_in.as<int>(), c->orank_in.as<int>(), n));
+        if (spec) return GSR_OK;                    // (the counts stay on the device: k_level_tail, once the output's capacity is known)
         Collect q;
         q.n = 6;
         q.src[0] = c->orank_in.as<int>() + (n - 1); q.src[1] = c->oflag_in.as<int>() + (n - 1); q.src[2] = overflow_flag;
-        q.src[3] = c->counters.as<int>() + 13;
-        q.src[4] = c->counters.as<int>() + 8; q.src[5] = c->counters.as<int>() + 10;      // heavy parents, their work items (statistics)
+        q.src[3] = cnt + 13;
+        q.src[4] = cnt + 8; q.src[5] = cnt + 10;      // heavy parents, their work items (statistics)
         for (int i = 0; i < 6; ++i) q.bytes[i] = 4;
         unsigned long long w[8];
         GSR_TRY(read_back(c, q, w));
@@ -4490,37 +4752,50 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(sums_exact());
         if (sharded) return fail(GSR_E_INVALID, "gsr_hem_run_level: bucket overflow on a sharded level");     // (sharded levels use the exact partition)
     }
-    const int64_t n_orph = (int64_t)o_last + o_flag;
+    n_orph = (int64_t)o_last + o_flag;
     c->stats[2] = n_orph;
-    const int64_t n_pre = (int64_t)P + n_orph;
+    n_pre = (int64_t)P + n_orph;
+    return GSR_OK;
+}
 
-    Level& O = c->nxt;
-    // gsr_hem_set_output: the new level goes straight into the caller's arrays (no copy out afterwards, none into the next level)
-    struct OutGuard {               // an error return below hands nxt its own buffers back
-        gsr_hem_ctx* c; bool active;
-        ~OutGuard() { if (active) for (int i = 0; i < 5; ++i) { DevBuf* b = level_big(c->nxt, i); b->p = nullptr; b->cap = 0; b->swap(c->spare_out[i]); } }
-    } out_guard{c, false};
+// ---- 4b. where the new level goes: the context's own arrays or the caller's (gsr_hem_set_output) ----------
+int32_t LevelRun::open_output() {
+    // rows the arrays must hold: n_pre -- or, for an asynchronous level, which does not know n_pre yet, the size of the level being reduced
+    // (parents + orphans exceed it only when parents are orphans too: k_level_tail checks, the level then reruns)
+    const int64_t need = spec ? n : n_pre;
     if (c->out_pending) {
         c->out_pending = false;                                 // one request, one level
-        if (n_pre > c->out_rows) return fail(GSR_E_INVALID, "gsr_hem_run_level: the output arrays hold %lld rows, the level has %lld", (long long)c->out_rows, (long long)n_pre);
+        if (spec && P > c->out_rows) return GSR_RETRY_SYNC;     // (the synchronous level reports it)
+        if (!spec && n_pre > c->out_rows) return fail(GSR_E_INVALID, "gsr_hem_run_level: the output arrays hold %lld rows, the level has %lld", (long long)c->out_rows, (long long)n_pre);
         if (F > 0 && !c->out_ptr[4]) return fail(GSR_E_INVALID, "gsr_hem_run_level: the output has no SH array but the level has F = %d", F);
-        if (n_pre > 0) {
+        if (need > 0) {
             for (int i = 0; i < 5; ++i) {
                 DevBuf* b = level_big(O, i);
                 b->swap(c->spare_out[i]);
                 b->p = c->out_ptr[i] ? c->out_ptr[i] : c->out_ptr[0]; b->cap = (size_t)-1;       // reserve() on them is a no-op
             }
-            out_guard.active = true;
+            out_active = true;
         }
     }
-    GSR_TRY(O.reserve(n_pre, F));
-    O.n = n_pre; O.F = F;
+    GSR_TRY(O.reserve(need, F));
+    out_cap = out_active ? std::min<int64_t>(c->out_rows, n + (int64_t)P) : need;     // (parents + orphans <= n + P)
+    O.n = spec ? 0 : n_pre; O.F = F;
+    if (spec)
+        hipLaunchKernelGGL(k_level_tail, dim3(1), dim3(1), 0, st, n, P, c->orank_in.as<int>(), c->oflag_in.as<int>(), (long long)out_cap, lvl, cnt + 2);
+    return GSR_OK;
+}
+
+// ---- 4c. M-step; orphans -----------------------------------------
+int32_t LevelRun::mstep_phase() {
+    const long long* n_pre_dev = spec ? lvl : nullptr;
     // the new level's parent flags depend on nothing but the stream position and n_pre: drawn on the second stream beside the
     // M-step (the jump to the stream position is a fixed ~40 us chain, 5 % of a 200 k-splat level)
-    bool flags_forked = false;
-    if (!part && c->aux && n_pre > 0) {
+    rng_pos0 = c->rng_pos;
+    const int64_t n_draw = spec ? out_cap : n_pre;
+    if (!part && c->aux && n_draw > 0) {
         GSR_HIP(hipEventRecord(c->ev_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0));
-        GSR_TRY(draw_flags_raw(c, n_pre, O.is_parent.as<uint8_t>(), c->aux));
+        GSR_TRY(O.is_parent.reserve((size_t)n_draw));
+        GSR_TRY(draw_flags_raw(c, n_draw, O.is_parent.as<uint8_t>(), c->aux, n_pre_dev));
         GSR_HIP(hipEventRecord(c->ev_join, c->aux));
         flags_forked = true;
     }
@@ -4535,21 +4810,23 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         ma.small = c->mstep_small ? 1 : 0;
         // processing order: the selection's (heavy parents by candidates scanned first, then Z-order) -- parents with many
         // candidates are the ones with many pairs.  The per-parent headers are laid out in that order.
-        const unsigned* mporder = M > 0 ? c->porder.as<unsigned>() : nullptr;
+        const unsigned* mporder = (spec || M > 0) ? c->porder.as<unsigned>() : nullptr;
         ma.xcd = mporder ? 1 : 0;
-        ma.nheavy = mporder ? c->counters.as<int>() + 8 : nullptr;
+        ma.nheavy = mporder ? cnt + 8 : nullptr;
         GSR_TRY(c->mhdr.reserve(Pm * sizeof(MstepHeader)));
-        // heavy parents (more than MSTEP_SEG pairs): their segments are work items of a second launch (mstep_segment)
-        const bool msplit = M > MSTEP_SEG;                        // (a parent of more than MSTEP_SEG pairs can exist)
+        // heavy parents (more than MSTEP_SEG pairs): their segments are work items of a second launch (mstep_segment).  An asynchronous
+        // level does not know whether there is one: the launch is always made (beside k_mstep, on the second stream) and finds its list empty
+        const bool msplit = spec || M > MSTEP_SEG;              // (a parent of more than MSTEP_SEG pairs can exist)
         if (msplit) {
-            const size_t cap_heavy = (size_t)(M / MSTEP_SEG) + 2, cap_items = 2 * (size_t)(M / MSTEP_SEG) + 4;
+            const size_t Mb = (size_t)(spec ? cap_pairs : (unsigned long long)M);      // pairs <= candidates <= what the buffers hold
+            const size_t cap_heavy = Mb / MSTEP_SEG + 2, cap_items = 2 * (Mb / MSTEP_SEG) + 4;
             GSR_TRY(c->mh_list.reserve(cap_heavy * sizeof(uint4))); GSR_TRY(c->mh_items.reserve(cap_items * sizeof(uint2)));
             GSR_TRY(c->mh_scratch.reserve(cap_items * (size_t)(16 + RSH) * 4));
         }
-        unsigned* hcount = c->counters.as<unsigned>();           // [0] heavy parents, [1] their segments (cleared with the level's counters)
+        unsigned* hcount = (unsigned*)cnt;                       // [0] heavy parents, [1] their segments (cleared with the level's counters)
         hipLaunchKernelGGL(k_mstep_headers, dim3(stride_grid(P)), blk, 0, st, P, mporder, c->plist.as<unsigned>(), seg,
                            c->pcnt.as<unsigned>(), c->order.as<unsigned>(), c->prank_in.as<int>(), c->A.as<float4>(), own_lo, own_hi,
-                           c->mhdr.as<MstepHeader>(), c->counters.as<unsigned>() + 15, (unsigned)MSTEP_SEG, msplit ? hcount : (unsigned*)nullptr,
+                           c->mhdr.as<MstepHeader>(), (unsigned*)cnt + 15, (unsigned)MSTEP_SEG, msplit ? hcount : (unsigned*)nullptr,
                            c->mh_list.as<uint4>(), c->mh_items.as<uint2>());
         ma.hdr = c->mhdr.as<MstepHeader>();
         ma.split = c->mstep_split ? 1 : 0;
@@ -4591,18 +4868,21 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         if (msplit && hst != st) GSR_HIP(hipStreamWaitEvent(st, c->ev_mjoin, 0));
         GSR_TIME1(c->evm[1], st);
     }
-    // many orphans on one GPU: their SH rows are copied over the list of the orphans (k_orphans_sh_list)
-    const bool orphan_list = F > 0 && n_orph * 64 > n && !part && !sharded && c->orphan_list;
-    if (orphan_list) GSR_TRY(c->olist.reserve((size_t)n_orph * 4));
+    // many orphans on one GPU: their SH rows are copied over the list of the orphans (k_orphans_sh_list); an asynchronous level always
+    // takes the list (the kernel reads the orphans' number on the device)
+    const bool orphan_list = F > 0 && !part && !sharded && c->orphan_list && (spec || n_orph * 64 > n);
+    if (orphan_list) GSR_TRY(c->olist.reserve((size_t)(spec ? n : n_orph) * 4));
     hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
                        c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
                        O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>(),
-                       orphan_list ? c->olist.as<unsigned>() : (unsigned*)nullptr);
-    if (F > 0 && n_orph > 0) {
-        if (orphan_list)
-            hipLaunchKernelGGL(k_orphans_sh_list, dim3(stride_grid(n_orph * (RSH >> 2))), blk, 0, st, n_orph, (int64_t)P, F, RSH, c->olist.as<unsigned>(),
-                               c->shs.as<float>(), O.sh.as<float>());
-        else if (n_orph * 64 > n)
+                       orphan_list ? c->olist.as<unsigned>() : (unsigned*)nullptr, (int64_t)(spec ? out_cap : n_pre));
+    if (F > 0 && (spec || n_orph > 0)) {
+        if (orphan_list) {
+            // (an asynchronous level: the grid for a quarter of the level being orphans at most; the kernel strides)
+            const int64_t nb = spec ? std::max<int64_t>(n / 4, 1) : n_orph;
+            hipLaunchKernelGGL(k_orphans_sh_list, dim3(stride_grid(nb * (RSH >> 2))), blk, 0, st, n_orph, (int64_t)P, F, RSH, c->olist.as<unsigned>(),
+                               c->shs.as<float>(), O.sh.as<float>(), spec ? lvl + 1 : (const long long*)nullptr, (int64_t)(spec ? out_cap : n_pre));
+        } else if (n_orph * 64 > n)
             hipLaunchKernelGGL(k_orphans_sh_wide, dim3(stride_grid(n * (RSH >> 2))), blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
         else
             hipLaunchKernelGGL(k_orphans_sh, grd, blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
@@ -4632,13 +4912,44 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
                                    O.color.as<float>(), O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>());
         }
     }
-    int64_t P_glob = P, O_glob = n_orph;
+    P_glob = P; O_glob = n_orph;
     if (part) GSR_TRY(pl.global_ranks(P, n_pre, P_glob, O_glob));
-    const int64_t n_pre_glob = P_glob + O_glob;
+    n_pre_glob = P_glob + O_glob;
     GSR_CHECKPOINT("M-step + orphans");
     GSR_TIME(c->ev[4], st);
+    return GSR_OK;
+}
 
-    // ---- 5. new parent flags (one draw per component, before the erase), validity erase ---------
+// the validity erase of a level that drops rows (mixture.cpp:262-282): the surviving rows of every array move up, in order
+int32_t LevelRun::compact_erased(int64_t n_keep) {
+    Level& T = c->tmp;
+    const dim3 g2(stride_grid(n_pre));
+    GSR_TRY(T.reserve(n_keep, F));
+    T.n = n_keep; T.F = F;
+    const int* keep = c->keep.as<int>();
+    const int* pos = c->kpos.as<int>();
+    hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 3)), blk, 0, st, n_pre, 3, keep, pos, O.xyz.as<float>(), T.xyz.as<float>());
+    hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 3)), blk, 0, st, n_pre, 3, keep, pos, O.color.as<float>(), T.color.as<float>());
+    hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 6)), blk, 0, st, n_pre, 6, keep, pos, O.cov6.as<float>(), T.cov6.as<float>());
+    hipLaunchKernelGGL(k_compact_rows, g2, blk, 0, st, n_pre, 1, keep, pos, O.opacity.as<float>(), T.opacity.as<float>());
+    hipLaunchKernelGGL(k_compact_rows, g2, blk, 0, st, n_pre, 1, keep, pos, O.weight.as<float>(), T.weight.as<float>());
+    if (F > 0)
+        hipLaunchKernelGGL(k_compact_rows4, dim3(stride_grid(n_pre * ((F + 3) / 4))), blk, 0, st, n_pre, F, keep, pos, O.sh.as<float>(), T.sh.as<float>());
+    hipLaunchKernelGGL(k_compact_bytes, g2, blk, 0, st, n_pre, keep, pos, O.is_parent.as<uint8_t>(), T.is_parent.as<uint8_t>());
+    if (out_active) {     // the caller's arrays stay the level's home: the compacted rows are copied back into them
+        const size_t row_bytes[5] = {12, 12, 24, 4, (size_t)F * 4};
+        for (int i = 0; i < 5; ++i)
+            if (row_bytes[i] > 0 && n_keep > 0)
+                GSR_HIP(hipMemcpyAsync(level_big(O, i)->p, level_big(T, i)->p, (size_t)n_keep * row_bytes[i], hipMemcpyDeviceToDevice, st));
+        O.weight.swap(T.weight); O.is_parent.swap(T.is_parent);
+        O.n = n_keep;
+    } else
+        O.swap(T);
+    return GSR_OK;
+}
+
+// ---- 5. new parent flags (one draw per component, before the erase), validity erase (synchronous schedule) ---------
+int32_t LevelRun::flags_and_validity() {
     if (part) {     // the libc stream is drawn for the GLOBAL level; a row takes the flag at its global rank
         GSR_TRY(c->allflags.reserve((size_t)(n_pre_glob > 0 ? n_pre_glob : 1)));
         GSR_TRY(draw_flags_raw(c, n_pre_glob, c->allflags.as<uint8_t>()));
@@ -4649,17 +4960,17 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
     } else {
         GSR_TRY(draw_flags(c, O));
     }
-    int64_t dropped = 0;
+    dropped = 0;
     if (n_pre > 0) {
         GSR_TRY(c->keep.reserve(n_pre * 4)); GSR_TRY(c->kpos.reserve(n_pre * 4));
         const dim3 g2(stride_grid(n_pre));
-        hipLaunchKernelGGL(k_valid, g2, blk, 0, st, n_pre, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>());
+        hipLaunchKernelGGL(k_valid, g2, blk, 0, st, n_pre, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>(), (const long long*)nullptr, (int*)nullptr);
         GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
         int k_last = 0, k_flag = 0;
         {
             Collect q;
             q.n = 3;
-            q.src[0] = c->kpos.as<int>() + (n_pre - 1); q.src[1] = c->keep.as<int>() + (n_pre - 1); q.src[2] = c->counters.as<int>() + 15;
+            q.src[0] = c->kpos.as<int>() + (n_pre - 1); q.src[1] = c->keep.as<int>() + (n_pre - 1); q.src[2] = cnt + 15;
             q.bytes[0] = q.bytes[1] = q.bytes[2] = 4;
             unsigned long long w[8];
             GSR_TRY(read_back(c, q, w));
@@ -4668,69 +4979,154 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         }
         const int64_t n_keep = (int64_t)k_last + k_flag;
         dropped = n_pre - n_keep;
-        if (dropped > 0) {
-            Level& T = c->tmp;
-            GSR_TRY(T.reserve(n_keep, F));
-            T.n = n_keep; T.F = F;
-            const int* keep = c->keep.as<int>();
-            const int* pos = c->kpos.as<int>();
-            hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 3)), blk, 0, st, n_pre, 3, keep, pos, O.xyz.as<float>(), T.xyz.as<float>());
-            hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 3)), blk, 0, st, n_pre, 3, keep, pos, O.color.as<float>(), T.color.as<float>());
-            hipLaunchKernelGGL(k_compact_rows, dim3(stride_grid(n_pre * 6)), blk, 0, st, n_pre, 6, keep, pos, O.cov6.as<float>(), T.cov6.as<float>());
-            hipLaunchKernelGGL(k_compact_rows, g2, blk, 0, st, n_pre, 1, keep, pos, O.opacity.as<float>(), T.opacity.as<float>());
-            hipLaunchKernelGGL(k_compact_rows, g2, blk, 0, st, n_pre, 1, keep, pos, O.weight.as<float>(), T.weight.as<float>());
-            if (F > 0)
-                hipLaunchKernelGGL(k_compact_rows4, dim3(stride_grid(n_pre * ((F + 3) / 4))), blk, 0, st, n_pre, F, keep, pos, O.sh.as<float>(), T.sh.as<float>());
-            hipLaunchKernelGGL(k_compact_bytes, g2, blk, 0, st, n_pre, keep, pos, O.is_parent.as<uint8_t>(), T.is_parent.as<uint8_t>());
-            if (out_guard.active) {     // the caller's arrays stay the level's home: the compacted rows are copied back into them
-                const size_t row_bytes[5] = {12, 12, 24, 4, (size_t)F * 4};
-                for (int i = 0; i < 5; ++i)
-                    if (row_bytes[i] > 0 && n_keep > 0)
-                        GSR_HIP(hipMemcpyAsync(level_big(O, i)->p, level_big(T, i)->p, (size_t)n_keep * row_bytes[i], hipMemcpyDeviceToDevice, st));
-                O.weight.swap(T.weight); O.is_parent.swap(T.is_parent);
-                O.n = n_keep;
-            } else
-            O.swap(T);
-        }
+        if (dropped > 0) GSR_TRY(compact_erased(n_keep));
     }
-    int64_t n_glob_next = n_pre_glob;
+    n_glob_next = n_pre_glob;
     if (part) GSR_TRY(pl.drop_erased(O, n_pre, n_pre_glob, dropped, n_glob_next));
     GSR_CHECKPOINT("flags + validity");
-    GSR_TIME1(c->ev[5], st);
-    GSR_HIP(hipStreamSynchronize(st));
+    return GSR_OK;
+}
+
+int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
+    memset(c->stats, 0, sizeof(c->stats));
+    memset(c->stats_ex, 0, sizeof(c->stats_ex));
+    memset(c->part_stats, 0, sizeof(c->part_stats));
+    c->stats[6] = n;
+    if (part) {
+        pl.W = gsr_comm_world(c->comm); pl.me = gsr_comm_rank(c->comm);
+        if (pl.W > 8) return fail(GSR_E_INVALID, "gsr_hem_run_level: more than 8 ranks");
+    }
+    if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld components (the candidate records carry the sorted position in 30 bits)", (long long)n);
+    if (part && c->shard_world > 1) return fail(GSR_E_INVALID, "gsr_hem_run_level: spatial partition and work sharding are exclusive");
+    if (part) GSR_TRY(pl.agree_on_preconditions(n));
+    if (n == 0) {
+        if (n_out) *n_out = 0;
+        if (n_dropped) *n_dropped = 0;
+        return GSR_OK;
+    }
+    // An asynchronous level: one GPU, the default path of every stage, and buffers to run on (a fresh context's first level sizes them the
+    // synchronous way).  What it cannot know beforehand it checks on the device (GSR_RETRY_SYNC).
+    spec = spec && !part && !sharded && !dbg_sync && c->sum_bucket && c->partition_fixed && !c->partition_overflowed && c->partition_factor == 0.0 &&
+           c->split_heavy && c->orphan_list && getenv("GSR_HEM_SPARSE_GB") == nullptr && c->aux != nullptr &&
+           std::min(c->sp_child.cap, c->sp_wl.cap) >= (size_t)4096 && std::min(c->spair_child.cap, c->spair_wl.cap) >= (size_t)4096;
+    grd = dim3(stride_grid(n));
+    GSR_TIME1(c->ev[0], st);
+    GSR_TRY(grid_phase());
+    GSR_TRY(select_phase());
+    GSR_TRY(sums_phase());
+    GSR_TRY(output_ranks());
+    GSR_TRY(open_output());
+    GSR_TRY(mstep_phase());
+
+    unsigned long long w[LC_WORDS];
+    bool have_next = false;             // w holds the next level's prologue
+    const int cb_next = c->cblock ^ 1;
+    LevelCollect q;
+    memset(&q, 0, sizeof(q));
+    q.cnt = cnt; q.gp = c->gparams.as<GridParams>(); q.bbox = c->bbox.as<unsigned>();
+    if (P > 0) { q.coff = c->coff.as<int64_t>(); q.pcap = c->pcap.as<unsigned>(); q.poff = c->poff.as<int64_t>(); q.pcnt = c->pcnt.as<unsigned>(); q.P = P; }
+    if (spec) {
+        // ---- 5 (asynchronous). flags joined, validity counted, the NEXT level's prologue on the rows as they are, ONE answer ----------
+        if (flags_forked) GSR_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
+        GSR_TRY(c->keep.reserve((size_t)out_cap * 4)); GSR_TRY(c->kpos.reserve((size_t)out_cap * 4));
+        hipLaunchKernelGGL(k_valid, dim3(stride_grid(out_cap)), blk, 0, st, out_cap, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>(), (const long long*)lvl, cnt + 3);
+        GSR_TIME1(c->ev[5], st);
+        GSR_TRY(enqueue_prologue(c, O, out_cap, lvl, cb_next));
+        q.lvl = lvl;
+        GSR_TRY(read_back_level(c, q, w));
+        if (w[LC_FLAGS] != 0ull) return GSR_RETRY_SYNC;        // a clamped segment, a full bucket region or item table, an output too small
+        cand = w[LC_CAND]; M = (int64_t)w[LC_PAIRS]; n_orph = (int64_t)w[LC_ORPHANS]; n_pre = (int64_t)w[LC_NPRE];
+        c->stats[4] = (int64_t)cand; c->stats[1] = M; c->stats[2] = n_orph;
+        c->stats_ex[3] = (int64_t)w[LC_HEAVY]; c->stats_ex[4] = (int64_t)w[LC_ITEMS]; c->stats_ex[5] = (int64_t)w[LC_MAXPAIRS];
+        c->rng_pos = rng_pos0 + (uint64_t)n_pre;                // one draw per row of the new level (the launch covered a bound)
+        O.n = n_pre;
+        P_glob = P; O_glob = n_orph; n_pre_glob = n_pre; n_glob_next = n_pre;
+        dropped = (int64_t)w[LC_DROPPED];
+        have_next = dropped == 0;
+        if (dropped > 0) {              // rows to erase: the host finishes the level (scan + compaction), and the prologue is taken again
+            GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
+            GSR_TRY(compact_erased(n_pre - dropped));
+        }
+    } else {
+        GSR_TRY(flags_and_validity());
+        GSR_TIME1(c->ev[5], st);
+    }
+    // the next level's prologue with this level's last round trip (one GPU); a partitioned / sharded level just waits for the stream
+    if (!part && !sharded && !have_next && O.n > 0) {
+        GSR_TRY(enqueue_prologue(c, O, O.n, nullptr, cb_next));
+        GSR_TRY(read_back_level(c, q, w));
+        have_next = true;
+    } else if (!have_next) {
+        GSR_HIP(hipStreamSynchronize(st));
+    }
     unborrow_level0(c);                 // a borrowed level 0 goes back to the caller; cur gets its own buffers again
     c->cur.swap(c->nxt);
-    if (out_guard.active) {             // the new current level lives in the caller's arrays: borrowed, its own buffers parked in spare
-        out_guard.active = false;
+    if (out_active) {                   // the new current level lives in the caller's arrays: borrowed, its own buffers parked in spare
+        out_active = false;
         for (int i = 0; i < 5; ++i) c->spare[i].swap(c->spare_out[i]);
         c->cur_borrowed = true;
     }
+    if (have_next && c->cur.n > 0) take_prologue(c, w, c->cur.n, cb_next); else c->pro.valid = false;
     if (part) { c->gid.swap(c->gid_next); c->n_global = n_glob_next; }
     c->stats[3] = dropped;
     c->stats[7] = c->cur.n;
+    c->stats_ex[6] = c->round_trips;
+    c->stats_ex[7] = spec ? 1 : 0;
     memset(c->phase_ms, 0, sizeof(c->phase_ms));
     memset(c->part_ms, 0, sizeof(c->part_ms));
     memset(c->kernel_ms, 0, sizeof(c->kernel_ms));
     if (c->timing >= 1) {
-    if (c->timing >= 2) for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
-    (void)hipEventElapsedTime(&c->phase_ms[5], c->ev[0], c->ev[5]);
-    c->phase_ms[6] = c->phase_ms[7] = 0.0f;
-    if (P > 0 && !c->sparse_path) (void)hipEventElapsedTime(&c->phase_ms[6], c->evk[0], c->evk[1]);
-    if (P > 0 && (M > 0 || c->sparse_path)) (void)hipEventElapsedTime(&c->phase_ms[7], c->evk[2], c->evk[3]);
-    if (part && c->timing >= 2) {
-        (void)hipEventElapsedTime(&c->part_ms[0], c->evp[0], c->evp[1]);
-        if (F > 0) { GSR_HIP(hipStreamSynchronize(c->aux2)); (void)hipEventElapsedTime(&c->part_ms[1], c->evp[2], c->evp[3]); }
-    }
-    c->kernel_ms[0] = c->phase_ms[7];
-    if (P > 0) (void)hipEventElapsedTime(&c->kernel_ms[1], c->evm[0], c->evm[1]);
-    if (c->timing >= 2 && fixed_tried && !c->partition_overflowed) {
-        (void)hipEventElapsedTime(&c->kernel_ms[2], c->evm[2], c->evm[3]);
-        (void)hipEventElapsedTime(&c->kernel_ms[3], c->evm[4], c->evm[5]);
-    }
+        if (c->timing >= 2) for (int i = 0; i < 5; ++i) (void)hipEventElapsedTime(&c->phase_ms[i], c->ev[i], c->ev[i + 1]);
+        (void)hipEventElapsedTime(&c->phase_ms[5], c->ev[0], c->ev[5]);
+        c->phase_ms[5] += pro_ms;           // the level's time includes its prologue, wherever that ran
+        if (c->timing >= 2) c->phase_ms[0] += pro_ms;
+        c->phase_ms[6] = c->phase_ms[7] = 0.0f;
+        if (P > 0 && !c->sparse_path) (void)hipEventElapsedTime(&c->phase_ms[6], c->evk[0], c->evk[1]);
+        if (P > 0 && (M > 0 || c->sparse_path)) (void)hipEventElapsedTime(&c->phase_ms[7], c->evk[2], c->evk[3]);
+        if (part && c->timing >= 2) {
+            (void)hipEventElapsedTime(&c->part_ms[0], c->evp[0], c->evp[1]);
+            if (F > 0) { GSR_HIP(hipStreamSynchronize(c->aux2)); (void)hipEventElapsedTime(&c->part_ms[1], c->evp[2], c->evp[3]); }
+        }
+        c->kernel_ms[0] = c->phase_ms[7];
+        if (P > 0) (void)hipEventElapsedTime(&c->kernel_ms[1], c->evm[0], c->evm[1]);
+        if (c->timing >= 2 && fixed_tried && !c->partition_overflowed) {
+            (void)hipEventElapsedTime(&c->kernel_ms[2], c->evm[2], c->evm[3]);
+            (void)hipEventElapsedTime(&c->kernel_ms[3], c->evm[4], c->evm[5]);
+        }
     }
     if (n_out) *n_out = c->cur.n;
     if (n_dropped) *n_dropped = dropped;
     return GSR_OK;
+}
+
+}  // namespace
+
+int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
+    if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_run_level: no level set");
+    GSR_HIP(hipSetDevice(c->device));
+    c->round_trips = 0;
+    const uint64_t rng_pos0 = c->rng_pos;
+    const bool out0 = c->out_pending;
+    int32_t r;
+    {
+        LevelRun run(c, c->async_ok);
+        r = run.run(n_out, n_dropped);
+    }                                   // (its destructor hands nxt its own buffers back)
+    if (r == GSR_RETRY_SYNC) {
+        // The asynchronous level ran on buffers that turned out too small (or met another case it leaves to the synchronous schedule).
+        // Its input is untouched: the stream is drained, the stream position and the output request are put back, and the level runs again
+        // with every buffer sized from the counts -- the context keeps those sizes, the next level of this size is asynchronous again.
+        GSR_HIP(hipStreamSynchronize(c->stream));
+        if (c->aux) GSR_HIP(hipStreamSynchronize(c->aux));
+        if (c->aux2) GSR_HIP(hipStreamSynchronize(c->aux2));
+        c->rng_pos = rng_pos0;
+        c->out_pending = out0;
+        c->pro.valid = false;
+        LevelRun run(c, false);
+        r = run.run(n_out, n_dropped);
+        c->stats_ex[7] = 2;             // (statistic: an asynchronous attempt was rerun)
+    }
+    return r;
 }
 
 #ifdef GSR_SELECT_PROFILE

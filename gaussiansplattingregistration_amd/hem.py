@@ -305,7 +305,10 @@ class HemMixture:
         _lib.check(self._L.gsr_hem_get_stats_ex(self._h, x), "gsr_hem_get_stats_ex")
         km = (C.c_float * 8)()
         _lib.check(self._L.gsr_hem_get_kernel_ms(self._h, km), "gsr_hem_get_kernel_ms")
+        # round_trips: host round trips of the level (1 = asynchronous: one answer behind the level's last kernel; a synchronous level takes
+        # four to six); schedule: 0 synchronous, 1 asynchronous, 2 an asynchronous attempt whose buffers were too small, rerun synchronously
         return {"irregular": x[0], "one_pass": x[1], "partition_overflow": x[2], "heavy_parents": x[3], "heavy_work_items": x[4], "max_pairs_of_a_parent": x[5],
+                "round_trips": x[6], "schedule": x[7],
                 "ms_k_select": km[0], "ms_k_mstep": km[1], "ms_k_partition": km[2], "ms_k_bucket_sum": km[3],
                 "parents": s[0], "pairs": s[1], "orphans": s[2], "dropped": s[3], "candidates": s[4], "cells": s[5],
                 "n_in": s[6], "n_out": s[7], "ms_grid": t[0], "ms_select": t[1], "ms_sumlw": t[2], "ms_mstep": t[3],

@@ -316,6 +316,70 @@ def test_parents_per_selection_wave_change_nothing(monkeypatch, shape):
                 assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (np_, budget, k, f)
 
 
+def _levels_on_one_context(m, c, levels, zero_copy):
+    out, stats = [], []
+    m.set_rng("glibc", 1, 0)
+    m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+    for _ in range(levels):
+        m.run_level(out=m.new_output() if zero_copy else None)
+        stats.append(m.stats())
+        lv = m.get_level(as_torch=zero_copy, with_state=True)
+        out.append({k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in lv.items()})
+    return out, stats
+
+
+@pytest.mark.parametrize("shape", ["iso", "aniso", "clustered"])
+def test_asynchronous_level_equals_the_synchronous_one(monkeypatch, shape):
+    """A level without a host round trip between its first and its last kernel (the default once the context's buffers exist: sizes stay on
+    the device, launches cover bounds, every write is clamped, ONE answer comes back with the next level's prologue) against the
+    synchronous schedule of rounds 1-4 (GSR_HEM_ASYNC=0: candidates, pairs, orphans and surviving rows read back on the way).  Three
+    levels, bit for bit, own buffers and zero-copy output, on a cloud with irregular components, heavy parents and erased rows; the
+    statistics say which schedule ran and how many round trips it took."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(120000, seed=31, sh_degree=2, shape=shape)
+    c["cov6"][5::997] = np.array([1.0, 0, 0, 1.0, 0, -1.0], np.float32)       # irregular: not positive definite -> erased from level 1
+    monkeypatch.setenv("GSR_HEM_ASYNC", "0")
+    with hem.HemMixture() as m:
+        ref, rst = _levels_on_one_context(m, c, 3, False)
+    assert all(s["schedule"] == 0 and s["round_trips"] >= 4 for s in rst), [(s["schedule"], s["round_trips"]) for s in rst]
+    assert rst[0]["dropped"] > 0
+    monkeypatch.delenv("GSR_HEM_ASYNC")
+    for zero_copy in (False, True):
+        with hem.HemMixture() as m:
+            first, fst = _levels_on_one_context(m, c, 3, zero_copy)           # a fresh context: its first level sizes the buffers synchronously
+            again, ast = _levels_on_one_context(m, c, 3, zero_copy)           # ... and from then on every level is asynchronous
+        assert fst[0]["schedule"] == 0 and all(s["schedule"] == 1 for s in fst[1:]), [s["schedule"] for s in fst]
+        assert all(s["schedule"] == 1 for s in ast), [s["schedule"] for s in ast]
+        # one round trip per level -- two when rows are erased (the host finishes the compaction and asks for the next prologue again)
+        assert all(s["round_trips"] == (2 if s["dropped"] else 1) for s in ast), [(s["round_trips"], s["dropped"]) for s in ast]
+        for got, st in ((first, fst), (again, ast)):
+            for k in range(3):
+                for f in ("parents", "pairs", "orphans", "dropped", "candidates", "n_out", "heavy_parents", "rng_draws", "max_pairs_of_a_parent"):
+                    assert st[k][f] == rst[k][f], (zero_copy, k, f, st[k][f], rst[k][f])
+                for f in ("xyz", "color", "cov6", "sh", "opacity", "weight", "is_parent"):
+                    assert np.array_equal(got[k][f].view(np.uint8), ref[k][f].view(np.uint8)), (zero_copy, k, f)
+
+
+def test_asynchronous_level_on_buffers_too_small_reruns_synchronously():
+    """An asynchronous level runs on the buffers the context has; a level that needs more (here: a context warmed on a small cloud, then a
+    cloud eight times as large) finds that out ON THE DEVICE -- clamped writes, an abort flag in its one answer -- and is run again the
+    synchronous way: same result as a fresh context, schedule 2 in the statistics, and asynchronous again afterwards."""
+    from gaussiansplattingregistration_amd import hem, synth
+    small, big = synth.make_cloud(20000, seed=41, sh_degree=1), synth.make_cloud(160000, seed=42, sh_degree=1)
+    with hem.HemMixture() as m:
+        ref, rst = _levels_on_one_context(m, big, 2, False)
+    with hem.HemMixture() as m:
+        _levels_on_one_context(m, small, 2, False)
+        got, st = _levels_on_one_context(m, big, 2, False)
+        again, ast = _levels_on_one_context(m, big, 2, False)
+    assert st[0]["schedule"] == 2, st[0]["schedule"]
+    assert all(s["schedule"] == 1 for s in ast), [s["schedule"] for s in ast]
+    for res in (got, again):
+        for k in range(2):
+            for f in ("xyz", "color", "cov6", "sh", "opacity", "weight", "is_parent"):
+                assert np.array_equal(res[k][f].view(np.uint8), ref[k][f].view(np.uint8)), (k, f)
+
+
 def test_survivor_ring_across_isolated_parents(monkeypatch, oracle):
     """The survivor ring of a selection wave holds 64 + one group of chunks (SEL_QCAP = 256) and is kept across the wave's four parents.
     ADVICE r04: a parent WITHOUT a candidate row never reached the scan's drain, so a wave could take the ring past its capacity -- parent
