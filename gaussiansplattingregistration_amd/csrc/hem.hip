@@ -476,7 +476,8 @@ __global__ void k_fill_const(int64_t n, OffT* p, OffT v) {
 //   radius = delta * sqrtf(lambda_max) for the parents                       (mixture.cpp:88)
 __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __restrict__ order, const float4* __restrict__ rec, float delta,
                                                 float4* __restrict__ A, float4* __restrict__ geo, float* __restrict__ Rs,
-                                                int* __restrict__ pflag, int* __restrict__ iflag) {
+                                                int* __restrict__ pflag, int* __restrict__ iflag,
+                                                const float* __restrict__ sh, int F, float* __restrict__ sh_tail /* [F rounded up to 4 + 4], or NULL */) {
     // The 64-byte records move with FOUR lanes per record: a load instruction touches 16 records' lines and a store
     // instruction writes 1 KiB of contiguous memory (a lane per record: 64 lines per instruction, both ways).  The lane that
     // owns sorted position j then reads its record back from LDS for the radius and the flags.
@@ -484,19 +485,29 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
     float4* st = s_t[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     if (blockIdx.x == 0 && threadIdx.x == 0) iflag[n] = 0;       // the scan runs over n + 1 entries: irank[n] = total
+    // the last row of the level's SH array, padded with zeros: the M-step reads THAT row here (load4_unaligned)
+    if (sh_tail && blockIdx.x == 0)
+        for (int t = threadIdx.x; t < ((F + 3) & ~3) + 4; t += blockDim.x) sh_tail[t] = t < F ? sh[(n - 1) * F + t] : 0.0f;
     for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += (int64_t)gridDim.x * blockDim.x) {
         const int64_t j = base + lane;
         const unsigned oi = j < n ? order[j] : 0u;
         // (the four rounds' loads together, pinned in front of the stores: inside `if (base + r < n)` every round was a round trip of its
         // own; the lanes behind the end read record order[0])
         float4 v[4];
+        unsigned iu[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const unsigned i = (unsigned)__shfl((int)oi, (lane >> 2) + 16 * u, 64);
-            v[u] = rec[4 * (int64_t)i + (lane & 3)];
+            iu[u] = (unsigned)__shfl((int)oi, (lane >> 2) + 16 * u, 64);
+            v[u] = rec[4 * (int64_t)iu[u] + (lane & 3)];
         }
         asm volatile("" : "+v"(v[0].x), "+v"(v[0].y), "+v"(v[0].z), "+v"(v[0].w), "+v"(v[1].x), "+v"(v[1].y), "+v"(v[1].z), "+v"(v[1].w),
                           "+v"(v[2].x), "+v"(v[2].y), "+v"(v[2].z), "+v"(v[2].w), "+v"(v[3].x), "+v"(v[3].y), "+v"(v[3].z), "+v"(v[3].w));
+        // the flags word {bit 0 parent, bit 1 regular} also carries the component's INPUT index (<< 2; n < 2^30): the M-step finds a
+        // child's SH row where the level lies -- no cell-sorted copy of the SH block (k_gather_sh: 1.8 GB of traffic at 5 M)
+        if ((lane & 3) == 0) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u].w = __uint_as_float((__float_as_uint(v[u].w) & 3u) | (iu[u] << 2));
+        }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int r = (lane >> 2) + 16 * u;
@@ -524,8 +535,25 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
 }
 struct __attribute__((packed, aligned(4))) f4u { float x, y, z, w; };      // a float4 at a 4-byte aligned address (gfx950 loads it with one dwordx4)
 // shs rows: the F SH-rest coefficients of the component, zero padded to RSH = whole float4.  One thread per float4.
+// Whether this copy is MADE is decided here, on the device, from the level's pair count (the kernel runs behind the selection, on
+// the third stream beside the pair partition and the per-child sums): a cell-sorted copy costs one pass over the SH block (1.8 GB of
+// traffic at 5 M) and buys the M-step locality -- rows of neighbouring children next to each other, 16-byte aligned -- for every READ
+// of a row.  An isotropic level reads a row 22 times (k_mstep 2.84 ms from the copy, 3.25 ms from the level's own array: the copy
+// pays); a level of thin discs reads it twice (1.09 against 1.14 ms: the copy, 0.47 ms, does not).  policy: 0 always copy, 1 never,
+// 2 copy iff pairs >= thr * n.  *mode_out = 1: no copy, the M-step and the orphans read the level's own array (k_mstep: sh_mode_p).
 __global__ __launch_bounds__(256) void k_gather_sh(int64_t n, int F, int RSH, const unsigned* __restrict__ order,
-                                                   const float* __restrict__ sh, float* __restrict__ shs) {
+                                                   const float* __restrict__ sh, float* __restrict__ shs,
+                                                   const int64_t* __restrict__ poff, const unsigned* __restrict__ pcnt, int P, int policy, float thr,
+                                                   int* __restrict__ mode_out) {
+    {
+        int direct = policy == 1 ? 1 : 0;
+        if (policy == 2) {
+            const double pairs = P > 0 ? (double)poff[P - 1] + (double)pcnt[P - 1] : 0.0;
+            direct = pairs < (double)thr * (double)n ? 1 : 0;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0) *mode_out = direct;
+        if (direct) return;
+    }
     const int Q = RSH >> 2;
     const int64_t total = n * Q;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -2041,8 +2069,16 @@ struct MstepHeader {           // 32 bytes, one per processing slot
 };
 struct MstepArgs {
     const float4* geo;
-    const float* shs;
-    int RSH;                   // row stride of shs in floats (F rounded up to 4)
+    const float* shs;          // the children's SH rows: sh_direct = 0 the cell-sorted, padded copy (row j at shs + j RSH); 1 = the level's own
+                               // array (row of input index i at shs + i F, unpadded: see load4_unaligned).  Which of the two a level uses is
+                               // decided on the device (k_gather_sh); the kernels set these two fields from *sh_mode_p when they start
+    int sh_direct;
+    const int* sh_mode_p;      // device: 1 = read the level's own array (sh_own), 0 = the cell-sorted copy (sh_sorted)
+    const float* sh_own;
+    const float* sh_sorted;
+    unsigned sh_last;          // sh_direct: the input index of the array's LAST row, which is read from sh_tail instead (0xffffffff: none)
+    const float* sh_tail;      // a copy of that row padded to RSH floats (k_gather wrote it): see load4_unaligned
+    int RSH;                   // F rounded up to whole float4 (the row stride of the padded copy)
     const MstepHeader* hdr;    // [P], processing order
     int xcd;
     const int* nheavy;
@@ -2108,6 +2144,17 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
 // The 14 moment sums of the parent in flight live in the PADDING of the record stage (s_rec rows are 80 bytes apart for the sake of the
 // LDS banks; the fifth float4 of rows 60 .. 63 is nobody's): an array of their own made the workgroup 10 304 bytes of LDS -- nine
 // allocation granules of 1 280 bytes, 14 waves per CU -- where 10 240 are eight granules and 16 waves, what the kernel's registers allow.
+// One global_load_dwordx4 from an address that is only 4-byte aligned (a row of the level's own SH array: F = 45 floats).  The hardware
+// takes it (HSA runs the memory pipeline in unaligned-access mode); the compiler, told the truth about the alignment, splits the load into
+// two or three pieces (dwordx2 + dwordx2, dwordx3 + dword), so it is not told.
+// A lane's float4 slot q covers floats [4 q, 4 q + 4) of the row; in an unpadded row the last slot runs up to three floats into the NEXT
+// row -- sums that are never stored (the output stops at F) -- and behind the array's end for the one row that is the array's last: that
+// row is read from a padded copy the library keeps (MstepArgs::sh_tail, written by k_gather), so no load leaves the caller's array.
+__device__ __forceinline__ float4 load4_unaligned(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ const float* sh_row_of(const float* rows, const float* tail, unsigned idx, unsigned last, int stride) {
+    const float* r = rows + (int64_t)idx * stride;
+    return idx == last ? tail : r;
+}
 struct MomRef {
     float4* rec;
     __device__ __forceinline__ float& operator[](int i) const { return reinterpret_cast<float*>(rec + (60 + (i >> 2)) * 5 + 4)[i & 3]; }
@@ -2118,6 +2165,7 @@ __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int 
                                               float4 (&acc)[MSTEP_NV]) {
     constexpr int GG = G > 0 ? G : 1;
     constexpr int CPR = 64 / GG;                                // children per round
+    const int sh_stride = a.sh_direct ? a.F : a.RSH;            // floats between two SH rows (qi: this lane's float offsets inside a row)
     if (lane < 16) s_mom[lane] = 0.0f;
     // SH sums: local to a chunk of pairs (they occupy no registers during part 1); a segment with more than MSTEP_CHUNK
     // pairs (rare) carries its per-lane partial sums from chunk to chunk in LDS
@@ -2158,6 +2206,7 @@ __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int 
                 __builtin_amdgcn_wave_barrier();
                 const float4 ca = s_rec[lane * 5], cb = s_rec[lane * 5 + 1], cc = s_rec[lane * 5 + 2], cd = s_rec[lane * 5 + 3];
                 __builtin_amdgcn_wave_barrier();
+                if (a.sh_direct) s_j[k0 + lane] = __float_as_uint(ca.w) >> 2;      // part 2 wants the child's row in the level's own SH array: its input index
                 const float sl = cd.w;                     // sumLw_i: k_bucket_sum stored it in the record (in place of det)
                 float w = 0.0f;
                 if (live && sl != 0.0f) {                  // sumLw == 0: skipped (mixture.cpp:190)
@@ -2203,9 +2252,9 @@ __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int 
                     const unsigned kc = k < cn ? k : cn - 1;    // unconditional LDS reads and loads
                     const unsigned j = s_j[kc];
                     wv_[u] = k < cn ? s_w[kc] : 0.0f;
-                    const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)j * a.RSH);
+                    const float* row = sh_row_of(a.shs, a.sh_tail, j, a.sh_last, sh_stride);
 #pragma unroll
-                    for (int v = 0; v < MSTEP_NV; ++v) rowv[u][v] = row[qi[v]];
+                    for (int v = 0; v < MSTEP_NV; ++v) rowv[u][v] = load4_unaligned(row + 4 * qi[v]);
                 }
 #pragma unroll
                 for (int u = 0; u < MSTEP_U; ++u) {
@@ -2243,6 +2292,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     __shared__ float4 s_rec_[WPB][64 * 5];                      // part 1: the batch's geometry records on their way to the pairs' lanes (80-byte stride)
     constexpr int GG = G > 0 ? G : 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    a.sh_direct = *a.sh_mode_p;                                 // (uniform: a scalar load)
+    a.shs = a.sh_direct ? a.sh_own : a.sh_sorted;
+    if (!a.sh_direct) a.sh_last = 0xffffffffu;
     float* s_w = s_w_[wv];
     unsigned* s_j = s_j_[wv];
     float4* s_acc = s_acc_[wv];
@@ -2366,6 +2418,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         float v00 = 0, v01 = 0, v02 = 0, v11 = 0, v12 = 0, v22 = 0, so = 0;
         if (live) {
             const float4 ca = s_rec[lane * 5], cb = s_rec[lane * 5 + 1], cc = s_rec[lane * 5 + 2], cd = s_rec[lane * 5 + 3];
+            if (a.sh_direct) s_j[lane] = __float_as_uint(ca.w) >> 2;          // the child's input index: where its SH row lies
             const float sl = cd.w;
             if (sl != 0.0f) {
                 const float r_is = wl / sl;            // mixture.cpp:196
@@ -2430,9 +2483,9 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                 if (lv) {
                     const unsigned jc = s_j[16 * q + k];
                     wr[r] = s_w[16 * q + k];
-                    const float4* row = reinterpret_cast<const float4*>(a.shs + (int64_t)jc * a.RSH);
+                    const float* row = sh_row_of(a.shs, a.sh_tail, jc, a.sh_last, a.sh_direct ? a.F : a.RSH);
 #pragma unroll
-                    for (int v = 0; v < MSTEP_NV; ++v) rowv[r][v] = row[qi[v]];
+                    for (int v = 0; v < MSTEP_NV; ++v) rowv[r][v] = load4_unaligned(row + 4 * qi[v]);
                 }
             }
             float4 tot[MSTEP_NV];
@@ -2562,87 +2615,52 @@ __global__ __launch_bounds__(64) void k_mstep_heavy_finish(MstepArgs a) {
     }
 }
 
-// orphans: components no parent addressed (sumLw == 0) are copied unchanged after all parents
-__global__ __launch_bounds__(256) void k_orphans(int64_t n, int P, const unsigned* __restrict__ order,
-                                                 const int* __restrict__ oflag_sorted, const int* __restrict__ orank_in,
-                                                 const float4* __restrict__ geo,
-                                                 float* o_xyz, float* o_color, float* o_cov6, float* o_opacity,
-                                                 float* o_weight, int64_t* __restrict__ oslot_sorted, unsigned* __restrict__ olist, int64_t out_cap) {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        int64_t slot = -1;
-        if (oflag_sorted[j]) {
-            const int rank = orank_in[order[j]];
-            slot = (int64_t)P + rank;
-            // (an asynchronous level writes into arrays sized before the number of orphans is known: a row beyond them is not written --
-            // k_level_tail has raised the abort flag, the level reruns synchronously)
-            if (slot >= out_cap) { oslot_sorted[j] = -1; continue; }
-            if (olist) olist[rank] = (unsigned)j;          // orphan `rank` (output row P + rank) sits at sorted position j: k_orphans_sh_list
-            const float4 a = geo[4 * j], b = geo[4 * j + 1], c = geo[4 * j + 2], d = geo[4 * j + 3];
-            o_xyz[3 * slot] = a.x; o_xyz[3 * slot + 1] = a.y; o_xyz[3 * slot + 2] = a.z;
-            o_color[3 * slot] = c.z; o_color[3 * slot + 1] = c.w; o_color[3 * slot + 2] = d.x;
-            o_cov6[6 * slot] = b.x; o_cov6[6 * slot + 1] = b.y; o_cov6[6 * slot + 2] = b.z;
-            o_cov6[6 * slot + 3] = b.w; o_cov6[6 * slot + 4] = c.x; o_cov6[6 * slot + 5] = c.y;
-            o_opacity[slot] = d.y;
-            o_weight[slot] = d.z;
+// Orphans: components no parent addressed (sumLw == 0) are copied unchanged after all parents (mixture.cpp:250-253), row P + (rank among the
+// orphans in input order).  ONE pass, a wave per 64 sorted positions: the lane of an orphan writes its 14 geometry values from the
+// record; the SH rows then leave one orphan at a time with the whole wave on a row (180 contiguous bytes in, 180 out) -- whether a level
+// has a handful of orphans (an isotropic level: 0.04 %) or is a third orphans (thin discs that merge with nothing).  Rounds 2-4 had four
+// kernels for this (a pass over the components for the records and a slot table, then one of three SH copies chosen by the orphans'
+// number on the host, which an asynchronous level does not know).  sh_rows: the cell-sorted copy (row j) or, sh_direct, the level's own
+// array (row order[j]).  Rows beyond out_cap are not written (an asynchronous level's arrays were sized before the count existed; the
+// abort flag is up then).
+__global__ __launch_bounds__(256) void k_orphan_rows(int64_t n, int P, const unsigned* __restrict__ order,
+                                                     const int* __restrict__ oflag_sorted, const int* __restrict__ orank_in,
+                                                     const float4* __restrict__ geo, const float* __restrict__ sh_own, const float* __restrict__ sh_sorted,
+                                                     const int* __restrict__ sh_mode_p, int F, int RSH,
+                                                     float* o_xyz, float* o_color, float* o_cov6, float* o_opacity,
+                                                     float* o_weight, float* o_sh, int64_t out_cap) {
+    const int lane = threadIdx.x & 63;
+    const int sh_direct = F > 0 ? *sh_mode_p : 1;
+    const float* sh_rows = sh_direct ? sh_own : sh_sorted;
+    const int stride = sh_direct ? F : RSH;
+    for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63; base < n; base += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = base + lane;
+        int slot = -1;
+        unsigned src = 0u;
+        if (j < n && oflag_sorted[j]) {
+            const unsigned i = order[j];
+            const int64_t sl = (int64_t)P + orank_in[i];
+            if (sl < out_cap) {
+                slot = (int)sl;
+                src = sh_direct ? i : (unsigned)j;
+                const float4 a = geo[4 * j], b = geo[4 * j + 1], c = geo[4 * j + 2], d = geo[4 * j + 3];
+                o_xyz[3 * sl] = a.x; o_xyz[3 * sl + 1] = a.y; o_xyz[3 * sl + 2] = a.z;
+                o_color[3 * sl] = c.z; o_color[3 * sl + 1] = c.w; o_color[3 * sl + 2] = d.x;
+                o_cov6[6 * sl] = b.x; o_cov6[6 * sl + 1] = b.y; o_cov6[6 * sl + 2] = b.z;
+                o_cov6[6 * sl + 3] = b.w; o_cov6[6 * sl + 4] = c.x; o_cov6[6 * sl + 5] = c.y;
+                o_opacity[sl] = d.y;
+                o_weight[sl] = d.z;
+            }
         }
-        oslot_sorted[j] = slot;
-    }
-}
-// SH rows of the orphans.  Rare orphans (0.04 % of an isotropic level): one thread per component -- a thread per (component,
-// coefficient) would spend its time finding out that there is nothing to copy.  Many orphans (half of a level of thin discs
-// that merge with nothing): one thread per float4 of a padded row, so that a row's reads coalesce.
-__global__ __launch_bounds__(256) void k_orphans_sh(int64_t n, int F, int RSH, const int64_t* __restrict__ oslot_sorted,
-                                                    const float* __restrict__ shs, float* __restrict__ o_sh) {
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t slot = oslot_sorted[j];
-        if (slot < 0) continue;
-        for (int f = 0; f < F; ++f) o_sh[slot * F + f] = shs[j * RSH + f];
-    }
-}
-// Many orphans, one GPU: over the LIST of the orphans (k_orphans wrote it: orphan k of the output sits at sorted position olist[k]) instead
-// of over all components -- on a surfel level 29 % of the components are orphans and the other 71 % of k_orphans_sh_wide's threads
-// loaded a slot only to find -1 (0.28 -> ms at 5 M).
-__global__ __launch_bounds__(256) void k_orphans_sh_list(int64_t n_orph, int64_t P, int F, int RSH, const unsigned* __restrict__ olist,
-                                                         const float* __restrict__ shs, float* __restrict__ o_sh,
-                                                         const long long* __restrict__ n_orph_dev, int64_t out_cap) {
-    if (n_orph_dev) { n_orph = *n_orph_dev; if (P + n_orph > out_cap) n_orph = out_cap > P ? out_cap - P : 0; }
-    const int Q = RSH >> 2;
-    const int64_t total = n_orph * Q;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t k = total < ((int64_t)1 << 31) ? (int64_t)((unsigned)t / (unsigned)Q) : t / Q;
-        const int q = (int)(t - k * Q);
-        const float4 v = reinterpret_cast<const float4*>(shs + (int64_t)olist[k] * RSH)[q];
-        float* dst = o_sh + (P + k) * F + 4 * q;
-        const int left = F - 4 * q;
-        if (left > 3) {                  // the output rows are only 4-byte aligned: one unaligned 16-byte store
-            f4u u; u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
-            *reinterpret_cast<f4u*>(dst) = u;
-        } else {
-            if (left > 0) dst[0] = v.x;
-            if (left > 1) dst[1] = v.y;
-            if (left > 2) dst[2] = v.z;
-        }
-    }
-}
-__global__ __launch_bounds__(256) void k_orphans_sh_wide(int64_t n, int F, int RSH, const int64_t* __restrict__ oslot_sorted,
-                                                         const float* __restrict__ shs, float* __restrict__ o_sh) {
-    const int Q = RSH >> 2;
-    const int64_t total = n * Q;
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t j = total < ((int64_t)1 << 31) ? (int64_t)((unsigned)t / (unsigned)Q) : t / Q;
-        const int64_t slot = oslot_sorted[j];
-        if (slot < 0) continue;
-        const int q = (int)(t - j * Q);
-        const float4 v = reinterpret_cast<const float4*>(shs + j * RSH)[q];
-        float* dst = o_sh + slot * F + 4 * q;
-        const int left = F - 4 * q;
-        if (left > 3) {                  // the output rows are only 4-byte aligned: one unaligned 16-byte store
-            f4u u; u.x = v.x; u.y = v.y; u.z = v.z; u.w = v.w;
-            *reinterpret_cast<f4u*>(dst) = u;
-        } else {
-            if (left > 0) dst[0] = v.x;
-            if (left > 1) dst[1] = v.y;
-            if (left > 2) dst[2] = v.z;
+        if (F > 0) {
+            unsigned long long m = __ballot(slot >= 0);
+            while (m != 0ull) {
+                const int b = __builtin_ctzll(m);
+                m &= m - 1ull;
+                const float* from = sh_rows + (int64_t)(unsigned)__builtin_amdgcn_readlane((int)src, b) * stride;
+                float* to = o_sh + (int64_t)__builtin_amdgcn_readlane(slot, b) * F;
+                for (int f = lane; f < F; f += 64) to[f] = from[f];
+            }
         }
     }
 }
@@ -3267,8 +3285,6 @@ struct gsr_hem_ctx {
     hipEvent_t evp[4] = {nullptr, nullptr, nullptr, nullptr};   // brackets of the two halo exchanges (records on the main stream, SH rows on aux2)
     float part_ms[4] = {0, 0, 0, 0};                            // their durations (gsr_hem_get_part_ms)
     DevBuf sh_send;
-    int sh_grid = 0;                // GSR_HEM_SH_GRID: workgroups of a forked k_gather_sh (0 = as many as in line)
-    int sh_overlap = 0;             // GSR_HEM_SH_OVERLAP: where k_gather_sh runs (0 in line, 1 forked in the grid phase, 2 forked beside k_select)
     float rho = 3.0f, delta = 3.0f, kappa = 2.5f, tau = 1.0f;
     int rng_mode = GSR_RNG_GLIBC;
     uint32_t rng_seed = 1;
@@ -3305,8 +3321,12 @@ struct gsr_hem_ctx {
     unsigned long long rb_seq = 0;
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
-    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec, rowlist, olist;
-    bool orphan_list = true;        // GSR_HEM_ORPHAN_LIST=0: the orphans' SH rows by k_orphans_sh_wide (a pass over all components) whatever their number
+    DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec, rowlist;
+    int sh_policy = 1;              // 1 (default): no cell-sorted copy of the SH block, the M-step reads the rows from the level's own array; GSR_HEM_SH_DIRECT=0:
+                                    // always the copy (k_gather_sh), as in rounds 1-4; GSR_HEM_SH_DIRECT_PAIRS=x: decided per level on the device -- the copy
+                                    // iff the level has at least x accepted pairs per component.  Measured at 5 M (profiles/r05e_ab_sh_direct.txt), level time
+                                    // copy / no copy: isotropic (22 pairs per component) 8.54 / 8.50 ms, clustered (7) 6.98 / 6.70, surfels (2) 6.55 / 6.25
+    float sh_direct_pairs = 8.0f;
     bool use_rowlist = true;        // GSR_HEM_ROWLIST=0: k_select computes every row span itself instead of taking the non-empty ones from k_spans
     int timing = 1;                 // gsr_hem_set_timing / GSR_HEM_TIMING: 0 no events, 1 level + k_select + k_mstep, 2 every phase (see GSR_TIME)
     int select_np = 0;              // GSR_HEM_SELECT_NP=1|2|4: light parents per selection wave (the rings are kept across them, see SEL_NP); 0 = by level size
@@ -3323,7 +3343,7 @@ struct gsr_hem_ctx {
     bool sparse_path = false;
     DevBuf hitem, hfirst, part_cnt, Ac, cellStartC;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
-    DevBuf oslot, keep, kpos, scratch, draws, counters, rocprim_tmp, rocprim_tmp2;
+    DevBuf keep, kpos, scratch, draws, counters, rocprim_tmp, rocprim_tmp2, sh_tail;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t stats_ex[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3645,14 +3665,13 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SPLIT")) c->split_heavy = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SMALL")) c->mstep_small = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SPLIT")) c->mstep_split = atoi(s) != 0;
-    if (const char* s = getenv("GSR_HEM_ORPHAN_LIST")) c->orphan_list = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_SH_DIRECT")) c->sh_policy = atoi(s) != 0 ? 1 : 0;
+    if (const char* s = getenv("GSR_HEM_SH_DIRECT_PAIRS")) { c->sh_direct_pairs = (float)atof(s); c->sh_policy = 2; }
     if (const char* s = getenv("GSR_HEM_ROWLIST")) c->use_rowlist = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_TIMING")) { const int v = atoi(s); c->timing = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* s = getenv("GSR_HEM_SELECT_NP")) { const int v = atoi(s); c->select_np = v < 1 ? 1 : (v > SEL_NP ? SEL_NP : v); }
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_ASYNC")) c->async_ok = atoi(s) != 0;
-    if (const char* s = getenv("GSR_HEM_SH_OVERLAP")) c->sh_overlap = atoi(s);
-    if (const char* s = getenv("GSR_HEM_SH_GRID")) c->sh_grid = atoi(s);
     if (const char* s = getenv("GSR_HEM_PARTITION_STAGE")) { const int v = atoi(s); if (v == 8192 || v == 6144 || v == 4096) c->partition_stage = v; }
     if (const char* s = getenv("GSR_HEM_PARTITION")) { c->partition_fixed = strcmp(s, "exact") != 0; c->partition_staged = strcmp(s, "walk") != 0; }
     if (const char* s = getenv("GSR_HEM_PARTITION_FACTOR")) c->partition_factor = atof(s);
@@ -3685,8 +3704,8 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->Ac, &c->cellStartC, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
-                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->rowlist, &c->olist, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl, &c->oslot,
-                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch, &c->lvl};
+                     &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->rowlist, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl,
+                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch, &c->lvl, &c->sh_tail};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -4207,6 +4226,8 @@ struct LevelRun {
     Level& O;
     const bool dbg_sync, part, sharded;
     bool spec = false;
+    const int sh_policy;                    // the cell-sorted copy of the SH block: 0 always made, 1 never (rows read from the level's own array), 2 decided on
+                                            // the device by the level's pairs per component (k_gather_sh); a partitioned level: 0 (its ghosts' rows lie elsewhere)
     const int64_t n_own;
     int64_t n;
     const int F, RSH;
@@ -4242,7 +4263,7 @@ struct LevelRun {
 
     LevelRun(gsr_hem_ctx* ctx, bool allow_async)
         : c(ctx), st(ctx->stream), L(ctx->cur), O(ctx->nxt), dbg_sync(getenv("GSR_HEM_DEBUG_SYNC") != nullptr), part(ctx->comm != nullptr),
-          sharded(ctx->shard_world > 1 && ctx->shard_allreduce != nullptr), n_own(ctx->cur.n), n(ctx->cur.n), F(ctx->cur.F), RSH((ctx->cur.F + 3) & ~3) {
+          sharded(ctx->shard_world > 1 && ctx->shard_allreduce != nullptr), sh_policy(ctx->comm == nullptr ? ctx->sh_policy : 0), n_own(ctx->cur.n), n(ctx->cur.n), F(ctx->cur.F), RSH((ctx->cur.F + 3) & ~3) {
         spec = allow_async;
         pl.c = c; pl.st = st; pl.n_own = n_own;
         memset(&sa, 0, sizeof(sa));
@@ -4295,13 +4316,14 @@ int32_t LevelRun::launch_gather_sh(bool fork) {
         GSR_HIP(hipEventRecord(c->ev_sh_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux2, c->ev_sh_fork, 0));
         sst = c->aux2;
     }
-    int shg = stride_grid(n * (RSH >> 2));
-    if (fork && c->sh_grid > 0 && shg > c->sh_grid) shg = c->sh_grid;
+    const int shg = stride_grid(n * (RSH >> 2));
     if (part)
         hipLaunchKernelGGL(k_gather_sh2, dim3(shg), blk, 0, sst, n, n_own, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(),
                            c->ghost_sh.as<float>(), c->shs.as<float>());
     else
-        hipLaunchKernelGGL(k_gather_sh, dim3(shg), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>());
+        hipLaunchKernelGGL(k_gather_sh, dim3(shg), blk, 0, sst, n, F, RSH, c->order.as<unsigned>(), L.sh.as<float>(), c->shs.as<float>(),
+                           P > 0 ? c->poff.as<int64_t>() : (const int64_t*)nullptr, c->pcnt.as<unsigned>(), P, sh_policy, c->sh_direct_pairs,
+                           reinterpret_cast<int*>(lvl + 3));
     if (fork) { GSR_HIP(hipEventRecord(c->ev_sh_join, c->aux2)); sh_pending = true; }
     return GSR_OK;
 }
@@ -4383,14 +4405,20 @@ int32_t LevelRun::grid_phase() {
     GSR_TRY(c->cellStart.reserve(((size_t)gp.ncells + 1) * 4));
     hipLaunchKernelGGL(k_run_starts<int>, grd, blk, 0, st, n, c->skeys.as<unsigned>(), (int64_t)gp.ncells, c->cellStart.as<int>());
 
-    GSR_TRY(c->A.reserve((n + SEL_PAD) * 16)); GSR_TRY(c->geo.reserve((size_t)n * 64)); GSR_TRY(c->shs.reserve((size_t)n * (RSH > 0 ? RSH : 1) * 4));
+    GSR_TRY(c->A.reserve((n + SEL_PAD) * 16)); GSR_TRY(c->geo.reserve((size_t)n * 64));
+    if (sh_policy != 1) GSR_TRY(c->shs.reserve((size_t)n * (RSH > 0 ? RSH : 1) * 4));
     GSR_TRY(c->Rs.reserve(n * 4)); GSR_TRY(c->pflag.reserve(n * 4));
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
+    const bool tail = !part && F > 0;
+    if (tail) GSR_TRY(c->sh_tail.reserve((size_t)(RSH + 4) * 4));
     hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), rec_src, c->delta, c->A.as<float4>(), c->geo.as<float4>(),
-                       c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>());
-    // (a partitioned level: always forked -- the third stream carries the ghosts' SH rows, the gather queues up behind them)
-    if (part && F > 0) { GSR_TRY(launch_gather_sh(true)); sh_launched = true; }
-    else if (c->sh_overlap != 2) { GSR_TRY(launch_gather_sh(c->sh_overlap == 1)); sh_launched = true; }
+                       c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>(), L.sh.as<float>(), F, tail ? c->sh_tail.as<float>() : (float*)nullptr);
+    // (a partitioned level: forked here -- the third stream carries the ghosts' SH rows, the gather queues up behind them; one GPU: behind
+    // the selection, when the pair count that decides about the copy exists)
+    if (part && F > 0) {
+        hipLaunchKernelGGL(k_fill_const<int>, dim3(1), dim3(1), 0, st, (int64_t)1, reinterpret_cast<int*>(lvl + 3), 0);
+        GSR_TRY(launch_gather_sh(true)); sh_launched = true;
+    }
     GSR_TRY(exclusive_scan<int>(c, c->pflag.as<int>(), c->ppos.as<int>(), n));
     if (part) {     // the parents this rank works on are the ones it owns; the ghosts' parent flags still keep them out of the children's stream
         GSR_TRY(c->pown.reserve(n * 4)); GSR_TRY(c->ppos_own.reserve(n * 4)); GSR_TRY(c->inv.reserve(n * 4));
@@ -4543,7 +4571,6 @@ int32_t LevelRun::select_phase() {
                 sparse = (double)cand * 8.0 <= (double)budget;
             }
         }
-        if (!sh_launched) { GSR_TRY(launch_gather_sh(true)); sh_launched = true; }
         if (sparse) {
             if (!spec) {
                 const size_t Cm = (size_t)(cand > 0 ? cand : 1);
@@ -4563,6 +4590,9 @@ int32_t LevelRun::select_phase() {
             GSR_TIME1(c->evk[1], st);
         }
         GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), P));
+        // the cell-sorted copy of the SH block -- if the level's pair count says it pays (k_gather_sh) -- on the third stream, beside the
+        // pair partition and the per-child sums; joined in front of the M-step
+        if (!sh_launched) { GSR_TRY(launch_gather_sh(c->aux2 != nullptr)); sh_launched = true; }
         if (!spec) GSR_TRY(total_of(c->poff.as<int64_t>(), c->pcnt.as<unsigned>(), P, &M));
         if (spec || M > 0) {
             if (sparse) {
@@ -4720,7 +4750,6 @@ int32_t LevelRun::sums_phase() {
 // ---- 4a. output ranks in input order: the orphans' flags back to input order, their scan, the level's row count ----------
 int32_t LevelRun::output_ranks() {
     GSR_TRY(c->pflag_in.reserve(n * 4)); GSR_TRY(c->oflag_in.reserve(n * 4)); GSR_TRY(c->prank_in.reserve(n * 4)); GSR_TRY(c->orank_in.reserve(n * 4));
-    GSR_TRY(c->oslot.reserve(n * 8));               // (n includes the ghosts of a partitioned level here)
     int o_last = 0, o_flag = 0;
     for (int attempt = 0; attempt < 2; ++attempt) {
         if (ranks_forked && attempt == 0) {
@@ -4788,6 +4817,7 @@ int32_t LevelRun::open_output() {
 // ---- 4c. M-step; orphans -----------------------------------------
 int32_t LevelRun::mstep_phase() {
     const long long* n_pre_dev = spec ? lvl : nullptr;
+    const int* sh_mode = reinterpret_cast<const int*>(lvl + 3);                     // where a child's SH row is read from: k_gather_sh decided
     // the new level's parent flags depend on nothing but the stream position and n_pre: drawn on the second stream beside the
     // M-step (the jump to the stream position is a fixed ~40 us chain, 5 % of a 200 k-splat level)
     rng_pos0 = c->rng_pos;
@@ -4804,7 +4834,9 @@ int32_t LevelRun::mstep_phase() {
     if (P > 0) {
         MstepArgs ma;
         memset(&ma, 0, sizeof(ma));
-        ma.geo = c->geo.as<float4>(); ma.shs = c->shs.as<float>(); ma.RSH = RSH;
+        ma.geo = c->geo.as<float4>(); ma.RSH = RSH;
+        ma.sh_mode_p = sh_mode; ma.sh_own = L.sh.as<float>(); ma.sh_sorted = c->shs.as<float>();
+        ma.sh_last = part ? 0xffffffffu : (unsigned)(n - 1); ma.sh_tail = c->sh_tail.as<float>();
         ma.pair_child = pc; ma.pair_wl = pw;
         ma.P = P; ma.F = F;
         ma.small = c->mstep_small ? 1 : 0;
@@ -4868,25 +4900,9 @@ int32_t LevelRun::mstep_phase() {
         if (msplit && hst != st) GSR_HIP(hipStreamWaitEvent(st, c->ev_mjoin, 0));
         GSR_TIME1(c->evm[1], st);
     }
-    // many orphans on one GPU: their SH rows are copied over the list of the orphans (k_orphans_sh_list); an asynchronous level always
-    // takes the list (the kernel reads the orphans' number on the device)
-    const bool orphan_list = F > 0 && !part && !sharded && c->orphan_list && (spec || n_orph * 64 > n);
-    if (orphan_list) GSR_TRY(c->olist.reserve((size_t)(spec ? n : n_orph) * 4));
-    hipLaunchKernelGGL(k_orphans, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
-                       c->geo.as<float4>(), O.xyz.as<float>(), O.color.as<float>(),
-                       O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), c->oslot.as<int64_t>(),
-                       orphan_list ? c->olist.as<unsigned>() : (unsigned*)nullptr, (int64_t)(spec ? out_cap : n_pre));
-    if (F > 0 && (spec || n_orph > 0)) {
-        if (orphan_list) {
-            // (an asynchronous level: the grid for a quarter of the level being orphans at most; the kernel strides)
-            const int64_t nb = spec ? std::max<int64_t>(n / 4, 1) : n_orph;
-            hipLaunchKernelGGL(k_orphans_sh_list, dim3(stride_grid(nb * (RSH >> 2))), blk, 0, st, n_orph, (int64_t)P, F, RSH, c->olist.as<unsigned>(),
-                               c->shs.as<float>(), O.sh.as<float>(), spec ? lvl + 1 : (const long long*)nullptr, (int64_t)(spec ? out_cap : n_pre));
-        } else if (n_orph * 64 > n)
-            hipLaunchKernelGGL(k_orphans_sh_wide, dim3(stride_grid(n * (RSH >> 2))), blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
-        else
-            hipLaunchKernelGGL(k_orphans_sh, grd, blk, 0, st, n, F, RSH, c->oslot.as<int64_t>(), c->shs.as<float>(), O.sh.as<float>());
-    }
+    hipLaunchKernelGGL(k_orphan_rows, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
+                       c->geo.as<float4>(), L.sh.as<float>(), c->shs.as<float>(), sh_mode, F, RSH, O.xyz.as<float>(), O.color.as<float>(),
+                       O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>(), (int64_t)(spec ? out_cap : n_pre));
     if (sharded && P > 0) {
         // exchange 2: the merged components.  Every rank packs the rows of ITS parents, ONE all-gather of equal chunks
         // (ceil(P / world) rows of 14 + F floats) moves them, and every rank scatters every chunk into the output rows
@@ -5007,7 +5023,7 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
     // An asynchronous level: one GPU, the default path of every stage, and buffers to run on (a fresh context's first level sizes them the
     // synchronous way).  What it cannot know beforehand it checks on the device (GSR_RETRY_SYNC).
     spec = spec && !part && !sharded && !dbg_sync && c->sum_bucket && c->partition_fixed && !c->partition_overflowed && c->partition_factor == 0.0 &&
-           c->split_heavy && c->orphan_list && getenv("GSR_HEM_SPARSE_GB") == nullptr && c->aux != nullptr &&
+           c->split_heavy && getenv("GSR_HEM_SPARSE_GB") == nullptr && c->aux != nullptr &&
            std::min(c->sp_child.cap, c->sp_wl.cap) >= (size_t)4096 && std::min(c->spair_child.cap, c->spair_wl.cap) >= (size_t)4096;
     grd = dim3(stride_grid(n));
     GSR_TIME1(c->ev[0], st);

@@ -443,21 +443,33 @@ def test_row_lists_from_the_capacity_pass_change_nothing(monkeypatch, shape):
                 assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (budget, k, f)
 
 
-@pytest.mark.parametrize("deg", [3, 1])
-def test_orphan_rows_over_the_orphan_list_change_nothing(monkeypatch, deg):
-    """A level with many orphans (a surfel cloud: a third of its components merge with nothing) copies their SH rows over the LIST of
-    the orphans instead of over all components (k_orphans_sh_list; GSR_HEM_ORPHAN_LIST=0: k_orphans_sh_wide): the same levels."""
+@pytest.mark.parametrize("shape,deg", [("aniso", 3), ("aniso", 1), ("iso", 3), ("clustered", 2), ("iso", 0)])
+def test_sh_rows_read_where_the_level_lies_change_nothing(monkeypatch, shape, deg):
+    """The M-step and the orphans' copy read a child's SH row from the level's OWN array through the child's input index (it rides in the
+    record's flags word) instead of from a cell-sorted, padded copy of the whole SH block (k_gather_sh, rounds 1-4: GSR_HEM_SH_DIRECT=0).
+    The rows of F = 45 / 9 floats are not 16-byte aligned there and the last float4 slot of a row runs into the next row (sums that are
+    never stored) -- or, for the array's last row, would run behind the array: that one row is read from a padded copy.  Same products
+    in the same order: three levels bit for bit, on clouds with many orphans (a third of a surfel level), heavy parents (segments) and
+    small parents (four per wave), own buffers and zero-copy output (the level's array is then the caller's)."""
     from gaussiansplattingregistration_amd import hem, synth
-    c = synth.make_cloud(150000, seed=81, sh_degree=deg, shape="aniso")
-    monkeypatch.setenv("GSR_HEM_ORPHAN_LIST", "0")
-    ref, rst = hem.create_mixture(c, 2)
-    assert rst[0]["orphans"] * 64 > rst[0]["n_in"], rst[0]          # (the list path is taken)
-    monkeypatch.setenv("GSR_HEM_ORPHAN_LIST", "1")
-    got, st = hem.create_mixture(c, 2)
-    for k in range(2):
-        assert (st[k]["parents"], st[k]["pairs"], st[k]["orphans"], st[k]["dropped"]) == (rst[k]["parents"], rst[k]["pairs"], rst[k]["orphans"], rst[k]["dropped"])
-        for f in ("xyz", "color", "cov6", "sh", "opacity"):
-            assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (k, f)
+    n = 300000 if shape == "aniso" else 150000
+    c = synth.make_cloud(n, seed=74 if shape == "aniso" else 81, sh_degree=deg, shape=shape)
+    if shape == "aniso":        # a few fat, nearly isotropic splats among the discs: parents of > 2048 pairs (segments); the array's last row among them
+        g = np.append(np.random.default_rng(5).choice(n, 40, replace=False), n - 1)
+        c["cov6"][g] = np.array([0.09, 0, 0, 0.08, 0, 0.07], np.float32)
+    monkeypatch.setenv("GSR_HEM_SH_DIRECT", "0")
+    with hem.HemMixture() as m:
+        ref, rst = _levels_on_one_context(m, c, 3, False)
+    monkeypatch.setenv("GSR_HEM_SH_DIRECT", "1")
+    for zero_copy in (False, True):
+        with hem.HemMixture() as m:
+            got, st = _levels_on_one_context(m, c, 3, zero_copy)
+        for k in range(3):
+            assert (st[k]["parents"], st[k]["pairs"], st[k]["orphans"], st[k]["dropped"]) == (rst[k]["parents"], rst[k]["pairs"], rst[k]["orphans"], rst[k]["dropped"])
+            for f in ("xyz", "color", "cov6", "sh", "opacity", "weight"):
+                assert np.array_equal(got[k][f].view(np.uint32), ref[k][f].view(np.uint32)), (zero_copy, k, f)
+    if shape == "aniso" and deg == 3:
+        assert rst[0]["orphans"] * 8 > rst[0]["n_in"] and max(s_["max_pairs_of_a_parent"] for s_ in rst) > 2048, [s_["max_pairs_of_a_parent"] for s_ in rst]
 
 
 @pytest.mark.parametrize("deg", [3, 2, 1, 0])
@@ -978,15 +990,15 @@ def test_pair_partition_variants_change_nothing(monkeypatch):
     two-pass fallback (compact CSR segments) and with many orphans (the anisotropic cloud).  GSR_HEM_PARTITION=walk: the
     partition kernel without its LDS staging (what chunks of heavy parents and levels beyond 23 M components use), GSR_HEM_PARTITION_STAGE:
     the smaller stages of the levels with more than 1 536 / 3 584 buckets;
-    GSR_HEM_SH_OVERLAP / GSR_HEM_SH_GRID: the SH gather forked onto the context's third stream."""
+    GSR_HEM_SH_DIRECT = 0 / 1: the cell-sorted copy of the SH block always / never made (by default the level's pair count decides)."""
     from gaussiansplattingregistration_amd import hem, synth
     clouds = [synth.make_cloud(250000, seed=21), synth.make_cloud(120000, seed=22, shape="aniso", sh_degree=1)]
     res = {}
     for tag, env in (("fixed", {}), ("exact", {"GSR_HEM_PARTITION": "exact"}), ("overflow", {"GSR_HEM_PARTITION_FACTOR": "0.3"}),
                      ("two-pass", {"GSR_HEM_SPARSE_GB": "0"}), ("walk", {"GSR_HEM_PARTITION": "walk"}), ("stage-6144", {"GSR_HEM_PARTITION_STAGE": "6144"}),
-                     ("stage-4096", {"GSR_HEM_PARTITION_STAGE": "4096"}), ("sh-fork", {"GSR_HEM_SH_OVERLAP": "1"}),
-                     ("sh-fork-2", {"GSR_HEM_SH_OVERLAP": "2", "GSR_HEM_SH_GRID": "256"})):
-        for k in ("GSR_HEM_PARTITION", "GSR_HEM_PARTITION_FACTOR", "GSR_HEM_PARTITION_STAGE", "GSR_HEM_SPARSE_GB", "GSR_HEM_SH_OVERLAP", "GSR_HEM_SH_GRID"):
+                     ("stage-4096", {"GSR_HEM_PARTITION_STAGE": "4096"}), ("sh-copy", {"GSR_HEM_SH_DIRECT": "0"}),
+                     ("sh-direct", {"GSR_HEM_SH_DIRECT": "1"})):
+        for k in ("GSR_HEM_PARTITION", "GSR_HEM_PARTITION_FACTOR", "GSR_HEM_PARTITION_STAGE", "GSR_HEM_SPARSE_GB", "GSR_HEM_SH_DIRECT"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
@@ -1001,7 +1013,7 @@ def test_pair_partition_variants_change_nothing(monkeypatch):
         res[tag] = out
     assert all(o[2] == 1 for o in res["overflow"][:3]) and not any(o[2] for o in res["fixed"])
     assert all(o[3] == 0 for o in res["two-pass"]) and all(o[3] == 1 for o in res["fixed"])
-    for tag in ("exact", "overflow", "two-pass", "walk", "stage-6144", "stage-4096", "sh-fork", "sh-fork-2"):
+    for tag in ("exact", "overflow", "two-pass", "walk", "stage-6144", "stage-4096", "sh-copy", "sh-direct"):
         for a, b in zip(res["fixed"], res[tag]):
             assert a[:2] == b[:2], (tag, a[:2], b[:2])
             for f in ("xyz", "color", "cov6", "opacity", "sh", "weight", "is_parent"):
