@@ -216,6 +216,7 @@ __device__ __forceinline__ float class_sum(float v) {
 //   products of two float32 values are exact in float64; the 2x2 minor and the cofactor expansion then carry a few
 //   float64 roundings of their largest term, so "minor > 1e-12 a00 a11" and "det > 1e-9 (sum of |terms|)" certify positive
 //   definiteness (Sylvester) and a determinant good to 1e-6 relative.
+#define ERASE_MAX 32          // erased rows a level compacts in place on the device (k_erase_save / k_erase_shift); more: the host path
 #define GSR_DET_TOL 0.04           // |det_float32 / det - 1| allowed for a regular component (enters the filter bound as is)
 __device__ __forceinline__ bool spd_det64(double a00, double a01, double a02, double a11, double a12, double a22, double& det) {
     const double m2 = a00 * a11 - a01 * a01;
@@ -3112,7 +3113,8 @@ __global__ void k_flip3(unsigned* __restrict__ w) { if (threadIdx.x < 3) w[threa
 
 // validity (mixture.cpp:262-282): keep iff !(isnan(mean) || isnan(det) || det <= 0)
 __global__ __launch_bounds__(256) void k_valid(int64_t n, const float* __restrict__ xyz, const float* __restrict__ cov6,
-                                               int* __restrict__ keep, const long long* __restrict__ n_dev, int* __restrict__ dropped) {
+                                               int* __restrict__ keep, const long long* __restrict__ n_dev, int* __restrict__ dropped,
+                                               int* __restrict__ holes /* [ERASE_MAX]: the erased rows, in any order (NULL: not wanted) */) {
     if (n_dev) n = *n_dev;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
         const float x = xyz[3 * i], y = xyz[3 * i + 1], z = xyz[3 * i + 2];
@@ -3120,7 +3122,129 @@ __global__ __launch_bounds__(256) void k_valid(int64_t n, const float* __restric
         const float d = det6(c);
         const bool bad = (x != x) || (y != y) || (z != z) || (d != d) || (d <= 0.0f);
         keep[i] = bad ? 0 : 1;
-        if (bad && dropped) atomicAdd(dropped, 1);       // (erased rows are a handful per level: the counter tells the host whether anything has to move)
+        if (bad && dropped) {                            // (erased rows are a handful per level: the counter says whether anything has to move, the list what)
+            const int slot = atomicAdd(dropped, 1);
+            if (holes && slot < ERASE_MAX) holes[slot] = (int)i;
+        }
+    }
+}
+
+// The validity erase IN PLACE (mixture.cpp:262-282 erases element by element, O(n) each).  A level drops a handful of rows (a surfel level of
+// 3.1 M rows: 22), and rounds 1-4 moved ALL rows of all seven arrays through a second buffer for it (and back, when the level lives in the
+// caller's arrays: 0.4 ms of a 7 ms level) behind a host round trip.  Here the rows behind the first hole slide down by the number of holes
+// below them, in tiles of ERASE_TILE rows: a tile's rows land on its own rows and on the last rows of the tile BELOW it, so those last rows
+// (at most as many as there are holes) are saved first (k_erase_save: one small copy per tile), every tile then stages its surviving
+// rows in LDS -- the ones the tile above may already have overwritten come from the saved copy -- and writes them out as one contiguous run
+// (k_erase_shift).  Tiles in front of the first hole do nothing.  Up to ERASE_MAX holes; a level with more takes the old path (host).
+// A tile of T rows x w floats is staged at once: T = min(256, 12288 / widest row), so that 48 KB of LDS hold it.
+struct EraseArgs {
+    float* arr[6];                  // xyz color cov6 opacity weight sh
+    int w[6];                       // floats per row: 3 3 6 1 1 F
+    uint8_t* flags;                 // is_parent
+    float* halo;                    // [tiles][ERASE_MAX][W] floats, then [tiles][ERASE_MAX] bytes
+    int W;                          // 14 + F
+    int tile;                       // rows per tile
+    int max_tiles;                  // tiles the halo buffer holds (the launch's bound)
+    const int* holes;               // k_valid's list
+    const int* dropped;             // its count
+    const long long* n_pre_p;       // rows before the erase (device)
+    long long* n_keep_out;          // rows after it (written by k_erase_save)
+};
+// the sorted holes of the level into LDS; returns their number (0: nothing to do -- none, or more than this path takes)
+__device__ __forceinline__ int erase_load_holes(const EraseArgs& a, int* s_holes) {
+    const int d = *a.dropped;
+    if (d <= 0 || d > ERASE_MAX) return 0;
+    if ((int)threadIdx.x < d) {                     // rank sort: at most 32 values
+        const int v = a.holes[threadIdx.x];
+        int r = 0;
+        for (int k = 0; k < d; ++k) r += a.holes[k] < v ? 1 : 0;
+        s_holes[r] = v;
+    }
+    __syncthreads();
+    return d;
+}
+__device__ __forceinline__ int holes_below(const int* s_holes, int d, int64_t row) {      // holes with index < row
+    int k = 0;
+    for (int i = 0; i < d; ++i) k += (int64_t)s_holes[i] < row ? 1 : 0;
+    return k;
+}
+__global__ __launch_bounds__(256) void k_erase_save(EraseArgs a) {
+    __shared__ int s_holes[ERASE_MAX];
+    const long long n_pre = *a.n_pre_p;
+    const int d = erase_load_holes(a, s_holes);
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.n_keep_out = n_pre - (d > 0 ? d : 0);      // (more than ERASE_MAX: the host finishes and sets the size)
+    if (d == 0) return;
+    const int64_t ntiles = (n_pre + a.tile - 1) / a.tile;
+    uint8_t* halo_b = reinterpret_cast<uint8_t*>(a.halo + (int64_t)a.max_tiles * ERASE_MAX * a.W);
+    for (int64_t t = 1 + blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t row0 = t * a.tile;
+        const int k0 = holes_below(s_holes, d, row0);
+        if (k0 == 0) continue;
+        float* h = a.halo + t * ERASE_MAX * a.W;
+        int off = 0;
+        for (int q = 0; q < 6; ++q) {
+            const int w = a.w[q];
+            if (w > 0) for (int e = threadIdx.x; e < k0 * w; e += blockDim.x) h[off + e] = a.arr[q][(row0 - k0) * w + e];
+            off += ERASE_MAX * w;
+        }
+        if ((int)threadIdx.x < k0) halo_b[t * ERASE_MAX + threadIdx.x] = a.flags[row0 - k0 + threadIdx.x];
+    }
+}
+__global__ __launch_bounds__(256) void k_erase_shift(EraseArgs a) {
+    extern __shared__ float s_stage[];              // tile x widest row floats
+    __shared__ int s_holes[ERASE_MAX];
+    __shared__ short s_k[256];                      // per row of the tile: holes below it (relative to the tile's first row), -1 = the row is a hole
+    const long long n_pre = *a.n_pre_p;
+    const int d = erase_load_holes(a, s_holes);
+    if (d == 0) return;
+    const int64_t ntiles = (n_pre + a.tile - 1) / a.tile;
+    const uint8_t* halo_b = reinterpret_cast<const uint8_t*>(a.halo + (int64_t)a.max_tiles * ERASE_MAX * a.W);
+    for (int64_t t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int64_t row0 = t * a.tile;
+        const int nrows = (int)(n_pre - row0 < a.tile ? n_pre - row0 : a.tile);
+        const int k0 = holes_below(s_holes, d, row0), k1 = holes_below(s_holes, d, row0 + nrows);
+        if (k1 == 0) continue;                      // in front of the first hole: nothing moves
+        // rows of THIS tile the tile above overwrites (its first rows land on them): read from the saved copy
+        const int kn = row0 + nrows < n_pre ? k1 : 0;
+        const int tail0 = nrows - kn;               // local index of the first such row
+        __syncthreads();
+        if ((int)threadIdx.x < nrows) {
+            const int64_t r = row0 + threadIdx.x;
+            int k = 0; bool hole = false;
+            for (int i = 0; i < d; ++i) { k += (int64_t)s_holes[i] < r ? 1 : 0; hole = hole || (int64_t)s_holes[i] == r; }
+            s_k[threadIdx.x] = hole ? (short)-1 : (short)(k - k0);
+        }
+        __syncthreads();
+        const int ndst = nrows - (k1 - k0);
+        const float* hn = a.halo + (t + 1) * ERASE_MAX * a.W;
+        int off = 0;
+        for (int q = 0; q < 6; ++q) {
+            const int w = a.w[q];
+            if (w > 0) {
+                float* arr = a.arr[q];
+                for (unsigned e = threadIdx.x; e < (unsigned)(nrows * w); e += blockDim.x) {
+                    const unsigned rl = e / (unsigned)w, cc = e - rl * (unsigned)w;
+                    const int kk = s_k[rl];
+                    if (kk < 0) continue;
+                    const float v = (int)rl >= tail0 ? hn[off + ((int)rl - tail0) * w + cc] : arr[(row0 + rl) * w + cc];
+                    s_stage[((int)rl - kk) * w + cc] = v;
+                }
+                __syncthreads();
+                for (int e = threadIdx.x; e < ndst * w; e += blockDim.x) arr[(row0 - k0) * w + e] = s_stage[e];
+                __syncthreads();
+            }
+            off += ERASE_MAX * w;
+        }
+        {   // the flag bytes
+            uint8_t* sb = reinterpret_cast<uint8_t*>(s_stage);
+            if ((int)threadIdx.x < nrows && s_k[threadIdx.x] >= 0) {
+                const int rl = threadIdx.x;
+                sb[rl - s_k[rl]] = rl >= tail0 ? halo_b[(t + 1) * ERASE_MAX + (rl - tail0)] : a.flags[row0 + rl];
+            }
+            __syncthreads();
+            if ((int)threadIdx.x < ndst) a.flags[row0 - k0 + threadIdx.x] = sb[threadIdx.x];
+            __syncthreads();
+        }
     }
 }
 
@@ -3343,7 +3467,7 @@ struct gsr_hem_ctx {
     bool sparse_path = false;
     DevBuf hitem, hfirst, part_cnt, Ac, cellStartC;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
-    DevBuf keep, kpos, scratch, draws, counters, rocprim_tmp, rocprim_tmp2, sh_tail;
+    DevBuf keep, kpos, scratch, draws, counters, rocprim_tmp, rocprim_tmp2, sh_tail, holes, erase_halo;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t stats_ex[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float phase_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3685,6 +3809,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     (void)hipFuncSetAttribute((const void*)k_partition<4096>, hipFuncAttributeMaxDynamicSharedMemorySize, 5632 * 8 + 4096 * 8);
     (void)hipFuncSetAttribute((const void*)k_part_max, hipFuncAttributeMaxDynamicSharedMemorySize, 4 << 13);
     (void)hipFuncSetAttribute((const void*)k_part_acc, hipFuncAttributeMaxDynamicSharedMemorySize, 12 << 13);
+    (void)hipFuncSetAttribute((const void*)k_erase_shift, hipFuncAttributeMaxDynamicSharedMemorySize, 12288 * 4);
     *out = c;
     return GSR_OK;
 }
@@ -3705,7 +3830,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
                      &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->rowlist, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl,
-                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch, &c->lvl, &c->sh_tail};
+                     &c->keep, &c->kpos, &c->scratch, &c->draws, &c->counters, &c->rocprim_tmp, &c->rocprim_tmp2, &c->mh_list, &c->mh_items, &c->mh_scratch, &c->lvl, &c->sh_tail, &c->holes, &c->erase_halo};
     for (DevBuf* b : all) b->release();
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     for (int i = 0; i < 8; ++i) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
@@ -4284,6 +4409,7 @@ struct LevelRun {
     int32_t mstep_phase();
     int32_t flags_and_validity();
     int32_t compact_erased(int64_t n_keep);
+    int32_t erase_in_place(int64_t rows_bound);
     int32_t launch_gather_sh(bool fork);
     int32_t widen_scan(const unsigned* cnt_in, int64_t* off, int64_t count);
     int32_t total_of(const int64_t* off, const unsigned* cnt_in, int64_t count, int64_t* out);
@@ -4936,7 +5062,29 @@ int32_t LevelRun::mstep_phase() {
     return GSR_OK;
 }
 
-// the validity erase of a level that drops rows (mixture.cpp:262-282): the surviving rows of every array move up, in order
+// The validity erase in place, on the device (k_erase_save + k_erase_shift): lvl[0] = rows before it, cnt[3] / c->holes = what k_valid found;
+// lvl[4] = rows after it.  Both kernels leave at once when there is nothing to erase -- or more than ERASE_MAX rows (the host's path then).
+int32_t LevelRun::erase_in_place(int64_t rows_bound) {
+    EraseArgs ea;
+    memset(&ea, 0, sizeof(ea));
+    float* arrs[6] = {O.xyz.as<float>(), O.color.as<float>(), O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>()};
+    const int ws[6] = {3, 3, 6, 1, 1, F};
+    for (int q = 0; q < 6; ++q) { ea.arr[q] = arrs[q]; ea.w[q] = ws[q]; }
+    ea.flags = O.is_parent.as<uint8_t>();
+    ea.W = 14 + F;
+    ea.tile = std::min(256, 12288 / std::max(F, 6));
+    ea.max_tiles = (int)((rows_bound + ea.tile - 1) / ea.tile) + 1;
+    GSR_TRY(c->erase_halo.reserve((size_t)ea.max_tiles * ERASE_MAX * ((size_t)ea.W * 4 + 1) + 64));
+    ea.halo = c->erase_halo.as<float>();
+    ea.holes = c->holes.as<int>(); ea.dropped = cnt + 3; ea.n_pre_p = lvl; ea.n_keep_out = lvl + 4;
+    const int g = std::min(ea.max_tiles, 2048);
+    hipLaunchKernelGGL(k_erase_save, dim3(g), blk, 0, st, ea);
+    hipLaunchKernelGGL(k_erase_shift, dim3(g), blk, (size_t)12288 * 4, st, ea);
+    GSR_HIP(hipGetLastError());
+    return GSR_OK;
+}
+
+// the validity erase of a level that drops MANY rows (mixture.cpp:262-282): the surviving rows of every array move up, in order, through a second buffer
 int32_t LevelRun::compact_erased(int64_t n_keep) {
     Level& T = c->tmp;
     const dim3 g2(stride_grid(n_pre));
@@ -4980,22 +5128,27 @@ int32_t LevelRun::flags_and_validity() {
     if (n_pre > 0) {
         GSR_TRY(c->keep.reserve(n_pre * 4)); GSR_TRY(c->kpos.reserve(n_pre * 4));
         const dim3 g2(stride_grid(n_pre));
-        hipLaunchKernelGGL(k_valid, g2, blk, 0, st, n_pre, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>(), (const long long*)nullptr, (int*)nullptr);
-        GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
-        int k_last = 0, k_flag = 0;
+        GSR_TRY(c->holes.reserve(ERASE_MAX * 4));
+        hipLaunchKernelGGL(k_valid, g2, blk, 0, st, n_pre, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>(), (const long long*)nullptr, cnt + 3, c->holes.as<int>());
+        if (part) GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));        // (drop_erased renumbers with it)
         {
             Collect q;
-            q.n = 3;
-            q.src[0] = c->kpos.as<int>() + (n_pre - 1); q.src[1] = c->keep.as<int>() + (n_pre - 1); q.src[2] = cnt + 15;
-            q.bytes[0] = q.bytes[1] = q.bytes[2] = 4;
+            q.n = 2;
+            q.src[0] = cnt + 3; q.src[1] = cnt + 15;
+            q.bytes[0] = q.bytes[1] = 4;
             unsigned long long w[8];
             GSR_TRY(read_back(c, q, w));
-            k_last = (int)w[0]; k_flag = (int)w[1];
-            if (P > 0) c->stats_ex[5] = (int64_t)(unsigned)w[2];
+            dropped = (int64_t)(unsigned)w[0];
+            if (P > 0) c->stats_ex[5] = (int64_t)(unsigned)w[1];
         }
-        const int64_t n_keep = (int64_t)k_last + k_flag;
-        dropped = n_pre - n_keep;
-        if (dropped > 0) GSR_TRY(compact_erased(n_keep));
+        if (dropped > 0 && dropped <= ERASE_MAX && !part) {         // a handful of rows: in place, on the device
+            hipLaunchKernelGGL(k_fill_const<long long>, dim3(1), dim3(1), 0, st, (int64_t)1, lvl, (long long)n_pre);
+            GSR_TRY(erase_in_place(n_pre));
+            O.n = n_pre - dropped;
+        } else if (dropped > 0) {
+            if (!part) GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
+            GSR_TRY(compact_erased(n_pre - dropped));
+        }
     }
     n_glob_next = n_pre_glob;
     if (part) GSR_TRY(pl.drop_erased(O, n_pre, n_pre_glob, dropped, n_glob_next));
@@ -5045,9 +5198,12 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
         // ---- 5 (asynchronous). flags joined, validity counted, the NEXT level's prologue on the rows as they are, ONE answer ----------
         if (flags_forked) GSR_HIP(hipStreamWaitEvent(st, c->ev_join, 0));
         GSR_TRY(c->keep.reserve((size_t)out_cap * 4)); GSR_TRY(c->kpos.reserve((size_t)out_cap * 4));
-        hipLaunchKernelGGL(k_valid, dim3(stride_grid(out_cap)), blk, 0, st, out_cap, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>(), (const long long*)lvl, cnt + 3);
+        GSR_TRY(c->holes.reserve(ERASE_MAX * 4));
+        hipLaunchKernelGGL(k_valid, dim3(stride_grid(out_cap)), blk, 0, st, out_cap, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>(), (const long long*)lvl, cnt + 3,
+                           c->holes.as<int>());
+        GSR_TRY(erase_in_place(out_cap));               // (leaves at once when nothing is erased; lvl[4] = the rows that remain)
         GSR_TIME1(c->ev[5], st);
-        GSR_TRY(enqueue_prologue(c, O, out_cap, lvl, cb_next));
+        GSR_TRY(enqueue_prologue(c, O, out_cap, lvl + 4, cb_next));
         q.lvl = lvl;
         GSR_TRY(read_back_level(c, q, w));
         if (w[LC_FLAGS] != 0ull) return GSR_RETRY_SYNC;        // a clamped segment, a full bucket region or item table, an output too small
@@ -5058,8 +5214,9 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
         O.n = n_pre;
         P_glob = P; O_glob = n_orph; n_pre_glob = n_pre; n_glob_next = n_pre;
         dropped = (int64_t)w[LC_DROPPED];
-        have_next = dropped == 0;
-        if (dropped > 0) {              // rows to erase: the host finishes the level (scan + compaction), and the prologue is taken again
+        have_next = dropped <= ERASE_MAX;               // (erased in place on the device: the prologue saw the level as it is now)
+        if (have_next) O.n = n_pre - dropped;
+        else {                          // many rows to erase: the host finishes the level (scan + compaction), and the prologue is taken again
             GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
             GSR_TRY(compact_erased(n_pre - dropped));
         }
