@@ -305,10 +305,12 @@ __global__ __launch_bounds__(256) void k_prep(int64_t n, const float* __restrict
 // bbox[0..2] = min, bbox[3..5] = max over the per-block partial boxes (order-preserving uint encoding)
 // (also clears the level's counters and the axis histograms: two memset launches less per level)
 __global__ __launch_bounds__(256) void k_bbox_reduce(int nblocks, const unsigned* __restrict__ part, unsigned* __restrict__ bbox,
-                                                     unsigned* __restrict__ zero_a, int na, unsigned* __restrict__ zero_b, int nzb) {
+                                                     unsigned* __restrict__ zero_a, int na, unsigned* __restrict__ zero_b, int nzb,
+                                                     unsigned* __restrict__ zero_c, int nzc) {
     __shared__ unsigned s_v[4][8];
     for (int i = threadIdx.x; i < na; i += blockDim.x) zero_a[i] = 0u;
     for (int i = threadIdx.x; i < nzb; i += blockDim.x) zero_b[i] = 0u;
+    for (int i = threadIdx.x; i < nzc; i += blockDim.x) zero_c[i] = 0u;      // (the bucket cursors of the pair partition: two memset launches less per level)
     unsigned v[8];
     for (int k = 0; k < 3; ++k) { v[k] = 0xffffffffu; v[3 + k] = 0u; }
     v[6] = v[7] = 0u;                                // bbox[6] = parents of the level, bbox[7] = irregular components (k_prep's counts)
@@ -602,7 +604,8 @@ __global__ __launch_bounds__(256) void k_scatter_list(int64_t n, const int* __re
 // before it).  ppos = exclusive scan of pflag; P = its total.
 __global__ __launch_bounds__(256) void k_child_stream(int64_t n, int64_t cells, int P, const float4* __restrict__ A, const int* __restrict__ pflag,
                                                       const int* __restrict__ ppos, const int* __restrict__ cellStart,
-                                                      float4* __restrict__ Ac, int* __restrict__ cellStartC, int pad) {
+                                                      float4* __restrict__ Ac, int* __restrict__ cellStartC, int pad,
+                                                      const int* __restrict__ irank /* NULL: the level has no irregular component */, int* __restrict__ cellStartI) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x, t0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     for (int64_t t = t0; t < pad; t += stride) Ac[(n - P) + t] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);     // the pad k_select reads past the last row
     for (int64_t j = t0; j < n; j += stride) {
@@ -613,6 +616,8 @@ __global__ __launch_bounds__(256) void k_child_stream(int64_t n, int64_t cells, 
     for (int64_t cidx = t0; cidx <= cells; cidx += stride) {
         const int sidx = cellStart[cidx];
         cellStartC[cidx] = sidx - (sidx < n ? ppos[sidx] : P);
+        // the grid's prefix table counted over the IRREGULAR components (pass B's row spans: two look-ups instead of a dependent pair of pairs)
+        if (irank) cellStartI[cidx] = irank[sidx];
     }
 }
 
@@ -659,6 +664,7 @@ struct SelectArgs {
     // prefix table counted over them.  A third of the components are parents.
     const float4* Ac;
     const int* cellStartC;
+    const int* cellStartI;          // the same table counted over the irregular components (the list pass B scans); only when n_irr > 0
     const double* logtab;           // glibc logf table (LDS copy)
     const int* irank;               // irank[j] = number of irregular components among sorted positions [0, j)   (n + 1 entries)
     const unsigned* ipos;           // sorted positions of the irregular components, ascending
@@ -958,7 +964,7 @@ __device__ __forceinline__ void select_row_span(const SelectArgs& a, const GridP
             xb = xb > x1 ? x1 : xb;
             const int rowbase = (rz * g.gy + ry) * g.gx;
             int e;
-            if (IRR) { s = a.irank[a.cellStart[rowbase + xa]]; e = a.irank[a.cellStart[rowbase + xb + 1]]; }
+            if (IRR) { s = a.cellStartI[rowbase + xa]; e = a.cellStartI[rowbase + xb + 1]; }      // positions in the irregular list
             else { s = a.cellStartC[rowbase + xa]; e = a.cellStartC[rowbase + xb + 1]; }      // positions in the children's stream
             len = e - s;
         }
@@ -3446,10 +3452,11 @@ struct gsr_hem_ctx {
     bool rb_poll = true;            // the host polls the sequence word (GSR_HEM_RB_POLL=0: hipStreamSynchronize)
     DevBuf rec, bbox, bbox_part, gparams, keys, idx, skeys, order, cellStart, A, geo, shs, Rs, pflag, ppos, plist;
     DevBuf pcap, coff, sp_child, sp_wl, porder, pkeys, pkeys2, pidx, mhdr, prec, rowlist;
-    int sh_policy = 1;              // 1 (default): no cell-sorted copy of the SH block, the M-step reads the rows from the level's own array; GSR_HEM_SH_DIRECT=0:
-                                    // always the copy (k_gather_sh), as in rounds 1-4; GSR_HEM_SH_DIRECT_PAIRS=x: decided per level on the device -- the copy
-                                    // iff the level has at least x accepted pairs per component.  Measured at 5 M (profiles/r05e_ab_sh_direct.txt), level time
-                                    // copy / no copy: isotropic (22 pairs per component) 8.54 / 8.50 ms, clustered (7) 6.98 / 6.70, surfels (2) 6.55 / 6.25
+    int sh_policy = 2;              // the cell-sorted, padded copy of the SH block (k_gather_sh) the M-step reads its children's rows from: 2 (default) = decided
+                                    // per level ON THE DEVICE -- made iff the level has at least sh_direct_pairs accepted pairs per component, else the rows are
+                                    // read from the level's own array; GSR_HEM_SH_DIRECT=0: always made (rounds 1-4), =1: never; GSR_HEM_SH_DIRECT_PAIRS=x: the
+                                    // threshold.  Measured at 5 M (profiles/r05e_ab_sh_direct.txt), level time copy / no copy: isotropic (22 pairs per component)
+                                    // 8.54 / 8.50 ms from own buffers but 8.63 / 8.78 in the bench's zero-copy cascade; clustered (7) 6.98 / 6.70; surfels (2) 6.55 / 6.25
     float sh_direct_pairs = 8.0f;
     bool use_rowlist = true;        // GSR_HEM_ROWLIST=0: k_select computes every row span itself instead of taking the non-empty ones from k_spans
     int timing = 1;                 // gsr_hem_set_timing / GSR_HEM_TIMING: 0 no events, 1 level + k_select + k_mstep, 2 every phase (see GSR_TIME)
@@ -3465,7 +3472,7 @@ struct gsr_hem_ctx {
     void* shard_user = nullptr;
     DevBuf shard_send, shard_recv;
     bool sparse_path = false;
-    DevBuf hitem, hfirst, part_cnt, Ac, cellStartC;
+    DevBuf hitem, hfirst, part_cnt, Ac, cellStartC, cellStartI;
     DevBuf pcnt, poff, pair_child, pair_wl, spair_child, spair_wl, cstart, sumLw, oflag, pflag_in, oflag_in, prank_in, orank_in;
     DevBuf keep, kpos, scratch, draws, counters, rocprim_tmp, rocprim_tmp2, sh_tail, holes, erase_halo;
     int64_t stats[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -3691,11 +3698,12 @@ int32_t enqueue_prologue(gsr_hem_ctx* c, Level& L, int64_t n, const long long* n
     GSR_TRY(c->rec.reserve((size_t)n * 64)); GSR_TRY(c->bbox.reserve(64));
     GSR_TRY(c->gparams.reserve(sizeof(GridParams))); GSR_TRY(c->counters.reserve(128));
     GSR_TRY(c->bbox_part.reserve((size_t)grd.x * 8 * 4)); GSR_TRY(c->hist.reserve(3 * HIST_BINS * 4));
+    GSR_TRY(c->bcursor.reserve(((size_t)SUM_MAX_BUCKETS + 1) * 8));
     if (c->timing >= 1) GSR_HIP(hipEventRecord(c->ev_pro[0], st));
     hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
                        L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>(), n_dev);
     hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>(),
-                       c->counters.as<unsigned>() + 16 * cblock, 16, c->hist.as<unsigned>(), 3 * HIST_BINS);
+                       c->counters.as<unsigned>() + 16 * cblock, 16, c->hist.as<unsigned>(), 3 * HIST_BINS, c->bcursor.as<unsigned>(), SUM_MAX_BUCKETS + 1);
     hipLaunchKernelGGL(k_hist, dim3(stride_grid(n) > 512 ? 512 : stride_grid(n)), blk, 0, st, n, L.xyz.as<float>(), c->bbox.as<unsigned>(), c->hist.as<unsigned>(), n_dev);
     hipLaunchKernelGGL(k_grid_params, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>(), c->hist.as<unsigned>(), n, c->cell_target,
                        c->max_cells, c->gparams.as<GridParams>(), n_dev);
@@ -3790,7 +3798,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_MSTEP_SMALL")) c->mstep_small = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_MSTEP_SPLIT")) c->mstep_split = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_SH_DIRECT")) c->sh_policy = atoi(s) != 0 ? 1 : 0;
-    if (const char* s = getenv("GSR_HEM_SH_DIRECT_PAIRS")) { c->sh_direct_pairs = (float)atof(s); c->sh_policy = 2; }
+    if (const char* s = getenv("GSR_HEM_SH_DIRECT_PAIRS")) c->sh_direct_pairs = (float)atof(s);
     if (const char* s = getenv("GSR_HEM_ROWLIST")) c->use_rowlist = atoi(s) != 0;
     if (const char* s = getenv("GSR_HEM_TIMING")) { const int v = atoi(s); c->timing = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* s = getenv("GSR_HEM_SELECT_NP")) { const int v = atoi(s); c->select_np = v < 1 ? 1 : (v > SEL_NP ? SEL_NP : v); }
@@ -3826,7 +3834,7 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
                            &c->grank, &c->allflags, &c->pcounts, &c->pmatrix};
     for (DevBuf* b : part_bufs) b->release();
     DevBuf* all[] = {&c->rec, &c->bbox, &c->bbox_part, &c->gparams, &c->keys, &c->idx, &c->skeys, &c->order, &c->cellStart, &c->A, &c->geo, &c->shs,
-                     &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->Ac, &c->cellStartC, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
+                     &c->Rs, &c->pflag, &c->ppos, &c->plist, &c->hitem, &c->hfirst, &c->part_cnt, &c->Ac, &c->cellStartC, &c->cellStartI, &c->pcnt, &c->poff, &c->pair_child, &c->pair_wl,
                      &c->spair_child, &c->spair_wl, &c->cstart, &c->sumLw, &c->oflag, &c->pflag_in, &c->oflag_in, &c->prank_in,
                      &c->orank_in, &c->hist, &c->iflag, &c->irank, &c->ipos, &c->rng_blocks, &c->bhist, &c->bstart, &c->bcursor,
                      &c->porder, &c->pkeys, &c->pkeys2, &c->pidx, &c->mhdr, &c->prec, &c->rowlist, &c->shard_send, &c->shard_recv, &c->pcap, &c->coff, &c->sp_child, &c->sp_wl,
@@ -4415,11 +4423,15 @@ struct LevelRun {
     int32_t total_of(const int64_t* off, const unsigned* cnt_in, int64_t count, int64_t* out);
 };
 
+struct WidenU32 { __device__ __host__ int64_t operator()(unsigned v) const { return (int64_t)v; } };
 int32_t LevelRun::widen_scan(const unsigned* cnt_in, int64_t* off, int64_t count) {      // off = exclusive scan of cnt_in (int64)
-    GSR_TRY(c->scratch.reserve(((size_t)count + 128) * 8));
-    int64_t* cnt64 = c->scratch.as<int64_t>();
-    GSR_HIP(rocprim::transform(cnt_in, cnt64, (size_t)count, [] __device__(unsigned v) { return (int64_t)v; }, st));
-    return exclusive_scan<int64_t>(c, cnt64, off, count);
+    // (the counts are widened on the fly by the scan's input iterator: a separate transform pass was a launch and 12 bytes per count)
+    auto in = rocprim::make_transform_iterator(cnt_in, WidenU32());
+    size_t bytes = 0;
+    GSR_HIP(rocprim::exclusive_scan(nullptr, bytes, in, off, (int64_t)0, (size_t)count, rocprim::plus<int64_t>(), st));
+    GSR_TRY(c->rocprim_tmp.reserve(bytes));
+    GSR_HIP(rocprim::exclusive_scan(c->rocprim_tmp.p, bytes, in, off, (int64_t)0, (size_t)count, rocprim::plus<int64_t>(), st));
+    return GSR_OK;
 }
 int32_t LevelRun::total_of(const int64_t* off, const unsigned* cnt_in, int64_t count, int64_t* out) {
     Collect q;
@@ -4476,7 +4488,7 @@ int32_t LevelRun::grid_phase() {
         hipLaunchKernelGGL(k_prep, grd, blk, 0, st, n, L.xyz.as<float>(), L.color.as<float>(), L.cov6.as<float>(), L.opacity.as<float>(),
                            L.weight.as<float>(), L.is_parent.as<uint8_t>(), c->rec.as<float4>(), c->bbox_part.as<unsigned>(), (const long long*)nullptr);
         hipLaunchKernelGGL(k_bbox_reduce, dim3(1), dim3(256), 0, st, (int)grd.x, c->bbox_part.as<unsigned>(), c->bbox.as<unsigned>(),
-                           (unsigned*)cnt, 16, c->hist.as<unsigned>(), 3 * HIST_BINS);
+                           (unsigned*)cnt, 16, c->hist.as<unsigned>(), 3 * HIST_BINS, (unsigned*)nullptr, 0);
         if (part) {     // the box of ALL ranks' components: maximum of the (order-preserving) codes, the minima complemented
             hipLaunchKernelGGL(k_flip3, dim3(1), dim3(64), 0, st, c->bbox.as<unsigned>());
             GSR_TRY(gsr_comm_allreduce(c->comm, c->bbox.p, 6, GSR_DT_U32, GSR_OP_MAX, (void*)st));
@@ -4576,8 +4588,11 @@ int32_t LevelRun::grid_phase() {
     c->stats_ex[0] = n_irr;
     // the candidate stream of pass A (non-parents only) and its prefix table
     GSR_TRY(c->Ac.reserve(((size_t)(n - P_all) + SEL_PAD) * 16)); GSR_TRY(c->cellStartC.reserve(((size_t)gp.ncells + 1) * 4));
+    const bool have_irr = part || n_irr > 0;
+    if (have_irr) GSR_TRY(c->cellStartI.reserve(((size_t)gp.ncells + 1) * 4));
     hipLaunchKernelGGL(k_child_stream, grd, blk, 0, st, n, (int64_t)gp.ncells, P_all, c->A.as<float4>(), c->pflag.as<int>(), c->ppos.as<int>(),
-                       c->cellStart.as<int>(), c->Ac.as<float4>(), c->cellStartC.as<int>(), (int)SEL_PAD);
+                       c->cellStart.as<int>(), c->Ac.as<float4>(), c->cellStartC.as<int>(), (int)SEL_PAD,
+                       have_irr ? c->irank.as<int>() : (const int*)nullptr, c->cellStartI.as<int>());
     GSR_CHECKPOINT("grid + gather");
     GSR_TIME(c->ev[1], st);
     return GSR_OK;
@@ -4595,7 +4610,7 @@ int32_t LevelRun::select_phase() {
     sa.A = c->A.as<float4>(); sa.geo = c->geo.as<float4>();
     sa.Rs = c->Rs.as<float>(); sa.plist = c->plist.as<unsigned>(); sa.cellStart = c->cellStart.as<int>();
     sa.gp = c->gparams.as<GridParams>(); sa.P = P;
-    sa.Ac = c->Ac.as<float4>(); sa.cellStartC = c->cellStartC.as<int>();
+    sa.Ac = c->Ac.as<float4>(); sa.cellStartC = c->cellStartC.as<int>(); sa.cellStartI = c->cellStartI.as<int>();
     sa.irank = c->irank.as<int>(); sa.ipos = c->ipos.as<unsigned>(); sa.n_irr = n_irr; sa.ell = c->use_ell ? 1 : 0;
     // work sharding: rank r of W evaluates the contiguous run [P r / W, P (r+1) / W) of the cell-sorted parents
     own_lo = sharded ? (int)((int64_t)P * c->shard_rank / c->shard_world) : 0;
@@ -4776,7 +4791,7 @@ int32_t LevelRun::sums_fixed() {
         GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * 4)); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
     }
     GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
-    GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
+    if (sharded) GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));      // (one GPU: the level's prologue cleared the cursors, k_bbox_reduce)
     (void)hipGetLastError();
     GSR_TIME(c->evm[2], st);
     launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),

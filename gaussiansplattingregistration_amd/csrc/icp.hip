@@ -459,6 +459,133 @@ __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restr
     }
 }
 
+// The search of a FINE level (rings == 1: the correspondence distance is at most one cell, so the 27 cells around the query's hold every
+// neighbour that can be accepted) over an LDS-staged tile.  k_icp_nn walks the grid per thread: 27 cell spans, two dependent table
+// look-ups and a chain of point loads each, every lane with its own trip counts -- 24 % of the lanes at work, ~3 000 issue slots per
+// query (profiles/r04t_pmc_icp.json).  The source is sorted by the target's cells, so the 256 queries of a workgroup sit in a run of
+// consecutive cells: ONE box of cells [xlo, xhi] x [ylo, yhi] x [zlo, zhi] around their cells (+ 1 ring) holds all their candidates.
+// Its rows are contiguous runs of the cell-sorted target: the workgroup copies them into LDS with coalesced loads (and the rows' cell
+// table with them), and every lane then scans its 3 x 3 spans of three cells from LDS.  Same candidates, same float64 distance, same
+// tie rule (lowest input index): the same neighbour as icp_nearest<0>, whatever the order.  A workgroup whose box does not fit (more
+// than ICP_TILE_ROWS rows or ICP_TILE_PTS points: queries far apart -- the ends of a level's source, a source that moved by cells)
+// searches the old way.
+#define ICP_TILE_ROWS 16
+#define ICP_TILE_PTS 3840
+#define ICP_TILE_XW 256
+#define ICP_TILE_LDS (ICP_TILE_PTS * 16 + ICP_TILE_ROWS * ICP_TILE_XW * 4)
+template <bool FROM_STATE>
+__global__ __launch_bounds__(256) void k_icp_nn_tile(int64_t ns, const float* __restrict__ src, Xform X, const IcpState* __restrict__ st,
+                                                     IcpGrid g, const int* __restrict__ cellStart, const float4* __restrict__ Tq,
+                                                     double max_corr2, int* __restrict__ nn_j, int nb_logical) {
+    extern __shared__ float4 s_dyn[];
+    float4* s_pts = s_dyn;                                             // the staged target points of the box, row after row
+    int* s_cs = reinterpret_cast<int*>(s_dyn + ICP_TILE_PTS);          // [rows][xw + 1]: cell starts as indices into s_pts
+    __shared__ int s_box[6];                                           // min / max cell of the workgroup's queries
+    __shared__ int s_gs[ICP_TILE_ROWS], s_off[ICP_TILE_ROWS + 1];      // a row's first point in Tq / in s_pts
+    __shared__ int s_ok;
+    double T[12];
+    if (FROM_STATE) {
+        if (icp_state_done(st)) return;
+        icp_state_T(st, T);
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) T[i] = X.m[i];
+    }
+    const IcpRange rg = icp_block_range(ns, nb_logical < 0 ? -nb_logical : nb_logical, nb_logical > 0);
+    if (rg.row < 0) return;
+    for (int64_t base = rg.lo; base < rg.hi; base += blockDim.x) {
+        const int64_t i = base + threadIdx.x;
+        const bool live = i < rg.hi;
+        double px = 0.0, py = 0.0, pz = 0.0;
+        int cx = 0, cy = 0, cz = 0;
+        bool finite = false;
+        if (live) {
+            const double x = (double)src[3 * i], y = (double)src[3 * i + 1], z = (double)src[3 * i + 2];
+            px = T[0] * x + T[1] * y + T[2] * z + T[3];
+            py = T[4] * x + T[5] * y + T[6] * z + T[7];
+            pz = T[8] * x + T[9] * y + T[10] * z + T[11];
+            finite = px == px && py == py && pz == pz;
+            cx = icp_cell(px, g.ox, g.inv_c, g.gx); cy = icp_cell(py, g.oy, g.inv_c, g.gy); cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
+        }
+        if (threadIdx.x < 3) { s_box[threadIdx.x] = 0x7fffffff; s_box[3 + threadIdx.x] = -1; }
+        __syncthreads();
+        if (live && finite) {
+            atomicMin(&s_box[0], cx); atomicMin(&s_box[1], cy); atomicMin(&s_box[2], cz);
+            atomicMax(&s_box[3], cx); atomicMax(&s_box[4], cy); atomicMax(&s_box[5], cz);
+        }
+        __syncthreads();
+        const int xlo = s_box[0] - 1 > 0 ? s_box[0] - 1 : 0, xhi = s_box[3] + 1 < g.gx - 1 ? s_box[3] + 1 : g.gx - 1;
+        const int ylo = s_box[1] - 1 > 0 ? s_box[1] - 1 : 0, yhi = s_box[4] + 1 < g.gy - 1 ? s_box[4] + 1 : g.gy - 1;
+        const int zlo = s_box[2] - 1 > 0 ? s_box[2] - 1 : 0, zhi = s_box[5] + 1 < g.gz - 1 ? s_box[5] + 1 : g.gz - 1;
+        const int ny = yhi - ylo + 1, nz = zhi - zlo + 1, xw = xhi - xlo + 1;
+        const int rows = s_box[3] < 0 ? 0 : ny * nz;                    // (no finite query at all: nothing to stage)
+        bool ok = rows > 0 && rows <= ICP_TILE_ROWS && xw + 1 <= ICP_TILE_XW;
+        if (ok && (int)threadIdx.x < rows) {
+            const int y = ylo + (int)threadIdx.x % ny, z = zlo + (int)threadIdx.x / ny;
+            const int rowbase = (z * g.gy + y) * g.gx;
+            s_gs[threadIdx.x] = cellStart[rowbase + xlo];
+            s_off[threadIdx.x + 1] = cellStart[rowbase + xhi + 1] - s_gs[threadIdx.x];       // (its length for now)
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int tot = 0;
+            s_off[0] = 0;
+            if (ok) for (int r = 0; r < rows; ++r) { const int len = s_off[r + 1]; s_off[r + 1] = tot + len; tot += len; }
+            s_ok = ok && tot <= ICP_TILE_PTS ? 1 : 0;
+        }
+        __syncthreads();
+        ok = s_ok != 0;
+        int best = -1;
+        double bd = max_corr2;
+        if (ok) {
+            // the box's points and its cell table into LDS: contiguous runs of Tq / cellStart, consecutive lanes on consecutive addresses
+            const int total = s_off[rows];
+            for (int t = threadIdx.x; t < total; t += blockDim.x) {
+                int r = 0;
+                while (t >= s_off[r + 1]) ++r;
+                s_pts[t] = Tq[s_gs[r] + (t - s_off[r])];
+            }
+            for (int t = threadIdx.x; t < rows * (xw + 1); t += blockDim.x) {
+                const int r = t / (xw + 1), x = t - r * (xw + 1);
+                const int y = ylo + r % ny, z = zlo + r / ny;
+                s_cs[t] = cellStart[(z * g.gy + y) * g.gx + xlo + x] - s_gs[r] + s_off[r];
+            }
+            __syncthreads();
+            if (live && finite) {
+                unsigned best_i = 0xffffffffu;
+                int bk = -1, br = 0;
+                const int xa = (cx - 1 > 0 ? cx - 1 : 0) - xlo, xb = (cx + 1 < g.gx - 1 ? cx + 1 : g.gx - 1) - xlo;
+#pragma unroll 1
+                for (int dz = -1; dz <= 1; ++dz) {
+                    const int z = cz + dz;
+                    if (z < 0 || z >= g.gz) continue;
+#pragma unroll 1
+                    for (int dy = -1; dy <= 1; ++dy) {
+                        const int y = cy + dy;
+                        if (y < 0 || y >= g.gy) continue;
+                        const int r = (z - zlo) * ny + (y - ylo);
+                        const int s = s_cs[r * (xw + 1) + xa], e = s_cs[r * (xw + 1) + xb + 1];
+                        for (int k = s; k < e; ++k) {
+                            const float4 q = s_pts[k];
+                            const double dx = px - (double)q.x, dyy = py - (double)q.y, dzz = pz - (double)q.z;
+                            const double d2 = dx * dx + dyy * dyy + dzz * dzz;
+                            const unsigned qi = __float_as_uint(q.w);
+                            if (d2 < bd || (d2 == bd && qi < best_i)) { bd = d2; bk = k; br = r; best_i = qi; }
+                        }
+                    }
+                }
+                if (bk >= 0) best = s_gs[br] + (bk - s_off[br]);
+            }
+        } else if (live) {
+            double d2;
+            best = icp_nearest<0>(g, cellStart, Tq, px, py, pz, d2, max_corr2);
+            bd = d2;
+        }
+        if (live) nn_j[i] = (best >= 0 && bd < max_corr2) ? best : -1;
+        __syncthreads();
+    }
+}
+
 __device__ __forceinline__ double icp_weight(int loss, double k, double r) {   // Open3D RobustKernel.cpp
     switch (loss) {
         case GSR_LOSS_TUKEY: { double t = fmin(1.0, fabs(r) / k); double u = 1.0 - t * t; return u * u; }
@@ -1517,6 +1644,11 @@ struct gsr_icp_ctx {
     bool src_sorted = false;
     bool device_loop = true;        // GSR_ICP_DEVICE_LOOP=0 selects the host-driven loop
     bool block_search = true;       // GSR_ICP_BLOCK_SEARCH=0: always the ring loop from ring 0
+    int tile_search = 0;            // GSR_ICP_TILE: the search of a fine level (rings == 1) over LDS-staged tiles (k_icp_nn_tile): 0 (default) = never, -1 = where
+                                    // the search has its own kernel (nn_mode), 1 = also for gsr_icp_correspondences on any size (tests).  Built for VERDICT r04
+                                    // item 5 and measured SLOWER on the bench's converged 5 M x 5 M level: 1.21 against 0.39 ms per iteration
+                                    // (profiles/r05g_icp_tile_ab.txt) -- a workgroup stages 3 264 target points (12 rows of the grid) for its 256 queries, of
+                                    // which a converged query needs the six in its own row: the per-thread search reads what it needs, the tile what it might
     bool xcd_ranges = true;         // GSR_ICP_XCD=0: logical block = physical block (every XCD walks the whole source)
     bool fused_step = false;        // GSR_ICP_FUSED_STEP=1: the accumulate kernel's last workgroup does k_icp_step's (or k_icp_reduce's) work instead of a launch of its own: measured equal (44.8 vs 44.0 us at 185 k), so off
                                     // accumulate kernel's last workgroup
@@ -1566,6 +1698,23 @@ inline int icp_blocks(int64_t ns, int cap) {
     return (int)((ns + ppb - 1) / ppb);
 }
 inline int nn_grid1(int64_t ns) { return icp_blocks(ns, 16384); }      // grid of the search kernel: one thread per point, capped
+// the search kernel of one evaluation: over LDS tiles on a fine level (rings == 1), else per thread (27-cell block first where the
+// correspondence distance spans two cells or more: blockf)
+template <bool FROM_STATE>
+void launch_icp_nn(gsr_icp_ctx* c, hipStream_t st, const Xform& X, const IcpState* state, double mc2, bool blockf) {
+    const int g1 = nn_grid1(c->ns);
+    const dim3 grid(8 * ((g1 + 7) / 8)), blk(256);
+    const int nbl = c->xcd_ranges ? g1 : -g1;
+    if (c->tile_search != 0 && c->grid.rings == 1)
+        hipLaunchKernelGGL((k_icp_nn_tile<FROM_STATE>), grid, blk, ICP_TILE_LDS, st, c->ns, c->src.as<float>(), X, state, c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(),
+                           mc2, c->nn_j.as<int>(), nbl);
+    else if (blockf)
+        hipLaunchKernelGGL((k_icp_nn<FROM_STATE, 1>), grid, blk, 0, st, c->ns, c->src.as<float>(), X, state, c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2,
+                           c->nn_j.as<int>(), nbl);
+    else
+        hipLaunchKernelGGL((k_icp_nn<FROM_STATE, 0>), grid, blk, 0, st, c->ns, c->src.as<float>(), X, state, c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2,
+                           c->nn_j.as<int>(), nbl);
+}
 
 int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, double k, double* acc, bool timed) {
     if (!c->have_target || !c->have_source) return fail(GSR_E_INVALID, "icp: target and source must be set first");
@@ -1588,8 +1737,7 @@ int32_t run_accumulate(gsr_icp_ctx* c, const double* T, int kind, int loss, doub
     const int* nnj = nullptr;
     if (c->nn_mode()) {
         GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-        hipLaunchKernelGGL((k_icp_nn<false, 0>), dim3(8 * ((nn_grid1(c->ns) + 7) / 8)), dim3(256), 0, st, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                           c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>(), c->xcd_ranges ? nn_grid1(c->ns) : -nn_grid1(c->ns));
+        launch_icp_nn<false>(c, st, X, (const IcpState*)nullptr, mc2, false);
         nnj = c->nn_j.as<int>();
     }
     const ColorArgs cargs = {c->Ti.as<double>(), c->Tg.as<double>(), c->Si.as<double>(), sqrt(c->lambda_geometric), sqrt(1.0 - c->lambda_geometric)};
@@ -1703,6 +1851,9 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     // Environment knobs (all of them): none changes a result, tests/test_icp_gpu.py::test_icp_knobs_change_nothing
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
+    if (const char* e = getenv("GSR_ICP_TILE")) c->tile_search = atoi(e);
+    (void)hipFuncSetAttribute((const void*)k_icp_nn_tile<true>, hipFuncAttributeMaxDynamicSharedMemorySize, ICP_TILE_LDS);
+    (void)hipFuncSetAttribute((const void*)k_icp_nn_tile<false>, hipFuncAttributeMaxDynamicSharedMemorySize, ICP_TILE_LDS);
     if (const char* e = getenv("GSR_ICP_XCD")) c->xcd_ranges = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_ROBUST_BOX")) c->robust_allowed = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_ADAPT")) c->adapt_cells = atoi(e) != 0;
@@ -2076,14 +2227,7 @@ int32_t gsr_icp_register(gsr_icp_ctx* c, const double* init_T, int32_t kind, int
         if (blockf) { if (fuse == 0) GSR_ICP_ACC1(KIND, 1, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, 1, 1, TN, SC); else GSR_ICP_ACC1(KIND, 1, 2, TN, SC); } \
         else { if (fuse == 0) GSR_ICP_ACC1(KIND, 0, 0, TN, SC); else if (fuse == 1) GSR_ICP_ACC1(KIND, 0, 1, TN, SC); else GSR_ICP_ACC1(KIND, 0, 2, TN, SC); } \
     } while (0)
-                if (c->nn_mode()) {
-                    if (blockf)
-                        hipLaunchKernelGGL((k_icp_nn<true, 1>), dim3(8 * ((nn_grid1(c->ns) + 7) / 8)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
-                                           c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>(), c->xcd_ranges ? nn_grid1(c->ns) : -nn_grid1(c->ns));
-                    else
-                        hipLaunchKernelGGL((k_icp_nn<true, 0>), dim3(8 * ((nn_grid1(c->ns) + 7) / 8)), dim3(256), 0, st, c->ns, c->src.as<float>(), Xform(),
-                                           c->state.as<IcpState>(), c->grid, c->cellStart.as<int>(), c->Tq.as<float4>(), mc2, c->nn_j.as<int>(), c->xcd_ranges ? nn_grid1(c->ns) : -nn_grid1(c->ns));
-                }
+                if (c->nn_mode()) launch_icp_nn<true>(c, st, Xform(), c->state.as<IcpState>(), mc2, blockf);
                 if (kind == GSR_ICP_COLORED) GSR_ICP_ACC(3, c->Tn.as<double>(), (const double*)nullptr);
                 else if (kind == GSR_ICP_POINT_TO_POINT) GSR_ICP_ACC(0, (const double*)nullptr, (const double*)nullptr);
                 else if (kind == GSR_ICP_POINT_TO_PLANE) GSR_ICP_ACC(1, c->Tn.as<double>(), (const double*)nullptr);
@@ -2150,8 +2294,12 @@ int32_t gsr_icp_correspondences(gsr_icp_ctx* c, const double* T, int64_t* idx, d
     Xform X;
     for (int i = 0; i < 12; ++i) X.m[i] = T[i];
     GSR_TRY(c->nn_j.reserve((size_t)c->ns * 4));
-    hipLaunchKernelGGL((k_icp_nn<false, 0>), dim3(8 * ((nn_grid1(c->ns) + 7) / 8)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, (const IcpState*)nullptr, c->grid,
-                       c->cellStart.as<int>(), c->Tq.as<float4>(), c->max_corr * c->max_corr, c->nn_j.as<int>(), c->xcd_ranges ? nn_grid1(c->ns) : -nn_grid1(c->ns));
+    {   // (the ring loop per thread -- or, GSR_ICP_TILE=1 and a fine level, the tile search: the tests compare both with the oracle's KD-tree)
+        const int keep = c->tile_search;
+        if (keep != 1) c->tile_search = 0;
+        launch_icp_nn<false>(c, c->stream, X, (const IcpState*)nullptr, c->max_corr * c->max_corr, false);
+        c->tile_search = keep;
+    }
     hipLaunchKernelGGL(k_icp_correspond, dim3(stride_grid(c->ns)), dim3(256), 0, c->stream, c->ns, c->src.as<float>(), X, c->nn_j.as<int>(),
                        c->Tq.as<float4>(), c->src_sorted ? c->src_order.as<unsigned>() : (const unsigned*)nullptr, c->corr_idx.as<int64_t>(),
                        c->corr_d2.as<double>());

@@ -95,6 +95,68 @@ def test_correspondences_exact_adversarial(oracle, case):
     assert (idx >= 0).any()
 
 
+@pytest.mark.parametrize("case", ["plain", "offset", "ties", "lattice", "outside", "clustered", "moved"])
+def test_tile_search_of_a_fine_level_is_exact(monkeypatch, oracle, case):
+    """k_icp_nn_tile: on a fine level (the correspondence distance is at most one grid cell: rings == 1) a workgroup stages the target
+    points of the box around its 256 queries in LDS and every lane scans its 27 cells from there.  GSR_ICP_TILE=1 routes
+    gsr_icp_correspondences through it: the indices must be the oracle's KD-tree neighbours bit for bit -- duplicated target points
+    (ties to the lowest index), coordinates around 2000, queries on cell faces, queries far outside the target's box (clamped cells),
+    a clustered target (boxes that do not fit the tile fall back to the per-thread search), a source that moved by several cells since
+    it was sorted (boxes too large: fallback again)."""
+    from gaussiansplattingregistration_amd import icp
+    monkeypatch.setenv("GSR_ICP_TILE", "1")
+    rng = np.random.default_rng(23)
+    n = 60000
+    tgt = rng.uniform(-1.6, 1.6, (n, 3)).astype(np.float32)
+    src = (tgt[rng.permutation(n)] + rng.normal(0, 0.01, (n, 3))).astype(np.float32)
+    max_corr = 0.1                              # ~ one cell at two points per cell
+    T = np.eye(4)
+    T[:3, 3] = [0.01, -0.02, 0.005]
+    if case == "offset":
+        tgt = tgt + np.float32(2000.0); src = src + np.float32(2000.0)
+    elif case == "ties":
+        tgt = np.concatenate([tgt[:15000]] * 4); src = tgt[rng.permutation(len(tgt))[:n]].copy(); T = np.eye(4)
+    elif case == "lattice":
+        g = np.stack(np.meshgrid(*[np.arange(40)] * 3, indexing="ij"), -1).reshape(-1, 3).astype(np.float32) * np.float32(0.0625)
+        tgt = g; src = (g[rng.permutation(len(g))[:n]] + np.float32(0.03125)).astype(np.float32); max_corr = 0.06; T = np.eye(4)
+    elif case == "outside":
+        src[: n // 2] = (src[: n // 2] * 3.0).astype(np.float32)
+    elif case == "clustered":
+        tgt[: n // 2] = (tgt[: n // 2] * 0.02).astype(np.float32)
+    elif case == "moved":                        # the evaluation's transform is far from the one the source was sorted under
+        T[:3, 3] = [0.9, -0.7, 0.4]
+    with icp.IcpContext() as c:
+        c.set_target(tgt, None, max_corr)
+        c.set_source(src)
+        idx, d2 = c.correspondences(T)
+        idx0, d20 = c.correspondences(np.eye(4))
+    for TT, (gi, gd) in ((T, (idx, d2)), (np.eye(4), (idx0, d20))):
+        widx, wd2 = oracle.icp_correspond(src, tgt, TT, max_corr)
+        assert np.array_equal(gi, widx), (case, int((gi != widx).sum()))
+        assert np.allclose(gd, wd2, rtol=1e-12, atol=0)
+    assert (idx >= 0).any() or (idx0 >= 0).any()
+
+
+def test_tile_search_changes_no_registration(monkeypatch):
+    """A registration whose finest schedule entry searches over LDS tiles (the default from 400 k source points on when max_corr is at
+    most a cell) against the same with GSR_ICP_TILE=0 (every level searched per thread): transform, fitness, RMSE and iteration count
+    equal -- the neighbours are the same, the accumulate kernel does not know who found them."""
+    from gaussiansplattingregistration_amd import icp, synth
+    src, tgt, _ = synth.make_pair(450000, seed=14, sh_degree=0)
+    nrm = icp.normals_from_cov(tgt["cov6"])
+    res = {}
+    for tile in ("0", "-1"):
+        monkeypatch.setenv("GSR_ICP_TILE", tile)
+        out = []
+        for kind, nn in ((0, None), (1, nrm)):
+            r = icp.registration_icp_arrays(src["xyz"], tgt["xyz"], nn, np.eye(4), kind=kind, max_corr=0.07, max_iter=12)
+            out.append((r["transformation"], r["fitness"], r["inlier_rmse"], r["iterations"]))
+        res[tile] = out
+    for a, b in zip(res["0"], res["-1"]):
+        assert np.abs(a[0] - b[0]).max() < 1e-12 and a[3] == b[3] and abs(a[1] - b[1]) < 1e-15 and abs(a[2] - b[2]) < 1e-12
+    assert res["0"][0][1] > 0.5
+
+
 def test_accumulators_match_numpy():
     from gaussiansplattingregistration_amd import icp, synth
     src, tgt, _ = synth.make_pair(20000, seed=8, sh_degree=0)
