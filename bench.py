@@ -68,7 +68,7 @@ def kernel_build_id():
     """Identifies the kernel sources a PMC summary belongs to (profiles/*_pmc.json carry it): the counter passes run
     scripts/prof_hem.py, the HEM level alone, so the HEM sources."""
     h = hashlib.sha256()
-    for f in ("hem.hip", "gsr_math.h", "gsr_common.h"):
+    for f in ("hem.hip", "hem_select.hip", "hem_select.h", "hem_device.h", "gsr_math.h", "gsr_common.h"):
         h.update(open(os.path.join(ROOT, "gaussiansplattingregistration_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 

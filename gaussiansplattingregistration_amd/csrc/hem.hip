@@ -51,6 +51,8 @@
 #include "gsr_common.h"
 #include "gsr_math.h"
 #include "gsr_test_hooks.h"
+#include "hem_device.h"
+#include "hem_select.h"
 
 #include <float.h>
 #include <math.h>
@@ -94,114 +96,6 @@ void GlibcRng::seed(uint32_t s) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// device-side structures
-// ------------------------------------------------------------------------------------------------
-struct GridParams {
-    float ox, oy, oz;      // origin (bbox min of the finite points)
-    float c, inv_c;        // cell edge and its reciprocal
-    float slack;           // absolute slack used when culling rows (covers float rounding of cell_of)
-    int gx, gy, gz;        // grid dimensions
-    int ncells;
-};
-
-__device__ __forceinline__ unsigned enc_f(float f) {      // order-preserving float -> uint
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __host__ inline float dec_f(unsigned u) {
-    unsigned v = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
-    float f;
-    memcpy(&f, &v, 4);
-    return f;
-}
-
-// Monotone non-decreasing map coordinate -> cell index in [0, g-1]; NaN -> 0.
-__device__ __forceinline__ int cell_of(float v, float o, float inv_c, int g) {
-    float t = (v - o) * inv_c;
-    t = fminf(fmaxf(t, 0.0f), (float)(g - 1));
-    return (int)t;
-}
-
-// XCD-aware block remap (MI355X: 8 XCDs, each with its own 4 MiB L2; blocks are dealt round-robin over
-// the XCDs).  Blocks b, b+8, b+16, ... share an XCD, so give them CONSECUTIVE logical tiles: every XCD
-// then sweeps its own contiguous run of cell-sorted parents and the children they share stay in that
-// XCD's L2.  Launch with a grid of 8*ceil(nblk/8) blocks; returns -1 for the padding blocks.
-__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
-    const int chunk = (nblk + 7) >> 3;
-    const int t = (bid & 7) * chunk + (bid >> 3);
-    return t < nblk ? t : -1;
-}
-
-// Processing slot of a block.  The first `hb` blocks (heavy parents, launched first) keep the natural
-// order; the remaining blocks (light parents in Z-order) are dealt to the XCDs in contiguous chunks so
-// that every XCD's L2 serves one compact 3-D region.  hb is a multiple of 8, so (bid - hb) & 7 is still
-// the XCD group of the block.  Returns -1 for padding blocks.
-__device__ __forceinline__ int block_slot(int bid, int nblk, int hb, int xcd) {
-    if (!xcd) return bid < nblk ? bid : -1;
-    if (bid < hb) return bid < nblk ? bid : -1;
-    const int t = xcd_remap(bid - hb, nblk - hb);
-    return t < 0 ? -1 : hb + t;
-}
-
-__device__ __forceinline__ float wave_min(float v) {
-    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_max(float v) {
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-// Sums across lanes WITHOUT the LDS crossbar (a ds_bpermute costs a SIMD 24 cycles of LDS-pipe issue, scripts/micro/
-// valu_issue.hip; the 14 butterfly sums of the first M-step were 84 of them per parent): rotations inside a row of 16
-// lanes by DPP, rows by gfx950's v_permlane16_swap / v_permlane32_swap.  Every lane must be active.
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) {
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, false));
-}
-__device__ __forceinline__ float swap16_sum(float v) {          // v[l] + v[l ^ 16]
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-__device__ __forceinline__ float swap32_sum(float v) {          // v[l] + v[l ^ 32]
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
-    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
-}
-// the row-local part of class_sum<1>: every lane ends with the total of its row of 16 lanes (the same rotations in the same order)
-__device__ __forceinline__ float row_sum16(float v) {
-    v += dpp_f<0x128>(v);
-    v += dpp_f<0x124>(v);
-    v += dpp_f<0x122>(v);
-    v += dpp_f<0x121>(v);
-    return v;
-}
-// the row-local part of class_sum<G>: the total of the lanes l' == l (mod G) of the lane's own row
-template <int G>
-__device__ __forceinline__ float row_class_sum(float v) {
-    if (G <= 8) v += dpp_f<0x128>(v);
-    if (G <= 4) v += dpp_f<0x124>(v);
-    if (G <= 2) v += dpp_f<0x122>(v);
-    if (G <= 1) v += dpp_f<0x121>(v);
-    return v;
-}
-// sum over the lanes l' == l (mod G), G a power of two: every lane ends with the total of its residue class
-template <int G>
-__device__ __forceinline__ float class_sum(float v) {
-    if (G <= 8) v += dpp_f<0x128>(v);        // row_ror:8
-    if (G <= 4) v += dpp_f<0x124>(v);        // row_ror:4
-    if (G <= 2) v += dpp_f<0x122>(v);        // row_ror:2
-    if (G <= 1) v += dpp_f<0x121>(v);        // row_ror:1
-    if (G <= 16) v = swap16_sum(v);
-    if (G <= 32) v = swap32_sum(v);
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------------
 // k_prep: det, parent query radius, bounding box of the finite centres
 //   radius = delta * sqrtf(lambda_max)                       (mixture.cpp:88)
 // ------------------------------------------------------------------------------------------------
@@ -217,15 +111,6 @@ __device__ __forceinline__ float class_sum(float v) {
 //   float64 roundings of their largest term, so "minor > 1e-12 a00 a11" and "det > 1e-9 (sum of |terms|)" certify positive
 //   definiteness (Sylvester) and a determinant good to 1e-6 relative.
 #define ERASE_MAX 32          // erased rows a level compacts in place on the device (k_erase_save / k_erase_shift); more: the host path
-#define GSR_DET_TOL 0.04           // |det_float32 / det - 1| allowed for a regular component (enters the filter bound as is)
-__device__ __forceinline__ bool spd_det64(double a00, double a01, double a02, double a11, double a12, double a22, double& det) {
-    const double m2 = a00 * a11 - a01 * a01;
-    const double t1 = a00 * (a11 * a22 - a12 * a12), t2 = a01 * (a01 * a22 - a12 * a02), t3 = a02 * (a01 * a12 - a11 * a02);
-    det = t1 - t2 + t3;
-    const double mag = fabs(a00) * (fabs(a11 * a22) + a12 * a12) + fabs(a01) * (fabs(a01 * a22) + fabs(a12 * a02)) +
-                       fabs(a02) * (fabs(a01 * a12) + fabs(a11 * a02));
-    return a00 > 0.0 && a11 > 0.0 && a22 > 0.0 && m2 > 1e-12 * a00 * a11 && det > 1e-9 * mag && mag < 1e300;
-}
 __device__ __forceinline__ bool is_regular(const s6& c, float det, float x, float y, float z) {
     const float big = 1e12f;
     if (!(fabsf(x) < big && fabsf(y) < big && fabsf(z) < big)) return false;
@@ -477,6 +362,9 @@ __global__ void k_fill_const(int64_t n, OffT* p, OffT v) {
 
 // Sorted working set.
 //   radius = delta * sqrtf(lambda_max) for the parents                       (mixture.cpp:88)
+// (ONE trip per wave, no grid-stride loop: with MachineLICM -- this translation unit is built with it since round 5 -- the compiler hoisted
+// the float64 constants of eig_max6 out of the loop into 116 VGPRs and halved the occupancy of a kernel that is nothing but gather
+// latency.  Launch with ceil(n / 256) workgroups.)
 __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __restrict__ order, const float4* __restrict__ rec, float delta,
                                                 float4* __restrict__ A, float4* __restrict__ geo, float* __restrict__ Rs,
                                                 int* __restrict__ pflag, int* __restrict__ iflag,
@@ -491,7 +379,8 @@ __global__ __launch_bounds__(256) void k_gather(int64_t n, const unsigned* __res
     // the last row of the level's SH array, padded with zeros: the M-step reads THAT row here (load4_unaligned)
     if (sh_tail && blockIdx.x == 0)
         for (int t = threadIdx.x; t < ((F + 3) & ~3) + 4; t += blockDim.x) sh_tail[t] = t < F ? sh[(n - 1) * F + t] : 0.0f;
-    for (int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < n; base += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t base = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63);
+    if (base < n) {
         const int64_t j = base + lane;
         const unsigned oi = j < n ? order[j] : 0u;
         // (the four rounds' loads together, pinned in front of the stores: inside `if (base + r < n)` every round was a round trip of its
@@ -621,832 +510,6 @@ __global__ __launch_bounds__(256) void k_child_stream(int64_t n, int64_t cells, 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_select: child selection (mixture.cpp:102-137) and wL_si (mixture.cpp:140-164), one wavefront per parent
-//
-//   rows      the grid rows (fixed y,z cell) that meet the parent's search region; lane r of a 64-row batch computes
-//             the contiguous span [s, s+len) of sorted components of its row (x-clipped to the sphere, and to the
-//             pre-reject ellipsoid for a regular parent)
-//   stream    the spans of a batch form one flattened index space [0, total); lane l of chunk c0 handles candidate
-//             c0 + l.  Its row comes from a BIT MASK in LDS (bit p set <=> a row starts at flat position p): one
-//             broadcast 8-byte LDS read per chunk and two v_mbcnt give every lane the number of row starts at or
-//             before it, one ds_bpermute fetches that row's (start - prefix).  (The six-step binary search by lane
-//             shuffles this replaces was a chain of six DEPENDENT ds_bpermute per chunk: 24 cycles of LDS-pipe issue
-//             each, scripts/micro/valu_issue.hip.)
-//   stage 1   a conservative filter, not a decision: for a regular parent the squared Mahalanobis distance in
-//             whitened form |U d|^2 (U = Cholesky factor of P^-1, nine fused multiply-adds) against the pre-reject
-//             bound + 1 %; for an irregular parent, and for the irregular children (pass B), the reference's own
-//             radius test.  Survivors are compacted (ballot + mbcnt) into a per-wave LDS ring.
-//   stage 2   on full batches of 64 survivors, the reference's float32 expressions bit for bit: radius test
-//             d2 < R^2 (pointindex.cpp:137), colour gate, KL gate, parent rule (mixture.cpp:122-133).  The KL gate's
-//             logf is decided with the hardware v_log_f32 when the result is farther from the threshold than its
-//             error bound, and with glibc's own algorithm (gsr_math.h) otherwise -- the decision is the reference's
-//             in both cases.  Accepted pairs go to a second LDS queue.
-//   stage 3   likelihood (mixture.cpp:54-64) on full batches of 64 accepted pairs, pair records out.
-//   modes     COUNT  only counts accepted pairs (first pass of the two-pass fallback)
-//             FILL   writes pairs at poff[p]  (second pass of the fallback)
-//             SPARSE single pass: writes pairs at coff[p] (capacity = candidates scanned, from k_spans), count to
-//                    pcnt[p]; k_compact_pairs then packs them
-// ------------------------------------------------------------------------------------------------
-struct ParentRec;
-struct SelectArgs {
-    const float4* A;                // compact {x, y, z, flags}
-    const float4* geo;              // 64-byte records {A, B, C, D}
-    const float* Rs;
-    const unsigned* plist;
-    const unsigned* porder;         // processing order of the parents (heavy ones first), or NULL = natural order
-    int xcd;                        // 1 = light parents are dealt to the XCDs in contiguous chunks (block_slot)
-    const int* nheavy;              // device: number of heavy parents at the head of porder
-    int own_lo, own_hi;             // sharded level: this rank evaluates parents [own_lo, own_hi) of plist only
-    const int* cellStart;
-    // pass A streams the NON-PARENT components only (a parent can be claimed by no parent but itself, mixture.cpp:131-133, and
-    // that pair is queued directly): Ac = their {x, y, z, (sorted position << 2) | flags} in cell order, cellStartC = the grid's
-    // prefix table counted over them.  A third of the components are parents.
-    const float4* Ac;
-    const int* cellStartC;
-    const int* cellStartI;          // the same table counted over the irregular components (the list pass B scans); only when n_irr > 0
-    const double* logtab;           // glibc logf table (LDS copy)
-    const int* irank;               // irank[j] = number of irregular components among sorted positions [0, j)   (n + 1 entries)
-    const unsigned* ipos;           // sorted positions of the irregular components, ascending
-    int n_irr;
-    int ell;                        // 1 = clip the grid rows of a regular parent to its Mahalanobis ellipsoid
-    const GridParams* gp;
-    int P;
-    float colorThr2;                // largest float x with sqrtf(x) <= kappa^2 / 2: the colour gate on the squared colour distance
-    float kldThr, tau2;
-    const ParentRec* prec;          // [P] per-parent records (k_parent_prep)
-    unsigned* pcnt;                 // COUNT / SPARSE out: accepted pairs per parent
-    unsigned* pcap;                 // k_spans out: candidates scanned per parent
-    const int64_t* poff;            // FILL: compact offsets;  SPARSE: capacity offsets
-    unsigned* pair_child;
-    float* pair_wl;
-    // heavy parents (the first *nheavy slots of porder) are cut into work items of SEL_PART candidates of their flat
-    // candidate space; a fixed number of workgroups at the head of the launch pulls the items from a queue
-    const uint2* hitem;             // item -> (slot in porder, part)
-    const int* hfirst;              // [P] first item of a heavy parent, -1 for the others
-    unsigned* part_cnt;             // accepted pairs per item (COUNT / SPARSE out, FILL in)
-    int* hq;                        // hq[0] = number of items, hq[1] = queue cursor
-    int heavy_blocks;               // workgroups at the head of the launch that serve the queue (0 = no splitting)
-    const unsigned* part_p;         // device: candidates per work item (<= SEL_PART; smaller on small levels, where an item is the critical path) -- k_heavy_items
-                                    // derives it from the level's candidate total, which the host of an asynchronous level never sees
-    // SPARSE: the pair buffers hold cap_pairs entries.  A segment that would end beyond them is SKIPPED (its parent gets no pairs) and
-    // *abort_p is raised: an asynchronous level sizes nothing from the candidate total -- it runs on the buffers the context has and
-    // reruns synchronously when they were too small -- so every write has to be clamped on the device.  0 = unchecked
-    unsigned long long cap_pairs;
-    int* abort_p;
-    int np;                         // light parents per wave (1 ... SEL_NP), see SEL_NP
-    int2* rowlist;                  // [P][2][SEL_ROWS]: the non-empty row spans {first position, length} of pass A / pass B in scan order (k_spans), or NULL
-};
-
-enum { SEL_COUNT = 0, SEL_FILL = 1, SEL_SPARSE = 2 };
-#define SEL_PART 8192         // candidates per work item of a heavy parent, at most (SelectArgs::part)
-#define SEL_HEAVY_BLOCKS 2048  // workgroups at the head of k_select that serve the queue of heavy work items (a multiple of 8)
-#define SEL_QCAP 256          // survivor ring (power of two >= 64 + SEL_U*64: the rest of a batch -- or 63 entries and a parent's own -- plus a group of chunks)
-#define SEL_U 3               // chunks whose candidate loads are in flight together (2 or 3: equal, 4: +1 %, 6: +2 %, 8: +14 % -- registers)
-#define SEL_MCAP 1024         // flat positions covered by the row-start bit mask at a time (a parent scans ~500 candidates; LDS is allocated in granules of 1 280 bytes and the workgroup sits just under eight)
-#define SEL_ROWS 16           // non-empty row spans per parent and pass that k_spans hands to k_select (a parent with more recomputes them)
-#define SEL_PAD (64 * SEL_U)  // entries the sorted A array is padded by: the inactive lanes of a batch's last chunks read past the last row
-
-// Everything k_select / k_spans need to know about a parent, computed ONCE per parent by k_parent_prep (one thread each)
-// and fetched by the selection waves with scalar loads: the cofactor inverse, the clipping and whitening constants cost
-// ~300 vector instructions, which every one of the 64 lanes of a wave used to repeat for its parent (17 % of k_select).
-struct EllClip {
-    float on;                 // 1.0f = clip (regular parent with a sane Schur complement)
-    float k11, k12, k22, kr, im00, m01, m02, T;
-};
-struct ParentRec {            // 40 dwords
-    f3 pm, pcol;
-    s6 pinv;
-    float det_p, inv_det_p, pweight, R, R2;
-    float white;              // 1.0f = stage 1 uses the whitened Mahalanobis filter (regular parent)
-    float u00, u01, u02, u11, u12, u22;   // upper Cholesky factor of pinv
-    float T1;                 // filter bound on |U d|^2: the pre-reject bound + 1 %
-    EllClip ec;
-    int js;
-    int active;               // 0: zero / NaN radius or non-finite mean -> no children at all
-    int selfq;                // 1: regular parent -- it is not in the stream of pass A and queues itself (flat candidate 0)
-    float ey, ez;             // half extents of the pre-reject ellipsoid along y and z (+0.1 %): no row of pass A lies beyond them
-    int rows;                 // written by k_spans: bit 31 = the row lists of this parent are valid; bits 0-7 / 8-15 = non-empty rows of pass A / B
-                              // (0xff = more than SEL_ROWS: that pass recomputes its spans)
-};
-static_assert(sizeof(ParentRec) == 160, "ParentRec is fetched as 40 dwords");
-
-__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }       // v_sqrt_f32, 1 ulp: clipping margins only
-
-// popc(mask & lanes below this one) + base, two VALU instructions
-__device__ __forceinline__ int mbcnt64(unsigned long long mask, int base) {
-    return (int)__builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, (unsigned)base));
-}
-__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
-    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-           (unsigned)__builtin_amdgcn_readfirstlane((int)v);
-}
-// inclusive prefix sum over the 64 lanes by DPP row shifts / row broadcasts (six VALU instructions, no LDS traffic);
-// every lane must be active
-__device__ __forceinline__ int wave_incl_scan(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);      // row_shr:1
-    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);      // row_shr:2
-    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);      // row_shr:4
-    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);      // row_shr:8
-    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);      // row_bcast:15 into rows 1, 3
-    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);      // row_bcast:31 into rows 2, 3
-    return v;
-}
-
-// GSR_SELECT_PROFILE (variant builds only, scripts/select_profile.py): where a selection wave spends its clock -- s_memtime deltas
-// of the phases, summed over all waves with one atomic per phase and parent
-#ifdef GSR_SELECT_PROFILE
-__device__ unsigned long long g_sel_prof[1024 * 16];       // 1024 copies (by workgroup): atomics on ONE address from 10^6 waves serialise
-#define SEL_PROF_T(var) const unsigned long long var = __builtin_amdgcn_s_memtime()
-#define SEL_PROF_ADD(slot, t0, lane) do { if ((lane) == 0) atomicAdd(&g_sel_prof[(blockIdx.x & 1023u) * 16 + (slot)], __builtin_amdgcn_s_memtime() - (t0)); } while (0)
-#define SEL_PROF_CNT(slot, v, lane) do { if ((lane) == 0) atomicAdd(&g_sel_prof[(blockIdx.x & 1023u) * 16 + (slot)], (unsigned long long)(v)); } while (0)
-#else
-#define SEL_PROF_T(var)
-#define SEL_PROF_ADD(slot, t0, lane)
-#define SEL_PROF_CNT(slot, v, lane)
-#endif
-
-// Parents per wave.  A wave takes up to SEL_NP consecutive slots of the processing order (neighbours on the Z-order curve) ONE AFTER
-// THE OTHER and keeps the survivor ring and the third-stage queue ACROSS them: stage 2 and stage 3 run on full batches of 64
-// whatever parent the entries belong to (a surfel-like parent leaves 57 survivors and 7 pairs -- alone it runs stage 2 at 52 % and
-// stage 3 at 10 % of the lanes), and only the wave's last batches are partial.  A ring entry carries its parent's number k in the
-// bits above the sorted position (positions are < 2^30: the stream packs `position << 2 | flags` into 32 bits), and what stages
-// 2 / 3 need of parent k they read per lane from LDS (struct ParLds) instead of the scalar registers -- which also takes 17 dwords
-// of every parent out of the SGPR file.  The rings are FIFO and the parents are scanned in turn, so every parent's pairs come out in
-// exactly the order (and at exactly the places) the one-parent-per-wave form wrote them.
-#define SEL_NP 4
-#define SEL_TAG_SHIFT 30
-#define SEL_TAG_MASK 0x3fffffffu
-struct __attribute__((aligned(16))) ParLds {      // 20 dwords; the first 16 are the head of the parent's ParentRec as it lies in memory
-    float4 r0;                                    // pm.x, pm.y, pm.z, pcol.x
-    float4 r1;                                    // pcol.y, pcol.z, pinv.e00, pinv.e01
-    float4 r2;                                    // pinv.e02, pinv.e11, pinv.e12, pinv.e22
-    float4 r3;                                    // det_p, inv_det_p, pweight, R
-    float R2;
-    int js;
-    int64_t base;                                 // FILL / SPARSE: where the parent's (this work item's) pairs go
-};
-static_assert(sizeof(ParLds) == 80, "ParLds is read as four float4 and two 8-byte words");
-
-// Third-stage queue (per wave, in LDS): the accepted pairs wait here until 64 of them fill a wavefront, so that
-// the likelihood (two expf, two sqrtf, two IEEE divisions) runs on full waves instead of the ~26 % of the lanes
-// that pass the KL gate.  rel = the pair's rank among its parent's accepted pairs: it goes to ParLds::base + rel.
-#define SEL_Q3CAP 128
-struct Q3 {
-    unsigned *j, *rel;             // j keeps the parent tag
-    float *d2, *cd, *op, *det;
-    int h, n;                      // head, fill (wave-uniform)
-};
-
-// wL_si = w_s * clamp(hemLikelihoodOpacity, FLT_MIN, 1e8)   (mixture.cpp:54-64,155-158) for `cnt` queued pairs
-__device__ __forceinline__ void select_stage3(const SelectArgs& a, const ParLds* par, int lane, int cnt, Q3& q3) {
-    if (lane < cnt) {
-        const int k = (q3.h + lane) & (SEL_Q3CAP - 1);
-        const unsigned e = q3.j[k];
-        const ParLds* pl = par + (e >> SEL_TAG_SHIFT);
-        const float distanceDiff = sqrtf(q3.d2[k]);
-        const float cdiff = sqrtf(q3.cd[k]);                  // ColorDelta (gaussian.hpp:111-114); the queue holds its square
-        const float distWeight = expf(-distanceDiff * distanceDiff / a.tau2);
-        const float colorInfluence = expf(-cdiff * cdiff / a.tau2);
-        const float L = distWeight * q3.op[k] * colorInfluence * sqrtf(q3.det[k]);
-        const int64_t dst = pl->base + (int64_t)q3.rel[k];
-        a.pair_child[dst] = e & SEL_TAG_MASK;
-        a.pair_wl[dst] = pl->r3.z * ref_clamp(L, FLT_MIN, 1e8f);
-    }
-    q3.h = (q3.h + cnt) & (SEL_Q3CAP - 1);
-    q3.n -= cnt;
-}
-
-// KL gate decision  KLD(child, parent) > thr  (gaussian.hpp:106-109, mixture.cpp:126-129) with
-//     k = 0.5f * (((smd + tr) - 3.0f) - logf(q)),   q = det_c / det_p,   s2 = (smd + tr) - 3.0f  as the reference rounds it.
-// Fast path: q' = det_c * (1 / det_p) (within 1.2e-7 of q) and v_log_f32 (1 ulp of log2 q', plus the rounding of the
-// product with ln 2) put lf within 4.2e-7 (1 + |ln q|) of ln q, glibc's logf is within 1 ulp of it, so k computed with lf
-// differs from the reference's k by less than 0.5 (4.8e-7 (1 + |lf|) + 2 ulp(s2 - lf)) < 1e-6 (1 + |lf| + |s2|) / 2:
-// outside that margin around thr both give the same decision; inside it (and for q' not a comfortably normal positive
-// number, or s2 not finite) the exact expression runs: IEEE division and glibc's own logf algorithm.
-// tests/test_hem_gpu.py::test_fast_log_margin checks the bound and the decisions on the device.
-__device__ __forceinline__ bool kl_gate_rejects(float s2, float det_c, float det_p, float inv_det_p, float thr, const double* logtab,
-                                                float* lf_out = nullptr, bool* exact_out = nullptr) {
-    const float qf = det_c * inv_det_p;
-    const float lf = __builtin_amdgcn_logf(qf) * 0.6931471805599453f;
-    const float kf = 0.5f * (s2 - lf);
-    const float margin = 1e-6f * (1.0f + fabsf(lf) + fabsf(s2));
-    bool reject = kf > thr;
-    const bool need_exact = !(qf >= 4.0f * FLT_MIN && qf <= 0.25f * FLT_MAX) || !(fabsf(s2) <= FLT_MAX) || !(fabsf(kf - thr) > margin);
-    if (need_exact) {
-        const float k = 0.5f * (s2 - glibc_logf_tab(det_c / det_p, logtab));
-        reject = k > thr;
-    }
-    if (lf_out) *lf_out = lf;
-    if (exact_out) *exact_out = need_exact;
-    return reject;
-}
-
-// stage 2 on up to 64 queued survivors (lane < cnt holds one): radius test, colour gate, KL gate, parent rule -- the
-// reference's decisions, every expression in its operand order; accepted pairs go to the third-stage queue.
-// count_v: lane k holds the number of pairs parent k has had accepted so far (read and advanced here).
-template <int MODE>
-__device__ __forceinline__ void select_stage2(const SelectArgs& a, const ParLds* par, int lane, int cnt, const unsigned* q, int qh,
-                                              unsigned& count_v, Q3& q3) {
-    SEL_PROF_T(tp2);
-    SEL_PROF_CNT(8, 1, lane); SEL_PROF_CNT(9, cnt, lane);
-    bool acc = false;
-    unsigned e = 0u;
-    int k = 0;
-    float d2 = 0.0f, cdiff = 0.0f, op = 0.0f, det_c = 0.0f;
-    if (lane < cnt) {
-        e = q[(qh + lane) & (SEL_QCAP - 1)];
-        const int j = (int)(e & SEL_TAG_MASK);
-        k = (int)(e >> SEL_TAG_SHIFT);
-        const ParLds* pl = par + k;
-        const float4 p0 = pl->r0, p1 = pl->r1;
-        const float R2 = pl->R2;
-        const float4* row = a.geo + 4 * (int64_t)j;
-        float4 ca = row[0], cb = row[1], cc = row[2], cd = row[3];   // 64 contiguous bytes, all four up front: one round trip
-        // (an empty statement the compiler cannot see through: without it the loads of the covariance and the determinant sink into the
-        // branch behind the radius / colour gates -- a SECOND round trip per batch, +2 800 cycles, found in the phase profile)
-        asm volatile("" : "+v"(ca.x), "+v"(ca.y), "+v"(ca.z), "+v"(ca.w), "+v"(cb.x), "+v"(cb.y), "+v"(cb.z), "+v"(cb.w),
-                          "+v"(cc.x), "+v"(cc.y), "+v"(cc.z), "+v"(cc.w), "+v"(cd.x), "+v"(cd.y), "+v"(cd.z), "+v"(cd.w));
-        const f3 cm = {ca.x, ca.y, ca.z};
-        const f3 ccol = {cc.z, cc.w, cd.x};
-        const f3 pm = {p0.x, p0.y, p0.z}, pcol = {p0.w, p1.x, p1.y};
-        const f3 d = sub3(cm, pm);
-        d2 = dot3(d, d);                                      // == dot(pm - cm, pm - cm) bit for bit (pointindex.cpp:137)
-        const f3 dc = sub3(ccol, pcol);                       // ColorDelta(child, parent), gaussian.hpp:111-114
-        cdiff = dot3(dc, dc);                                 // its square; sqrtf(x) > colorThr  <=>  x > colorThr2 (a.colorThr2, host)
-        if (d2 < R2 && !(cdiff > a.colorThr2)) {              // radiusSearch (strict), mixture.cpp:122-124
-            const float4 p2 = pl->r2, p3 = pl->r3;
-            const s6 ccov = {cb.x, cb.y, cb.z, cb.w, cc.x, cc.y};
-            const s6 pinv = {p1.z, p1.w, p2.x, p2.y, p2.z, p2.w};
-            det_c = cd.w;
-            op = cd.y;
-            const float smd = dot3(d, mul6(pinv, d));         // gaussian.hpp:82-85
-            const float tr = trace_prod6(pinv, ccov);
-            const float s2 = smd + tr - 3.0f;                 // gaussian.hpp:106-109: 0.5f * (smd + tr - 3.0f - log(q))
-            if (!kl_gate_rejects(s2, det_c, p3.x, p3.y, a.kldThr, a.logtab)) {      // mixture.cpp:126-129 (NaN passes)
-                const bool child_is_parent = (__float_as_uint(ca.w) & 1u) != 0u;
-                acc = !(child_is_parent && j != pl->js);      // mixture.cpp:131-133
-            }
-        }
-    }
-    const unsigned long long m = __ballot(acc);
-    const int na = __popcll(m);
-    SEL_PROF_CNT(15, na, lane);
-    if (na == 0) { SEL_PROF_ADD(2, tp2, lane); return; }
-    // the entries are in parent order (FIFO): the batch holds the parents k_lo .. k_hi, every one a contiguous run of lanes
-    const int k_lo = __builtin_amdgcn_readfirstlane(k);
-    const int k_hi = __builtin_amdgcn_readlane(k, __builtin_amdgcn_readfirstlane(cnt - 1));
-    unsigned rel = 0u;
-#pragma unroll
-    for (int kk = 0; kk < SEL_NP; ++kk) {
-        if (kk < k_lo || kk > k_hi) continue;                 // (uniform)
-        const unsigned long long mk = __ballot(acc && k == kk);
-        const unsigned ck = (unsigned)__builtin_amdgcn_readlane((int)count_v, kk);
-        if (acc && k == kk) rel = ck + (unsigned)mbcnt64(mk, 0);
-        if (lane == kk) count_v += (unsigned)__popcll(mk);
-    }
-    if (MODE == SEL_COUNT) { SEL_PROF_ADD(2, tp2, lane); return; }
-    if (acc) {
-        const int t = mbcnt64(m, q3.h + q3.n) & (SEL_Q3CAP - 1);
-        q3.j[t] = e; q3.rel[t] = rel; q3.d2[t] = d2; q3.cd[t] = cdiff; q3.op[t] = op; q3.det[t] = det_c;
-    }
-    q3.n += na;
-    __builtin_amdgcn_wave_barrier();
-    if (q3.n >= 64) select_stage3(a, par, lane, 64, q3);
-    __builtin_amdgcn_wave_barrier();
-    SEL_PROF_ADD(2, tp2, lane);
-}
-
-// Row clipping by the parent's filter ellipsoid E = { d : d^T M d <= T_clip } (struct EllClip, filled by make_filter, which
-// also carries the argument): a regular child outside E fails the stage-1 filter anyway, so only the grid cells E touches need
-// scanning (E is inscribed in the query sphere; for a flat disc it holds a few percent of its volume).
-
-// The span (first sorted position, length) of one grid row (ry, rz) for a parent at pm: the row's cells within the
-// sphere of radius sqrt(Ra2), clipped to the pre-reject ellipsoid when `clip`.  IRR: positions in the irregular list.
-// ONE definition shared by k_select (every mode) and k_spans: the capacities must equal what the passes scan.
-// (The square roots are the hardware's 1-ulp v_sqrt_f32: every one of them sits behind a margin of 1e-5 or more.)
-template <bool IRR>
-__device__ __forceinline__ void select_row_span(const SelectArgs& a, const GridParams& g, const f3& pm, const EllClip& ec, bool clip,
-                                                float Ra2, int x0, int x1, int ry, int rz, int& s, int& len) {
-    // distance from the parent to the row's y/z slab (widened by the rounding slack)
-    // (the first / last row of the grid also holds every centre clamped in from outside: half-infinite)
-    const bool edge = ry == 0 || ry == g.gy - 1 || rz == 0 || rz == g.gz - 1;
-    const float ylo = ry == 0 ? -FLT_MAX : g.oy + ry * g.c - g.slack, yhi = ry == g.gy - 1 ? FLT_MAX : g.oy + (ry + 1) * g.c + g.slack;
-    const float zlo = rz == 0 ? -FLT_MAX : g.oz + rz * g.c - g.slack, zhi = rz == g.gz - 1 ? FLT_MAX : g.oz + (rz + 1) * g.c + g.slack;
-    const float dy = fmaxf(0.0f, fmaxf(ylo - pm.y, pm.y - yhi));
-    const float dz = fmaxf(0.0f, fmaxf(zlo - pm.z, pm.z - zhi));
-    const float rem = Ra2 - dy * dy - dz * dz;
-    if (rem >= 0.0f) {
-        const float hx = fast_sqrt(rem) * 1.00001f + g.slack;
-        float lo = -hx, hi = hx;                                   // x interval relative to the parent
-        if (clip && !edge) {
-            const float cy = 0.5f * (ylo + yhi) - pm.y, cz = 0.5f * (zlo + zhi) - pm.z;
-            const float hy = 0.5f * (yhi - ylo), hz = 0.5f * (zhi - zlo);
-            const float sc = fast_sqrt(fmaxf(0.0f, ec.k11 * cy * cy + 2.0f * ec.k12 * cy * cz + ec.k22 * cz * cz));
-            const float smin = fmaxf(0.0f, sc * 0.999f - ec.kr * fast_sqrt(hy * hy + hz * hz));
-            const float rem2 = ec.T - smin * smin;
-            if (rem2 < 0.0f) {
-                lo = 1.0f; hi = -1.0f;                             // the row misses the ellipsoid
-            } else {
-                const float w = fast_sqrt(rem2 * ec.im00) * 1.001f;
-                const float t1 = ec.m01 * cy, t2 = ec.m02 * cz;
-                const float xc = -(t1 + t2) * ec.im00;
-                const float dl = (fabsf(ec.m01) * hy + fabsf(ec.m02) * hz) * ec.im00 * 1.001f;
-                // the two terms of xc may cancel (a thin disc tilted against the axes): its rounding error is relative to them, not to xc
-                const float pad = g.slack + 1e-5f * fabsf(xc) + 1e-6f * (fabsf(t1) + fabsf(t2)) * ec.im00;
-                lo = fmaxf(lo, xc - dl - w - pad);
-                hi = fminf(hi, xc + dl + w + pad);
-            }
-        }
-        if (lo <= hi) {
-            int xa = cell_of(pm.x + lo, g.ox, g.inv_c, g.gx), xb = cell_of(pm.x + hi, g.ox, g.inv_c, g.gx);
-            xa = xa < x0 ? x0 : xa;
-            xb = xb > x1 ? x1 : xb;
-            const int rowbase = (rz * g.gy + ry) * g.gx;
-            int e;
-            if (IRR) { s = a.cellStartI[rowbase + xa]; e = a.cellStartI[rowbase + xb + 1]; }      // positions in the irregular list
-            else { s = a.cellStartC[rowbase + xa]; e = a.cellStartC[rowbase + xb + 1]; }      // positions in the children's stream
-            len = e - s;
-        }
-    }
-}
-
-// The stage-1 filter of a regular parent, and the row clipping that goes with it (one thread per parent, float64).
-//
-// What the reference decides (gaussian.hpp:106-109, mixture.cpp:126-129), with M = its float32 cofactor inverse of the
-// parent's covariance (pr.pinv, the very numbers stage 2 uses), d = the float32 mean difference, C the child:
-//     reject  <=>  fl(0.5 (s2 - lf)) > thr,   s2 = fl(fl(smd + tr) - 3),  smd = fl(d^T M d),  tr = fl(tr(M C)),  lf = logf(fl(det_c / det_p)).
-// Stage 1 may drop a pair only when that is CERTAIN.  With u = 2^-24, S = d^T M d and Tr = tr(M C) in real arithmetic
-// on the float32 data, K >= tr(M) / lambda_min(M), and a regular child (is_regular: C positive definite, its float32
-// determinant within DET_TOL of det C, quotient of determinants a normal number):
-//     smd >= S (1 - 6.1 u K),  tr >= Tr (1 - 5.1 u K)                       (dot products of length 3 + 3 / 3 + 2, |M|:|C| <= K Tr)
-//     s2 - lf >= (S + Tr)(1 - theta) - 3 - ln(det_c / det_p) - 1.5e-5,     theta = 6.1 u K + 2 u
-//     Tr (1 - theta) - ln det C >= 3 + ln det((1 - theta) M)               (M positive definite: minimum over all SPD C)
-//  => s2 - lf >= S (1 - theta) + 3 ln(1 - theta) - G - DET_TOL - 2e-5,     G = -ln(det M * det_p)   (0 for an exact inverse)
-// so the pair is rejected for certain when S > S_min = (2 thr + G + DET_TOL + 3.2 theta + 4e-5) / (1 - theta).  The filter
-// evaluates S as |U d|^2 with the float32-rounded Cholesky factor U of M (nine fused multiply-adds): that value is below
-// S (1 + 4.1 u sqrt(K))^2 (1 + 3.1 u), which the factor (1 + theta)^2 on the bound covers.  Everything a parent needs
-// for it -- M positive definite, K, G -- is computed HERE from M's float32 entries in float64; a parent for which it
-// cannot be certified (theta > 1/4: condition number beyond ~3e5; M not positive definite; |G| > 1) scans its search
-// sphere with the reference's radius test instead (white = 0), like every parent did before round 1's pre-reject.
-// tests/test_hem_gpu.py::test_stage1_filter_never_rejects_an_accepted_pair attacks the bound on the device.
-//
-// Row clipping: only the grid rows the ellipsoid E = { d : S <= T_clip } meets need scanning, T_clip = T1 (1 + theta)^2 (1 + 1e-4)
-// (beyond it the filter's own float32 value exceeds T1).  For a row = the slab dy in [cy - hy, cy + hy], dz in [cz - hz, cz + hz]:
-// S = M00 (dx - xc(dy, dz))^2 + q(dy, dz), q the quadratic form of the Schur complement Ks of M; sqrt(q) is a norm, so over the
-// slab sqrt(q) >= sqrt(q(c)) - sqrt(lmax(Ks)) |h|, lmax(Ks) <= tr Ks, and xc is linear: a conservative x interval in ~45
-// flops (select_row_span).  The constants are float64 values rounded to float32 with the margins folded in: Ks scaled
-// down by (1 - 4 theta - 2e-3) -- the float32 evaluation of q loses up to 12 u tr(Ks) / lmin(Ks) <= 4 theta of it --
-// T_clip and 1 / M00 rounded up.
-__device__ __forceinline__ void make_filter(const s6& Mf, float det_p, float kldThr, int ell, bool parent_regular, ParentRec& pr) {
-    EllClip ec;
-    ec.on = 0.0f; ec.k11 = ec.k12 = ec.k22 = ec.kr = ec.im00 = ec.m01 = ec.m02 = 0.0f; ec.T = __builtin_inff();
-    pr.white = 0.0f;
-    pr.u00 = pr.u01 = pr.u02 = pr.u11 = pr.u12 = pr.u22 = 0.0f;
-    pr.T1 = __builtin_inff();
-    pr.ey = pr.ez = __builtin_inff();
-    const double thr2 = 2.0 * (double)kldThr;
-    if (parent_regular && thr2 >= 0.0 && thr2 < 1e30) {
-        const double m00 = Mf.e00, m01 = Mf.e01, m02 = Mf.e02, m11 = Mf.e11, m12 = Mf.e12, m22 = Mf.e22;
-        double detM;
-        const bool finite = fabs(m00) < 1e30 && fabs(m01) < 1e30 && fabs(m02) < 1e30 && fabs(m11) < 1e30 && fabs(m12) < 1e30 && fabs(m22) < 1e30;
-        if (finite && spd_det64(m00, m01, m02, m11, m12, m22, detM)) {
-            const double trM = m00 + m11 + m22;
-            const double e2 = (m00 * m11 - m01 * m01) + (m00 * m22 - m02 * m02) + (m11 * m22 - m12 * m12);   // >= lmax * lmid
-            const double K = trM * e2 / detM * 1.000001;                 // >= tr(M) / lambda_min(M)
-            const double u = 5.9604644775390625e-8;
-            const double theta = 6.1 * u * K + 2.0 * u;
-            const double G = -(log(detM) + log((double)det_p)) + 2e-6;
-            if (theta <= 0.25 && fabs(G) <= 1.0) {
-                const double smin = (thr2 * (1.0 + 2.0 * u) + G + (double)GSR_DET_TOL + 3.2 * theta / (1.0 - theta) + 4e-5) / (1.0 - theta);
-                const double T1 = smin * (1.0 + theta) * (1.0 + theta) * (1.0 + 1e-5);
-                if (T1 > 0.0 && T1 < 1e30) {
-                    // Cholesky factor of M (upper), float64, rounded to float32
-                    const double u00 = sqrt(m00), u01 = m01 / u00, u02 = m02 / u00;
-                    const double t11 = m11 - u01 * u01, u11 = sqrt(t11), u12 = (m12 - u01 * u02) / u11;
-                    const double t22 = m22 - u02 * u02 - u12 * u12, u22 = sqrt(t22);
-                    if (t11 > 0.0 && t22 > 0.0) {
-                        pr.u00 = (float)u00; pr.u01 = (float)u01; pr.u02 = (float)u02; pr.u11 = (float)u11; pr.u12 = (float)u12; pr.u22 = (float)u22;
-                        pr.T1 = (float)(T1 * (1.0 + 2.0 * u));
-                        pr.white = 1.0f;
-                        if (ell) {
-                            const double Tc = T1 * (1.0 + theta) * (1.0 + theta) * (1.0 + 1e-4);
-                            const double fk = 1.0 - 4.0 * theta - 2e-3;                       // > 0 for theta <= 1/4... only just: see `ok`
-                            const double im00 = 1.0 / m00;
-                            const double k11 = (m11 - m01 * m01 * im00) * fk, k12 = (m12 - m01 * m02 * im00) * fk, k22 = (m22 - m02 * m02 * im00) * fk;
-                            ec.k11 = (float)k11; ec.k12 = (float)k12; ec.k22 = (float)k22;
-                            ec.kr = (float)(sqrt((k11 + k22) / fk) * 1.001);
-                            ec.im00 = (float)(im00 * (1.0 + 4.0 * u));
-                            ec.m01 = (float)m01; ec.m02 = (float)m02;
-                            ec.T = (float)(Tc * (1.0 + 2.0 * u));
-                            const bool ok = fk > 0.5 && k11 > 0.0 && k22 > 0.0 && k11 * k22 > k12 * k12 && ec.kr < FLT_MAX && ec.im00 < FLT_MAX && ec.T < FLT_MAX;
-                            ec.on = ok ? 1.0f : 0.0f;
-                            // extent of E along y / z = sqrt(T_clip (M^-1)_yy / zz), M^-1 from M itself
-                            pr.ey = (float)(sqrt(fmax(0.0, Tc * (m00 * m22 - m02 * m02) / detM)) * 1.001);
-                            pr.ez = (float)(sqrt(fmax(0.0, Tc * (m00 * m11 - m01 * m01) / detM)) * 1.001);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    pr.ec = ec;
-}
-
-// One thread per parent: the record the selection kernels read (see struct ParentRec).
-__global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __restrict__ plist, const float4* __restrict__ geo,
-                                                     const float* __restrict__ Rs, float kldThr, int ell, ParentRec* __restrict__ prec) {
-    // a wave's 64 records leave as 10 KiB of contiguous memory (through LDS): a lane storing its own 160-byte record wrote 16
-    // bytes of 64 different records per instruction
-    __shared__ ParentRec s_pr[4][64];
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    for (int base = blockIdx.x * blockDim.x + (threadIdx.x & ~63); base < P; base += gridDim.x * blockDim.x) {
-        const int p = base + lane;
-        if (p < P) {
-        ParentRec pr;
-        pr.js = (int)plist[p];
-        const float4* prow = geo + 4 * (int64_t)pr.js;
-        const float4 pa = prow[0], pb = prow[1], pc = prow[2], pd = prow[3];
-        pr.pm = {pa.x, pa.y, pa.z};
-        pr.det_p = pd.w;
-        pr.inv_det_p = 1.0f / pd.w;
-        const s6 pcov = {pb.x, pb.y, pb.z, pb.w, pc.x, pc.y};
-        pr.pcol = {pc.z, pc.w, pd.x};
-        pr.pweight = pd.z;
-        pr.pinv = inverse6(pcov, pr.det_p);
-        pr.R = Rs[pr.js];
-        pr.R2 = pr.R * pr.R;
-        make_filter(pr.pinv, pr.det_p, kldThr, ell, (__float_as_uint(pa.w) & 2u) != 0u, pr);
-        // R2 is NaN for a NaN radius and 0 for R = 0: `d2 < R2` is then never true -> no children.
-        const bool pm_finite = fabsf(pr.pm.x) <= FLT_MAX && fabsf(pr.pm.y) <= FLT_MAX && fabsf(pr.pm.z) <= FLT_MAX;
-        pr.active = (pr.R2 > 0.0f && pm_finite) ? 1 : 0;
-        pr.selfq = (pr.active && (__float_as_uint(pa.w) & 2u)) ? 1 : 0;
-        pr.rows = 0;
-        s_pr[wv][lane] = pr;
-        }
-        __builtin_amdgcn_wave_barrier();
-        const int nrec = P - base < 64 ? P - base : 64;
-        const float4* src = reinterpret_cast<const float4*>(s_pr[wv]);
-        float4* dst = reinterpret_cast<float4*>(prec + base);
-        for (int t = lane; t < nrec * (int)(sizeof(ParentRec) / 16); t += 64) dst[t] = src[t];
-        __builtin_amdgcn_wave_barrier();
-    }
-}
-
-// The stage-1 filter value |U d|^2 (make_filter): vc = {parent mean, u00, u01, u02, u11, u12, u22, T1}; nine fused multiply-adds
-__device__ __forceinline__ float white_smd(const float (&vc)[11], float cx, float cy, float cz) {
-    const float dx = cx - vc[0], dy = cy - vc[1], dz = cz - vc[2];
-    const float y2 = vc[8] * dz;
-    const float y1 = __builtin_fmaf(vc[6], dy, vc[7] * dz);
-    const float y0 = __builtin_fmaf(vc[3], dx, __builtin_fmaf(vc[4], dy, vc[5] * dz));
-    return __builtin_fmaf(y0, y0, __builtin_fmaf(y1, y1, y2 * y2));
-}
-
-// One pass of a parent over its grid rows: IRR = false scans the cell-sorted components themselves and keeps the
-// REGULAR ones; IRR = true scans the list of irregular components (ipos, addressed through irank at the cell
-// boundaries).  Survivors of the stage-1 filter go to the LDS ring.
-// Full batches of 64 survivors go through stage 2 from inside the scan (the ring holds the rest of a batch plus one group of chunks).
-// (Tried on the way to four parents per wave: the scan only FILLING a 512-entry ring, suspended when it is full and resumed through
-// the work items' [lo, hi) mechanism, the drain behind it -- it kept stage 2's registers out of the scan's when the kernel held 96
-// VGPRs.  With the parent record in scalar registers both forms need 65, and this one is 5 % faster: no suspended scans (6 % of the
-// parents recomputed a batch of row spans), half the ring.  profiles/r04o_*.)
-template <int MODE, bool IRR>
-__device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const ParLds* par, unsigned ktag,
-                                            const float (&vc)[11], int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count_v,
-                                            Q3& q3, unsigned& cum, unsigned lo, unsigned hi, const int2* rl, int lcnt) {
-    const f3 pm = pr.pm;
-    const EllClip& ec = pr.ec;
-    // rl != NULL: the spans of the parent's lcnt non-empty rows, in scan order, as k_spans left them (it computes every span anyway,
-    // for the capacities): one 8-byte load per row instead of the box, ~80 instructions per row and two dependent look-ups in the
-    // prefix table.  The candidates, their order and with it the pairs are the same either way (select_row_span made both).
-    const bool listed = rl != nullptr;
-    bool clip = false;
-    int x0 = 0, x1 = 0, y0 = 0, z0 = 0, ny = 1, nrows = lcnt;
-    float Ra2 = 0.0f;
-    if (!listed) {
-        // (uniform values, but float arithmetic is VALU work and its results would sit in vector registers for the whole scan: the box
-        // goes back to the scalar file.  The compiler knows the values are uniform and folds a plain readfirstlane away -- leaving them
-        // where they are; a zero it cannot see through, added to the bit pattern, keeps the instruction)
-        int vz;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(vz));
-        const auto uni = [vz](int v) { return __builtin_amdgcn_readfirstlane(v + vz); };
-        const auto unif = [vz](float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v) + vz)); };
-        const float Ra = unif(fabsf(pr.R) * 1.00001f + g.slack);       // conservative search extent
-        clip = !IRR && ec.on != 0.0f;
-        // rows: the sphere's box, cut down to the pre-reject ellipsoid's box when the rows are clipped to it (rows beyond its y / z
-        // extent would come out empty one by one)
-        const float Ry = clip ? fminf(Ra, pr.ey + g.slack) : Ra, Rz = clip ? fminf(Ra, pr.ez + g.slack) : Ra;
-        x0 = uni(cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx)); x1 = uni(cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx));
-        y0 = uni(cell_of(pm.y - Ry, g.oy, g.inv_c, g.gy));
-        const int y1 = uni(cell_of(pm.y + Ry, g.oy, g.inv_c, g.gy));
-        z0 = uni(cell_of(pm.z - Rz, g.oz, g.inv_c, g.gz));
-        const int z1 = uni(cell_of(pm.z + Rz, g.oz, g.inv_c, g.gz));
-        ny = y1 - y0 + 1;
-        nrows = ny * (z1 - z0 + 1);
-        Ra2 = unif(Ra * Ra);
-    }
-    const bool white = !IRR && pr.white != 0.0f;                // wave-uniform
-    SEL_PROF_CNT(10, nrows, lane);
-    for (int rb = 0; rb < nrows; rb += 64) {
-        SEL_PROF_T(tpr);
-        SEL_PROF_CNT(11, 1, lane);
-        const int r = rb + lane;
-        int s = 0, len = 0;
-        if (r < nrows) {
-            if (listed) { const int2 e = rl[r]; s = e.x; len = e.y; }
-            else select_row_span<IRR>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
-        }
-        len = len > 0 ? len : 0;
-        const unsigned long long nz_m = __ballot(len > 0);
-        if (nz_m == 0ull) continue;
-        // flattened candidate space of the batch: row r covers flat positions [pre, pre + len)
-        const int incl = wave_incl_scan(len);
-        const int pre = incl - len;
-        const int total = __builtin_amdgcn_readlane(incl, 63);
-        // this work item's part [lo, hi) of the parent's flat candidate space (cum = candidates of the batches before this
-        // one; a parent that is not split has lo = 0, hi = 2^32 - 1)
-        const unsigned cum0 = cum;
-        cum += (unsigned)total;
-        if (hi <= cum0 || lo >= cum) continue;
-        const int b_lo = lo > cum0 ? (int)(lo - cum0) : 0;
-        const int b_hi = hi - cum0 < (unsigned)total ? (int)(hi - cum0) : total;
-        // (start - prefix) of the q-th non-empty row goes to lane q (the empty rows take the lanes behind them: a permutation)
-        const int nrb = __popcll(nz_m);
-        const int below = mbcnt64(nz_m, 0);
-        const int dst = len > 0 ? below : nrb + (lane - below);
-        const int delta = __builtin_amdgcn_ds_permute(dst << 2, s - pre);
-        SEL_PROF_ADD(1, tpr, lane);
-        SEL_PROF_CNT(12, nrb, lane); SEL_PROF_CNT(13, total, lane);
-        for (int seg0 = b_lo; seg0 < b_hi; seg0 += SEL_MCAP) {
-            const int rel = pre - seg0;
-            const bool mine = len > 0 && rel >= 0 && rel < SEL_MCAP;
-            if (mine) atomicOr(&bits[rel >> 6], 1ull << (rel & 63));
-            int rows_before = __popcll(__ballot(len > 0 && rel < 0));      // rows that start before this segment (uniform)
-            __builtin_amdgcn_wave_barrier();
-            const int seg_end = b_hi < seg0 + SEL_MCAP ? b_hi : seg0 + SEL_MCAP;
-            for (int t0 = seg0; t0 < seg_end; t0 += 64 * SEL_U) {
-                SEL_PROF_CNT(14, 1, lane);
-                SEL_PROF_T(tps);
-                float4 ca[SEL_U];
-                int jj[SEL_U];
-                int left[SEL_U];                                              // active lanes of each chunk (uniform)
-#pragma unroll
-                for (int u = 0; u < SEL_U; ++u) {
-                    const int c0 = t0 + 64 * u;                               // uniform
-                    // row of candidate c0 + lane = (row starts at flat positions <= c0 + lane) - 1
-                    const unsigned long long word = uniform64(bits[(c0 - seg0) >> 6]);     // broadcast read; the words behind the segment are zero
-                    const int row = mbcnt64(word >> 1, rows_before - 1 + (int)(word & 1ull));
-                    rows_before += __popcll(word);
-                    left[u] = seg_end - c0;
-                    const int k = c0 + lane + __builtin_amdgcn_ds_bpermute(row << 2, delta);
-                    // the inactive lanes behind the batch's last candidate read on past the last row: the sorted A array is
-                    // padded by SEL_PAD entries, so the load stays unconditional (a load under a branch would make hipcc
-                    // wait vmcnt(0) after each one instead of overlapping the SEL_U loads)
-                    if (IRR) { jj[u] = lane < left[u] ? (int)a.ipos[k] : pr.js; ca[u] = a.A[jj[u]]; }
-                    else { jj[u] = k; ca[u] = a.Ac[k]; }                      // pass A: jj becomes the sorted position below
-                }
-#pragma unroll
-                for (int u = 0; u < SEL_U; ++u) {
-                    if (left[u] <= 0) continue;
-                    const f3 cm = {ca[u].x, ca[u].y, ca[u].z};
-                    bool in;
-                    if (white) {                                              // regular parent, regular children
-                        // vc = {pm, U, T1} in VECTOR registers: a VALU instruction with an SGPR operand issues at half rate
-                        in = !(white_smd(vc, cm.x, cm.y, cm.z) > vc[9]);
-                    } else {                                                  // the reference's radius test (pointindex.cpp:137)
-                        const f3 dq = sub3(pm, cm);
-                        in = dot3(dq, dq) < pr.R2;
-                    }
-                    if (!IRR) {
-                        in = in && (__float_as_uint(ca[u].w) & 2u);           // irregular children belong to pass B
-                        jj[u] = (int)(__float_as_uint(ca[u].w) >> 2);         // the stream carries the sorted position
-                    } else {
-                        // the parent rule (mixture.cpp:131-133): a component that is a parent itself is claimed by no parent but
-                        // itself.  Pass A's stream holds no parents at all; the irregular list does
-                        in = in && (!(__float_as_uint(ca[u].w) & 1u) || jj[u] == pr.js);
-                    }
-                    in = in && lane < left[u];
-                    const unsigned long long m = __ballot(in);
-                    if (m == 0ull) continue;
-                    if (in) q[mbcnt64(m, qh + qn) & (SEL_QCAP - 1)] = (unsigned)jj[u] | ktag;
-                    qn += __popcll(m);
-                }
-                __builtin_amdgcn_wave_barrier();
-                SEL_PROF_ADD(4, tps, lane);
-                // drain: stage 2 appears ONCE in the code (not once per unrolled u), on full batches of 64
-                while (qn >= 64) {
-                    select_stage2<MODE>(a, par, lane, 64, q, qh, count_v, q3);
-                    qh = (qh + 64) & (SEL_QCAP - 1);
-                    qn -= 64;
-                }
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (mine) bits[rel >> 6] = 0ull;                                  // leave the mask clean for the next segment / batch
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
-}
-
-// What stages 2 / 3 need of parent p, from its record in memory to the wave's LDS slot (ONE lane calls this per parent; the slot is
-// free: a wave's parents take different slots, a work item's rings are flushed before the next one starts).  (Lane 0 writing it from
-// the scalar copy of the record inside select_parent, measured: +5 % at four parents per wave -- 17 more live SGPRs and 20 v_mov.)
-__device__ __forceinline__ void select_fill_par(const SelectArgs& a, int p, int64_t base, ParLds* slot) {
-    const float4* r = reinterpret_cast<const float4*>(a.prec + p);
-    const float4 r0 = r[0], r1 = r[1], r2 = r[2], r3 = r[3];
-    slot->r0 = r0; slot->r1 = r1; slot->r2 = r2; slot->r3 = r3;
-    slot->R2 = a.prec[p].R2; slot->js = a.prec[p].js; slot->base = base;
-}
-
-// One work item: parent p (the wave's k-th), part [lo, hi) of its flat candidate space (the whole parent: 0, 2^32 - 1); its pairs
-// go to par[k].base on (FILL / SPARSE; select_fill_par has filled par[k]).  Survivors and accepted pairs may stay behind in the
-// rings: select_flush ends a wave's (a work item's) run.  The number of accepted pairs accumulates in lane k of count_v.
-template <int MODE>
-__device__ __forceinline__ void select_parent(const SelectArgs& a, const GridParams& g, int p, int k, unsigned lo, unsigned hi, int lane,
-                                              const ParLds* par, unsigned* q, int& qh, int& qn, unsigned long long* bits, unsigned& count_v, Q3& q3) {
-    SEL_PROF_T(tp0);
-    // The record lives in SGPRs.  As inline assembly: this body runs in a loop behind the wave's own stores (pcnt, the pairs), the
-    // compiler cannot tell that they leave prec[] alone, and a load that "may be clobbered" is not made a scalar load however uniform
-    // its address -- it became ten global_load_dwordx4 with 64 lanes reading the same 160 bytes, and 40 v_readfirstlane behind them
-    // (SQ_INSTS_VMEM_RD +16 M per 5 M level, profiles/r04o_*).
-    ParentRec pr;
-    {
-        typedef unsigned u16v __attribute__((ext_vector_type(16)));
-        typedef unsigned u8v __attribute__((ext_vector_type(8)));
-        u16v w0, w1; u8v w2;
-        const ParentRec* rp = a.prec + p;
-        asm volatile("s_load_dwordx16 %0, %3, 0x0\n\ts_load_dwordx16 %1, %3, 0x40\n\ts_load_dwordx8 %2, %3, 0x80\n\ts_waitcnt lgkmcnt(0)"
-                     : "=&s"(w0), "=&s"(w1), "=&s"(w2) : "s"(rp) : "memory");
-        unsigned raw[40];
-        static_assert(sizeof(raw) == sizeof(ParentRec), "the three scalar loads cover the record");
-#pragma unroll
-        for (int i = 0; i < 16; ++i) { raw[i] = w0[i]; raw[16 + i] = w1[i]; }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) raw[32 + i] = w2[i];
-        __builtin_memcpy(&pr, raw, sizeof(pr));
-    }
-    // the constants of the stage-1 filter in vector registers (v_mov from the SGPRs once per parent)
-    float vc[11];
-    {
-        const float src[11] = {pr.pm.x, pr.pm.y, pr.pm.z, pr.u00, pr.u01, pr.u02, pr.u11, pr.u12, pr.u22, pr.T1, 0.0f};
-#pragma unroll
-        for (int i = 0; i < 11; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(vc[i]) : "s"(src[i]));
-    }
-    const unsigned ktag = (unsigned)k << SEL_TAG_SHIFT;
-    unsigned cum = 0;                   // flat candidates of the batches behind the scan
-    if (pr.selfq) {                     // the parent itself: flat candidate 0, straight into the survivor ring (stage 2 decides)
-        cum = 1u;
-        if (lo == 0u) {
-            if (lane == 0) q[(qh + qn) & (SEL_QCAP - 1)] = (unsigned)pr.js | ktag;
-            qn += 1;
-        }
-        __builtin_amdgcn_wave_barrier();
-        // The ring holds 64 + one group of chunks (SEL_QCAP): the scan's drain keeps qn < 64 behind every group, but a parent WITHOUT a
-        // non-empty candidate row never gets there -- several isolated parents in a row (SEL_NP per wave) each add their own entry, and
-        // a following parent's first group of SEL_U * 64 survivors would wrap onto the oldest entries (an accepted pair lost silently,
-        // ADVICE r04).  So a full batch goes through stage 2 right here: qn <= 63 again in front of every scan.
-        if (qn >= 64) {
-            select_stage2<MODE>(a, par, lane, 64, q, qh, count_v, q3);
-            qh = (qh + 64) & (SEL_QCAP - 1);
-            qn -= 64;
-        }
-    }
-    if (pr.active) {
-        // pass A: the regular children (rows clipped to the parent's Mahalanobis ellipsoid when it is regular);
-        // pass B: the irregular children, which the pre-reject never applies to (rows clipped to the sphere only)
-        // the row lists k_spans left for this parent (bit 31 of pr.rows), per pass: a count of at most SEL_ROWS is a complete list
-        const int cA = pr.rows & 0xff, cB = (pr.rows >> 8) & 0xff;
-        const int2* rlp = (a.rowlist != nullptr && pr.rows < 0) ? a.rowlist + (int64_t)p * (2 * SEL_ROWS) : nullptr;
-        select_scan<MODE, false>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, cum, lo, hi,
-                                 rlp != nullptr && cA <= SEL_ROWS ? rlp : nullptr, cA);
-        if (a.n_irr > 0) select_scan<MODE, true>(a, g, pr, par, ktag, vc, lane, bits, q, qh, qn, count_v, q3, cum, lo, hi,
-                                                 rlp != nullptr && cB <= SEL_ROWS ? rlp + SEL_ROWS : nullptr, cB);
-    }
-    SEL_PROF_ADD(0, tp0, lane);
-    SEL_PROF_CNT(7, 1, lane);
-}
-
-// The partial batches at the end of a wave's run: the survivors left in the ring, then the accepted pairs left in the queue.
-template <int MODE>
-__device__ __forceinline__ void select_flush(const SelectArgs& a, const ParLds* par, int lane, const unsigned* q, int& qh, int& qn,
-                                             unsigned& count_v, Q3& q3) {
-    while (qn > 0) {                    // (the parent's own entry may have made it 64)
-        const int c = qn < 64 ? qn : 64;
-        select_stage2<MODE>(a, par, lane, c, q, qh, count_v, q3);
-        qh = (qh + c) & (SEL_QCAP - 1);
-        qn -= c;
-    }
-    SEL_PROF_T(tp3);
-    if ((MODE == SEL_FILL || MODE == SEL_SPARSE) && q3.n > 0) select_stage3(a, par, lane, q3.n, q3);
-    SEL_PROF_ADD(3, tp3, lane);
-    __builtin_amdgcn_wave_barrier();
-}
-
-// WPB = wavefronts per workgroup.  QUEUE = false: a.np (1 ... SEL_NP) consecutive light parents of the processing order per wave,
-// one after the other with the rings kept across them (the heavy slots at the order's head are skipped when a.heavy_blocks > 0).
-// QUEUE = true, launched beside it on a second stream with
-// a.heavy_blocks workgroups: every wave serves the queue of heavy work items (item <its index> first, then it pulls).
-// Two kernels rather than one: the item loop's uniform state does not fit the scalar registers beside the parent record,
-// and the spills would cost the light parents, 99.7 % of the work, two waves per SIMD.
-template <int MODE, int WPB, bool QUEUE>
-__global__ __launch_bounds__(64 * WPB) void k_select(SelectArgs a) {
-    __shared__ unsigned s_q[WPB][SEL_QCAP];
-    __shared__ unsigned s_q3u[WPB][2][SEL_Q3CAP];
-    __shared__ float s_q3f[WPB][4][SEL_Q3CAP];
-    __shared__ unsigned long long s_bits[WPB][SEL_MCAP / 64 + SEL_U];
-    __shared__ ParLds s_par[WPB][SEL_NP];
-    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    a.logtab = k_logf_tab;                                  // (the exact logf is a rare path: its table stays in constant memory, 256 bytes of LDS less)
-    if (lane < SEL_MCAP / 64 + SEL_U) s_bits[wv][lane] = 0ull;
-    unsigned* q = s_q[wv];
-    ParLds* par = s_par[wv];
-    Q3 q3 = {s_q3u[wv][0], s_q3u[wv][1], s_q3f[wv][0], s_q3f[wv][1], s_q3f[wv][2], s_q3f[wv][3], 0, 0};
-    __builtin_amdgcn_wave_barrier();
-    const GridParams g = *a.gp;
-    int qh = 0, qn = 0;                 // survivor ring: head and fill (uniform)
-
-    if constexpr (QUEUE) {
-        const int n_items = a.hq[0];
-        const unsigned part = *a.part_p;
-        int item = (int)blockIdx.x * WPB + wv;
-        while (item < n_items) {
-            const uint2 it = a.hitem[item];
-            const int p = __builtin_amdgcn_readfirstlane((int)a.porder[it.x]);
-            const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(it.y * part));
-            const unsigned hi = lo + part > lo ? lo + part : 0xffffffffu;
-            int64_t base = 0;
-            if (MODE == SEL_SPARSE) base = a.poff[p] + lo;          // accepted <= candidates of the part: the parts cannot collide
-            if (MODE == SEL_SPARSE && a.cap_pairs && (unsigned long long)base + part > a.cap_pairs) {      // beyond the buffers: no pairs, the level reruns
-                if (lane == 0) { a.part_cnt[item] = 0u; *a.abort_p = 1; }
-                int nxt0 = 0;
-                if (lane == 0) nxt0 = atomicAdd(&a.hq[1], 1);
-                item = __builtin_amdgcn_readfirstlane(nxt0);
-                continue;
-            }
-            if (MODE == SEL_FILL) {
-                base = a.poff[p];
-                for (int k = a.hfirst[p]; k < item; ++k) base += a.part_cnt[k];
-            }
-            unsigned count_v = 0u;
-            if (lane == 0) select_fill_par(a, p, base, par);
-            __builtin_amdgcn_wave_barrier();
-            select_parent<MODE>(a, g, p, 0, lo, hi, lane, par, q, qh, qn, s_bits[wv], count_v, q3);
-            select_flush<MODE>(a, par, lane, q, qh, qn, count_v, q3);
-            if (lane == 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) {
-                a.part_cnt[item] = count_v;
-                atomicAdd(&a.pcnt[p], count_v);                     // integer sum: the order of the parts does not matter
-            }
-            int nxt = 0;
-            if (lane == 0) nxt = atomicAdd(&a.hq[1], 1);
-            item = __builtin_amdgcn_readfirstlane(nxt);
-            __builtin_amdgcn_wave_barrier();
-        }
-    } else {
-        SEL_PROF_T(tpk);
-        const int np = a.np;
-        const int ppb = WPB * np;                                   // parents per workgroup
-        const int nheavy = a.nheavy ? *a.nheavy : 0;
-        const int nblk = (a.P + ppb - 1) / ppb;
-        const int hb = ((nheavy + ppb - 1) / ppb + 7) & ~7;
-        const int bid = block_slot((int)blockIdx.x, nblk, hb < nblk ? hb : nblk, a.xcd);
-        if (bid < 0) return;
-        const int slot0 = (bid * WPB + wv) * np;
-        // lane k < np looks at the wave's k-th slot: whose parent it is, whether it is this launch's, and fills its LDS record --
-        // nothing of this stays in the scalar registers while the parents are scanned
-        int p_v = -1;                                               // lane k: the wave's k-th parent (-1: none, or not this launch's)
-        if (lane < np) {
-            const int slot = slot0 + lane;
-            if (slot < a.P && !(a.heavy_blocks > 0 && slot < nheavy)) {      // (a heavy parent: the queue has it)
-                const int p = a.porder ? (int)a.porder[slot] : slot;
-                if (p < a.own_lo || p >= a.own_hi) {                // another rank's parent: no work, no pairs
-                    if (MODE == SEL_COUNT || MODE == SEL_SPARSE) a.pcnt[p] = 0u;
-                } else {
-                    const int64_t base = (MODE == SEL_FILL || MODE == SEL_SPARSE) ? a.poff[p] : 0;
-                    if (MODE == SEL_SPARSE && a.cap_pairs && (unsigned long long)base + a.pcap[p] > a.cap_pairs) {
-                        a.pcnt[p] = 0u; *a.abort_p = 1;             // the segment would end beyond the buffers: no pairs, the level reruns
-                    } else {
-                        p_v = p;
-                        select_fill_par(a, p, base, par + lane);
-                    }
-                }
-            }
-        }
-        unsigned long long todo = __ballot(p_v >= 0);
-        unsigned count_v = 0u;
-        __builtin_amdgcn_wave_barrier();
-        SEL_PROF_ADD(5, tpk, lane);
-        while (todo != 0ull) {
-            const int k = __builtin_ctzll(todo);
-            todo &= todo - 1ull;
-            const int p = __builtin_amdgcn_readlane(p_v, k);
-            select_parent<MODE>(a, g, p, k, 0u, 0xffffffffu, lane, par, q, qh, qn, s_bits[wv], count_v, q3);
-        }
-        SEL_PROF_T(tpf);
-        select_flush<MODE>(a, par, lane, q, qh, qn, count_v, q3);
-        SEL_PROF_ADD(6, tpf, lane);
-        if (p_v >= 0 && (MODE == SEL_COUNT || MODE == SEL_SPARSE)) a.pcnt[p_v] = count_v;      // no global atomics: totals come from the scans
-    }
-}
-
 // Morton bits per axis of the ordering key: the curve runs over blocks of (grid / 2^bits)^3 cells, the parents of a block stay in
 // cell order (stable sort).  6 bits: 20-bit keys = two 10-bit Onesweep passes where 10 bits per axis took four (-0.1 ms at 5 M;
 // k_select and k_mstep, which run in this order, measure the same with 6, 7 and 10 bits).
@@ -1510,83 +573,6 @@ __global__ __launch_bounds__(1024) void k_heavy_items(int P, const unsigned* __r
         __syncthreads();
     }
     if (threadIdx.x == 0) { hq[0] = s_base < max_items ? s_base : max_items; hq[1] = first_pull; }
-}
-
-// Capacities (candidates every parent's passes will scan), with 16 lanes per parent instead of a wavefront: the pass has no
-// candidate work, so its cost is the per-parent set-up, which four parents per wavefront share.  Same row spans as k_select
-// by construction (select_row_span).  (Measured in round 4: three rows per lane with their table look-ups issued together -- 0.30
-// against 0.25 ms on the isotropic 5 M level, 0.58 against 0.58 on the surfel one: the pass is bound by the rows' arithmetic, ~80
-// instructions each for 15 / 68 rows per parent, not by the look-ups.)
-__global__ __launch_bounds__(256) void k_spans(SelectArgs a) {
-    const int sub = threadIdx.x & 15;
-    const int p = (int)(((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4);
-    if (p >= a.P) return;
-    unsigned long long scanned = 0;
-    int selfq = 0;
-    int nA = 0, nB = 0;                                         // non-empty rows of the two passes
-    if (p >= a.own_lo && p < a.own_hi) {
-        const GridParams g = *a.gp;
-        // the record's fields with six 16-byte loads issued together (field by field the compiler fetched `active` first, waited, then
-        // the rest one by one behind the branches that use them: four dependent round trips in a kernel that is nothing but latency)
-        const float4* rq = reinterpret_cast<const float4*>(a.prec + p);
-        float4 q0 = rq[0], q3 = rq[3], q6 = rq[6], q7 = rq[7], q8 = rq[8], q9 = rq[9];
-        asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q0.z), "+v"(q3.w), "+v"(q6.y), "+v"(q6.z), "+v"(q6.w), "+v"(q7.x), "+v"(q7.y), "+v"(q7.z), "+v"(q7.w),
-                          "+v"(q8.x), "+v"(q8.y), "+v"(q8.w), "+v"(q9.x), "+v"(q9.y), "+v"(q9.z));
-        static_assert(offsetof(ParentRec, R) == 60 && offsetof(ParentRec, ec) == 100 && offsetof(ParentRec, active) == 140 && offsetof(ParentRec, ey) == 148,
-                      "k_spans reads the record by offsets");
-        const f3 pm = {q0.x, q0.y, q0.z};
-        const EllClip ec = {q6.y, q6.z, q6.w, q7.x, q7.y, q7.z, q7.w, q8.x, q8.y};
-        struct { float R, ey, ez; int active; } rv = {q3.w, q9.y, q9.z, __float_as_int(q8.w)};
-        const auto* rp = &rv;
-        selfq = __float_as_int(q9.x);
-        // The non-empty spans go to k_select in scan order (ascending row): in one trip of the loops below the parent's 16 lanes hold 16
-        // consecutive rows, so a span's place is the count so far plus the non-empty rows on the lanes below it.
-        const unsigned gsh = (unsigned)(threadIdx.x & 48);          // this parent's 16 lanes inside the wave's ballot
-        const auto keep_span = [&](int pass, int s, int len, int& n) {
-            const unsigned gm = (unsigned)(__ballot(len > 0) >> gsh) & 0xffffu;
-            if (len > 0 && a.rowlist) {
-                const int pos = n + __popc(gm & ((1u << sub) - 1u));
-                if (pos < SEL_ROWS) a.rowlist[((int64_t)p * 2 + pass) * SEL_ROWS + pos] = make_int2(s, len);
-            }
-            n += __popc(gm);
-        };
-        if (rp->active) {
-            const float Ra = fabsf(rp->R) * 1.00001f + g.slack;
-            const float Ra2 = Ra * Ra;
-            const int x0 = cell_of(pm.x - Ra, g.ox, g.inv_c, g.gx), x1 = cell_of(pm.x + Ra, g.ox, g.inv_c, g.gx);
-            {   // pass A (the same rows as select_scan<.., false>)
-                const bool clip = ec.on != 0.0f;
-                const float Ry = clip ? fminf(Ra, rp->ey + g.slack) : Ra, Rz = clip ? fminf(Ra, rp->ez + g.slack) : Ra;
-                const int y0 = cell_of(pm.y - Ry, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ry, g.oy, g.inv_c, g.gy);
-                const int z0 = cell_of(pm.z - Rz, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Rz, g.oz, g.inv_c, g.gz);
-                const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-                for (int r = sub; r < nrows; r += 16) {
-                    int s = 0, len = 0;
-                    select_row_span<false>(a, g, pm, ec, clip, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
-                    scanned += (unsigned long long)(len > 0 ? len : 0);
-                    keep_span(0, s, len, nA);
-                }
-            }
-            if (a.n_irr > 0) {      // pass B: the irregular list over the sphere's rows
-                const int y0 = cell_of(pm.y - Ra, g.oy, g.inv_c, g.gy), y1 = cell_of(pm.y + Ra, g.oy, g.inv_c, g.gy);
-                const int z0 = cell_of(pm.z - Ra, g.oz, g.inv_c, g.gz), z1 = cell_of(pm.z + Ra, g.oz, g.inv_c, g.gz);
-                const int ny = y1 - y0 + 1, nrows = ny * (z1 - z0 + 1);
-                for (int r = sub; r < nrows; r += 16) {
-                    int s = 0, len = 0;
-                    select_row_span<true>(a, g, pm, ec, false, Ra2, x0, x1, y0 + r % ny, z0 + r / ny, s, len);
-                    scanned += (unsigned long long)(len > 0 ? len : 0);
-                    keep_span(1, s, len, nB);
-                }
-            }
-        }
-    }
-    for (int o = 8; o > 0; o >>= 1) scanned += __shfl_xor(scanned, o);
-    if (selfq) scanned += 1ull;                                 // the parent itself is flat candidate 0
-    if (sub == 0) {
-        a.pcap[p] = (unsigned)(scanned > 0xffffffffull ? 0xffffffffull : scanned);
-        // (the record is this kernel's input and k_select's; the count rides in it so that k_select gets it with the record's scalar loads)
-        if (a.rowlist) const_cast<ParentRec*>(a.prec)[p].rows = (int)(0x80000000u | (unsigned)(nA > SEL_ROWS ? 0xff : nA) | ((unsigned)(nB > SEL_ROWS ? 0xff : nB) << 8));
-    }
 }
 
 // Longest-processing-time-first: work per parent is heavy-tailed (a few parents scan 10^5 candidates), so the
@@ -4113,16 +3099,21 @@ struct PartLevel {
     // Ownership follows the parents, so a rank CAN run out of components on a later level: that is data, not a local error.  The
     // ranks agree on the level's preconditions before its first data collective (one all-reduce of a status word), so that
     // every rank returns the error instead of one returning and its peers waiting in the next collective for ever.
-    int32_t agree_on_preconditions(int64_t n) {
+    int32_t agree_on_preconditions(int64_t n, unsigned local_code) {
         GSR_TRY(c->pcounts.reserve(64));
-        const unsigned status = n == 0 ? 1u : 0u;
+        // (every rank-local precondition rides in the word: the largest code over the ranks is everybody's answer)
+        const unsigned status = local_code ? local_code : (n == 0 ? 1u : 0u);
         GSR_HIP(hipMemcpyAsync(c->pcounts.p, &status, 4, hipMemcpyHostToDevice, st));
         GSR_HIP(hipStreamSynchronize(st));               // (status lives on this stack frame)
         GSR_TRY(gsr_comm_allreduce(c->comm, c->pcounts.p, 1, GSR_DT_U32, GSR_OP_MAX, (void*)st));
         unsigned agreed = 0;
         GSR_HIP(hipMemcpyAsync(&agreed, c->pcounts.p, 4, hipMemcpyDeviceToHost, st));
         GSR_HIP(hipStreamSynchronize(st));
-        if (agreed) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank of the partitioned level owns no component (reported on every rank; use fewer ranks)");
+        if (agreed == 1u) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank of the partitioned level owns no component (reported on every rank; use fewer ranks)");
+        if (agreed == 2u) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank holds 2^30 or more components (reported on every rank)");
+        if (agreed == 3u) return fail(GSR_E_INVALID, "gsr_hem_run_level: more than 8 ranks");
+        if (agreed == 4u) return fail(GSR_E_INVALID, "gsr_hem_run_level: spatial partition and work sharding are exclusive (reported on every rank)");
+        if (agreed) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank failed a precondition of the partitioned level (code %u)", agreed);
         return GSR_OK;
     }
 
@@ -4549,7 +3540,7 @@ int32_t LevelRun::grid_phase() {
     GSR_TRY(c->iflag.reserve((n + 1) * 4)); GSR_TRY(c->irank.reserve((n + 1) * 4)); GSR_TRY(c->ipos.reserve(n * 4)); GSR_TRY(c->ppos.reserve(n * 4)); GSR_TRY(c->plist.reserve(n * 4));
     const bool tail = !part && F > 0;
     if (tail) GSR_TRY(c->sh_tail.reserve((size_t)(RSH + 4) * 4));
-    hipLaunchKernelGGL(k_gather, grd, blk, 0, st, n, c->order.as<unsigned>(), rec_src, c->delta, c->A.as<float4>(), c->geo.as<float4>(),
+    hipLaunchKernelGGL(k_gather, dim3((unsigned)((n + 255) / 256)), blk, 0, st, n, c->order.as<unsigned>(), rec_src, c->delta, c->A.as<float4>(), c->geo.as<float4>(),
                        c->Rs.as<float>(), c->pflag.as<int>(), c->iflag.as<int>(), L.sh.as<float>(), F, tail ? c->sh_tail.as<float>() : (float*)nullptr);
     // (a partitioned level: forked here -- the third stream carries the ghosts' SH rows, the gather queues up behind them; one GPU: behind
     // the selection, when the pair count that decides about the copy exists)
@@ -4640,28 +3631,19 @@ int32_t LevelRun::select_phase() {
     // parents per selection wave: SEL_NP, but no fewer waves than the chip holds at once (256 CUs x 28)
     sa.np = c->select_np > 0 ? c->select_np : (P >= SEL_NP * 7168 ? SEL_NP : (P >= 2 * 7168 ? 2 : 1));
     M = 0;
-    constexpr int WPB = 2;      // parents per workgroup (work per parent is heavy-tailed: small workgroups free their CU slot sooner)
-    // the queue-serving kernel runs beside the light parents' on the context's second stream (fork / join by events)
-#define GSR_LAUNCH_SELECT(MODE) do { \
-        if (sa.heavy_blocks) { \
-            GSR_HIP(hipEventRecord(c->ev_fork, st)); GSR_HIP(hipStreamWaitEvent(c->aux, c->ev_fork, 0)); \
-            hipLaunchKernelGGL((k_select<MODE, WPB, true>), dim3(sa.heavy_blocks), dim3(64 * WPB), 0, c->aux, sa); \
-            GSR_HIP(hipEventRecord(c->ev_join, c->aux)); \
-        } \
-        hipLaunchKernelGGL((k_select<MODE, WPB, false>), dim3(8 * ceil_div(ceil_div(P, WPB * sa.np), 8)), dim3(64 * WPB), 0, st, sa); \
-        if (sa.heavy_blocks) GSR_HIP(hipStreamWaitEvent(st, c->ev_join, 0)); \
-    } while (0)
+    constexpr int WPB = SEL_WPB;
+    // (the queue-serving kernel runs beside the light parents' on the context's second stream: launch_select forks / joins by events)
+#define GSR_LAUNCH_SELECT(MODE) GSR_TRY(launch_select(MODE, sa, st, c->aux, c->ev_fork, c->ev_join))
     c->sparse_path = false;
     if (P > 0) {
         GSR_TRY(c->prec.reserve(Pm * sizeof(ParentRec)));
-        hipLaunchKernelGGL(k_parent_prep, dim3(stride_grid(P)), blk, 0, st, P, c->plist.as<unsigned>(), c->geo.as<float4>(), c->Rs.as<float>(),
-                           sa.kldThr, sa.ell, c->prec.as<ParentRec>());
+        launch_parent_prep(st, P, c->plist.as<unsigned>(), c->geo.as<float4>(), c->Rs.as<float>(), sa.kldThr, sa.ell, c->prec.as<ParentRec>());
         sa.prec = c->prec.as<ParentRec>();
         if (c->use_rowlist) {
             GSR_TRY(c->rowlist.reserve(Pm * 2 * SEL_ROWS * sizeof(int2)));
             sa.rowlist = c->rowlist.as<int2>();
         }
-        hipLaunchKernelGGL(k_spans, dim3(ceil_div(P, 16)), dim3(256), 0, st, sa);      // candidates scanned per parent
+        launch_spans(st, sa);                                                         // candidates scanned per parent
         GSR_TRY(c->coff.reserve((Pm + 1) * 8));
         GSR_TRY(widen_scan(c->pcap.as<unsigned>(), c->coff.as<int64_t>(), P));
         // what the pair buffers hold today: an asynchronous level runs on that (k_select clamps every segment to it)
@@ -5177,12 +4159,13 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
     memset(c->part_stats, 0, sizeof(c->part_stats));
     c->stats[6] = n;
     if (part) {
+        // the rank-local preconditions of a partitioned level are AGREED ON before its first data collective (one all-reduce of a status
+        // word): a rank that returned by itself would leave its peers in the next collective for ever
         pl.W = gsr_comm_world(c->comm); pl.me = gsr_comm_rank(c->comm);
-        if (pl.W > 8) return fail(GSR_E_INVALID, "gsr_hem_run_level: more than 8 ranks");
+        const unsigned code = c->shard_world > 1 ? 4u : (pl.W > 8 ? 3u : (n >= (1ll << 30) ? 2u : 0u));
+        GSR_TRY(pl.agree_on_preconditions(n, code));
     }
     if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld components (the candidate records carry the sorted position in 30 bits)", (long long)n);
-    if (part && c->shard_world > 1) return fail(GSR_E_INVALID, "gsr_hem_run_level: spatial partition and work sharding are exclusive");
-    if (part) GSR_TRY(pl.agree_on_preconditions(n));
     if (n == 0) {
         if (n_out) *n_out = 0;
         if (n_dropped) *n_dropped = 0;
@@ -5318,15 +4301,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
 }
 
 #ifdef GSR_SELECT_PROFILE
-int32_t gsr_debug_select_profile(unsigned long long* out16, int32_t reset) {
-    static unsigned long long h[1024 * 16];
-    if (out16) {
-        if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_sel_prof), sizeof(h)) != hipSuccess) return GSR_E_HIP;
-        for (int k = 0; k < 16; ++k) { out16[k] = 0; for (int b = 0; b < 1024; ++b) out16[k] += h[b * 16 + k]; }
-    }
-    if (reset) { memset(h, 0, sizeof(h)); if (hipMemcpyToSymbol(HIP_SYMBOL(g_sel_prof), h, sizeof(h)) != hipSuccess) return GSR_E_HIP; }
-    return GSR_OK;
-}
+int32_t gsr_debug_select_profile(unsigned long long* out16, int32_t reset) { return select_profile(out16, reset); }
 #endif
 
 int32_t gsr_debug_logf(const float* x, int64_t n, float* out, int32_t device) {

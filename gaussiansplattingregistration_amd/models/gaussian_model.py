@@ -121,7 +121,13 @@ class GaussianModel:
             device = torch.device(self.device_name).index or 0
         if is_path and device is not None:
             self.device_name = f"cuda:{int(device)}"
-            d = ply_io.load_gaussian_device(path_or_arrays, int(device), timing=timing)
+            try:
+                d = ply_io.load_gaussian_device(path_or_arrays, int(device), timing=timing)
+            except ValueError:
+                # the device loader takes binary little-endian float32 files whose vertex element comes first (what 3DGS writes); anything else the
+                # format allows -- ASCII, big-endian, other property types, other element orders -- goes through the host reader, like the
+                # reference's plyfile would read it, and is uploaded afterwards (from_arrays below)
+                d = ply_io.load_gaussian_arrays(path_or_arrays)
         else:
             d = ply_io.load_gaussian_arrays(path_or_arrays) if is_path else path_or_arrays
         self.from_arrays(d["xyz"], d["color"], d["opacity"], d["cov6"], d["sh"], d["sh_degree"])

@@ -4,6 +4,7 @@ set -euo pipefail
 mkdir -p variants
 NAME=$1; FLAGS=${2:-}
 C=gaussiansplattingregistration_amd/csrc
-hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -mllvm -disable-machine-licm $FLAGS -c $C/hem.hip -o /tmp/hem_$NAME.o
-hipcc --offload-arch=gfx950 -shared -fPIC /tmp/hem_$NAME.o $C/icp.o $C/voxel.o $C/model.o $C/comm.o -o variants/$NAME.so
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result $FLAGS -c $C/hem.hip -o /tmp/hem_$NAME.o
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-result -mllvm -disable-machine-licm $FLAGS -c $C/hem_select.hip -o /tmp/hem_select_$NAME.o
+hipcc --offload-arch=gfx950 -shared -fPIC /tmp/hem_$NAME.o /tmp/hem_select_$NAME.o $C/icp.o $C/voxel.o $C/model.o $C/comm.o -o variants/$NAME.so
 echo built variants/$NAME.so
