@@ -704,6 +704,12 @@ def main():
                 "why_not_hbm_bound": "the level evaluates ~170 candidate tests and ~50 KL divergences per input splat and gathers 256 bytes per accepted pair "
                                      "(22 pairs per splat) -- neighbour work the 8(d) byte model does not count: k_select is bound by VALU issue and L2 request rate, "
                                      "k_mstep by the L2 -> CU gather rate (28 GB per 5 M level), see DESIGN.md 4"}
+        lvl_pmc, _ = pmc_summary("level_total")
+        if lvl_pmc and l1_bytes:
+            # the whole 5 M level's HBM traffic (every gsr:: kernel of it, the same PMC passes) against SURVEY 8(d)'s algorithmic bytes
+            roof["level1"].update({"traffic_raw": lvl_pmc["traffic_raw"], "traffic": lvl_pmc["traffic_x2"],
+                                   "traffic_raw_over_algorithmic": lvl_pmc["traffic_raw"] / l1_bytes, "traffic_over_algorithmic": lvl_pmc["traffic_x2"] / l1_bytes,
+                                   "traffic_source": lvl_pmc["source"] + " (level_total: FETCH_SIZE + WRITE_SIZE of every gsr:: kernel of one level; `traffic` with FETCH_SIZE x 2)"})
         if pmc:
             rd_raw, wr = pmc.get("hbm_read_bytes_per_launch_raw", 0.0), pmc.get("hbm_write_bytes_per_launch", 0.0)
             roof["traffic"] = pmc.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) + wr
@@ -770,6 +776,10 @@ def main():
             "hem_s_per_step": hem_s / a.steps, "icp_s_per_step": icp_s / a.steps,
             "icp_result": {"fitness": last["fitness"], "inlier_rmse": last["rmse"], "T_err_vs_ground_truth_F": float(np.linalg.norm(last["T"] - T_gt))},
             "hem_phase_ms_per_step": phases,
+            # per level of the LAST step, in order (cloud 1: levels 1-3, cloud 2: levels 1-3): input size, time, host round trips (1 = the asynchronous
+            # schedule: one answer behind the level's last kernel), schedule (1 asynchronous, 0 synchronous, 2 an asynchronous attempt rerun)
+            "hem_levels_last_step": [{"n_in": k["n_in"], "n_out": k["n_out"], "ms_level": k["ms_level"], "round_trips": k.get("round_trips"),
+                                      "schedule": k.get("schedule"), "dropped": k["dropped"]} for k in last["kern"]],
             "roofline": roof,
         }
         if strong is not None:
@@ -787,20 +797,21 @@ def main():
                 ca = synth.make_cloud_torch(n, seed=300, device=dev, shape="aniso")
                 m = ctxs["hem"]
                 rows = []
-                for _ in range(3):
+                for _ in range(5):                  # (the first repetitions on another shape grow the context's buffers: the last three count)
                     m.set_rng("glibc", 1, 0)
                     m.set_level0(ca["xyz"], ca["color"], ca["opacity"], ca["cov6"], ca["sh"], borrow=True)
                     m.run_level()
                     rows.append(m.stats())
                 st = rows[-1]
-                ms = float(np.median([r["ms_level"] for r in rows]))
+                ms = float(np.median([r["ms_level"] for r in rows[2:]]))
                 c6 = ca["cov6"][:200000].double().cpu().numpy()
                 ev = np.linalg.eigvalsh(np.stack([c6[:, [0, 1, 2]], c6[:, [1, 3, 4]], c6[:, [2, 4, 5]]], 1))
                 line["aniso_level"] = {"workload": f"one {n}-splat cloud, synth shape 'aniso' (60 % discs, 15 % needles on a smooth orientation field), level 1",
                                        "condition_number_percentiles_50_90_99": [float(v) for v in np.percentile(ev[:, 2] / ev[:, 0], [50, 90, 99])],
                                        "irregular_fraction": st["irregular"] / st["n_in"], "parents": st["parents"],
                                        "candidates_per_parent": st["candidates"] / max(1, st["parents"]), "pairs": st["pairs"], "orphans": st["orphans"],
-                                       "n_out": st["n_out"], "ms_level": ms, "ms_k_select": st["ms_k_select"], "ms_k_mstep": st["ms_k_mstep"],
+                                       "n_out": st["n_out"], "dropped": st["dropped"], "round_trips": st["round_trips"], "schedule": st["schedule"],
+                                       "ms_level": ms, "ms_k_select": st["ms_k_select"], "ms_k_mstep": st["ms_k_mstep"],
                                        "gaussians_per_s": st["n_in"] / (ms * 1e-3),
                                        "iso_level1_ms_same_n": l1_ms, "ratio_to_iso_level": ms / l1_ms if l1_ms else None}
                 del ca
@@ -813,15 +824,15 @@ def main():
                 cc = synth.make_cloud_torch(n, seed=400, device=dev, shape="clustered")
                 m = ctxs["hem"]
                 rows = []
-                for rep in range(4):
-                    m.set_timing(2 if rep == 3 else 1)                  # three timed like the isotropic level, a fourth with the phase events on
+                for rep in range(6):
+                    m.set_timing(2 if rep == 5 else 1)                  # two to grow the buffers, three timed like the isotropic level, a sixth with the phase events on
                     m.set_rng("glibc", 1, 0)
                     m.set_level0(cc["xyz"], cc["color"], cc["opacity"], cc["cov6"], cc["sh"], borrow=True)
                     m.run_level()
                     rows.append(m.stats())
                 m.set_timing(1)
                 st = rows[-1]
-                ms = float(np.median([r["ms_level"] for r in rows[:3]]))
+                ms = float(np.median([r["ms_level"] for r in rows[2:5]]))
                 line["clustered_level"] = {"workload": f"one {n}-splat cloud, synth shape 'clustered' (60 % in 40 Gaussian clumps of 30-100 x the background density with "
                                                        "splats shrunk by the cube root of that, 6 giants of 40 x sigma, 12 outliers at 20-60 h), level 1",
                                            "parents": st["parents"], "candidates_per_parent": st["candidates"] / max(1, st["parents"]), "pairs": st["pairs"],

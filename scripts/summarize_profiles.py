@@ -93,6 +93,15 @@ for k, v in pmc.items():
         e["l2_hit_rate"] = v["TCC_HIT_sum"] / max(1.0, v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
     derived(e, v, n)
     out[k] = e
+# the whole level: every kernel's launches of the pass added up, per repetition of the level (the pass runs scripts/prof_hem.py ... 2: the
+# level twice; a level's prologue runs with its input and the next level's behind its last kernel -- both are in the sum)
+REPS = 2
+tot_r = sum(e.get("hbm_read_bytes_per_launch_raw", 0.0) * e["launches_in_pass"] for k, e in out.items() if isinstance(e, dict)) / REPS
+tot_w = sum(e.get("hbm_write_bytes_per_launch", 0.0) * e["launches_in_pass"] for k, e in out.items() if isinstance(e, dict)) / REPS
+out["level_total"] = {"repetitions_in_pass": REPS, "hbm_read_bytes_raw": tot_r, "hbm_read_bytes_x2_corrected": 2.0 * tot_r, "hbm_write_bytes": tot_w,
+                      "traffic_raw": tot_r + tot_w, "traffic_x2": 2.0 * tot_r + tot_w,
+                      "note": "sum over every gsr:: kernel of one 5 M-splat level (FETCH_SIZE + WRITE_SIZE); rocPRIM's sorts and scans are not gsr:: kernels "
+                              "and are left out (~0.2 GB)"}
 json.dump(out, open(dst + "_pmc.json", "w"), indent=1, sort_keys=True)
 
 
