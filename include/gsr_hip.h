@@ -157,7 +157,9 @@ int32_t gsr_hem_set_shard(gsr_hem_ctx* ctx, int32_t rank, int32_t world, gsr_all
  *     fixed-point partial sums, the owners' float32 sums back -- no floating-point value is ever combined across ranks.
  * The new level stays distributed (gsr_hem_get_level returns the owned rows, gsr_hem_get_gids their global indices; ownership
  * follows the parents).  All of it goes through the communicator: RCCL enqueued on the context's stream, or callbacks.
- * ERRORS ARE LOCAL: a rank whose call fails (an allocation, a callback returning non-zero) returns its error code while the
+ * A level's rank-local PRECONDITIONS (a rank that owns nothing, 2^30 components, more than 8 ranks) are agreed on with one all-reduce
+ * of a status word before its first data collective: every rank returns the same error.  Beyond that ERRORS ARE LOCAL: a rank whose
+ * call fails (an allocation, a callback returning non-zero) returns its error code while the
  * other ranks are inside or in front of the next collective -- as with any RCCL program the caller must then abort the process
  * group (ncclCommAbort / tear the job down); the library does not try to agree on a status across ranks.  The same holds for
  * gsr_icp_register with a communicator or an all-reduce callback. */
@@ -185,7 +187,13 @@ int32_t gsr_hem_set_output(gsr_hem_ctx* ctx, float* xyz, float* color, float* co
 
 /* One clustering level on the current level (Mixture::createClusterLevel, mixture.cpp:66-285).
  * n_out = components of the new level (after the validity erase); n_dropped = components erased by
- * it (the reference prints these to cerr, mixture.cpp:270-274).  The new level becomes current. */
+ * it (the reference prints these to cerr, mixture.cpp:270-274).  The new level becomes current.
+ * The call returns when the level is complete.  On one GPU it makes ONE host round trip, behind the level's last kernel (the level's
+ * own prologue -- grid geometry, parent count -- was computed with its input and travelled with the round trip of gsr_hem_set_level0 /
+ * of the level before; every other count stays on the device and every write is clamped to the context's buffers).  When those buffers
+ * turn out too small -- a context's first level, a much larger cloud than before -- the level is run again with every buffer sized from
+ * counts read back on the way (gsr_hem_get_stats_ex [6], [7]); its input is never written, the result is the same.  GSR_HEM_ASYNC=0
+ * always takes that second schedule.  (The reference's level has no such boundary: one function, mixture.cpp:25-35.) */
 int32_t gsr_hem_run_level(gsr_hem_ctx* ctx, int64_t* n_out, int64_t* n_dropped);
 
 int32_t gsr_hem_level_size(gsr_hem_ctx* ctx, int64_t* n, int32_t* F);
@@ -202,7 +210,10 @@ int32_t gsr_hem_get_stats(gsr_hem_ctx* ctx, int64_t* out8);
  * verified symmetric positive definite with an accurate float32 determinant -- they take the exact gates only)
  * [1] 1 = the one-pass selection ran, 0 = the COUNT + FILL fallback  [2] 1 = a bucket region of the pair partition overflowed (in this level or an
  * earlier one of the context) and the level's sums took the exact partition  [3] heavy parents (candidates scanned > 16 x the mean: cut
- * into work items)  [4] their work items  [5] the largest number of accepted pairs of one parent  [6..7] reserved (0). */
+ * into work items)  [4] their work items  [5] the largest number of accepted pairs of one parent
+ * [6] host round trips of the level (1: the asynchronous schedule; 4-6: the synchronous one)
+ * [7] schedule: 1 = no round trip between the level's first and last kernel, 0 = synchronous (buffers sized from counts read back on the way: a
+ *     context's first level, partitioned / sharded levels, GSR_HEM_ASYNC=0), 2 = an asynchronous attempt whose buffers were too small, rerun. */
 int32_t gsr_hem_get_stats_ex(gsr_hem_ctx* ctx, int64_t* out8);
 /* Device time of the phases of the most recent level, in milliseconds (hipEvent pairs on the
  * context's stream):  [0] prep+grid  [1] selection (count+scan+fill)  [2] per-child sums
