@@ -530,8 +530,16 @@ def main():
         # degrees about its centre would move the corners by four correspondence distances -- nearest-neighbour ICP cannot start from there
         # (measured at full size, profiles/r05a_bench_c5_40m_8ranks_one_gpu.json: fitness 0.59, T_err 0.76)
         rel = min(1.0, synth.half_extent(5_000_000) / src["h"])
-        T_gt = synth.rigid_transform(PAIR_ANGLE_DEG * rel, (1, 1, 1), PAIR_SHIFT_H * rel * src["h"] * np.array([1.0, -1.0, 0.5]))
         nt = min(a.target_splats, n)
+        # ... and the target is a SUB-SAMPLE of the scene: (n / nt)^(1/3) times the point spacing the schedule's correspondence distances were
+        # chosen for (a 5 M target in the volume of a 40 M scene: twice the spacing).  They scale with it, and the pair's motion with them
+        # -- the same ratio of displacement to max_corr as on the 2 x 5 M pair (without it: fitness 0.61, T_err 0.22 at full size)
+        global MAX_CORR
+        corr_scale = (n / nt) ** (1.0 / 3.0)
+        MAX_CORR = [m_ * corr_scale for m_ in MAX_CORR]
+        rel = min(1.0, rel * corr_scale)
+        PAIR_ANGLE_DEG, PAIR_SHIFT_H = PAIR_ANGLE_DEG * rel, PAIR_SHIFT_H * rel
+        T_gt = synth.rigid_transform(PAIR_ANGLE_DEG, (1, 1, 1), PAIR_SHIFT_H * src["h"] * np.array([1.0, -1.0, 0.5]))
         fields = ("xyz", "color", "opacity", "cov6", "sh")
         parts = {f: [] for f in fields}
         for r in range(world):

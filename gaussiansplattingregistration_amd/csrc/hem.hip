@@ -3408,7 +3408,8 @@ struct LevelRun {
     int32_t mstep_phase();
     int32_t flags_and_validity();
     int32_t compact_erased(int64_t n_keep);
-    int32_t erase_in_place(int64_t rows_bound);
+    int32_t erase_in_place(int64_t rows_bound, bool may_allocate);
+    bool erase_on_device = false;           // the erase kernels were enqueued (an asynchronous level without the tails' buffer leaves the erase to the host)
     int32_t launch_gather_sh(bool fork);
     int32_t widen_scan(const unsigned* cnt_in, int64_t* off, int64_t count);
     int32_t total_of(const int64_t* off, const unsigned* cnt_in, int64_t count, int64_t* out);
@@ -4061,7 +4062,18 @@ int32_t LevelRun::mstep_phase() {
 
 // The validity erase in place, on the device (k_erase_save + k_erase_shift): lvl[0] = rows before it, cnt[3] / c->holes = what k_valid found;
 // lvl[4] = rows after it.  Both kernels leave at once when there is nothing to erase -- or more than ERASE_MAX rows (the host's path then).
-int32_t LevelRun::erase_in_place(int64_t rows_bound) {
+int32_t LevelRun::erase_in_place(int64_t rows_bound, bool may_allocate) {
+    // (the saved tails need 32 rows per tile of the bound -- 150 MB at 5 M rows -- and most clouds never erase a row: the buffer is allocated
+    // the first time a level of this context does, by the host's path; until then an asynchronous level only COUNTS the erased rows)
+    {
+        const int tile0 = std::min(256, 12288 / std::max(F, 6));
+        const size_t need = (size_t)((rows_bound + tile0 - 1) / tile0 + 1) * ERASE_MAX * ((size_t)(14 + F) * 4 + 1) + 64;
+        if (!may_allocate && c->erase_halo.cap < need) {
+            hipLaunchKernelGGL(k_fill_const<long long>, dim3(1), dim3(1), 0, st, (int64_t)1, lvl + 4, (long long)0);     // (unused: the prologue reads lvl[0])
+            return GSR_OK;
+        }
+    }
+    erase_on_device = true;
     EraseArgs ea;
     memset(&ea, 0, sizeof(ea));
     float* arrs[6] = {O.xyz.as<float>(), O.color.as<float>(), O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>()};
@@ -4140,7 +4152,7 @@ int32_t LevelRun::flags_and_validity() {
         }
         if (dropped > 0 && dropped <= ERASE_MAX && !part) {         // a handful of rows: in place, on the device
             hipLaunchKernelGGL(k_fill_const<long long>, dim3(1), dim3(1), 0, st, (int64_t)1, lvl, (long long)n_pre);
-            GSR_TRY(erase_in_place(n_pre));
+            GSR_TRY(erase_in_place(n_pre, true));
             O.n = n_pre - dropped;
         } else if (dropped > 0) {
             if (!part) GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
@@ -4199,9 +4211,9 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
         GSR_TRY(c->holes.reserve(ERASE_MAX * 4));
         hipLaunchKernelGGL(k_valid, dim3(stride_grid(out_cap)), blk, 0, st, out_cap, O.xyz.as<float>(), O.cov6.as<float>(), c->keep.as<int>(), (const long long*)lvl, cnt + 3,
                            c->holes.as<int>());
-        GSR_TRY(erase_in_place(out_cap));               // (leaves at once when nothing is erased; lvl[4] = the rows that remain)
+        GSR_TRY(erase_in_place(out_cap, false));        // (leaves at once when nothing is erased; lvl[4] = the rows that remain)
         GSR_TIME1(c->ev[5], st);
-        GSR_TRY(enqueue_prologue(c, O, out_cap, lvl + 4, cb_next));
+        GSR_TRY(enqueue_prologue(c, O, out_cap, erase_on_device ? lvl + 4 : lvl, cb_next));
         q.lvl = lvl;
         GSR_TRY(read_back_level(c, q, w));
         if (w[LC_FLAGS] != 0ull) return GSR_RETRY_SYNC;        // a clamped segment, a full bucket region or item table, an output too small
@@ -4212,9 +4224,12 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
         O.n = n_pre;
         P_glob = P; O_glob = n_orph; n_pre_glob = n_pre; n_glob_next = n_pre;
         dropped = (int64_t)w[LC_DROPPED];
-        have_next = dropped <= ERASE_MAX;               // (erased in place on the device: the prologue saw the level as it is now)
+        have_next = dropped == 0 || (erase_on_device && dropped <= ERASE_MAX);      // (erased in place on the device: the prologue saw the level as it is now)
         if (have_next) O.n = n_pre - dropped;
-        else {                          // many rows to erase: the host finishes the level (scan + compaction), and the prologue is taken again
+        else if (dropped <= ERASE_MAX) {                // the first level of this context that erases rows: in place, from here (the buffer exists from now on)
+            GSR_TRY(erase_in_place(n_pre, true));
+            O.n = n_pre - dropped;
+        } else {                        // many rows to erase: the host finishes the level (scan + compaction), and the prologue is taken again
             GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
             GSR_TRY(compact_erased(n_pre - dropped));
         }
