@@ -1123,15 +1123,19 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
 #define MSTEP_SEG 2048        // pairs per SEGMENT of a parent's sums (a multiple of MSTEP_CHUNK); see mstep_segment
 #define MSTEP_NV 3            // float4 per lane and SH row
 #define MSTEP_K 4             // parents per wavefront
-#define MSTEP_U 3             // rounds of SH row loads in flight (each: MSTEP_NV float4 per lane, 64/G children)
+#ifndef MSTEP_U
+#define MSTEP_U 4             // rounds of SH row loads in flight (each: MSTEP_NV float4 per lane, 64/G children)
+#endif
 
 // One SEGMENT of a parent's sums: the pairs [off, off + cnt) (cnt <= MSTEP_SEG), from zero.  Leaves the 14 moment sums in s_mom and
-// the SH sums, folded over the lane classes, in acc (every lane of a class holds the class's total).
+// the SH sums folded over the lane classes: G <= 16 (mstep_packed) in shp -- shp[v] of a lane of row q and class gl = lane mod G is
+// the total of float 4 (gl + G v) + packed_slot(q) of the row, the four components of a float4 spread over the wave's four rows
+// (two sums per swap, see pack32_sum) --, larger rows in acc (every lane of a class holds the class's total of its float4).
 // How a parent's sums are DEFINED (all paths agree bit for bit, test_mstep_heavy_parent_split_changes_nothing): its pairs are cut
-// into segments of MSTEP_SEG; inside a segment the sums run as they always did -- chunks of MSTEP_CHUNK pairs, lane l of a chunk
-// taking pairs l, l + 64, ..., the chunk's lane sums folded by class_sum<1> and added to the segment's running sums in chunk order,
-// the SH products accumulated per lane group along the segment by fused multiply-adds and folded once at its end -- and the
-// segments' totals are added in segment order.  A parent of at most MSTEP_SEG pairs (all but the giants) is one segment: nothing
+// into segments of MSTEP_SEG; inside a segment the sums run in chunks of MSTEP_CHUNK pairs, lane l of a chunk
+// taking pairs l, l + 64, ..., the chunk's lane sums folded over the lanes (moment_sums: halves, row pairs, then inside the row) and
+// added to the segment's running sums in chunk order, the SH products accumulated per lane group along the segment by fused
+// multiply-adds and folded once at its end (the same order of levels) -- and the segments' totals are added in segment order.  A parent of at most MSTEP_SEG pairs (all but the giants) is one segment: nothing
 // changed for it.  The giants' segments are independent, which is the point: a parent with 5 * 10^4 pairs (found on the surfel
 // cloud) kept ONE wave busy for 2.5 ms, the whole M-step of that level.
 // The 14 moment sums of the parent in flight live in the PADDING of the record stage (s_rec rows are 80 bytes apart for the sake of the
@@ -1148,6 +1152,7 @@ __device__ __forceinline__ const float* sh_row_of(const float* rows, const float
     const float* r = rows + (int64_t)idx * stride;
     return idx == last ? tail : r;
 }
+__host__ __device__ constexpr bool mstep_packed(int G) { return G >= 1 && G <= 16; }
 struct MomRef {
     float4* rec;
     __device__ __forceinline__ float& operator[](int i) const { return reinterpret_cast<float*>(rec + (60 + (i >> 2)) * 5 + 4)[i & 3]; }
@@ -1155,7 +1160,7 @@ struct MomRef {
 template <int G>
 __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int gl, int grp, const int (&qi)[MSTEP_NV], float* s_w, unsigned* s_j,
                                               float4* s_acc, MomRef s_mom, float4* s_rec, long long off, unsigned cnt, const f3 pm,
-                                              float4 (&acc)[MSTEP_NV]) {
+                                              float4 (&acc)[MSTEP_NV], float (&shp)[MSTEP_NV]) {
     constexpr int GG = G > 0 ? G : 1;
     constexpr int CPR = 64 / GG;                                // children per round
     const int sh_stride = a.sh_direct ? a.F : a.RSH;            // floats between two SH rows (qi: this lane's float offsets inside a row)
@@ -1216,16 +1221,16 @@ __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int 
                 }
                 if (live) s_w[k] = w;
             }
-            // the chunk's 14 sums over the lanes, then out of the registers (part 2 needs them for its row loads)
-            w_s = class_sum<1>(w_s);
-            smx = class_sum<1>(smx); smy = class_sum<1>(smy); smz = class_sum<1>(smz);
-            scx = class_sum<1>(scx); scy = class_sum<1>(scy); scz = class_sum<1>(scz);
-            v00 = class_sum<1>(v00); v01 = class_sum<1>(v01); v02 = class_sum<1>(v02);
-            v11 = class_sum<1>(v11); v12 = class_sum<1>(v12); v22 = class_sum<1>(v22);
-            so = class_sum<1>(so);
-            if (lane == 0) {
-                s_mom[0] += w_s; s_mom[1] += smx; s_mom[2] += smy; s_mom[3] += smz; s_mom[4] += scx; s_mom[5] += scy; s_mom[6] += scz;
-                s_mom[7] += v00; s_mom[8] += v01; s_mom[9] += v02; s_mom[10] += v11; s_mom[11] += v12; s_mom[12] += v22; s_mom[13] += so;
+            // the chunk's 14 sums over the lanes (moment_sums: two values per swap, four registers left for the row level), then out of
+            // the registers (part 2 needs them for its row loads): the first lane of each row adds the row's four values
+            const float mom[14] = {w_s, smx, smy, smz, scx, scy, scz, v00, v01, v02, v11, v12, v22, so};
+            float mr[4];
+            moment_sums(mom, mr);
+            if ((lane & 15) == 0) {
+                const int q = lane >> 4;
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) s_mom[moment_of(jj, q)] += mr[jj];
+                if ((q & 1) == 0) s_mom[moment_of(3, q)] += mr[3];
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -1268,8 +1273,13 @@ __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int 
     if (G > 0) {
 #pragma unroll
         for (int v = 0; v < MSTEP_NV; ++v) {
-            acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
-            acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
+            if constexpr (mstep_packed(G)) {
+                // x, y, z, w of the float4 end in rows 0, 2, 1, 3 (packed_slot), each row holding its component's class totals
+                shp[v] = row_class_sum<GG>(pack16_sum(pack32_sum(acc[v].x, acc[v].y), pack32_sum(acc[v].z, acc[v].w)));
+            } else {
+                acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
+                acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
+            }
         }
     }
 }
@@ -1314,10 +1324,17 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                 const unsigned first = it.y * MSTEP_SEG;
                 const unsigned cn = h.cnt - first < MSTEP_SEG ? h.cnt - first : MSTEP_SEG;
                 float4 acc[MSTEP_NV];
-                mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off + first, cn, pm, acc);
+                float shp[MSTEP_NV];
+                mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off + first, cn, pm, acc, shp);
                 float* rec = a.hscratch + (int64_t)item * RS;
                 if (lane < 14) rec[lane] = s_mom[lane];
-                if (G > 0 && grp == 0) {
+                if constexpr (mstep_packed(G)) {
+                    if ((lane & 15) < GG) {
+#pragma unroll
+                        for (int v = 0; v < MSTEP_NV; ++v)
+                            if (gl + GG * v < nq) rec[16 + 4 * (gl + GG * v) + packed_slot(lane >> 4)] = shp[v];
+                    }
+                } else if (G > 0 && grp == 0) {
 #pragma unroll
                     for (int v = 0; v < MSTEP_NV; ++v)
                         if (gl + GG * v < nq) reinterpret_cast<float4*>(rec + 16)[gl + GG * v] = acc[v];
@@ -1340,10 +1357,10 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
     // The wave's small parents are served TOGETHER, parent q in DPP row q (lanes 16 q .. 16 q + 15), instead of one after the other
     // with 6 of 64 lanes alive: one pair-list load, one record gather, one set of row loads and one output sequence for up to four
     // parents.  Bit for bit the sums of the general path below: there lane l < 16 holds pair l, the lanes above hold +0.0, and
-    // class_sum<1> is the row-local rotations followed by two additions of +0.0 (swap16, swap32); the SH sum of a parent with
-    // <= 16 pairs is one product per lane group (16 / G groups per row), reduced by class_sum<G>'s row-local rotations inside each
-    // of the wave's four rows and then (S0 + S1) + (S2 + S3) over the rows -- here the four rows of the general path are four
-    // ROUNDS of this parent's own row, combined in the same order.  (G <= 4: a round then holds 16 / G >= 4 children per row and
+    // moment_sums is two additions of +0.0 (the other half, the other row of the pair) followed by row_sum16; the SH sum of a parent
+    // with <= 16 pairs is one product per lane group (16 / G groups per row), and the general path folds its four rows first over the
+    // halves, (S0 + S2) and (S1 + S3), then over the row pairs, then inside the row (class G) -- here the four rows of the general path
+    // are four ROUNDS of this parent's own row, combined in the same order.  (G <= 4: a round then holds 16 / G >= 4 children per row and
     // <= 16 children never chain two products through one fmaf; larger rows -- SH degree 4 and up -- take the general path.)
     // The wave's (up to four) headers with ONE load: lane l takes dword l of the 128 contiguous bytes, a field is a v_readlane away.
     // (`a.hdr[s0 + it]` per parent came out as vector loads of one header at a time, each waited for: eight dependent round trips at
@@ -1491,12 +1508,12 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                     if (r < GG) {       // the general path's first accumulation into a zero: fmaf(row, w, +0.0); an absent child: +0.0
                         pr.x = __builtin_fmaf(rowv[r][v].x, wr[r], 0.0f); pr.y = __builtin_fmaf(rowv[r][v].y, wr[r], 0.0f);
                         pr.z = __builtin_fmaf(rowv[r][v].z, wr[r], 0.0f); pr.w = __builtin_fmaf(rowv[r][v].w, wr[r], 0.0f);
-                        pr.x = row_class_sum<GG>(pr.x); pr.y = row_class_sum<GG>(pr.y); pr.z = row_class_sum<GG>(pr.z); pr.w = row_class_sum<GG>(pr.w);
                     }
                     sr[r] = pr;
                 }
-                tot[v].x = (sr[0].x + sr[1].x) + (sr[2].x + sr[3].x); tot[v].y = (sr[0].y + sr[1].y) + (sr[2].y + sr[3].y);
-                tot[v].z = (sr[0].z + sr[1].z) + (sr[2].z + sr[3].z); tot[v].w = (sr[0].w + sr[1].w) + (sr[2].w + sr[3].w);
+                // the general path's levels in its order: the halves (rows 0 + 2, 1 + 3), the row pairs, then inside the row
+                tot[v].x = row_class_sum<GG>((sr[0].x + sr[2].x) + (sr[1].x + sr[3].x)); tot[v].y = row_class_sum<GG>((sr[0].y + sr[2].y) + (sr[1].y + sr[3].y));
+                tot[v].z = row_class_sum<GG>((sr[0].z + sr[2].z) + (sr[1].z + sr[3].z)); tot[v].w = row_class_sum<GG>((sr[0].w + sr[2].w) + (sr[1].w + sr[3].w));
             }
             __builtin_amdgcn_wave_barrier();
             if (gi == 0) {
@@ -1524,7 +1541,8 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         const unsigned cnt = h.cnt;
         if (cnt > MSTEP_SEG) continue;                          // a heavy parent: its segments belong to k_mstep<.., HEAVY> + k_mstep_heavy_finish
         float4 acc[MSTEP_NV];
-        mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off, cnt, pm, acc);
+        float shp[MSTEP_NV];
+        mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off, cnt, pm, acc, shp);
         const float w_s = s_mom[0];
         const float inv_w = 1.0f / w_s;                        // mixture.cpp:209
         const int64_t slot = h.oslot;
@@ -1550,7 +1568,12 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         if (G > 0) {
             // the row leaves through LDS: F consecutive floats, one coalesced store per 64
             __builtin_amdgcn_wave_barrier();
-            if (grp == 0) {
+            if constexpr (mstep_packed(G)) {
+                if ((lane & 15) < GG) {                          // G lanes of each row: the row's component of every float4
+#pragma unroll
+                    for (int v = 0; v < MSTEP_NV; ++v) s_out[4 * (gl + GG * v) + packed_slot(lane >> 4)] = shp[v] * inv_w;
+                }
+            } else if (grp == 0) {
 #pragma unroll
                 for (int v = 0; v < MSTEP_NV; ++v) {
                     const int f0 = 4 * (gl + GG * v);

@@ -118,7 +118,37 @@ __device__ __forceinline__ float class_sum(float v) {
     return v;
 }
 
-#define GSR_DET_TOL 0.04           // |det_float32 / det - 1| allowed for a regular component (enters the filter bound as is)
+// TWO sums per swap: the swap instructions exchange halves (rows) between two registers, so the addition behind one swap folds a
+// DIFFERENT value in each half of the wave.  pack32_sum: lanes 0..31 end with a[l] + a[l + 32], lanes 32..63 with b[l - 32] + b[l];
+// pack16_sum: row 0 ends with a's rows 0 + 1, row 1 with b's rows 0 + 1, row 2 with a's rows 2 + 3, row 3 with b's rows 2 + 3.
+// (v_permlane32_swap: the upper half of the first operand <-> the lower half of the second; v_permlane16_swap: the odd rows of the first
+// <-> the even rows of the second.)  Folding N values over the wave this way costs N + N / 2 instructions for the two cross-row levels
+// where swap16_sum / swap32_sum cost 6 N (a copy, a swap, an addition each), and leaves a quarter of the registers for the row level.
+__device__ __forceinline__ float pack32_sum(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ __forceinline__ float pack16_sum(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    return __builtin_bit_cast(float, (unsigned)r[0]) + __builtin_bit_cast(float, (unsigned)r[1]);
+}
+// which of four values x0..x3 row q holds after pack16_sum(pack32_sum(x0, x1), pack32_sum(x2, x3)): 0, 2, 1, 3
+__device__ __forceinline__ int packed_slot(int q) { return ((q & 1) << 1) | (q >> 1); }
+// The 14 moment sums of the M-step over the wave's 64 lanes: 7 + 4 swaps with their additions and 16 row rotations (39 instructions;
+// class_sum<1> of each was 140).  The tree of every sum: (v[l] + v[l + 32]) over the halves, then over the row pairs (+ 16), then
+// row_sum16 -- a value that lives in lanes 0..15 only (the others +0.0) comes out as row_sum16 of it.  r[j], row q, every lane of the
+// row: moment 4 j + packed_slot(q) for j < 3; r[3]: moment 12 in rows 0 and 1, moment 13 in rows 2 and 3.
+__device__ __forceinline__ void moment_sums(const float (&m)[14], float (&r)[4]) {
+    const float a0 = pack32_sum(m[0], m[1]), a1 = pack32_sum(m[2], m[3]), a2 = pack32_sum(m[4], m[5]), a3 = pack32_sum(m[6], m[7]);
+    const float a4 = pack32_sum(m[8], m[9]), a5 = pack32_sum(m[10], m[11]), a6 = pack32_sum(m[12], m[13]);
+    r[0] = row_sum16(pack16_sum(a0, a1));
+    r[1] = row_sum16(pack16_sum(a2, a3));
+    r[2] = row_sum16(pack16_sum(a4, a5));
+    r[3] = row_sum16(swap16_sum(a6));
+}
+__device__ __forceinline__ int moment_of(int j, int q) { return j < 3 ? 4 * j + packed_slot(q) : 12 + (q >> 1); }
+
+#define GSR_DET_TOL 0.04          // |det_float32 / det - 1| allowed for a regular component (enters the filter bound as is)
 __device__ __forceinline__ bool spd_det64(double a00, double a01, double a02, double a11, double a12, double a22, double& det) {
     const double m2 = a00 * a11 - a01 * a01;
     const double t1 = a00 * (a11 * a22 - a12 * a12), t2 = a01 * (a01 * a22 - a12 * a02), t3 = a02 * (a01 * a12 - a11 * a02);
