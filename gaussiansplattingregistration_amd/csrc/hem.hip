@@ -691,6 +691,10 @@ __global__ __launch_bounds__(256) void k_join_parts(const int* __restrict__ nhea
 // touches with ONE global atomic each, and places the pairs on a second walk (L2 resident).  A bucket that overflows raises
 // *overflow; the caller then takes the exact path (histogram + scan of a compacted copy).
 #define PART_PPW 128
+// The bucketed copy of a pair: its child's SLOT inside the bucket (sorted position mod the bucket size, 16 bits: buckets hold at most
+// 8 192 children) and wL -- what the sums need and nothing else (the bucket itself is where the pair lies): 6 bytes where rounds 2-4
+// wrote 8 (the child's whole sorted position), read twice by k_bucket_sum.
+typedef unsigned short slot_t;
 #define PART_STAGE_T 1024
 // STAGE > 0: the workgroup (1 024 threads, STAGE * 112 / 8192 parents of ~60 pairs each) reads every pair ONCE into registers,
 // ranks it inside its bucket with an LDS atomic, lays the pairs out by bucket in LDS (8 bytes each) and writes every bucket's run
@@ -703,9 +707,10 @@ __global__ __launch_bounds__(256) void k_join_parts(const int* __restrict__ nhea
 template <int STAGE>
 __global__ __launch_bounds__(STAGE ? PART_STAGE_T : 256, STAGE ? 8 : 1) void k_partition(int P, const int64_t* __restrict__ seg, const unsigned* __restrict__ pcnt,
                                                    const unsigned* __restrict__ sc, const float* __restrict__ sw, int nb, int shift, unsigned cap,
-                                                   unsigned* __restrict__ cursor, unsigned* __restrict__ o_child, float* __restrict__ o_wl,
+                                                   unsigned* __restrict__ cursor, slot_t* __restrict__ o_child, float* __restrict__ o_wl,
                                                    int* __restrict__ overflow) {
     constexpr bool STAGED = STAGE > 0;
+    const unsigned smask = (1u << shift) - 1u;
     constexpr int PPW = STAGED ? STAGE * 112 / 8192 : PART_PPW;
     constexpr int PART_STAGE = STAGED ? STAGE : 1;
     extern __shared__ unsigned s_h[];
@@ -813,7 +818,7 @@ __global__ __launch_bounds__(STAGE ? PART_STAGE_T : 256, STAGE ? 8 : 1) void k_p
             const unsigned c = st_c[pos];
             const unsigned bk = c >> shift;
             const unsigned sl = s_g[bk] + pos;
-            if (sl < cap) { const size_t gp = (size_t)bk * cap + sl; o_child[gp] = c; o_wl[gp] = st_w[pos]; }
+            if (sl < cap) { const size_t gp = (size_t)bk * cap + sl; o_child[gp] = (slot_t)(c & smask); o_wl[gp] = st_w[pos]; }
         }
         return;
     }
@@ -823,7 +828,7 @@ __global__ __launch_bounds__(STAGE ? PART_STAGE_T : 256, STAGE ? 8 : 1) void k_p
             const unsigned ch = sc[at];
             const int bk = (int)(ch >> shift);
             const unsigned slot = atomicAdd(&s_h[bk], 1u);
-            if (pass == 1 && slot < cap) { const size_t pos = (size_t)bk * cap + slot; o_child[pos] = ch; o_wl[pos] = sw[at]; }
+            if (pass == 1 && slot < cap) { const size_t pos = (size_t)bk * cap + slot; o_child[pos] = (slot_t)(ch & smask); o_wl[pos] = sw[at]; }
         }
         __syncthreads();
         if (pass == 0) {
@@ -842,12 +847,12 @@ __global__ __launch_bounds__(STAGE ? PART_STAGE_T : 256, STAGE ? 8 : 1) void k_p
 // one launch of the pair partition: the largest stage whose LDS fits twice on a CU
 template <int STAGE>
 static inline void launch_partition_staged(hipStream_t st, int P, const int64_t* seg, const unsigned* pcnt, const unsigned* sc, const float* sw, int nb, int shift,
-                                           unsigned cap, unsigned* cursor, unsigned* o_child, float* o_wl, int* overflow) {
+                                           unsigned cap, unsigned* cursor, slot_t* o_child, float* o_wl, int* overflow) {
     hipLaunchKernelGGL(k_partition<STAGE>, dim3(ceil_div(P, STAGE * 112 / 8192)), dim3(PART_STAGE_T), (size_t)nb * 8 + (size_t)STAGE * 8, st, P, seg, pcnt, sc, sw,
                        nb, shift, cap, cursor, o_child, o_wl, overflow);
 }
 static inline void launch_partition(hipStream_t st, int staged_ok /* 0 walk, 1 auto, else the stage size to force */, int P, const int64_t* seg, const unsigned* pcnt, const unsigned* sc, const float* sw, int nb,
-                                    int shift, unsigned cap, unsigned* cursor, unsigned* o_child, float* o_wl, int* overflow) {
+                                    int shift, unsigned cap, unsigned* cursor, slot_t* o_child, float* o_wl, int* overflow) {
     if ((staged_ok == 1 || staged_ok == 8192) && nb <= 1536) launch_partition_staged<8192>(st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child, o_wl, overflow);
     else if ((staged_ok == 1 || staged_ok == 6144) && nb <= 3584) launch_partition_staged<6144>(st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child, o_wl, overflow);
     else if ((staged_ok == 1 || staged_ok == 4096) && nb <= 5632) launch_partition_staged<4096>(st, P, seg, pcnt, sc, sw, nb, shift, cap, cursor, o_child, o_wl, overflow);
@@ -909,7 +914,7 @@ __global__ __launch_bounds__(256) void k_bucket_hist(int64_t M, int tile, const 
 // bucket offsets are 64-bit (10^9 pairs at 40 M splats); cursor[b] starts at the bucket's first slot
 __global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, int tile, const unsigned* __restrict__ child, const float* __restrict__ wl, int nb, int shift,
                                                         const unsigned long long* __restrict__ bstart, unsigned long long* __restrict__ cursor,
-                                                        unsigned* __restrict__ o_child, float* __restrict__ o_wl) {
+                                                        slot_t* __restrict__ o_child, float* __restrict__ o_wl) {
     // ONE 32-bit word of LDS per bucket (4 883 buckets at 40 M components: 20 KB; with a count and a 64-bit base per bucket
     // it was 59 KB = two workgroups per CU): first the tile's count, then the next free slot of the tile's run in the bucket,
     // relative to the bucket's first slot bstart[b]
@@ -928,13 +933,13 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(int64_t M, int tile, con
         const unsigned ch = child[k];
         const int b = (int)(ch >> shift);
         const unsigned long long pos = bstart[b] + atomicAdd(&s_h[b], 1u);
-        o_child[pos] = ch;
+        o_child[pos] = (slot_t)(ch & ((1u << shift) - 1u));
         o_wl[pos] = wl[k];
     }
 }
 // bstart != NULL: bucket b holds the pairs [bstart[b], bstart[b + 1]) (exact partition); else its region [b cap, b cap + cursor[b])
 __global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, int shift, const unsigned long long* __restrict__ bstart, unsigned cap,
-                                                     const unsigned* __restrict__ cursor, const unsigned* __restrict__ child,
+                                                     const unsigned* __restrict__ cursor, const slot_t* __restrict__ child,
                                                      const float* __restrict__ wl, float* __restrict__ sumLw, int* __restrict__ orphan_flag,
                                                      float* __restrict__ geo_sl) {
     extern __shared__ unsigned long long s_acc[];  // [bucket] int64 accumulators, then [bucket] max bit patterns
@@ -955,16 +960,15 @@ __global__ __launch_bounds__(1024) void k_bucket_sum(int64_t n, int shift, const
         for (; k + 3 * bd < k1; k += 4 * bd) {
             const unsigned c_0 = child[k], c_1 = child[k + bd], c_2 = child[k + 2 * bd], c_3 = child[k + 3 * bd];
             const float w_0 = wl[k], w_1 = wl[k + bd], w_2 = wl[k + 2 * bd], w_3 = wl[k + 3 * bd];
-            atomicMax(&s_max[c_0 - (unsigned)c0], __float_as_uint(w_0) & 0x7fffffffu);           // |wL| as an ordered integer
-            atomicMax(&s_max[c_1 - (unsigned)c0], __float_as_uint(w_1) & 0x7fffffffu);
-            atomicMax(&s_max[c_2 - (unsigned)c0], __float_as_uint(w_2) & 0x7fffffffu);
-            atomicMax(&s_max[c_3 - (unsigned)c0], __float_as_uint(w_3) & 0x7fffffffu);
+            atomicMax(&s_max[c_0], __float_as_uint(w_0) & 0x7fffffffu);           // |wL| as an ordered integer
+            atomicMax(&s_max[c_1], __float_as_uint(w_1) & 0x7fffffffu);
+            atomicMax(&s_max[c_2], __float_as_uint(w_2) & 0x7fffffffu);
+            atomicMax(&s_max[c_3], __float_as_uint(w_3) & 0x7fffffffu);
         }
-        for (; k < k1; k += bd) atomicMax(&s_max[child[k] - (unsigned)c0], __float_as_uint(wl[k]) & 0x7fffffffu);
+        for (; k < k1; k += bd) atomicMax(&s_max[child[k]], __float_as_uint(wl[k]) & 0x7fffffffu);
     }
     __syncthreads();
-    const auto add_term = [&](unsigned ch, float w) {
-        const unsigned i = ch - (unsigned)c0;
+    const auto add_term = [&](unsigned i, float w) {          // i = the child's slot in this bucket
         const unsigned mb = s_max[i];
         if (mb >= 0x7f800000u) {                   // a non-finite term somewhere: collect flags (1 +inf, 2 -inf, 4 NaN)
             const unsigned wb = __float_as_uint(w);
@@ -1969,7 +1973,7 @@ __global__ __launch_bounds__(256) void k_gather_sh2(int64_t n, int64_t n_own, in
     }
 }
 // k_bucket_sum in three steps with global per-child arrays (sorted positions): the largest |wL| ...
-__global__ __launch_bounds__(1024) void k_part_max(int64_t n, int shift, unsigned cap, const unsigned* __restrict__ cursor, const unsigned* __restrict__ child,
+__global__ __launch_bounds__(1024) void k_part_max(int64_t n, int shift, unsigned cap, const unsigned* __restrict__ cursor, const slot_t* __restrict__ child,
                                                    const float* __restrict__ wl, unsigned* __restrict__ gmax) {
     extern __shared__ unsigned s_m[];
     const int bucket = 1 << shift;
@@ -1980,12 +1984,12 @@ __global__ __launch_bounds__(1024) void k_part_max(int64_t n, int shift, unsigne
     __syncthreads();
     const unsigned cnt = cursor[b];
     const unsigned long long k0 = (unsigned long long)b * cap, k1 = k0 + (cnt < cap ? cnt : cap);
-    for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) atomicMax(&s_m[child[k] - (unsigned)c0], __float_as_uint(wl[k]) & 0x7fffffffu);
+    for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) atomicMax(&s_m[child[k]], __float_as_uint(wl[k]) & 0x7fffffffu);
     __syncthreads();
     for (int i = threadIdx.x; i < nc; i += blockDim.x) gmax[c0 + i] = s_m[i];
 }
 // ... the fixed-point sums on the scale of the (now global) maximum: 64-bit integers, or flag bits where a term is not finite ...
-__global__ __launch_bounds__(1024) void k_part_acc(int64_t n, int shift, unsigned cap, const unsigned* __restrict__ cursor, const unsigned* __restrict__ child,
+__global__ __launch_bounds__(1024) void k_part_acc(int64_t n, int shift, unsigned cap, const unsigned* __restrict__ cursor, const slot_t* __restrict__ child,
                                                    const float* __restrict__ wl, const unsigned* __restrict__ gmax, unsigned long long* __restrict__ gacc) {
     extern __shared__ unsigned long long s_acc[];
     const int bucket = 1 << shift;
@@ -1998,7 +2002,7 @@ __global__ __launch_bounds__(1024) void k_part_acc(int64_t n, int shift, unsigne
     const unsigned cnt = cursor[b];
     const unsigned long long k0 = (unsigned long long)b * cap, k1 = k0 + (cnt < cap ? cnt : cap);
     for (unsigned long long k = k0 + threadIdx.x; k < k1; k += blockDim.x) {
-        const unsigned i = child[k] - (unsigned)c0;
+        const unsigned i = child[k];
         const float w = wl[k];
         const unsigned mb = s_max[i];
         if (mb >= 0x7f800000u) {                   // a non-finite term somewhere: collect flags (1 +inf, 2 -inf, 4 NaN)
@@ -3231,12 +3235,12 @@ struct PartLevel {
             const double capd = (double)M / (double)nbuckets * factor + 4096.0;
             if (capd > 4.0e9) return fail(GSR_E_INVALID, "gsr_hem_run_level: pair partition capacity");
             cap = (unsigned)capd;
-            GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * 4)); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
+            GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * sizeof(slot_t))); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
             GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));
             GSR_HIP(hipMemsetAsync(overflow_flag, 0, 4, st));
             if (M > 0 && P > 0)
                 launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
-                                 c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
+                                 c->spair_child.as<slot_t>(), c->spair_wl.as<float>(), overflow_flag);
             GSR_HIP(hipGetLastError());
             Collect q;
             q.n = 1; q.src[0] = overflow_flag; q.bytes[0] = 4;
@@ -3248,7 +3252,7 @@ struct PartLevel {
         const dim3 gs(stride_grid(n_sent > 0 ? n_sent : 1)), gg(stride_grid(n_ghost > 0 ? n_ghost : 1));
         GSR_TRY(c->xsend.reserve((size_t)(n_sent + n_ghost + 1) * 8)); GSR_TRY(c->xrecv.reserve((size_t)(n_sent + n_ghost + 1) * 8));
         // 1. the largest |wL| of every child: local, then the ghosts' maxima to their owners, then the owners' result back
-        hipLaunchKernelGGL(k_part_max, dim3(nbuckets), bblk, (size_t)4 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(),
+        hipLaunchKernelGGL(k_part_max, dim3(nbuckets), bblk, (size_t)4 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<slot_t>(),
                            c->spair_wl.as<float>(), c->gmax.as<unsigned>());
         GSR_HIP(hipGetLastError());
         if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_gather<unsigned>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->gmax.as<unsigned>(), c->xsend.as<unsigned>());
@@ -3258,7 +3262,7 @@ struct PartLevel {
         GSR_TRY(exchange(c->xsend.p, c->xrecv.p, 4, false));
         if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_set<unsigned>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->xrecv.as<unsigned>(), c->gmax.as<unsigned>());
         // 2. the fixed-point sums on that scale: local, then the ghosts' partial sums to their owners (integer addition)
-        hipLaunchKernelGGL(k_part_acc, dim3(nbuckets), bblk, (size_t)12 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(),
+        hipLaunchKernelGGL(k_part_acc, dim3(nbuckets), bblk, (size_t)12 << bshift, st, n, bshift, cap, c->bcursor.as<unsigned>(), c->spair_child.as<slot_t>(),
                            c->spair_wl.as<float>(), c->gmax.as<unsigned>(), c->gacc.as<unsigned long long>());
         GSR_HIP(hipGetLastError());
         if (n_ghost > 0) hipLaunchKernelGGL(k_ghost_gather<unsigned long long>, gg, blk, 0, st, n_ghost, n_own, c->inv.as<unsigned>(), c->gacc.as<unsigned long long>(), c->xsend.as<unsigned long long>());
@@ -3786,7 +3790,7 @@ int32_t LevelRun::compact_pairs() {
 int32_t LevelRun::sums_fixed() {
     unsigned cap;
     if (spec) {
-        const size_t have = std::min(c->spair_child.cap, c->spair_wl.cap) / 4 / (size_t)nbuckets;
+        const size_t have = std::min(c->spair_child.cap / sizeof(slot_t), c->spair_wl.cap / 4) / (size_t)nbuckets;
         if (have < 4096) return GSR_RETRY_SYNC;
         cap = (unsigned)std::min<size_t>(have, 0xfffff000u);
     } else {
@@ -3794,20 +3798,20 @@ int32_t LevelRun::sums_fixed() {
         double capd = mean * (c->partition_factor > 0.0 ? c->partition_factor : (M < (1 << 24) ? 8.0 : 6.0)) + (c->partition_factor > 0.0 ? 64.0 : 4096.0);
         if (capd > 4.0e9) return GSR_E_INVALID;                  // (not an error: the caller takes the exact path)
         cap = (unsigned)capd;
-        GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * 4)); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
+        GSR_TRY(c->spair_child.reserve((size_t)nbuckets * cap * sizeof(slot_t))); GSR_TRY(c->spair_wl.reserve((size_t)nbuckets * cap * 4));
     }
     GSR_TRY(c->bcursor.reserve(((size_t)nbuckets + 1) * 8));
     if (sharded) GSR_HIP(hipMemsetAsync(c->bcursor.p, 0, ((size_t)nbuckets + 1) * 4, st));      // (one GPU: the level's prologue cleared the cursors, k_bbox_reduce)
     (void)hipGetLastError();
     GSR_TIME(c->evm[2], st);
     launch_partition(st, c->partition_staged ? (c->partition_stage ? c->partition_stage : 1) : 0, P, seg, c->pcnt.as<unsigned>(), pc, pw, nbuckets, bshift, cap, c->bcursor.as<unsigned>(),
-                     c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), overflow_flag);
+                     c->spair_child.as<slot_t>(), c->spair_wl.as<float>(), overflow_flag);
     GSR_HIP(hipGetLastError());
     GSR_TIME(c->evm[3], st);
     GSR_CHECKPOINT("pair partition (fixed capacity)");
     GSR_TIME(c->evm[4], st);
     hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, (const unsigned long long*)nullptr, cap,
-                       c->bcursor.as<unsigned>(), c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
+                       c->bcursor.as<unsigned>(), c->spair_child.as<slot_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
                        c->geo.as<float>() + 15);
     GSR_TIME(c->evm[5], st);
     GSR_HIP(hipGetLastError());
@@ -3832,11 +3836,11 @@ int32_t LevelRun::sums_exact() {
     GSR_HIP(hipMemcpyAsync(c->bcursor.p, c->bstart.p, ((size_t)nbuckets + 1) * 8, hipMemcpyDeviceToDevice, st));
     hipLaunchKernelGGL(k_bucket_scatter, dim3(ntiles), blk, (size_t)nbuckets * 4, st, M, tile, c->pair_child.as<unsigned>(),
                        c->pair_wl.as<float>(), nbuckets, bshift, c->bstart.as<unsigned long long>(), c->bcursor.as<unsigned long long>(),
-                       c->spair_child.as<unsigned>(), c->spair_wl.as<float>());
+                       c->spair_child.as<slot_t>(), c->spair_wl.as<float>());
     GSR_HIP(hipGetLastError());
     GSR_CHECKPOINT("pair partition");
     hipLaunchKernelGGL(k_bucket_sum, dim3(nbuckets), dim3(bshift >= 10 ? 1024 : 256), (size_t)12 << bshift, st, n, bshift, c->bstart.as<unsigned long long>(), 0u,
-                       (const unsigned*)nullptr, c->spair_child.as<unsigned>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
+                       (const unsigned*)nullptr, c->spair_child.as<slot_t>(), c->spair_wl.as<float>(), c->sumLw.as<float>(), c->oflag.as<int>(),
                        c->geo.as<float>() + 15);
     GSR_HIP(hipGetLastError());
     return GSR_OK;
@@ -4210,7 +4214,7 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
     // synchronous way).  What it cannot know beforehand it checks on the device (GSR_RETRY_SYNC).
     spec = spec && !part && !sharded && !dbg_sync && c->sum_bucket && c->partition_fixed && !c->partition_overflowed && c->partition_factor == 0.0 &&
            c->split_heavy && getenv("GSR_HEM_SPARSE_GB") == nullptr && c->aux != nullptr &&
-           std::min(c->sp_child.cap, c->sp_wl.cap) >= (size_t)4096 && std::min(c->spair_child.cap, c->spair_wl.cap) >= (size_t)4096;
+           std::min(c->sp_child.cap, c->sp_wl.cap) >= (size_t)4096 && std::min(c->spair_child.cap / sizeof(slot_t), c->spair_wl.cap / 4) >= (size_t)4096;
     grd = dim3(stride_grid(n));
     GSR_TIME1(c->ev[0], st);
     GSR_TRY(grid_phase());
