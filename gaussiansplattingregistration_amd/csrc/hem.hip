@@ -668,12 +668,23 @@ __global__ __launch_bounds__(256) void k_join_parts(const int* __restrict__ nhea
             const unsigned cnt = part_cnt[h0 + k];
             const int64_t src = coff[p] + (int64_t)k * part;
             if (dst != src) {
-                for (unsigned i0 = 0; i0 < cnt; i0 += 256) {
-                    const unsigned i = i0 + threadIdx.x;
-                    unsigned vc = 0; float vw = 0.0f;
-                    if (i < cnt) { vc = sc[src + i]; vw = sw[src + i]; }
+                // (eight pairs of a thread in flight between the two barriers: one pair per trip made a part of 3 000 pairs twelve
+                // dependent round trips, and the largest parent's chain is this kernel's duration -- 0.10 ms at the 5 M level)
+                constexpr int JU = 8;
+                for (unsigned i0 = 0; i0 < cnt; i0 += 256 * JU) {
+                    unsigned vc[JU]; float vw[JU];
+#pragma unroll
+                    for (int u = 0; u < JU; ++u) {
+                        const unsigned i = i0 + 256u * u + threadIdx.x;
+                        vc[u] = 0u; vw[u] = 0.0f;
+                        if (i < cnt) { vc[u] = sc[src + i]; vw[u] = sw[src + i]; }
+                    }
                     __syncthreads();
-                    if (i < cnt) { sc[dst + i] = vc; sw[dst + i] = vw; }
+#pragma unroll
+                    for (int u = 0; u < JU; ++u) {
+                        const unsigned i = i0 + 256u * u + threadIdx.x;
+                        if (i < cnt) { sc[dst + i] = vc[u]; sw[dst + i] = vw[u]; }
+                    }
                     __syncthreads();
                 }
             }
@@ -1117,9 +1128,18 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
             for (unsigned k = 0; k < nseg; ++k) hitems[base + k] = make_uint2((unsigned)s, k);
         }
     }
-    // the largest pair count of a parent of this level (a statistic: gsr_hem_get_stats_ex [5])
+    // the largest pair count of a parent of this level (a statistic: gsr_hem_get_stats_ex [5]).  One atomic per WORKGROUP, and only
+    // where it would raise the word as the workgroup sees it: an atomicMax per wave was 8 192 same-address atomics at the 5 M level,
+    // ~12 ns each one after the other -- 100 of this kernel's 128 us (35 of 38 us at 556 k).
+    __shared__ unsigned s_mx[4];
     for (int o = 32; o > 0; o >>= 1) { const unsigned t = (unsigned)__shfl_xor((int)mx, o); mx = t > mx ? t : mx; }
-    if ((threadIdx.x & 63) == 0 && mx > 0u) atomicMax(max_cnt, mx);
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned bm = s_mx[0];
+        for (int w = 1; w < 4; ++w) bm = s_mx[w] > bm ? s_mx[w] : bm;
+        if (bm > __hip_atomic_load(max_cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(max_cnt, bm);
+    }
 }
 
 #define MSTEP_CHUNK 256
@@ -2472,6 +2492,8 @@ struct gsr_hem_ctx {
                                     // 8.54 / 8.50 ms from own buffers but 8.63 / 8.78 in the bench's zero-copy cascade; clustered (7) 6.98 / 6.70; surfels (2) 6.55 / 6.25
     float sh_direct_pairs = 8.0f;
     bool use_rowlist = true;        // GSR_HEM_ROWLIST=0: k_select computes every row span itself instead of taking the non-empty ones from k_spans
+    size_t rowlist_max = (size_t)4096 << 20;   // GSR_HEM_ROWLIST_MAX_MB: the row lists are 256 bytes per parent (0.43 GB at the 1.67 M parents of a 5 M level,
+                                    // 3.4 GB at 40 M splats), kept by the context; a level whose lists would be larger runs without them
     int timing = 1;                 // gsr_hem_set_timing / GSR_HEM_TIMING: 0 no events, 1 level + k_select + k_mstep, 2 every phase (see GSR_TIME)
     int select_np = 0;              // GSR_HEM_SELECT_NP=1|2|4: light parents per selection wave (the rings are kept across them, see SEL_NP); 0 = by level size
     bool mstep_split = true;        // GSR_HEM_MSTEP_SPLIT=0: a parent of more than MSTEP_SEG pairs keeps ONE wave for all its segments (the schedule of rounds 1-3)
@@ -2813,6 +2835,7 @@ int32_t gsr_hem_create(gsr_hem_ctx** out, int32_t device, void* stream) {
     if (const char* s = getenv("GSR_HEM_SH_DIRECT")) c->sh_policy = atoi(s) != 0 ? 1 : 0;
     if (const char* s = getenv("GSR_HEM_SH_DIRECT_PAIRS")) c->sh_direct_pairs = (float)atof(s);
     if (const char* s = getenv("GSR_HEM_ROWLIST")) c->use_rowlist = atoi(s) != 0;
+    if (const char* s = getenv("GSR_HEM_ROWLIST_MAX_MB")) c->rowlist_max = (size_t)(atof(s) * 1048576.0);
     if (const char* s = getenv("GSR_HEM_TIMING")) { const int v = atoi(s); c->timing = v < 0 ? 0 : (v > 2 ? 2 : v); }
     if (const char* s = getenv("GSR_HEM_SELECT_NP")) { const int v = atoi(s); c->select_np = v < 1 ? 1 : (v > SEL_NP ? SEL_NP : v); }
     if (const char* s = getenv("GSR_HEM_RB_POLL")) c->rb_poll = atoi(s) != 0;
@@ -3140,6 +3163,7 @@ struct PartLevel {
         if (agreed == 2u) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank holds 2^30 or more components (reported on every rank)");
         if (agreed == 3u) return fail(GSR_E_INVALID, "gsr_hem_run_level: more than 8 ranks");
         if (agreed == 4u) return fail(GSR_E_INVALID, "gsr_hem_run_level: spatial partition and work sharding are exclusive (reported on every rank)");
+        if (agreed == 5u) return fail(GSR_E_HIP, "gsr_hem_run_level: a rank could not allocate the buffers of its halo (reported on every rank)");
         if (agreed) return fail(GSR_E_INVALID, "gsr_hem_run_level: a rank failed a precondition of the partitioned level (code %u)", agreed);
         return GSR_OK;
     }
@@ -3178,21 +3202,42 @@ struct PartLevel {
             hipLaunchKernelGGL(k_last_total, dim3(1), dim3(1), 0, st, c->dpos.as<int>() + (int64_t)q * n_own + (n_own - 1),
                                c->dflag.as<int>() + (int64_t)q * n_own + (n_own - 1), c->pcounts.as<long long>() + q);
         }
+        // (the rank's own slot of its row is free: its owned count rides there, so that every rank knows every rank's working set)
+        const long long own_ll = (long long)n_own;
+        GSR_HIP(hipMemcpyAsync(c->pcounts.as<long long>() + me, &own_ll, 8, hipMemcpyHostToDevice, st));
         GSR_TRY(gsr_comm_allgather(c->comm, c->pcounts.p, c->pmatrix.p, 64, (void*)st));
         long long mat[64];
         GSR_HIP(hipMemcpyAsync(mat, c->pmatrix.p, (size_t)W * 64, hipMemcpyDeviceToHost, st));
         GSR_HIP(hipStreamSynchronize(st));
         for (int q = 0; q < W; ++q) { send_cnt[q] = q == me ? 0 : mat[me * 8 + q]; recv_cnt[q] = q == me ? 0 : mat[q * 8 + me]; }
         for (int q = 0; q < W; ++q) { soff[q] = n_sent; n_sent += send_cnt[q]; roff[q] = n_ghost; n_ghost += recv_cnt[q]; }
+        // Errors past this point would be rank-local with the collectives already under way (a peer would wait in the next one for
+        // ever): the size limit is evaluated for EVERY rank from the matrix all of them hold, and the allocations'
+        // outcome is agreed on before the first exchange
+        for (int r = 0; r < W; ++r) {
+            long long tot = 0;
+            for (int q = 0; q < W; ++q) tot += mat[q * 8 + r];                   // owned (q == r) + what every peer sends
+            if (tot >= (1ll << 30))
+                return fail(GSR_E_INVALID, "gsr_hem_run_level: rank %d would hold %lld local components (owned + ghosts; the limit is 2^30; reported on every rank)", r, tot);
+        }
         // TWO exchanges along the same lists: the 72-byte rows {record, global index, index at the owner} -- what the grid, the sort
         // and the selection need -- on the level's stream, and the SH rows (4 F bytes: 71 % of a ghost at SH degree 3), which only the
         // M-step reads, on the third stream beside the rest of the grid phase and the selection, received straight into ghost_sh
         constexpr int RW = 16 + PART_ROW_EXTRA;
         const size_t Fm = (size_t)(F > 0 ? F : 1);
-        GSR_TRY(c->rows_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * RW * 4)); GSR_TRY(c->rows_recv.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * RW * 4));
-        GSR_TRY(c->sh_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * Fm * 4));
-        GSR_TRY(c->sent_idx.reserve((size_t)(n_sent > 0 ? n_sent : 1) * 4));
-        GSR_TRY(c->ghost_sh.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * Fm * 4)); GSR_TRY(c->ghost_src.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * 4));
+        n = n_own + n_ghost;
+        {
+            int32_t rs = c->rows_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * RW * 4);
+            const auto also = [&rs](int32_t r) { if (rs == GSR_OK) rs = r; };
+            also(c->rows_recv.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * RW * 4));
+            also(c->sh_send.reserve((size_t)(n_sent > 0 ? n_sent : 1) * Fm * 4));
+            also(c->sent_idx.reserve((size_t)(n_sent > 0 ? n_sent : 1) * 4));
+            also(c->ghost_sh.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * Fm * 4));
+            also(c->ghost_src.reserve((size_t)(n_ghost > 0 ? n_ghost : 1) * 4));
+            also(c->rec_loc.reserve((size_t)n * 64));
+            also(c->gid_loc.reserve((size_t)n * 4));
+            GSR_TRY(agree_on_preconditions(1, rs != GSR_OK ? 5u : 0u));
+        }
         for (int q = 0; q < W; ++q)
             if (send_cnt[q] > 0)
                 hipLaunchKernelGGL(k_pack_rows, dim3(stride_grid(n_own * 64)), blk, 0, st, n_own, F, c->dflag.as<int>() + (int64_t)q * n_own,
@@ -3210,9 +3255,6 @@ struct PartLevel {
             halo_sh_pending = true;
         }
         c->part_stats[0] = n_ghost; c->part_stats[1] = n_sent; c->part_stats[2] = c->part_stats[3]; c->part_stats[3] = 0;
-        n = n_own + n_ghost;
-        if (n >= (1ll << 30)) return fail(GSR_E_INVALID, "gsr_hem_run_level: %lld local components", (long long)n);
-        GSR_TRY(c->rec_loc.reserve((size_t)n * 64)); GSR_TRY(c->gid_loc.reserve((size_t)n * 4));
         GSR_HIP(hipMemcpyAsync(c->rec_loc.p, c->rec.p, (size_t)n_own * 64, hipMemcpyDeviceToDevice, st));
         GSR_HIP(hipMemcpyAsync(c->gid_loc.p, c->gid.p, (size_t)n_own * 4, hipMemcpyDeviceToDevice, st));
         if (n_ghost > 0)
@@ -3667,7 +3709,7 @@ int32_t LevelRun::select_phase() {
         GSR_TRY(c->prec.reserve(Pm * sizeof(ParentRec)));
         launch_parent_prep(st, P, c->plist.as<unsigned>(), c->geo.as<float4>(), c->Rs.as<float>(), sa.kldThr, sa.ell, c->prec.as<ParentRec>());
         sa.prec = c->prec.as<ParentRec>();
-        if (c->use_rowlist) {
+        if (c->use_rowlist && Pm * 2 * SEL_ROWS * sizeof(int2) <= c->rowlist_max) {
             GSR_TRY(c->rowlist.reserve(Pm * 2 * SEL_ROWS * sizeof(int2)));
             sa.rowlist = c->rowlist.as<int2>();
         }

@@ -13,7 +13,7 @@ python3 - <<PY
 import csv,glob
 f=glob.glob("gpurun_out/kstats/tr/**/*kernel_stats.csv",recursive=True)[0]
 rows=sorted(csv.DictReader(open(f)), key=lambda r:-float(r["TotalDurationNs"]))
-for r in rows[:32]:
+for r in rows[:70]:
     if r["Name"].startswith("void at::") or "rocclr" in r["Name"] or "distribution" in r["Name"]: continue
     print(f'{r["Name"][:72]:72s} calls/level {int(r["Calls"])/3:5.1f}  avg us {float(r["AverageNs"])/1e3:8.1f}  per level us {float(r["TotalDurationNs"])/3e3:8.1f}')
 PY

@@ -428,16 +428,20 @@ def test_row_lists_from_the_capacity_pass_change_nothing(monkeypatch, shape):
     """``k_spans`` computes every row span of every parent for the capacities; it now also leaves the non-empty ones (up to 16 per
     pass) in scan order for ``k_select``, which reads them instead of computing them again.  GSR_HEM_ROWLIST=0 (every span computed
     twice, as before): the same levels bit for bit -- with irregular components (pass B has its own list), heavy parents (more rows than
-    a list holds: they recompute) and on the COUNT + FILL fallback."""
+    a list holds: they recompute), on the COUNT + FILL fallback, and when the lists would exceed GSR_HEM_ROWLIST_MAX_MB (a level of
+    more than 16 M parents by default: 256 bytes per parent are kept by the context)."""
     from gaussiansplattingregistration_amd import hem, synth
     c = synth.make_cloud(200000, seed=78, sh_degree=1, shape=shape)
     c["cov6"][7::499] = np.array([1.0, 0, 0, 1.0, 0, -1.0], np.float32)       # irregular: not positive definite
     monkeypatch.setenv("GSR_HEM_ROWLIST", "0")
     ref, rst = hem.create_mixture(c, 2)
     assert rst[0]["irregular"] > 0 and rst[0]["heavy_parents"] > 0, rst[0]
-    for budget in (None, "0"):
+    for budget in (None, "0", "cap"):
         monkeypatch.setenv("GSR_HEM_ROWLIST", "1")
-        if budget is not None:
+        if budget == "cap":                 # lists larger than the cap (256 bytes per parent): the level runs without them
+            monkeypatch.delenv("GSR_HEM_SPARSE_GB")
+            monkeypatch.setenv("GSR_HEM_ROWLIST_MAX_MB", "1")
+        elif budget is not None:
             monkeypatch.setenv("GSR_HEM_SPARSE_GB", budget)
         got, st = hem.create_mixture(c, 2)
         for k in range(2):
