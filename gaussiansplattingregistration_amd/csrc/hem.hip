@@ -1656,50 +1656,62 @@ __global__ __launch_bounds__(64) void k_mstep_heavy_finish(MstepArgs a) {
 }
 
 // Orphans: components no parent addressed (sumLw == 0) are copied unchanged after all parents (mixture.cpp:250-253), row P + (rank among the
-// orphans in input order).  ONE pass, a wave per 64 sorted positions: the lane of an orphan writes its 14 geometry values from the
-// record; the SH rows then leave one orphan at a time with the whole wave on a row (180 contiguous bytes in, 180 out) -- whether a level
-// has a handful of orphans (an isotropic level: 0.04 %) or is a third orphans (thin discs that merge with nothing).  Rounds 2-4 had four
-// kernels for this (a pass over the components for the records and a slot table, then one of three SH copies chosen by the orphans'
-// number on the host, which an asynchronous level does not know).  sh_rows: the cell-sorted copy (row j) or, sh_direct, the level's own
-// array (row order[j]).  Rows beyond out_cap are not written (an asynchronous level's arrays were sized before the count existed; the
-// abort flag is up then).
-__global__ __launch_bounds__(256) void k_orphan_rows(int64_t n, int P, const unsigned* __restrict__ order,
-                                                     const int* __restrict__ oflag_sorted, const int* __restrict__ orank_in,
-                                                     const float4* __restrict__ geo, const float* __restrict__ sh_own, const float* __restrict__ sh_sorted,
-                                                     const int* __restrict__ sh_mode_p, int F, int RSH,
+// orphans in input order).  ONE pass over the level in INPUT order, a wave per 64 components, straight from the level's own arrays (the
+// records and the cell-sorted SH copy hold the same bits): an orphan's lane copies its 14 geometry values, the SH rows then leave with
+// the whole wave on a row, four rows in flight.  Input order because the ranks ascend with it: the orphans of a wave's 64 components take
+// CONSECUTIVE output rows, so the wave writes one contiguous block per array -- in cell order (rounds 1-5a) every orphan's 180-byte SH row
+// and its 12- / 24-byte pieces landed at a place of their own, partial cache lines the L2 could not merge before it evicted them
+// (0.34 ms for 0.69 GB on the surfel level, a third of whose components are orphans).  Rounds 2-4 had four kernels for this (a pass over
+// the components for the records and a slot table, then one of three SH copies chosen by the orphans' number on the host, which an
+// asynchronous level does not know).  Rows beyond out_cap are not written (an asynchronous level's arrays were sized before the count
+// existed; the abort flag is up then).
+__global__ __launch_bounds__(256) void k_orphan_rows(int64_t n, int P, const int* __restrict__ oflag_in, const int* __restrict__ orank_in,
+                                                     const float* __restrict__ i_xyz, const float* __restrict__ i_color, const float* __restrict__ i_cov6,
+                                                     const float* __restrict__ i_opacity, const float* __restrict__ i_weight, const float* __restrict__ i_sh, int F,
                                                      float* o_xyz, float* o_color, float* o_cov6, float* o_opacity,
                                                      float* o_weight, float* o_sh, int64_t out_cap) {
     const int lane = threadIdx.x & 63;
-    const int sh_direct = F > 0 ? *sh_mode_p : 1;
-    const float* sh_rows = sh_direct ? sh_own : sh_sorted;
-    const int stride = sh_direct ? F : RSH;
     for (int64_t base = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) & ~(int64_t)63; base < n; base += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t j = base + lane;
+        const int64_t i = base + lane;
         int slot = -1;
-        unsigned src = 0u;
-        if (j < n && oflag_sorted[j]) {
-            const unsigned i = order[j];
+        if (i < n && oflag_in[i]) {
             const int64_t sl = (int64_t)P + orank_in[i];
             if (sl < out_cap) {
                 slot = (int)sl;
-                src = sh_direct ? i : (unsigned)j;
-                const float4 a = geo[4 * j], b = geo[4 * j + 1], c = geo[4 * j + 2], d = geo[4 * j + 3];
-                o_xyz[3 * sl] = a.x; o_xyz[3 * sl + 1] = a.y; o_xyz[3 * sl + 2] = a.z;
-                o_color[3 * sl] = c.z; o_color[3 * sl + 1] = c.w; o_color[3 * sl + 2] = d.x;
-                o_cov6[6 * sl] = b.x; o_cov6[6 * sl + 1] = b.y; o_cov6[6 * sl + 2] = b.z;
-                o_cov6[6 * sl + 3] = b.w; o_cov6[6 * sl + 4] = c.x; o_cov6[6 * sl + 5] = c.y;
-                o_opacity[sl] = d.y;
-                o_weight[sl] = d.z;
+                const float x = i_xyz[3 * i], y = i_xyz[3 * i + 1], z = i_xyz[3 * i + 2];
+                const float c0 = i_color[3 * i], c1 = i_color[3 * i + 1], c2 = i_color[3 * i + 2];
+                const float v0 = i_cov6[6 * i], v1 = i_cov6[6 * i + 1], v2 = i_cov6[6 * i + 2], v3 = i_cov6[6 * i + 3], v4 = i_cov6[6 * i + 4], v5 = i_cov6[6 * i + 5];
+                const float op = i_opacity[i], wt = i_weight[i];
+                o_xyz[3 * sl] = x; o_xyz[3 * sl + 1] = y; o_xyz[3 * sl + 2] = z;
+                o_color[3 * sl] = c0; o_color[3 * sl + 1] = c1; o_color[3 * sl + 2] = c2;
+                o_cov6[6 * sl] = v0; o_cov6[6 * sl + 1] = v1; o_cov6[6 * sl + 2] = v2;
+                o_cov6[6 * sl + 3] = v3; o_cov6[6 * sl + 4] = v4; o_cov6[6 * sl + 5] = v5;
+                o_opacity[sl] = op;
+                o_weight[sl] = wt;
             }
         }
         if (F > 0) {
+            // the SH rows of the wave's orphans: four rows in flight, the whole wave on a row
             unsigned long long m = __ballot(slot >= 0);
             while (m != 0ull) {
-                const int b = __builtin_ctzll(m);
-                m &= m - 1ull;
-                const float* from = sh_rows + (int64_t)(unsigned)__builtin_amdgcn_readlane((int)src, b) * stride;
-                float* to = o_sh + (int64_t)__builtin_amdgcn_readlane(slot, b) * F;
-                for (int f = lane; f < F; f += 64) to[f] = from[f];
+                const float* from[4];
+                float* to[4];
+                bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    on[u] = m != 0ull;                                   // (uniform)
+                    const int b = on[u] ? __builtin_ctzll(m) : 0;
+                    m &= m - 1ull;                                       // (0 stays 0)
+                    from[u] = i_sh + (base + b) * F;
+                    to[u] = o_sh + (int64_t)__builtin_amdgcn_readlane(slot, b) * F;
+                }
+                for (int f = lane; f < F; f += 64) {
+                    float v[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) v[u] = on[u] ? from[u][f] : 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) if (on[u]) to[u][f] = v[u];
+                }
             }
         }
     }
@@ -3783,18 +3795,19 @@ int32_t LevelRun::select_phase() {
             GSR_TIME1(c->evk[1], st);
         }
         GSR_TRY(widen_scan(c->pcnt.as<unsigned>(), c->poff.as<int64_t>(), P));
+        if (!spec) GSR_TRY(total_of(c->poff.as<int64_t>(), c->pcnt.as<unsigned>(), P, &M));
+        // the pairs stay where the selection wrote them (segments of capacity pcap[p] at coff[p]): the partition pass and the
+        // M-step walk the segments.  Only the parts of the split parents are slid together (in place) -- by a handful of workgroups
+        // in a chain of dependent copies, BEFORE the SH copy is let loose beside it: under that kernel's 5 TB/s the chain took 0.13 ms
+        // of the 5 M level's critical path.
+        if ((spec || M > 0) && sparse && sa.heavy_blocks)
+            hipLaunchKernelGGL(k_join_parts, dim3(1024), blk, 0, st, sa.nheavy, sa.porder, c->coff.as<int64_t>(), sa.hfirst, sa.part_cnt,
+                               c->pcap.as<unsigned>(), sa.part_p, c->sp_child.as<unsigned>(), c->sp_wl.as<float>());
         // the cell-sorted copy of the SH block -- if the level's pair count says it pays (k_gather_sh) -- on the third stream, beside the
         // pair partition and the per-child sums; joined in front of the M-step
         if (!sh_launched) { GSR_TRY(launch_gather_sh(c->aux2 != nullptr)); sh_launched = true; }
-        if (!spec) GSR_TRY(total_of(c->poff.as<int64_t>(), c->pcnt.as<unsigned>(), P, &M));
         if (spec || M > 0) {
-            if (sparse) {
-                // the pairs stay where the selection wrote them (segments of capacity pcap[p] at coff[p]): the partition pass and the
-                // M-step walk the segments.  Only the parts of the split parents are slid together (in place).
-                if (sa.heavy_blocks)
-                    hipLaunchKernelGGL(k_join_parts, dim3(1024), blk, 0, st, sa.nheavy, sa.porder, c->coff.as<int64_t>(), sa.hfirst, sa.part_cnt,
-                                       c->pcap.as<unsigned>(), sa.part_p, c->sp_child.as<unsigned>(), c->sp_wl.as<float>());
-            } else {
+            if (!sparse) {
                 const size_t Mm = (size_t)(M > 0 ? M : 1);
                 GSR_TRY(c->pair_child.reserve(Mm * 4)); GSR_TRY(c->pair_wl.reserve(Mm * 4));
                 sa.poff = c->poff.as<int64_t>(); sa.pair_child = c->pair_child.as<unsigned>(); sa.pair_wl = c->pair_wl.as<float>();
@@ -4093,8 +4106,8 @@ int32_t LevelRun::mstep_phase() {
         if (msplit && hst != st) GSR_HIP(hipStreamWaitEvent(st, c->ev_mjoin, 0));
         GSR_TIME1(c->evm[1], st);
     }
-    hipLaunchKernelGGL(k_orphan_rows, grd, blk, 0, st, n, P, c->order.as<unsigned>(), c->oflag.as<int>(), c->orank_in.as<int>(),
-                       c->geo.as<float4>(), L.sh.as<float>(), c->shs.as<float>(), sh_mode, F, RSH, O.xyz.as<float>(), O.color.as<float>(),
+    hipLaunchKernelGGL(k_orphan_rows, dim3(stride_grid(n_own)), blk, 0, st, n_own, P, c->oflag_in.as<int>(), c->orank_in.as<int>(), L.xyz.as<float>(), L.color.as<float>(),
+                       L.cov6.as<float>(), L.opacity.as<float>(), L.weight.as<float>(), L.sh.as<float>(), F, O.xyz.as<float>(), O.color.as<float>(),
                        O.cov6.as<float>(), O.opacity.as<float>(), O.weight.as<float>(), O.sh.as<float>(), (int64_t)(spec ? out_cap : n_pre));
     if (sharded && P > 0) {
         // exchange 2: the merged components.  Every rank packs the rows of ITS parents, ONE all-gather of equal chunks
