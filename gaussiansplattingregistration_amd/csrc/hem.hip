@@ -1142,13 +1142,21 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
     }
 }
 
-#define MSTEP_CHUNK 256
+#ifndef MSTEP_CHUNK
+#define MSTEP_CHUNK 128       // pairs per chunk: what the wave's LDS holds of a parent at a time (child indices, weights)
+#endif
 #define MSTEP_SMALL 16        // parents with at most this many pairs are served four at a time, one per DPP row
 #define MSTEP_SEG 2048        // pairs per SEGMENT of a parent's sums (a multiple of MSTEP_CHUNK); see mstep_segment
 #define MSTEP_NV 3            // float4 per lane and SH row
 #define MSTEP_K 4             // parents per wavefront
 #ifndef MSTEP_U
-#define MSTEP_U 4             // rounds of SH row loads in flight (each: MSTEP_NV float4 per lane, 64/G children)
+#define MSTEP_U 2             // rounds of SH row loads in flight (each: MSTEP_NV float4 per lane, 64/G children): what 96 VGPRs hold (MSTEP_WAVES)
+#endif
+#ifndef MSTEP_WAVES
+#define MSTEP_WAVES 5         // waves per SIMD the kernel is built for: 96 VGPRs and 7 424 bytes of LDS (six granules of 1 280) per one-wave workgroup.
+                              // The kernel's time follows 1.66 ms + 17.6 ms / (waves per CU) at the 5 M level (measured at 8 / 12 / 16 waves by padding
+                              // the LDS, profiles/r05y_mstep_occupancy.txt): a gather floor and a latency term the waves share out.  16 -> 20 waves with
+                              // two rounds in flight instead of four: 2.71 -> 2.61 ms (surfels -6 %, clusters -5 %), profiles/r05z_ab_mstep_waves.txt
 #endif
 
 // One SEGMENT of a parent's sums: the pairs [off, off + cnt) (cnt <= MSTEP_SEG), from zero.  Leaves the 14 moment sums in s_mom and
@@ -1158,13 +1166,16 @@ __global__ __launch_bounds__(256) void k_mstep_headers(int P, const unsigned* __
 // How a parent's sums are DEFINED (all paths agree bit for bit, test_mstep_heavy_parent_split_changes_nothing): its pairs are cut
 // into segments of MSTEP_SEG; inside a segment the sums run in chunks of MSTEP_CHUNK pairs, lane l of a chunk
 // taking pairs l, l + 64, ..., the chunk's lane sums folded over the lanes (moment_sums: halves, row pairs, then inside the row) and
-// added to the segment's running sums in chunk order, the SH products accumulated per lane group along the segment by fused
-// multiply-adds and folded once at its end (the same order of levels) -- and the segments' totals are added in segment order.  A parent of at most MSTEP_SEG pairs (all but the giants) is one segment: nothing
+// added to the segment's running sums in chunk order, the SH products accumulated per lane group along the CHUNK by fused
+// multiply-adds, folded behind it (the same order of levels) and added to the running totals in chunk order -- and the segments'
+// totals are added in segment order.  A parent of at most MSTEP_SEG pairs (all but the giants) is one segment: nothing
 // changed for it.  The giants' segments are independent, which is the point: a parent with 5 * 10^4 pairs (found on the surfel
 // cloud) kept ONE wave busy for 2.5 ms, the whole M-step of that level.
 // The 14 moment sums of the parent in flight live in the PADDING of the record stage (s_rec rows are 80 bytes apart for the sake of the
-// LDS banks; the fifth float4 of rows 60 .. 63 is nobody's): an array of their own made the workgroup 10 304 bytes of LDS -- nine
-// allocation granules of 1 280 bytes, 14 waves per CU -- where 10 240 are eight granules and 16 waves, what the kernel's registers allow.
+// LDS banks; the fifth float4 of rows 60 .. 63 is nobody's); LDS is allocated in granules of 1 280 bytes: the wave's 7 424 bytes (128 child
+// indices, 128 weights, the record stage, 1 280 bytes for the row on its way out) are six of them, 20 waves per CU.  (Until late in round 5:
+// chunks of 256 pairs and 3 KB for the per-lane SH products of a parent with more than one chunk, carried from chunk to chunk -- 10 240 bytes,
+// 16 waves.  Now a chunk's products are folded behind the chunk and the running totals wait in the row's staging area.)
 // One global_load_dwordx4 from an address that is only 4-byte aligned (a row of the level's own SH array: F = 45 floats).  The hardware
 // takes it (HSA runs the memory pipeline in unaligned-access mode); the compiler, told the truth about the alignment, splits the load into
 // two or three pieces (dwordx2 + dwordx2, dwordx3 + dword), so it is not told.
@@ -1183,17 +1194,19 @@ struct MomRef {
 };
 template <int G>
 __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int gl, int grp, const int (&qi)[MSTEP_NV], float* s_w, unsigned* s_j,
-                                              float4* s_acc, MomRef s_mom, float4* s_rec, long long off, unsigned cnt, const f3 pm,
+                                              MomRef s_mom, float4* s_rec, float* s_park, long long off, unsigned cnt, const f3 pm,
                                               float4 (&acc)[MSTEP_NV], float (&shp)[MSTEP_NV]) {
     constexpr int GG = G > 0 ? G : 1;
     constexpr int CPR = 64 / GG;                                // children per round
     const int sh_stride = a.sh_direct ? a.F : a.RSH;            // floats between two SH rows (qi: this lane's float offsets inside a row)
     if (lane < 16) s_mom[lane] = 0.0f;
-    // SH sums: local to a chunk of pairs (they occupy no registers during part 1); a segment with more than MSTEP_CHUNK
-    // pairs (rare) carries its per-lane partial sums from chunk to chunk in LDS
+    // SH sums: per chunk of pairs, from zero (the per-lane products occupy no registers during part 1), folded over the lanes behind the
+    // chunk and added to the segment's running totals in chunk order (three registers in the packed form)
 #pragma unroll
-    for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    const bool multi = cnt > MSTEP_CHUNK;
+    for (int v = 0; v < MSTEP_NV; ++v) { acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f); shp[v] = 0.0f; }
+    float4 tot4[MSTEP_NV];                                      // (rows of more than 16 lanes: the unpacked totals)
+#pragma unroll
+    for (int v = 0; v < MSTEP_NV; ++v) tot4[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     for (unsigned c0 = 0; c0 < cnt; c0 += MSTEP_CHUNK) {
         const unsigned cn = (cnt - c0) < MSTEP_CHUNK ? (cnt - c0) : MSTEP_CHUNK;
         // part 1
@@ -1261,10 +1274,8 @@ __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int 
         // part 2: children in pair order, MSTEP_U rounds of row loads in flight; a skipped child has w = 0 (its row is
         // loaded all the same: no branch per load)
         if (G > 0) {
-            if (multi && c0 > 0) {
 #pragma unroll
-                for (int v = 0; v < MSTEP_NV; ++v) acc[v] = s_acc[v * 64 + lane];
-            }
+            for (int v = 0; v < MSTEP_NV; ++v) acc[v] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
             for (unsigned k0 = 0; k0 < cn; k0 += CPR * MSTEP_U) {
                 float4 rowv[MSTEP_U][MSTEP_NV];
                 float wv_[MSTEP_U];
@@ -1287,35 +1298,49 @@ __device__ __forceinline__ void mstep_segment(const MstepArgs& a, int lane, int 
                     }
                 }
             }
-            if (multi && c0 + MSTEP_CHUNK < cnt) {
+            // the chunk's products over the lanes; the first chunk's totals ARE the running totals (0 + x would turn a -0 into +0)
 #pragma unroll
-                for (int v = 0; v < MSTEP_NV; ++v) s_acc[v * 64 + lane] = acc[v];
+            for (int v = 0; v < MSTEP_NV; ++v) {
+                if constexpr (mstep_packed(G)) {
+                    // x, y, z, w of the float4 end in rows 0, 2, 1, 3 (packed_slot), each row holding its component's class totals
+                    const float t = row_class_sum<GG>(pack16_sum(pack32_sum(acc[v].x, acc[v].y), pack32_sum(acc[v].z, acc[v].w)));
+                    // (between the chunks the running totals wait in LDS -- the row's staging area, idle until the parent's output -- and
+                    // not in three registers that would be alive through part 1)
+                    const float r = c0 == 0 ? t : s_park[v * 64 + lane] + t;
+                    if (c0 + MSTEP_CHUNK < cnt) s_park[v * 64 + lane] = r; else shp[v] = r;
+                } else {
+                    const float tx = class_sum<GG>(acc[v].x), ty = class_sum<GG>(acc[v].y), tz = class_sum<GG>(acc[v].z), tw = class_sum<GG>(acc[v].w);
+                    tot4[v].x = c0 == 0 ? tx : tot4[v].x + tx; tot4[v].y = c0 == 0 ? ty : tot4[v].y + ty;
+                    tot4[v].z = c0 == 0 ? tz : tot4[v].z + tz; tot4[v].w = c0 == 0 ? tw : tot4[v].w + tw;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (G > 0) {
+    if constexpr (G > 0 && !mstep_packed(G)) {
 #pragma unroll
-        for (int v = 0; v < MSTEP_NV; ++v) {
-            if constexpr (mstep_packed(G)) {
-                // x, y, z, w of the float4 end in rows 0, 2, 1, 3 (packed_slot), each row holding its component's class totals
-                shp[v] = row_class_sum<GG>(pack16_sum(pack32_sum(acc[v].x, acc[v].y), pack32_sum(acc[v].z, acc[v].w)));
-            } else {
-                acc[v].x = class_sum<GG>(acc[v].x); acc[v].y = class_sum<GG>(acc[v].y);
-                acc[v].z = class_sum<GG>(acc[v].z); acc[v].w = class_sum<GG>(acc[v].w);
-            }
-        }
+        for (int v = 0; v < MSTEP_NV; ++v) acc[v] = tot4[v];
     }
 }
 
 // G = lanes per SH row (power of two, G * MSTEP_NV float4 >= RSH / 4); G == 0: no SH at all.  HEAVY: the work items of the heavy
 // parents (k_mstep_headers) instead of the parents themselves -- one wave per segment, the segment's sums out to hscratch;
 // k_mstep_heavy_finish adds a parent's segments in order and writes its row
+#if MSTEP_WAVES > 0
+#define MSTEP_ATTR __attribute__((amdgpu_waves_per_eu(MSTEP_WAVES, MSTEP_WAVES)))
+#else
+#define MSTEP_ATTR
+#endif
 template <int G, int WPB, bool HEAVY = false>
-__global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
+__global__ __launch_bounds__(64 * WPB) MSTEP_ATTR void k_mstep(MstepArgs a) {
     __shared__ float s_w_[WPB][MSTEP_CHUNK];
     __shared__ unsigned s_j_[WPB][MSTEP_CHUNK];
-    __shared__ float4 s_acc_[WPB][MSTEP_NV * 64];               // per-lane SH partial sums of a parent with more than MSTEP_CHUNK pairs
+#ifndef MSTEP_PAD4
+#define MSTEP_PAD4 0            // (occupancy experiments: extra float4 of LDS per wave)
+#endif
+    // a parent's SH row on its way out (F floats; the small-parent path: four rows 64 floats apart and the four parents' moment sums
+    // behind them, 320 floats)
+    __shared__ float4 s_acc_[WPB][(G > 16 ? MSTEP_NV * 32 : 80) + MSTEP_PAD4];
     __shared__ float4 s_rec_[WPB][64 * 5];                      // part 1: the batch's geometry records on their way to the pairs' lanes (80-byte stride)
     constexpr int GG = G > 0 ? G : 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -1349,7 +1374,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
                 const unsigned cn = h.cnt - first < MSTEP_SEG ? h.cnt - first : MSTEP_SEG;
                 float4 acc[MSTEP_NV];
                 float shp[MSTEP_NV];
-                mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off + first, cn, pm, acc, shp);
+                mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_mom, s_rec, s_out, h.off + first, cn, pm, acc, shp);
                 float* rec = a.hscratch + (int64_t)item * RS;
                 if (lane < 14) rec[lane] = s_mom[lane];
                 if constexpr (mstep_packed(G)) {
@@ -1566,7 +1591,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mstep(MstepArgs a) {
         if (cnt > MSTEP_SEG) continue;                          // a heavy parent: its segments belong to k_mstep<.., HEAVY> + k_mstep_heavy_finish
         float4 acc[MSTEP_NV];
         float shp[MSTEP_NV];
-        mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_acc, s_mom, s_rec, h.off, cnt, pm, acc, shp);
+        mstep_segment<G>(a, lane, gl, grp, qi, s_w, s_j, s_mom, s_rec, s_out, h.off, cnt, pm, acc, shp);
         const float w_s = s_mom[0];
         const float inv_w = 1.0f / w_s;                        // mixture.cpp:209
         const int64_t slot = h.oslot;

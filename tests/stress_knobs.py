@@ -12,7 +12,7 @@ KNOBS = [{"GSR_HEM_ELL": "0"}, {"GSR_HEM_SPLIT": "0"}, {"GSR_HEM_PARTITION": "wa
          {"GSR_HEM_PARTITION_STAGE": "4096"}, {"GSR_HEM_PARTITION_FACTOR": "0.3"}, {"GSR_HEM_SPARSE_GB": "0"}, {"GSR_HEM_CELL_TARGET": "4"},
          {"GSR_HEM_CELL_TARGET": "40"}, {"GSR_HEM_SH_DIRECT": "1"}, {"GSR_HEM_RB_POLL": "0"}, {"GSR_HEM_SUMLW": "sort"},
          {"GSR_HEM_MSTEP_SMALL": "0"}, {"GSR_HEM_MSTEP_SPLIT": "0"}, {"GSR_HEM_SELECT_NP": "1"}, {"GSR_HEM_SELECT_NP": "2"},
-         {"GSR_HEM_SELECT_NP": "4"}, {"GSR_HEM_ROWLIST": "0"}, {"GSR_HEM_SH_DIRECT": "0"}, {"GSR_HEM_ASYNC": "0"}]
+         {"GSR_HEM_SELECT_NP": "4"}, {"GSR_HEM_ROWLIST": "0"}, {"GSR_HEM_ROWLIST_MAX_MB": "0.25"}, {"GSR_HEM_SH_DIRECT": "0"}, {"GSR_HEM_ASYNC": "0"}]
 ALL = sorted({k for d in KNOBS for k in d})
 
 
