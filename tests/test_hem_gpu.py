@@ -758,15 +758,20 @@ def test_anisotropic_cloud_equals_oracle(oracle):
                 _check_level_mostly(got, want[k], ("aniso", k))
 
 
-def test_sh_wider_than_a_wavefront(oracle):
-    """F = 72 feature floats (> 64 lanes) exercises the multi-coefficient-per-lane M-step instantiation."""
+@pytest.mark.parametrize("deg,F", [(4, 72), (5, 105), (8, 240)])
+def test_sh_wider_than_a_wavefront(oracle, deg, F):
+    """F = 72 / 105 / 240 feature floats: the M-step instantiations with 8, 16 and 32 lanes per SH row -- the last one folds its sums the
+    unpacked way (a row is wider than the 16 lanes a packed sum needs for itself).  A few fat splats make parents of several hundred
+    pairs: more than one chunk of 128, so the per-chunk totals are added up on every path."""
     from gaussiansplattingregistration_amd import hem, synth
-    c = synth.make_cloud(3000, seed=41, h=0.6, sh_degree=4)
-    assert c["sh"].shape[1] == 72
-    want, _ = oracle.hem(c, 2)
-    got, _ = hem.create_mixture(c, 2)
+    c = synth.make_cloud(3000, seed=41, h=0.6, sh_degree=deg)
+    assert c["sh"].shape[1] == F
+    c["cov6"][5:35:5] = np.array([0.05, 0, 0, 0.04, 0, 0.045], np.float32)
+    want, wst = oracle.hem(c, 2)
+    got, st = hem.create_mixture(c, 2)
+    assert st[0]["max_pairs_of_a_parent"] > 128, st[0]
     for k in range(2):
-        _check_level(got[k], want[k], ("F72", k))
+        _check_level(got[k], want[k], ("F%d" % F, k))
 
 
 def test_work_sharded_level_equals_single_gpu():
