@@ -2726,8 +2726,15 @@ int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n, bool side
 #ifndef GSR_SORT_MERGE_LIMIT
 #define GSR_SORT_MERGE_LIMIT (256 * 1024)      // measured on the bench levels (profiles/r04i): 1 M -> 256 k takes 0.05 ms off the 1.67 M level (its 556 k parents) and 0.04 off the 556 k level; 128 k, 32 k: the same
 #endif
+#ifndef GSR_SORT_BS
+#define GSR_SORT_BS 1024
+#endif
+#ifndef GSR_SORT_IPT
+#define GSR_SORT_IPT 12        // keys per thread of the Onesweep kernels (1 024 threads): 16 -> 12 takes 44 us off a 5 M level's two sorts (230 -> 186 us;
+                               // 10 the same, 8: 198, 4: 243; 512- and 256-thread workgroups 260 ... 600 us), profiles/r05ah_onesweep_configs.txt
+#endif
 using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                            rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, GSR_SORT_RADIX_BITS,
+                                            rocprim::radix_sort_onesweep_config<rocprim::kernel_config<GSR_SORT_BS, GSR_SORT_IPT>, rocprim::kernel_config<GSR_SORT_BS, GSR_SORT_IPT>, GSR_SORT_RADIX_BITS,
                                                                                 rocprim::block_radix_rank_algorithm::match>,
                                             GSR_SORT_MERGE_LIMIT>;
 template <typename V>
