@@ -2749,7 +2749,16 @@ int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n, bool side
 #define GSR_SORT_IPT 12        // keys per thread of the Onesweep kernels (1 024 threads): 16 -> 12 takes 44 us off a 5 M level's two sorts (230 -> 186 us;
                                // 10 the same, 8: 198, 4: 243; 512- and 256-thread workgroups 260 ... 600 us), profiles/r05ah_onesweep_configs.txt
 #endif
-using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+// (the sorts of up to GSR_SORT_MERGE_LIMIT keys: block sort of 1 024 x 8 keys, then merge passes -- 20 us less per 200 k-splat level than rocPRIM's
+// default shape, equal at 50 k and 556 k: profiles/r05am_merge_sort_configs.txt)
+#ifndef GSR_MERGE_SORT_BS
+#define GSR_MERGE_SORT_BS 1024
+#define GSR_MERGE_SORT_IPT 8
+#define GSR_MERGE_MP_BS 128
+#define GSR_MERGE_MP_IPT 4
+#endif
+using merge_cfg = rocprim::merge_sort_config<512, GSR_MERGE_SORT_BS, GSR_MERGE_SORT_IPT, 128, GSR_MERGE_MP_BS, GSR_MERGE_MP_IPT>;
+using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, merge_cfg,
                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<GSR_SORT_BS, GSR_SORT_IPT>, rocprim::kernel_config<GSR_SORT_BS, GSR_SORT_IPT>, GSR_SORT_RADIX_BITS,
                                                                                 rocprim::block_radix_rank_algorithm::match>,
                                             GSR_SORT_MERGE_LIMIT>;
