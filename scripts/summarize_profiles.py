@@ -21,6 +21,13 @@ src, dst = sys.argv[1], sys.argv[2]
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 
 
+def newest(pattern):
+    """gpurun MERGES every call's output into the local directory, so a pass's directory can hold the files of several runs: only the
+    newest run's counter file counts (one file per profiled process)."""
+    fs = glob.glob(pattern)
+    return [max(fs, key=os.path.getmtime)] if fs else []
+
+
 def short(name):
     name = re.sub(r"rocprim::ROCPRIM_\d+_NS::detail::", "rocprim::", name)
     m = re.search(r"(radix_sort_\w+|scan_\w+|lookback_scan\w*|transform_\w+|init_\w+)", name)
@@ -30,7 +37,7 @@ def short(name):
     return name[:90]
 
 
-f = glob.glob(os.path.join(src, "prof_stats", "*", "*kernel_stats.csv"))
+f = newest(os.path.join(src, "prof_stats", "*", "*kernel_stats.csv"))
 if f:
     rows = list(csv.DictReader(open(f[0])))
     agg = collections.OrderedDict()
@@ -64,7 +71,7 @@ def derived(e, v, n):
 pmc = collections.defaultdict(lambda: collections.defaultdict(float))
 launches = collections.defaultdict(int)
 for d in ("pmc_fetch", "pmc_write", "pmc_l2", "pmc_sq", "pmc_sq2", "pmc_tc"):
-    for f in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+    for f in newest(os.path.join(src, d, "*", "*counter_collection.csv")):
         seen = set()
         for r in csv.DictReader(open(f)):
             k = short(r["Kernel_Name"])
@@ -112,7 +119,7 @@ def pmc_set(dirs, prefix, command, fetch_dir, marker=None, levels=4):
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
     nl = collections.defaultdict(int)
     for d in dirs:
-        for fn in glob.glob(os.path.join(src, d, "*", "*counter_collection.csv")):
+        for fn in newest(os.path.join(src, d, "*", "*counter_collection.csv")):
             seen_ = set()
             rows_ = sorted(csv.DictReader(open(fn)), key=lambda r: int(r["Dispatch_Id"]))
             marks, last_mark = 0, None
@@ -161,7 +168,7 @@ pmc_set(("pmc_icp_fetch", "pmc_icp_write", "pmc_icp_l2", "pmc_icp_sq", "pmc_icp_
         marker="gsr::k_debug_logf")
 pmc_set(("pmc_aniso_fetch", "pmc_aniso_write", "pmc_aniso_l2", "pmc_aniso_sq", "pmc_aniso_sq2"), "_pmc_aniso.json",
         "scripts/prof_hem.py 5000000 1 2 aniso  (level 1 of a 5 M surfel-shaped cloud)", "pmc_aniso_fetch")
-f = glob.glob(os.path.join(src, "icp_stats", "*", "*kernel_stats.csv"))
+f = newest(os.path.join(src, "icp_stats", "*", "*kernel_stats.csv"))
 if f:
     rows = list(csv.DictReader(open(f[0])))
     with open(dst + "_icp_kernel_stats.csv", "w") as o:
