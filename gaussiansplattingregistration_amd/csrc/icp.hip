@@ -40,7 +40,14 @@
 namespace gsr {
 // rocPRIM's Onesweep with its gfx950 kernel shapes but 11 bits per pass: the 22-bit cell keys of a 5 M-point grid take two passes
 // instead of three (up to 2^20 keys rocPRIM's merge sort runs as before)
-using icp_sort_cfg = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+// (the merge sorts of up to 2^20 keys with block sorts of 1 024 x 4 keys: 20-25 us less per target / source sort at 556 k points than rocPRIM's
+// default shape, equal at 185 k: profiles/r05aj_icp_merge_sort_configs.txt)
+#ifndef GSR_ICP_MERGE_BS
+#define GSR_ICP_MERGE_BS 1024
+#define GSR_ICP_MERGE_IPT 4
+#endif
+using icp_merge_cfg = rocprim::merge_sort_config<512, GSR_ICP_MERGE_BS, GSR_ICP_MERGE_IPT, 128, 128, 4>;
+using icp_sort_cfg = rocprim::radix_sort_config<rocprim::default_config, icp_merge_cfg,
                                                 rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 11,
                                                                                     rocprim::block_radix_rank_algorithm::match>>;
 
