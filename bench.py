@@ -51,8 +51,14 @@ LEVELS = 3
 ITER_VALUES = [50, 30, 20, 10]
 MAX_CORR = [0.5, 0.3, 0.2, 0.1]
 PAIR_ANGLE_DEG, PAIR_SHIFT_H = 5.0, 0.05      # rotation 5 degrees about (1,1,1)/sqrt(3), translation 0.05 h (1, -1, 0.5)
+# configs[3]: the two clouds' HEM levels run on two GPUs at once, so cloud B cannot continue cloud A's rand() stream where A's levels end
+# (qt_gaussian_mixture.py:55,79 does: one process, one stream).  Cloud k starts at position k * C4_STREAM_STRIDE of the same seed-1 stream
+# (the device generator jumps ahead in O(log) steps).  Both from position 0 -- rounds 4-5 -- gave the synthetic pair, whose cloud B is cloud A
+# moved with its rows in the same order, IDENTICAL parent flags: B's hierarchy was A's moved and the ICP converged in 50 / 2 / 1 / 1
+# iterations instead of the 50 / 29 / 4 / 2 of the shared stream.
+C4_STREAM_STRIDE = 1 << 40
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.3 TB/s achievable copy rate)
-# measured on MI355X (profiles/r02_valu_issue_microbench.txt): cycles a SIMD needs per wave64 VALU instruction with >= 2 waves resident
+# measured on MI355X (profiles/archive/r02_valu_issue_microbench.txt): cycles a SIMD needs per wave64 VALU instruction with >= 2 waves resident
 VALU_CYCLES = {"full_rate (v_fma/mul/add/and/or with VGPR or constant operands)": 2.2,
                "half_rate (any SGPR operand, v_cmp, v_cndmask, v_bcnt/mbcnt, shifts, cvt, DPP, pk_*, f64)": 4.1,
                "transcendental": 8.1, "one wave alone": 4.9}
@@ -237,7 +243,7 @@ def step_c4(ctxs, lru, src, tgt, device, sync, rank, world, comm=None):
     mine = None
     if rank < 2:
         m = ctxs["hem"]
-        m.set_rng("glibc", 1, 0)                   # context-local stream: the two clouds are independent
+        m.set_rng("glibc", 1, rank * C4_STREAM_STRIDE)     # context-local stream: the two clouds are independent (C4_STREAM_STRIDE above)
         mine, st = hem_levels(m, src if rank == 0 else tgt)
         out["kern"] = st
         out["hem_gaussians"] = sum(s["n_in"] for s in st)
@@ -723,7 +729,7 @@ def main():
             roof["traffic"] = pmc.get("hbm_read_bytes_per_launch_x2_corrected", 0.0) + wr
             roof["traffic_source"] = pmc["source"] + " (level-1 launch at 5 M; FETCH_SIZE x2 per MI355X_MICROARCH.md)"
             # MI355X_MICROARCH.md: "other access widths are uncalibrated: calibrate on a known byte count in your own access pattern".
-            # profiles/r03_fetch_calibration.txt: FETCH_SIZE counts streams at x0.5 but random 64-byte records in full -- the x2 doubles
+            # profiles/archive/r03_fetch_calibration.txt: FETCH_SIZE counts streams at x0.5 but random 64-byte records in full -- the x2 doubles
             # the gathers of these two kernels.  Calibrated: raw + the half of the kernel's STREAMED bytes the counter leaves out
             # (k_mstep: the pair list, 8 B per pair, and the 32-byte headers; k_select: nothing of size is streamed from HBM).
             lv1 = [k for k in kern if k["n_in"] == big_n]
@@ -732,7 +738,7 @@ def main():
             roof["traffic_calibrated"] = rd_raw + 0.5 * streamed + wr
             roof["traffic_note"] = ("traffic = FETCH_SIZE x 2 + WRITE_SIZE (the guide's streaming-read correction, kept for comparison with "
                                     "earlier rounds); traffic_calibrated = FETCH_SIZE + half of the kernel's streamed bytes + WRITE_SIZE "
-                                    "(profiles/r03_fetch_calibration.txt: gathers of 64-byte records are counted in full)")
+                                    "(profiles/archive/r03_fetch_calibration.txt: gathers of 64-byte records are counted in full)")
             vi, va = pmc.get("SQ_INSTS_VALU_per_launch"), pmc.get("SQ_ACTIVE_INST_VALU_per_launch")
             busy = pmc.get("SQ_BUSY_CYCLES_per_launch")
             roof["valu"] = {"insts_per_launch": vi, "active_quad_cycles_per_launch": va,

@@ -3546,7 +3546,7 @@ struct LevelRun {
     int32_t mstep_phase();
     int32_t flags_and_validity();
     int32_t compact_erased(int64_t n_keep);
-    int32_t erase_in_place(int64_t rows_bound, bool may_allocate);
+    int32_t erase_in_place(int64_t rows_bound, bool may_allocate, int64_t alloc_rows = 0);
     bool erase_on_device = false;           // the erase kernels were enqueued (an asynchronous level without the tails' buffer leaves the erase to the host)
     int32_t launch_gather_sh(bool fork);
     int32_t widen_scan(const unsigned* cnt_in, int64_t* off, int64_t count);
@@ -4077,6 +4077,9 @@ int32_t LevelRun::open_output() {
     }
     GSR_TRY(O.reserve(need, F));
     out_cap = out_active ? std::min<int64_t>(c->out_rows, n + (int64_t)P) : need;     // (parents + orphans <= n + P)
+    // an asynchronous level: O.weight / is_parent are the library's own arrays, reserved for `need` = n rows -- no row beyond them may be
+    // written (a degenerate level whose parents are orphans too has more than n rows: k_level_tail raises the flag, the level reruns)
+    if (spec) out_cap = std::min(out_cap, need);
     O.n = spec ? 0 : n_pre; O.F = F;
     if (spec)
         hipLaunchKernelGGL(k_level_tail, dim3(1), dim3(1), 0, st, n, P, c->orank_in.as<int>(), c->oflag_in.as<int>(), (long long)out_cap, lvl, cnt + 2);
@@ -4207,12 +4210,16 @@ int32_t LevelRun::mstep_phase() {
 
 // The validity erase in place, on the device (k_erase_save + k_erase_shift): lvl[0] = rows before it, cnt[3] / c->holes = what k_valid found;
 // lvl[4] = rows after it.  Both kernels leave at once when there is nothing to erase -- or more than ERASE_MAX rows (the host's path then).
-int32_t LevelRun::erase_in_place(int64_t rows_bound, bool may_allocate) {
+int32_t LevelRun::erase_in_place(int64_t rows_bound, bool may_allocate, int64_t alloc_rows) {
     // (the saved tails need 32 rows per tile of the bound -- 150 MB at 5 M rows -- and most clouds never erase a row: the buffer is allocated
-    // the first time a level of this context does, by the host's path; until then an asynchronous level only COUNTS the erased rows)
+    // the first time a level of this context does, by the host's path; until then an asynchronous level only COUNTS the erased rows.
+    // alloc_rows: that first allocation covers the bound the ASYNCHRONOUS levels of this size will ask for -- the level's input size, not the
+    // n_pre the host's path knows (sized for n_pre, every later asynchronous level found the buffer too small and took the
+    // host's path again, a second round trip per surfel level))
+    const int tile0 = std::min(256, 12288 / std::max(F, 6));
+    const auto halo_bytes = [&](int64_t rows) { return (size_t)((rows + tile0 - 1) / tile0 + 1) * ERASE_MAX * ((size_t)(14 + F) * 4 + 1) + 64; };
     {
-        const int tile0 = std::min(256, 12288 / std::max(F, 6));
-        const size_t need = (size_t)((rows_bound + tile0 - 1) / tile0 + 1) * ERASE_MAX * ((size_t)(14 + F) * 4 + 1) + 64;
+        const size_t need = halo_bytes(rows_bound);
         if (!may_allocate && c->erase_halo.cap < need) {
             hipLaunchKernelGGL(k_fill_const<long long>, dim3(1), dim3(1), 0, st, (int64_t)1, lvl + 4, (long long)0);     // (unused: the prologue reads lvl[0])
             return GSR_OK;
@@ -4228,7 +4235,7 @@ int32_t LevelRun::erase_in_place(int64_t rows_bound, bool may_allocate) {
     ea.W = 14 + F;
     ea.tile = std::min(256, 12288 / std::max(F, 6));
     ea.max_tiles = (int)((rows_bound + ea.tile - 1) / ea.tile) + 1;
-    GSR_TRY(c->erase_halo.reserve((size_t)ea.max_tiles * ERASE_MAX * ((size_t)ea.W * 4 + 1) + 64));
+    GSR_TRY(c->erase_halo.reserve(halo_bytes(std::max(rows_bound, alloc_rows))));
     ea.halo = c->erase_halo.as<float>();
     ea.holes = c->holes.as<int>(); ea.dropped = cnt + 3; ea.n_pre_p = lvl; ea.n_keep_out = lvl + 4;
     const int g = std::min(ea.max_tiles, 2048);
@@ -4297,7 +4304,7 @@ int32_t LevelRun::flags_and_validity() {
         }
         if (dropped > 0 && dropped <= ERASE_MAX && !part) {         // a handful of rows: in place, on the device
             hipLaunchKernelGGL(k_fill_const<long long>, dim3(1), dim3(1), 0, st, (int64_t)1, lvl, (long long)n_pre);
-            GSR_TRY(erase_in_place(n_pre, true));
+            GSR_TRY(erase_in_place(n_pre, true, n));
             O.n = n_pre - dropped;
         } else if (dropped > 0) {
             if (!part) GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));
@@ -4372,7 +4379,7 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
         have_next = dropped == 0 || (erase_on_device && dropped <= ERASE_MAX);      // (erased in place on the device: the prologue saw the level as it is now)
         if (have_next) O.n = n_pre - dropped;
         else if (dropped <= ERASE_MAX) {                // the first level of this context that erases rows: in place, from here (the buffer exists from now on)
-            GSR_TRY(erase_in_place(n_pre, true));
+            GSR_TRY(erase_in_place(n_pre, true, out_cap));
             O.n = n_pre - dropped;
         } else {                        // many rows to erase: the host finishes the level (scan + compaction), and the prologue is taken again
             GSR_TRY(exclusive_scan<int>(c, c->keep.as<int>(), c->kpos.as<int>(), n_pre));

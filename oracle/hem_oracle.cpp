@@ -208,6 +208,98 @@ struct Grid {
         cells[cur] = {start, (unsigned)sorted.size()};
     }
 
+    // ---- accelerated search (gsr_oracle_hem_set_fast_search): the SAME result list, found through a finer grid ------------
+    // The reference's list is { i : coord(p_i) - coord(q) in {-1,0,1}^3  and  sqdist(q, p_i) < R*R }, in the order of the 27-cell
+    // scan (dz, dy, dx ascending) and, inside a cell, of the sorted index array.  With cell = the LARGEST radius a cell of the
+    // 5 M-splat bench cloud holds ~60 000 points and a parent tests 1.6 M of them for the ~200 it keeps.  The fast path finds the
+    // points with sqdist < R*R (the same float expression) through a uniform grid of ~8 points per cell, keeps those whose
+    // REFERENCE cell is one of the 27 (the reference's own coord(), clamp quirk included), and orders them by (scan position of
+    // that cell, position in the reference's sorted array): element for element the list radius_search() returns.  Only for
+    // clouds of finite coordinates (anything else keeps the plain scan).  tests/test_oracle_golden.py checks both searches
+    // against the golden vectors; tests/golden/make_golden_5m.py shows equality with oracle/_ref at 1 M before it is used at 5 M.
+    std::vector<unsigned> pos;        // pos[sorted[k]] = k
+    std::vector<I3> pcoord;           // coord() of every point
+    std::vector<unsigned> fstart, fidx;
+    double fmin[3] = {0, 0, 0}, finv = 0;
+    int fdim[3] = {0, 0, 0};
+    bool fast_ready = false;
+
+    void build_fast() {
+        fast_ready = false;
+        const std::vector<V3>& P = *pts;
+        const size_t n = P.size();
+        if (n == 0 || n >= 0xffffffffull) return;
+        double mn[3] = {DBL_MAX, DBL_MAX, DBL_MAX}, mx[3] = {-DBL_MAX, -DBL_MAX, -DBL_MAX};
+        for (const V3& p : P) {
+            if (!std::isfinite(p.x) || !std::isfinite(p.y) || !std::isfinite(p.z)) return;
+            const double c[3] = {p.x, p.y, p.z};
+            for (int a = 0; a < 3; ++a) { mn[a] = std::min(mn[a], c[a]); mx[a] = std::max(mx[a], c[a]); }
+        }
+        const double ex = mx[0] - mn[0], ey = mx[1] - mn[1], ez = mx[2] - mn[2];
+        const double emax = std::max(ex, std::max(ey, ez));
+        if (!(emax > 0)) return;
+        double c = std::cbrt(std::max(ex, emax * 1e-3) * std::max(ey, emax * 1e-3) * std::max(ez, emax * 1e-3) * 8.0 / (double)n);
+        for (;;) {
+            double tot = 1;
+            for (int a = 0; a < 3; ++a) { fdim[a] = (int)std::floor((mx[a] - mn[a]) / c) + 1; tot *= fdim[a]; }
+            if (tot <= 6.4e7) break;
+            c *= 1.26;
+        }
+        finv = 1.0 / c;
+        for (int a = 0; a < 3; ++a) fmin[a] = mn[a];
+        const size_t nc = (size_t)fdim[0] * fdim[1] * fdim[2];
+        fstart.assign(nc + 1, 0);
+        std::vector<unsigned> cell_of(n);
+        for (size_t i = 0; i < n; ++i) {
+            const int cx = fcell(P[i].x, 0), cy = fcell(P[i].y, 1), cz = fcell(P[i].z, 2);
+            cell_of[i] = (unsigned)(((size_t)cz * fdim[1] + cy) * fdim[0] + cx);
+            ++fstart[cell_of[i] + 1];
+        }
+        for (size_t k = 0; k < nc; ++k) fstart[k + 1] += fstart[k];
+        fidx.resize(n);
+        std::vector<unsigned> cur(fstart.begin(), fstart.end() - 1);
+        for (size_t i = 0; i < n; ++i) fidx[cur[cell_of[i]]++] = (unsigned)i;
+        pos.resize(n);
+        for (size_t k = 0; k < n; ++k) pos[sorted[k]] = (unsigned)k;
+        pcoord.resize(n);
+        for (size_t i = 0; i < n; ++i) pcoord[i] = coord(P[i]);
+        fast_ready = true;
+    }
+    inline int fcell(double v, int a) const {
+        double t = std::floor((v - fmin[a]) * finv);
+        if (t < 0) t = 0;
+        if (t > fdim[a] - 1) t = fdim[a] - 1;
+        return (int)t;
+    }
+    void radius_search_fast(const V3& q, float radius, std::vector<unsigned>& out, std::vector<uint64_t>& keys) const {
+        out.clear();
+        keys.clear();
+        if (!(radius > 0) || !std::isfinite(q.x) || !std::isfinite(q.y) || !std::isfinite(q.z)) return;   // every `d2 < R*R` fails / no cell holds q
+        const float r2 = radius * radius;
+        // sqdist < fl(R*R) in float32 implies a true distance below R (1 + 1e-6): the pad covers it with room to spare
+        const double R = (double)radius * (1.0 + 1e-4) + 1e-30;
+        const I3 cq = coord(q);
+        const int x0 = fcell(q.x - R, 0), x1 = fcell(q.x + R, 0), y0 = fcell(q.y - R, 1), y1 = fcell(q.y + R, 1);
+        const int z0 = fcell(q.z - R, 2), z1 = fcell(q.z + R, 2);
+        for (int z = z0; z <= z1; ++z)
+            for (int y = y0; y <= y1; ++y) {
+                const size_t row = ((size_t)z * fdim[1] + y) * fdim[0];
+                for (unsigned k = fstart[row + x0]; k < fstart[row + x1 + 1]; ++k) {
+                    const unsigned i = fidx[k];
+                    if (!(sqdist(q, (*pts)[i]) < r2)) continue;
+                    const I3& ci = pcoord[i];
+                    // the same wrapped integer arithmetic as radius_search(): n = c + d  <=>  d = ci - cq
+                    const unsigned dx = (unsigned)ci.x - (unsigned)cq.x + 1u, dy = (unsigned)ci.y - (unsigned)cq.y + 1u,
+                                   dz = (unsigned)ci.z - (unsigned)cq.z + 1u;
+                    if (dx > 2u || dy > 2u || dz > 2u) continue;
+                    keys.push_back(((uint64_t)(dz * 9u + dy * 3u + dx) << 32) | pos[i]);
+                }
+            }
+        std::sort(keys.begin(), keys.end());
+        out.reserve(keys.size());
+        for (uint64_t k : keys) out.push_back(sorted[(unsigned)(k & 0xffffffffu)]);
+    }
+
     // pointindex.cpp:120-143; offsets in the order of pointindex.hpp:28-38 (x fastest, then y, then z)
     void radius_search(const V3& q, float radius, std::vector<unsigned>& out) const {
         out.clear();
@@ -245,6 +337,8 @@ struct gsr_oracle_hem {
     int64_t stats[6] = {0, 0, 0, 0, 0, 0};
     double margins[2] = {0, 0};
     double phase[5] = {0, 0, 0, 0, 0};
+    bool fast_search = false;          // gsr_oracle_hem_set_fast_search: the same lists through a finer grid (Grid::radius_search_fast)
+    bool used_fast = false;
 
     // mixture.cpp:54-64
     float likelihood(const Level& L, int64_t s, int64_t i) const {
@@ -279,6 +373,9 @@ struct gsr_oracle_hem {
         Grid grid;
         const bool searchable = nC > 0 && maxR > 0;
         if (searchable) grid.create(P.mean, maxR);
+        if (searchable && fast_search) grid.build_fast();
+        used_fast = searchable && fast_search && grid.fast_ready;
+        const bool fast = used_fast;
         double t1 = now_s();
 
         // 3. child selection (mixture.cpp:102-137) -- the reference's only OpenMP loop
@@ -295,7 +392,9 @@ struct gsr_oracle_hem {
         for (int64_t s_ = 0; s_ < nP; ++s_) {
             const int64_t s = parents[s_];
             std::vector<unsigned> result;
-            if (searchable) grid.radius_search(P.mean[s], radii[s_], result);
+            std::vector<uint64_t> keys;
+            if (fast) grid.radius_search_fast(P.mean[s], radii[s_], result, keys);
+            else if (searchable) grid.radius_search(P.mean[s], radii[s_], result);
             nCand += (int64_t)result.size();
             for (unsigned i : result) {
                 float colorDiff = dist(P.color[i], P.color[s]);          // gaussian.hpp:111-114
@@ -464,6 +563,13 @@ int64_t gsr_oracle_hem_level(gsr_oracle_hem* h, int32_t threads) {
     if (!h) return -1;
     return h->run_level(threads);
 }
+
+int gsr_oracle_hem_set_fast_search(gsr_oracle_hem* h, int32_t on) {
+    if (!h) return -1;
+    h->fast_search = on != 0;
+    return 0;
+}
+int gsr_oracle_hem_used_fast_search(const gsr_oracle_hem* h) { return h && h->used_fast ? 1 : 0; }
 
 int32_t gsr_oracle_hem_num_levels(const gsr_oracle_hem* h) { return h ? (int32_t)h->levels.size() : -1; }
 

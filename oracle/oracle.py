@@ -52,6 +52,8 @@ def lib():
     L.gsr_oracle_hem_level.restype = C.c_int64
     L.gsr_oracle_hem_level.argtypes = [vp, C.c_int32]
     L.gsr_oracle_hem_num_levels.argtypes = [vp]
+    L.gsr_oracle_hem_set_fast_search.argtypes = [vp, C.c_int32]
+    L.gsr_oracle_hem_used_fast_search.argtypes = [vp]
     L.gsr_oracle_hem_level_size.restype = C.c_int64
     L.gsr_oracle_hem_level_size.argtypes = [vp, C.c_int32]
     L.gsr_oracle_hem_get_level.argtypes = [vp, C.c_int32] + [vp] * 7
@@ -108,6 +110,15 @@ class HemOracle:
 
     def set_weights(self, w):
         self._L.gsr_oracle_hem_set_weights(self._h, _c(w, np.float32))
+
+    def set_fast_search(self, on=True):
+        """The reference's result lists (same members, same order) through a finer grid: for clouds whose 27-cell scans would take
+        hours (cell = the largest parent radius, mixture.cpp:92-99).  ``used_fast_search`` says whether the last level took it."""
+        self._L.gsr_oracle_hem_set_fast_search(self._h, 1 if on else 0)
+
+    @property
+    def used_fast_search(self) -> bool:
+        return bool(self._L.gsr_oracle_hem_used_fast_search(self._h))
 
     def run_level(self, threads=0) -> int:
         n = self._L.gsr_oracle_hem_level(self._h, threads)

@@ -35,6 +35,12 @@ int gsr_oracle_hem_set_weights(gsr_oracle_hem* h, const float* w);
 // Returns the new component count (after the validity erase), or -1 on error.
 int64_t gsr_oracle_hem_level(gsr_oracle_hem* h, int32_t threads);
 
+// Accelerated neighbour search for LARGE clouds (the 5 M-splat digest, tests/golden/make_golden_5m.py): the result list of every
+// parent is element for element the reference's 27-cell scan (same members, same order), found through a finer grid.  Off by
+// default; applies to the following levels.  used_fast_search: whether the most recent level took it (finite coordinates only).
+int gsr_oracle_hem_set_fast_search(gsr_oracle_hem* h, int32_t on);
+int gsr_oracle_hem_used_fast_search(const gsr_oracle_hem* h);
+
 int32_t gsr_oracle_hem_num_levels(const gsr_oracle_hem* h);           // including level 0
 int64_t gsr_oracle_hem_level_size(const gsr_oracle_hem* h, int32_t level);
 // Copy a level out (any pointer may be NULL).  weight/is_parent are internal state the reference

@@ -15,7 +15,7 @@ c5  (SURVEY 8(e) row 3).  The cloud is synth.make_block_cloud_torch's: defined b
     exchanges, bit-map bytes, heavy parents / bucket overflow / one-pass flags, level time.
 
 c4  (SURVEY 8(e) rows 1 + 2).  bench.py's own pair.
-    1. ONE process: the levels of cloud A and of cloud B (each from rand() position 0: two independent clouds), then the 4-entry
+    1. ONE process: the levels of cloud A and of cloud B (cloud k from rand() position k * bench.C4_STREAM_STRIDE: two independent clouds), then the 4-entry
        coarse-to-fine point-to-plane ICP.
     2. TWO fresh processes on device 0: cloud A's levels on rank 0, cloud B's on rank 1, one broadcast of the level lists, ICP with the
        source split over both ranks and the library's all-reduce of 32 float64 per iteration (bench.step_c4).
@@ -182,8 +182,8 @@ def worker_c4_single(a):
     src, tgt, T_gt = _c4_pair(a.splats, dev)
     m = hem.HemMixture(device=0, rng_mode="glibc", **bench.HEM_PARAMS)
     lists = []
-    for c in (src, tgt):
-        m.set_rng("glibc", 1, 0)                       # every cloud from a fresh stream position: two independent clouds (step_c4 does the same)
+    for ci, c in enumerate((src, tgt)):
+        m.set_rng("glibc", 1, ci * bench.C4_STREAM_STRIDE)     # every cloud from its own stream position: two independent clouds (step_c4 does the same)
         lists.append(bench.hem_levels(m, c)[0])
     torch.cuda.synchronize()
     t0 = time.perf_counter()

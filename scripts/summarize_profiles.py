@@ -4,7 +4,7 @@ The kernel-stats table comes from the bench.py run; the PMC passes profile scrip
 cloud alone), and the summary records the hash of the kernel sources it was taken with (bench.py only quotes it when the
 sources still match).
 
-usage: python scripts/summarize_profiles.py gpurun_out/r01 profiles/r01
+usage: python scripts/summarize_profiles.py gpurun_out/r01 profiles/archive/r01
 Writes <dst>_kernel_stats.csv (the --stats summary, kernel names shortened), <dst>_pmc.json (per-kernel
 counter sums / launch, with the gfx950 FETCH_SIZE x2 correction of MI355X_MICROARCH.md applied where
 stated) and copies the bench JSON lines."""
@@ -143,7 +143,7 @@ def pmc_set(dirs, prefix, command, fetch_dir, marker=None, levels=4):
         return None
     o = {"kernel_build": bench.kernel_build_id(), "command": command,
          "note": "FETCH_SIZE / WRITE_SIZE in KiB; on gfx950 FETCH_SIZE reports 1/2 of the bytes of a streaming read, x1.0 of random 64-byte "
-                 "records, x0.67 of random 192-byte rows (profiles/r03_fetch_calibration.txt): raw and x2 figures are both given"}
+                 "records, x0.67 of random 192-byte rows (profiles/archive/r03_fetch_calibration.txt): raw and x2 figures are both given"}
     for k, v in acc.items():
         n_ = max(1, nl.get(k, 1))
         e_ = {"launches_in_pass": n_}

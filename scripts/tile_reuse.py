@@ -7,7 +7,7 @@ candidate sets (all components within the query radius R_s = delta sqrt(lambda_m
 stage 1 streams).  Reported per tile size: the union (records and bytes at 16 B), the sum of the per-parent sets, and
 their ratio = how often a staged record would be re-used; then the same for the ACCEPTED children (the M-step's gathers).  CPU only (scipy cKDTree); run on a sub-box of the cloud.
 
-    python scripts/tile_reuse.py [n_splats=400000]  > profiles/r02_tile_reuse.txt
+    python scripts/tile_reuse.py [n_splats=400000]  > profiles/archive/r02_tile_reuse.txt
 """
 import os
 import sys

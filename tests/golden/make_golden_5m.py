@@ -1,0 +1,121 @@
+#!/usr/bin/env python3
+"""tests/golden/hem_5m_digest.npz: the REFERENCE's level 1 (and the sizes / moments of levels 2-3) of the bench's own 5 M-splat cloud
+(synth.make_cloud(5_000_000, seed=0): SURVEY 8(d) recipe, SH degree 3, rho 3 / delta 3 / kappa 2.5 / tau 1), reduced to a digest
+(tests/digest5m.py) -- BASELINE configs[2] compared with the reference's VALUES at its own size.
+
+Run in the BUILD CONTAINER (CPU only; needs /root/reference for `make -C oracle ref`):
+
+    python tests/golden/make_golden_5m.py                # 1 M equality check against oracle/_ref, then the 5 M digest   (~15 min on 8 cores)
+    python tests/golden/make_golden_5m.py --ref-5m       # ALSO the reference's own extension on the 5 M cloud (hours on 8 cores), compared
+                                                         #   bit for bit with the oracle's level 1 -> tests/golden/hem_5m_ref_check.json
+
+How the 5 M level is computed.  The reference's grid cell is the LARGEST parent radius (mixture.cpp:92-99): at 5 M a cell holds ~60 000
+points and a parent scans 1.6 M for the ~200 it keeps (2 141 s on 256 cores, profiles/r04_cpu_reference_5m.json -- whose output was not
+kept).  oracle/hem_oracle.cpp -- bit-equal to the reference's compiled extension on every golden vector and live
+(tests/test_oracle_vs_ref.py) -- has a second search that returns the SAME list for every parent (same members, same order: members of
+the 27 reference cells with sqdist < R*R, ordered by scan position of their cell, then by position in the reference's sorted array),
+found through a finer grid.  Step 1 below shows, on a 1 M-splat cloud of the same recipe, that this oracle equals oracle/_ref bit for bit
+in all five exported arrays; step 2 runs it at 5 M.  `--ref-5m` removes the remaining inference by running oracle/_ref itself at 5 M.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import digest5m                                                     # noqa: E402
+from gaussiansplattingregistration_amd import synth                 # noqa: E402
+from oracle import oracle                                           # noqa: E402
+
+PARAMS = dict(rho=3.0, delta=3.0, kappa=2.5, tau=1.0)
+FIVE = ("xyz", "color", "opacity", "cov6", "sh")
+
+
+def run_ref(cloud, threads, levels=1):
+    """The reference's own compiled extension in a fresh process (libc rand() is process-global).  -> per-level dicts, wall seconds."""
+    with tempfile.TemporaryDirectory() as td:
+        inp, outp = os.path.join(td, "i.npz"), os.path.join(td, "o.npz")
+        np.savez(inp, levels=levels, **PARAMS, **{k: cloud[k] for k in FIVE})
+        subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "run_ref.py"), inp, outp, "--threads", str(threads)], check=True)
+        r = np.load(outp)
+        return [{f: r[f"{f}_{k}"] for f in FIVE} for k in range(int(r["n_levels"]))], float(r["wall_s"])
+
+
+def run_oracle(cloud, levels, threads, fast):
+    o = oracle.HemOracle(cloud["xyz"], cloud["color"], cloud["cov6"], cloud["opacity"], cloud["sh"], **PARAMS)
+    o.set_fast_search(fast)
+    out = []
+    for k in range(levels):
+        t = time.perf_counter()
+        o.run_level(threads)
+        st = o.stats()
+        st["wall_s"] = time.perf_counter() - t
+        st["fast_search"] = o.used_fast_search
+        out.append((o.level(k + 1), st))
+        print(f"  oracle level {k + 1}: {out[-1][0]['xyz'].shape[0]} rows, {st['pairs']} pairs, {st['wall_s']:.1f} s, fast={st['fast_search']}", flush=True)
+    o.close()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--n", type=int, default=5_000_000)
+    ap.add_argument("--check-n", type=int, default=1_000_000)
+    ap.add_argument("--skip-check", action="store_true")
+    ap.add_argument("--ref-5m", action="store_true")
+    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
+    ap.add_argument("--out", default=os.path.join(HERE, "hem_5m_digest.npz"))
+    a = ap.parse_args()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"], stdout=subprocess.DEVNULL)
+    meta = {"numpy": np.__version__, "params": PARAMS, "generator": "tests/golden/make_golden_5m.py",
+            "cloud": f"synth.make_cloud({a.n}, seed=0)", "threads": a.threads}
+
+    if not a.skip_check:
+        c1 = synth.make_cloud(a.check_n, seed=0)
+        print(f"step 1: oracle (fast search) against oracle/_ref at {a.check_n} splats", flush=True)
+        ref, ref_s = run_ref(c1, a.threads)
+        got = run_oracle(c1, 1, a.threads, fast=True)
+        assert got[0][1]["fast_search"]
+        for f in FIVE:
+            assert ref[0][f].shape == got[0][0][f].shape and ref[0][f].tobytes() == got[0][0][f].tobytes(), ("oracle != _ref", f)
+        meta["check"] = {"n": a.check_n, "reference_wall_s": ref_s, "oracle_fast_wall_s": got[0][1]["wall_s"], "n_out": int(ref[0]["xyz"].shape[0]),
+                         "bit_equal_arrays": list(FIVE)}
+        print(f"  bit-equal in {FIVE}: {ref[0]['xyz'].shape[0]} rows (reference {ref_s:.0f} s, oracle {got[0][1]['wall_s']:.0f} s)", flush=True)
+        del c1, ref, got
+
+    print(f"step 2: the {a.n}-splat cloud", flush=True)
+    cloud = synth.make_cloud(a.n, seed=0)
+    lv = run_oracle(cloud, 3, a.threads, fast=True)
+    d = digest5m.digest(lv[0][0], lv[0][1])
+    d["input_sha256"] = np.frombuffer(digest5m.input_hash(cloud).encode(), np.uint8)
+    for k in (1, 2):            # levels 2 and 3: sizes, counters and global moments (compared end to end: a pair within 1e-7 of a gate may flip)
+        g = digest5m.global_moments(lv[k][0])
+        for key, v in g.items():
+            d[f"l{k + 1}_g_{key}"] = np.asarray(v, np.float64)
+        for key in ("parents", "pairs", "orphans", "dropped", "draws"):
+            d[f"l{k + 1}_{key}"] = np.int64(lv[k][1][key])
+        d[f"l{k + 1}_n_out"] = np.int64(lv[k][0]["xyz"].shape[0])
+    meta["levels"] = [{"n_out": int(l["xyz"].shape[0]), **{k: (float(v) if isinstance(v, float) else v) for k, v in s.items()}} for l, s in lv]
+    d["meta_json"] = np.frombuffer(json.dumps(meta).encode(), np.uint8)
+    np.savez_compressed(a.out, **d)
+    print(f"wrote {a.out}: {os.path.getsize(a.out) / 1e6:.1f} MB; level 1 = {int(d['n_out'])} rows, {int(d['pairs'])} pairs", flush=True)
+
+    if a.ref_5m:
+        print("step 3: oracle/_ref itself on the 5 M cloud (hours)", flush=True)
+        ref, ref_s = run_ref(cloud, a.threads)
+        rec = {"n": a.n, "reference_wall_s": ref_s, "threads": a.threads, "n_out_reference": int(ref[0]["xyz"].shape[0]), "n_out_oracle": int(d["n_out"]),
+               "bit_equal": {f: bool(ref[0][f].shape == lv[0][0][f].shape and ref[0][f].tobytes() == lv[0][0][f].tobytes()) for f in FIVE}}
+        json.dump(rec, open(os.path.join(HERE, "hem_5m_ref_check.json"), "w"), indent=1)
+        print(json.dumps(rec), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -363,6 +363,27 @@ def test_asynchronous_level_equals_the_synchronous_one(monkeypatch, shape, bad_e
                     assert np.array_equal(got[k][f].view(np.uint8), ref[k][f].view(np.uint8)), (zero_copy, k, f)
 
 
+def test_repeated_surfel_level_erases_on_the_device_in_one_round_trip():
+    """the buffer of the device-side validity erase was first allocated by the host's path for n_pre rows, the
+    asynchronous check asked for the level's INPUT size (1.6 x n_pre on a surfel level, 3 x on an isotropic one), so every later level found
+    it too small, only counted the erased rows and took the host's path again -- a second erase, a second prologue, a second round trip,
+    and k_erase_save / k_erase_shift fed by the device count never ran on a real level.  A surfel cloud whose level 1 drops a merged
+    component (oracle: 1 row at 300 k splats, seed 13), the level repeated on one context: from the second repetition on ONE round trip,
+    the erase on the device, the same bits as the first (synchronous) level."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(300000, seed=13, shape="aniso", sh_degree=1)
+    for zero_copy in (False, True):
+        with hem.HemMixture() as m:
+            runs = [_levels_on_one_context(m, c, 1, zero_copy) for _ in range(3)]
+        (ref, rst), rest = runs[0], runs[1:]
+        assert rst[0]["dropped"] >= 1 and rst[0]["schedule"] == 0, (rst[0]["dropped"], rst[0]["schedule"])
+        for got, st in rest:
+            assert st[0]["schedule"] == 1 and st[0]["dropped"] == rst[0]["dropped"] and st[0]["n_out"] == rst[0]["n_out"]
+            for f in ("xyz", "color", "cov6", "sh", "opacity", "weight", "is_parent"):
+                assert np.array_equal(got[0][f].view(np.uint8), ref[0][f].view(np.uint8)), (zero_copy, f)
+        assert rest[-1][1][0]["round_trips"] == 1, [r[1][0]["round_trips"] for r in rest]
+
+
 def test_asynchronous_level_on_buffers_too_small_reruns_synchronously():
     """An asynchronous level runs on the buffers the context has; a level that needs more (here: a context warmed on a small cloud, then a
     cloud eight times as large) finds that out ON THE DEVICE -- clamped writes, an abort flag in its one answer -- and is run again the
