@@ -99,17 +99,30 @@ def pmc_summary(kernel_prefix):
     return None, "no profiles/*_pmc.json taken with the current kernel sources (kernel_build %s)" % build
 
 
-def hem_levels(m, cloud, borrow=True):
-    """3 HEM levels of one cloud on context m; returns (level list for ICP, per-level stats)."""
+def hem_levels(m, cloud, borrow=True, arenas=None, key=None, normals=False):
+    """3 HEM levels of one cloud on context m, ONE library call (gsr_hem_run_levels = MixtureCreator::CreateMixture, mixture_wrapper.cpp:10-18);
+    returns (level list for ICP, per-level stats).  arenas / key: a dict that keeps this cloud's output arenas from step to step (no
+    allocation in steady state).  normals: the levels' normals leave with the levels (computed on the library's side stream beside the next
+    level) and level 0's with them -- the target side of point-to-plane ICP (point_cloud_converter.py:40-43)."""
+    import torch
     from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
-    lv = [PointCloud(xyz32=cloud["xyz"], cov6=cloud["cov6"])]
     m.set_level0(cloud["xyz"], cloud["color"], cloud["opacity"], cloud["cov6"], cloud["sh"], borrow=borrow)     # resident in HBM: read in place
-    stats = []
-    for _ in range(LEVELS):
-        m.run_level(out=m.new_output())             # zero-copy: the level is written into these tensors and read from them by the next level
-        stats.append(m.stats())
-        d = m.get_level(as_torch=True)              # views of their first n_out rows
-        lv.append(PointCloud(xyz32=d["xyz"], cov6=d["cov6"]))
+    n0 = int(cloud["xyz"].shape[0])
+    arena = nrm0 = None
+    if arenas is not None:
+        arena = arenas.get((key, n0, normals))
+        if arena is None:
+            arena = arenas[(key, n0, normals)] = m.new_arena(int(1.5 * n0) + 64 * LEVELS, normals=normals)
+            if normals:
+                arena["normals0"] = torch.empty((n0, 3), dtype=torch.float64, device=arena["xyz"].device)
+        nrm0 = arena.get("normals0")
+    elif normals:
+        arena = m.new_arena(int(1.5 * n0) + 64 * LEVELS, normals=True)
+        nrm0 = torch.empty((n0, 3), dtype=torch.float64, device=arena["xyz"].device)
+    levels, stats = m.run_levels(LEVELS, arena=arena, normals0=nrm0)       # zero-copy: every level is written into the arena and read from it by the next
+    lv = [PointCloud(xyz32=cloud["xyz"], cov6=cloud["cov6"], normals=nrm0)]
+    for d in levels:
+        lv.append(PointCloud(xyz32=d["xyz"], cov6=d["cov6"], normals=d.get("normals")))
     return lv, stats
 
 
@@ -164,8 +177,8 @@ def step_replicas(ctxs, lru, src, tgt, device, sync):
         clouds = []
         m = ctxs["hem"]
         m.set_rng("glibc", 1, 0)                       # a fresh reference process: cloud 1 then cloud 2 on one stream
-        for c in (src, tgt):
-            lv, st = hem_levels(m, c)
+        for ci, c in enumerate((src, tgt)):
+            lv, st = hem_levels(m, c, arenas=ctxs.setdefault("arenas", {}), key=ci, normals=(ci == 1))       # the target's normals leave with its levels
             out["hem_gaussians"] += sum(s["n_in"] for s in st)
             out["kern"] += st
             clouds.append(lv)

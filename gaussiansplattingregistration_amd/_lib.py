@@ -72,6 +72,7 @@ SIGNATURES = {
     "gsr_hem_get_part_stats": (_i32, [_vp, C.POINTER(_i64)]),
     "gsr_hem_get_part_ms": (_i32, [_vp, C.POINTER(C.c_float)]),
     "gsr_hem_run_level": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "gsr_hem_run_levels": (_i32, [_vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp]),
     "gsr_hem_level_size": (_i32, [_vp, C.POINTER(_i64), C.POINTER(_i32)]),
     "gsr_hem_get_level": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32]),
     "gsr_hem_get_stats": (_i32, [_vp, C.POINTER(_i64)]),
@@ -118,6 +119,12 @@ TEST_HOOKS = {
 }
 
 _lib = None
+
+
+class HemLevelReport(C.Structure):
+    """gsr_hem_level_report (include/gsr_hip.h): what gsr_hem_run_levels reports per level."""
+    _fields_ = [("offset_rows", C.c_int64), ("rows", C.c_int64), ("dropped", C.c_int64), ("rng_position", C.c_uint64),
+                ("stats", C.c_int64 * 8), ("stats_ex", C.c_int64 * 8), ("phase_ms", C.c_float * 8), ("kernel_ms", C.c_float * 8)]
 
 
 def load(require_device: bool = False):

@@ -50,6 +50,7 @@
 // is re-evaluated here with the same float expression.
 #include "gsr_common.h"
 #include "gsr_math.h"
+#include "gsr_normals.h"
 #include "gsr_test_hooks.h"
 #include "hem_device.h"
 #include "hem_select.h"
@@ -2563,6 +2564,9 @@ struct gsr_hem_ctx {
     int cblock = 0;                 // which of the two counter blocks the running level uses (the next level's prologue clears the other)
     DevBuf lvl;                     // long long[8]: device-resident counts of an asynchronous level (k_level_tail); [2] = work-item size (k_heavy_items)
     bool async_ok = true;           // GSR_HEM_ASYNC=0: every level sizes its buffers from counts read back on the way (five round trips, the rounds 1-4 schedule)
+    bool last_level = false;        // gsr_hem_run_levels: the level being run is the last of its hierarchy -- no prologue of a next level behind it
+    hipStream_t side = nullptr;     // gsr_hem_run_levels: the levels' normals beside the next level
+    hipEvent_t ev_side = nullptr, ev_side_fork = nullptr;
     int round_trips = 0;            // host round trips of the last gsr_hem_run_level (statistic: gsr_hem_get_stats_ex [6])
     int was_async = 0;              // the last level ran without a round trip between its first and its last kernel ([7])
     float cell_target = 16.0f;      // components per grid cell (GSR_HEM_CELL_TARGET; the result does not depend on it).  Swept at 5 M after the parents left
@@ -2961,6 +2965,9 @@ int32_t gsr_hem_destroy(gsr_hem_ctx* c) {
     for (int i = 0; i < 2; ++i) if (c->ev_pro[i]) (void)hipEventDestroy(c->ev_pro[i]);
     if (c->aux) (void)hipStreamDestroy(c->aux);
     if (c->aux2) (void)hipStreamDestroy(c->aux2);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_side) (void)hipEventDestroy(c->ev_side);
+    if (c->ev_side_fork) (void)hipEventDestroy(c->ev_side_fork);
     delete c;
     return GSR_OK;
 }
@@ -4351,6 +4358,7 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
 
     unsigned long long w[LC_WORDS];
     bool have_next = false;             // w holds the next level's prologue
+    const bool want_pro = !c->last_level;       // (the last level of a gsr_hem_run_levels hierarchy: nobody will read it)
     const int cb_next = c->cblock ^ 1;
     LevelCollect q;
     memset(&q, 0, sizeof(q));
@@ -4365,7 +4373,7 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
                            c->holes.as<int>());
         GSR_TRY(erase_in_place(out_cap, false));        // (leaves at once when nothing is erased; lvl[4] = the rows that remain)
         GSR_TIME1(c->ev[5], st);
-        GSR_TRY(enqueue_prologue(c, O, out_cap, erase_on_device ? lvl + 4 : lvl, cb_next));
+        if (want_pro) GSR_TRY(enqueue_prologue(c, O, out_cap, erase_on_device ? lvl + 4 : lvl, cb_next));
         q.lvl = lvl;
         GSR_TRY(read_back_level(c, q, w));
         if (w[LC_FLAGS] != 0ull) return GSR_RETRY_SYNC;        // a clamped segment, a full bucket region or item table, an output too small
@@ -4390,7 +4398,7 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
         GSR_TIME1(c->ev[5], st);
     }
     // the next level's prologue with this level's last round trip (one GPU); a partitioned / sharded level just waits for the stream
-    if (!part && !sharded && !have_next && O.n > 0) {
+    if (!part && !sharded && !have_next && O.n > 0 && want_pro) {
         GSR_TRY(enqueue_prologue(c, O, O.n, nullptr, cb_next));
         GSR_TRY(read_back_level(c, q, w));
         have_next = true;
@@ -4404,7 +4412,7 @@ int32_t LevelRun::run(int64_t* n_out, int64_t* n_dropped) {
         for (int i = 0; i < 5; ++i) c->spare[i].swap(c->spare_out[i]);
         c->cur_borrowed = true;
     }
-    if (have_next && c->cur.n > 0) take_prologue(c, w, c->cur.n, cb_next); else c->pro.valid = false;
+    if (have_next && want_pro && c->cur.n > 0) take_prologue(c, w, c->cur.n, cb_next); else c->pro.valid = false;
     if (part) { c->gid.swap(c->gid_next); c->n_global = n_glob_next; }
     c->stats[3] = dropped;
     c->stats[7] = c->cur.n;
@@ -4463,6 +4471,77 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* c, int64_t* n_out, int64_t* n_dropped) {
         LevelRun run(c, false);
         r = run.run(n_out, n_dropped);
         c->stats_ex[7] = 2;             // (statistic: an asynchronous attempt was rerun)
+    }
+    return r;
+}
+
+// the normals of a level leave with the level (gsr_hem_run_levels): the arithmetic of gsr_normals_from_cov (icp.hip), gsr_normals.h
+__global__ __launch_bounds__(256) void k_level_normals(int64_t n, const float* __restrict__ cov6, double* __restrict__ out) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        double v[3];
+        gsr::normal_of_cov_d(cov6[6 * i], cov6[6 * i + 1], cov6[6 * i + 2], cov6[6 * i + 3], cov6[6 * i + 4], cov6[6 * i + 5], v);
+        out[3 * i] = v[0]; out[3 * i + 1] = v[1]; out[3 * i + 2] = v[2];
+    }
+}
+
+int32_t gsr_hem_run_levels(gsr_hem_ctx* c, int32_t n_levels, float* xyz, float* color, float* cov6, float* opacity, float* sh, double* normals,
+                           double* normals0, int64_t arena_rows, gsr_hem_level_report* reports) {
+    if (!c || !c->have_level) return fail(GSR_E_INVALID, "gsr_hem_run_levels: no level set");
+    if (n_levels < 0 || (n_levels > 0 && !reports)) return fail(GSR_E_INVALID, "gsr_hem_run_levels: bad argument (n_levels = %d)", n_levels);
+    if (n_levels > 0 && (!xyz || !color || !cov6 || !opacity || arena_rows <= 0)) return fail(GSR_E_INVALID, "gsr_hem_run_levels: NULL arena");
+    if (c->cur.F > 0 && !sh && n_levels > 0) return fail(GSR_E_INVALID, "gsr_hem_run_levels: the levels have F = %d but there is no SH arena", c->cur.F);
+    if (c->comm || c->shard_world > 1) return fail(GSR_E_INVALID, "gsr_hem_run_levels: not for partitioned / sharded levels (run them level by level)");
+    GSR_HIP(hipSetDevice(c->device));
+    const int F = c->cur.F;
+    const bool want_normals = normals != nullptr || normals0 != nullptr;
+    if (want_normals && !c->side) {
+        GSR_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+        GSR_HIP(hipEventCreateWithFlags(&c->ev_side, hipEventDisableTiming));
+        GSR_HIP(hipEventCreateWithFlags(&c->ev_side_fork, hipEventDisableTiming));
+    }
+    bool side_used = false;
+    // the side stream starts behind whatever the caller has enqueued on the context's stream (the arrays of level 0 may still be written)
+    if (want_normals) { GSR_HIP(hipEventRecord(c->ev_side_fork, c->stream)); GSR_HIP(hipStreamWaitEvent(c->side, c->ev_side_fork, 0)); }
+    if (normals0 && c->cur.n > 0) {
+        hipLaunchKernelGGL(k_level_normals, dim3(stride_grid(c->cur.n)), dim3(256), 0, c->side, c->cur.n, c->cur.cov6.as<float>(), normals0);
+        side_used = true;
+    }
+    int64_t off = 0;
+    int32_t r = GSR_OK;
+    for (int k = 0; k < n_levels; ++k) {
+        const int64_t n_in = c->cur.n;
+        if (off + n_in > arena_rows) {
+            r = fail(GSR_E_INVALID, "gsr_hem_run_levels: level %d needs rows [%lld, %lld) of arenas that hold %lld rows", k + 1, (long long)off, (long long)(off + n_in),
+                     (long long)arena_rows);
+            break;
+        }
+        gsr_hem_level_report& R = reports[k];
+        memset(&R, 0, sizeof(R));
+        R.offset_rows = off;
+        if (n_in > 0) {
+            r = gsr_hem_set_output(c, xyz + 3 * off, color + 3 * off, cov6 + 6 * off, opacity + off, F > 0 ? sh + (size_t)F * off : nullptr, n_in);
+            if (r != GSR_OK) break;
+        }
+        int64_t n_out = 0, dropped = 0;
+        c->last_level = k == n_levels - 1;
+        r = gsr_hem_run_level(c, &n_out, &dropped);
+        c->last_level = false;
+        if (r != GSR_OK) break;
+        R.rows = n_out; R.dropped = dropped; R.rng_position = c->rng_pos;
+        memcpy(R.stats, c->stats, sizeof(R.stats)); memcpy(R.stats_ex, c->stats_ex, sizeof(R.stats_ex));
+        memcpy(R.phase_ms, c->phase_ms, sizeof(R.phase_ms)); memcpy(R.kernel_ms, c->kernel_ms, sizeof(R.kernel_ms));
+        // the level is complete (its answer came back behind its last kernel, the validity erase included) and from here on it is only
+        // read: its normals beside the next level, on the side stream
+        if (normals && n_out > 0) {
+            hipLaunchKernelGGL(k_level_normals, dim3(stride_grid(n_out)), dim3(256), 0, c->side, n_out, cov6 + 6 * off, normals + 3 * off);
+            side_used = true;
+        }
+        off += (n_out + 63) / 64 * 64;
+    }
+    if (side_used) {            // whatever is enqueued on the context's stream after this call sees the normals
+        GSR_HIP(hipEventRecord(c->ev_side, c->side));
+        GSR_HIP(hipStreamWaitEvent(c->stream, c->ev_side, 0));
+        GSR_HIP(hipGetLastError());
     }
     return r;
 }

@@ -236,6 +236,63 @@ class HemMixture:
         self._out_cur = out
         return int(n_out.value), int(n_drop.value)
 
+    def new_arena(self, rows, normals=False):
+        """Uninitialised arenas for ``run_levels``: ``rows`` rows of every exported array (+ float64 normals)."""
+        dev = torch.device("cuda", self.device)
+        e = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+        rows = int(rows)
+        a = {"xyz": e(rows, 3), "color": e(rows, 3), "cov6": e(rows, 6), "opacity": e(rows), "sh": e(rows, self.F)}
+        if normals:
+            a["normals"] = torch.empty((rows, 3), dtype=torch.float64, device=dev)
+        return a
+
+    def run_levels(self, n_levels, arena=None, normals0=None):
+        """``MixtureCreator.CreateMixture(clusterLevel, ...)`` in ONE library call (``gsr_hem_run_levels``; mixture_wrapper.cpp:10-18):
+        ``n_levels`` clustering levels on the current level, written one behind the other into the CUDA tensors of ``arena``
+        (``new_arena``; default: 1.5 x the current level's rows, ``n_levels`` x when that is not enough) -- no return to Python between
+        the levels.  Returns ``(levels, stats)``: per level a dict of VIEWS ``xyz color cov6 opacity sh`` (+ ``normals`` when the arena has
+        a ``normals`` array: the normals leave with the level) and the dict ``stats()`` would have returned after it (+ ``dropped_now``).
+        ``normals0``: a (n, 3) float64 CUDA tensor that receives the normals of the level the call starts from.
+        The arena must stay untouched until the next ``run_level(s)`` / ``set_level0`` has returned (this object keeps it alive)."""
+        n_levels = int(n_levels)
+        n0 = self.size
+        if arena is None:
+            arena = self.new_arena(max(64, int(1.5 * n0) + 64 * n_levels))
+        rows = int(arena["xyz"].shape[0])
+        for k, w in (("xyz", 3), ("color", 3), ("cov6", 6), ("opacity", 1), ("sh", self.F)):
+            t = arena.get(k)
+            if w == 0 and k == "sh":
+                continue
+            if t is None or not t.is_cuda or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != rows * w or t.device.index != self.device:
+                raise RuntimeError(f"run_levels(arena=...): '{k}' must be a contiguous float32 CUDA tensor of {rows} x {w} on cuda:{self.device}")
+        nrm = arena.get("normals")
+        for t, r in ((nrm, rows), (normals0, n0)):
+            if t is not None and (not t.is_cuda or t.dtype != torch.float64 or not t.is_contiguous() or t.numel() != r * 3 or t.device.index != self.device):
+                raise RuntimeError(f"run_levels: normals must be contiguous float64 CUDA tensors of rows x 3 on cuda:{self.device}")
+        reports = (_lib.HemLevelReport * max(1, n_levels))()
+        torch.cuda.current_stream(self.device).synchronize()
+        rc = self._L.gsr_hem_run_levels(self._h, n_levels, arena["xyz"].data_ptr(), arena["color"].data_ptr(), arena["cov6"].data_ptr(),
+                                        arena["opacity"].data_ptr(), arena["sh"].data_ptr() if self.F > 0 else None,
+                                        nrm.data_ptr() if nrm is not None else None, normals0.data_ptr() if normals0 is not None else None,
+                                        rows, C.cast(reports, C.c_void_p))
+        self._borrowed = None
+        self._arena = arena                         # keeps the current level's memory alive
+        self._out_prev, self._out_cur = None, None
+        _lib.check(rc, "gsr_hem_run_levels")
+        levels, stats = [], []
+        for k in range(n_levels):
+            R = reports[k]
+            o, n = int(R.offset_rows), int(R.rows)
+            lv = {f: arena[f][o:o + n] for f in ("xyz", "color", "cov6", "opacity", "sh")}
+            if nrm is not None:
+                lv["normals"] = nrm[o:o + n]
+            levels.append(lv)
+            stats.append(self._stats_dict(R.stats, R.phase_ms, R.stats_ex, R.kernel_ms, int(R.rng_position), dropped_now=int(R.dropped)))
+        if n_levels > 0:
+            last = levels[-1]
+            self._out_cur = {f: last[f] for f in ("xyz", "color", "cov6", "opacity", "sh")}      # get_level(as_torch=True) returns these views
+        return levels, stats
+
     def new_output(self, rows=None):
         """Uninitialised output arrays for ``run_level(out=...)``: ``rows`` defaults to the current level's size (always enough)."""
         rows = self.size if rows is None else int(rows)
@@ -305,15 +362,19 @@ class HemMixture:
         _lib.check(self._L.gsr_hem_get_stats_ex(self._h, x), "gsr_hem_get_stats_ex")
         km = (C.c_float * 8)()
         _lib.check(self._L.gsr_hem_get_kernel_ms(self._h, km), "gsr_hem_get_kernel_ms")
+        return self._stats_dict(s, t, x, km, int(pos.value))
+
+    @staticmethod
+    def _stats_dict(s, t, x, km, rng_draws, **extra):
         # round_trips: host round trips of the level (1 = asynchronous: one answer behind the level's last kernel; a synchronous level takes
         # four to six); schedule: 0 synchronous, 1 asynchronous, 2 an asynchronous attempt whose buffers were too small, rerun synchronously
-        return {"irregular": x[0], "one_pass": x[1], "partition_overflow": x[2], "heavy_parents": x[3], "heavy_work_items": x[4], "max_pairs_of_a_parent": x[5],
+        return {**extra, "irregular": x[0], "one_pass": x[1], "partition_overflow": x[2], "heavy_parents": x[3], "heavy_work_items": x[4], "max_pairs_of_a_parent": x[5],
                 "round_trips": x[6], "schedule": x[7],
                 "ms_k_select": km[0], "ms_k_mstep": km[1], "ms_k_partition": km[2], "ms_k_bucket_sum": km[3],
                 "parents": s[0], "pairs": s[1], "orphans": s[2], "dropped": s[3], "candidates": s[4], "cells": s[5],
                 "n_in": s[6], "n_out": s[7], "ms_grid": t[0], "ms_select": t[1], "ms_sumlw": t[2], "ms_mstep": t[3],
                 "ms_flags": t[4], "ms_level": t[5], "ms_k_select_count": t[6], "ms_k_select_fill": t[7],
-                "rng_draws": int(pos.value)}
+                "rng_draws": rng_draws}
 
 
 def create_mixture(cloud: dict, cluster_level: int, hem_reduction=3.0, distance_delta=3.0, color_delta=2.5,

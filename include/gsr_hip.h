@@ -11,7 +11,8 @@
  *                 MixtureLevel.CreateMixtureLevel(xyz, colors, opacities, covariance, features)
  *                     src/cpp_ext/include/mixturelevel.hpp:17-22, src/mixturelevel.cpp:14-28  -> gsr_hem_set_level0
  *                 MixtureCreator.CreateMixture(clusterLevel, hemReduction, distanceDelta, colorDelta, decayRate, level)
- *                     src/cpp_ext/mixture_wrapper.hpp:10, mixture_wrapper.cpp:10-18              -> gsr_hem_create + gsr_hem_run_level x clusterLevel
+ *                     src/cpp_ext/mixture_wrapper.hpp:10, mixture_wrapper.cpp:10-18              -> gsr_hem_create + gsr_hem_run_level x clusterLevel,
+ *                                                                                                    or gsr_hem_run_levels (all levels in one call)
  *                 MixtureLevel.CreatePythonLists(level)  src/mixturelevel.cpp:30-70             -> gsr_hem_get_level
  *               (arithmetic: src/cpp_ext/src/mixture.cpp:54-64,66-285,287-333; include/gaussian.hpp:82-114;
  *                include/vec.hpp:736-768,863-872; src/pointindex.cpp:55-143; include/base.hpp:24-27,44-56)
@@ -195,6 +196,37 @@ int32_t gsr_hem_set_output(gsr_hem_ctx* ctx, float* xyz, float* color, float* co
  * counts read back on the way (gsr_hem_get_stats_ex [6], [7]); its input is never written, the result is the same.  GSR_HEM_ASYNC=0
  * always takes that second schedule.  (The reference's level has no such boundary: one function, mixture.cpp:25-35.) */
 int32_t gsr_hem_run_level(gsr_hem_ctx* ctx, int64_t* n_out, int64_t* n_dropped);
+
+/* MixtureCreator::CreateMixture(clusterLevel, ...) in ONE call (mixture_wrapper.cpp:10-18: the reference runs every level inside one
+ * function and returns the list of levels): `n_levels` clustering levels on the current level, each written straight into caller-owned
+ * DEVICE arenas -- xyz[arena_rows*3], color[arena_rows*3], cov6[arena_rows*6], opacity[arena_rows], sh[arena_rows*F] (NULL when
+ * F = 0) -- one level behind the other: level k occupies rows [reports[k].offset_rows, + reports[k].rows) of every arena (offsets are
+ * multiples of 64 rows, so every level's arrays start 256-byte aligned).  A level needs room for as many rows as its INPUT has while it
+ * runs: the call fails cleanly (GSR_E_INVALID, nothing of that level written) when offset + input rows > arena_rows; arena_rows =
+ * n_levels x (rows of level 0) always suffices, 1.5 x is enough for the usual reduction by 3.  Equivalent to gsr_hem_set_output +
+ * gsr_hem_run_level per level -- the same bits -- without a return to the host language between the levels (a Python caller spent
+ * ~0.15 ms per level there, a tenth of a 556 k-splat level); reports[k] carries what gsr_hem_get_stats / _stats_ex / _phase_ms /
+ * _kernel_ms / _rng_position would have returned after level k.
+ * normals (optional, DEVICE, arena_rows*3 float64): the normal of every component of every new level -- the eigenvector of the smallest
+ * eigenvalue of its covariance, what `estimate_normals()` gives a cloud whose covariances are set (point_cloud_converter.py:40-43),
+ * bit for bit gsr_normals_from_cov -- at the level's row offset: the normals leave with the level, computed
+ * on a side stream beside the next level and joined into the context's stream before the call returns.
+ * normals0 (optional, DEVICE, rows of the current level * 3 float64): the same for the level the call starts from.
+ * The arenas must stay valid and unchanged until the next gsr_hem_run_level(s) / gsr_hem_set_level0 / destroy has returned (the last
+ * level of the call is the context's current level, borrowed).  Not for partitioned / sharded levels (gsr_hem_set_comm, _set_shard). */
+typedef struct gsr_hem_level_report {
+    int64_t offset_rows;        /* first row of the level in the arenas */
+    int64_t rows;               /* components of the level (after the validity erase) */
+    int64_t dropped;            /* components the validity erase removed */
+    uint64_t rng_position;      /* gsr_hem_get_rng_position after the level */
+    int64_t stats[8];           /* gsr_hem_get_stats */
+    int64_t stats_ex[8];        /* gsr_hem_get_stats_ex */
+    float phase_ms[8];          /* gsr_hem_get_phase_ms */
+    float kernel_ms[8];         /* gsr_hem_get_kernel_ms */
+} gsr_hem_level_report;
+int32_t gsr_hem_run_levels(gsr_hem_ctx* ctx, int32_t n_levels, float* xyz, float* color, float* cov6, float* opacity, float* sh,
+                           double* normals, double* normals0, int64_t arena_rows,
+                           gsr_hem_level_report* reports);
 
 int32_t gsr_hem_level_size(gsr_hem_ctx* ctx, int64_t* n, int32_t* F);
 /* Copy the current level into caller buffers (any may be NULL).  weight / is_parent are internal

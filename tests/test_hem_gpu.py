@@ -384,6 +384,55 @@ def test_repeated_surfel_level_erases_on_the_device_in_one_round_trip():
         assert rest[-1][1][0]["round_trips"] == 1, [r[1][0]["round_trips"] for r in rest]
 
 
+@pytest.mark.parametrize("shape", ["iso", "aniso"])
+def test_all_levels_in_one_call_equal_the_level_by_level_path(shape):
+    """gsr_hem_run_levels (MixtureCreator::CreateMixture in one library call, mixture_wrapper.cpp:10-18): three levels written one behind the
+    other into caller-owned arenas = set_output + run_level per level, bit for bit, statistics included; the normals that leave with the
+    levels (side stream) = gsr_normals_from_cov on the same rows, bit for bit, level 0's too; the context goes on from the last level (whose
+    trailing prologue was skipped: the next call takes it again); an arena that is too small fails cleanly before anything is written."""
+    from gaussiansplattingregistration_amd import hem, icp, synth
+    c = synth.make_cloud(150000, seed=17, sh_degree=2, shape=shape)
+    c["cov6"][7::19997] = np.array([1.0, 0, 0, 1.0, 0, -1.0], np.float32)           # a few rows the validity erase drops in place
+    with hem.HemMixture() as m:
+        ref, rst = _levels_on_one_context(m, c, 4, True)
+    for rep in range(2):                    # second repetition: every level asynchronous
+        with hem.HemMixture() as m:
+            if rep:
+                _levels_on_one_context(m, c, 3, True)
+            m.set_rng("glibc", 1, 0)
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+            n0 = m.size
+            arena = m.new_arena(int(1.5 * n0) + 256, normals=True)
+            nrm0 = torch.empty((n0, 3), dtype=torch.float64, device="cuda")
+            levels, st = m.run_levels(3, arena=arena, normals0=nrm0)
+            assert [s["n_out"] for s in st] == [s["n_out"] for s in rst[:3]]
+            offs = [int(lv["xyz"].data_ptr() - arena["xyz"].data_ptr()) // 12 for lv in levels]
+            assert offs[0] == 0 and all(o % 64 == 0 for o in offs) and all(b >= a + lv["xyz"].shape[0] for a, b, lv in zip(offs, offs[1:], levels))
+            for k in range(3):
+                for f in ("parents", "pairs", "orphans", "dropped", "candidates", "n_in", "n_out", "rng_draws", "heavy_parents", "max_pairs_of_a_parent"):
+                    assert st[k][f] == rst[k][f], (rep, k, f, st[k][f], rst[k][f])
+                assert st[k]["dropped_now"] == rst[k]["dropped"]
+                for f in ("xyz", "color", "cov6", "sh", "opacity"):
+                    assert np.array_equal(levels[k][f].cpu().numpy().view(np.uint8), ref[k][f].view(np.uint8)), (rep, k, f)
+                want = icp.normals_from_cov(levels[k]["cov6"].contiguous(), device=0)
+                assert torch.equal(levels[k]["normals"], want if isinstance(want, torch.Tensor) else torch.from_numpy(want).cuda()), (rep, k)
+            want0 = icp.normals_from_cov(torch.from_numpy(c["cov6"]).cuda(), device=0)
+            assert torch.equal(nrm0, want0 if isinstance(want0, torch.Tensor) else torch.from_numpy(want0).cuda())
+            # the context goes on: level 4 through the level-by-level entry (state and flags of level 3 are the context's)
+            m.run_level()
+            got4 = m.get_level(with_state=True)
+            for f in ("xyz", "color", "cov6", "sh", "opacity", "weight", "is_parent"):
+                assert np.array_equal(np.asarray(got4[f]).view(np.uint8), ref[3][f].view(np.uint8)), (rep, "level 4", f)
+    with hem.HemMixture() as m:
+        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+        with pytest.raises(RuntimeError, match="arenas that hold"):
+            m.run_levels(2, arena=m.new_arena(m.size + 64))                  # level 1 fits, level 2 (input ~ n/3 rows behind n/3 rows) fits too ...
+            m.run_levels(1, arena=m.new_arena(10))                           # ... this one cannot
+        m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+        with pytest.raises(RuntimeError, match="arenas that hold"):
+            m.run_levels(1, arena=m.new_arena(m.size - 1))
+
+
 def test_asynchronous_level_on_buffers_too_small_reruns_synchronously():
     """An asynchronous level runs on the buffers the context has; a level that needs more (here: a context warmed on a small cloud, then a
     cloud eight times as large) finds that out ON THE DEVICE -- clamped writes, an abort flag in its one answer -- and is run again the
