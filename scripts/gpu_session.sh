@@ -6,7 +6,7 @@
 #   usage: bash scripts/gpu_session.sh TAG STEP [STEP ...]        output under gpurun_out/TAG/ (copy what is to be judged into profiles/)
 #
 # Steps (each may carry arguments after a colon, comma separated):
-#   tests[:PYTEST_ARGS]      pytest -m gpu (default: the whole suite, -x -q); e.g. tests:tests/test_hem_gpu.py
+#   tests[:PYTEST_ARGS]      pytest -q -m gpu (default: tests -x, the whole suite); e.g. tests:tests/test_hem_gpu.py,--maxfail=5
 #   smoke                    __graft_entry__.smoke()
 #   bench[:ARGS]             python bench.py ARGS            -> bench.json (e.g. bench:--steps,10)
 #   c2                       bench.py --splats 1000000 (BASELINE configs[1])
@@ -49,8 +49,8 @@ for step in "$@"; do
     name=${step%%:*}
     echo "=== $TAG $step"
     case $name in
-    tests)    a=$( [ "$step" = "$name" ] && echo "tests" || args "$step" )
-              python -m pytest $a -x -q -m gpu > "$OUT/pytest_gpu.log" 2>&1; echo "exit $?"; tail -5 "$OUT/pytest_gpu.log" ;;
+    tests)    a=$( [ "$step" = "$name" ] && echo "tests -x" || args "$step" )
+              python -m pytest $a -q -m gpu > "$OUT/pytest_gpu.log" 2>&1; echo "exit $?"; tail -5 "$OUT/pytest_gpu.log" ;;
     smoke)    python -c "import __graft_entry__ as g; g.smoke()" > "$OUT/smoke.log" 2>&1; tail -2 "$OUT/smoke.log" ;;
     bench)    a=$( [ "$step" = "$name" ] && echo "" || args "$step" )
               python bench.py $a > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -c 700 "$OUT/bench.json"; echo ;;

@@ -74,8 +74,10 @@ def assert_rows_close(got, want, tag, tol=1e-4):
     off by far more than 1e-4 of itself; VERDICT r05 "weak" 3: every array, not positions and covariance diagonals only).  ALL SIX
     covariance entries against the component's own trace, positions against its own extent sqrt(trace) (absolute floor: 1e-3 of the
     field's median trace -- a degenerate component is not asked for more than float32 can give the sum it came from); colour, SH,
-    opacity and weight against the row's own largest |entry| of that array, floored at 1e-3 of the array's RMS (a merged colour that
-    cancels to nearly zero is a sum of terms 1e3 times its size)."""
+    opacity and weight against the row's own largest |entry| of that array, floored at 5 % of the array's RMS: these are zero-mean fields,
+    and an entry that cancels far below the array's scale is a float32 sum of terms tens to thousands of times its size -- 1e-4 of the
+    entry itself would ask for more digits than float32 carried through the sum (seen at 1 M rows: a merged opacity of -3.98e-4 from raw
+    opacities of magnitude 2, GPU and oracle 1.6e-7 apart: two summation orders of the same float32 terms)."""
     gx, wx = _np(got["xyz"]).astype(np.float64), _np(want["xyz"]).astype(np.float64)
     gc, wc = _np(got["cov6"]).astype(np.float64), _np(want["cov6"]).astype(np.float64)
     assert gx.shape == wx.shape and gc.shape == wc.shape, tag
@@ -92,7 +94,7 @@ def assert_rows_close(got, want, tag, tol=1e-4):
         g_, w_ = _np(got[f]).astype(np.float64).reshape(len(wx), -1), _np(want[f]).astype(np.float64).reshape(len(wx), -1)
         if w_.shape[1] == 0:
             continue
-        e = np.abs(g_ - w_).max(1) / np.maximum(np.abs(w_).max(1), 1e-3 * np.sqrt((w_ * w_).mean()))
+        e = np.abs(g_ - w_).max(1) / np.maximum(np.abs(w_).max(1), 5e-2 * np.sqrt((w_ * w_).mean()))
         k = int(np.argmax(e))
         assert e[k] <= tol, (tag, f + ", per component", k, float(e[k]), g_[k][:6], w_[k][:6])
 
