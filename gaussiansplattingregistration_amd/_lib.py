@@ -97,6 +97,8 @@ SIGNATURES = {
     "gsr_icp_set_allreduce_dev": (_i32, [_vp, ALLREDUCE_DEV_FN, _vp, _i64]),
     "gsr_icp_set_comm": (_i32, [_vp, _vp, _i64]),
     "gsr_icp_accumulate": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp]),
+    "gsr_icp_register_clouds": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _vp, _i32, _i32, _f64, _f64, _f64, _i32, _vp, C.POINTER(_f64),
+                                       C.POINTER(_f64), C.POINTER(_i32)]),
     "gsr_icp_register": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _i32, _vp, C.POINTER(_f64), C.POINTER(_f64),
                                 C.POINTER(_i32)]),
     "gsr_icp_correspondences": (_i32, [_vp, _vp, _vp, _vp]),

@@ -1586,7 +1586,9 @@ struct gsr_icp_ctx {
     void* allreduce_user = nullptr;
     gsr_allreduce_dev64_fn allreduce_dev = nullptr;      // device-resident loop with a stream-ordered collective per iteration
     void* allreduce_dev_user = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr, eb0 = nullptr, eb1 = nullptr;      // e0 / e1: the iteration loop; eb0 / eb1: the target index build
+    bool defer_sync = false;        // gsr_icp_register_clouds: set_target / set_source do not wait for the stream (the registration behind them does)
+    bool build_pending = false;     // ms_build has not been read from eb0 / eb1 yet
     float ms_build = 0, ms_iter = 0;
     int n_iter_kernels = 0;
     int max_cells = 1 << 25;
@@ -1755,7 +1757,9 @@ int32_t gsr_icp_create(gsr_icp_ctx** out, int32_t device, void* stream) {
     gsr_icp_ctx* c = new gsr_icp_ctx();
     c->device = device;
     c->stream = (hipStream_t)stream;
-    if (hipEventCreate(&c->e0) != hipSuccess || hipEventCreate(&c->e1) != hipSuccess) { delete c; return fail(GSR_E_HIP, "hipEventCreate failed"); }
+    if (hipEventCreate(&c->e0) != hipSuccess || hipEventCreate(&c->e1) != hipSuccess || hipEventCreate(&c->eb0) != hipSuccess || hipEventCreate(&c->eb1) != hipSuccess) {
+        delete c; return fail(GSR_E_HIP, "hipEventCreate failed");
+    }
     // Environment knobs (all of them): none changes a result, tests/test_icp_gpu.py::test_icp_knobs_change_nothing
     if (const char* e = getenv("GSR_ICP_DEVICE_LOOP")) c->device_loop = atoi(e) != 0;
     if (const char* e = getenv("GSR_ICP_BLOCK_SEARCH")) c->block_search = atoi(e) != 0;
@@ -1789,6 +1793,8 @@ int32_t gsr_icp_destroy(gsr_icp_ctx* c) {
     for (DevBuf* b : all) b->release();
     if (c->e0) (void)hipEventDestroy(c->e0);
     if (c->e1) (void)hipEventDestroy(c->e1);
+    if (c->eb0) (void)hipEventDestroy(c->eb0);
+    if (c->eb1) (void)hipEventDestroy(c->eb1);
     if (c->host_rb) (void)hipHostFree(c->host_rb);
     delete c;
     return GSR_OK;
@@ -1801,7 +1807,7 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     if (n >= ((int64_t)1 << 31) - 1) return fail(GSR_E_INVALID, "gsr_icp_set_target: n too large");
     GSR_HIP(hipSetDevice(c->device));
     hipStream_t st = c->stream;
-    GSR_HIP(hipEventRecord(c->e0, st));
+    GSR_HIP(hipEventRecord(c->eb0, st));
     const float* dxyz = xyz;
     const double* dnrm = normals;
     if (!on_device) {
@@ -1891,9 +1897,13 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     if (normals) GSR_TRY(c->Tn.reserve((size_t)n * 24));
     hipLaunchKernelGGL(k_icp_gather_target, dim3(stride_grid(n)), dim3(256), 0, st, n, c->order.as<unsigned>(), dxyz, dnrm,
                        c->Tq.as<float4>(), normals ? c->Tn.as<double>() : (double*)nullptr);
-    GSR_HIP(hipEventRecord(c->e1, st));
-    GSR_HIP(hipStreamSynchronize(st));
-    (void)hipEventElapsedTime(&c->ms_build, c->e0, c->e1);
+    GSR_HIP(hipEventRecord(c->eb1, st));
+    if (c->defer_sync) c->build_pending = true;      // (gsr_icp_register_clouds: the registration behind this waits for the stream)
+    else {
+        GSR_HIP(hipStreamSynchronize(st));
+        (void)hipEventElapsedTime(&c->ms_build, c->eb0, c->eb1);
+        c->build_pending = false;
+    }
     GSR_HIP(hipGetLastError());                      // the launches of the index build
     c->nt = n; c->max_corr = max_corr; c->have_target = true; c->have_normals = normals != nullptr;
     c->have_tcov = false; c->have_scov = false; c->have_tcol = false; c->have_scol = false;
@@ -1936,7 +1946,7 @@ int32_t gsr_icp_set_source(gsr_icp_ctx* c, const float* xyz, int64_t n, int32_t 
     } else {
         GSR_HIP(hipMemcpyAsync(c->src.p, xyz, (size_t)n * 12, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, st));
     }
-    GSR_HIP(hipStreamSynchronize(st));
+    if (!c->defer_sync) GSR_HIP(hipStreamSynchronize(st));
     c->ns = n; c->have_source = true; c->have_scov = false; c->have_scol = false;
     if (!c->allreduce && !c->allreduce_dev && !c->comm) c->ns_global = n;
     return GSR_OK;
@@ -2231,8 +2241,38 @@ int32_t gsr_icp_get_centre(gsr_icp_ctx* c, double* centre3) {
     return GSR_OK;
 }
 
+static void icp_read_build_ms(gsr_icp_ctx* c) {
+    if (!c->build_pending) return;
+    (void)hipEventSynchronize(c->eb1);
+    (void)hipEventElapsedTime(&c->ms_build, c->eb0, c->eb1);
+    c->build_pending = false;
+}
+
+// registration_icp(source, target, max_correspondence_distance, init, estimation, criteria) -- Open3D's own entry takes the two CLOUDS
+// (local_registration_util.py:88-90): target index, source order and the iteration loop in one call, no return to the host language and
+// no stream synchronisation between them (a Python caller spent ~0.2 ms per registration in those gaps: profiles/r06d_icp_timeline.txt).
+int32_t gsr_icp_register_clouds(gsr_icp_ctx* c, const float* src_xyz, int64_t ns, const float* tgt_xyz, const double* tgt_normals, int64_t nt,
+                                int32_t on_device, double max_corr, const double* init_T, int32_t kind, int32_t loss, double k, double rel_fitness,
+                                double rel_rmse, int32_t max_iter, double* out_T, double* fitness, double* inlier_rmse, int32_t* iterations) {
+    if (!c) return fail(GSR_E_INVALID, "gsr_icp_register_clouds: NULL context");
+    if (kind != GSR_ICP_POINT_TO_POINT && kind != GSR_ICP_POINT_TO_PLANE)
+        return fail(GSR_E_INVALID, "gsr_icp_register_clouds: point-to-point and point-to-plane only (covariances / colours: the step-by-step entry points)");
+    if (kind == GSR_ICP_POINT_TO_PLANE && !tgt_normals) return fail(GSR_E_PRECONDITION, "TransformationEstimationPointToPlane requires target normals");
+    // one process, one GPU: a communicator or an all-reduce callback of an earlier sharded call must not stay behind
+    c->comm = nullptr; c->allreduce = nullptr; c->allreduce_user = nullptr; c->allreduce_dev = nullptr; c->allreduce_dev_user = nullptr;
+    c->defer_sync = c->device_loop;                 // (the host-driven loop, GSR_ICP_DEVICE_LOOP=0, keeps the waits)
+    int32_t r = gsr_icp_set_target(c, tgt_xyz, kind == GSR_ICP_POINT_TO_PLANE ? tgt_normals : nullptr, nt, max_corr, on_device);
+    if (r == GSR_OK) r = gsr_icp_set_source(c, src_xyz, ns, on_device);
+    c->defer_sync = false;
+    if (r == GSR_OK) { c->ns_global = ns; r = gsr_icp_register(c, init_T, kind, loss, k, rel_fitness, rel_rmse, max_iter, out_T, fitness, inlier_rmse, iterations); }
+    if (r != GSR_OK) (void)hipStreamSynchronize(c->stream);         // (the caller's arrays are free again whatever happened)
+    icp_read_build_ms(c);
+    return r;
+}
+
 int32_t gsr_icp_get_timing(gsr_icp_ctx* c, float* out3) {
     if (!c || !out3) return fail(GSR_E_INVALID, "gsr_icp_get_timing: NULL argument");
+    icp_read_build_ms(c);
     out3[0] = c->ms_build; out3[1] = c->ms_iter; out3[2] = (float)c->n_iter_kernels;
     return GSR_OK;
 }

@@ -240,6 +240,28 @@ class IcpContext:
                    "gsr_icp_register")
         return {"transformation": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iterations": int(it.value)}
 
+    def register_clouds(self, src_xyz, tgt_xyz, tgt_normals, max_corr, init=None, kind=0, loss=0, k=0.0, rel_fitness=1e-6, rel_rmse=1e-6, max_iter=30):
+        """``registration_icp(source, target, max_correspondence_distance, init, estimation, criteria)`` in ONE library call
+        (``gsr_icp_register_clouds``): target index, source order and the iteration loop without a return to Python or a stream
+        synchronisation between them.  Point-to-point / point-to-plane, one process; the same result as ``set_target`` + ``set_source`` +
+        ``register``.  All arrays on the host or all on the device."""
+        ns, nt = int(src_xyz.shape[0]), int(tgt_xyz.shape[0])
+        ps, ks, ds = _prep(src_xyz, (ns, 3), np.float32, self.device)
+        pt, kt, dt = _prep(tgt_xyz, (nt, 3), np.float32, self.device)
+        pn, kn, dn = (None, None, dt) if tgt_normals is None else _prep(tgt_normals, (nt, 3), np.float64, self.device)
+        if not (ds == dt == dn):
+            raise RuntimeError("register_clouds: source, target and normals must live in the same place (all host or all device)")
+        if dt:
+            self._sync_torch()
+        init = np.eye(4) if init is None else np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
+        T = np.empty((4, 4), np.float64)
+        fit, rmse, it = C.c_double(0), C.c_double(0), C.c_int32(0)
+        _lib.check(self._L.gsr_icp_register_clouds(self._h, ps, ns, pt, pn, nt, 1 if dt else 0, float(max_corr), init.ctypes.data, kind, loss, float(k),
+                                                   float(rel_fitness), float(rel_rmse), int(max_iter), T.ctypes.data, C.byref(fit), C.byref(rmse),
+                                                   C.byref(it)), "gsr_icp_register_clouds")
+        self.n_target, self.n_source = nt, ns
+        return {"transformation": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iterations": int(it.value)}
+
     def correspondences(self, T):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
         idx = np.empty(self.n_source, np.int64)

@@ -158,6 +158,17 @@ def registration_icp(source, target, max_correspondence_distance, init, estimati
     if own:
         ctx = _icp.IcpContext(device=dev)
     try:
+        if (estimation_method.kind in (_icp.KIND_POINT_TO_POINT, _icp.KIND_POINT_TO_PLANE) and not target_prepared and comm is None
+                and allreduce_device is None and allreduce is None and len(source) > 0
+                and len({bool(getattr(a, "is_cuda", False)) for a in (source.xyz32, target.xyz32, target.normals) if a is not None}) == 1):
+            # the plain single-process call: the two clouds go to the library in ONE call (gsr_icp_register_clouds), like Open3D's own
+            # registration_icp(source, target, ...) -- no Python and no stream synchronisation between index build, source sort and loop
+            r = ctx.register_clouds(source.xyz32, target.xyz32, target.normals if estimation_method.kind == _icp.KIND_POINT_TO_PLANE else None,
+                                    max_correspondence_distance, np.asarray(init, dtype=np.float64), estimation_method.kind, loss.code, loss.k,
+                                    criteria.relative_fitness, criteria.relative_rmse, criteria.max_iteration)
+            res = _icp.RegistrationResult(r["transformation"], r["fitness"], r["inlier_rmse"], r["iterations"])
+            res.timing = ctx.timing()
+            return res
         if target_prepared:
             if ctx is None or own or getattr(ctx, "n_target", -1) != len(target):
                 raise RuntimeError("registration_icp: target_prepared needs the caller's context with this target set")

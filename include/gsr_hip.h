@@ -340,6 +340,15 @@ int32_t gsr_icp_accumulate(gsr_icp_ctx* ctx, const double* T, int32_t kind, int3
 int32_t gsr_icp_register(gsr_icp_ctx* ctx, const double* init_T, int32_t kind, int32_t loss, double k,
                          double rel_fitness, double rel_rmse, int32_t max_iter,
                          double* out_T, double* fitness, double* inlier_rmse, int32_t* iterations);
+/* The same with the two CLOUDS as arguments -- Open3D's own signature, registration_icp(source, target, max_correspondence_distance,
+ * init, estimation_method, criteria) (local_registration_util.py:88-90): gsr_icp_set_target + gsr_icp_set_source + gsr_icp_register in
+ * one call, without a return to the host language or a stream synchronisation between them; same result, bit for bit.  Point-to-point
+ * and point-to-plane (tgt_normals[nt*3] float64, required for the latter; ignored for the former); one process, one GPU (an installed
+ * communicator / all-reduce callback is removed).  on_device: 0 = host arrays, 1 = device arrays (read in place). */
+int32_t gsr_icp_register_clouds(gsr_icp_ctx* ctx, const float* src_xyz, int64_t ns, const float* tgt_xyz, const double* tgt_normals,
+                                int64_t nt, int32_t on_device, double max_corr, const double* init_T, int32_t kind, int32_t loss,
+                                double k, double rel_fitness, double rel_rmse, int32_t max_iter, double* out_T, double* fitness,
+                                double* inlier_rmse, int32_t* iterations);
 /* Nearest target index (or -1) and squared distance for every source point at transform T. */
 int32_t gsr_icp_correspondences(gsr_icp_ctx* ctx, const double* T, int64_t* idx, double* d2);
 /* Device milliseconds: [0] target index build, [1] all correspondence/accumulate kernels of the last

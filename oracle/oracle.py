@@ -153,14 +153,16 @@ class HemOracle:
                 "t_grid": t[0], "t_select": t[1], "t_likelihood": t[2], "t_mstep": t[3], "t_rest": t[4]}
 
 
-def hem(cloud: dict, levels: int, rho=3.0, delta=3.0, kappa=2.5, tau=1.0, threads=0, rng_seed=1, rng_skip=0):
-    """MixtureCreator::CreateMixture on the oracle: list of ``levels`` level dicts (level 0 dropped)."""
+def hem(cloud: dict, levels: int, rho=3.0, delta=3.0, kappa=2.5, tau=1.0, threads=0, rng_seed=1, rng_skip=0, fast_search=False):
+    """MixtureCreator::CreateMixture on the oracle: list of ``levels`` level dicts (level 0 dropped).  ``fast_search``: the same result
+    lists through a finer grid (HemOracle.set_fast_search); stats carry ``fast_search`` = whether a level took it."""
     o = HemOracle(cloud["xyz"], cloud["color"], cloud["cov6"], cloud["opacity"], cloud["sh"], rho, delta, kappa, tau,
                   rng_seed, rng_skip)
+    o.set_fast_search(fast_search)
     out, st = [], []
     for _ in range(levels):
         o.run_level(threads)
-        st.append(o.stats())
+        st.append(dict(o.stats(), fast_search=o.used_fast_search))
         out.append(o.level(o.num_levels - 1))
     o.close()
     return out, st

@@ -15,7 +15,8 @@
 #   pmc_icp                  the same over scripts/prof_icp.py 5000000 2
 #   summary                  scripts/summarize_profiles.py: TAG_kernel_stats.csv, TAG_pmc.json, TAG_pmc_aniso.json, TAG_pmc_icp.json, ... in gpurun_out/TAG/
 #   kstats:N,SHAPE           per-kernel averages of ONE level (rocprofv3 --stats over scripts/prof_hem.py N 1 3 SHAPE)
-#   timeline:N               kernel timeline (durations, idle gaps) of one level (scripts/trace_timeline.py)
+#   timeline:N               kernel timeline (durations, idle gaps) of one level of N splats (scripts/trace_timeline.py)
+#   icp_timeline             kernel timeline of the bench's ICP phase, last repetition (scripts/prof_bench_icp.py)
 #   ladder                   scripts/small_levels.py + scripts/level_ladder.py (small levels, async / sync)
 #   levels:SHAPE             per-kernel table of the three levels of a 5 M cloud (scripts/prof_hem.py 5000000 3 3 SHAPE)
 #   icp                      scripts/prof_bench_icp.py (the ICP phase of the step, per entry)
@@ -73,7 +74,10 @@ for r in sorted(csv.DictReader(open(f)), key=lambda r: -float(r["TotalDurationNs
 PY
               head -45 "$OUT"/kstats_*.txt ;;
     timeline) n=$(args "$step"); ( cd /tmp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$SCRATCH/tl" -- python3 "$ABS/scripts/prof_hem.py" $n 1 3 > "$OUT/timeline.log" 2>&1 )
-              python scripts/trace_timeline.py "$SCRATCH/tl" k_prep > "$OUT/timeline_$n.txt"; tail -40 "$OUT/timeline_$n.txt" | grep -E "window|before" | head -40 ;;
+              # the level's own first kernel is k_keys (its prologue travelled with the level's input): the last level from there on
+              python scripts/trace_timeline.py "$SCRATCH/tl" "gsr::k_keys" > "$OUT/timeline_$n.txt"; tail -40 "$OUT/timeline_$n.txt" | grep -E "window|before" | head -40 ;;
+    icp_timeline) ( cd /tmp; timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$SCRATCH/it" -- python3 "$ABS/scripts/prof_icp.py" 5000000 2 > "$OUT/icp_timeline.log" 2>&1 )
+              python scripts/trace_timeline.py "$SCRATCH/it" "gsr::k_debug_logf" -4 > "$OUT/icp_timeline.txt"; grep -E "window|before" "$OUT/icp_timeline.txt" | head -60 ;;
     ladder)   python scripts/small_levels.py > "$OUT/small_levels.txt" 2>&1; tail -12 "$OUT/small_levels.txt" ;;
     levels)   python scripts/prof_hem.py 5000000 3 3 $(args "$step") 2>&1 | grep -E "rep2 L. " > "$OUT/levels_$(args "$step" | tr ' ' '_').txt"; cut -c1-260 "$OUT"/levels_*.txt ;;
     icp)      python scripts/prof_bench_icp.py > "$OUT/prof_bench_icp.txt" 2>&1; tail -20 "$OUT/prof_bench_icp.txt" ;;
