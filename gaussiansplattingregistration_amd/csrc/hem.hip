@@ -514,9 +514,19 @@ __global__ __launch_bounds__(256) void k_child_stream(int64_t n, int64_t cells, 
 // Morton bits per axis of the ordering key: the curve runs over blocks of (grid / 2^bits)^3 cells, the parents of a block stay in
 // cell order (stable sort).  6 bits: 20-bit keys = two 10-bit Onesweep passes where 10 bits per axis took four (-0.1 ms at 5 M;
 // k_select and k_mstep, which run in this order, measure the same with 6, 7 and 10 bits).
+// The ordering key: [work class : 2 bits][Morton code of the parent's block of cells : kb bits].  Large levels: 6 bits per axis (kb = 18: two
+// Onesweep passes of 10 bits); levels of fewer than ORDER_FINE_FROM parents: 3 bits per axis less the finest x bit (kb = 8) -- the whole key
+// fits ONE Onesweep pass, and on a small level the coarser blocks cost the selection nothing (measured, profiles/r06f_ab_order_key_bits.txt:
+// 556 k level 1.185 -> 1.135 ms, 1.67 M level 2.98 -> 2.94, 5 M level 8.31 -> 8.34: the 5 M level keeps the fine key).
 #ifndef ORDER_AXIS_BITS
 #define ORDER_AXIS_BITS 6
 #endif
+#ifndef ORDER_FINE_FROM
+#define ORDER_FINE_FROM 1000000
+#endif
+__host__ __device__ inline int order_axis_bits(int P) { return P >= ORDER_FINE_FROM ? ORDER_AXIS_BITS : 3; }
+__host__ __device__ inline int order_drop_bits(int P) { return P >= ORDER_FINE_FROM ? 0 : 1; }
+__host__ __device__ inline int order_key_bits(int P) { return 3 * order_axis_bits(P) - order_drop_bits(P); }
 // The work items of the heavy parents (the first *nheavy slots of the processing order): parts of SEL_PART candidates.
 // ONE workgroup: the heavy parents are a few thousand.  hq[0] = number of items, hq[1] = the queue cursor, which starts
 // behind the items the waves of the serving workgroups take without asking (see k_select).
@@ -540,7 +550,7 @@ __global__ __launch_bounds__(1024) void k_heavy_items(int P, const unsigned* __r
     if (threadIdx.x == 0) {
         *part_out = part;
         int lo = 0, hi = P;                       // first key of class 3
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << (3 * ORDER_AXIS_BITS))) hi = mid; else lo = mid + 1; }
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << order_key_bits(P))) hi = mid; else lo = mid + 1; }
         s_nheavy = lo;
         *nheavy_p = lo;
         s_base = 0;
@@ -601,7 +611,8 @@ __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __res
     int gm = g.gx > g.gy ? g.gx : g.gy;
     gm = gm > g.gz ? gm : g.gz;
     int sh = 0;
-    while ((gm >> sh) > (1 << ORDER_AXIS_BITS)) ++sh;
+    const int ab = order_axis_bits(P), db = order_drop_bits(P), kb = order_key_bits(P);
+    while ((gm >> sh) > (1 << ab)) ++sh;
     for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
         const unsigned w = work[p];
         // classes: 0 = >= 64 thr, 1 = >= 8 thr, 2 = >= thr, 3 = light
@@ -610,14 +621,14 @@ __global__ __launch_bounds__(256) void k_heavy_keys(int P, const unsigned* __res
         const unsigned cx = (unsigned)cell_of(a.x, g.ox, g.inv_c, g.gx) >> sh;
         const unsigned cy = (unsigned)cell_of(a.y, g.oy, g.inv_c, g.gy) >> sh;
         const unsigned cz = (unsigned)cell_of(a.z, g.oz, g.inv_c, g.gz) >> sh;
-        keys[p] = (cls << (3 * ORDER_AXIS_BITS)) | spread10(cx) | (spread10(cy) << 1) | (spread10(cz) << 2);
+        keys[p] = (cls << kb) | ((spread10(cx) | (spread10(cy) << 1) | (spread10(cz) << 2)) >> db);
         idx[p] = (unsigned)p;
     }
 }
 
 __global__ void k_count_heavy(int P, const unsigned* __restrict__ sorted_keys, int* __restrict__ out) {
     int lo = 0, hi = P;                       // first key of class 3
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << (3 * ORDER_AXIS_BITS))) hi = mid; else lo = mid + 1; }
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted_keys[mid] >= (3u << order_key_bits(P))) hi = mid; else lo = mid + 1; }
     *out = lo;
 }
 
@@ -2766,12 +2777,21 @@ using sort_cfg = rocprim::radix_sort_config<rocprim::default_config, merge_cfg,
                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<GSR_SORT_BS, GSR_SORT_IPT>, rocprim::kernel_config<GSR_SORT_BS, GSR_SORT_IPT>, GSR_SORT_RADIX_BITS,
                                                                                 rocprim::block_radix_rank_algorithm::match>,
                                             GSR_SORT_MERGE_LIMIT>;
-template <typename V>
+// the ordering sort (parents by work class + block of space, ORDER_KEY_BITS + 2 bits): when its key fits ONE Onesweep pass the merge sort's
+// block sort + log2(n / 8192) merge passes lose from a few ten thousand keys on
+#ifndef GSR_ORDER_MERGE_LIMIT
+#define GSR_ORDER_MERGE_LIMIT 16384
+#endif
+using order_cfg = rocprim::radix_sort_config<rocprim::default_config, merge_cfg,
+                                             rocprim::radix_sort_onesweep_config<rocprim::kernel_config<GSR_SORT_BS, GSR_SORT_IPT>, rocprim::kernel_config<GSR_SORT_BS, GSR_SORT_IPT>, GSR_SORT_RADIX_BITS,
+                                                                                 rocprim::block_radix_rank_algorithm::match>,
+                                             GSR_ORDER_MERGE_LIMIT>;
+template <typename V, typename CFG = sort_cfg>
 int32_t sort_pairs(gsr_hem_ctx* c, const unsigned* kin, unsigned* kout, const V* vin, V* vout, int64_t n, int end_bit) {
     size_t bytes = 0;
-    GSR_HIP(rocprim::radix_sort_pairs<sort_cfg>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
+    GSR_HIP(rocprim::radix_sort_pairs<CFG>(nullptr, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
     GSR_TRY(c->rocprim_tmp.reserve(bytes));
-    GSR_HIP(rocprim::radix_sort_pairs<sort_cfg>(c->rocprim_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
+    GSR_HIP(rocprim::radix_sort_pairs<CFG>(c->rocprim_tmp.p, bytes, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)end_bit, c->stream));
     return GSR_OK;
 }
 
@@ -3812,7 +3832,7 @@ int32_t LevelRun::select_phase() {
             // "heavy" = 16x the mean capacity: k_heavy_keys takes the total from the scan itself
             hipLaunchKernelGGL(k_heavy_keys, dim3(stride_grid(P)), blk, 0, st, P, c->pcap.as<unsigned>(), c->coff.as<int64_t>(), c->plist.as<unsigned>(),
                                c->A.as<float4>(), c->gparams.as<GridParams>(), c->pkeys.as<unsigned>(), c->pidx.as<unsigned>());
-            GSR_TRY(sort_pairs<unsigned>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, 3 * ORDER_AXIS_BITS + 2));
+            GSR_TRY((sort_pairs<unsigned, order_cfg>(c, c->pkeys.as<unsigned>(), c->pkeys2.as<unsigned>(), c->pidx.as<unsigned>(), c->porder.as<unsigned>(), P, order_key_bits(P) + 2)));
             if (!c->split_heavy)
                 hipLaunchKernelGGL(k_count_heavy, dim3(1), dim3(1), 0, st, P, c->pkeys2.as<unsigned>(), cnt + 8);
             sa.porder = c->porder.as<unsigned>();
