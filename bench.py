@@ -787,7 +787,8 @@ def main():
                                    (f"2x{n} splats, clouds one per GPU + ICP source split (BASELINE configs[3])" if a.mode == "c4" else
                                     f"one {n}-splat cloud vs a {min(a.target_splats, n)}-splat target, sharded HEM + split ICP (BASELINE configs[4])"),
                        "mode": a.mode, "splat_shapes": a.workload, "pair": {"angle_deg": PAIR_ANGLE_DEG, "shift_h": PAIR_SHIFT_H}, "hem_params": HEM_PARAMS, "iter_values": ITER_VALUES, "max_corr": MAX_CORR, "level_sizes": last["level_sizes"],
-                       "clouds": (("serial: cloud 1 then cloud 2 on one context and ONE shared rand() stream (a single reference process), ICP set-up inside the ICP phase"
+                       "clouds": (("serial: cloud 1 then cloud 2 on one context and ONE shared rand() stream (a single reference process); each cloud's three levels are one library call "
+                                   "(gsr_hem_run_levels); the target's normals leave with its levels (side stream, inside the HEM phase); index builds and source sorts inside the ICP phase"
                                    if ctxs.get("serial") else
                                    "concurrent: the two clouds' HEM levels side by side on two contexts / streams (each cloud = a fresh reference process: rand() "
                                    "stream at position 0), every target level's normals computed by the target cloud's thread inside the HEM phase")
@@ -817,6 +818,32 @@ def main():
             line["exchange_s_per_step"] = sum(r["exchange_s"] for r in runs) / a.steps
         if "part" in last:
             line["partition_rank0"] = last["part"]
+        if world == 1 and a.mode == "replicas" and a.workload == "iso":
+            # ONE local registration on the full clouds (the LocalRegistrator path, qt_local_registrator.py:26-32: do_icp_registration(pc1, pc2, init,
+            # params) with LocalRegistrationParams' defaults, registration_parameters.py:7-15 -- point-to-point, 30 iterations, 1e-6 / 1e-6) from a start
+            # 0.3 degrees and 0.3 max_corr off the answer: the fine-level search kernel over its whole budget instead of the two iterations the
+            # coarse-to-fine schedule leaves it.  max_correspondence = the schedule's finest (the default, 5.0 scene units, is
+            # the whole scene).  Outside the timed region.
+            try:
+                from gaussiansplattingregistration_amd.models.point_cloud import PointCloud
+                est0 = lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Point, lru.RobustLoss(0))
+                off = synth.rigid_transform(0.3, (0.3, -1.0, 0.5), 0.3 * MAX_CORR[-1] * np.array([0.6, 0.5, -0.62]))
+                s0, t0 = PointCloud(xyz32=src["xyz"]), PointCloud(xyz32=tgt["xyz"])
+                best = None
+                for _ in range(2):
+                    sync(); tw = time.perf_counter()
+                    r1 = lru.registration_icp(s0, t0, MAX_CORR[-1], off @ T_gt, est0, lru.get_convergence_criteria(1e-6, 1e-6, 30), device=device, ctx=ctxs["icp"])
+                    sync(); tw = time.perf_counter() - tw
+                    best = tw if best is None else min(best, tw)
+                per = r1.timing["ms_iters"] / max(1, r1.timing["iter_kernels"])
+                line["icp_single_level_5m"] = {"workload": f"registration_icp on the {n} x {n} level-0 clouds, point-to-point, max_corr {MAX_CORR[-1]}, <= 30 iterations, start 0.3 degrees / "
+                                                           f"{0.3 * MAX_CORR[-1]:.3f} off the ground truth", "iterations": r1.iterations, "evaluations": r1.timing["iter_kernels"],
+                                               "ms_total": best * 1e3, "ms_target_index_build": r1.timing["ms_build"], "ms_iterations": r1.timing["ms_iters"], "ms_per_iteration": per,
+                                               "algorithmic_bytes_per_iteration": 24.0 * n, "achieved_GBps": 24.0 * n / (per * 1e-3) / 1e9 if per else None,
+                                               "frac_of_hbm_peak": 24.0 * n / (per * 1e-3) / 1e9 / HBM_PEAK_GBS if per else None,
+                                               "fitness": r1.fitness, "inlier_rmse": r1.inlier_rmse, "T_err_vs_ground_truth_F": float(np.linalg.norm(r1.transformation - T_gt))}
+            except Exception as e:  # pragma: no cover
+                line["icp_single_level_5m"] = {"error": str(e)[:200]}
         if world == 1 and a.mode == "replicas" and a.workload == "iso" and not a.no_aniso:
             # the same level on the surfel workload (real 3DGS splats are flat discs and needles, far outside the condition numbers of the
             # isotropic recipe): one 5 M-splat cloud, level 1, beside the isotropic level above

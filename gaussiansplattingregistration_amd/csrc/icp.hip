@@ -52,11 +52,15 @@ using icp_sort_cfg = rocprim::radix_sort_config<rocprim::default_config, icp_mer
                                                 rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 16>, rocprim::kernel_config<1024, 16>, 11,
                                                                                     rocprim::block_radix_rank_algorithm::match>>;
 
+#ifndef ICP_CELL_FLOOR_DIV
+#define ICP_CELL_FLOOR_DIV 64.0     // a grid cell is never finer than max_corr / this (bounds the rings of a query that finds nothing)
+#endif
 struct IcpGrid {
     double ox, oy, oz, inv_c, c;
     double cx, cy, cz;     // centre used to condition the point-to-point sums
     int gx, gy, gz, ncells;
     int rings;             // ceil(max_corr / c): cells beyond this Chebyshev ring cannot hold an accepted neighbour
+    double bx0, by0, bz0, bx1, by1, bz1;      // box of ALL finite target points (the grid may lie over a trimmed one): a query farther from it than max_corr has no neighbour
 };
 
 __device__ __forceinline__ int icp_cell(double v, double o, double inv_c, int g) {
@@ -304,6 +308,12 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
     unsigned best_i = 0xffffffffu;
     double bd = bound2;
     if (!(px == px) || !(py == py) || !(pz == pz)) { best_d2 = 1.0 / 0.0; return -1; }
+    {   // a query farther from the box of all target points than the caller's bound has nothing to find: no ring is walked (with a cell of two
+        // points and a correspondence distance of many cells -- the reference's default max_correspondence is 5 scene units,
+        // registration_parameters.py:9 -- a floater of the source would walk (2 rings + 1)^3 cells and hold up its wave)
+        const double ex = fmax(fmax(g.bx0 - px, px - g.bx1), 0.0), ey = fmax(fmax(g.by0 - py, py - g.by1), 0.0), ez = fmax(fmax(g.bz0 - pz, pz - g.bz1), 0.0);
+        if ((ex * ex + ey * ey + ez * ez) * 0.999999999 >= bound2) { best_d2 = bound2; return -1; }
+    }
     const int cx = icp_cell(px, g.ox, g.inv_c, g.gx), cy = icp_cell(py, g.oy, g.inv_c, g.gy), cz = icp_cell(pz, g.oz, g.inv_c, g.gz);
     // absolute slack of every geometric bound: ~500 ulp of the largest coordinate involved
     const double eps = 1e-13 * (fabs(px) + fabs(py) + fabs(pz) + fabs(g.ox) + fabs(g.oy) + fabs(g.oz) + g.c * (double)(g.gx + g.gy + g.gz));
@@ -1832,6 +1842,7 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
     hipLaunchKernelGGL(k_icp_trim, dim3(1), dim3(64), 0, st, c->hist.as<unsigned>(), c->bbox.as<float>(), c->bbox.as<float>() + 6, c->bbox.as<float>() + 12);
     float hb[13];
     GSR_TRY(icp_fetch(c, c->bbox.p, hb, 13 * 4));
+    const float raw_box[6] = {hb[0], hb[1], hb[2], hb[3], hb[4], hb[5]};
     c->robust_box = hb[12] != 0.0f && c->robust_allowed;
     if (c->robust_box) {        // far outliers: one refinement at the resolution of the trimmed range, then the grid goes over THAT
         GSR_HIP(hipMemsetAsync(c->hist.p, 0, 3 * ICP_HIST_BINS * 4, st));
@@ -1850,7 +1861,10 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
         const double emax = fmax(ex, fmax(ey, ez)), eps = emax * 1e-6 + 1e-30;
         cell = cbrt((ex + eps) * (ey + eps) * (ez + eps) * c->cell_target / (double)n);
         if (!(cell > 0)) cell = max_corr;
-        if (cell < max_corr / 8.0) cell = max_corr / 8.0;
+        // (round 6: max_corr / 64, was / 8.  The floor bounds the ring count of a query that finds nothing; with / 8 the reference's DEFAULT
+        // max_correspondence of 5 scene units put 450 points into every cell of a 1 M-splat cloud and an iteration took 4.9 ms instead of
+        // 0.15, scripts/icp_default_params.py.  A query beyond the target's box + max_corr leaves before the first ring, icp_nearest)
+        if (cell < max_corr / ICP_CELL_FLOOR_DIV) cell = max_corr / ICP_CELL_FLOOR_DIV;
     }
     GSR_TRY(c->keys.reserve(n * 4)); GSR_TRY(c->idx.reserve(n * 4)); GSR_TRY(c->skeys.reserve(n * 4)); GSR_TRY(c->order.reserve(n * 4));
     c->occupancy = 0.0;
@@ -1866,6 +1880,8 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
         g.ncells = g.gx * g.gy * g.gz;
         g.rings = (int)ceil(max_corr / cell);
         if (g.rings < 1) g.rings = 1;
+        g.bx0 = raw_box[0]; g.by0 = raw_box[1]; g.bz0 = raw_box[2]; g.bx1 = raw_box[3]; g.by1 = raw_box[4]; g.bz1 = raw_box[5];
+        if (!(raw_box[3] >= raw_box[0])) { g.bx0 = g.by0 = g.bz0 = -1.0 / 0.0; g.bx1 = g.by1 = g.bz1 = 1.0 / 0.0; }      // (no finite point: no box, no early leave)
         hipLaunchKernelGGL(k_icp_keys, dim3(stride_grid(n)), dim3(256), 0, st, n, dxyz, g, c->keys.as<unsigned>(), c->idx.as<unsigned>());
         int bits = 1;
         while (bits < 32 && ((int64_t)1 << bits) < g.ncells) ++bits;
@@ -1886,7 +1902,7 @@ int32_t gsr_icp_set_target(gsr_icp_ctx* c, const float* xyz, const double* norma
         unsigned long long sumsq = 0;
         GSR_TRY(icp_fetch(c, c->hist.p, &sumsq, 8));
         c->occupancy = (double)sumsq / (double)n;
-        const double floor_cell = max_corr / 8.0;
+        const double floor_cell = max_corr / ICP_CELL_FLOOR_DIV;
         if (!(c->occupancy > 12.0) || cell <= floor_cell * 1.0001 || (double)g.ncells * 1.9 > (double)c->max_cells) break;
         double f = cbrt(4.0 / c->occupancy);
         f = f < 0.4 ? 0.4 : f;
