@@ -433,6 +433,32 @@ def test_all_levels_in_one_call_equal_the_level_by_level_path(shape):
             m.run_levels(1, arena=m.new_arena(m.size - 1))
 
 
+def test_all_levels_in_one_call_edge_cases():
+    """gsr_hem_run_levels on the cases the level-by-level entry handles: no SH block (F = 0), a hierarchy without parents (rho = 1e9: every level
+    returns its input, mixture.cpp:250-253), rho = 1 (every component a parent), zero levels, a tiny cloud -- each equal to run_level per level."""
+    from gaussiansplattingregistration_amd import hem, synth
+    cases = [("F=0", dict(n=5000, sh_degree=0), dict()), ("no parents", dict(n=3000, sh_degree=1), dict(hem_reduction=1e9)),
+             ("all parents", dict(n=3000, sh_degree=1), dict(hem_reduction=1.0)), ("tiny", dict(n=7, sh_degree=1), dict())]
+    for tag, ck, hk in cases:
+        c = synth.make_cloud(ck["n"], seed=23, sh_degree=ck["sh_degree"], h=0.5)
+        with hem.HemMixture(**hk) as m:
+            ref, rst = _levels_on_one_context(m, c, 3, False)
+        with hem.HemMixture(**hk) as m:
+            m.set_rng("glibc", 1, 0)
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+            lv0, st0 = m.run_levels(0)
+            assert lv0 == [] and st0 == [] and m.size == ck["n"], tag
+            levels, st = m.run_levels(3, arena=m.new_arena(3 * ck["n"] + 256, normals=True))
+            for k in range(3):
+                assert st[k]["n_out"] == rst[k]["n_out"] and st[k]["rng_draws"] == rst[k]["rng_draws"], (tag, k)
+                for f in ("xyz", "color", "cov6", "sh", "opacity"):
+                    assert np.array_equal(levels[k][f].cpu().numpy().view(np.uint8), ref[k][f].view(np.uint8)), (tag, k, f)
+                assert levels[k]["normals"].shape == (st[k]["n_out"], 3) and bool(torch.isfinite(levels[k]["normals"]).all()), (tag, k)
+            got = m.get_level(with_state=True)
+            for f in ("weight", "is_parent"):
+                assert np.array_equal(np.asarray(got[f]).view(np.uint8), ref[2][f].view(np.uint8)), (tag, f)
+
+
 def test_asynchronous_level_on_buffers_too_small_reruns_synchronously():
     """An asynchronous level runs on the buffers the context has; a level that needs more (here: a context warmed on a small cloud, then a
     cloud eight times as large) finds that out ON THE DEVICE -- clamped writes, an abort flag in its one answer -- and is run again the
