@@ -545,18 +545,21 @@ def main():
         # sorts the 40 M splats); the target is a sub-sample of the same scene -- the first rows of every block, gathered ONCE onto
         # every rank (set-up, outside the timed region) -- moved by T_gt
         src, owned = synth.make_block_cloud_torch(n, rank, world, seed=seed, device=dev)
-        # the pair's motion in ABSOLUTE terms is the 2 x 5 M pair's (5 degrees and 0.05 h there): at 40 M the scene is twice as wide, and 5
-        # degrees about its centre would move the corners by four correspondence distances -- nearest-neighbour ICP cannot start from there
-        # (measured at full size, profiles/r05a_bench_c5_40m_8ranks_one_gpu.json: fitness 0.59, T_err 0.76)
+        # The c5 schedule (what runs, stated once).  Two scalings, both recorded in the line's config ("pair", "max_corr", "c5_scaling"):
+        #   rel        the pair's motion relative to the 2 x 5 M pair's, so that the ratio of displacement to correspondence distance stays that pair's:
+        #              a scene twice as wide (40 M) moved by the same 5 degrees displaces its corners twice as far (alone: rel = 0.5; measured at full
+        #              size without it, profiles/r05a_bench_c5_40m_8ranks_one_gpu.json: fitness 0.59, T_err 0.76) ...
+        #   corr_scale ... but the target is a SUB-SAMPLE of the scene, (n / nt)^(1/3) times the point spacing the schedule's correspondence distances
+        #              were chosen for, so those grow by that factor and the motion with them: at 40 M against 5 M both factors are 2 and cancel --
+        #              the pair moves by the full 5 degrees / 0.05 h with DOUBLED correspondence distances.  Lines of this mode are therefore not
+        #              comparable with round 4's (fixed 0.5 ... 0.1).  (main() rebinds the module's MAX_CORR / PAIR_* for this process only.)
         rel = min(1.0, synth.half_extent(5_000_000) / src["h"])
         nt = min(a.target_splats, n)
-        # ... and the target is a SUB-SAMPLE of the scene: (n / nt)^(1/3) times the point spacing the schedule's correspondence distances were
-        # chosen for (a 5 M target in the volume of a 40 M scene: twice the spacing).  They scale with it, and the pair's motion with them
-        # -- the same ratio of displacement to max_corr as on the 2 x 5 M pair (without it: fitness 0.61, T_err 0.22 at full size)
         global MAX_CORR
         corr_scale = (n / nt) ** (1.0 / 3.0)
         MAX_CORR = [m_ * corr_scale for m_ in MAX_CORR]
         rel = min(1.0, rel * corr_scale)
+        c5_scaling = {"corr_scale": corr_scale, "motion_rel": rel}
         PAIR_ANGLE_DEG, PAIR_SHIFT_H = PAIR_ANGLE_DEG * rel, PAIR_SHIFT_H * rel
         T_gt = synth.rigid_transform(PAIR_ANGLE_DEG, (1, 1, 1), PAIR_SHIFT_H * src["h"] * np.array([1.0, -1.0, 0.5]))
         fields = ("xyz", "color", "opacity", "cov6", "sh")
@@ -810,6 +813,8 @@ def main():
                                       "schedule": k.get("schedule"), "dropped": k["dropped"]} for k in last["kern"]],
             "roofline": roof,
         }
+        if a.mode == "c5":
+            line["config"]["c5_scaling"] = c5_scaling
         if strong is not None:
             line["strong"] = strong
         if comm is not None:
