@@ -485,8 +485,8 @@ def main():
     global PAIR_ANGLE_DEG, PAIR_SHIFT_H
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)       # (the first step grows the contexts' buffers: 48 ms; the second is within 2 % of the steady state, scripts/steps_probe.py)
     ap.add_argument("--splats", "--n", dest="n", type=int, default=None, help="splats per cloud (c5: of the LARGE cloud); use --splats under torchrun")
     ap.add_argument("--target-splats", type=int, default=5_000_000, help="c5: splats of the target cloud")
     ap.add_argument("--mode", choices=["replicas", "c4", "c5"], default="replicas")
