@@ -1,0 +1,83 @@
+"""The digest machinery of the 5 M-splat fixture (tests/digest5m.py) on a small level: it must accept what differs by float32 summation
+order and catch what the GPU test is there to catch -- a wrong count, one flipped parent flag, ONE wrong row anywhere in the level (the
+per-block column sums cover the rows the sample skips), a sampled row off by more than 1e-4 of its own scale in any array.  CPU only."""
+import numpy as np
+import pytest
+
+import digest5m
+
+
+@pytest.fixture(scope="module")
+def level(oracle):
+    from gaussiansplattingregistration_amd import synth
+    c = synth.make_cloud(40000, seed=4, sh_degree=3)
+    lv, st = oracle.hem(c, 1)
+    o = oracle.HemOracle(c["xyz"], c["color"], c["cov6"], c["opacity"], c["sh"])
+    o.run_level()
+    full = o.level(1)
+    o.close()
+    return full, st[0]
+
+
+def _copy(lv):
+    return {k: v.copy() for k, v in lv.items()}
+
+
+def test_digest_accepts_rounding_and_catches_errors(level):
+    lv, st = level
+    want = digest5m.digest(lv, st)
+    assert digest5m.compare(digest5m.digest(lv, st, idx=want["sample_idx"]), want) == []
+    # float32 noise of a different summation order: accepted
+    rng = np.random.default_rng(0)
+    noisy = _copy(lv)
+    for f in ("xyz", "color", "cov6", "opacity", "sh", "weight"):
+        noisy[f] = (noisy[f].astype(np.float64) * (1.0 + rng.normal(0, 2e-7, noisy[f].shape))).astype(np.float32)
+    assert digest5m.compare(digest5m.digest(noisy, st, idx=want["sample_idx"]), want) == []
+    n = lv["xyz"].shape[0]
+    sampled = set(want["sample_idx"].tolist())
+    unsampled = next(i for i in range(n // 2, n) if i not in sampled)
+    # a wrong count
+    bad_st = dict(st, pairs=st["pairs"] + 1)
+    assert any("pairs" in b for b in digest5m.compare(digest5m.digest(lv, bad_st, idx=want["sample_idx"]), want))
+    # one flipped parent flag, anywhere
+    flip = _copy(lv); flip["is_parent"][unsampled] ^= 1
+    assert any("flags" in b for b in digest5m.compare(digest5m.digest(flip, st, idx=want["sample_idx"]), want))
+    # ONE row the sample does not hold takes another row's SH block (a mis-indexed row): the block sums see it
+    wrong = _copy(lv); wrong["sh"][unsampled] = lv["sh"][(unsampled + 7) % n]
+    assert any("block sums" in b for b in digest5m.compare(digest5m.digest(wrong, st, idx=want["sample_idx"]), want))
+    # a sampled row off by 3e-4 of its own scale in one array -- colour, opacity, a covariance off-diagonal, an SH entry, the weight
+    i = int(want["sample_idx"][len(sampled) // 3])
+    for f, col in (("color", 1), ("opacity", None), ("cov6", 1), ("sh", 17), ("weight", None), ("xyz", 2)):
+        off = _copy(lv)
+        a = off[f]
+        if f == "cov6":
+            a[i, col] += 3e-4 * (lv["cov6"][i, 0] + lv["cov6"][i, 3] + lv["cov6"][i, 5])
+        elif f == "xyz":
+            a[i, col] += 3e-4 * np.sqrt(lv["cov6"][i, 0] + lv["cov6"][i, 3] + lv["cov6"][i, 5])
+        elif col is None:
+            a[i] += 3e-4 * max(abs(a[i]), 0.05 * float(np.sqrt((lv[f].astype(np.float64) ** 2).mean())))
+        else:
+            a[i, col] += 3e-4 * max(np.abs(lv[f][i]).max(), 0.05 * float(np.sqrt((lv[f].astype(np.float64) ** 2).mean())))
+        bad = digest5m.compare(digest5m.digest(off, st, idx=want["sample_idx"]), want)
+        assert any("sampled row" in b for b in bad), (f, bad)
+
+
+def test_fixture_is_self_consistent():
+    """tests/golden/hem_5m_digest.npz: the counters, the sample and the blocks describe one level."""
+    import json
+    import os
+    from conftest import GOLDEN
+    d = dict(np.load(os.path.join(GOLDEN, "hem_5m_digest.npz")))
+    n = int(d["n_out"])
+    assert n == int(d["parents"]) + int(d["orphans"]) - int(d["dropped"]) == 1668351 and int(d["pairs"]) == 109092251
+    assert d["flags_packed"].size == (n + 7) // 8 and d["block_sum"].shape == ((n + digest5m.BLOCK - 1) // digest5m.BLOCK, 3 + 3 + 6 + 1 + 45 + 1)
+    assert d["sample_idx"].size == digest5m.SAMPLE_ROWS and np.all(np.diff(d["sample_idx"]) > 0) and int(d["sample_idx"][-1]) < n
+    assert np.array_equal(d["sample_idx"], digest5m.sample_index(n))
+    # the sampled rows' flags are the packed flags' bits; the global weight is the blocks' weight column summed
+    bits = np.unpackbits(d["flags_packed"])[:n]
+    assert 0.30 < bits.mean() < 0.37
+    assert abs(d["block_sum"][:, -1].sum() - float(d["g_W"])) <= 1e-9 * float(d["g_W"])
+    assert int(d["draws"]) == 5_000_000 + n + int(d["dropped"])
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    assert meta["check"]["n_out"] == 333657 and meta["check"]["bit_equal_arrays"] == ["xyz", "color", "opacity", "cov6", "sh"]
+    assert [l["n_out"] for l in meta["levels"]] == [n, int(d["l2_n_out"]), int(d["l3_n_out"])] and all(l["fast_search"] for l in meta["levels"])
