@@ -29,6 +29,33 @@ def rel(a, b):
     return float(np.max(np.abs(a[fa] - b[fb])) / (np.max(np.abs(b[fb])) + 1e-30))
 
 
+def unmatched_rows_near_singular(got, want, lim=1e-3):
+    """The validity erase (det <= 0 of a MERGED covariance in float32, mixture.cpp:262-274) dropped different rows on the two sides.  Match the rows of the
+    two levels on their positions (nearest neighbour within 1e-4 of the scene's extent); -> (rows only in `got`, rows only in `want`, all of them
+    NEAR-SINGULAR): |det| in float64 of the float32 entries below `lim` x the product of the diagonal -- a determinant that is cancellation noise in
+    float32, whose sign follows the summation order of the M-step -- or not finite.  Rows with non-finite positions must be equally many."""
+    from scipy.spatial import cKDTree
+    gx, wx = np.asarray(got["xyz"], np.float64), np.asarray(want["xyz"], np.float64)
+    fg, fw = np.isfinite(gx).all(1), np.isfinite(wx).all(1)
+    if int((~fg).sum()) != int((~fw).sum()):
+        return int((~fg).sum()), int((~fw).sum()), False
+    ig, iw = np.where(fg)[0], np.where(fw)[0]
+    if len(ig) == 0 or len(iw) == 0:
+        return len(ig), len(iw), False
+    scale = np.abs(wx[iw]).max() + 1e-30
+    dg, _ = cKDTree(wx[iw]).query(gx[ig], k=1)
+    dw, _ = cKDTree(gx[ig]).query(wx[iw], k=1)
+    only_g, only_w = ig[dg > 1e-4 * scale], iw[dw > 1e-4 * scale]
+
+    def near_singular(c6):
+        c = np.asarray(c6, np.float64).reshape(-1, 6)
+        det = (-c[:, 2] * c[:, 2] * c[:, 3] + 2 * c[:, 1] * c[:, 2] * c[:, 4] - c[:, 0] * c[:, 4] * c[:, 4] - c[:, 1] * c[:, 1] * c[:, 5] + c[:, 0] * c[:, 3] * c[:, 5])
+        ref = np.abs(c[:, 0] * c[:, 3] * c[:, 5])
+        return ~np.isfinite(det) | ~np.isfinite(ref) | (np.abs(det) <= lim * ref)
+    ok = bool(near_singular(np.asarray(got["cov6"])[only_g]).all()) and bool(near_singular(np.asarray(want["cov6"])[only_w]).all())
+    return len(only_g), len(only_w), ok
+
+
 def make_case(rng, pathologies=None):
     if pathologies is None:
         pathologies = bool(os.environ.get("STRESS_PATHOLOGIES"))
@@ -91,6 +118,13 @@ def sweep(cases=40, seed=2026, log=print, pathologies=None):
         ok = a == b and err < TOL
         lim = 8 if pathologies else 2     # (merges with a 1e8-scaled needle: the determinant is cancellation noise)
         edge_case = (not ok) and a[:3] == b[:3] and abs(a[3] - b[3]) <= lim and abs(a[4] - b[4]) <= lim
+        if (not ok) and (not edge_case) and a[:3] == b[:3]:
+            # more rows than that (round 6, seed 607 case 178: 3 582 needles, rho 2, delta 4 and thirty 1e8-scaled covariances -- every parent merges ~240
+            # children and a sixth of the merges swallow a giant: 299 against 341 rows dropped): the same class iff EVERY row that one side kept and the
+            # other dropped is near-singular (its float32 determinant is cancellation noise)
+            ng, nw, singular = unmatched_rows_near_singular(got, want[0])
+            edge_case = singular and (ng + nw) > 0
+            desc = dict(desc, unmatched=(ng, nw), all_near_singular=singular)
         edge += 1 if edge_case else 0
         bad += 0 if (ok or edge_case) else 1
         log(f"{'ok  ' if ok else ('edge' if edge_case else 'FAIL')} {k:3d} {desc}  gpu {a}  oracle {b}  irregular {st['irregular']}  max rel {err:.2e}")
