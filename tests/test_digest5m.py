@@ -81,3 +81,7 @@ def test_fixture_is_self_consistent():
     meta = json.loads(bytes(d["meta_json"]).decode())
     assert meta["check"]["n_out"] == 333657 and meta["check"]["bit_equal_arrays"] == ["xyz", "color", "opacity", "cov6", "sh"]
     assert [l["n_out"] for l in meta["levels"]] == [n, int(d["l2_n_out"]), int(d["l3_n_out"])] and all(l["fast_search"] for l in meta["levels"])
+    # ... and the reference's own compiled extension, run once on the 5 M cloud in the build container (make_golden_5m.py --ref-5m), returned the level the
+    # digest was taken from, bit for bit in all five exported arrays
+    chk = json.load(open(os.path.join(GOLDEN, "hem_5m_ref_check.json")))
+    assert chk["n"] == 5_000_000 and chk["n_out_reference"] == chk["n_out_oracle"] == n and all(chk["bit_equal"][f] for f in ("xyz", "color", "opacity", "cov6", "sh"))
