@@ -471,8 +471,8 @@ def cpu_baseline(gpu_level1_rate, gpu_icp_coarse):
     # the bench's OWN size on the reference, measured once by hand (it takes 36 minutes on 256 cores: scripts/cpu_reference_5m.py) and
     # kept under profiles/ -- quoted here as what it is, not re-measured in this run
     try:
-        ref5 = json.load(open(os.path.join(ROOT, "profiles", "r04_cpu_reference_5m.json")))
-        res["reference_5m_measured_offline"] = {"source": "profiles/r04_cpu_reference_5m.json (scripts/cpu_reference_5m.py, not part of this run)",
+        ref5 = json.load(open(os.path.join(ROOT, "profiles", "archive", "r04_cpu_reference_5m.json")))
+        res["reference_5m_measured_offline"] = {"source": "profiles/archive/r04_cpu_reference_5m.json (scripts/cpu_reference_5m.py, not part of this run)",
                                                 "cores": ref5["cores"], "reference_wall_s_one_level": ref5["reference_wall_s"],
                                                 "gpu_level_s_same_cloud": ref5["gpu_level_s"], "speedup_like_for_like": ref5["speedup_like_for_like"],
                                                 "level_sizes_equal": ref5["level_sizes_equal"]}
@@ -498,7 +498,7 @@ def main():
     ap.add_argument("--no-aniso", action="store_true", help="skip the anisotropic and clustered side measurements of the default run")
     ap.add_argument("--concurrent-clouds", action="store_true", help="replica mode: the two clouds' HEM levels side by side on two contexts / streams / host "
                     "threads (each cloud's rand() stream at position 0) and the target levels' normals computed in that phase, instead of cloud 1 then "
-                    "cloud 2 on ONE context and one shared rand() stream (the default: what a single reference process does).  Measured (profiles/r04c_*, "
+                    "cloud 2 on ONE context and one shared rand() stream (the default: what a single reference process does).  Measured (profiles/archive/r04c_*, "
                     "r04d_*): the HEM levels alone overlap to 27.0 instead of 28.9 ms in a bare harness, but the full step does not gain (37.7 - 43 ms "
                     "against 39.0): the two clouds' big kernels each fill the chip, and two Python threads add jitter")
     ap.add_argument("--no-strong", action="store_true", help="--gpus N > 1, replica mode: skip the strong-scaling children (c5, and c4 at N = 2)")
@@ -600,7 +600,7 @@ def main():
 
     if a.mode == "replicas" and a.concurrent_clouds:
         # two HEM contexts on two streams (the two clouds side by side); the target cloud's thread also computes every level's normals.
-        # (Measured and not kept, profiles/r04c_*: one ICP context per schedule entry with its target index built in that thread too --
+        # (Measured and not kept, profiles/archive/r04c_*: one ICP context per schedule entry with its target index built in that thread too --
         # the step fell from 38.97 to 37.7 ms, but the ICP iterations on the early-built indices ran 6-20 % slower and the HEM phase, with
         # the index builds inside it, rose from 29.4 to 32.5 ms: the headline rate fell by 9 %.)
         sa_, sb_ = torch.cuda.Stream(dev), torch.cuda.Stream(dev)

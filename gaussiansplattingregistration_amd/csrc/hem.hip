@@ -2755,7 +2755,7 @@ int32_t exclusive_scan(gsr_hem_ctx* c, const T* in, T* out, int64_t n, bool side
 #endif
 // GSR_SORT_MERGE_LIMIT: up to this many keys rocPRIM sorts by block sort + merge passes (~20 launches at 5 * 10^5 keys), beyond it by Onesweep
 #ifndef GSR_SORT_MERGE_LIMIT
-#define GSR_SORT_MERGE_LIMIT (256 * 1024)      // measured on the bench levels (profiles/r04i): 1 M -> 256 k takes 0.05 ms off the 1.67 M level (its 556 k parents) and 0.04 off the 556 k level; 128 k, 32 k: the same
+#define GSR_SORT_MERGE_LIMIT (256 * 1024)      // measured on the bench levels (profiles/archive/r04i): 1 M -> 256 k takes 0.05 ms off the 1.67 M level (its 556 k parents) and 0.04 off the 556 k level; 128 k, 32 k: the same
 #endif
 #ifndef GSR_SORT_BS
 #define GSR_SORT_BS 1024

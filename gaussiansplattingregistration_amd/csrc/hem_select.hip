@@ -172,7 +172,7 @@ __global__ __launch_bounds__(256) void k_parent_prep(int P, const unsigned* __re
 // (Tried on the way to four parents per wave: the scan only FILLING a 512-entry ring, suspended when it is full and resumed through
 // the work items' [lo, hi) mechanism, the drain behind it -- it kept stage 2's registers out of the scan's when the kernel held 96
 // VGPRs.  With the parent record in scalar registers both forms need 65, and this one is 5 % faster: no suspended scans (6 % of the
-// parents recomputed a batch of row spans), half the ring.  profiles/r04o_*.)
+// parents recomputed a batch of row spans), half the ring.  profiles/archive/r04o_*.)
 template <int MODE, bool IRR>
 __device__ __forceinline__ void select_scan(const SelectArgs& a, const GridParams& g, const ParentRec& pr, const ParLds* par, unsigned ktag,
                                             const float (&vc)[11], int lane, unsigned long long* bits, unsigned* q, int& qh, int& qn, unsigned& count_v,
@@ -330,7 +330,7 @@ __device__ __forceinline__ void select_parent(const SelectArgs& a, const GridPar
     // The record lives in SGPRs.  As inline assembly: this body runs in a loop behind the wave's own stores (pcnt, the pairs), the
     // compiler cannot tell that they leave prec[] alone, and a load that "may be clobbered" is not made a scalar load however uniform
     // its address -- it became ten global_load_dwordx4 with 64 lanes reading the same 160 bytes, and 40 v_readfirstlane behind them
-    // (SQ_INSTS_VMEM_RD +16 M per 5 M level, profiles/r04o_*).
+    // (SQ_INSTS_VMEM_RD +16 M per 5 M level, profiles/archive/r04o_*).
     ParentRec pr;
     {
         typedef unsigned u16v __attribute__((ext_vector_type(16)));

@@ -346,7 +346,7 @@ __device__ __forceinline__ int icp_nearest(const IcpGrid& g, const int* __restri
             // ICP_ROW_BATCH points per round trip; the slots behind the row's end re-read its last point.  (A row of three cells holds
             // ~6 points at two per cell, so four per batch are two dependent round trips per row -- and yet 2, 3 and 4 per batch measure
             // the same, 6 per batch +3 % and 8 per batch +15-35 % on the coarse levels: the registers cost more waves than the shorter
-            // chain buys, profiles/r04q_icp_row_batch_ab.txt.)
+            // chain buys, profiles/archive/r04q_icp_row_batch_ab.txt.)
             for (int j = rs[t]; j < re[t]; j += ICP_ROW_BATCH) {
                 const int l = re[t] - 1;
                 int jj[ICP_ROW_BATCH];
@@ -480,7 +480,7 @@ __global__ __launch_bounds__(256) void k_icp_nn(int64_t ns, const float* __restr
 // The search of a FINE level (rings == 1: the correspondence distance is at most one cell, so the 27 cells around the query's hold every
 // neighbour that can be accepted) over an LDS-staged tile.  k_icp_nn walks the grid per thread: 27 cell spans, two dependent table
 // look-ups and a chain of point loads each, every lane with its own trip counts -- 24 % of the lanes at work, ~3 000 issue slots per
-// query (profiles/r04t_pmc_icp.json).  The source is sorted by the target's cells, so the 256 queries of a workgroup sit in a run of
+// query (profiles/archive/r04t_pmc_icp.json).  The source is sorted by the target's cells, so the 256 queries of a workgroup sit in a run of
 // consecutive cells: ONE box of cells [xlo, xhi] x [ylo, yhi] x [zlo, zhi] around their cells (+ 1 ring) holds all their candidates.
 // Its rows are contiguous runs of the cell-sorted target: the workgroup copies them into LDS with coalesced loads (and the rows' cell
 // table with them), and every lane then scans its 3 x 3 spans of three cells from LDS.  Same candidates, same float64 distance, same

@@ -10,7 +10,7 @@ Run in the BUILD CONTAINER (CPU only; needs /root/reference for `make -C oracle 
                                                          #   bit for bit with the oracle's level 1 -> tests/golden/hem_5m_ref_check.json
 
 How the 5 M level is computed.  The reference's grid cell is the LARGEST parent radius (mixture.cpp:92-99): at 5 M a cell holds ~60 000
-points and a parent scans 1.6 M for the ~200 it keeps (2 141 s on 256 cores, profiles/r04_cpu_reference_5m.json -- whose output was not
+points and a parent scans 1.6 M for the ~200 it keeps (2 141 s on 256 cores, profiles/archive/r04_cpu_reference_5m.json -- whose output was not
 kept).  oracle/hem_oracle.cpp -- bit-equal to the reference's compiled extension on every golden vector and live
 (tests/test_oracle_vs_ref.py) -- has a second search that returns the SAME list for every parent (same members, same order: members of
 the 27 reference cells with sqdist < R*R, ordered by scan position of their cell, then by position in the reference's sorted array),

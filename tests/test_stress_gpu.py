@@ -1,5 +1,5 @@
 """A fixed-seed slice of every randomised sweep (tests/stress_*.py) under `-m gpu`, so that the driver's GPU tier sees them
-(VERDICT r03 "what's weak" 3).  The full sweeps are run through gpurun and their logs are kept under profiles/r04_stress_*.txt (round 5, after the M-step and orphan-copy changes: r05_stress_*.txt).
+(VERDICT r03 "what's weak" 3).  The full sweeps are run through gpurun and their logs are kept under profiles/archive/r04_stress_*.txt (round 5, after the M-step and orphan-copy changes: r05_stress_*.txt).
 
 Outcome classes: `ok` = discrete outcomes EQUAL to the oracle and values within 1e-4; `edge` = exactly the one documented class --
 parents, accepted pairs and orphans equal, the validity erase of a near-singular MERGED covariance (det <= 0 of a float32 sum,
