@@ -26,8 +26,8 @@ def input_hash(cloud):
     return h.hexdigest()
 
 
-def sample_index(n_out, seed=2024):
-    return np.sort(np.random.default_rng(seed).choice(n_out, size=min(SAMPLE_ROWS, n_out), replace=False))
+def sample_index(n_out, seed=2024, rows=SAMPLE_ROWS):
+    return np.sort(np.random.default_rng(seed).choice(n_out, size=min(rows, n_out), replace=False))
 
 
 def _cols(lv):

@@ -72,14 +72,23 @@ def main():
     ap.add_argument("--skip-check", action="store_true")
     ap.add_argument("--ref-5m", action="store_true")
     ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
-    ap.add_argument("--out", default=os.path.join(HERE, "hem_5m_digest.npz"))
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--shape", default="iso", choices=["iso", "aniso", "clustered"], help="synth.make_cloud shape; the isotropic cloud (seed 0) is the bench's, "
+                    "the surfel cloud (seed 12) the 1 M test's recipe at 5 M: hem_5m_aniso_digest.npz")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--sample-rows", type=int, default=digest5m.SAMPLE_ROWS)
     a = ap.parse_args()
+    if a.seed is None:
+        a.seed = 0 if a.shape == "iso" else 12
+    if a.out is None:
+        a.out = os.path.join(HERE, "hem_5m_digest.npz" if a.shape == "iso" else f"hem_5m_{a.shape}_digest.npz")
+    make = (lambda n: synth.make_cloud(n, seed=a.seed)) if a.shape == "iso" else (lambda n: synth.make_cloud(n, seed=a.seed, shape=a.shape))
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle"), "oracle", "ref"], stdout=subprocess.DEVNULL)
     meta = {"numpy": np.__version__, "params": PARAMS, "generator": "tests/golden/make_golden_5m.py",
-            "cloud": f"synth.make_cloud({a.n}, seed=0)", "threads": a.threads}
+            "cloud": f"synth.make_cloud({a.n}, seed={a.seed}" + ("" if a.shape == "iso" else f", shape='{a.shape}'") + ")", "threads": a.threads}
 
     if not a.skip_check:
-        c1 = synth.make_cloud(a.check_n, seed=0)
+        c1 = make(a.check_n)
         print(f"step 1: oracle (fast search) against oracle/_ref at {a.check_n} splats", flush=True)
         ref, ref_s = run_ref(c1, a.threads)
         got = run_oracle(c1, 1, a.threads, fast=True)
@@ -92,9 +101,9 @@ def main():
         del c1, ref, got
 
     print(f"step 2: the {a.n}-splat cloud", flush=True)
-    cloud = synth.make_cloud(a.n, seed=0)
+    cloud = make(a.n)
     lv = run_oracle(cloud, 3, a.threads, fast=True)
-    d = digest5m.digest(lv[0][0], lv[0][1])
+    d = digest5m.digest(lv[0][0], lv[0][1], idx=digest5m.sample_index(lv[0][0]['xyz'].shape[0], rows=a.sample_rows))
     d["input_sha256"] = np.frombuffer(digest5m.input_hash(cloud).encode(), np.uint8)
     for k in (1, 2):            # levels 2 and 3: sizes, counters and global moments (compared end to end: a pair within 1e-7 of a gate may flip)
         g = digest5m.global_moments(lv[k][0])
@@ -113,7 +122,7 @@ def main():
         ref, ref_s = run_ref(cloud, a.threads)
         rec = {"n": a.n, "reference_wall_s": ref_s, "threads": a.threads, "n_out_reference": int(ref[0]["xyz"].shape[0]), "n_out_oracle": int(d["n_out"]),
                "bit_equal": {f: bool(ref[0][f].shape == lv[0][0][f].shape and ref[0][f].tobytes() == lv[0][0][f].tobytes()) for f in FIVE}}
-        json.dump(rec, open(os.path.join(HERE, "hem_5m_ref_check.json"), "w"), indent=1)
+        json.dump(rec, open(os.path.join(HERE, "hem_5m_ref_check.json" if a.shape == "iso" else f"hem_5m_{a.shape}_ref_check.json"), "w"), indent=1)
         print(json.dumps(rec), flush=True)
 
 
