@@ -277,17 +277,15 @@ def test_c3_5m_level_equals_the_reference_digest():
                 assert np.abs(g["sh"] - o["sh"]).max() <= 1e-4 * o["rms_sh"]
 
 
-def test_surfel_5m_level_equals_the_reference_digest():
-    """The same at the size of BASELINE configs[2] on the SURFEL recipe (what trained 3DGS scenes look like: 60 % discs, 15 % needles, covariance
-    condition numbers 1e2 .. 1e5; synth.make_cloud(5_000_000, seed=12, shape="aniso")): level 1 against the reference's digest
-    (tests/golden/hem_5m_aniso_digest.npz; the oracle that computed it equals oracle/_ref bit for bit on the 1 M cloud of this recipe,
-    make_golden_5m.py --shape aniso).  3 054 641 rows: parents, pairs, orphans exact; the validity erase's count exact or -- the documented
-    class: det <= 0 of a near-singular MERGED covariance follows the summation order of the M-step -- off by a handful, in which case the rows
-    no longer line up and the comparison falls back to the global moments."""
+def _level1_against_digest(fixture, seed, shape):
+    """Level 1 of synth.make_cloud(5_000_000, seed, shape) against the reference's digest `fixture` (tests/golden/make_golden_5m.py --shape ...): parents,
+    pairs, orphans exact; the validity erase's count exact or -- the documented class: det <= 0 of a near-singular MERGED covariance follows the
+    summation order of the M-step -- off by a handful, in which case the rows no longer line up and the comparison falls back to the global
+    moments.  -> (dropped on the GPU, dropped by the reference)."""
     import digest5m
     from gaussiansplattingregistration_amd import hem, synth
-    want = dict(np.load(os.path.join(GOLDEN, "hem_5m_aniso_digest.npz")))
-    cloud = synth.make_cloud(5_000_000, seed=12, shape="aniso")
+    want = dict(np.load(os.path.join(GOLDEN, fixture)))
+    cloud = synth.make_cloud(5_000_000, seed=seed, shape=shape)
     assert digest5m.input_hash(cloud) == bytes(want["input_sha256"]).decode(), "this box drew a different cloud than the fixture's (numpy version?)"
     with hem.HemMixture(rng_mode="glibc", **HEM_PARAMS) as m:
         m.set_rng("glibc", 1, 0)
@@ -308,6 +306,24 @@ def test_surfel_5m_level_equals_the_reference_digest():
         assert abs(g["W"] - o["W"]) <= 1e-4 * o["W"] and np.abs(g["mean"] - o["mean"]).max() <= 1e-4 * o["extent"]
         assert np.abs(g["cov"] - o["cov"]).max() <= 1e-4 * np.abs(o["cov"]).max() and np.abs(g["sh"] - o["sh"]).max() <= 1e-4 * o["rms_sh"]
         assert np.abs(g["color"] - o["color"]).max() <= 1e-4 * o["rms_color"] and abs(g["opacity"] - o["opacity"]) <= 1e-4 * o["rms_opacity"]
+    return dropped, int(want["dropped"]), st
+
+
+def test_surfel_5m_level_equals_the_reference_digest():
+    """The size of BASELINE configs[2] on the SURFEL recipe (what trained 3DGS scenes look like: 60 % discs, 15 % needles, covariance condition
+    numbers 1e2 .. 1e5): the reference's level 1 has 3 054 641 rows, 21 of them erased (tests/golden/hem_5m_aniso_digest.npz; the oracle that
+    computed it equals oracle/_ref bit for bit on the 1 M cloud of this recipe)."""
+    got, want, st = _level1_against_digest("hem_5m_aniso_digest.npz", 12, "aniso")
+    assert want == 21 and st["irregular"] > 0
+
+
+def test_clustered_5m_level_equals_the_reference_digest():
+    """... and on the large-scene recipe (README.md:113 of the reference: 60 % of the splats in 40 clumps of 30 - 100 x the background density, six giant
+    splats whose search spheres span the scene, far outliers): heavy parents cut into work items, crowded sum buckets, long grid rows.  The
+    reference's level 1: 1 710 339 rows, 37 263 229 pairs (tests/golden/hem_5m_clustered_digest.npz; oracle = oracle/_ref bit for bit at 300 k splats of
+    this recipe)."""
+    got, want, st = _level1_against_digest("hem_5m_clustered_digest.npz", 21, "clustered")
+    assert st["heavy_parents"] > 0 and st["one_pass"] == 1
 
 
 def test_c3_2x5m_four_level_coarse_to_fine(oracle):
