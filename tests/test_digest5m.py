@@ -85,3 +85,19 @@ def test_fixture_is_self_consistent():
     # digest was taken from, bit for bit in all five exported arrays
     chk = json.load(open(os.path.join(GOLDEN, "hem_5m_ref_check.json")))
     assert chk["n"] == 5_000_000 and chk["n_out_reference"] == chk["n_out_oracle"] == n and all(chk["bit_equal"][f] for f in ("xyz", "color", "opacity", "cov6", "sh"))
+
+
+@pytest.mark.parametrize("name,n_out,pairs,check_n", [("hem_5m_aniso_digest.npz", 3054641, 11042105, 1_000_000), ("hem_5m_clustered_digest.npz", 1710339, 37263229, 300_000)])
+def test_shape_fixtures_are_self_consistent(name, n_out, pairs, check_n):
+    """The surfel and the clustered 5 M digests: one level each, made behind an equality check of the oracle against oracle/_ref on that recipe."""
+    import json
+    import os
+    from conftest import GOLDEN
+    d = dict(np.load(os.path.join(GOLDEN, name)))
+    n = int(d["n_out"])
+    assert n == n_out == int(d["parents"]) + int(d["orphans"]) - int(d["dropped"]) and int(d["pairs"]) == pairs
+    assert d["flags_packed"].size == (n + 7) // 8 and d["block_sum"].shape[0] == (n + digest5m.BLOCK - 1) // digest5m.BLOCK
+    assert np.all(np.diff(d["sample_idx"]) > 0) and int(d["sample_idx"][-1]) < n and d["s_sh"].shape == (d["sample_idx"].size, 45)
+    assert int(d["draws"]) == 5_000_000 + n + int(d["dropped"])
+    meta = json.loads(bytes(d["meta_json"]).decode())
+    assert meta["check"]["n"] == check_n and meta["check"]["bit_equal_arrays"] == ["xyz", "color", "opacity", "cov6", "sh"] and meta["levels"][0]["fast_search"]
