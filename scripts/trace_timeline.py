@@ -7,6 +7,8 @@ nth = int(sys.argv[3]) if len(sys.argv) > 3 else -1          # which occurrence 
 starts = [i for i, r in enumerate(rows) if first in r["Kernel_Name"]]
 i0 = starts[nth]
 i1 = starts[nth + 1] if nth != -1 and nth + 1 < len(starts) else len(rows)
+if len(sys.argv) > 4 and sys.argv[4] == "end":                # the window runs to the end of the trace (e.g. the last four registrations of a schedule)
+    i1 = len(rows)
 win = rows[i0:i1]
 t0 = int(win[0]["Start_Timestamp"]); prev = None; busy = 0; idle = 0; big = []
 for r in win:
