@@ -112,12 +112,14 @@ def hem_levels(m, cloud, borrow=True, arenas=None, key=None, normals=False):
     if arenas is not None:
         arena = arenas.get((key, n0, normals))
         if arena is None:
-            arena = arenas[(key, n0, normals)] = m.new_arena(int(1.5 * n0) + 64 * LEVELS, normals=normals)
+            # LEVELS x n0 rows: always enough (a level never grows).  The isotropic cloud's three levels fill 0.48 n0 + room for level 3's input, the surfel
+            # cloud's 1.6 n0 (its levels keep 60 - 90 % of their input: 1.5 n0 was too small, found by --workload aniso)
+            arena = arenas[(key, n0, normals)] = m.new_arena(LEVELS * (n0 + 64), normals=normals)
             if normals:
                 arena["normals0"] = torch.empty((n0, 3), dtype=torch.float64, device=arena["xyz"].device)
         nrm0 = arena.get("normals0")
     elif normals:
-        arena = m.new_arena(int(1.5 * n0) + 64 * LEVELS, normals=True)
+        arena = m.new_arena(LEVELS * (n0 + 64), normals=True)
         nrm0 = torch.empty((n0, 3), dtype=torch.float64, device=arena["xyz"].device)
     levels, stats = m.run_levels(LEVELS, arena=arena, normals0=nrm0)       # zero-copy: every level is written into the arena and read from it by the next
     lv = [PointCloud(xyz32=cloud["xyz"], cov6=cloud["cov6"], normals=nrm0)]

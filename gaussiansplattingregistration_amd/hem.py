@@ -249,15 +249,15 @@ class HemMixture:
     def run_levels(self, n_levels, arena=None, normals0=None):
         """``MixtureCreator.CreateMixture(clusterLevel, ...)`` in ONE library call (``gsr_hem_run_levels``; mixture_wrapper.cpp:10-18):
         ``n_levels`` clustering levels on the current level, written one behind the other into the CUDA tensors of ``arena``
-        (``new_arena``; default: 1.5 x the current level's rows, ``n_levels`` x when that is not enough) -- no return to Python between
+        (``new_arena``; default: ``n_levels`` x the current level's rows, always enough -- a level never grows) -- no return to Python between
         the levels.  Returns ``(levels, stats)``: per level a dict of VIEWS ``xyz color cov6 opacity sh`` (+ ``normals`` when the arena has
         a ``normals`` array: the normals leave with the level) and the dict ``stats()`` would have returned after it (+ ``dropped_now``).
         ``normals0``: a (n, 3) float64 CUDA tensor that receives the normals of the level the call starts from.
         The arena must stay untouched until the next ``run_level(s)`` / ``set_level0`` has returned (this object keeps it alive)."""
         n_levels = int(n_levels)
         n0 = self.size
-        if arena is None:
-            arena = self.new_arena(max(64, int(1.5 * n0) + 64 * n_levels))
+        if arena is None:                 # always enough: a level never grows (the isotropic bench cloud needs 1.5 x, a cloud of discs and needles 1.7 x for three levels)
+            arena = self.new_arena(max(64, n_levels * (n0 + 64)))
         rows = int(arena["xyz"].shape[0])
         for k, w in (("xyz", 3), ("color", 3), ("cov6", 6), ("opacity", 1), ("sh", self.F)):
             t = arena.get(k)

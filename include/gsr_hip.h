@@ -203,7 +203,7 @@ int32_t gsr_hem_run_level(gsr_hem_ctx* ctx, int64_t* n_out, int64_t* n_dropped);
  * F = 0) -- one level behind the other: level k occupies rows [reports[k].offset_rows, + reports[k].rows) of every arena (offsets are
  * multiples of 64 rows, so every level's arrays start 256-byte aligned).  A level needs room for as many rows as its INPUT has while it
  * runs: the call fails cleanly (GSR_E_INVALID, nothing of that level written) when offset + input rows > arena_rows; arena_rows =
- * n_levels x (rows of level 0) always suffices, 1.5 x is enough for the usual reduction by 3.  Equivalent to gsr_hem_set_output +
+ * n_levels x (rows of level 0) always suffices; 1.5 x is enough for a reduction by 3 per level, a cloud of discs and needles (levels keep 60 - 90 % of their input) needs 1.7 x for three levels.  Equivalent to gsr_hem_set_output +
  * gsr_hem_run_level per level -- the same bits -- without a return to the host language between the levels (a Python caller spent
  * ~0.15 ms per level there, a tenth of a 556 k-splat level); reports[k] carries what gsr_hem_get_stats / _stats_ex / _phase_ms /
  * _kernel_ms / _rng_position would have returned after level k.

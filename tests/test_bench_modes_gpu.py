@@ -42,6 +42,21 @@ def test_default_line_small():
     assert d["config"]["clouds"].startswith("serial")
 
 
+@pytest.mark.parametrize("workload", ["aniso", "clustered"])
+def test_other_workloads_line_small(workload):
+    """--workload aniso | clustered: levels that keep 60 - 90 % of their input (round 6: arenas of 1.5 x the cloud were too small for the surfel pair's
+    three levels -- the call failed cleanly, the bench did not run; the arenas hold n_levels x the cloud now) and the large-scene shape."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--splats", "200000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--workload", workload],
+                       cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _line(r.stdout)
+    sizes = d["config"]["level_sizes"]
+    assert d["config"]["splat_shapes"] == workload and sizes[0] == 200000 and all(b <= a for a, b in zip(sizes, sizes[1:]))
+    if workload == "aniso":
+        assert sizes[1] > 0.5 * sizes[0]                  # (discs and needles merge with little)
+    assert d["icp_result"]["T_err_vs_ground_truth_F"] < 1e-2
+
+
 def test_concurrent_clouds_line_small():
     """--concurrent-clouds: the two clouds' HEM levels on two contexts / streams / host threads, normals of the target levels beside them."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--splats", "150000", "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-aniso",
