@@ -361,6 +361,23 @@ def test_registration_in_one_call_equals_the_step_by_step_entry_points(kind, on_
         assert np.array_equal(got["transformation"], want["transformation"])
 
 
+@pytest.mark.parametrize("knob", ["GSR_ICP_DEVICE_LOOP=0", "GSR_ICP_NN_KERNEL=2", "GSR_ICP_XCD=0", "GSR_ICP_RB_POLL=0", "GSR_ICP_ROBUST_BOX=0"])
+def test_registration_in_one_call_under_the_knobs(monkeypatch, knob):
+    """gsr_icp_register_clouds under the library's own knobs (the host-driven loop keeps its stream waits: defer_sync follows device_loop): the result of
+    the default run to 1e-12, the same iteration count."""
+    from gaussiansplattingregistration_amd import icp, synth
+    src, tgt, T_gt = synth.make_pair(50000, seed=19)
+    nrm = np.asarray(icp.normals_from_cov(tgt["cov6"]))
+    with icp.IcpContext() as c:
+        want = c.register_clouds(src["xyz"], tgt["xyz"], nrm, 0.3, np.eye(4), 1, 0, 0.0, 1e-6, 1e-6, 40)
+    k, v = knob.split("=")
+    monkeypatch.setenv(k, v)
+    with icp.IcpContext() as c:
+        got = c.register_clouds(src["xyz"], tgt["xyz"], nrm, 0.3, np.eye(4), 1, 0, 0.0, 1e-6, 1e-6, 40)
+        assert c.timing()["ms_build"] > 0
+    assert got["iterations"] == want["iterations"] and np.linalg.norm(got["transformation"] - want["transformation"]) < 1e-12, knob
+
+
 def test_icp_error_behaviour():
     from gaussiansplattingregistration_amd import icp
     with icp.IcpContext() as c:
