@@ -433,6 +433,32 @@ def test_all_levels_in_one_call_equal_the_level_by_level_path(shape):
             m.run_levels(1, arena=m.new_arena(m.size - 1))
 
 
+@pytest.mark.parametrize("knob", ["GSR_HEM_ASYNC=0", "GSR_HEM_SH_DIRECT=1", "GSR_HEM_SPLIT=0", "GSR_HEM_TIMING=0", "GSR_HEM_SUMLW=sort"])
+def test_all_levels_in_one_call_under_the_knobs(monkeypatch, knob):
+    """gsr_hem_run_levels under the library's knobs -- the synchronous schedule (whose last level skips the trailing prologue through another branch),
+    SH rows read where the level lies, unsplit heavy parents, no events, sorted sums: the default's bits, and the context goes on afterwards."""
+    from gaussiansplattingregistration_amd import hem, synth
+    c = synth.make_cloud(90000, seed=29, sh_degree=1, shape="clustered")
+    with hem.HemMixture() as m:
+        ref, rst = _levels_on_one_context(m, c, 3, True)
+    k, v = knob.split("=")
+    monkeypatch.setenv(k, v)
+    with hem.HemMixture() as m:
+        for rep in range(2):
+            m.set_rng("glibc", 1, 0)
+            m.set_level0(c["xyz"], c["color"], c["opacity"], c["cov6"], c["sh"])
+            levels, st = m.run_levels(2)
+            for q in range(2):
+                assert st[q]["n_out"] == rst[q]["n_out"] and st[q]["pairs"] == rst[q]["pairs"], (knob, rep, q)
+                for f in ("xyz", "color", "cov6", "sh", "opacity"):
+                    if knob == "GSR_HEM_SUMLW=sort":        # (another summation of the per-child sums: equal to 1e-5, not bit for bit)
+                        assert np.allclose(levels[q][f].cpu().numpy(), ref[q][f], rtol=1e-4, atol=1e-6), (knob, q, f)
+                    else:
+                        assert np.array_equal(levels[q][f].cpu().numpy().view(np.uint8), ref[q][f].view(np.uint8)), (knob, rep, q, f)
+            m.run_level()                                   # level 3 through the level-by-level entry: the prologue the last level skipped is taken here
+            assert m.size == rst[2]["n_out"]
+
+
 def test_all_levels_in_one_call_edge_cases():
     """gsr_hem_run_levels on the cases the level-by-level entry handles: no SH block (F = 0), a hierarchy without parents (rho = 1e9: every level
     returns its input, mixture.cpp:250-253), rho = 1 (every component a parent), zero levels, a tiny cloud -- each equal to run_level per level."""
