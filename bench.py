@@ -138,6 +138,22 @@ def coarse_to_fine(lru, ctx, clouds_src, clouds_tgt, device, sharded=None, comm=
     T = np.eye(4)
     est = lru.get_estimation(lru.LocalRegistrationType.ICP_Point_To_Plane, lru.RobustLoss(0))
     out = {"icp_iters": 0, "levels": []}
+    if src_global_sizes is None and not sharded and prepared is None:
+        # the plain single-process schedule: ONE library call (gsr_icp_register_multiscale = the loop of qt_multiscale_registrator.py:197-236), no Python
+        # between the entries
+        entries = []
+        for k in range(LEVELS + 1):
+            s, t = clouds_src[-(k + 1)], clouds_tgt[-(k + 1)]
+            if not t.has_normals():
+                t.estimate_normals()
+            entries.append((s.xyz32, t.xyz32, t.normals, MAX_CORR[k], ITER_VALUES[k]))
+        res = ctx.register_multiscale(entries, T, est.kind, 0, 0.0, 1e-6, 1e-6)
+        for e, r in zip(entries, res):
+            out["icp_iters"] += r["iterations"]
+            out["levels"].append({"ns": int(e[0].shape[0]), "nt": int(e[1].shape[0]), "iterations": r["iterations"], "ms_iters": r["ms_iters"],
+                                  "evals": r["evaluations"], "ms_build": r["ms_build"]})
+        out["T"], out["fitness"], out["rmse"] = res[-1]["transformation"], res[-1]["fitness"], res[-1]["inlier_rmse"]
+        return out
     for k in range(LEVELS + 1):
         s, t = clouds_src[-(k + 1)], clouds_tgt[-(k + 1)]
         if not t.has_normals():

@@ -99,6 +99,7 @@ SIGNATURES = {
     "gsr_icp_accumulate": (_i32, [_vp, _vp, _i32, _i32, _f64, _vp]),
     "gsr_icp_register_clouds": (_i32, [_vp, _vp, _i64, _vp, _vp, _i64, _i32, _f64, _vp, _i32, _i32, _f64, _f64, _f64, _i32, _vp, C.POINTER(_f64),
                                        C.POINTER(_f64), C.POINTER(_i32)]),
+    "gsr_icp_register_multiscale": (_i32, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _f64, _f64, _f64, _vp, _vp]),
     "gsr_icp_register": (_i32, [_vp, _vp, _i32, _i32, _f64, _f64, _f64, _i32, _vp, C.POINTER(_f64), C.POINTER(_f64),
                                 C.POINTER(_i32)]),
     "gsr_icp_correspondences": (_i32, [_vp, _vp, _vp, _vp]),
@@ -127,6 +128,18 @@ class HemLevelReport(C.Structure):
     """gsr_hem_level_report (include/gsr_hip.h): what gsr_hem_run_levels reports per level."""
     _fields_ = [("offset_rows", C.c_int64), ("rows", C.c_int64), ("dropped", C.c_int64), ("rng_position", C.c_uint64),
                 ("stats", C.c_int64 * 8), ("stats_ex", C.c_int64 * 8), ("phase_ms", C.c_float * 8), ("kernel_ms", C.c_float * 8)]
+
+
+class IcpEntry(C.Structure):
+    """gsr_icp_entry (include/gsr_hip.h): one entry of a coarse-to-fine schedule."""
+    _fields_ = [("src_xyz", C.c_void_p), ("ns", C.c_int64), ("tgt_xyz", C.c_void_p), ("tgt_normals", C.c_void_p), ("nt", C.c_int64),
+                ("max_corr", C.c_double), ("max_iter", C.c_int32), ("reserved", C.c_int32)]
+
+
+class IcpEntryResult(C.Structure):
+    """gsr_icp_entry_result (include/gsr_hip.h)."""
+    _fields_ = [("init_T", C.c_double * 16), ("T", C.c_double * 16), ("fitness", C.c_double), ("inlier_rmse", C.c_double),
+                ("iterations", C.c_int32), ("evaluations", C.c_int32), ("ms_build", C.c_float), ("ms_iters", C.c_float)]
 
 
 def load(require_device: bool = False):

@@ -2286,6 +2286,30 @@ int32_t gsr_icp_register_clouds(gsr_icp_ctx* c, const float* src_xyz, int64_t ns
     return r;
 }
 
+// The coarse-to-fine schedule in one call (MultiScaleRegistratorMixture._register_main_point_clouds, qt_multiscale_registrator.py:197-236: entry k registers
+// level list[-(k + 1)] of the two clouds from the transform entry k - 1 ended with): gsr_icp_register_clouds per entry, no return to the host language between
+// the entries.  entries[k] describes entry k (coarsest first); results[k] receives its outcome; out_T the last entry's transform.
+int32_t gsr_icp_register_multiscale(gsr_icp_ctx* c, int32_t n_entries, const gsr_icp_entry* entries, int32_t on_device, const double* init_T, int32_t kind,
+                                    int32_t loss, double k, double rel_fitness, double rel_rmse, gsr_icp_entry_result* results, double* out_T) {
+    if (!c || !init_T || !out_T || n_entries < 0 || (n_entries > 0 && (!entries || !results)))
+        return fail(GSR_E_INVALID, "gsr_icp_register_multiscale: bad argument");
+    double T[16];
+    memcpy(T, init_T, sizeof(T));
+    for (int e = 0; e < n_entries; ++e) {
+        const gsr_icp_entry& E = entries[e];
+        gsr_icp_entry_result& R = results[e];
+        memset(&R, 0, sizeof(R));
+        memcpy(R.init_T, T, sizeof(T));
+        const int32_t r = gsr_icp_register_clouds(c, E.src_xyz, E.ns, E.tgt_xyz, E.tgt_normals, E.nt, on_device, E.max_corr, T, kind, loss, k, rel_fitness, rel_rmse,
+                                                  E.max_iter, R.T, &R.fitness, &R.inlier_rmse, &R.iterations);
+        if (r != GSR_OK) return r;
+        R.ms_build = c->ms_build; R.ms_iters = c->ms_iter; R.evaluations = c->n_iter_kernels;
+        memcpy(T, R.T, sizeof(T));
+    }
+    memcpy(out_T, T, sizeof(T));
+    return GSR_OK;
+}
+
 int32_t gsr_icp_get_timing(gsr_icp_ctx* c, float* out3) {
     if (!c || !out3) return fail(GSR_E_INVALID, "gsr_icp_get_timing: NULL argument");
     icp_read_build_ms(c);

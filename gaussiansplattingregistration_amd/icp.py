@@ -262,6 +262,42 @@ class IcpContext:
         self.n_target, self.n_source = nt, ns
         return {"transformation": T, "fitness": fit.value, "inlier_rmse": rmse.value, "iterations": int(it.value)}
 
+    def register_multiscale(self, entries, init=None, kind=0, loss=0, k=0.0, rel_fitness=1e-6, rel_rmse=1e-6):
+        """The coarse-to-fine schedule in ONE library call (``gsr_icp_register_multiscale``; qt_multiscale_registrator.py:197-236).  ``entries``: coarsest
+        first, each ``(src_xyz, tgt_xyz, tgt_normals or None, max_corr, max_iter)`` with all arrays on the host or all on the device.  Returns the list of
+        per-entry dicts (``init``, ``transformation``, ``fitness``, ``inlier_rmse``, ``iterations``, ``evaluations``, ``ms_build``, ``ms_iters``)."""
+        n = len(entries)
+        ent = (_lib.IcpEntry * max(1, n))()
+        res = (_lib.IcpEntryResult * max(1, n))()
+        keep, place = [], set()
+        for i, (sx, tx, tn, mc, it) in enumerate(entries):
+            ns, nt = int(sx.shape[0]), int(tx.shape[0])
+            ps, ks, ds = _prep(sx, (ns, 3), np.float32, self.device)
+            pt, kt, dt = _prep(tx, (nt, 3), np.float32, self.device)
+            pn, kn, dn = (None, None, dt) if tn is None else _prep(tn, (nt, 3), np.float64, self.device)
+            keep += [ks, kt, kn]
+            place |= {ds, dt, dn}
+            ent[i].src_xyz, ent[i].ns, ent[i].tgt_xyz, ent[i].tgt_normals, ent[i].nt = ps, ns, pt, pn, nt
+            ent[i].max_corr, ent[i].max_iter = float(mc), int(it)
+        if len(place) > 1:
+            raise RuntimeError("register_multiscale: every array of every entry must live in the same place (all host or all device)")
+        on_dev = bool(place.pop()) if place else False
+        if on_dev:
+            self._sync_torch()
+        init = np.eye(4) if init is None else np.ascontiguousarray(init, dtype=np.float64).reshape(4, 4)
+        T = np.empty((4, 4), np.float64)
+        _lib.check(self._L.gsr_icp_register_multiscale(self._h, n, C.cast(ent, C.c_void_p), 1 if on_dev else 0, init.ctypes.data, kind, loss, float(k),
+                                                       float(rel_fitness), float(rel_rmse), C.cast(res, C.c_void_p), T.ctypes.data), "gsr_icp_register_multiscale")
+        out = []
+        for i in range(n):
+            r = res[i]
+            out.append({"init": np.array(r.init_T[:], np.float64).reshape(4, 4), "transformation": np.array(r.T[:], np.float64).reshape(4, 4),
+                        "fitness": r.fitness, "inlier_rmse": r.inlier_rmse, "iterations": int(r.iterations), "evaluations": int(r.evaluations),
+                        "ms_build": float(r.ms_build), "ms_iters": float(r.ms_iters)})
+        if n:
+            self.n_target, self.n_source = int(entries[-1][1].shape[0]), int(entries[-1][0].shape[0])
+        return out
+
     def correspondences(self, T):
         T = np.ascontiguousarray(T, dtype=np.float64).reshape(4, 4)
         idx = np.empty(self.n_source, np.int64)

@@ -349,6 +349,25 @@ int32_t gsr_icp_register_clouds(gsr_icp_ctx* ctx, const float* src_xyz, int64_t 
                                 int64_t nt, int32_t on_device, double max_corr, const double* init_T, int32_t kind, int32_t loss,
                                 double k, double rel_fitness, double rel_rmse, int32_t max_iter, double* out_T, double* fitness,
                                 double* inlier_rmse, int32_t* iterations);
+/* The coarse-to-fine schedule in one call (MultiScaleRegistratorMixture._register_main_point_clouds, qt_multiscale_registrator.py:197-236: entry k registers
+ * the k-th coarsest level of the two clouds, starting from the transform entry k - 1 ended with): gsr_icp_register_clouds per entry without a return to
+ * the host language between the entries.  entries[] coarsest first; results[k] = entry k's outcome (its start, its transform, fitness, RMSE, iterations, the
+ * device milliseconds of its index build and of its iterations); out_T = the last entry's transform (init_T when n_entries = 0). */
+typedef struct gsr_icp_entry {
+    const float* src_xyz; int64_t ns;
+    const float* tgt_xyz; const double* tgt_normals; int64_t nt;
+    double max_corr;            /* max_correspondence_distance of the entry */
+    int32_t max_iter; int32_t reserved;
+} gsr_icp_entry;
+typedef struct gsr_icp_entry_result {
+    double init_T[16], T[16];
+    double fitness, inlier_rmse;
+    int32_t iterations, evaluations;
+    float ms_build, ms_iters;
+} gsr_icp_entry_result;
+int32_t gsr_icp_register_multiscale(gsr_icp_ctx* ctx, int32_t n_entries, const gsr_icp_entry* entries, int32_t on_device, const double* init_T,
+                                    int32_t kind, int32_t loss, double k, double rel_fitness, double rel_rmse, gsr_icp_entry_result* results,
+                                    double* out_T);
 /* Nearest target index (or -1) and squared distance for every source point at transform T. */
 int32_t gsr_icp_correspondences(gsr_icp_ctx* ctx, const double* T, int64_t* idx, double* d2);
 /* Device milliseconds: [0] target index build, [1] all correspondence/accumulate kernels of the last

@@ -378,6 +378,35 @@ def test_registration_in_one_call_under_the_knobs(monkeypatch, knob):
     assert got["iterations"] == want["iterations"] and np.linalg.norm(got["transformation"] - want["transformation"]) < 1e-12, knob
 
 
+def test_coarse_to_fine_schedule_in_one_call_equals_the_entry_by_entry_loop():
+    """gsr_icp_register_multiscale (MultiScaleRegistratorMixture._register_main_point_clouds, qt_multiscale_registrator.py:197-236) against the loop of
+    gsr_icp_register_clouds it replaces: every entry's start, transform, fitness, RMSE and iteration count equal bit for bit; an empty schedule returns
+    the initial transform."""
+    from gaussiansplattingregistration_amd import icp, synth
+    rng = np.random.default_rng(3)
+    src, tgt, T_gt = synth.make_pair(80000, seed=13)
+    nrm = np.asarray(icp.normals_from_cov(tgt["cov6"]))
+    sub = [np.sort(rng.choice(80000, m, replace=False)) for m in (5000, 20000)] + [np.arange(80000)]
+    entries = [(np.ascontiguousarray(src["xyz"][i]), np.ascontiguousarray(tgt["xyz"][i]), np.ascontiguousarray(nrm[i]), mc, it)
+               for i, mc, it in zip(sub, (0.6, 0.4, 0.2), (30, 20, 10))]
+    for on_device in (False, True):
+        ent = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), torch.from_numpy(c_).cuda(), mc, it) for a, b, c_, mc, it in entries] if on_device else entries
+        with icp.IcpContext() as c:
+            want, T = [], np.eye(4)
+            for sx, tx, tn, mc, it in ent:
+                r = c.register_clouds(sx, tx, tn, mc, T, 1, 0, 0.0, 1e-6, 1e-6, it)
+                want.append((T.copy(), r))
+                T = r["transformation"]
+            got = c.register_multiscale(ent, np.eye(4), 1, 0, 0.0, 1e-6, 1e-6)
+            assert len(got) == 3
+            for (T0, w), g in zip(want, got):
+                assert np.array_equal(g["init"], T0) and np.array_equal(g["transformation"], w["transformation"])
+                assert g["iterations"] == w["iterations"] and g["fitness"] == w["fitness"] and g["inlier_rmse"] == w["inlier_rmse"]
+                assert g["ms_build"] > 0 and g["evaluations"] >= g["iterations"]
+            assert np.linalg.norm(got[-1]["transformation"] - T_gt) < 5e-3
+            assert c.register_multiscale([], np.eye(4)) == []
+
+
 def test_icp_error_behaviour():
     from gaussiansplattingregistration_amd import icp
     with icp.IcpContext() as c:
