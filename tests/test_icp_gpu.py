@@ -418,6 +418,44 @@ def test_icp_error_behaviour():
             c.register(kind=1)
 
 
+def test_new_entry_points_error_behaviour():
+    """The round-6 entry points through the raw C ABI: NULL / negative arguments and unsupported estimators are refused with a message, nothing crashes,
+    and the context serves a good call afterwards."""
+    import ctypes as C
+    from gaussiansplattingregistration_amd import _lib, hem, icp, synth
+    L = _lib.load()
+    T0 = np.eye(4)
+    out = np.empty((4, 4))
+    fit, rm, it = C.c_double(0), C.c_double(0), C.c_int32(0)
+    xyz = np.random.default_rng(0).random((200, 3)).astype(np.float32)
+    with icp.IcpContext() as c:
+        call = lambda *a: L.gsr_icp_register_clouds(c._h, *a, out.ctypes.data, C.byref(fit), C.byref(rm), C.byref(it))
+        assert call(xyz.ctypes.data, 200, xyz.ctypes.data, None, 200, 0, 0.3, T0.ctypes.data, 2, 0, 0.0, 1e-6, 1e-6, 5) < 0           # generalized ICP: not this entry
+        assert b"point-to-point and point-to-plane" in L.gsr_last_error()
+        assert call(xyz.ctypes.data, 200, xyz.ctypes.data, None, 200, 0, 0.3, T0.ctypes.data, 1, 0, 0.0, 1e-6, 1e-6, 5) < 0           # point-to-plane without normals
+        assert call(xyz.ctypes.data, 0, xyz.ctypes.data, None, 200, 0, 0.3, T0.ctypes.data, 0, 0, 0.0, 1e-6, 1e-6, 5) < 0             # empty source
+        assert call(xyz.ctypes.data, 200, None, None, 0, 0, 0.3, T0.ctypes.data, 0, 0, 0.0, 1e-6, 1e-6, 5) < 0                        # empty target
+        assert call(xyz.ctypes.data, 200, xyz.ctypes.data, None, 200, 0, -1.0, T0.ctypes.data, 0, 0, 0.0, 1e-6, 1e-6, 5) < 0          # max_corr <= 0
+        assert L.gsr_icp_register_multiscale(c._h, 2, None, 0, T0.ctypes.data, 0, 0, 0.0, 1e-6, 1e-6, None, out.ctypes.data) < 0
+        assert L.gsr_icp_register_multiscale(c._h, -1, None, 0, T0.ctypes.data, 0, 0, 0.0, 1e-6, 1e-6, None, out.ctypes.data) < 0
+        r = c.register_clouds(xyz, xyz, None, 0.3, T0, 0, 0, 0.0, 1e-6, 1e-6, 5)                                                       # ... and a good call
+        assert r["fitness"] == 1.0 and np.allclose(r["transformation"], np.eye(4), atol=1e-12)
+    cloud = synth.make_cloud(2000, seed=1, sh_degree=1, h=0.4)
+    with hem.HemMixture() as m:
+        reports = (_lib.HemLevelReport * 2)()
+        rp = C.cast(reports, C.c_void_p)
+        assert L.gsr_hem_run_levels(m._h, 1, None, None, None, None, None, None, None, 100, rp) < 0                                   # no level set
+        m.set_level0(cloud["xyz"], cloud["color"], cloud["opacity"], cloud["cov6"], cloud["sh"])
+        assert L.gsr_hem_run_levels(m._h, 1, None, None, None, None, None, None, None, 100, rp) < 0                                   # NULL arenas
+        assert L.gsr_hem_run_levels(m._h, -1, None, None, None, None, None, None, None, 100, rp) < 0
+        a = m.new_arena(4096)
+        assert L.gsr_hem_run_levels(m._h, 1, a["xyz"].data_ptr(), a["color"].data_ptr(), a["cov6"].data_ptr(), a["opacity"].data_ptr(), None, None, None, 4096, rp) < 0
+        assert b"no SH arena" in L.gsr_last_error()
+        assert L.gsr_hem_run_levels(m._h, 2, a["xyz"].data_ptr(), a["color"].data_ptr(), a["cov6"].data_ptr(), a["opacity"].data_ptr(), a["sh"].data_ptr(), None, None, 4096, None) < 0
+        levels, st = m.run_levels(2, arena=a)                                                                                          # ... and a good call
+        assert st[0]["n_in"] == 2000 and levels[1]["xyz"].shape[0] == st[1]["n_out"]
+
+
 def test_icp_knobs_change_nothing(monkeypatch):
     """The environment knobs of the ICP half select implementations, never results: the fused search + accumulate kernel
     against the split one (GSR_ICP_NN_KERNEL), the host-driven loop against the device-resident one (GSR_ICP_DEVICE_LOOP),
